@@ -1,0 +1,64 @@
+/* oracle/blosc_oracle.h — CPU oracle for the c-blosc hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This is a from-scratch plain-C restatement of the algorithms on the path
+ *     blocked shuffle -> compress   /   decompress -> unshuffle
+ * of c-blosc 1.21.7.dev (reference tree at /root/reference).  It exists so that the HIP
+ * kernels can be checked against something that runs everywhere (the GPU box has no
+ * /root/reference).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * link or load it; the product library (c-blosc_amd/) never does.
+ *
+ * Parity status: PINNED.  tests/test_oracle_vs_reference.py checks, in the dev container,
+ *   - every orc_* filter against blosc_internal_{shuffle,unshuffle,bitshuffle,bitunshuffle}
+ *   - orc_lz4_compress / orc_blosclz_compress BYTE-FOR-BYTE against LZ4_compress_fast /
+ *     blosclz_compress, and the decoders against LZ4_decompress_safe / blosclz_decompress
+ *   - whole chunks from orc_compress byte-for-byte against blosc_compress (nthreads=1)
+ *   against oracle/_ref/libblosc_ref.so (the real reference compiled from its own sources),
+ *   and tests/test_oracle_golden.py checks the 17 LZ4 / LZ4HC / BloscLZ compat vectors
+ *   (committed under tests/golden/compat/, byte copies of /root/reference/compat/.cdata files)
+ *   decode to arange(1e6, int32).
+ */
+#ifndef BLOSC_ORACLE_H
+#define BLOSC_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* codec codes == blosc/blosc.h:64-69 ; split modes == blosc/blosc.h:114-117 */
+enum { ORC_BLOSCLZ = 0, ORC_LZ4 = 1, ORC_LZ4HC = 2, ORC_SNAPPY = 3, ORC_ZLIB = 4, ORC_ZSTD = 5 };
+enum { ORC_SPLIT_ALWAYS = 1, ORC_SPLIT_NEVER = 2, ORC_SPLIT_AUTO = 3, ORC_SPLIT_FWD_COMPAT = 4 };
+
+/* ---- filters (blosc/shuffle.c:367-443, shuffle-generic.h:32-81, bitshuffle-generic.c) ---- */
+void orc_shuffle(size_t typesize, size_t blocksize, const uint8_t* src, uint8_t* dst);
+void orc_unshuffle(size_t typesize, size_t blocksize, const uint8_t* src, uint8_t* dst);
+int  orc_bitshuffle(size_t typesize, size_t blocksize, const uint8_t* src, uint8_t* dst);
+int  orc_bitunshuffle(size_t typesize, size_t blocksize, const uint8_t* src, uint8_t* dst);
+
+/* ---- codecs ---- */
+/* LZ4 block, LZ4_compress_fast semantics (lz4.c:930-1338, 1382-1469) */
+int orc_lz4_compress(const uint8_t* src, int srclen, uint8_t* dst, int dstcap, int accel);
+/* LZ4_decompress_safe semantics, safe-loop rules (lz4.c:2215-2445): >=0 bytes written, <0 error */
+int orc_lz4_decompress(const uint8_t* src, int srclen, uint8_t* dst, int dstcap);
+/* blosclz.c:421-613 / 679-789 */
+int orc_blosclz_compress(int clevel, const uint8_t* src, int srclen, uint8_t* dst, int dstcap,
+                         int split_block);
+int orc_blosclz_decompress(const uint8_t* src, int srclen, uint8_t* dst, int dstcap);
+
+/* ---- policy (blosc/blosc.c:929-1060) ---- */
+int orc_split_block(int codec, int typesize, int blocksize, int splitmode);
+int orc_compute_blocksize(int clevel, int typesize, int nbytes, int forced_blocksize, int codec,
+                          int splitmode);
+
+/* ---- chunk level (blosc/blosc.c:591-867, 1062-1279, 1435-1518, 1574-1703) ----
+ * Same return conventions as blosc_compress_ctx / blosc_decompress / blosc_getitem with one
+ * thread.  Codecs other than BloscLZ and LZ4 give -5 (as a stock build without them would). */
+int orc_compress(int clevel, int doshuffle, size_t typesize, size_t nbytes, const void* src,
+                 void* dest, size_t destsize, int codec, size_t forced_blocksize, int splitmode);
+int orc_decompress(const void* src, void* dest, size_t destsize);
+int orc_getitem(const void* src, int start, int nitems, void* dest);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
