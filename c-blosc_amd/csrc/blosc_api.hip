@@ -1,0 +1,321 @@
+// blosc_api.hip — the exported C ABI (include/blosc.h, include/blosc_gpu.h).
+//
+// Host-side mirror of the reference's public layer (blosc/blosc.c:1282-1703, :1951-2317):
+// process globals, the per-call environment overrides, name/code tables and cbuffer introspection
+// behave like the reference; the work itself is handed to the engine (engine.hip), never to a CPU
+// implementation.
+#include <errno.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/blosc.h"
+#include "../../include/blosc_gpu.h"
+#include "blosc_format.h"
+#include "engine.h"
+
+using namespace bamd;
+
+// ---- process globals (blosc/blosc.c:143-150) ---------------------------------------------------
+static pthread_mutex_t g_mutex = PTHREAD_MUTEX_INITIALIZER;   // the reference's global_comp_mutex
+static int g_compressor = BLOSC_BLOSCLZ;
+static int g_threads = 1;
+static int g_force_blocksize = 0;
+static int g_initlib = 0;
+static int g_splitmode = BLOSC_FORWARD_COMPAT_SPLIT;
+
+static const char* const kNames[6] = {BLOSC_BLOSCLZ_COMPNAME, BLOSC_LZ4_COMPNAME, BLOSC_LZ4HC_COMPNAME,
+                                      BLOSC_SNAPPY_COMPNAME, BLOSC_ZLIB_COMPNAME, BLOSC_ZSTD_COMPNAME};
+static bool codec_built(int code) { return code == BLOSC_BLOSCLZ || code == BLOSC_LZ4 || code == BLOSC_LZ4HC; }
+
+extern "C" {
+
+void blosc_init(void) { g_initlib = 1; }
+
+void blosc_destroy(void) {
+  if (!g_initlib) return;
+  g_initlib = 0;
+  engine_release();
+}
+
+int blosc_free_resources(void) {            // blosc/blosc.c:2311-2317
+  if (!g_initlib) return -1;
+  engine_release();
+  return 0;
+}
+
+int blosc_get_nthreads(void) { return g_threads; }
+
+int blosc_set_nthreads(int nthreads_new) {  // blosc/blosc.c:1958-1973
+  int ret = g_threads;
+  if (!g_initlib) blosc_init();
+  if (nthreads_new != ret) g_threads = nthreads_new;
+  return ret;
+}
+
+int blosc_compcode_to_compname(int compcode, const char** compname) {  // blosc/blosc.c:330-374
+  const char* name = NULL;
+  if (compcode >= 0 && compcode <= 5) name = kNames[compcode];
+  *compname = name;
+  return codec_built(compcode) ? compcode : -1;
+}
+
+int blosc_compname_to_compcode(const char* compname) {                 // blosc/blosc.c:377-409
+  for (int c = 0; c <= 5; c++)
+    if (codec_built(c) && strcmp(compname, kNames[c]) == 0) return c;
+  return -1;
+}
+
+const char* blosc_get_compressor(void) {
+  const char* n;
+  blosc_compcode_to_compname(g_compressor, &n);
+  return n;
+}
+
+int blosc_set_compressor(const char* compname) {                        // blosc/blosc.c:2010-2020
+  int code = blosc_compname_to_compcode(compname);
+  g_compressor = code;
+  if (!g_initlib) blosc_init();
+  return code;
+}
+
+const char* blosc_list_compressors(void) { return "blosclz,lz4,lz4hc"; }
+
+const char* blosc_get_version_string(void) { return BLOSC_VERSION_STRING; }
+
+int blosc_get_complib_info(const char* compname, char** complib, char** version) {  // blosc/blosc.c:2052-2109
+  int clib = -1;
+  const char* libname = NULL;
+  const char* ver = "unknown";
+  if (strcmp(compname, BLOSC_BLOSCLZ_COMPNAME) == 0) { clib = BLOSC_BLOSCLZ_LIB; libname = BLOSC_BLOSCLZ_LIBNAME; ver = "2.5.1"; }
+  else if (strcmp(compname, BLOSC_LZ4_COMPNAME) == 0 || strcmp(compname, BLOSC_LZ4HC_COMPNAME) == 0) {
+    clib = BLOSC_LZ4_LIB; libname = BLOSC_LZ4_LIBNAME; ver = "1.10.0";   // block format implemented, lz4.h:LZ4_VERSION_*
+  }
+  if (clib < 0) {   // Snappy / Zlib / Zstd are not built in: same answer as a stock build without them
+    if (complib) *complib = NULL;
+    if (version) *version = NULL;
+    return -1;
+  }
+  if (complib) *complib = strdup(libname);
+  if (version) *version = strdup(ver);
+  return clib;
+}
+
+// ---- cbuffer introspection (blosc/blosc.c:2112-2180) --------------------------------------------
+void blosc_cbuffer_sizes(const void* cbuffer, size_t* nbytes, size_t* cbytes, size_t* blocksize) {
+  const uint8_t* s = (const uint8_t*)cbuffer;
+  if (s[0] != BLOSC_VERSION_FORMAT) { *nbytes = *blocksize = *cbytes = 0; return; }
+  *nbytes = (size_t)rd_i32(s + 4);
+  *blocksize = (size_t)rd_i32(s + 8);
+  *cbytes = (size_t)rd_i32(s + 12);
+}
+
+int blosc_cbuffer_validate(const void* cbuffer, size_t cbytes, size_t* nbytes) {
+  size_t hc, hb;
+  if (cbytes < BLOSC_MIN_HEADER_LENGTH) return -1;
+  blosc_cbuffer_sizes(cbuffer, nbytes, &hc, &hb);
+  if (hc != cbytes) return -1;
+  if (*nbytes > BLOSC_MAX_BUFFERSIZE) return -1;
+  return 0;
+}
+
+void blosc_cbuffer_metainfo(const void* cbuffer, size_t* typesize, int* flags) {
+  const uint8_t* s = (const uint8_t*)cbuffer;
+  if (s[0] != BLOSC_VERSION_FORMAT) { *flags = 0; *typesize = 0; return; }
+  *flags = (int)s[2] & 7;
+  *typesize = (size_t)s[3];
+}
+
+void blosc_cbuffer_versions(const void* cbuffer, int* version, int* versionlz) {
+  const uint8_t* s = (const uint8_t*)cbuffer;
+  *version = (int)s[0];
+  *versionlz = (int)s[1];
+}
+
+const char* blosc_cbuffer_complib(const void* cbuffer) {
+  static const char* const libs[5] = {BLOSC_BLOSCLZ_LIBNAME, BLOSC_LZ4_LIBNAME, BLOSC_SNAPPY_LIBNAME,
+                                      BLOSC_ZLIB_LIBNAME, BLOSC_ZSTD_LIBNAME};
+  int clib = (((const uint8_t*)cbuffer)[2] & 0xe0) >> 5;
+  return clib < 5 ? libs[clib] : NULL;
+}
+
+int blosc_get_blocksize(void) { return g_force_blocksize; }
+void blosc_set_blocksize(size_t size) { g_force_blocksize = (int32_t)size; }
+void blosc_set_splitmode(int mode) { g_splitmode = mode; }
+
+// ---- compression ---------------------------------------------------------------------------------
+static int compress_one(int clevel, int doshuffle, size_t typesize, size_t nbytes, const void* src, void* dest,
+                        size_t destsize, int compcode, size_t blocksize) {
+  CompressParams p{clevel, doshuffle, typesize, compcode, (int32_t)blocksize, g_splitmode};
+  // initialize_context_compression's checks that precede anything codec related (blosc.c:1076-1120)
+  if (compcode < 0 || compcode > 5 || !codec_built(compcode)) {
+    // order of the reference: size checks and parameter checks come first, the codec error (-5) last
+    if (nbytes > (size_t)BLOSC_MAX_BUFFERSIZE || destsize < BLOSC_MAX_OVERHEAD) return 0;
+    if (clevel < 0 || clevel > 9 || doshuffle < 0 || doshuffle > 2 || typesize == 0) return -10;
+    fprintf(stderr, "Blosc has not been compiled with '%s' compression support.  Please use one having it.",
+            (compcode >= 0 && compcode <= 5) ? kNames[compcode] : "(null)");
+    return -5;
+  }
+  const bool sd = engine_is_device_pointer(src), dd = engine_is_device_pointer(dest);
+  if (sd != dd && nbytes > 0) {
+    fprintf(stderr, "blosc_amd: src and dest must both be host or both be device pointers\n");
+    return -1;
+  }
+  Job job{src, dest, nbytes, destsize};
+  int result = -1;
+  if (engine_compress_batch(p, 1, &job, &result, sd && dd, (hipStream_t)0) != 0) return -1;
+  return result;
+}
+
+int blosc_compress_ctx(int clevel, int doshuffle, size_t typesize, size_t nbytes, const void* src, void* dest,
+                       size_t destsize, const char* compressor, size_t blocksize, int numinternalthreads) {
+  (void)numinternalthreads;
+  return compress_one(clevel, doshuffle, typesize, nbytes, src, dest, destsize,
+                      blosc_compname_to_compcode(compressor), blocksize);
+}
+
+int blosc_compress(int clevel, int doshuffle, size_t typesize, size_t nbytes, const void* src, void* dest,
+                   size_t destsize) {
+  if (!g_initlib) blosc_init();
+  const char* ev;
+  // environment overrides, re-read on every call (blosc/blosc.c:1320-1395)
+  if ((ev = getenv("BLOSC_CLEVEL")) != NULL) { long v = strtol(ev, NULL, 10); if (v != EINVAL && v >= 0) clevel = (int)v; }
+  if ((ev = getenv("BLOSC_SHUFFLE")) != NULL) {
+    if (strcmp(ev, "NOSHUFFLE") == 0) doshuffle = BLOSC_NOSHUFFLE;
+    if (strcmp(ev, "SHUFFLE") == 0) doshuffle = BLOSC_SHUFFLE;
+    if (strcmp(ev, "BITSHUFFLE") == 0) doshuffle = BLOSC_BITSHUFFLE;
+  }
+  if ((ev = getenv("BLOSC_TYPESIZE")) != NULL) { long v = strtol(ev, NULL, 10); if (v != EINVAL && v > 0) typesize = (size_t)(int)v; }
+  if ((ev = getenv("BLOSC_COMPRESSOR")) != NULL) { int r = blosc_set_compressor(ev); if (r < 0) return r; }
+  if ((ev = getenv("BLOSC_BLOCKSIZE")) != NULL) { long v = strtol(ev, NULL, 10); if (v != EINVAL && v > 0) blosc_set_blocksize((size_t)v); }
+  if ((ev = getenv("BLOSC_NTHREADS")) != NULL) { long v = strtol(ev, NULL, 10); if (v != EINVAL && v > 0) { int r = blosc_set_nthreads((int)v); if (r < 0) return r; } }
+  if ((ev = getenv("BLOSC_SPLITMODE")) != NULL) {
+    if (strcmp(ev, "FORWARD_COMPAT") == 0) blosc_set_splitmode(BLOSC_FORWARD_COMPAT_SPLIT);
+    else if (strcmp(ev, "AUTO") == 0) blosc_set_splitmode(BLOSC_AUTO_SPLIT);
+    else if (strcmp(ev, "ALWAYS") == 0) blosc_set_splitmode(BLOSC_ALWAYS_SPLIT);
+    else if (strcmp(ev, "NEVER") == 0) blosc_set_splitmode(BLOSC_NEVER_SPLIT);
+    else { fprintf(stderr, "BLOSC_SPLITMODE environment variable '%s' not recognized\n", ev); return -1; }
+  }
+  // BLOSC_NOLOCK (blosc.c:1400-1408) only changes locking in the reference; the engine serialises
+  // device work itself, so both paths are the same call here.
+  const bool nolock = getenv("BLOSC_NOLOCK") != NULL;
+  if (!nolock) pthread_mutex_lock(&g_mutex);
+  int r = compress_one(clevel, doshuffle, typesize, nbytes, src, dest, destsize, g_compressor, (size_t)g_force_blocksize);
+  if (!nolock) pthread_mutex_unlock(&g_mutex);
+  return r;
+}
+
+// ---- decompression -------------------------------------------------------------------------------
+static int decompress_one(const void* src, void* dest, size_t destsize) {
+  const bool sd = engine_is_device_pointer(src), dd = engine_is_device_pointer(dest);
+  if (sd != dd) {
+    // an empty chunk never touches dest (blosc.c:1463-1466); otherwise mixed residency is an error
+    fprintf(stderr, "blosc_amd: src and dest must both be host or both be device pointers\n");
+    return -1;
+  }
+  Job job{src, dest, 0, destsize};
+  int result = -1;
+  if (engine_decompress_batch(1, &job, &result, sd && dd, (hipStream_t)0) != 0) return -1;
+  return result;
+}
+
+int blosc_decompress_ctx(const void* src, void* dest, size_t destsize, int numinternalthreads) {
+  (void)numinternalthreads;
+  return decompress_one(src, dest, destsize);
+}
+
+int blosc_decompress(const void* src, void* dest, size_t destsize) {
+  if (!g_initlib) blosc_init();
+  const char* ev;
+  if ((ev = getenv("BLOSC_NTHREADS")) != NULL) {   // blosc.c:1546-1553
+    long v = strtol(ev, NULL, 10);
+    if (v != EINVAL && v > 0) { int r = blosc_set_nthreads((int)v); if (r < 0) return r; }
+  }
+  const bool nolock = getenv("BLOSC_NOLOCK") != NULL;
+  if (!nolock) pthread_mutex_lock(&g_mutex);
+  int r = decompress_one(src, dest, destsize);
+  if (!nolock) pthread_mutex_unlock(&g_mutex);
+  return r;
+}
+
+int blosc_getitem(const void* src, int start, int nitems, void* dest) {
+  return engine_getitem(src, start, nitems, dest, engine_is_device_pointer(src), engine_is_device_pointer(dest), (hipStream_t)0);
+}
+
+// ---- device-resident batched extension (include/blosc_gpu.h) ---------------------------------------
+int blosc_gpu_set_device(int device) { return engine_set_device(device); }
+
+int blosc_gpu_compress_batch(int clevel, int doshuffle, size_t typesize, const char* compressor, size_t blocksize,
+                             int nchunks, const void* const* src, const size_t* nbytes, void* const* dest,
+                             const size_t* destsize, int* cbytes_out, void* stream) {
+  if (nchunks <= 0) return 0;
+  const int code = compressor ? blosc_compname_to_compcode(compressor) : g_compressor;
+  if (code < 0 || !codec_built(code)) { for (int i = 0; i < nchunks; i++) cbytes_out[i] = -5; return 0; }
+  Job* jobs = (Job*)malloc(sizeof(Job) * (size_t)nchunks);
+  if (!jobs) return -1;
+  for (int i = 0; i < nchunks; i++) jobs[i] = Job{src[i], dest[i], nbytes[i], destsize[i]};
+  CompressParams p{clevel, doshuffle, typesize, code, (int32_t)(blocksize ? blocksize : (size_t)g_force_blocksize), g_splitmode};
+  int r = engine_compress_batch(p, nchunks, jobs, cbytes_out, true, (hipStream_t)stream);
+  free(jobs);
+  return r;
+}
+
+int blosc_gpu_decompress_batch(int nchunks, const void* const* src, const size_t* srcsize, void* const* dest,
+                               const size_t* destsize, int* nbytes_out, void* stream) {
+  if (nchunks <= 0) return 0;
+  Job* jobs = (Job*)malloc(sizeof(Job) * (size_t)nchunks);
+  if (!jobs) return -1;
+  for (int i = 0; i < nchunks; i++) jobs[i] = Job{src[i], dest[i], srcsize ? srcsize[i] : 0, destsize[i]};
+  int r = engine_decompress_batch(nchunks, jobs, nbytes_out, true, (hipStream_t)stream);
+  free(jobs);
+  return r;
+}
+
+int blosc_gpu_getitem(const void* src, int start, int nitems, void* dest, void* stream) {
+  return engine_getitem(src, start, nitems, dest, true, true, (hipStream_t)stream);
+}
+
+// Filters as stand-alone calls on HOST buffers, same names and signatures as the symbols the
+// reference exports for its own shuffle tests (blosc/shuffle.h:34-61 under BLOSC_TESTING).  The
+// shuffle variants of the byte filter with a bitshuffle-only case (bsize < typesize: not applied,
+// blosc/blosc.c:608-609) are handled by the kernels exactly like inside a chunk.
+__attribute__((visibility("default"))) void blosc_internal_shuffle(const size_t typesize, const size_t blocksize,
+                                                                   const uint8_t* src, const uint8_t* dest) {
+  if (engine_filter(0, typesize, blocksize, src, (void*)dest) != 0) fprintf(stderr, "blosc_amd: shuffle failed (no GPU?)\n");
+}
+__attribute__((visibility("default"))) void blosc_internal_unshuffle(const size_t typesize, const size_t blocksize,
+                                                                     const uint8_t* src, const uint8_t* dest) {
+  if (engine_filter(1, typesize, blocksize, src, (void*)dest) != 0) fprintf(stderr, "blosc_amd: unshuffle failed (no GPU?)\n");
+}
+__attribute__((visibility("default"))) int blosc_internal_bitshuffle(const size_t typesize, const size_t blocksize,
+                                                                     const uint8_t* src, const uint8_t* dest,
+                                                                     const uint8_t* tmp) {
+  (void)tmp;
+  if (engine_filter(2, typesize, blocksize, src, (void*)dest) != 0) return -1;
+  const size_t n = blocksize / typesize;                      // return value of shuffle.c:393-416
+  return (int)((n % 8) ? n : n * typesize);
+}
+__attribute__((visibility("default"))) int blosc_internal_bitunshuffle(const size_t typesize, const size_t blocksize,
+                                                                       const uint8_t* src, const uint8_t* dest,
+                                                                       const uint8_t* tmp) {
+  (void)tmp;
+  if (engine_filter(3, typesize, blocksize, src, (void*)dest) != 0) return -1;
+  const size_t n = blocksize / typesize;
+  return (int)((n % 8) ? n : n * typesize);
+}
+
+// test hooks for the host policy (tests/test_host_policy.py compares them with the oracle)
+__attribute__((visibility("default"))) int blosc_amd_policy_blocksize(int clevel, int typesize, int nbytes, int forced,
+                                                                      int codec, int splitmode) {
+  return compute_blocksize(clevel, typesize, nbytes, forced, codec, splitmode);
+}
+__attribute__((visibility("default"))) int blosc_amd_policy_split(int codec, int typesize, int blocksize, int splitmode) {
+  return split_block(codec, typesize, blocksize, splitmode);
+}
+
+void blosc_gpu_profile(int enable) { engine_prof_enable(enable); }
+void blosc_gpu_profile_reset(void) { engine_prof_reset(); }
+int blosc_gpu_profile_get(const char* kernel, double* total_ms, int* launches) { return engine_prof_get(kernel, total_ms, launches); }
+
+}  // extern "C"

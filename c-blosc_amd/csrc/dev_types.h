@@ -1,0 +1,67 @@
+// dev_types.h — descriptor tables shared by the host engine and the HIP kernels.
+//
+// The reference walks chunk -> block -> split with nested loops on one thread
+// (blosc/blosc.c:803-867 serial_blosc, :591-800 blosc_c/blosc_d).  On the GPU every level is
+// flattened into a table so that one launch covers every block / stream of every chunk of a
+// batch:  ChunkDesc[nchunks]  ->  BlockDesc[nblocks_total]  ->  StreamDesc[nstreams_total]
+// ("stream" = one split of a block, or the whole block when it is not split: the unit a codec sees).
+#pragma once
+#include <stdint.h>
+
+namespace bamd {
+
+enum : int32_t {
+  FMT_BLOSCLZ = 0,  // header flag bits 5-7 (blosc/blosc.h:93-99)
+  FMT_LZ4 = 1,
+};
+
+enum : uint32_t {
+  CH_SHUFFLE = 1u,     // byte shuffle active for this chunk's blocks (flag bit0 && typesize > 1)
+  CH_BITSHUFFLE = 2u,  // bit shuffle active (flag bit2; applied per block when bsize >= typesize)
+  CH_MEMCPYED = 4u,    // payload is the raw input after the 16-byte header (flag bit1)
+  CH_SKIP = 8u,        // chunk needs no device work (error found on host, or empty)
+};
+
+struct ChunkDesc {
+  const uint8_t* src;   // decompress: compressed chunk.  compress: uncompressed input
+  uint8_t* dst;         // decompress: output buffer.     compress: chunk being written
+  uint8_t* filt;        // plane-major scratch for this chunk's filtered bytes (nullptr: no filter)
+  uint8_t* stage;       // compress only: staging area, one slot of `neblock` bytes per stream
+  int32_t nbytes;       // uncompressed size
+  int32_t cbytes;       // decompress: header cbytes.  compress: maxbytes (destsize clamped)
+  int32_t blocksize;
+  int32_t typesize;
+  int32_t nblocks;
+  int32_t leftover;     // nbytes % blocksize
+  int32_t nsplits;      // streams per full block (1 or typesize); the leftover block always has 1
+  int32_t fmt;          // FMT_*
+  uint32_t mode;        // CH_* bits
+  int32_t first_block;  // index of this chunk's block 0 in BlockDesc[]
+  int32_t first_stream; // index of its first stream in StreamDesc[]
+  int32_t clevel;       // compress only
+  int32_t hdr_flags;    // compress only: header flag byte to write
+};
+
+struct BlockDesc {
+  int32_t chunk;        // owning chunk
+  int32_t blk;          // block index inside the chunk
+  int32_t first_stream; // global stream index of split 0
+  int32_t nstreams;     // 1 or typesize
+};
+
+struct StreamDesc {
+  const uint8_t* in;    // decode: compressed bytes.  encode: (filtered) plain bytes
+  uint8_t* out;         // decode: where the plain bytes go.  encode: staging slot
+  int32_t in_size;      // decode: csize.  encode: neblock
+  int32_t out_size;     // decode: neblock (must be produced exactly).  encode: slot capacity
+  int32_t chunk;
+  int32_t fmt;          // FMT_*
+  int32_t aux;          // encode: clevel / accel.  decode: unused
+  int32_t result;       // encode: compressed size (0 = store raw).  decode: bytes produced or <0
+};
+
+// Negative per-chunk status codes written by kernels (host maps them to the reference's
+// return values, blosc/blosc.c:762-782): -1 bad csize chain / bounds, -2 codec produced wrong size.
+enum : int32_t { ST_OK = 0, ST_BADCHAIN = -1, ST_BADCODEC = -2 };
+
+}  // namespace bamd

@@ -1,0 +1,731 @@
+// engine.hip — host engine implementation (see engine.h).  Compiled together with the kernels.
+#include "engine.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "blosc_format.h"
+#include "dev_types.h"
+
+#include "k_filters.hip"
+#include "k_decode.hip"
+#include "k_encode.hip"
+
+namespace bamd {
+
+// ---------------------------------------------------------------------------------------------
+// small utilities
+// ---------------------------------------------------------------------------------------------
+static bool g_warned = false;
+#define HIP_TRY(expr)                                                                             \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess) {                                                                       \
+      fprintf(stderr, "blosc_amd: HIP error '%s' at %s:%d (%s)\n", hipGetErrorString(_e), __FILE__, __LINE__, #expr); \
+      return -1;                                                                                  \
+    }                                                                                             \
+  } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct DeviceArena {   // one grow-only device allocation carved up per call
+  uint8_t* base = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (base) { (void)hipFree(base); base = nullptr; cap = 0; }
+    size_t want = align_up(bytes + bytes / 8, 1 << 20);
+    HIP_TRY(hipMalloc((void**)&base, want));
+    cap = want;
+    return 0;
+  }
+  void release() { if (base) (void)hipFree(base); base = nullptr; cap = 0; }
+};
+struct PinnedArena {
+  uint8_t* base = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (base) { (void)hipHostFree(base); base = nullptr; cap = 0; }
+    size_t want = align_up(bytes + bytes / 4, 1 << 16);
+    HIP_TRY(hipHostMalloc((void**)&base, want, hipHostMallocDefault));
+    cap = want;
+    return 0;
+  }
+  void release() { if (base) (void)hipHostFree(base); base = nullptr; cap = 0; }
+};
+
+struct ProfEntry { double ms = 0; int launches = 0; };
+
+struct EngineState {
+  std::mutex mu;
+  bool device_ok = false;
+  int device = -1;
+  DeviceArena dev;      // descriptors + scratch
+  DeviceArena io;       // staging for host-pointer calls
+  PinnedArena pin;
+  // profiling
+  bool prof = false;
+  std::map<std::string, ProfEntry> prof_acc;
+  struct Pending { std::string name; hipEvent_t a, b; };
+  std::vector<Pending> prof_pending;
+  std::vector<hipEvent_t> ev_pool;
+};
+static EngineState& S() { static EngineState s; return s; }
+
+static int ensure_device(EngineState& st) {
+  if (st.device_ok) return 0;
+  int cnt = 0;
+  hipError_t e = hipGetDeviceCount(&cnt);
+  if (e != hipSuccess || cnt <= 0) {
+    if (!g_warned) {
+      fprintf(stderr, "blosc_amd: no usable HIP device (%s); this library has no CPU path\n",
+              e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+      g_warned = true;
+    }
+    return -1;
+  }
+  if (st.device >= 0) HIP_TRY(hipSetDevice(st.device));
+  else HIP_TRY(hipGetDevice(&st.device));
+  st.device_ok = true;
+  return 0;
+}
+
+// ---- profiling helpers ------------------------------------------------------------------------
+static hipEvent_t prof_event(EngineState& st) {
+  if (!st.ev_pool.empty()) { hipEvent_t e = st.ev_pool.back(); st.ev_pool.pop_back(); return e; }
+  hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+struct ProfScope {
+  EngineState& st; hipStream_t s; const char* name; hipEvent_t a{}, b{}; bool on;
+  ProfScope(EngineState& st_, hipStream_t s_, const char* n) : st(st_), s(s_), name(n), on(st_.prof) {
+    if (on) { a = prof_event(st); b = prof_event(st); (void)hipEventRecord(a, s); }
+  }
+  ~ProfScope() { if (on) { (void)hipEventRecord(b, s); st.prof_pending.push_back({name, a, b}); } }
+};
+static void prof_collect(EngineState& st) {   // call after the stream has been synchronised
+  for (auto& p : st.prof_pending) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { auto& e = st.prof_acc[p.name]; e.ms += ms; e.launches++; }
+    st.ev_pool.push_back(p.a); st.ev_pool.push_back(p.b);
+  }
+  st.prof_pending.clear();
+}
+
+// ---- gather of the 16-byte headers of device-resident chunks ------------------------------------
+__global__ void k_gather_headers(const uint8_t* const* __restrict__ srcs, uint8_t* __restrict__ out, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * 16) return;
+  out[i] = srcs[i >> 4][i & 15];
+}
+
+// ---------------------------------------------------------------------------------------------
+// layout helper: sub-allocations inside one arena
+// ---------------------------------------------------------------------------------------------
+struct Carver {
+  size_t off = 0;
+  size_t take(size_t bytes, size_t align = 256) { off = align_up(off, align); size_t r = off; off += bytes; return r; }
+};
+
+static dim3 grid1(size_t n, int per) { return dim3((unsigned)((n + per - 1) / per)); }
+
+// ---------------------------------------------------------------------------------------------
+// compress
+// ---------------------------------------------------------------------------------------------
+int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* results, bool device_ptrs,
+                          hipStream_t stream) {
+  EngineState& st = S();
+  std::lock_guard<std::mutex> lock(st.mu);
+  if (n <= 0) return 0;
+  if (ensure_device(st)) return -1;
+
+  std::vector<ChunkDesc> chunks((size_t)n);
+  std::vector<BlockDesc> blocks;
+  std::vector<StreamDesc> streams;
+  std::vector<uint8_t> live((size_t)n, 0);
+  size_t filt_bytes = 0, stage_bytes = 0, io_src = 0, io_dst = 0;
+  int tiles_shuf = 0, tiles_bit = 0;
+  bool any_shuf = false, any_bit = false;
+
+  // ---- per-chunk parameter checks and geometry (blosc.c:1062-1145, :1148-1247) ----
+  for (int i = 0; i < n; i++) {
+    ChunkDesc& c = chunks[(size_t)i];
+    memset(&c, 0, sizeof c);
+    c.mode = CH_SKIP;
+    size_t nbytes = jobs[i].srcsize, destsize = jobs[i].dstsize, typesize = p.typesize;
+    if (nbytes > (size_t)kMaxBufferSize) { results[i] = 0; continue; }
+    if (destsize < (size_t)kMaxOverhead) { results[i] = 0; continue; }
+    if (destsize - kMaxOverhead > nbytes) destsize = nbytes + kMaxOverhead;
+    if (p.clevel < 0 || p.clevel > 9) { results[i] = -10; continue; }
+    if (p.doshuffle != 0 && p.doshuffle != 1 && p.doshuffle != 2) { results[i] = -10; continue; }
+    if (typesize == 0) { results[i] = -10; continue; }
+    if (typesize > (size_t)kMaxTypeSize) typesize = 1;
+    const int codec = p.codec;
+    if (codec != kBloscLZ && codec != kLZ4 && codec != kLZ4HC) { results[i] = -5; continue; }  // blosc.c:1197-1207
+    const int32_t T = (int32_t)typesize, nb = (int32_t)nbytes;
+    const int32_t bs = compute_blocksize(p.clevel, T, nb, p.forced_blocksize, codec, p.splitmode);
+    int32_t nblocks = nb / bs;
+    const int32_t leftover = nb % bs;
+    if (leftover > 0) nblocks++;
+    int flags = 0;
+    bool memcpyed = (p.clevel == 0) || (nb < kMinBufferSize);
+    if (memcpyed) flags |= kFlagMemcpyed;
+    if (p.doshuffle == 1) flags |= kFlagShuffle;
+    if (p.doshuffle == 2) flags |= kFlagBitShuffle;
+    const int split = split_block(codec, T, bs, p.splitmode);
+    flags |= (!split) << 4;
+    flags |= codec_to_format(codec) << 5;
+    if (memcpyed && (size_t)nb + kMaxOverhead > destsize) { results[i] = 0; continue; }  // blosc.c:1254-1257
+
+    c.src = (const uint8_t*)jobs[i].src; c.dst = (uint8_t*)jobs[i].dst;
+    c.nbytes = nb; c.cbytes = (int32_t)destsize; c.blocksize = bs; c.typesize = T;
+    c.nblocks = nblocks; c.leftover = leftover; c.nsplits = split ? T : 1;
+    c.fmt = codec_to_format(codec); c.clevel = (codec == kLZ4HC) ? 9 : p.clevel; c.hdr_flags = flags;
+    c.mode = 0;
+    c.first_block = (int32_t)blocks.size(); c.first_stream = (int32_t)streams.size();
+    if (memcpyed) c.mode |= CH_MEMCPYED;
+    else if (p.doshuffle == 1 && T > 1) c.mode |= CH_SHUFFLE;
+    else if (p.doshuffle == 2) c.mode |= CH_BITSHUFFLE;
+    live[(size_t)i] = 1;
+    results[i] = 0;
+    if (!device_ptrs) { io_src = align_up(io_src, 256) + (size_t)nb; io_dst = align_up(io_dst, 256) + destsize; }
+    const bool filtered = (c.mode & (CH_SHUFFLE | CH_BITSHUFFLE)) != 0;
+    if (filtered) {
+      const int32_t N = bs / T;
+      if (c.mode & CH_SHUFFLE) { any_shuf = true; int t = (N + shuffle_tile_elems(T) - 1) / shuffle_tile_elems(T); if (t > tiles_shuf) tiles_shuf = t; }
+      else { any_bit = true; int t = (N + bitshuffle_tile_elems(T) - 1) / bitshuffle_tile_elems(T); if (t < 1) t = 1; if (t > tiles_bit) tiles_bit = t; }
+    }
+    // blocks + streams; pointers are patched once the arenas are placed (offsets stored for now)
+    for (int32_t j = 0; j < nblocks; j++) {
+      BlockDesc b;
+      b.chunk = i; b.blk = j; b.first_stream = (int32_t)streams.size();
+      const bool last = (j == nblocks - 1) && leftover > 0;
+      b.nstreams = memcpyed ? 0 : ((split && !last) ? T : 1);
+      const int32_t bsize = last ? leftover : bs;
+      const int32_t neblock = b.nstreams ? bsize / b.nstreams : 0;
+      for (int32_t s = 0; s < b.nstreams; s++) {
+        StreamDesc sd;
+        memset(&sd, 0, sizeof sd);
+        sd.in = (const uint8_t*)(uintptr_t)((size_t)j * bs + (size_t)s * neblock);   // offset, patched below
+        sd.out = (uint8_t*)(uintptr_t)((size_t)j * bs + (size_t)s * neblock);
+        sd.in_size = neblock; sd.out_size = neblock; sd.chunk = i; sd.fmt = c.fmt; sd.aux = c.clevel;
+        streams.push_back(sd);
+      }
+      blocks.push_back(b);
+    }
+    if (!memcpyed) {
+      if (filtered) filt_bytes = align_up(filt_bytes, 256) + (size_t)nb;
+      stage_bytes = align_up(stage_bytes, 256) + (size_t)nb;
+    }
+  }
+
+  const size_t nblk = blocks.size(), nstr = streams.size();
+  // ---- device workspace ----
+  Carver cv;
+  const size_t o_chunks = cv.take(sizeof(ChunkDesc) * (size_t)n);
+  const size_t o_blocks = cv.take(sizeof(BlockDesc) * (nblk ? nblk : 1));
+  const size_t o_streams = cv.take(sizeof(StreamDesc) * (nstr ? nstr : 1));
+  const size_t o_blkoff = cv.take(sizeof(int32_t) * (nblk ? nblk : 1));
+  const size_t o_results = cv.take(sizeof(int32_t) * (size_t)n);
+  const size_t o_filt = cv.take(filt_bytes + 256);
+  const size_t o_stage = cv.take(stage_bytes + 256);
+  if (st.dev.ensure(cv.off)) return -1;
+  uint8_t* D = st.dev.base;
+  uint8_t *io_s = nullptr, *io_d = nullptr;
+  if (!device_ptrs) {
+    if (st.io.ensure(align_up(io_src + 256, 256) + io_dst + 512)) return -1;
+    io_s = st.io.base; io_d = st.io.base + align_up(io_src + 256, 256);
+  }
+  // ---- patch pointers ----
+  {
+    size_t fo = 0, so = 0, is = 0, id = 0;
+    for (int i = 0; i < n; i++) {
+      if (!live[(size_t)i]) continue;
+      ChunkDesc& c = chunks[(size_t)i];
+      if (!device_ptrs) {
+        is = align_up(is, 256); id = align_up(id, 256);
+        HIP_TRY(hipMemcpyAsync(io_s + is, jobs[i].src, (size_t)c.nbytes, hipMemcpyHostToDevice, stream));
+        c.src = io_s + is; c.dst = io_d + id;
+        is += (size_t)c.nbytes; id += (size_t)c.cbytes;
+      }
+      if (c.mode & CH_MEMCPYED) continue;
+      const bool filtered = (c.mode & (CH_SHUFFLE | CH_BITSHUFFLE)) != 0;
+      if (filtered) { fo = align_up(fo, 256); c.filt = D + o_filt + fo; fo += (size_t)c.nbytes; }
+      so = align_up(so, 256); c.stage = D + o_stage + so; so += (size_t)c.nbytes;
+      const uint8_t* inbase = filtered ? c.filt : c.src;
+      for (int32_t j = 0; j < c.nblocks; j++) {
+        const BlockDesc& b = blocks[(size_t)c.first_block + j];
+        for (int32_t s = 0; s < b.nstreams; s++) {
+          StreamDesc& sd = streams[(size_t)b.first_stream + s];
+          sd.in = inbase + (uintptr_t)sd.in;
+          sd.out = c.stage + (uintptr_t)sd.out;
+        }
+      }
+    }
+  }
+  // ---- upload tables ----
+  Carver pc;
+  const size_t p_chunks = pc.take(sizeof(ChunkDesc) * (size_t)n);
+  const size_t p_blocks = pc.take(sizeof(BlockDesc) * (nblk ? nblk : 1));
+  const size_t p_streams = pc.take(sizeof(StreamDesc) * (nstr ? nstr : 1));
+  const size_t p_results = pc.take(sizeof(int32_t) * (size_t)n);
+  if (st.pin.ensure(pc.off)) return -1;
+  uint8_t* P = st.pin.base;
+  memcpy(P + p_chunks, chunks.data(), sizeof(ChunkDesc) * (size_t)n);
+  if (nblk) memcpy(P + p_blocks, blocks.data(), sizeof(BlockDesc) * nblk);
+  if (nstr) memcpy(P + p_streams, streams.data(), sizeof(StreamDesc) * nstr);
+  HIP_TRY(hipMemcpyAsync(D + o_chunks, P + p_chunks, sizeof(ChunkDesc) * (size_t)n, hipMemcpyHostToDevice, stream));
+  if (nblk) HIP_TRY(hipMemcpyAsync(D + o_blocks, P + p_blocks, sizeof(BlockDesc) * nblk, hipMemcpyHostToDevice, stream));
+  if (nstr) HIP_TRY(hipMemcpyAsync(D + o_streams, P + p_streams, sizeof(StreamDesc) * nstr, hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemsetAsync(D + o_results, 0, sizeof(int32_t) * (size_t)n, stream));
+
+  ChunkDesc* d_chunks = (ChunkDesc*)(D + o_chunks);
+  BlockDesc* d_blocks = (BlockDesc*)(D + o_blocks);
+  StreamDesc* d_streams = (StreamDesc*)(D + o_streams);
+  int32_t* d_blkoff = (int32_t*)(D + o_blkoff);
+  int32_t* d_results = (int32_t*)(D + o_results);
+
+  // ---- pipeline ----
+  if (any_shuf && nblk) {
+    ProfScope ps(st, stream, "k_shuffle");
+    hipLaunchKernelGGL(k_shuffle, dim3((unsigned)nblk, (unsigned)tiles_shuf), dim3(FT_THREADS), 0, stream, d_chunks, d_blocks);
+  }
+  if (any_bit && nblk) {
+    ProfScope ps(st, stream, "k_bitshuffle");
+    hipLaunchKernelGGL(k_bitshuffle, dim3((unsigned)nblk, (unsigned)tiles_bit), dim3(FT_THREADS), 0, stream, d_chunks, d_blocks);
+  }
+  if (nstr) {
+    ProfScope ps(st, stream, "k_encode_streams");
+    hipLaunchKernelGGL(k_encode_streams, grid1(nstr, ENC_WAVES), dim3(64 * ENC_WAVES), 0, stream, d_streams, (int)nstr);
+  }
+  {
+    ProfScope ps(st, stream, "k_chunk_scan");
+    hipLaunchKernelGGL(k_chunk_scan, dim3((unsigned)n), dim3(SCAN_THREADS), 0, stream, d_chunks, d_blocks, d_streams, d_blkoff, d_results);
+  }
+  if (nblk) {
+    ProfScope ps(st, stream, "k_chunk_compact");
+    hipLaunchKernelGGL(k_chunk_compact, dim3((unsigned)nblk), dim3(COMPACT_THREADS), 0, stream, d_chunks, d_blocks, d_streams, d_blkoff);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(P + p_results, d_results, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  prof_collect(st);
+  const int32_t* r = (const int32_t*)(P + p_results);
+  for (int i = 0; i < n; i++) if (live[(size_t)i]) results[i] = r[i];
+  if (!device_ptrs) {
+    for (int i = 0; i < n; i++) {
+      if (!live[(size_t)i] || results[i] <= 0) continue;
+      HIP_TRY(hipMemcpyAsync(jobs[i].dst, chunks[(size_t)i].dst, (size_t)results[i], hipMemcpyDeviceToHost, stream));
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// decompress
+// ---------------------------------------------------------------------------------------------
+// header validation shared by decompress and getitem; returns 1 = go on, else *res holds the result
+static int classify_for_decompress(const Header& h, size_t srcsize, size_t destsize, int* res, int* fmt) {
+  if (h.nbytes == 0) { *res = 0; return 0; }                                   // blosc.c:1463-1466
+  if (h.blocksize <= 0 || (size_t)h.blocksize > destsize || h.blocksize > kMaxBlockSize || h.typesize <= 0) { *res = -1; return 0; }
+  if (h.version != kVersionFormat) { *res = -1; return 0; }                    // blosc.c:1474-1477
+  if (h.flags & kFlagReserved) { *res = -1; return 0; }                        // blosc.c:1478-1481
+  if (h.nbytes < 0 || (size_t)h.nbytes > destsize) { *res = -1; return 0; }    // blosc.c:1490-1492
+  if (srcsize && (h.cbytes < 0 || (size_t)h.cbytes > srcsize)) { *res = -1; return 0; }  // extension: caller told us the buffer size
+  if (h.flags & kFlagMemcpyed) {
+    if (h.nbytes + kMaxOverhead != h.cbytes) { *res = -1; return 0; }          // blosc.c:1494-1499
+    *fmt = 0;
+    return 1;
+  }
+  const int f = (h.flags & 0xe0) >> 5;                                         // blosc.c:525-574
+  if (f != FMT_BLOSCLZ && f != FMT_LZ4) { *res = -5; return 0; }
+  if (h.versionlz != 1) { *res = -9; return 0; }
+  *fmt = f;
+  int32_t nblocks = h.nbytes / h.blocksize + ((h.nbytes % h.blocksize) ? 1 : 0);
+  if (nblocks > (h.cbytes - 16) / 4) { *res = -1; return 0; }                  // blosc.c:1504-1507
+  return 1;
+}
+
+static int fetch_headers(EngineState& st, int n, const Job* jobs, bool device_ptrs, hipStream_t stream,
+                         std::vector<Header>& hdrs) {
+  hdrs.resize((size_t)n);
+  if (!device_ptrs) {
+    for (int i = 0; i < n; i++) hdrs[(size_t)i] = parse_header((const uint8_t*)jobs[i].src);
+    return 0;
+  }
+  Carver cv;
+  const size_t o_ptrs = cv.take(sizeof(void*) * (size_t)n);
+  const size_t o_hdr = cv.take(16 * (size_t)n);
+  if (st.dev.ensure(cv.off)) return -1;
+  if (st.pin.ensure(cv.off)) return -1;
+  const void** pp = (const void**)(st.pin.base + o_ptrs);
+  for (int i = 0; i < n; i++) pp[i] = jobs[i].src;
+  HIP_TRY(hipMemcpyAsync(st.dev.base + o_ptrs, pp, sizeof(void*) * (size_t)n, hipMemcpyHostToDevice, stream));
+  hipLaunchKernelGGL(k_gather_headers, grid1((size_t)n * 16, 256), dim3(256), 0, stream,
+                     (const uint8_t* const*)(st.dev.base + o_ptrs), st.dev.base + o_hdr, n);
+  HIP_TRY(hipMemcpyAsync(st.pin.base + o_hdr, st.dev.base + o_hdr, 16 * (size_t)n, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  for (int i = 0; i < n; i++) hdrs[(size_t)i] = parse_header(st.pin.base + o_hdr + 16 * (size_t)i);
+  return 0;
+}
+
+// Builds the tables for decoding blocks [j0, j1) of one validated chunk.
+static void add_decode_chunk(const Header& h, int fmt, int chunk_index, int32_t j0, int32_t j1,
+                             ChunkDesc& c, std::vector<BlockDesc>& blocks, size_t& nstreams) {
+  memset(&c, 0, sizeof c);
+  const int32_t T = h.typesize, bs = h.blocksize;
+  c.nbytes = h.nbytes; c.cbytes = h.cbytes; c.blocksize = bs; c.typesize = T;
+  c.nblocks = h.nbytes / bs + ((h.nbytes % bs) ? 1 : 0);
+  c.leftover = h.nbytes % bs;
+  c.fmt = fmt;
+  const bool dont_split = (h.flags & kFlagDontSplit) != 0;
+  const bool split = !dont_split && T <= kMaxSplits && bs / T >= kMinBufferSize;   // blosc.c:749-757
+  c.nsplits = split ? T : 1;
+  c.mode = 0;
+  if (h.flags & kFlagMemcpyed) c.mode |= CH_MEMCPYED;
+  else if ((h.flags & kFlagShuffle) && T > 1) c.mode |= CH_SHUFFLE;            // blosc.c:739-741
+  else if (h.flags & kFlagBitShuffle) c.mode |= CH_BITSHUFFLE;
+  c.first_block = (int32_t)blocks.size();
+  c.first_stream = (int32_t)nstreams;
+  if (c.mode & CH_MEMCPYED) return;
+  for (int32_t j = j0; j < j1; j++) {
+    BlockDesc b;
+    b.chunk = chunk_index; b.blk = j; b.first_stream = (int32_t)nstreams;
+    const bool last = (j == c.nblocks - 1) && c.leftover > 0;
+    b.nstreams = (split && !last) ? T : 1;
+    nstreams += (size_t)b.nstreams;
+    blocks.push_back(b);
+  }
+}
+
+struct DecodeLaunch {
+  ChunkDesc* d_chunks; BlockDesc* d_blocks; StreamDesc* d_streams; int32_t* d_status;
+  size_t nblk, nstr; int nchunks;
+  bool any_shuf, any_bit, any_copy; int tiles_shuf, tiles_bit;
+};
+
+static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t stream) {
+  if (L.nblk) {
+    {
+      ProfScope ps(st, stream, "k_decode_plan");
+      hipLaunchKernelGGL(k_decode_plan, grid1(L.nblk, 256), dim3(256), 0, stream, L.d_chunks, L.d_blocks, L.d_streams, L.d_status, (int)L.nblk);
+    }
+    {
+      ProfScope ps(st, stream, "k_decode_streams");
+      hipLaunchKernelGGL(k_decode_streams, grid1(L.nstr, DEC_WAVES), dim3(64 * DEC_WAVES), 0, stream, L.d_streams, L.d_status, (int)L.nstr);
+    }
+    if (L.any_shuf) {
+      ProfScope ps(st, stream, "k_unshuffle");
+      hipLaunchKernelGGL(k_unshuffle, dim3((unsigned)L.nblk, (unsigned)L.tiles_shuf), dim3(FT_THREADS), 0, stream, L.d_chunks, L.d_blocks);
+    }
+    if (L.any_bit) {
+      ProfScope ps(st, stream, "k_bitunshuffle");
+      hipLaunchKernelGGL(k_bitunshuffle, dim3((unsigned)L.nblk, (unsigned)L.tiles_bit), dim3(FT_THREADS), 0, stream, L.d_chunks, L.d_blocks);
+    }
+  }
+  if (L.any_copy) {
+    ProfScope ps(st, stream, "k_copy_chunks");
+    hipLaunchKernelGGL(k_copy_chunks, dim3(64, (unsigned)L.nchunks), dim3(COMPACT_THREADS), 0, stream, L.d_chunks, kMaxOverhead);
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+static void filter_tiles(const ChunkDesc& c, bool& any_shuf, bool& any_bit, int& tiles_shuf, int& tiles_bit) {
+  const int32_t T = c.typesize, N = c.blocksize / T;
+  if (c.mode & CH_SHUFFLE) {
+    any_shuf = true;
+    int t = (N + shuffle_tile_elems(T) - 1) / shuffle_tile_elems(T); if (t < 1) t = 1;
+    if (t > tiles_shuf) tiles_shuf = t;
+  } else if (c.mode & CH_BITSHUFFLE) {
+    any_bit = true;
+    int t = (N + bitshuffle_tile_elems(T) - 1) / bitshuffle_tile_elems(T); if (t < 1) t = 1;
+    if (t > tiles_bit) tiles_bit = t;
+  }
+}
+
+int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_ptrs, hipStream_t stream) {
+  EngineState& st = S();
+  std::lock_guard<std::mutex> lock(st.mu);
+  if (n <= 0) return 0;
+  if (ensure_device(st)) return -1;
+
+  std::vector<Header> hdrs;
+  if (fetch_headers(st, n, jobs, device_ptrs, stream, hdrs)) return -1;
+
+  std::vector<ChunkDesc> chunks((size_t)n);
+  std::vector<BlockDesc> blocks;
+  std::vector<uint8_t> live((size_t)n, 0);
+  size_t nstr = 0, filt_bytes = 0, io_src = 0, io_dst = 0;
+  DecodeLaunch L{};
+  for (int i = 0; i < n; i++) {
+    ChunkDesc& c = chunks[(size_t)i];
+    memset(&c, 0, sizeof c);
+    c.mode = CH_SKIP;
+    int res = -1, fmt = 0;
+    if (!classify_for_decompress(hdrs[(size_t)i], jobs[i].srcsize, jobs[i].dstsize, &res, &fmt)) { results[i] = res; continue; }
+    add_decode_chunk(hdrs[(size_t)i], fmt, i, 0, hdrs[(size_t)i].nbytes / hdrs[(size_t)i].blocksize + ((hdrs[(size_t)i].nbytes % hdrs[(size_t)i].blocksize) ? 1 : 0),
+                     c, blocks, nstr);
+    c.src = (const uint8_t*)jobs[i].src; c.dst = (uint8_t*)jobs[i].dst;
+    live[(size_t)i] = 1;
+    results[i] = c.nbytes;
+    if (c.mode & CH_MEMCPYED) L.any_copy = true;
+    filter_tiles(c, L.any_shuf, L.any_bit, L.tiles_shuf, L.tiles_bit);
+    if (c.mode & (CH_SHUFFLE | CH_BITSHUFFLE)) filt_bytes = align_up(filt_bytes, 256) + (size_t)c.nbytes;
+    if (!device_ptrs) { io_src = align_up(io_src, 256) + (size_t)c.cbytes; io_dst = align_up(io_dst, 256) + (size_t)c.nbytes; }
+  }
+  const size_t nblk = blocks.size();
+
+  Carver cv;
+  const size_t o_chunks = cv.take(sizeof(ChunkDesc) * (size_t)n);
+  const size_t o_blocks = cv.take(sizeof(BlockDesc) * (nblk ? nblk : 1));
+  const size_t o_streams = cv.take(sizeof(StreamDesc) * (nstr ? nstr : 1));
+  const size_t o_status = cv.take(sizeof(int32_t) * (size_t)n);
+  const size_t o_filt = cv.take(filt_bytes + 256);
+  if (st.dev.ensure(cv.off)) return -1;
+  uint8_t* D = st.dev.base;
+  uint8_t *io_s = nullptr, *io_d = nullptr;
+  if (!device_ptrs) {
+    if (st.io.ensure(align_up(io_src + 256, 256) + io_dst + 512)) return -1;
+    io_s = st.io.base; io_d = st.io.base + align_up(io_src + 256, 256);
+  }
+  {
+    size_t fo = 0, is = 0, id = 0;
+    for (int i = 0; i < n; i++) {
+      if (!live[(size_t)i]) continue;
+      ChunkDesc& c = chunks[(size_t)i];
+      if (!device_ptrs) {
+        is = align_up(is, 256); id = align_up(id, 256);
+        HIP_TRY(hipMemcpyAsync(io_s + is, jobs[i].src, (size_t)c.cbytes, hipMemcpyHostToDevice, stream));
+        c.src = io_s + is; c.dst = io_d + id;
+        is += (size_t)c.cbytes; id += (size_t)c.nbytes;
+      }
+      if (c.mode & (CH_SHUFFLE | CH_BITSHUFFLE)) { fo = align_up(fo, 256); c.filt = D + o_filt + fo; fo += (size_t)c.nbytes; }
+    }
+  }
+  Carver pc;
+  const size_t p_chunks = pc.take(sizeof(ChunkDesc) * (size_t)n);
+  const size_t p_blocks = pc.take(sizeof(BlockDesc) * (nblk ? nblk : 1));
+  const size_t p_status = pc.take(sizeof(int32_t) * (size_t)n);
+  if (st.pin.ensure(pc.off)) return -1;
+  uint8_t* P = st.pin.base;
+  memcpy(P + p_chunks, chunks.data(), sizeof(ChunkDesc) * (size_t)n);
+  if (nblk) memcpy(P + p_blocks, blocks.data(), sizeof(BlockDesc) * nblk);
+  HIP_TRY(hipMemcpyAsync(D + o_chunks, P + p_chunks, sizeof(ChunkDesc) * (size_t)n, hipMemcpyHostToDevice, stream));
+  if (nblk) HIP_TRY(hipMemcpyAsync(D + o_blocks, P + p_blocks, sizeof(BlockDesc) * nblk, hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemsetAsync(D + o_status, 0, sizeof(int32_t) * (size_t)n, stream));
+
+  L.d_chunks = (ChunkDesc*)(D + o_chunks); L.d_blocks = (BlockDesc*)(D + o_blocks);
+  L.d_streams = (StreamDesc*)(D + o_streams); L.d_status = (int32_t*)(D + o_status);
+  L.nblk = nblk; L.nstr = nstr; L.nchunks = n;
+  if (launch_decode(st, L, stream)) return -1;
+  HIP_TRY(hipMemcpyAsync(P + p_status, D + o_status, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  prof_collect(st);
+  const int32_t* stt = (const int32_t*)(P + p_status);
+  for (int i = 0; i < n; i++) {
+    if (!live[(size_t)i]) continue;
+    if (stt[i] < 0) results[i] = -1;       // blosc.c:1511-1514: every block-level error surfaces as -1
+  }
+  if (!device_ptrs) {
+    for (int i = 0; i < n; i++) {
+      if (!live[(size_t)i] || results[i] <= 0) continue;
+      HIP_TRY(hipMemcpyAsync(jobs[i].dst, chunks[(size_t)i].dst, (size_t)results[i], hipMemcpyDeviceToHost, stream));
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// getitem (blosc/blosc.c:1574-1703): decode only the blocks overlapping [start, start+nitems)
+// ---------------------------------------------------------------------------------------------
+int engine_getitem(const void* src, int start, int nitems, void* dest, bool src_dev, bool dst_dev, hipStream_t stream) {
+  EngineState& st = S();
+  std::lock_guard<std::mutex> lock(st.mu);
+  if (ensure_device(st)) return -1;
+  Job job{src, nullptr, 0, 0};
+  std::vector<Header> hdrs;
+  if (fetch_headers(st, 1, &job, src_dev, stream, hdrs)) return -1;
+  const Header h = hdrs[0];
+  const int stop = start + nitems;
+  if (h.version != kVersionFormat) return -9;                                    // blosc.c:1603-1604
+  if (h.blocksize <= 0 || h.blocksize > h.nbytes || h.blocksize > kMaxBlockSize || h.typesize <= 0) return -1;
+  const int32_t T = h.typesize, bs = h.blocksize;
+  const int32_t nblocks = h.nbytes / bs + ((h.nbytes % bs) ? 1 : 0);
+  int fmt = 0;
+  if (h.flags & kFlagMemcpyed) {
+    if (h.nbytes + kMaxOverhead != h.cbytes) return -1;
+  } else {
+    const int f = (h.flags & 0xe0) >> 5;
+    if (f != FMT_BLOSCLZ && f != FMT_LZ4) return -5;
+    if (h.versionlz != 1) return -9;
+    fmt = f;
+    if (nblocks >= (h.cbytes - 16) / 4) return -1;                               // blosc.c:1630-1632 (sic: >=)
+  }
+  if (start < 0 || (int64_t)start * T > h.nbytes) { fprintf(stderr, "`start` out of bounds"); return -1; }
+  if (stop < 0 || (int64_t)stop * T > h.nbytes) { fprintf(stderr, "`start`+`nitems` out of bounds"); return -1; }
+  const int64_t lo = (int64_t)start * T, hi = (int64_t)stop * T;
+  if (hi <= lo) return 0;
+  const size_t want = (size_t)(hi - lo);
+  const hipMemcpyKind out_kind = dst_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+
+  const uint8_t* dsrc = (const uint8_t*)src;
+  if (!src_dev) {   // bring the chunk to the device
+    if (h.cbytes < kMaxOverhead) return -1;
+    if (st.io.ensure((size_t)h.cbytes + 256)) return -1;
+    HIP_TRY(hipMemcpyAsync(st.io.base, src, (size_t)h.cbytes, hipMemcpyHostToDevice, stream));
+    dsrc = st.io.base;
+  }
+  if (h.flags & kFlagMemcpyed) {
+    HIP_TRY(hipMemcpyAsync(dest, dsrc + kMaxOverhead + lo, want, dst_dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return (int)want;
+  }
+  const int32_t j0 = (int32_t)(lo / bs), j1 = (int32_t)((hi + bs - 1) / bs);
+  ChunkDesc c;
+  std::vector<BlockDesc> blocks;
+  size_t nstr = 0;
+  add_decode_chunk(h, fmt, 0, j0, j1, c, blocks, nstr);
+  const size_t nblk = blocks.size();
+  const size_t span = (size_t)(j1 - j0) * (size_t)bs;
+  Carver cv;
+  const size_t o_chunks = cv.take(sizeof(ChunkDesc));
+  const size_t o_blocks = cv.take(sizeof(BlockDesc) * nblk);
+  const size_t o_streams = cv.take(sizeof(StreamDesc) * nstr);
+  const size_t o_status = cv.take(sizeof(int32_t));
+  const size_t o_out = cv.take(span + 256);
+  const size_t o_filt = cv.take(span + 256);
+  if (st.dev.ensure(cv.off)) return -1;
+  uint8_t* D = st.dev.base;
+  c.src = dsrc;
+  // kernels address block j at base + j*blocksize: bias the bases so that block j0 lands at offset 0
+  c.dst = D + o_out - (size_t)j0 * bs;
+  c.filt = (c.mode & (CH_SHUFFLE | CH_BITSHUFFLE)) ? D + o_filt - (size_t)j0 * bs : nullptr;
+  Carver pc;
+  const size_t p_chunks = pc.take(sizeof(ChunkDesc));
+  const size_t p_blocks = pc.take(sizeof(BlockDesc) * nblk);
+  const size_t p_status = pc.take(sizeof(int32_t));
+  if (st.pin.ensure(pc.off)) return -1;
+  uint8_t* P = st.pin.base;
+  memcpy(P + p_chunks, &c, sizeof c);
+  memcpy(P + p_blocks, blocks.data(), sizeof(BlockDesc) * nblk);
+  HIP_TRY(hipMemcpyAsync(D + o_chunks, P + p_chunks, sizeof c, hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemcpyAsync(D + o_blocks, P + p_blocks, sizeof(BlockDesc) * nblk, hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemsetAsync(D + o_status, 0, sizeof(int32_t), stream));
+  DecodeLaunch L{};
+  L.d_chunks = (ChunkDesc*)(D + o_chunks); L.d_blocks = (BlockDesc*)(D + o_blocks);
+  L.d_streams = (StreamDesc*)(D + o_streams); L.d_status = (int32_t*)(D + o_status);
+  L.nblk = nblk; L.nstr = nstr; L.nchunks = 1;
+  filter_tiles(c, L.any_shuf, L.any_bit, L.tiles_shuf, L.tiles_bit);
+  if (launch_decode(st, L, stream)) return -1;
+  HIP_TRY(hipMemcpyAsync(P + p_status, D + o_status, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  prof_collect(st);
+  const int32_t stt = *(const int32_t*)(P + p_status);
+  if (stt < 0) return stt;                                                        // blosc.c:1689-1692: blosc_d's code is returned as is
+  HIP_TRY(hipMemcpyAsync(dest, D + o_out + (size_t)(lo - (int64_t)j0 * bs), want, out_kind, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  return (int)want;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stand-alone filter calls on host buffers (the reference exports blosc_internal_* for its own
+// tests under BLOSC_TESTING, blosc/shuffle.h:34-61 + blosc/blosc-export.h:38-43)
+// kind: 0 shuffle, 1 unshuffle, 2 bitshuffle, 3 bitunshuffle
+// ---------------------------------------------------------------------------------------------
+int engine_filter(int kind, size_t typesize, size_t blocksize, const void* src, void* dst) {
+  EngineState& st = S();
+  std::lock_guard<std::mutex> lock(st.mu);
+  if (ensure_device(st)) return -1;
+  if (blocksize == 0) return 0;
+  if (typesize == 0 || typesize > 255 || blocksize > (size_t)kMaxBlockSize) return -1;
+  hipStream_t stream = 0;
+  const int32_t T = (int32_t)typesize, bs = (int32_t)blocksize;
+  Carver cv;
+  const size_t o_chunk = cv.take(sizeof(ChunkDesc));
+  const size_t o_block = cv.take(sizeof(BlockDesc));
+  const size_t o_in = cv.take(blocksize + 256);
+  const size_t o_out = cv.take(blocksize + 256);
+  if (st.dev.ensure(cv.off)) return -1;
+  uint8_t* D = st.dev.base;
+  ChunkDesc c;
+  memset(&c, 0, sizeof c);
+  c.nbytes = bs; c.blocksize = bs; c.typesize = T; c.nblocks = 1; c.leftover = 0; c.nsplits = 1;
+  const bool fwd = (kind == 0 || kind == 2);
+  c.mode = (kind < 2) ? CH_SHUFFLE : CH_BITSHUFFLE;
+  // forward kernels read c.src and write c.filt; inverse kernels read c.filt and write c.dst
+  if (fwd) { c.src = D + o_in; c.filt = D + o_out; c.dst = nullptr; }
+  else { c.filt = D + o_in; c.dst = D + o_out; c.src = nullptr; }
+  BlockDesc b{0, 0, 0, 1};
+  HIP_TRY(hipMemcpyAsync(D + o_chunk, &c, sizeof c, hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemcpyAsync(D + o_block, &b, sizeof b, hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemcpyAsync(D + o_in, src, blocksize, hipMemcpyHostToDevice, stream));
+  const int32_t N = bs / T;
+  int tiles;
+  if (kind < 2) tiles = (N + shuffle_tile_elems(T) - 1) / shuffle_tile_elems(T);
+  else tiles = (N + bitshuffle_tile_elems(T) - 1) / bitshuffle_tile_elems(T);
+  if (tiles < 1) tiles = 1;
+  const ChunkDesc* dc = (const ChunkDesc*)(D + o_chunk);
+  const BlockDesc* db = (const BlockDesc*)(D + o_block);
+  switch (kind) {
+    case 0: hipLaunchKernelGGL(k_shuffle, dim3(1, (unsigned)tiles), dim3(FT_THREADS), 0, stream, dc, db); break;
+    case 1: hipLaunchKernelGGL(k_unshuffle, dim3(1, (unsigned)tiles), dim3(FT_THREADS), 0, stream, dc, db); break;
+    case 2: hipLaunchKernelGGL(k_bitshuffle, dim3(1, (unsigned)tiles), dim3(FT_THREADS), 0, stream, dc, db); break;
+    default: hipLaunchKernelGGL(k_bitunshuffle, dim3(1, (unsigned)tiles), dim3(FT_THREADS), 0, stream, dc, db); break;
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(dst, D + o_out, blocksize, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// misc
+// ---------------------------------------------------------------------------------------------
+int engine_set_device(int dev) {
+  EngineState& st = S();
+  std::lock_guard<std::mutex> lock(st.mu);
+  int cnt = 0;
+  if (hipGetDeviceCount(&cnt) != hipSuccess || dev < 0 || dev >= cnt) return -1;
+  if (st.device_ok && st.device != dev) { st.dev.release(); st.io.release(); }
+  HIP_TRY(hipSetDevice(dev));
+  st.device = dev; st.device_ok = true;
+  return 0;
+}
+
+void engine_release() {
+  EngineState& st = S();
+  std::lock_guard<std::mutex> lock(st.mu);
+  if (!st.device_ok) return;
+  st.dev.release(); st.io.release(); st.pin.release();
+}
+
+bool engine_is_device_pointer(const void* p) {
+  if (!p) return false;
+  hipPointerAttribute_t a;
+  hipError_t e = hipPointerGetAttributes(&a, p);
+  if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+void engine_prof_enable(int on) { EngineState& st = S(); std::lock_guard<std::mutex> lock(st.mu); st.prof = on != 0; }
+void engine_prof_reset() { EngineState& st = S(); std::lock_guard<std::mutex> lock(st.mu); st.prof_acc.clear(); }
+int engine_prof_get(const char* kernel, double* total_ms, int* launches) {
+  EngineState& st = S();
+  std::lock_guard<std::mutex> lock(st.mu);
+  auto it = st.prof_acc.find(kernel);
+  if (it == st.prof_acc.end()) { if (total_ms) *total_ms = 0; if (launches) *launches = 0; return -1; }
+  if (total_ms) *total_ms = it->second.ms;
+  if (launches) *launches = it->second.launches;
+  return 0;
+}
+
+}  // namespace bamd

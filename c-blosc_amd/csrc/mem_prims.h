@@ -1,0 +1,41 @@
+// mem_prims.h — address-space-explicit memory helpers for the gfx950 kernels.
+//
+// Pointers that reach a kernel through a descriptor table are "generic" to the compiler, which
+// then emits flat_load/flat_store (slower issue, and they tie vmcnt to lgkmcnt).  Every kernel
+// therefore casts them once to address space 1 (global) and uses these helpers, which lower to
+// global_load/global_store with arbitrary byte alignment (gfx950 global memory accepts
+// unaligned dword..dwordx4 accesses; amdhsa enables unaligned-access-mode).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bamd {
+
+#define BAMD_GAS __attribute__((address_space(1)))
+typedef BAMD_GAS uint8_t gu8;
+
+typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
+typedef v4u32 __attribute__((aligned(1))) v4u32_una;
+typedef uint32_t __attribute__((aligned(1))) u32una;
+typedef uint64_t __attribute__((aligned(1))) u64una;
+typedef uint16_t __attribute__((aligned(1))) u16una;
+
+__device__ __forceinline__ const gu8* as_global(const uint8_t* p) { return (const gu8*)p; }
+__device__ __forceinline__ gu8* as_global(uint8_t* p) { return (gu8*)p; }
+
+__device__ __forceinline__ uint4 g_ld16(const gu8* p) {
+  v4u32 t = *(const BAMD_GAS v4u32_una*)p;
+  return make_uint4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ void g_st16(gu8* p, uint4 v) {
+  v4u32 t = {v.x, v.y, v.z, v.w};
+  *(BAMD_GAS v4u32_una*)p = t;
+}
+__device__ __forceinline__ uint32_t g_ld4(const gu8* p) { return *(const BAMD_GAS u32una*)p; }
+__device__ __forceinline__ uint64_t g_ld8(const gu8* p) { return *(const BAMD_GAS u64una*)p; }
+__device__ __forceinline__ void g_st4(gu8* p, uint32_t v) { *(BAMD_GAS u32una*)p = v; }
+
+__device__ __forceinline__ int32_t g_ld_i32le(const gu8* p) { return (int32_t)g_ld4(p); }   // device is little endian
+__device__ __forceinline__ void g_st_i32le(gu8* p, int32_t v) { g_st4(p, (uint32_t)v); }
+
+}  // namespace bamd

@@ -1,0 +1,148 @@
+// wave_prims.h — wavefront-level building blocks used by the LZ codecs (gfx950, wave64).
+//
+// One wavefront owns one LZ stream.  Everything that steers control flow (input position,
+// output position, lengths, offsets) is wave-uniform and kept in SGPRs (readfirstlane /
+// readlane); the 64 lanes are only used as a 64- to 1024-byte wide copy engine.
+//
+// Memory-ordering contract relied upon below: vector memory operations of ONE wavefront are
+// performed in program order (LLVM AMDGPU memory model, wavefront scope needs no s_waitcnt and
+// no cache maintenance: one wave lives on one CU and uses that CU's L1).  A load issued after a
+// store of the same wave therefore observes the stored bytes, also when another lane wrote them.
+// That is what makes "store literal bytes, then gather match bytes that may overlap them"
+// correct without fences; tests/test_gpu_lz_decode.py has adversarial streams for it.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mem_prims.h"
+
+namespace bamd {
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+__device__ __forceinline__ uint4 ld16u(const gu8* p) { return g_ld16(p); }
+__device__ __forceinline__ void st16u(gu8* p, const uint4& v) { g_st16(p, v); }
+__device__ __forceinline__ uint32_t ld4u(const gu8* p) { return g_ld4(p); }
+
+// ---- copy of n bytes between disjoint buffers (literals, raw streams): 1 KiB per wave step ----
+__device__ __forceinline__ void wave_copy_disjoint(gu8* dst, const gu8* src, uint32_t n, int lane) {
+  uint32_t done = 0;
+  while (n - done >= 1024) {
+    st16u(dst + done + 16 * lane, ld16u(src + done + 16 * lane));
+    done += 1024;
+  }
+  uint32_t rem = n - done;
+  if (rem >= 16) {
+    uint32_t n16 = rem >> 4;
+    if ((uint32_t)lane < n16) st16u(dst + done + 16 * lane, ld16u(src + done + 16 * lane));
+    done += n16 << 4;
+    rem -= n16 << 4;
+  }
+  if ((uint32_t)lane < rem) dst[done + lane] = src[done + lane];
+}
+
+// ---- LZ match: out[pos + k] = out[pos - off + k], k = 0..len-1, byte-wise forward semantics ----
+// (blosc/fastcopy.c:530-639 copy_match, lz4.c:2387-2434).  `off` >= 1, pos - off >= 0 checked by
+// the caller.  All arguments wave-uniform.
+__device__ __forceinline__ void wave_match_copy(gu8* out, uint32_t pos, uint32_t off, uint32_t len, int lane) {
+  uint32_t done = 0;
+  uint32_t off_e = off;  // effective distance: a multiple of `off` not exceeding the periodic history
+  if (off < 64 && off < len) {
+    // Short period: the match replicates the `off` bytes before pos.  Fetch them once, spread them
+    // over the lanes (lane i holds pattern byte i mod off) and store G = off * floor(64/off) bytes
+    // per step with no further loads.
+    uint32_t pat = ((uint32_t)lane < off) ? out[pos - off + lane] : 0u;
+    const uint32_t M = 65536u / off + 1u;                 // floor(i/off) == (i*M)>>16 for i < 64
+    const uint32_t reps = (64u * M) >> 16;                 // floor(64/off)
+    const uint32_t G = reps * off;
+    const uint32_t i_mod = (uint32_t)lane - (((uint32_t)lane * M) >> 16) * off;
+    const uint32_t val = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(i_mod << 2), (int)pat);
+    const uint32_t head = len < 2048u ? len : 1024u;       // long runs switch to 16-byte copies
+    while (done < head) {
+      uint32_t chunk = head - done < G ? head - done : G;
+      if ((uint32_t)lane < chunk) out[pos + done + lane] = (uint8_t)val;
+      done += chunk;
+    }
+    if (done >= len) return;
+    off_e = G;
+    // `done` may not be a multiple of G when head was cut; any multiple of `off` <= off+done is valid
+    // only if the copied prefix really is periodic up to `done`, which it is.  Restart from G.
+  }
+  while (done < len) {
+    uint32_t rem = len - done;
+    while (off_e < 1024u && 2u * off_e <= off + done) off_e *= 2u;  // history grew: lengthen the stride
+    uint32_t chunk = rem < 1024u ? rem : 1024u;
+    if (chunk > off_e) chunk = off_e;
+    if (chunk >= 16u) {
+      uint32_t n16 = chunk >> 4;
+      if ((uint32_t)lane < n16) {
+        gu8* d = out + pos + done + 16 * lane;
+        st16u(d, ld16u(d - off_e));
+      }
+      done += n16 << 4;
+    } else {
+      if ((uint32_t)lane < chunk) {
+        gu8* d = out + pos + done + lane;
+        *d = *(d - off_e);
+      }
+      done += chunk;
+    }
+  }
+}
+
+// ---- 512-byte register window over the compressed stream ------------------------------------
+// lane l holds stream bytes [base + 4l, +4) in `lo` and [base + 256 + 4l, +4) in `hi`.
+// Bytes beyond the stream end read as 0 and are never consumed (every consumer bounds-checks
+// against in_size first).
+struct Window {
+  const gu8* in;
+  uint32_t in_size;
+  uint32_t base;
+  uint32_t lo, hi;
+  int lane;
+
+  __device__ __forceinline__ uint32_t fetch(uint32_t pos) const {
+    uint32_t p = pos + 4u * (uint32_t)lane;
+    uint32_t v = 0;
+    if (p + 4u <= in_size) v = ld4u(in + p);
+    else if (p < in_size) {
+      if (in_size >= 4u) v = ld4u(in + in_size - 4u) >> (8u * (p + 4u - in_size));   // last dword, shifted down
+      else for (uint32_t b = 0; p + b < in_size; b++) v |= (uint32_t)in[p + b] << (8u * b);
+    }
+    return v;
+  }
+  __device__ __forceinline__ void init(const gu8* in_, uint32_t n, int lane_) {
+    in = in_; in_size = n; lane = lane_; base = 0;
+    lo = fetch(0); hi = fetch(256);
+  }
+  // make [p, p+8) readable: base <= p and p + 8 <= base + 512
+  __device__ __forceinline__ void seek(uint32_t p) {
+    if (p - base < 256u) return;
+    if (p - base < 504u) { lo = hi; base += 256u; hi = fetch(base + 256u); return; }
+    base = p & ~3u; lo = fetch(base); hi = fetch(base + 256u);
+  }
+  // four stream bytes starting at p (little endian); needs seek(p) or an earlier seek within 248 bytes
+  __device__ __forceinline__ uint32_t peek32(uint32_t p) const {
+    uint32_t r = p - base;
+    uint32_t i0 = r >> 2, i1 = i0 + 1u;
+    uint32_t a = (i0 < 64u) ? (uint32_t)__builtin_amdgcn_readlane((int)lo, (int)i0)
+                            : (uint32_t)__builtin_amdgcn_readlane((int)hi, (int)(i0 - 64u));
+    uint32_t b = (i1 < 64u) ? (uint32_t)__builtin_amdgcn_readlane((int)lo, (int)i1)
+                            : (uint32_t)__builtin_amdgcn_readlane((int)hi, (int)((i1 - 64u) & 63u));
+    uint64_t w = ((uint64_t)b << 32) | a;
+    return (uint32_t)(w >> ((r & 3u) * 8u));
+  }
+  __device__ __forceinline__ uint32_t byte_at(uint32_t p) { seek(p); return peek32(p) & 0xffu; }
+
+  // lane i < n gets stream byte (p + i) out of the window.  Requires base <= p, p + n <= base + 512, n <= 64.
+  __device__ __forceinline__ uint32_t gather_bytes(uint32_t p) const {
+    uint32_t r = p - base + (uint32_t)lane;
+    uint32_t d = r >> 2;
+    uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d & 63u) << 2), (int)lo);
+    uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d & 63u) << 2), (int)hi);
+    uint32_t v = (d < 64u) ? a : b;
+    return (v >> ((r & 3u) * 8u)) & 0xffu;
+  }
+};
+
+}  // namespace bamd

@@ -1,0 +1,99 @@
+"""Shared fixtures.  GPU tests are marked `gpu`; everything else runs on a CPU-only box.
+
+Layers under test
+  oracle   oracle/liboracle.so        plain-C restatement of the reference (checker)
+  ref      oracle/_ref/libblosc_ref.so  the real reference, when built (dev container / prebuilt)
+  lib      c-blosc_amd/libblosc_amd.so  the product (HIP, gfx950) through its C ABI
+"""
+import ctypes as C
+import importlib.util
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _load_pkg():
+    spec = importlib.util.spec_from_file_location("c_blosc_amd", os.path.join(ROOT, "c-blosc_amd", "__init__.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["c_blosc_amd"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _ensure_oracle():
+    so = os.path.join(ROOT, "oracle", "liboracle.so")
+    src = os.path.join(ROOT, "oracle", "blosc_oracle.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def _ensure_product():
+    so = os.path.join(ROOT, "c-blosc_amd", "libblosc_amd.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "c-blosc_amd")], stdout=subprocess.DEVNULL)
+    return so
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    O = C.CDLL(_ensure_oracle())
+    sz, i, vp = C.c_size_t, C.c_int, C.c_void_p
+    O.orc_compress.argtypes = [i, i, sz, sz, vp, vp, sz, i, sz, i]
+    O.orc_decompress.argtypes = [vp, vp, sz]
+    O.orc_getitem.argtypes = [vp, i, i, vp]
+    for f in (O.orc_shuffle, O.orc_unshuffle):
+        f.argtypes = [sz, sz, vp, vp]; f.restype = None
+    for f in (O.orc_bitshuffle, O.orc_bitunshuffle):
+        f.argtypes = [sz, sz, vp, vp]
+    O.orc_lz4_compress.argtypes = [vp, i, vp, i, i]
+    O.orc_lz4_decompress.argtypes = [vp, i, vp, i]
+    O.orc_blosclz_compress.argtypes = [i, vp, i, vp, i, i]
+    O.orc_blosclz_decompress.argtypes = [vp, i, vp, i]
+    O.orc_compute_blocksize.argtypes = [i, i, i, i, i, i]
+    O.orc_split_block.argtypes = [i, i, i, i]
+    return O
+
+
+@pytest.fixture(scope="session")
+def ref():
+    """The real reference, or None when oracle/_ref has not been built."""
+    so = os.path.join(ROOT, "oracle", "_ref", "libblosc_ref.so")
+    if not os.path.exists(so):
+        return None
+    R = C.CDLL(so)
+    sz, i, vp = C.c_size_t, C.c_int, C.c_void_p
+    R.blosc_compress_ctx.argtypes = [i, i, sz, sz, vp, vp, sz, C.c_char_p, sz, i]
+    R.blosc_decompress_ctx.argtypes = [vp, vp, sz, i]
+    R.blosc_decompress.argtypes = [vp, vp, sz]
+    R.blosc_getitem.argtypes = [vp, i, i, vp]
+    R.LZ4_decompress_safe.argtypes = [vp, vp, i, i]
+    R.LZ4_compress_fast.argtypes = [vp, vp, i, i, i]
+    R.blosclz_compress.argtypes = [i, vp, i, vp, i, i]
+    R.blosclz_decompress.argtypes = [vp, i, vp, i]
+    return R
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    _ensure_product()
+    return _load_pkg()
+
+
+@pytest.fixture(scope="session")
+def lib(pkg):
+    return pkg.load()
+
+
+def has_gpu():
+    return os.path.exists("/dev/kfd") and os.path.exists("/dev/dri")

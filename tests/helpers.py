@@ -1,0 +1,97 @@
+"""Data sets and small wrappers shared by the tests (SURVEY.md §8d inputs)."""
+import ctypes as C
+
+import numpy as np
+
+CODECS = {"blosclz": 0, "lz4": 1}
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def bench19(nbytes):
+    """bench/bench.c:141-170 generator: int32 v[i] = ((i<<26)^(i<<18)^(i<<11)^(i<<3)^i) & (2^19-1)."""
+    i = np.arange((nbytes + 3) // 4, dtype=np.int64)
+    v = ((i << 26) ^ (i << 18) ^ (i << 11) ^ (i << 3) ^ i) & ((1 << 19) - 1)
+    return v.astype("<i4").view(np.uint8)[:nbytes].copy()
+
+
+def linspace_f64(nbytes):
+    n = (nbytes + 7) // 8
+    return np.linspace(0, 1, n).astype("<f8").view(np.uint8)[:nbytes].copy()
+
+
+def randwalk_f64(nbytes, seed=42):
+    n = (nbytes + 7) // 8
+    return np.cumsum(np.random.default_rng(seed).standard_normal(n)).astype("<f8").view(np.uint8)[:nbytes].copy()
+
+
+def randbytes(nbytes, seed=1234):
+    return np.frombuffer(np.random.default_rng(seed).bytes(nbytes), np.uint8).copy()
+
+
+def arange_i32(nbytes):
+    return np.arange((nbytes + 3) // 4, dtype="<i4").view(np.uint8)[:nbytes].copy()
+
+
+def smallints_i32(nbytes, seed=7):
+    return np.random.default_rng(seed).integers(0, 1 << 12, (nbytes + 3) // 4).astype("<i4").view(np.uint8)[:nbytes].copy()
+
+
+DATASETS = {
+    "bench19": bench19, "linspace": linspace_f64, "randwalk": randwalk_f64, "random": randbytes,
+    "arange": arange_i32, "smallints": smallints_i32,
+    "zeros": lambda n: np.zeros(n, np.uint8),
+}
+
+
+def orc_compress(O, data, typesize, clevel=5, shuffle=1, codec="lz4", blocksize=0, destsize=None, splitmode=4):
+    data = np.ascontiguousarray(data)
+    cap = data.size + 16 if destsize is None else destsize
+    out = np.zeros(max(cap, 16) + 64, np.uint8)
+    r = O.orc_compress(clevel, shuffle, typesize, data.size, ptr(data), ptr(out), cap, CODECS[codec], blocksize, splitmode)
+    return r, (out[:r].copy() if r > 0 else None)
+
+
+def orc_decompress(O, chunk, nbytes):
+    chunk = np.ascontiguousarray(chunk)
+    out = np.zeros(max(nbytes, 1), np.uint8)
+    r = O.orc_decompress(ptr(chunk), ptr(out), nbytes)
+    return r, out[:max(r, 0)]
+
+
+def ref_compress(R, data, typesize, clevel=5, shuffle=1, codec=b"lz4", blocksize=0, nthreads=1):
+    data = np.ascontiguousarray(data)
+    out = np.zeros(data.size + 16 + 64, np.uint8)
+    r = R.blosc_compress_ctx(clevel, shuffle, typesize, data.size, ptr(data), ptr(out), data.size + 16, codec, blocksize, nthreads)
+    return r, (out[:r].copy() if r > 0 else None)
+
+
+def ref_decompress(R, chunk, nbytes):
+    chunk = np.ascontiguousarray(chunk)
+    out = np.zeros(max(nbytes, 1), np.uint8)
+    r = R.blosc_decompress_ctx(ptr(chunk), ptr(out), nbytes, 1)
+    return r, out[:max(r, 0)]
+
+
+def header(chunk):
+    c = np.asarray(chunk[:16], np.uint8)
+    return dict(version=int(c[0]), versionlz=int(c[1]), flags=int(c[2]), typesize=int(c[3]),
+                nbytes=int(c[4:8].view("<i4")[0]), blocksize=int(c[8:12].view("<i4")[0]), cbytes=int(c[12:16].view("<i4")[0]))
+
+
+def wrap_stream_as_chunk(stream, nbytes, fmt):
+    """A one-block, unsplit chunk around ONE codec stream (for hand-built LZ streams).
+    fmt: 0 BloscLZ, 1 LZ4.  typesize 1, no filter, dont_split set."""
+    stream = np.asarray(stream, np.uint8)
+    total = 16 + 4 + 4 + stream.size
+    c = np.zeros(total, np.uint8)
+    c[0] = 2; c[1] = 1; c[2] = 0x10 | (fmt << 5); c[3] = 1
+    c[4:8] = np.array([nbytes], "<i4").view(np.uint8)
+    c[8:12] = np.array([nbytes], "<i4").view(np.uint8)
+    c[12:16] = np.array([total], "<i4").view(np.uint8)
+    c[16:20] = np.array([20], "<i4").view(np.uint8)
+    c[20:24] = np.array([stream.size], "<i4").view(np.uint8)
+    c[24:] = stream
+    return c

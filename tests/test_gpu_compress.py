@@ -1,0 +1,125 @@
+"""GPU compress path: chunks are valid c-blosc chunks — the oracle (pinned to the reference) and,
+when present, the real reference decode them bit-exactly; headers equal the reference's for the
+same parameters; return codes follow tests/test_maxout.c and tests/test_compressor.c."""
+import numpy as np
+import pytest
+
+from helpers import DATASETS, orc_compress, orc_decompress, ref_decompress, header, ptr
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_roundtrip(pkg, oracle, ref, data, T, clevel, shuffle, cname, blocksize=0):
+    r, chunk = pkg.compress(data, T, clevel, shuffle, cname, blocksize)
+    assert r > 0, (r, T, data.size, clevel, shuffle, cname)
+    assert r <= data.size + 16
+    h = header(chunk)
+    assert h["cbytes"] == r and h["nbytes"] == data.size
+    r2, out = orc_decompress(oracle, chunk, data.size)
+    assert r2 == data.size and np.array_equal(out, data), ("oracle cannot read GPU chunk", T, data.size, clevel, shuffle, cname, r2)
+    if ref is not None:
+        r3, out3 = ref_decompress(ref, chunk, data.size)
+        assert r3 == data.size and np.array_equal(out3, data), ("stock c-blosc cannot read GPU chunk", T, data.size, cname, r3)
+    r4, out4 = pkg.decompress(chunk, data.size)
+    assert r4 == data.size and np.array_equal(out4, data)
+    return r, chunk
+
+
+@pytest.mark.parametrize("cname", [b"lz4", b"blosclz", b"lz4hc"])
+@pytest.mark.parametrize("shuffle", [0, 1, 2])
+def test_roundtrip_grid(pkg, oracle, ref, cname, shuffle):
+    """T x N grid of tests/test_compress_roundtrip.csv (+ leftovers), clevels {1,5,9}."""
+    for T in [1, 2, 3, 4, 7, 8, 16, 17, 32]:
+        for n in [128, 129, 1000, 4096, 32768, 65536 + 17, 300001, 1 << 20, (1 << 21) + 5, 641091]:
+            for dname in ["bench19", "randwalk", "zeros", "smallints"]:
+                if n > 400000 and T not in (4, 8) and dname != "bench19":
+                    continue
+                data = DATASETS[dname](n)
+                for clevel in ([1, 5, 9] if n <= 300001 else [5]):
+                    _check_roundtrip(pkg, oracle, ref, data, T, clevel, shuffle, cname)
+
+
+def test_headers_equal_reference_policy(pkg, oracle):
+    """Same (clevel, typesize, nbytes, codec) -> same version/flags/typesize/nbytes/blocksize bytes as
+    the reference writes (blosc.c:1148-1247, compute_blocksize :962-1060)."""
+    for cname, codec in [(b"lz4", "lz4"), (b"blosclz", "blosclz")]:
+        for T in [1, 4, 8, 16, 32]:
+            for n in [1000, 40000, 300001, 1 << 20, (1 << 22) + 12]:
+                for clevel in range(1, 10):
+                    data = DATASETS["bench19"](n)
+                    r, chunk = pkg.compress(data, T, clevel, 1, cname)
+                    ro, ochunk = orc_compress(oracle, data, T, clevel, 1, codec)
+                    assert r > 0 and ro > 0
+                    assert np.array_equal(chunk[:12], ochunk[:12]), (cname, T, n, clevel, header(chunk), header(ochunk))
+
+
+def test_ratio_close_to_reference(pkg, oracle):
+    """Encoders differ, ratios should not collapse: within 25% of the reference algorithm's on the
+    bench19 / float64 inputs.  Printed for the record."""
+    for cname, codec in [(b"lz4", "lz4"), (b"blosclz", "blosclz")]:
+        for dname, T, shuffle in [("bench19", 8, 1), ("bench19", 4, 2), ("linspace", 8, 1), ("randwalk", 8, 1), ("arange", 4, 1)]:
+            data = DATASETS[dname](1 << 22)
+            r, _ = pkg.compress(data, T, 5, shuffle, cname)
+            ro, _ = orc_compress(oracle, data, T, 5, shuffle, codec)
+            print(f"ratio {cname.decode():8s} {dname:9s} T={T} shuffle={shuffle}: gpu {data.size / r:8.2f}  reference {data.size / ro:8.2f}")
+            assert r <= ro * 1.25 + 64, (cname, dname, r, ro)
+
+
+def test_return_codes_maxout(pkg, lib):
+    """tests/test_maxout.c:26-144 and tests/test_compressor.c:232-289."""
+    data = DATASETS["random"](1000)
+    out = np.zeros(2000, np.uint8)
+    # destsize = n + 15 on incompressible input -> 0 ; n + 16 -> n + 16 ; dest < 16 -> 0
+    assert lib.blosc_compress_ctx(5, 1, 1, 1000, ptr(data), ptr(out), 1000 + 15, b"lz4", 0, 1) == 0
+    assert lib.blosc_compress_ctx(5, 1, 1, 1000, ptr(data), ptr(out), 1000 + 16, b"lz4", 0, 1) == 1016
+    assert lib.blosc_compress_ctx(5, 1, 1, 1000, ptr(data), ptr(out), 15, b"lz4", 0, 1) == 0
+    assert lib.blosc_compress_ctx(5, 1, 1, 1000, ptr(data), ptr(out), 2000, b"lz4", 0, 1) == 1016
+    # invalid parameters -> -10 ; unknown / not-built codec -> -5
+    assert lib.blosc_compress_ctx(10, 1, 4, 1000, ptr(data), ptr(out), 2000, b"lz4", 0, 1) == -10
+    assert lib.blosc_compress_ctx(5, 3, 4, 1000, ptr(data), ptr(out), 2000, b"lz4", 0, 1) == -10
+    assert lib.blosc_compress_ctx(5, 1, 0, 1000, ptr(data), ptr(out), 2000, b"lz4", 0, 1) == -10
+    assert lib.blosc_compress_ctx(5, 1, 4, 1000, ptr(data), ptr(out), 2000, b"zstd", 0, 1) == -5
+    # empty buffer -> 16 ; 1..15 byte buffers -> n + 16
+    assert lib.blosc_compress_ctx(5, 1, 4, 0, ptr(data), ptr(out), 2000, b"blosclz", 0, 1) == 16
+    for n in range(1, 16):
+        assert lib.blosc_compress_ctx(5, 1, 4, n, ptr(data), ptr(out), 2000, b"blosclz", 0, 1) == n + 16
+    # typesize > 255 is treated as 1 (blosc.c:1117-1120)
+    d2 = DATASETS["bench19"](100000); o2 = np.zeros(d2.size + 16, np.uint8)
+    r = lib.blosc_compress_ctx(5, 1, 300, d2.size, ptr(d2), ptr(o2), o2.size, b"lz4", 0, 1)
+    assert r > 0 and o2[3] == 1
+
+
+def test_global_api_and_env(pkg, lib, oracle, monkeypatch):
+    """blosc_compress + globals + environment overrides (tests/test_compressor.c:26-229)."""
+    data = DATASETS["arange"](8 * 100000)
+    out = np.zeros(data.size + 16, np.uint8)
+    lib.blosc_init()
+    assert lib.blosc_set_compressor(b"lz4") == 1
+    r1 = lib.blosc_compress(5, 1, 8, data.size, ptr(data), ptr(out), out.size)
+    assert r1 > 0 and (out[2] >> 5) == 1
+    monkeypatch.setenv("BLOSC_COMPRESSOR", "blosclz")
+    r2 = lib.blosc_compress(5, 1, 8, data.size, ptr(data), ptr(out), out.size)
+    assert r2 > 0 and (out[2] >> 5) == 0
+    monkeypatch.delenv("BLOSC_COMPRESSOR")
+    monkeypatch.setenv("BLOSC_SHUFFLE", "NOSHUFFLE")
+    r3 = lib.blosc_compress(5, 1, 8, data.size, ptr(data), ptr(out), out.size)
+    assert r3 > r2 and (out[2] & 1) == 0          # shuffle helps on this ramp
+    monkeypatch.delenv("BLOSC_SHUFFLE")
+    monkeypatch.setenv("BLOSC_CLEVEL", "0")
+    assert lib.blosc_compress(5, 1, 8, data.size, ptr(data), ptr(out), out.size) == data.size + 16
+    monkeypatch.delenv("BLOSC_CLEVEL")
+    monkeypatch.setenv("BLOSC_TYPESIZE", "4")
+    assert lib.blosc_compress(5, 1, 8, data.size, ptr(data), ptr(out), out.size) > 0 and out[3] == 4
+    monkeypatch.delenv("BLOSC_TYPESIZE")
+    monkeypatch.setenv("BLOSC_SPLITMODE", "NEVER")
+    assert lib.blosc_compress(5, 1, 8, data.size, ptr(data), ptr(out), out.size) > 0 and (out[2] & 0x10)
+    monkeypatch.delenv("BLOSC_SPLITMODE")
+    lib.blosc_set_splitmode(4)
+    lib.blosc_set_blocksize(65536)
+    assert lib.blosc_compress(5, 1, 8, data.size, ptr(data), ptr(out), out.size) > 0
+    assert int(out[8:12].view("<i4")[0]) == 65536
+    lib.blosc_set_blocksize(0)
+    back = np.zeros(data.size, np.uint8)
+    assert lib.blosc_decompress(ptr(out), ptr(back), back.size) == data.size and np.array_equal(back, data)
+    lib.blosc_set_compressor(b"blosclz")
+    lib.blosc_destroy()

@@ -1,0 +1,189 @@
+"""GPU decompress path (plan -> LZ decode -> unshuffle) is bit-exact on chunks written by the
+reference algorithm (oracle, pinned to the real reference) and on the reference's golden vectors."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from helpers import DATASETS, orc_compress, header, ptr, wrap_stream_as_chunk
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("fname", sorted(os.path.basename(f) for f in glob.glob(os.path.join(GOLDEN, "compat", "*.cdata"))))
+def test_compat_golden_vectors(pkg, fname):
+    """compat/*.cdata (blosc 1.3.0 ... 1.18.0 writers): BloscLZ / LZ4 / LZ4HC decode to arange(1e6, int32);
+    Snappy / Zlib / Zstd give -5 (not built in), as stock does for Snappy (compat/filegen.c:97-103)."""
+    chunk = np.fromfile(os.path.join(GOLDEN, "compat", fname), np.uint8)
+    r, out = pkg.decompress(chunk, 4000000)
+    if any(k in fname for k in ("snappy", "zlib", "zstd")):
+        assert r == -5
+    else:
+        assert r == 4000000
+        assert np.array_equal(out.view("<i4"), np.arange(10**6, dtype="<i4"))
+
+
+@pytest.mark.parametrize("codec", ["lz4", "blosclz"])
+@pytest.mark.parametrize("shuffle", [0, 1, 2])
+def test_decode_oracle_chunks(pkg, oracle, codec, shuffle):
+    rng_sizes = [0, 1, 15, 127, 128, 129, 1000, 4096, 32768, 65536 + 17, 300001, (1 << 20), (1 << 21) + 5, 641091]
+    bad = []
+    for T in [1, 2, 3, 4, 7, 8, 16, 17, 32]:
+        for n in rng_sizes:
+            for dname in ["bench19", "randwalk", "zeros", "smallints", "random"]:
+                if n > 400000 and dname in ("random", "zeros") and T not in (4, 8):
+                    continue
+                data = DATASETS[dname](n)
+                for clevel in ([1, 5, 9] if n < 400000 else [5]):
+                    r, chunk = orc_compress(oracle, data, T, clevel, shuffle, codec)
+                    assert r > 0
+                    r2, out = pkg.decompress(chunk, n)
+                    if r2 != n or not np.array_equal(out, data):
+                        bad.append((T, n, dname, clevel, r2))
+    assert not bad, bad[:10]
+
+
+def test_forced_blocksizes_and_splitmodes(pkg, oracle):
+    bad = []
+    for T in [4, 8, 16]:
+        for bs in [128, 1000, 4096 + T, 65536, 1 << 18]:
+            for sm in [1, 2, 3, 4]:
+                data = DATASETS["bench19"](500000)
+                r, chunk = orc_compress(oracle, data, T, 5, 1, "lz4", blocksize=bs, splitmode=sm)
+                r2, out = pkg.decompress(chunk, data.size)
+                if r2 != data.size or not np.array_equal(out, data):
+                    bad.append((T, bs, sm, r2))
+    assert not bad, bad
+
+
+def test_memcpyed_and_empty(pkg, oracle):
+    for n in [0, 1, 100, 127]:
+        data = DATASETS["random"](n)
+        r, chunk = orc_compress(oracle, data, 4, 5, 1, "lz4")
+        assert r == n + 16
+        r2, out = pkg.decompress(chunk, n)
+        assert r2 == n and np.array_equal(out, data)
+    data = DATASETS["random"](1 << 20)   # incompressible -> MEMCPYED fallback chunk
+    r, chunk = orc_compress(oracle, data, 8, 5, 1, "lz4")
+    assert header(chunk)["flags"] & 2
+    r2, out = pkg.decompress(chunk, data.size)
+    assert r2 == data.size and np.array_equal(out, data)
+    data = DATASETS["bench19"](1 << 20)  # clevel 0
+    r, chunk = orc_compress(oracle, data, 8, 0, 1, "lz4")
+    r2, out = pkg.decompress(chunk, data.size)
+    assert r2 == data.size and np.array_equal(out, data)
+
+
+def test_error_returns_match_oracle(pkg, oracle, lib):
+    """Header / chain validation (blosc.c:1463-1508, :762-770): same negative codes as the oracle."""
+    data = DATASETS["bench19"](300000)
+    _, good = orc_compress(oracle, data, 4, 5, 1, "lz4")
+    cases = []
+    c = good.copy(); c[0] = 3; cases.append(("version", c))
+    c = good.copy(); c[1] = 2; cases.append(("versionlz", c))
+    c = good.copy(); c[2] |= 0x08; cases.append(("reserved flag", c))
+    c = good.copy(); c[2] = (c[2] & 0x1f) | (3 << 5); cases.append(("zlib format", c))
+    c = good.copy(); c[8:12] = 0; cases.append(("blocksize 0", c))
+    c = good.copy(); c[12:16] = np.array([20], "<i4").view(np.uint8); cases.append(("cbytes too small", c))
+    c = good.copy(); c[16:20] = np.array([10**9], "<i4").view(np.uint8); cases.append(("bstart oob", c))
+    c = good.copy(); c[16:20] = np.array([-5], "<i4").view(np.uint8); cases.append(("bstart negative", c))
+    hb = header(good); first = int(good[16:20].view("<i4")[0])
+    c = good.copy(); c[first:first + 4] = np.array([10**8], "<i4").view(np.uint8); cases.append(("csize oob", c))
+    for name, ch in cases:
+        want = oracle.orc_decompress(ptr(ch), ptr(np.zeros(data.size, np.uint8)), data.size)
+        got, _ = pkg.decompress(ch, data.size)
+        assert got == want and got < 0, (name, got, want)
+    # destination too small
+    got = lib.blosc_decompress_ctx(ptr(good), ptr(np.zeros(data.size, np.uint8)), data.size - 1, 1)
+    assert got == -1
+
+
+def test_corrupt_payload_never_crashes(pkg, oracle):
+    """Memory-safety promise (blosc.h:258-263): random damage gives an error or garbage, never a fault,
+    and an intact chunk still decodes afterwards."""
+    rng = np.random.default_rng(3)
+    data = DATASETS["bench19"](1 << 20)
+    for codec in ["lz4", "blosclz"]:
+        _, good = orc_compress(oracle, data, 8, 5, 1, codec)
+        first = 16 + 4 * ((data.size + header(good)["blocksize"] - 1) // header(good)["blocksize"])
+        for trial in range(60):
+            c = good.copy()
+            k = rng.integers(1, 20)
+            pos = rng.integers(first, c.size, k)
+            c[pos] = rng.integers(0, 256, k, dtype=np.uint8)
+            r, out = pkg.decompress(c, data.size)
+            assert r == data.size or r < 0
+        r, out = pkg.decompress(good, data.size)
+        assert r == data.size and np.array_equal(out, data)
+
+
+def _lz4_seq(lit, off, mlen):
+    """one LZ4 sequence (token, ext, literals, offset, ext)"""
+    out = bytearray()
+    ll = len(lit); mc = mlen - 4
+    out.append((min(ll, 15) << 4) | min(mc, 15))
+    if ll >= 15:
+        v = ll - 15
+        while v >= 255: out.append(255); v -= 255
+        out.append(v)
+    out += bytes(lit)
+    out += bytes([off & 255, off >> 8])
+    if mc >= 15:
+        v = mc - 15
+        while v >= 255: out.append(255); v -= 255
+        out.append(v)
+    return out
+
+
+def _lz4_tail(lit):
+    out = bytearray()
+    ll = len(lit)
+    out.append(min(ll, 15) << 4)
+    if ll >= 15:
+        v = ll - 15
+        while v >= 255: out.append(255); v -= 255
+        out.append(v)
+    out += bytes(lit)
+    return out
+
+
+def test_handbuilt_lz4_streams(pkg, oracle):
+    """Adversarial LZ4 blocks: overlapping matches at every small offset and at the copy-path
+    boundaries (63/64/65, 1023/1024/1025), matches that read the literals of their own sequence,
+    long literal runs, long runs — the cases the wave-cooperative copy logic branches on."""
+    rng = np.random.default_rng(11)
+    streams = []
+    for off in list(range(1, 70)) + [127, 128, 129, 255, 256, 257, 1000, 1023, 1024, 1025, 2047, 2048, 4099]:
+        for mlen in [4, 5, 7, 8, 15, 16, 18, 19, 31, 63, 64, 65, 100, 255, 256, 300, 1023, 1024, 1025, 2047, 2048, 2049, 5000, 70000]:
+            s = bytearray()
+            pre = rng.integers(0, 256, max(off, 16) + 3, dtype=np.uint8).tobytes()
+            s += _lz4_seq(pre, off, mlen)
+            # a second sequence whose match source overlaps the literals it has just emitted
+            lit2 = rng.integers(0, 256, 5, dtype=np.uint8).tobytes()
+            s += _lz4_seq(lit2, 3, 9)
+            s += _lz4_seq(b"", 1, 40)
+            s += _lz4_tail(rng.integers(0, 256, 12, dtype=np.uint8).tobytes())
+            streams.append(bytes(s))
+    # long literal runs around the register-window limits
+    for ll in [0, 1, 14, 15, 16, 63, 64, 65, 200, 255, 256, 270, 300, 500, 511, 512, 513, 1024, 5000, 70000]:
+        s = bytearray()
+        s += _lz4_seq(rng.integers(0, 256, ll + 4, dtype=np.uint8).tobytes(), 4, 20)
+        s += _lz4_seq(rng.integers(0, 256, ll, dtype=np.uint8).tobytes(), 7, 4)
+        s += _lz4_tail(rng.integers(0, 256, ll + 13, dtype=np.uint8).tobytes())
+        streams.append(bytes(s))
+    bad = []
+    for i, s in enumerate(streams):
+        s = np.frombuffer(s, np.uint8)
+        cap = 1 << 20
+        tmp = np.zeros(cap, np.uint8)
+        n = oracle.orc_lz4_decompress(ptr(s), s.size, ptr(tmp), cap)
+        # exact-size decode (blosc requires the codec to produce exactly neblock bytes)
+        want = np.zeros(n, np.uint8)
+        assert oracle.orc_lz4_decompress(ptr(s), s.size, ptr(want), n) == n
+        chunk = wrap_stream_as_chunk(s, n, 1)
+        r, out = pkg.decompress(chunk, n)
+        if r != n or not np.array_equal(out, want):
+            bad.append((i, r, n))
+    assert not bad, bad[:20]
