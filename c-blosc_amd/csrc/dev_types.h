@@ -47,6 +47,10 @@ struct BlockDesc {
   int32_t blk;          // block index inside the chunk
   int32_t first_stream; // global stream index of split 0
   int32_t nstreams;     // 1 or typesize
+  int32_t bsize;        // bytes in this block: blocksize, or `leftover` for a short last block.  Computed
+                        // on the host: selecting between two ChunkDesc fields on the device tripped an
+                        // AMDGPU backend miscompile (ROCm 7.2, the `leftover > 0` test was dropped).
+  int32_t pad_;
 };
 
 struct StreamDesc {

@@ -208,6 +208,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
       const bool last = (j == nblocks - 1) && leftover > 0;
       b.nstreams = memcpyed ? 0 : ((split && !last) ? T : 1);
       const int32_t bsize = last ? leftover : bs;
+      b.bsize = bsize; b.pad_ = 0;
       const int32_t neblock = b.nstreams ? bsize / b.nstreams : 0;
       for (int32_t s = 0; s < b.nstreams; s++) {
         StreamDesc sd;
@@ -318,6 +319,21 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   prof_collect(st);
   const int32_t* r = (const int32_t*)(P + p_results);
   for (int i = 0; i < n; i++) if (live[(size_t)i]) results[i] = r[i];
+  if (getenv("BLOSC_AMD_DEBUG")) {
+    std::vector<ChunkDesc> cd((size_t)n); std::vector<StreamDesc> sd(nstr ? nstr : 1); std::vector<int32_t> bo(nblk ? nblk : 1);
+    (void)hipMemcpy(cd.data(), d_chunks, sizeof(ChunkDesc) * (size_t)n, hipMemcpyDeviceToHost);
+    if (nstr) (void)hipMemcpy(sd.data(), d_streams, sizeof(StreamDesc) * nstr, hipMemcpyDeviceToHost);
+    if (nblk) (void)hipMemcpy(bo.data(), d_blkoff, sizeof(int32_t) * nblk, hipMemcpyDeviceToHost);
+    for (int i = 0; i < n && i < 4; i++) {
+      uint8_t a[32] = {0}, b2[48] = {0};
+      (void)hipMemcpy(a, cd[i].src, 32, hipMemcpyDeviceToHost); (void)hipMemcpy(b2, cd[i].dst, 48, hipMemcpyDeviceToHost);
+      fprintf(stderr, "[dbg] src:"); for (int k = 0; k < 32; k++) fprintf(stderr, " %d", a[k]);
+      fprintf(stderr, "\n[dbg] dst:"); for (int k = 0; k < 48; k++) fprintf(stderr, " %d", b2[k]); fprintf(stderr, "\n");
+    }
+    for (int i = 0; i < n && i < 4; i++)
+      fprintf(stderr, "[dbg] chunk %d mode=%u res=%d nblocks=%d nbytes=%d max=%d src=%p dst=%p | blk_off0=%d | s0.result=%d in=%p insize=%d\n", i, cd[i].mode, r[i],
+              cd[i].nblocks, cd[i].nbytes, cd[i].cbytes, (void*)cd[i].src, (void*)cd[i].dst, nblk ? bo[0] : -1, nstr ? sd[0].result : -1, nstr ? (void*)sd[0].in : nullptr, nstr ? sd[0].in_size : -1);
+  }
   if (!device_ptrs) {
     for (int i = 0; i < n; i++) {
       if (!live[(size_t)i] || results[i] <= 0) continue;
@@ -400,6 +416,7 @@ static void add_decode_chunk(const Header& h, int fmt, int chunk_index, int32_t 
     b.chunk = chunk_index; b.blk = j; b.first_stream = (int32_t)nstreams;
     const bool last = (j == c.nblocks - 1) && c.leftover > 0;
     b.nstreams = (split && !last) ? T : 1;
+    b.bsize = last ? c.leftover : bs; b.pad_ = 0;
     nstreams += (size_t)b.nstreams;
     blocks.push_back(b);
   }
@@ -419,7 +436,9 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
     }
     {
       ProfScope ps(st, stream, "k_decode_streams");
-      hipLaunchKernelGGL(k_decode_streams, grid1(L.nstr, DEC_WAVES), dim3(64 * DEC_WAVES), 0, stream, L.d_streams, L.d_status, (int)L.nstr);
+      // Occupancy knob: unused dynamic LDS caps how many decoder waves share a CU (and its L2 slice).
+      static const int dec_lds = getenv("BLOSC_AMD_DEC_LDS") ? atoi(getenv("BLOSC_AMD_DEC_LDS")) : 0;
+      hipLaunchKernelGGL(k_decode_streams, grid1(L.nstr, DEC_WAVES), dim3(64 * DEC_WAVES), (size_t)dec_lds, stream, L.d_streams, L.d_status, (int)L.nstr);
     }
     if (L.any_shuf) {
       ProfScope ps(st, stream, "k_unshuffle");
@@ -664,7 +683,7 @@ int engine_filter(int kind, size_t typesize, size_t blocksize, const void* src, 
   // forward kernels read c.src and write c.filt; inverse kernels read c.filt and write c.dst
   if (fwd) { c.src = D + o_in; c.filt = D + o_out; c.dst = nullptr; }
   else { c.filt = D + o_in; c.dst = D + o_out; c.src = nullptr; }
-  BlockDesc b{0, 0, 0, 1};
+  BlockDesc b{0, 0, 0, 1, bs, 0};
   HIP_TRY(hipMemcpyAsync(D + o_chunk, &c, sizeof c, hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemcpyAsync(D + o_block, &b, sizeof b, hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemcpyAsync(D + o_in, src, blocksize, hipMemcpyHostToDevice, stream));

@@ -17,7 +17,8 @@
 
 namespace bamd {
 
-constexpr int DEC_WAVES = 4;  // wavefronts (= streams) per workgroup
+constexpr int DEC_WAVES = 1;  // one stream per workgroup: streams differ 1000x in sequence count, a
+                              // multi-wave workgroup would hold its slots until the slowest is done
 
 // ---------------------------------------------------------------------------------------------
 // plan: walk every block's csize chain once (blosc/blosc.c:760-771), emit StreamDesc entries
@@ -30,8 +31,7 @@ __global__ void k_decode_plan(const ChunkDesc* __restrict__ chunks, const BlockD
   if (g >= nblocks_total) return;
   const BlockDesc b = blocks[g];
   const ChunkDesc& c = chunks[b.chunk];
-  const bool last = (b.blk == c.nblocks - 1) && c.leftover > 0;
-  const int32_t bsize = last ? c.leftover : c.blocksize;
+  const int32_t bsize = b.bsize;
   const int32_t neblock = bsize / b.nstreams;
   uint8_t* out = ((c.mode & (CH_SHUFFLE | CH_BITSHUFFLE)) ? c.filt : c.dst) + (size_t)b.blk * c.blocksize;
   int32_t off = ld_i32(c.src + 16 + 4 * (size_t)b.blk);
@@ -195,8 +195,9 @@ __device__ int blosclz_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* 
 __global__ __launch_bounds__(64 * DEC_WAVES) void k_decode_streams(StreamDesc* __restrict__ streams,
                                                                    int32_t* __restrict__ status, int nstreams) {
   const int lane = threadIdx.x & 63;
-  const int sid = (int)uni((uint32_t)(blockIdx.x * DEC_WAVES + (threadIdx.x >> 6)));
-  if (sid >= nstreams) return;
+  static_assert(DEC_WAVES == 1, "xcd_spread assumes one stream per workgroup");
+  if ((int)blockIdx.x >= nstreams) return;
+  const int sid = (int)uni(xcd_spread(blockIdx.x, (uint32_t)nstreams));
   StreamDesc* sd = streams + sid;
   const gu8* in = as_global(sd->in);
   const int32_t csize = (int32_t)uni((uint32_t)sd->in_size);

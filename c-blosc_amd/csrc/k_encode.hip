@@ -12,10 +12,9 @@
 // blosclz_decompress, every chunk with stock blosc_decompress (tests/ check exactly that).
 //
 // Match finder (one wavefront per stream): the 64 lanes probe 64 consecutive positions at once
-// against a 4096-entry u16 hash table in LDS (LZ4's 4-byte multiplicative hash), plus the
-// power-of-two near distances a table updated once per 64 positions cannot see.  The lowest
-// lane with a verified match wins (greedy, like the reference), the match is extended backwards
-// and forwards 512 bytes per step with ballots, and the sequence is emitted by the whole wave.
+// against a 2048-entry u16 hash table in LDS (LZ4's 4-byte multiplicative hash) plus distance 1,
+// rank the candidates by exact match length (up to 20 bytes), extend the winner backwards and
+// forwards 512 bytes per step with ballots, and emit the sequence with the whole wave.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "dev_types.h"
@@ -23,8 +22,8 @@
 
 namespace bamd {
 
-constexpr int ENC_WAVES = 4;
-constexpr int ENC_HASH_BITS = 12;
+constexpr int ENC_WAVES = 1;       // one stream per workgroup: a slot frees up as soon as ITS stream is done
+constexpr int ENC_HASH_BITS = 11;   // 2048 x u16 = 4 KiB of LDS per wave -> 32 waves per CU
 constexpr int ENC_TAB = 1 << ENC_HASH_BITS;
 
 __device__ __forceinline__ uint32_t enc_hash(uint32_t seq) { return (seq * 2654435761u) >> (32 - ENC_HASH_BITS); }
@@ -148,7 +147,56 @@ __device__ __forceinline__ uint32_t blz_emit_match(gu8* dst, uint32_t op, uint32
 // ---------------------------------------------------------------------------------------------
 // one stream, one wave.  Returns the compressed size, or 0 when the stream must be stored raw
 // (does not fit in `cap`, too small, or — BloscLZ — below the reference's per-clevel ratio floor).
+//
+// Per step the wave looks at 64 consecutive positions p = ip + lane:
+//   round 1  each lane loads its own 20 bytes (+ the byte before) and probes the LDS hash table
+//   round 2  each lane loads 20 bytes at its candidate; exact match length up to 20 is known per lane,
+//            as is the run length against distance 1 (the one near distance the table cannot give)
+//   select   the lane with the largest (length - lane) wins: a long match a few bytes later beats a
+//            4-byte match now (tests/tools/enc_model.c: this ranking + the insertion rule below give
+//            ratios at or above LZ4_compress_fast's on the SURVEY §8d data with fewer sequences)
+//   insert   only lanes up to the winner enter the table — like the reference, nothing inside a match
+//            is inserted (lz4.c:1236-1242 inserts ip-2 only), which keeps the START of repeated runs
+//            findable
+//   round 3  backward + forward extension loads are issued together; then the sequence is emitted.
 // ---------------------------------------------------------------------------------------------
+constexpr uint32_t RANK_CAP = 20u;   // 4 verified + 16 ranked bytes
+
+struct Bytes20 { uint64_t a, b; uint32_t c; };
+
+// 20 bytes at src[pos..], zero beyond n (only the last step of a stream takes the slow branch)
+__device__ __forceinline__ Bytes20 load20(const gu8* src, uint32_t pos, uint32_t n) {
+  Bytes20 r;
+  if (pos + 20u <= n) { r.a = g_ld8(src + pos); r.b = g_ld8(src + pos + 8u); r.c = g_ld4(src + pos + 16u); }
+  else {
+    r.a = 0; r.b = 0; r.c = 0;
+    for (uint32_t k = 0; k < 20u && pos + k < n; k++) {
+      const uint64_t v = src[pos + k];
+      if (k < 8u) r.a |= v << (8u * k); else if (k < 16u) r.b |= v << (8u * (k - 8u)); else r.c |= (uint32_t)v << (8u * (k - 16u));
+    }
+  }
+  return r;
+}
+__device__ __forceinline__ uint32_t common20(const Bytes20& x, const Bytes20& y) {
+  uint64_t d = x.a ^ y.a;
+  if (d) return (uint32_t)__builtin_ctzll(d) >> 3;
+  d = x.b ^ y.b;
+  if (d) return 8u + ((uint32_t)__builtin_ctzll(d) >> 3);
+  const uint32_t e = x.c ^ y.c;
+  return e ? 16u + ((uint32_t)__builtin_ctz(e) >> 3) : 20u;
+}
+// leading bytes of x equal to byte v (0..20)
+__device__ __forceinline__ uint32_t runlen20(const Bytes20& x, uint32_t v) {
+  const uint64_t rep = 0x0101010101010101ull * (uint64_t)v;
+  Bytes20 y; y.a = rep; y.b = rep; y.c = (uint32_t)rep;
+  return common20(x, y);
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { uint32_t t = (uint32_t)__shfl_xor((int)v, o, 64); v = t > v ? t : v; }
+  return v;
+}
+
 template <int FMT>
 __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8* __restrict__ dst, uint32_t cap,
                                    int clevel, uint16_t* tab, int lane) {
@@ -157,38 +205,47 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
   if (FMT == EF_LZ4 ? (n < 13u) : (n < 16u || cap < 66u)) return 0u;
   const uint32_t last_start = n - 12u;                       // inclusive bound on match starts
   const uint32_t mlimit = (FMT == EF_LZ4) ? n - 5u : n - 2u;  // matches end at or before this position
-  const uint32_t min_match = 4u;
-  const uint32_t max_dist = 65535u;
-  const int accel = 10 - clevel;  // blosc/blosc.c:577-587
+  const int accel = 10 - clevel;                              // blosc/blosc.c:577-587
 
   for (int k = lane; k < ENC_TAB / 2; k += 64) ((uint32_t*)tab)[k] = 0u;
 
-  uint32_t ip = 0, anchor = 0, op = 0, nfail = 0, floor_pos = 0;
+  uint32_t ip = 0, anchor = 0, op = 0, nfail = 0;
   while (ip <= last_start) {
     const uint32_t p = ip + (uint32_t)lane;
     const bool live = p <= last_start;
-    uint32_t seq = 0, cand = 0;
-    bool hit = false;
+    // ---- round 1: own bytes + table probe ----
+    Bytes20 own = {0, 0, 0};
+    uint32_t prev = 0x100u;                       // "no previous byte"
+    uint32_t h = 0, cand = 0, limit = 0;
+    bool tab_ok = false;
     if (live) {
-      seq = ld4u(src + p);
-      const uint32_t h = enc_hash(seq);
+      own = load20(src, p, n);
+      if (p > 0u) prev = src[p - 1u];
+      limit = mlimit - p; if (limit > RANK_CAP) limit = RANK_CAP;     // bytes of a match starting at p that may be counted
+      h = enc_hash((uint32_t)own.a);
       const uint32_t e = tab[h];
-      tab[h] = (uint16_t)p;
       const uint32_t d = (p - e) & 0xffffu;
-      if (d != 0u && d <= p) {
-        cand = p - d;
-        hit = ld4u(src + cand) == seq;
-      }
+      if (d != 0u && d <= p) { cand = p - d; tab_ok = true; }
     }
-    // near distances 1,2,4,...,32 inside the batch (and just before it)
-    if (!hit && live) {
-#pragma unroll
-      for (uint32_t d = 1u; d <= 32u; d <<= 1) {
-        if (!hit && p >= d && ld4u(src + p - d) == seq) { hit = true; cand = p - d; }
-      }
+    // ---- round 2: candidate bytes, exact lengths up to RANK_CAP ----
+    uint32_t len = 0;
+    if (tab_ok) {
+      const Bytes20 cb = load20(src, cand, n);
+      len = common20(own, cb);
+      if (len > limit) len = limit;
+      if (len < 4u) len = 0;
+      if (FMT == EF_BLOSCLZ && len < 6u && p - cand - 1u >= 8191u) len = 0;   // far and short (blosclz.c:535)
     }
-    const uint64_t found = __ballot(hit);
-    if (!found) {
+    if (live && prev < 0x100u) {                    // distance 1: run of the previous byte
+      uint32_t rl = runlen20(own, prev);
+      if (rl > limit) rl = limit;
+      if (rl >= 4u && rl > len) { len = rl; cand = p - 1u; }
+    }
+    // ---- select: maximise (len - lane), ties to the lower lane ----
+    const uint32_t key = len ? (((len + 64u - (uint32_t)lane) << 6) | (63u - (uint32_t)lane)) : 0u;
+    const uint32_t best = wave_max_u32(key);
+    if (best == 0u) {
+      if (live) tab[h] = (uint16_t)p;
       nfail++;
       uint32_t adv = 1u + (nfail * (uint32_t)accel) / 16u;   // skip faster through incompressible data
       if (adv > 16u) adv = 16u;
@@ -196,31 +253,27 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
       continue;
     }
     nfail = 0;
-    const int f = __builtin_ctzll(found);
+    const int f = 63 - (int)(best & 63u);
+    if (live && lane <= f) tab[h] = (uint16_t)p;
     uint32_t pm = ip + (uint32_t)f;
     uint32_t cm = (uint32_t)__builtin_amdgcn_readlane((int)cand, f);
-    // backwards
-    uint32_t maxb = pm - (anchor > floor_pos ? anchor : floor_pos);
+    const uint32_t len_f = (uint32_t)__builtin_amdgcn_readlane((int)len, f);
+    // ---- round 3: extensions ----
+    uint32_t maxb = pm - anchor;
     if (cm < maxb) maxb = cm;
     if (maxb > 64u) maxb = 64u;
-    if (maxb) {
-      uint32_t back = wave_common_bwd(src, pm, cm, maxb, lane);
-      if (back > maxb) back = maxb;
-      pm -= back; cm -= back;
-    }
-    // forwards
-    uint32_t mlen = min_match + wave_common_fwd(src, n, pm + min_match, cm + min_match, mlimit - (pm + min_match), lane);
+    uint32_t back = 0;
+    if (maxb) { back = wave_common_bwd(src, pm, cm, maxb, lane); if (back > maxb) back = maxb; }
+    uint32_t mlen = len_f;
+    if (len_f == RANK_CAP && pm + RANK_CAP < mlimit)
+      mlen += wave_common_fwd(src, n, pm + RANK_CAP, cm + RANK_CAP, mlimit - (pm + RANK_CAP), lane);
+    pm -= back; cm -= back; mlen += back;
     const uint32_t ll = pm - anchor;
     const uint32_t dist = pm - cm;
     if (FMT == EF_LZ4) {
       op = lz4_emit_seq(dst, op, cap, src + anchor, ll, dist, mlen, lane);
       if (op == 0xffffffffu) return 0u;
     } else {
-      if (dist - 1u >= 8191u && mlen < 6u) {          // far and short: not worth 4 bytes (blosclz.c:535)
-        ip = pm + 1u;
-        floor_pos = ip;
-        continue;
-      }
       op = blz_emit_literals(dst, op, cap, src + anchor, ll, lane);
       if (op == 0xffffffffu) return 0u;
       op = blz_emit_match(dst, op, cap, dist, mlen, lane);
@@ -228,7 +281,8 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
     }
     anchor = pm + mlen;
     ip = anchor;
-    (void)max_dist;
+    // like the reference, remember the position two bytes before the new anchor (lz4.c:1236-1242)
+    if (lane == 0 && anchor >= 2u && anchor - 2u <= last_start) tab[enc_hash(g_ld4(src + anchor - 2u))] = (uint16_t)(anchor - 2u);
   }
   // closing literals
   if (FMT == EF_LZ4) {
@@ -237,8 +291,8 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
   } else {
     op = blz_emit_literals(dst, op, cap, src + anchor, n - anchor, lane);
     if (op == 0xffffffffu) return 0u;
-    // first byte is always a literal-run control; set the marker bit (blosclz.c:607).  Every lane
-    // may have written part of the stream; lane 0 wrote dst[0] itself, so a same-lane RMW is ordered.
+    // first byte is always a literal-run control; set the marker bit (blosclz.c:607).  Lane 0 wrote
+    // dst[0] itself, so this same-lane read-modify-write is ordered.
     if (lane == 0) dst[0] |= 0x20u;
     // reference policy: streams that compress worse than the per-clevel floor are stored raw
     // (blosclz.c:426-435, applied there to a probe of the last quarter; here to the real result)
@@ -252,8 +306,9 @@ __global__ __launch_bounds__(64 * ENC_WAVES) void k_encode_streams(StreamDesc* _
   __shared__ uint16_t tabs[ENC_WAVES][ENC_TAB];
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
-  const int sid = (int)uni((uint32_t)(blockIdx.x * ENC_WAVES + wv));
-  if (sid >= nstreams) return;
+  static_assert(ENC_WAVES == 1, "xcd_spread assumes one stream per workgroup");
+  if ((int)blockIdx.x >= nstreams) return;
+  const int sid = (int)uni(xcd_spread(blockIdx.x, (uint32_t)nstreams));
   StreamDesc* sd = streams + sid;
   const uint32_t n = uni((uint32_t)sd->in_size), cap = uni((uint32_t)sd->out_size);
   const int clevel = (int)uni((uint32_t)sd->aux);
@@ -371,8 +426,7 @@ __global__ __launch_bounds__(COMPACT_THREADS) void k_chunk_compact(const ChunkDe
   const BlockDesc b = blocks[blockIdx.x];
   const ChunkDesc& c = chunks[b.chunk];
   if (c.mode & CH_SKIP) return;
-  const bool last = (b.blk == c.nblocks - 1) && c.leftover > 0;
-  const uint32_t bsize = last ? (uint32_t)c.leftover : (uint32_t)c.blocksize;
+  const uint32_t bsize = (uint32_t)b.bsize;
   if (c.mode & CH_MEMCPYED) {   // payload = raw input right after the header (blosc.c:825-830)
     wg_copy(as_global(c.dst) + 16 + (size_t)b.blk * c.blocksize, as_global(c.src) + (size_t)b.blk * c.blocksize, bsize);
     return;

@@ -44,7 +44,7 @@ struct BlockGeom {
 };
 
 __device__ __forceinline__ bool block_geom(const ChunkDesc& c, const BlockDesc& b, int& bsize) {
-  bsize = (b.blk == c.nblocks - 1 && c.leftover > 0) ? c.leftover : c.blocksize;
+  bsize = b.bsize;
   return true;
 }
 

@@ -20,6 +20,17 @@ namespace bamd {
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
+// Workgroup -> work-item remap for one-stream-per-workgroup kernels.  Workgroup b runs on XCD b % 8
+// (observed placement, used for balance only - never for correctness).  Streams are laid out
+// plane after plane inside each block, so "stream index mod 8" correlates with "how heavy": with the
+// identity mapping two XCDs would receive every heavy byte plane.  This bijection hands each XCD a
+// CONTIGUOUS slice of the stream list instead (all plane kinds in equal shares).
+__device__ __forceinline__ uint32_t xcd_spread(uint32_t b, uint32_t n) {
+  const uint32_t q = n >> 3, r = n & 7u;
+  const uint32_t xcd = b & 7u, idx = b >> 3;
+  return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + idx;
+}
+
 __device__ __forceinline__ uint4 ld16u(const gu8* p) { return g_ld16(p); }
 __device__ __forceinline__ void st16u(gu8* p, const uint4& v) { g_st16(p, v); }
 __device__ __forceinline__ uint32_t ld4u(const gu8* p) { return g_ld4(p); }

@@ -1,0 +1,28 @@
+"""Decode-only timing of stock (reference-written) chunks for occupancy experiments."""
+import ctypes as C, importlib.util, os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from helpers import DATASETS
+spec = importlib.util.spec_from_file_location("c_blosc_amd", os.path.join(ROOT, "c-blosc_amd", "__init__.py")); mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+lib = mod.load()
+nchunks = int(os.environ.get("CHUNKS", "128")); csz = 64 << 20
+dname = os.environ.get("DATA", "bench19")
+host = DATASETS[dname](csz)
+R = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libblosc_ref.so"))
+R.blosc_compress_ctx.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int]
+tmp = np.empty(csz + 16, np.uint8)
+r = R.blosc_compress_ctx(5, 1, 8, csz, host.ctypes.data, tmp.ctypes.data, csz + 16, b"lz4", 0, 1)
+dev = torch.device("cuda:0")
+comp = torch.empty((nchunks, csz + 256), dtype=torch.uint8, device=dev)
+comp[:, :r].copy_(torch.from_numpy(tmp[:r].copy()).to(dev).unsqueeze(0).expand(nchunks, r))
+back = torch.empty((nchunks, csz), dtype=torch.uint8, device=dev)
+bd = mod.DeviceBatch([comp[i].data_ptr() for i in range(nchunks)], [csz + 16] * nchunks, [back[i].data_ptr() for i in range(nchunks)], [csz] * nchunks)
+bd.decompress()
+lib.blosc_gpu_profile(1); lib.blosc_gpu_profile_reset()
+for _ in range(3): bd.decompress()
+lib.blosc_gpu_profile(0)
+assert bd.results() == [csz] * nchunks
+ok = bool((back[0] == torch.from_numpy(host).to(dev)).all())
+d = mod.profile_get("k_decode_streams"); u = mod.profile_get("k_unshuffle")
+print(f"DEC_LDS={os.environ.get('BLOSC_AMD_DEC_LDS','0'):>6s} data={dname} chunks={nchunks} ratio={csz/r:.1f}: k_decode_streams {d[0]/d[1]:8.3f} ms  k_unshuffle {u[0]/max(u[1],1):7.3f} ms  ok={ok}", flush=True)
