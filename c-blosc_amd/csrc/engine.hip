@@ -438,7 +438,21 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
       ProfScope ps(st, stream, "k_decode_streams");
       // Occupancy knob: unused dynamic LDS caps how many decoder waves share a CU (and its L2 slice).
       static const int dec_lds = getenv("BLOSC_AMD_DEC_LDS") ? atoi(getenv("BLOSC_AMD_DEC_LDS")) : 0;
+#ifdef BAMD_PROFILE_DECODE
+      uint32_t* d_prof = nullptr;
+      if (getenv("BLOSC_AMD_DEC_PROFILE")) { (void)hipMalloc((void**)&d_prof, L.nstr * 64); (void)hipMemsetAsync(d_prof, 0, L.nstr * 64, stream); }
+      hipLaunchKernelGGL(k_decode_streams, grid1(L.nstr, DEC_WAVES), dim3(64 * DEC_WAVES), (size_t)dec_lds, stream, L.d_streams, L.d_status, (int)L.nstr, d_prof);
+      if (d_prof) {
+        std::vector<uint32_t> h(L.nstr * 16);
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(h.data(), d_prof, L.nstr * 64, hipMemcpyDeviceToHost);
+        FILE* f = fopen(getenv("BLOSC_AMD_DEC_PROFILE"), "wb");
+        if (f) { fwrite(h.data(), 4, h.size(), f); fclose(f); }
+        (void)hipFree(d_prof);
+      }
+#else
       hipLaunchKernelGGL(k_decode_streams, grid1(L.nstr, DEC_WAVES), dim3(64 * DEC_WAVES), (size_t)dec_lds, stream, L.d_streams, L.d_status, (int)L.nstr);
+#endif
     }
     if (L.any_shuf) {
       ProfScope ps(st, stream, "k_unshuffle");

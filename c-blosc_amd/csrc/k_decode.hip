@@ -56,6 +56,161 @@ __global__ void k_decode_plan(const ChunkDesc* __restrict__ chunks, const BlockD
 }
 
 // ---------------------------------------------------------------------------------------------
+// Batched LZ4 step: decode up to 16 consecutive sequences whose tokens, literals, offsets (and at most
+// one match-length extension byte) all lie in the 64 stream bytes starting at `ip`.
+//
+//   1. every lane l treats stream byte ip+l as if it were a token and works out where the next token
+//      would be (speculative parse, pure VALU + cross-lane reads of the 64 window bytes);
+//   2. a scalar walk follows that next-token chain from lane 0 (ip is a real token by invariant), which
+//      marks the real tokens, ranks them and prefix-sums their output sizes;
+//   3. literal bytes of ALL accepted sequences go out with one scattered byte store;
+//   4. matches that are short (<= 24 bytes) and whose source lies entirely before the step's output
+//      ("independent") are copied by 4 lanes per sequence with overlapping 4/8-byte pieces — one or two
+//      gathers, one or two scatters for up to 16 matches;
+//   5. the remaining matches (long, or reading bytes this very step produces) run in stream order
+//      through wave_match_copy with their fields already parsed.
+// Same-wave memory ordering (wave_prims.h) makes 3 -> 4 -> 5 safe without waits.
+//
+// The caller guarantees ip + 72 <= n (so no accepted sequence can be the stream's final one and the
+// input-side rule "literals end >= 8 bytes before the input end", lz4.c:2279, holds) and has done
+// w.seek(ip).  Output-side rules (lz4.c:2279, :2423) and offset validity are checked per sequence in
+// the walk; a sequence that breaks one is simply not accepted, so the scalar path re-parses it and
+// reports the error exactly as before.  Returns the number of sequences done (0: nothing accepted).
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t BATCH_MAXSEQ = 16;
+
+// Optional phase profiling (build with -DBAMD_PROFILE_DECODE -> libblosc_amd_prof.so, scripts/dec_phase.py):
+// 16 wave-uniform counters per stream, cycles from s_memtime.
+#ifdef BAMD_PROFILE_DECODE
+struct DecProf { uint64_t t0; uint32_t c[16]; };
+#define PROF_DECL DecProf prof_; for (int i_ = 0; i_ < 16; i_++) prof_.c[i_] = 0; prof_.t0 = __builtin_amdgcn_s_memtime();
+#define PROF_ARG , DecProf& prof_
+#define PROF_PASS , prof_
+#define PROF_ADD(i, v) prof_.c[i] += (uint32_t)(v)
+#define PROF_LAP(i) do { uint64_t t_ = __builtin_amdgcn_s_memtime(); prof_.c[i] += (uint32_t)(t_ - prof_.t0); prof_.t0 = t_; } while (0)
+#else
+#define PROF_DECL
+#define PROF_ARG
+#define PROF_PASS
+#define PROF_ADD(i, v)
+#define PROF_LAP(i)
+#endif
+// counter slots: 0 batches, 1 sequences done in batches, 2 of those "others" (sequential), 3 scalar-path sequences,
+// 8 cycles: seek+gather+parse, 9 chain walk, 10 literals+pieces issue, 11 others, 12 scalar path, 13 raw/other
+
+__device__ __forceinline__ uint32_t bperm(uint32_t src_lane, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v);
+}
+// value of lane (l - n) within the same row of 16 lanes, 0 when that lane is outside the row (DPP row_shr:n)
+template <int N>
+__device__ __forceinline__ uint32_t row_shr(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + N, 0xf, 0xf, true);
+}
+// one hop through a next-position table held one entry per lane; position 64 ("stop") is absorbing
+__device__ __forceinline__ uint32_t hop(uint32_t table, uint32_t x) {
+  const uint32_t t = bperm(x & 63u, table);
+  return x >= 64u ? 64u : t;
+}
+
+__device__ __forceinline__ uint32_t lz4_batch_step(const Window& w, gu8* out, volatile uint32_t* scr, uint32_t& ip, uint32_t& op,
+                                                   uint32_t cap, int lane PROF_ARG) {
+  const uint32_t B = w.gather_bytes(ip);                       // stream byte ip + lane
+  // ---- 1. speculative parse: every lane reads "its" byte as a token ----
+  const uint32_t ll = B >> 4, mlc = B & 15u;
+  const uint32_t offpos = (uint32_t)lane + 1u + ll;            // where this token's offset would start
+  const uint32_t o_lo = bperm(offpos & 63u, B), o_hi = bperm((offpos + 1u) & 63u, B), e1 = bperm((offpos + 2u) & 63u, B);
+  const bool has_ext = mlc == 15u;
+  const uint32_t ml = has_ext ? 19u + e1 : mlc + 4u;           // <= 273
+  const uint32_t size = 3u + ll + (has_ext ? 1u : 0u);         // token + literals + offset (+ ext)
+  const bool complete = ll != 15u && !(has_ext && e1 == 255u) && (uint32_t)lane + size <= 64u;
+  const uint32_t off = o_lo | (o_hi << 8);
+  const uint32_t nxt = complete ? (uint32_t)lane + size : 64u; // position of the following token, 64 = stop here
+  PROF_LAP(8);
+  // ---- 2. token chain in "rank space": lane r (< 16) finds the position of the r-th token by pointer
+  //         doubling over the next-position table: J1 = J0 o J0, J2 = J1 o J1, J3 = J2 o J2 ----
+  const uint32_t J0 = nxt;
+  const uint32_t J1 = hop(J0, J0), J2 = hop(J1, J1), J3 = hop(J2, J2);
+  uint32_t c = 0;                                              // ip is a real token by invariant
+  { const uint32_t t = hop(J0, c); c = (lane & 1) ? t : c; }
+  { const uint32_t t = hop(J1, c); c = (lane & 2) ? t : c; }
+  { const uint32_t t = hop(J2, c); c = (lane & 4) ? t : c; }
+  { const uint32_t t = hop(J3, c); c = (lane & 8) ? t : c; }
+  // fields of the token at c, fetched into the rank lane
+  const uint32_t pk = bperm(c & 63u, ll | (ml << 4) | ((complete ? 1u : 0u) << 13) | (nxt << 14));
+  const uint32_t off_r = bperm(c & 63u, off);
+  const uint32_t ll_r = pk & 15u, ml_r = (pk >> 4) & 0x1ffu, nxt_r = pk >> 14;
+  const bool valid = lane < (int)BATCH_MAXSEQ && c < 64u && ((pk >> 13) & 1u);
+  const uint32_t tot_r = valid ? ll_r + ml_r : 0u;
+  uint32_t incl = tot_r;                                       // inclusive prefix sum over the 16 rank lanes (one DPP row)
+  incl += row_shr<1>(incl); incl += row_shr<2>(incl); incl += row_shr<4>(incl); incl += row_shr<8>(incl);
+  const uint32_t excl = incl - tot_r;                          // output offset of sequence r relative to op
+  const uint32_t mrel_r = excl + ll_r;                         // its match start, relative to op
+  // acceptance: offset inside the produced data (lz4.c:2356, and offset 0), and far enough from the output
+  // end that neither lz4.c:2279 nor :2423 can apply (the scalar path handles those sequences)
+  const bool ok = valid && off_r != 0u && off_r <= op + mrel_r && op + excl + tot_r + 12u <= cap;
+  const uint32_t okmask = (uint32_t)__ballot(ok) & 0xffffu;
+  const uint32_t cnt = (uint32_t)__builtin_ctz(~okmask);       // leading accepted sequences (<= 16)
+  PROF_LAP(9);
+  if (cnt == 0u) return 0u;
+  const uint32_t consumed = (uint32_t)__builtin_amdgcn_readlane((int)nxt_r, (int)(cnt - 1u));
+  const uint32_t acc = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(cnt - 1u));
+  // ---- 3. literals: token info goes back to byte-lane space through a 64-dword LDS scratch, then one
+  //         scattered byte store covers the literals of every accepted sequence ----
+  // (volatile: lanes talk to each other through this scratch; without it the compiler forwards a lane's
+  //  own "= 0" store to its later load, which is legal for unsynchronised memory and wrong here)
+  scr[lane] = 0u;
+  if ((uint32_t)lane < cnt) scr[c] = 0x80000000u | excl | (ll_r << 16);
+  const uint64_t mask = __ballot(scr[lane] >> 31);
+  {
+    const uint64_t below = mask & ((2ull << lane) - 1ull);     // accepted tokens at or before this byte lane
+    const uint32_t s = 63u - (uint32_t)__builtin_clzll(below | 1ull);
+    const uint32_t inf = scr[s];
+    const uint32_t k = (uint32_t)lane - s - 1u;
+    if ((uint32_t)lane < consumed && (uint32_t)lane > s && k < ((inf >> 16) & 15u)) out[op + (inf & 0xffffu) + k] = (uint8_t)B;
+  }
+  // ---- 4. short independent matches: 4 lanes per sequence, overlapping 4/8/16-byte pieces ----
+  const bool fast_r = (uint32_t)lane < cnt && ml_r <= 64u && off_r >= mrel_r + ml_r;   // source ends at or before op
+  {
+    const uint32_t r = (uint32_t)lane >> 2, q = (uint32_t)lane & 3u;
+    const uint32_t fA = bperm(r, fast_r ? (ml_r | 0x200u | (mrel_r << 10)) : 0u);
+    const uint32_t fB = bperm(r, off_r);
+    const uint32_t mlen = fA & 0x1ffu;
+    const bool go = (fA & 0x200u) != 0u;
+    gu8* d = out + op + (fA >> 10);
+    const gu8* sp = d - fB;
+    const bool w16 = go && mlen >= 16u && q < ((mlen + 15u) >> 4);
+    const bool w8 = go && mlen >= 8u && mlen < 16u && q < 2u;
+    const bool w4 = go && mlen < 8u && q < 2u;
+    const uint32_t np16 = (mlen + 15u) >> 4;
+    const uint32_t po16 = (q == np16 - 1u) ? mlen - 16u : 16u * q;
+    const uint32_t po8 = q ? mlen - 8u : 0u, po4 = q ? mlen - 4u : 0u;
+    uint4 v16 = make_uint4(0, 0, 0, 0); uint64_t v8 = 0; uint32_t v4 = 0;
+    if (w16) v16 = g_ld16(sp + po16);
+    if (w8) v8 = g_ld8(sp + po8);
+    if (w4) v4 = g_ld4(sp + po4);
+    if (w16) g_st16(d + po16, v16);
+    if (w8) *(BAMD_GAS u64una*)(d + po8) = v8;
+    if (w4) g_st4(d + po4, v4);
+  }
+  PROF_LAP(10);
+  // ---- 5. everything else (long, or reading bytes this very step produces), in stream order ----
+  uint32_t rest = (uint32_t)__ballot((uint32_t)lane < cnt && !fast_r);
+  PROF_ADD(0, 1); PROF_ADD(1, cnt); PROF_ADD(2, __builtin_popcount(rest));
+  while (rest) {
+    const int sl = __builtin_ctz(rest);
+    rest &= rest - 1u;
+    const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)ml_r, sl);
+    const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)off_r, sl);
+    const uint32_t mr = (uint32_t)__builtin_amdgcn_readlane((int)mrel_r, sl);
+    wave_match_copy(out, op + mr, o, m, lane);
+  }
+  ip += consumed;
+  op += acc;
+  PROF_LAP(11);
+  return cnt;
+}
+
+// ---------------------------------------------------------------------------------------------
 // LZ4 block decode, one wave.  Returns bytes produced (== cap on success) or a negative number.
 // Acceptance rules are those of the reference's safe loop (lz4.c:2215-2435):
 //   literal-length extension stops reading at n-15, match-length extension at n-4;
@@ -64,7 +219,7 @@ __global__ void k_decode_plan(const ChunkDesc* __restrict__ chunks, const BlockD
 //   least 5 bytes before the output end.  Offset 0 (accepted by the reference with unspecified
 //   output) is rejected here.
 // ---------------------------------------------------------------------------------------------
-__device__ int lz4_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* out, int32_t cap_, int lane) {
+__device__ int lz4_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* out, int32_t cap_, volatile uint32_t* scr, int lane PROF_ARG) {
   if (cap_ == 0) return (n_ == 1 && in[0] == 0) ? 0 : -1;
   if (n_ <= 0) return -1;
   const uint32_t n = (uint32_t)n_, cap = (uint32_t)cap_;
@@ -73,6 +228,8 @@ __device__ int lz4_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* out,
   uint32_t ip = 0, op = 0;
   for (;;) {
     w.seek(ip);
+    if (ip + 72u <= n && lz4_batch_step(w, out, scr, ip, op, cap, lane PROF_PASS)) continue;
+    PROF_ADD(3, 1);
     const uint32_t hdr = w.peek32(ip);
     const uint32_t token = hdr & 0xffu;
     ip += 1;
@@ -129,7 +286,9 @@ __device__ int lz4_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* out,
       wave_match_copy(out, mpos, off, ml, lane);
     }
     op = mpos + ml;
+    PROF_LAP(12);
   }
+  PROF_LAP(12);
   return (int)op;
 }
 
@@ -193,7 +352,13 @@ __device__ int blosclz_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* 
 // decode kernel: grid = ceil(nstreams / DEC_WAVES), block = 64 * DEC_WAVES
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * DEC_WAVES) void k_decode_streams(StreamDesc* __restrict__ streams,
-                                                                   int32_t* __restrict__ status, int nstreams) {
+                                                                   int32_t* __restrict__ status, int nstreams
+#ifdef BAMD_PROFILE_DECODE
+                                                                   , uint32_t* __restrict__ profbuf
+#endif
+                                                                   ) {
+  PROF_DECL
+  __shared__ uint32_t scr[DEC_WAVES][64];   // per-wave scratch of the batched LZ4 step
   const int lane = threadIdx.x & 63;
   static_assert(DEC_WAVES == 1, "xcd_spread assumes one stream per workgroup");
   if ((int)blockIdx.x >= nstreams) return;
@@ -209,10 +374,14 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void k_decode_streams(StreamDesc* _
     wave_copy_disjoint(out, in, (uint32_t)want, lane);
     got = want;
   } else if (sd->fmt == FMT_LZ4) {
-    got = lz4_decode_wave(in, csize, out, want, lane);
+    got = lz4_decode_wave(in, csize, out, want, scr[threadIdx.x >> 6], lane PROF_PASS);
   } else {
     got = blosclz_decode_wave(in, csize, out, want, lane);
   }
+#ifdef BAMD_PROFILE_DECODE
+  PROF_LAP(13);
+  if (lane == 0 && profbuf) for (int i_ = 0; i_ < 16; i_++) profbuf[(size_t)sid * 16 + i_] = prof_.c[i_];
+#endif
   if (lane == 0) {
     sd->result = got;
     if (got != want) atomicMin(&status[sd->chunk], (int32_t)ST_BADCODEC);  // blosc.c:780-782

@@ -75,13 +75,27 @@ __device__ __forceinline__ void wave_match_copy(gu8* out, uint32_t pos, uint32_t
       done += chunk;
     }
     if (done >= len) return;
+    if ((off & (off - 1u)) == 0u && off <= 16u) {
+      // period divides 16: every 16-byte group of the run is the same value -> no more loads at all
+      const uint4 v = ld16u(out + pos + done - 16u);
+      while (len - done >= 1024u) { st16u(out + pos + done + 16 * lane, v); done += 1024u; }
+      if (done >= len) return;
+    }
     off_e = G;
     // `done` may not be a multiple of G when head was cut; any multiple of `off` <= off+done is valid
     // only if the copied prefix really is periodic up to `done`, which it is.  Restart from G.
   }
   while (done < len) {
     uint32_t rem = len - done;
-    while (off_e < 1024u && 2u * off_e <= off + done) off_e *= 2u;  // history grew: lengthen the stride
+    while (off_e < 4096u && 2u * off_e <= off + done) off_e *= 2u;  // history grew: lengthen the stride
+    if (off_e >= 4096u && rem >= 4096u) {
+      // four independent 1 KiB rows per step: one memory round trip per 4 KiB instead of per 1 KiB
+      gu8* d = out + pos + done + 16 * lane;
+      const uint4 a0 = ld16u(d - off_e), a1 = ld16u(d - off_e + 1024), a2 = ld16u(d - off_e + 2048), a3 = ld16u(d - off_e + 3072);
+      st16u(d, a0); st16u(d + 1024, a1); st16u(d + 2048, a2); st16u(d + 3072, a3);
+      done += 4096u;
+      continue;
+    }
     uint32_t chunk = rem < 1024u ? rem : 1024u;
     if (chunk > off_e) chunk = off_e;
     if (chunk >= 16u) {
@@ -136,10 +150,13 @@ struct Window {
   __device__ __forceinline__ uint32_t peek32(uint32_t p) const {
     uint32_t r = p - base;
     uint32_t i0 = r >> 2, i1 = i0 + 1u;
-    uint32_t a = (i0 < 64u) ? (uint32_t)__builtin_amdgcn_readlane((int)lo, (int)i0)
-                            : (uint32_t)__builtin_amdgcn_readlane((int)hi, (int)(i0 - 64u));
-    uint32_t b = (i1 < 64u) ? (uint32_t)__builtin_amdgcn_readlane((int)lo, (int)i1)
-                            : (uint32_t)__builtin_amdgcn_readlane((int)hi, (int)((i1 - 64u) & 63u));
+    // uniform branches (not selects): `hi` may still be in flight right after a slide and must not be
+    // waited for unless the bytes really come from it
+    uint32_t a, b;
+    if (i0 < 64u) a = (uint32_t)__builtin_amdgcn_readlane((int)lo, (int)i0);
+    else a = (uint32_t)__builtin_amdgcn_readlane((int)hi, (int)(i0 - 64u));
+    if (i1 < 64u) b = (uint32_t)__builtin_amdgcn_readlane((int)lo, (int)i1);
+    else b = (uint32_t)__builtin_amdgcn_readlane((int)hi, (int)((i1 - 64u) & 63u));
     uint64_t w = ((uint64_t)b << 32) | a;
     return (uint32_t)(w >> ((r & 3u) * 8u));
   }
@@ -147,11 +164,19 @@ struct Window {
 
   // lane i < n gets stream byte (p + i) out of the window.  Requires base <= p, p + n <= base + 512, n <= 64.
   __device__ __forceinline__ uint32_t gather_bytes(uint32_t p) const {
-    uint32_t r = p - base + (uint32_t)lane;
-    uint32_t d = r >> 2;
-    uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d & 63u) << 2), (int)lo);
-    uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d & 63u) << 2), (int)hi);
-    uint32_t v = (d < 64u) ? a : b;
+    const uint32_t r0 = p - base;                    // uniform
+    const uint32_t r = r0 + (uint32_t)lane;
+    const uint32_t d = r >> 2;
+    uint32_t v;
+    if (r0 + 64u <= 256u) {                          // all 64 bytes come from `lo`: do not wait for `hi`
+      v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(d << 2), (int)lo);
+    } else if (r0 >= 256u) {
+      v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d & 63u) << 2), (int)hi);
+    } else {
+      const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d & 63u) << 2), (int)lo);
+      const uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((d & 63u) << 2), (int)hi);
+      v = (d < 64u) ? a : b;
+    }
     return (v >> ((r & 3u) * 8u)) & 0xffu;
   }
 };

@@ -87,6 +87,15 @@ def ref():
 @pytest.fixture(scope="session")
 def pkg():
     _ensure_product()
+    if has_gpu():
+        # torch bundles its own HIP runtime; whichever copy is loaded first serves the whole process.
+        # Loading ours first leaves torch without a device ("No HIP GPUs are available"), so on a GPU
+        # box torch initialises before libblosc_amd.so is dlopen'ed (bench.py does the same).
+        try:
+            import torch
+            torch.cuda.init()
+        except Exception:
+            pass
     return _load_pkg()
 
 
