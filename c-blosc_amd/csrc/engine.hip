@@ -133,6 +133,14 @@ struct Carver {
   size_t take(size_t bytes, size_t align = 256) { off = align_up(off, align); size_t r = off; off += bytes; return r; }
 };
 
+// grid of a persistent one-wave-per-workgroup kernel: as many waves as the device keeps resident
+static unsigned persistent_grid(size_t nitems, int waves_per_cu) {
+  static int cus = 0;
+  if (!cus) { hipDeviceProp_t pr; int dev = 0; (void)hipGetDevice(&dev); if (hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount; if (cus <= 0) cus = 256; }
+  size_t g = (size_t)cus * (size_t)waves_per_cu;
+  return (unsigned)(nitems < g ? nitems : g);
+}
+
 static dim3 grid1(size_t n, int per) { return dim3((unsigned)((n + per - 1) / per)); }
 
 // ---------------------------------------------------------------------------------------------
@@ -233,7 +241,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   const size_t o_blocks = cv.take(sizeof(BlockDesc) * (nblk ? nblk : 1));
   const size_t o_streams = cv.take(sizeof(StreamDesc) * (nstr ? nstr : 1));
   const size_t o_blkoff = cv.take(sizeof(int32_t) * (nblk ? nblk : 1));
-  const size_t o_results = cv.take(sizeof(int32_t) * (size_t)n);
+  const size_t o_results = cv.take(sizeof(int32_t) * (size_t)n + 64);   // + ticket counter of the encode queue
   const size_t o_filt = cv.take(filt_bytes + 256);
   const size_t o_stage = cv.take(stage_bytes + 256);
   if (st.dev.ensure(cv.off)) return -1;
@@ -284,7 +292,8 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   HIP_TRY(hipMemcpyAsync(D + o_chunks, P + p_chunks, sizeof(ChunkDesc) * (size_t)n, hipMemcpyHostToDevice, stream));
   if (nblk) HIP_TRY(hipMemcpyAsync(D + o_blocks, P + p_blocks, sizeof(BlockDesc) * nblk, hipMemcpyHostToDevice, stream));
   if (nstr) HIP_TRY(hipMemcpyAsync(D + o_streams, P + p_streams, sizeof(StreamDesc) * nstr, hipMemcpyHostToDevice, stream));
-  HIP_TRY(hipMemsetAsync(D + o_results, 0, sizeof(int32_t) * (size_t)n, stream));
+  HIP_TRY(hipMemsetAsync(D + o_results, 0, sizeof(int32_t) * (size_t)n + 64, stream));
+  uint32_t* d_ticket = (uint32_t*)(D + o_results + sizeof(int32_t) * (size_t)n + 32);
 
   ChunkDesc* d_chunks = (ChunkDesc*)(D + o_chunks);
   BlockDesc* d_blocks = (BlockDesc*)(D + o_blocks);
@@ -303,7 +312,8 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   }
   if (nstr) {
     ProfScope ps(st, stream, "k_encode_streams");
-    hipLaunchKernelGGL(k_encode_streams, grid1(nstr, ENC_WAVES), dim3(64 * ENC_WAVES), 0, stream, d_streams, (int)nstr);
+    static const int enc_wpc = getenv("BLOSC_AMD_ENC_WPC") ? atoi(getenv("BLOSC_AMD_ENC_WPC")) : 24;
+    hipLaunchKernelGGL(k_encode_streams, dim3(persistent_grid(nstr, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, (int)nstr, d_ticket);
   }
   {
     ProfScope ps(st, stream, "k_chunk_scan");
@@ -423,7 +433,7 @@ static void add_decode_chunk(const Header& h, int fmt, int chunk_index, int32_t 
 }
 
 struct DecodeLaunch {
-  ChunkDesc* d_chunks; BlockDesc* d_blocks; StreamDesc* d_streams; int32_t* d_status;
+  ChunkDesc* d_chunks; BlockDesc* d_blocks; StreamDesc* d_streams; int32_t* d_status; uint32_t* d_ticket;
   size_t nblk, nstr; int nchunks;
   bool any_shuf, any_bit, any_copy; int tiles_shuf, tiles_bit;
 };
@@ -438,10 +448,12 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
       ProfScope ps(st, stream, "k_decode_streams");
       // Occupancy knob: unused dynamic LDS caps how many decoder waves share a CU (and its L2 slice).
       static const int dec_lds = getenv("BLOSC_AMD_DEC_LDS") ? atoi(getenv("BLOSC_AMD_DEC_LDS")) : 0;
+      static const int dec_wpc = getenv("BLOSC_AMD_DEC_WPC") ? atoi(getenv("BLOSC_AMD_DEC_WPC")) : 24;
+      const dim3 dgrid(persistent_grid(L.nstr, dec_wpc));
 #ifdef BAMD_PROFILE_DECODE
       uint32_t* d_prof = nullptr;
       if (getenv("BLOSC_AMD_DEC_PROFILE")) { (void)hipMalloc((void**)&d_prof, L.nstr * 64); (void)hipMemsetAsync(d_prof, 0, L.nstr * 64, stream); }
-      hipLaunchKernelGGL(k_decode_streams, grid1(L.nstr, DEC_WAVES), dim3(64 * DEC_WAVES), (size_t)dec_lds, stream, L.d_streams, L.d_status, (int)L.nstr, d_prof);
+      hipLaunchKernelGGL(k_decode_streams, dgrid, dim3(64 * DEC_WAVES), (size_t)dec_lds, stream, L.d_streams, L.d_status, (int)L.nstr, L.d_ticket, d_prof);
       if (d_prof) {
         std::vector<uint32_t> h(L.nstr * 16);
         (void)hipStreamSynchronize(stream);
@@ -451,7 +463,7 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
         (void)hipFree(d_prof);
       }
 #else
-      hipLaunchKernelGGL(k_decode_streams, grid1(L.nstr, DEC_WAVES), dim3(64 * DEC_WAVES), (size_t)dec_lds, stream, L.d_streams, L.d_status, (int)L.nstr);
+      hipLaunchKernelGGL(k_decode_streams, dgrid, dim3(64 * DEC_WAVES), (size_t)dec_lds, stream, L.d_streams, L.d_status, (int)L.nstr, L.d_ticket);
 #endif
     }
     if (L.any_shuf) {
@@ -520,7 +532,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   const size_t o_chunks = cv.take(sizeof(ChunkDesc) * (size_t)n);
   const size_t o_blocks = cv.take(sizeof(BlockDesc) * (nblk ? nblk : 1));
   const size_t o_streams = cv.take(sizeof(StreamDesc) * (nstr ? nstr : 1));
-  const size_t o_status = cv.take(sizeof(int32_t) * (size_t)n);
+  const size_t o_status = cv.take(sizeof(int32_t) * (size_t)n + 64);   // + ticket counter of the decode queue
   const size_t o_filt = cv.take(filt_bytes + 256);
   if (st.dev.ensure(cv.off)) return -1;
   uint8_t* D = st.dev.base;
@@ -553,10 +565,11 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   if (nblk) memcpy(P + p_blocks, blocks.data(), sizeof(BlockDesc) * nblk);
   HIP_TRY(hipMemcpyAsync(D + o_chunks, P + p_chunks, sizeof(ChunkDesc) * (size_t)n, hipMemcpyHostToDevice, stream));
   if (nblk) HIP_TRY(hipMemcpyAsync(D + o_blocks, P + p_blocks, sizeof(BlockDesc) * nblk, hipMemcpyHostToDevice, stream));
-  HIP_TRY(hipMemsetAsync(D + o_status, 0, sizeof(int32_t) * (size_t)n, stream));
+  HIP_TRY(hipMemsetAsync(D + o_status, 0, sizeof(int32_t) * (size_t)n + 64, stream));
 
   L.d_chunks = (ChunkDesc*)(D + o_chunks); L.d_blocks = (BlockDesc*)(D + o_blocks);
   L.d_streams = (StreamDesc*)(D + o_streams); L.d_status = (int32_t*)(D + o_status);
+  L.d_ticket = (uint32_t*)(D + o_status + sizeof(int32_t) * (size_t)n + 32);
   L.nblk = nblk; L.nstr = nstr; L.nchunks = n;
   if (launch_decode(st, L, stream)) return -1;
   HIP_TRY(hipMemcpyAsync(P + p_status, D + o_status, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, stream));
@@ -633,7 +646,7 @@ int engine_getitem(const void* src, int start, int nitems, void* dest, bool src_
   const size_t o_chunks = cv.take(sizeof(ChunkDesc));
   const size_t o_blocks = cv.take(sizeof(BlockDesc) * nblk);
   const size_t o_streams = cv.take(sizeof(StreamDesc) * nstr);
-  const size_t o_status = cv.take(sizeof(int32_t));
+  const size_t o_status = cv.take(sizeof(int32_t) + 64);
   const size_t o_out = cv.take(span + 256);
   const size_t o_filt = cv.take(span + 256);
   if (st.dev.ensure(cv.off)) return -1;
@@ -652,10 +665,11 @@ int engine_getitem(const void* src, int start, int nitems, void* dest, bool src_
   memcpy(P + p_blocks, blocks.data(), sizeof(BlockDesc) * nblk);
   HIP_TRY(hipMemcpyAsync(D + o_chunks, P + p_chunks, sizeof c, hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemcpyAsync(D + o_blocks, P + p_blocks, sizeof(BlockDesc) * nblk, hipMemcpyHostToDevice, stream));
-  HIP_TRY(hipMemsetAsync(D + o_status, 0, sizeof(int32_t), stream));
+  HIP_TRY(hipMemsetAsync(D + o_status, 0, sizeof(int32_t) + 64, stream));
   DecodeLaunch L{};
   L.d_chunks = (ChunkDesc*)(D + o_chunks); L.d_blocks = (BlockDesc*)(D + o_blocks);
   L.d_streams = (StreamDesc*)(D + o_streams); L.d_status = (int32_t*)(D + o_status);
+  L.d_ticket = (uint32_t*)(D + o_status + 32);
   L.nblk = nblk; L.nstr = nstr; L.nchunks = 1;
   filter_tiles(c, L.any_shuf, L.any_bit, L.tiles_shuf, L.tiles_bit);
   if (launch_decode(st, L, stream)) return -1;

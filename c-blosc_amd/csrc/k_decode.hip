@@ -83,7 +83,8 @@ constexpr uint32_t BATCH_MAXSEQ = 16;
 // 16 wave-uniform counters per stream, cycles from s_memtime.
 #ifdef BAMD_PROFILE_DECODE
 struct DecProf { uint64_t t0; uint32_t c[16]; };
-#define PROF_DECL DecProf prof_; for (int i_ = 0; i_ < 16; i_++) prof_.c[i_] = 0; prof_.t0 = __builtin_amdgcn_s_memtime();
+#define PROF_DECL DecProf prof_; for (int i_ = 0; i_ < 16; i_++) prof_.c[i_] = 0; prof_.t0 = __builtin_amdgcn_s_memtime(); \
+  prof_.c[14] = (uint32_t)(prof_.t0 >> 6); prof_.c[4] = __builtin_amdgcn_s_getreg(0xF804); prof_.c[5] = __builtin_amdgcn_s_getreg((3 << 11) | 20);
 #define PROF_ARG , DecProf& prof_
 #define PROF_PASS , prof_
 #define PROF_ADD(i, v) prof_.c[i] += (uint32_t)(v)
@@ -112,8 +113,9 @@ __device__ __forceinline__ uint32_t hop(uint32_t table, uint32_t x) {
   return x >= 64u ? 64u : t;
 }
 
-__device__ __forceinline__ uint32_t lz4_batch_step(const Window& w, gu8* out, volatile uint32_t* scr, uint32_t& ip, uint32_t& op,
+__device__ __forceinline__ uint32_t lz4_batch_step(const Window& w, gu8* out, volatile uint32_t* scr_generic, uint32_t& ip, uint32_t& op,
                                                    uint32_t cap, int lane PROF_ARG) {
+  volatile __attribute__((address_space(3))) uint32_t* scr = (volatile __attribute__((address_space(3))) uint32_t*)scr_generic;   // LDS
   const uint32_t B = w.gather_bytes(ip);                       // stream byte ip + lane
   // ---- 1. speculative parse: every lane reads "its" byte as a token ----
   const uint32_t ll = B >> 4, mlc = B & 15u;
@@ -349,21 +351,17 @@ __device__ int blosclz_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* 
 }
 
 // ---------------------------------------------------------------------------------------------
-// decode kernel: grid = ceil(nstreams / DEC_WAVES), block = 64 * DEC_WAVES
+// decode kernel: persistent waves + ticket queue, block = 64 * DEC_WAVES
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64 * DEC_WAVES) void k_decode_streams(StreamDesc* __restrict__ streams,
-                                                                   int32_t* __restrict__ status, int nstreams
+// One stream, start to finish.  Deliberately NOT inlined into the queue loop below: with the decoders
+// inlined, the compiler restructured the loop with partial exec masks and re-read the ticket with lane 0
+// masked off (an endless loop on stream 0).  A real call keeps the loop's control flow trivial.
+__device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int32_t* status, volatile uint32_t* scr, int lane
 #ifdef BAMD_PROFILE_DECODE
-                                                                   , uint32_t* __restrict__ profbuf
+                                                            , uint32_t* profslot
 #endif
-                                                                   ) {
+                                                            ) {
   PROF_DECL
-  __shared__ uint32_t scr[DEC_WAVES][64];   // per-wave scratch of the batched LZ4 step
-  const int lane = threadIdx.x & 63;
-  static_assert(DEC_WAVES == 1, "xcd_spread assumes one stream per workgroup");
-  if ((int)blockIdx.x >= nstreams) return;
-  const int sid = (int)uni(xcd_spread(blockIdx.x, (uint32_t)nstreams));
-  StreamDesc* sd = streams + sid;
   const gu8* in = as_global(sd->in);
   const int32_t csize = (int32_t)uni((uint32_t)sd->in_size);
   const int32_t want = (int32_t)uni((uint32_t)sd->out_size);
@@ -374,17 +372,44 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void k_decode_streams(StreamDesc* _
     wave_copy_disjoint(out, in, (uint32_t)want, lane);
     got = want;
   } else if (sd->fmt == FMT_LZ4) {
-    got = lz4_decode_wave(in, csize, out, want, scr[threadIdx.x >> 6], lane PROF_PASS);
+    got = lz4_decode_wave(in, csize, out, want, scr, lane PROF_PASS);
   } else {
     got = blosclz_decode_wave(in, csize, out, want, lane);
   }
 #ifdef BAMD_PROFILE_DECODE
   PROF_LAP(13);
-  if (lane == 0 && profbuf) for (int i_ = 0; i_ < 16; i_++) profbuf[(size_t)sid * 16 + i_] = prof_.c[i_];
+  prof_.c[15] = (uint32_t)(prof_.t0 >> 6);
+  if (lane == 0 && profslot) for (int i_ = 0; i_ < 16; i_++) profslot[i_] = prof_.c[i_];
 #endif
   if (lane == 0) {
     sd->result = got;
     if (got != want) atomicMin(&status[sd->chunk], (int32_t)ST_BADCODEC);  // blosc.c:780-782
+  }
+}
+
+// Persistent launch: the grid is sized to what the chip can hold (engine.hip) and every wave pulls
+// stream indices from one global ticket counter until the list is empty.  Streams of one batch differ
+// by 1000x in cost (a byte plane of zeros is two sequences, a noisy plane thousands); with one
+// workgroup per stream the dispatcher kept only 4-9 waves per CU busy, with the queue every resident
+// wave stays busy until the list is empty.
+__global__ __launch_bounds__(64 * DEC_WAVES) void k_decode_streams(StreamDesc* __restrict__ streams,
+                                                                   int32_t* __restrict__ status, int nstreams,
+                                                                   uint32_t* __restrict__ ticket
+#ifdef BAMD_PROFILE_DECODE
+                                                                   , uint32_t* __restrict__ profbuf
+#endif
+                                                                   ) {
+  __shared__ uint32_t scr[DEC_WAVES][64];   // per-wave scratch of the batched LZ4 step
+  static_assert(DEC_WAVES == 1, "one stream per wave, one wave per workgroup");
+  const int lane = threadIdx.x & 63;
+  uint32_t sid = take_ticket(ticket, lane);
+  while (sid < (uint32_t)nstreams) {
+#ifdef BAMD_PROFILE_DECODE
+    decode_one_stream(streams + sid, status, scr[0], lane, profbuf ? profbuf + (size_t)sid * 16 : nullptr);
+#else
+    decode_one_stream(streams + sid, status, scr[0], lane);
+#endif
+    sid = take_ticket(ticket, lane);
   }
 }
 

@@ -199,7 +199,10 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 
 template <int FMT>
 __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8* __restrict__ dst, uint32_t cap,
-                                   int clevel, uint16_t* tab, int lane) {
+                                   int clevel, uint16_t* tab_generic, int lane) {
+  // the table lives in LDS; say so explicitly (a generic pointer in a non-inlined function would make
+  // every probe a flat_load)
+  __attribute__((address_space(3))) uint16_t* tab = (__attribute__((address_space(3))) uint16_t*)tab_generic;
   // stream-end rules.  LZ4: last match starts <= n-12, ends <= n-5 (lz4.c:245-246, :963-964).
   // BloscLZ: matches start < n-12 (blosclz.c:465), stream must end with >= 1 literal (blosclz.c:708-710).
   if (FMT == EF_LZ4 ? (n < 13u) : (n < 16u || cap < 66u)) return 0u;
@@ -207,7 +210,7 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
   const uint32_t mlimit = (FMT == EF_LZ4) ? n - 5u : n - 2u;  // matches end at or before this position
   const int accel = 10 - clevel;                              // blosc/blosc.c:577-587
 
-  for (int k = lane; k < ENC_TAB / 2; k += 64) ((uint32_t*)tab)[k] = 0u;
+  for (int k = lane; k < ENC_TAB / 2; k += 64) ((__attribute__((address_space(3))) uint32_t*)tab)[k] = 0u;
 
   uint32_t ip = 0, anchor = 0, op = 0, nfail = 0;
   while (ip <= last_start) {
@@ -302,20 +305,27 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
   return op < n ? op : 0u;
 }
 
-__global__ __launch_bounds__(64 * ENC_WAVES) void k_encode_streams(StreamDesc* __restrict__ streams, int nstreams) {
-  __shared__ uint16_t tabs[ENC_WAVES][ENC_TAB];
-  const int lane = threadIdx.x & 63;
-  const int wv = threadIdx.x >> 6;
-  static_assert(ENC_WAVES == 1, "xcd_spread assumes one stream per workgroup");
-  if ((int)blockIdx.x >= nstreams) return;
-  const int sid = (int)uni(xcd_spread(blockIdx.x, (uint32_t)nstreams));
-  StreamDesc* sd = streams + sid;
+// one stream, not inlined into the queue loop (see decode_one_stream in k_decode.hip for why)
+__device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, uint16_t* tab, int lane) {
   const uint32_t n = uni((uint32_t)sd->in_size), cap = uni((uint32_t)sd->out_size);
   const int clevel = (int)uni((uint32_t)sd->aux);
   uint32_t r;
-  if (sd->fmt == FMT_LZ4) r = lz_encode_wave<EF_LZ4>(as_global(sd->in), n, as_global(sd->out), cap, clevel, tabs[wv], lane);
-  else r = lz_encode_wave<EF_BLOSCLZ>(as_global(sd->in), n, as_global(sd->out), cap, clevel, tabs[wv], lane);
+  if (sd->fmt == FMT_LZ4) r = lz_encode_wave<EF_LZ4>(as_global(sd->in), n, as_global(sd->out), cap, clevel, tab, lane);
+  else r = lz_encode_wave<EF_BLOSCLZ>(as_global(sd->in), n, as_global(sd->out), cap, clevel, tab, lane);
   if (lane == 0) sd->result = (int32_t)r;
+}
+
+// persistent waves + ticket queue, like k_decode_streams (stream costs differ by orders of magnitude)
+__global__ __launch_bounds__(64 * ENC_WAVES) void k_encode_streams(StreamDesc* __restrict__ streams, int nstreams,
+                                                                   uint32_t* __restrict__ ticket) {
+  __shared__ uint16_t tabs[ENC_WAVES][ENC_TAB];
+  static_assert(ENC_WAVES == 1, "one stream per wave, one wave per workgroup");
+  const int lane = threadIdx.x & 63;
+  uint32_t sid = take_ticket(ticket, lane);
+  while (sid < (uint32_t)nstreams) {
+    encode_one_stream(streams + sid, tabs[0], lane);
+    sid = take_ticket(ticket, lane);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -31,6 +31,15 @@ __device__ __forceinline__ uint32_t xcd_spread(uint32_t b, uint32_t n) {
   return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + idx;
 }
 
+// Next index of a global work queue, the same value in every lane.  Lane 0 draws the ticket; the value
+// is then read from lane 0 EXPLICITLY (v_readlane ignores the exec mask), so the result is right even if
+// the compiler has restructured the surrounding loop with partial exec masks.
+__device__ __forceinline__ uint32_t take_ticket(uint32_t* ticket, int lane) {
+  uint32_t t = 0;
+  if (lane == 0) t = atomicAdd(ticket, 1u);
+  return (uint32_t)__builtin_amdgcn_readlane((int)t, 0);
+}
+
 __device__ __forceinline__ uint4 ld16u(const gu8* p) { return g_ld16(p); }
 __device__ __forceinline__ void st16u(gu8* p, const uint4& v) { g_st16(p, v); }
 __device__ __forceinline__ uint32_t ld4u(const gu8* p) { return g_ld4(p); }

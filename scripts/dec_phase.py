@@ -37,3 +37,19 @@ for plane in range(8):
     tot = q[8:14].sum()
     print(f" plane {plane}: " + "  ".join(f"{names[i]}={q[i]:.0f}" for i in names) + f"  | total cyc {tot:.0f}  cyc/seq {tot / max(q[1] + q[3], 1):.0f}")
 allm = p.mean(axis=0); print(" max stream total cycles:", p[:, 8:14].sum(axis=1).max(), " mean:", p[:, 8:14].sum(axis=1).mean())
+
+
+# concurrency per XCD (s_memtime counters are per XCD): mean number of streams in flight
+raw = np.fromfile("/tmp/decprof.bin", np.uint32).reshape(-1, 16)
+hw = raw[:, 4]; xcc = raw[:, 5] & 0xf
+cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7; simd = (hw >> 4) & 3; wave = hw & 0xf
+print(" wave slot ids seen:", np.unique(wave), " simd:", np.unique(simd))
+for x in range(8):
+    m = xcc == x
+    st = raw[m, 14].astype(np.int64); en = raw[m, 15].astype(np.int64)
+    t0 = st.min(); st -= t0; en -= t0; en[en < st] += 1 << 32
+    span = en.max()
+    key = (se[m].astype(np.int64) << 8) | (sh[m].astype(np.int64) << 4) | cu[m]
+    ncu = np.unique(key).size
+    tl = [int(((st <= f * span) & (en > f * span)).sum()) for f in (0.1, 0.3, 0.5, 0.7, 0.9, 0.97)]
+    print(f" xcc {x}: streams {m.sum()} CUs {ncu} span {span * 64 / 1e6:.2f} Mticks  mean in flight {(en - st).sum() / span:.0f} ({(en - st).sum() / span / ncu:.1f}/CU)  timeline {tl}")
