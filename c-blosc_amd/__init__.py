@@ -13,7 +13,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libblosc_amd.so")
+LIB_PATH = os.environ.get("BLOSC_AMD_LIB", os.path.join(_HERE, "libblosc_amd.so"))   # override: tuning experiments only
 
 STOCK_SYMBOLS = [
     "blosc_init", "blosc_destroy", "blosc_compress", "blosc_compress_ctx", "blosc_decompress",

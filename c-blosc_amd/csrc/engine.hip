@@ -312,7 +312,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   }
   if (nstr) {
     ProfScope ps(st, stream, "k_encode_streams");
-    static const int enc_wpc = getenv("BLOSC_AMD_ENC_WPC") ? atoi(getenv("BLOSC_AMD_ENC_WPC")) : 24;
+    static const int enc_wpc = getenv("BLOSC_AMD_ENC_WPC") ? atoi(getenv("BLOSC_AMD_ENC_WPC")) : 32;
     hipLaunchKernelGGL(k_encode_streams, dim3(persistent_grid(nstr, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, (int)nstr, d_ticket);
   }
   {
@@ -448,7 +448,7 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
       ProfScope ps(st, stream, "k_decode_streams");
       // Occupancy knob: unused dynamic LDS caps how many decoder waves share a CU (and its L2 slice).
       static const int dec_lds = getenv("BLOSC_AMD_DEC_LDS") ? atoi(getenv("BLOSC_AMD_DEC_LDS")) : 0;
-      static const int dec_wpc = getenv("BLOSC_AMD_DEC_WPC") ? atoi(getenv("BLOSC_AMD_DEC_WPC")) : 24;
+      static const int dec_wpc = getenv("BLOSC_AMD_DEC_WPC") ? atoi(getenv("BLOSC_AMD_DEC_WPC")) : 32;
       const dim3 dgrid(persistent_grid(L.nstr, dec_wpc));
 #ifdef BAMD_PROFILE_DECODE
       uint32_t* d_prof = nullptr;

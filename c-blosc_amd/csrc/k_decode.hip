@@ -392,7 +392,10 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
 // by 1000x in cost (a byte plane of zeros is two sequences, a noisy plane thousands); with one
 // workgroup per stream the dispatcher kept only 4-9 waves per CU busy, with the queue every resident
 // wave stays busy until the list is empty.
-__global__ __launch_bounds__(64 * DEC_WAVES) void k_decode_streams(StreamDesc* __restrict__ streams,
+#ifndef BAMD_DEC_MINWAVES
+#define BAMD_DEC_MINWAVES 8
+#endif
+__global__ __launch_bounds__(64 * DEC_WAVES, BAMD_DEC_MINWAVES) void k_decode_streams(StreamDesc* __restrict__ streams,
                                                                    int32_t* __restrict__ status, int nstreams,
                                                                    uint32_t* __restrict__ ticket
 #ifdef BAMD_PROFILE_DECODE

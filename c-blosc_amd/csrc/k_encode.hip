@@ -80,15 +80,27 @@ enum { EF_LZ4 = 0, EF_BLOSCLZ = 1 };
 // ---- emitters --------------------------------------------------------------------------------
 // LZ4 sequence (lz4.c:1111-1226): token | litlen ext | literals | offset LE16 | matchlen ext.
 // Returns new op, or 0xffffffff when the limitedOutput budget (lz4.c:1114-1117, :1187-1211) is hit.
+// When the literal run lies inside the positions this step has just loaded (lit_lane0 >= 0: lane
+// lit_lane0 + k holds literal byte k in `ownbyte`), the bytes are taken from registers with one
+// ds_bpermute instead of being re-read from memory (saves a full memory round trip per sequence).
+__device__ __forceinline__ void emit_literals(gu8* dst, const gu8* lit, uint32_t ll, int lit_lane0, uint32_t ownbyte, int lane) {
+  if (lit_lane0 >= 0 && ll <= 64u && (uint32_t)lit_lane0 + ll <= 64u) {
+    const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lit_lane0 + (uint32_t)lane) & 63u) << 2, (int)ownbyte);
+    if ((uint32_t)lane < ll) dst[lane] = (uint8_t)v;
+  } else {
+    wave_copy_disjoint(dst, lit, ll, lane);
+  }
+}
+
 __device__ __forceinline__ uint32_t lz4_emit_seq(gu8* dst, uint32_t op, uint32_t cap, const gu8* lit,
-                                                 uint32_t ll, uint32_t off, uint32_t mlen, int lane) {
+                                                 uint32_t ll, uint32_t off, uint32_t mlen, int lit_lane0, uint32_t ownbyte, int lane) {
   if (op + 1u + ll + (2u + 1u + 5u) + ll / 255u > cap) return 0xffffffffu;
   const uint32_t mcode = mlen - 4u;
   const uint32_t tok = ((ll < 15u ? ll : 15u) << 4) | (mcode < 15u ? mcode : 15u);
   if (lane == 0) dst[op] = (uint8_t)tok;
   op += 1u;
   if (ll >= 15u) op += emit_ext255(dst + op, ll - 15u, lane);
-  wave_copy_disjoint(dst + op, lit, ll, lane);
+  emit_literals(dst + op, lit, ll, lit_lane0, ownbyte, lane);
   op += ll;
   if (lane < 2) dst[op + lane] = (uint8_t)(off >> (8 * lane));
   op += 2u;
@@ -274,7 +286,7 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
     const uint32_t ll = pm - anchor;
     const uint32_t dist = pm - cm;
     if (FMT == EF_LZ4) {
-      op = lz4_emit_seq(dst, op, cap, src + anchor, ll, dist, mlen, lane);
+      op = lz4_emit_seq(dst, op, cap, src + anchor, ll, dist, mlen, anchor >= ip ? (int)(anchor - ip) : -1, (uint32_t)own.a & 0xffu, lane);
       if (op == 0xffffffffu) return 0u;
     } else {
       op = blz_emit_literals(dst, op, cap, src + anchor, ll, lane);
@@ -316,7 +328,10 @@ __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, uint
 }
 
 // persistent waves + ticket queue, like k_decode_streams (stream costs differ by orders of magnitude)
-__global__ __launch_bounds__(64 * ENC_WAVES) void k_encode_streams(StreamDesc* __restrict__ streams, int nstreams,
+#ifndef BAMD_ENC_MINWAVES
+#define BAMD_ENC_MINWAVES 8   // waves per SIMD the register allocator must leave room for (tuned on MI355X: 8 > 6 > 4)
+#endif
+__global__ __launch_bounds__(64 * ENC_WAVES, BAMD_ENC_MINWAVES) void k_encode_streams(StreamDesc* __restrict__ streams, int nstreams,
                                                                    uint32_t* __restrict__ ticket) {
   __shared__ uint16_t tabs[ENC_WAVES][ENC_TAB];
   static_assert(ENC_WAVES == 1, "one stream per wave, one wave per workgroup");

@@ -97,12 +97,26 @@ __device__ __forceinline__ void wave_match_copy(gu8* out, uint32_t pos, uint32_t
   while (done < len) {
     uint32_t rem = len - done;
     while (off_e < 4096u && 2u * off_e <= off + done) off_e *= 2u;  // history grew: lengthen the stride
-    if (off_e >= 4096u && rem >= 4096u) {
-      // four independent 1 KiB rows per step: one memory round trip per 4 KiB instead of per 1 KiB
+    if (off_e == 1024u && (off & (off - 1u)) == 0u && rem >= 2048u) {
+      // the period divides 1024: every 1 KiB row from here on equals the previous one -> load one row,
+      // then only store (constant and short-period byte planes decode at store-issue speed)
       gu8* d = out + pos + done + 16 * lane;
-      const uint4 a0 = ld16u(d - off_e), a1 = ld16u(d - off_e + 1024), a2 = ld16u(d - off_e + 2048), a3 = ld16u(d - off_e + 3072);
-      st16u(d, a0); st16u(d + 1024, a1); st16u(d + 2048, a2); st16u(d + 3072, a3);
-      done += 4096u;
+      const uint4 row = ld16u(d - 1024);
+      while (len - done >= 1024u) { st16u(out + pos + done + 16 * lane, row); done += 1024u; }
+      continue;
+    }
+    if (off_e >= 2048u && rem >= 2048u) {
+      // up to four independent 1 KiB rows per step: one memory round trip per 2-4 KiB
+      uint32_t rows = (rem < off_e ? rem : off_e) >> 10;
+      if (rows > 4u) rows = 4u;
+      gu8* d = out + pos + done + 16 * lane;
+      uint4 a0 = ld16u(d - off_e), a1 = ld16u(d - off_e + 1024), a2 = make_uint4(0, 0, 0, 0), a3 = a2;
+      if (rows > 2u) a2 = ld16u(d - off_e + 2048);
+      if (rows > 3u) a3 = ld16u(d - off_e + 3072);
+      st16u(d, a0); st16u(d + 1024, a1);
+      if (rows > 2u) st16u(d + 2048, a2);
+      if (rows > 3u) st16u(d + 3072, a3);
+      done += rows << 10;
       continue;
     }
     uint32_t chunk = rem < 1024u ? rem : 1024u;
