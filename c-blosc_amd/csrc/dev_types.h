@@ -20,6 +20,7 @@ enum : uint32_t {
   CH_BITSHUFFLE = 2u,  // bit shuffle active (flag bit2; applied per block when bsize >= typesize)
   CH_MEMCPYED = 4u,    // payload is the raw input after the 16-byte header (flag bit1)
   CH_SKIP = 8u,        // chunk needs no device work (error found on host, or empty)
+  CH_FUSED_UNSHUF = 16u,  // decompress: the decode kernel itself unshuffles each block when its last stream is done
 };
 
 struct ChunkDesc {
@@ -60,7 +61,7 @@ struct StreamDesc {
   int32_t out_size;     // decode: neblock (must be produced exactly).  encode: slot capacity
   int32_t chunk;
   int32_t fmt;          // FMT_*
-  int32_t aux;          // encode: clevel / accel.  decode: unused
+  int32_t aux;          // encode: clevel / accel.  decode: global index of the owning block
   int32_t result;       // encode: compressed size (0 = store raw).  decode: bytes produced or <0
 };
 

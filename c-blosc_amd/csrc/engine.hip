@@ -432,8 +432,24 @@ static void add_decode_chunk(const Header& h, int fmt, int chunk_index, int32_t 
   }
 }
 
+// Deals whole blocks round-robin to 8 per-XCD queues; queue x lists the stream ids of its blocks.
+// Layout: qoff[9] (int32) followed by qlist[nstr].
+static void build_xcd_queues(const std::vector<BlockDesc>& blocks, size_t nstr, std::vector<int32_t>& out) {
+  out.assign(9 + (nstr ? nstr : 1), 0);
+  int32_t cnt[8] = {0};
+  for (size_t g = 0; g < blocks.size(); g++) cnt[g & 7] += blocks[g].nstreams;
+  int32_t off[9]; off[0] = 0;
+  for (int x = 0; x < 8; x++) off[x + 1] = off[x] + cnt[x];
+  for (int x = 0; x <= 8; x++) out[(size_t)x] = off[x];
+  int32_t fill[8];
+  for (int x = 0; x < 8; x++) fill[x] = off[x];
+  for (size_t g = 0; g < blocks.size(); g++)
+    for (int32_t s = 0; s < blocks[g].nstreams; s++) out[9 + (size_t)fill[g & 7]++] = blocks[g].first_stream + s;
+}
+
 struct DecodeLaunch {
-  ChunkDesc* d_chunks; BlockDesc* d_blocks; StreamDesc* d_streams; int32_t* d_status; uint32_t* d_ticket;
+  ChunkDesc* d_chunks; BlockDesc* d_blocks; StreamDesc* d_streams; int32_t* d_status; uint32_t* d_ticket; uint32_t* d_blkdone;
+  const int32_t* d_qlist; const int32_t* d_qoff;   // per-XCD stream queues
   size_t nblk, nstr; int nchunks;
   bool any_shuf, any_bit, any_copy; int tiles_shuf, tiles_bit;
 };
@@ -453,7 +469,7 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
 #ifdef BAMD_PROFILE_DECODE
       uint32_t* d_prof = nullptr;
       if (getenv("BLOSC_AMD_DEC_PROFILE")) { (void)hipMalloc((void**)&d_prof, L.nstr * 64); (void)hipMemsetAsync(d_prof, 0, L.nstr * 64, stream); }
-      hipLaunchKernelGGL(k_decode_streams, dgrid, dim3(64 * DEC_WAVES), (size_t)dec_lds, stream, L.d_streams, L.d_status, (int)L.nstr, L.d_ticket, d_prof);
+      hipLaunchKernelGGL(k_decode_streams, dgrid, dim3(64 * DEC_WAVES), (size_t)dec_lds, stream, L.d_streams, L.d_status, L.d_ticket, L.d_qlist, L.d_qoff, L.d_chunks, L.d_blocks, L.d_blkdone, d_prof);
       if (d_prof) {
         std::vector<uint32_t> h(L.nstr * 16);
         (void)hipStreamSynchronize(stream);
@@ -463,7 +479,7 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
         (void)hipFree(d_prof);
       }
 #else
-      hipLaunchKernelGGL(k_decode_streams, dgrid, dim3(64 * DEC_WAVES), (size_t)dec_lds, stream, L.d_streams, L.d_status, (int)L.nstr, L.d_ticket);
+      hipLaunchKernelGGL(k_decode_streams, dgrid, dim3(64 * DEC_WAVES), (size_t)dec_lds, stream, L.d_streams, L.d_status, L.d_ticket, L.d_qlist, L.d_qoff, L.d_chunks, L.d_blocks, L.d_blkdone);
 #endif
     }
     if (L.any_shuf) {
@@ -483,8 +499,11 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
   return 0;
 }
 
-static void filter_tiles(const ChunkDesc& c, bool& any_shuf, bool& any_bit, int& tiles_shuf, int& tiles_bit) {
+static bool fuse_unshuffle_enabled() { static const bool on = !(getenv("BLOSC_AMD_FUSE") && atoi(getenv("BLOSC_AMD_FUSE")) == 0); return on; }
+
+static void filter_tiles(ChunkDesc& c, bool& any_shuf, bool& any_bit, int& tiles_shuf, int& tiles_bit) {
   const int32_t T = c.typesize, N = c.blocksize / T;
+  if ((c.mode & CH_SHUFFLE) && (T == 8 || T == 4) && fuse_unshuffle_enabled()) { c.mode |= CH_FUSED_UNSHUF; return; }
   if (c.mode & CH_SHUFFLE) {
     any_shuf = true;
     int t = (N + shuffle_tile_elems(T) - 1) / shuffle_tile_elems(T); if (t < 1) t = 1;
@@ -532,7 +551,8 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   const size_t o_chunks = cv.take(sizeof(ChunkDesc) * (size_t)n);
   const size_t o_blocks = cv.take(sizeof(BlockDesc) * (nblk ? nblk : 1));
   const size_t o_streams = cv.take(sizeof(StreamDesc) * (nstr ? nstr : 1));
-  const size_t o_status = cv.take(sizeof(int32_t) * (size_t)n + 64);   // + ticket counter of the decode queue
+  const size_t o_status = cv.take(sizeof(int32_t) * (size_t)n + 64 + sizeof(uint32_t) * (nblk ? nblk : 1));   // + 8 tickets + per-block arrival counters
+  const size_t o_queues = cv.take(sizeof(int32_t) * (9 + (nstr ? nstr : 1)));
   const size_t o_filt = cv.take(filt_bytes + 256);
   if (st.dev.ensure(cv.off)) return -1;
   uint8_t* D = st.dev.base;
@@ -555,21 +575,28 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
       if (c.mode & (CH_SHUFFLE | CH_BITSHUFFLE)) { fo = align_up(fo, 256); c.filt = D + o_filt + fo; fo += (size_t)c.nbytes; }
     }
   }
+  std::vector<int32_t> queues;
+  build_xcd_queues(blocks, nstr, queues);
   Carver pc;
   const size_t p_chunks = pc.take(sizeof(ChunkDesc) * (size_t)n);
   const size_t p_blocks = pc.take(sizeof(BlockDesc) * (nblk ? nblk : 1));
   const size_t p_status = pc.take(sizeof(int32_t) * (size_t)n);
+  const size_t p_queues = pc.take(sizeof(int32_t) * queues.size());
   if (st.pin.ensure(pc.off)) return -1;
   uint8_t* P = st.pin.base;
   memcpy(P + p_chunks, chunks.data(), sizeof(ChunkDesc) * (size_t)n);
   if (nblk) memcpy(P + p_blocks, blocks.data(), sizeof(BlockDesc) * nblk);
+  memcpy(P + p_queues, queues.data(), sizeof(int32_t) * queues.size());
   HIP_TRY(hipMemcpyAsync(D + o_chunks, P + p_chunks, sizeof(ChunkDesc) * (size_t)n, hipMemcpyHostToDevice, stream));
   if (nblk) HIP_TRY(hipMemcpyAsync(D + o_blocks, P + p_blocks, sizeof(BlockDesc) * nblk, hipMemcpyHostToDevice, stream));
-  HIP_TRY(hipMemsetAsync(D + o_status, 0, sizeof(int32_t) * (size_t)n + 64, stream));
+  HIP_TRY(hipMemcpyAsync(D + o_queues, P + p_queues, sizeof(int32_t) * queues.size(), hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemsetAsync(D + o_status, 0, sizeof(int32_t) * (size_t)n + 64 + sizeof(uint32_t) * (nblk ? nblk : 1), stream));
 
   L.d_chunks = (ChunkDesc*)(D + o_chunks); L.d_blocks = (BlockDesc*)(D + o_blocks);
   L.d_streams = (StreamDesc*)(D + o_streams); L.d_status = (int32_t*)(D + o_status);
   L.d_ticket = (uint32_t*)(D + o_status + sizeof(int32_t) * (size_t)n + 32);
+  L.d_blkdone = (uint32_t*)(D + o_status + sizeof(int32_t) * (size_t)n + 64);
+  L.d_qoff = (const int32_t*)(D + o_queues); L.d_qlist = L.d_qoff + 9;
   L.nblk = nblk; L.nstr = nstr; L.nchunks = n;
   if (launch_decode(st, L, stream)) return -1;
   HIP_TRY(hipMemcpyAsync(P + p_status, D + o_status, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, stream));
@@ -646,7 +673,8 @@ int engine_getitem(const void* src, int start, int nitems, void* dest, bool src_
   const size_t o_chunks = cv.take(sizeof(ChunkDesc));
   const size_t o_blocks = cv.take(sizeof(BlockDesc) * nblk);
   const size_t o_streams = cv.take(sizeof(StreamDesc) * nstr);
-  const size_t o_status = cv.take(sizeof(int32_t) + 64);
+  const size_t o_status = cv.take(sizeof(int32_t) + 64 + sizeof(uint32_t) * nblk);
+  const size_t o_queues = cv.take(sizeof(int32_t) * (9 + nstr));
   const size_t o_out = cv.take(span + 256);
   const size_t o_filt = cv.take(span + 256);
   if (st.dev.ensure(cv.off)) return -1;
@@ -655,23 +683,30 @@ int engine_getitem(const void* src, int start, int nitems, void* dest, bool src_
   // kernels address block j at base + j*blocksize: bias the bases so that block j0 lands at offset 0
   c.dst = D + o_out - (size_t)j0 * bs;
   c.filt = (c.mode & (CH_SHUFFLE | CH_BITSHUFFLE)) ? D + o_filt - (size_t)j0 * bs : nullptr;
+  DecodeLaunch L{};
+  filter_tiles(c, L.any_shuf, L.any_bit, L.tiles_shuf, L.tiles_bit);   // may set CH_FUSED_UNSHUF: before the upload
   Carver pc;
   const size_t p_chunks = pc.take(sizeof(ChunkDesc));
   const size_t p_blocks = pc.take(sizeof(BlockDesc) * nblk);
   const size_t p_status = pc.take(sizeof(int32_t));
+  std::vector<int32_t> queues;
+  build_xcd_queues(blocks, nstr, queues);
+  const size_t p_queues = pc.take(sizeof(int32_t) * queues.size());
   if (st.pin.ensure(pc.off)) return -1;
   uint8_t* P = st.pin.base;
+  memcpy(P + p_queues, queues.data(), sizeof(int32_t) * queues.size());
   memcpy(P + p_chunks, &c, sizeof c);
   memcpy(P + p_blocks, blocks.data(), sizeof(BlockDesc) * nblk);
   HIP_TRY(hipMemcpyAsync(D + o_chunks, P + p_chunks, sizeof c, hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemcpyAsync(D + o_blocks, P + p_blocks, sizeof(BlockDesc) * nblk, hipMemcpyHostToDevice, stream));
-  HIP_TRY(hipMemsetAsync(D + o_status, 0, sizeof(int32_t) + 64, stream));
-  DecodeLaunch L{};
+  HIP_TRY(hipMemcpyAsync(D + o_queues, P + p_queues, sizeof(int32_t) * queues.size(), hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemsetAsync(D + o_status, 0, sizeof(int32_t) + 64 + sizeof(uint32_t) * nblk, stream));
   L.d_chunks = (ChunkDesc*)(D + o_chunks); L.d_blocks = (BlockDesc*)(D + o_blocks);
   L.d_streams = (StreamDesc*)(D + o_streams); L.d_status = (int32_t*)(D + o_status);
   L.d_ticket = (uint32_t*)(D + o_status + 32);
+  L.d_blkdone = (uint32_t*)(D + o_status + 68);
+  L.d_qoff = (const int32_t*)(D + o_queues); L.d_qlist = L.d_qoff + 9;
   L.nblk = nblk; L.nstr = nstr; L.nchunks = 1;
-  filter_tiles(c, L.any_shuf, L.any_bit, L.tiles_shuf, L.tiles_bit);
   if (launch_decode(st, L, stream)) return -1;
   HIP_TRY(hipMemcpyAsync(P + p_status, D + o_status, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));

@@ -38,7 +38,7 @@ __global__ void k_decode_plan(const ChunkDesc* __restrict__ chunks, const BlockD
   bool bad = false;
   for (int j = 0; j < b.nstreams; j++) {
     StreamDesc s;
-    s.chunk = b.chunk; s.fmt = c.fmt; s.aux = 0; s.result = 0;
+    s.chunk = b.chunk; s.fmt = c.fmt; s.aux = g; s.result = 0;
     s.out = out + (size_t)j * neblock; s.out_size = neblock;
     s.in = nullptr; s.in_size = -1;  // -1: nothing to decode (chain broken)
     if (!bad) {
@@ -353,10 +353,78 @@ __device__ int blosclz_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* 
 // ---------------------------------------------------------------------------------------------
 // decode kernel: persistent waves + ticket queue, block = 64 * DEC_WAVES
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// Fused byte-unshuffle of one block by ONE wavefront (typesize 4 or 8), used by the decode kernel when the
+// last stream of a block has been decoded.  Plane-major scratch -> element-major destination
+// (blosc/shuffle-generic.h:61-81).  Per step each lane loads 16 bytes of every plane (coalesced 1 KiB
+// rows), transposes bytes in registers (v_perm_b32) and stores 16-byte pieces of its own contiguous
+// T*16-byte output; the 128 steps of a 1 MiB block keep two steps of loads in flight.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void transpose4x4(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3,
+                                             uint32_t& t0, uint32_t& t1, uint32_t& t2, uint32_t& t3) {
+  // r_j = bytes (e0,e1,e2,e3) of plane j  ->  t_e = bytes (plane0,plane1,plane2,plane3) of element e
+  const uint32_t a01 = __builtin_amdgcn_perm(r1, r0, 0x05010400u), b01 = __builtin_amdgcn_perm(r1, r0, 0x07030602u);
+  const uint32_t a23 = __builtin_amdgcn_perm(r3, r2, 0x05010400u), b23 = __builtin_amdgcn_perm(r3, r2, 0x07030602u);
+  t0 = __builtin_amdgcn_perm(a23, a01, 0x05040100u); t1 = __builtin_amdgcn_perm(a23, a01, 0x07060302u);
+  t2 = __builtin_amdgcn_perm(b23, b01, 0x05040100u); t3 = __builtin_amdgcn_perm(b23, b01, 0x07060302u);
+}
+
+// One step: lane l owns elements e + 4l .. e + 4l + 3: a 4-byte load from every plane (each wave load
+// instruction reads 256 contiguous bytes of one plane), a byte transpose in registers, and T*4 contiguous
+// output bytes per lane (consecutive lanes are consecutive in memory: fully coalesced 16-byte stores).
+template <int T>
+struct Rows { uint32_t r[T]; };
+
+template <int T>
+__device__ __forceinline__ Rows<T> unshuffle_load(const gu8* src, uint32_t N, uint32_t e, int lane) {
+  Rows<T> x;
+  const uint32_t el = e + 4u * (uint32_t)lane;
+#pragma unroll
+  for (int j = 0; j < T; j++) x.r[j] = g_ld4(src + (size_t)j * N + el);
+  return x;
+}
+template <int T>
+__device__ __forceinline__ void unshuffle_store(gu8* dst, uint32_t e, int lane, const Rows<T>& x) {
+  gu8* o = dst + (size_t)(e + 4u * (uint32_t)lane) * T;
+  uint32_t t0, t1, t2, t3;
+  transpose4x4(x.r[0], x.r[1], x.r[2], x.r[3], t0, t1, t2, t3);
+  if (T == 8) {
+    uint32_t u0, u1, u2, u3;
+    transpose4x4(x.r[4], x.r[5], x.r[6], x.r[7], u0, u1, u2, u3);
+    g_st16(o, make_uint4(t0, u0, t1, u1));         // elements 0, 1 (8 bytes each)
+    g_st16(o + 16, make_uint4(t2, u2, t3, u3));    // elements 2, 3
+  } else {
+    g_st16(o, make_uint4(t0, t1, t2, t3));         // elements 0..3 (4 bytes each)
+  }
+}
+
+template <int T>
+__device__ void unshuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize, int lane) {
+  const uint32_t N = bsize / T;
+  uint32_t e = 0;
+  // 4 steps (1024 elements) per iteration: all loads are issued before the first store
+  for (; e + 1024u <= N; e += 1024u) {
+    const Rows<T> a = unshuffle_load<T>(src, N, e, lane), b = unshuffle_load<T>(src, N, e + 256u, lane);
+    const Rows<T> c = unshuffle_load<T>(src, N, e + 512u, lane), d = unshuffle_load<T>(src, N, e + 768u, lane);
+    unshuffle_store<T>(dst, e, lane, a); unshuffle_store<T>(dst, e + 256u, lane, b);
+    unshuffle_store<T>(dst, e + 512u, lane, c); unshuffle_store<T>(dst, e + 768u, lane, d);
+  }
+  for (; e + 256u <= N; e += 256u) unshuffle_store<T>(dst, e, lane, unshuffle_load<T>(src, N, e, lane));
+  // tail: fewer than 256 elements, then the bytes that do not form a whole element
+  for (uint32_t k = e * T + (uint32_t)lane; k < N * T; k += 64u) { const uint32_t el = k / T, j = k - el * T; dst[k] = src[(size_t)j * N + el]; }
+  for (uint32_t k = N * T + (uint32_t)lane; k < bsize; k += 64u) dst[k] = src[k];
+}
+
+__device__ __attribute__((noinline)) void unshuffle_block_wave(const uint8_t* src, uint8_t* dst, uint32_t bsize, int typesize, int lane) {
+  if (typesize == 8) unshuffle_block_wave_T<8>(as_global(src), as_global(dst), bsize, lane);
+  else unshuffle_block_wave_T<4>(as_global(src), as_global(dst), bsize, lane);
+}
+
 // One stream, start to finish.  Deliberately NOT inlined into the queue loop below: with the decoders
 // inlined, the compiler restructured the loop with partial exec masks and re-read the ticket with lane 0
 // masked off (an endless loop on stream 0).  A real call keeps the loop's control flow trivial.
-__device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int32_t* status, volatile uint32_t* scr, int lane
+__device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int32_t* status, volatile uint32_t* scr,
+                                                            const ChunkDesc* chunks, const BlockDesc* blocks, uint32_t* blk_done, int lane
 #ifdef BAMD_PROFILE_DECODE
                                                             , uint32_t* profslot
 #endif
@@ -385,34 +453,59 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
     sd->result = got;
     if (got != want) atomicMin(&status[sd->chunk], (int32_t)ST_BADCODEC);  // blosc.c:780-782
   }
+  // ---- fused unshuffle: the wave that completes a block's LAST stream transposes the block ----
+  const ChunkDesc* c = chunks + sd->chunk;
+  const uint32_t mode = uni(c->mode);
+  if (!(mode & CH_FUSED_UNSHUF) || got != want) return;
+  const uint32_t gb = uni((uint32_t)sd->aux);
+  const BlockDesc* b = blocks + gb;
+  // All streams of one block are handed out from the SAME per-XCD queue (see k_decode_streams), so the
+  // producers and this consumer share one L2: a store that has completed (vmcnt) is in that L2, and the
+  // consumer only has to drop its own L1 lines.  No L2 write-back (`buffer_wbl2`) is needed - with 65 536
+  // streams per launch an agent-scope release per stream flushed whole L2s and tripled the kernel time.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  uint32_t old = 0;
+  if (lane == 0) old = __hip_atomic_fetch_add(&blk_done[gb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  old = (uint32_t)__builtin_amdgcn_readlane((int)old, 0);
+  if (old + 1u != (uint32_t)uni((uint32_t)b->nstreams)) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // buffer_inv sc1: this CU's L1 forgets the block's scratch lines
+  const size_t boff = (size_t)uni((uint32_t)b->blk) * (size_t)uni((uint32_t)c->blocksize);
+  unshuffle_block_wave(c->filt + boff, c->dst + boff, uni((uint32_t)b->bsize), (int)uni((uint32_t)c->typesize), lane);
 }
 
-// Persistent launch: the grid is sized to what the chip can hold (engine.hip) and every wave pulls
-// stream indices from one global ticket counter until the list is empty.  Streams of one batch differ
-// by 1000x in cost (a byte plane of zeros is two sequences, a noisy plane thousands); with one
-// workgroup per stream the dispatcher kept only 4-9 waves per CU busy, with the queue every resident
-// wave stays busy until the list is empty.
 #ifndef BAMD_DEC_MINWAVES
-#define BAMD_DEC_MINWAVES 8
+#define BAMD_DEC_MINWAVES 7
 #endif
-__global__ __launch_bounds__(64 * DEC_WAVES, BAMD_DEC_MINWAVES) void k_decode_streams(StreamDesc* __restrict__ streams,
-                                                                   int32_t* __restrict__ status, int nstreams,
-                                                                   uint32_t* __restrict__ ticket
+// Persistent launch: the grid is sized to what the chip can hold (engine.hip) and every wave pulls stream
+// indices from a ticket queue until it is empty.  Streams of one batch differ by 1000x in cost (a byte
+// plane of zeros is two sequences, a noisy plane thousands); with one workgroup per stream the dispatcher
+// kept only 4-9 waves per CU busy, with queues every resident wave stays busy.
+// There is one queue per XCD (the host deals whole BLOCKS round-robin to the 8 queues, qlist/qoff): a wave
+// reads its XCC id and serves only that queue, so every stream of a block - and the block's fused
+// unshuffle - runs on one XCD and shares one L2.  Placement is used for speed and for the cheap hand-off
+// above; a wave that finds its own queue empty simply exits (queues are equal shares of the same work).
+__global__ __launch_bounds__(64 * DEC_WAVES, BAMD_DEC_MINWAVES) void k_decode_streams(
+    StreamDesc* __restrict__ streams, int32_t* __restrict__ status, uint32_t* __restrict__ tickets /*[8]*/,
+    const int32_t* __restrict__ qlist, const int32_t* __restrict__ qoff /*[9]*/,
+    const ChunkDesc* __restrict__ chunks, const BlockDesc* __restrict__ blocks, uint32_t* __restrict__ blk_done
 #ifdef BAMD_PROFILE_DECODE
-                                                                   , uint32_t* __restrict__ profbuf
+    , uint32_t* __restrict__ profbuf
 #endif
-                                                                   ) {
+    ) {
   __shared__ uint32_t scr[DEC_WAVES][64];   // per-wave scratch of the batched LZ4 step
   static_assert(DEC_WAVES == 1, "one stream per wave, one wave per workgroup");
   const int lane = threadIdx.x & 63;
-  uint32_t sid = take_ticket(ticket, lane);
-  while (sid < (uint32_t)nstreams) {
+  const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;   // HW_REG_XCC_ID[3:0]
+  const uint32_t qbase = (uint32_t)qoff[xcc], qlen = (uint32_t)qoff[xcc + 1] - qbase;
+  uint32_t t = take_ticket(tickets + xcc, lane);
+  while (t < qlen) {
+    const uint32_t sid = (uint32_t)qlist[qbase + t];
 #ifdef BAMD_PROFILE_DECODE
-    decode_one_stream(streams + sid, status, scr[0], lane, profbuf ? profbuf + (size_t)sid * 16 : nullptr);
+    decode_one_stream(streams + sid, status, scr[0], chunks, blocks, blk_done, lane, profbuf ? profbuf + (size_t)sid * 16 : nullptr);
 #else
-    decode_one_stream(streams + sid, status, scr[0], lane);
+    decode_one_stream(streams + sid, status, scr[0], chunks, blocks, blk_done, lane);
 #endif
-    sid = take_ticket(ticket, lane);
+    t = take_ticket(tickets + xcc, lane);
   }
 }
 
