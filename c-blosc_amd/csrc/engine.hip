@@ -313,7 +313,21 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   if (nstr) {
     ProfScope ps(st, stream, "k_encode_streams");
     static const int enc_wpc = getenv("BLOSC_AMD_ENC_WPC") ? atoi(getenv("BLOSC_AMD_ENC_WPC")) : 32;
+#ifdef BAMD_PROFILE_DECODE
+    uint32_t* d_prof = nullptr;
+    if (getenv("BLOSC_AMD_ENC_PROFILE")) { (void)hipMalloc((void**)&d_prof, nstr * 64); (void)hipMemsetAsync(d_prof, 0, nstr * 64, stream); }
+    hipLaunchKernelGGL(k_encode_streams, dim3(persistent_grid(nstr, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, (int)nstr, d_ticket, d_prof);
+    if (d_prof) {
+      std::vector<uint32_t> h(nstr * 16);
+      (void)hipStreamSynchronize(stream);
+      (void)hipMemcpy(h.data(), d_prof, nstr * 64, hipMemcpyDeviceToHost);
+      FILE* f = fopen(getenv("BLOSC_AMD_ENC_PROFILE"), "wb");
+      if (f) { fwrite(h.data(), 4, h.size(), f); fclose(f); }
+      (void)hipFree(d_prof);
+    }
+#else
     hipLaunchKernelGGL(k_encode_streams, dim3(persistent_grid(nstr, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, (int)nstr, d_ticket);
+#endif
   }
   {
     ProfScope ps(st, stream, "k_chunk_scan");

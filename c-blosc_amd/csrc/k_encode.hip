@@ -22,6 +22,17 @@
 
 namespace bamd {
 
+// Optional phase profiling of the encoder (prof build, scripts/enc_phase.py); same slot layout as k_decode.hip's.
+// slots: 0 steps, 1 steps without a match, 2 forward extensions, 3 literal runs copied from memory, 6 window refills
+//        8 cycles: window+probe, 9 candidates+select, 10 extension, 11 emit, 12 tail
+#ifdef BAMD_PROFILE_DECODE
+#define EPROF_ARG , DecProf& prof_
+#define EPROF_PASS , prof_
+#else
+#define EPROF_ARG
+#define EPROF_PASS
+#endif
+
 constexpr int ENC_WAVES = 1;       // one stream per workgroup: a slot frees up as soon as ITS stream is done
 constexpr int ENC_HASH_BITS = 11;   // 2048 x u16 = 4 KiB of LDS per wave -> 32 waves per CU
 constexpr int ENC_TAB = 1 << ENC_HASH_BITS;
@@ -30,11 +41,40 @@ __device__ __forceinline__ uint32_t enc_hash(uint32_t seq) { return (seq * 26544
 
 __device__ __forceinline__ uint64_t ld8u(const gu8* p) { return g_ld8(p); }
 
+// leading equal bytes (0..16) of two 16-byte groups
+__device__ __forceinline__ uint32_t common16(const uint4& x, const uint4& y) {
+  const uint64_t lo = ((uint64_t)(x.y ^ y.y) << 32) | (x.x ^ y.x);
+  const uint64_t hi = ((uint64_t)(x.w ^ y.w) << 32) | (x.z ^ y.z);
+  if (lo) return (uint32_t)__builtin_ctzll(lo) >> 3;
+  return hi ? 8u + ((uint32_t)__builtin_ctzll(hi) >> 3) : 16u;
+}
+
 // number of leading equal bytes of src[a..] and src[b..], at most `maxlen`; a > b, wave-uniform
 // arguments, wave-uniform result.  Never reads at or beyond src + n.
+// Long matches dominate some byte planes (a constant plane is ONE 128 KiB match), so the bulk is
+// compared 2 KiB per memory round trip (two 1 KiB rows, all four loads in flight together) with the
+// exact mismatch byte found in the same trip; only the last < 2 KiB of a stream go 512 bytes per
+// step through byte-safe loads.
 __device__ __forceinline__ uint32_t wave_common_fwd(const gu8* src, uint32_t n, uint32_t a, uint32_t b,
                                                     uint32_t maxlen, int lane) {
   uint32_t done = 0;
+  while (done < maxlen && a + done + 2048u <= n) {
+    const gu8* pa = src + a + done + 16 * lane;
+    const gu8* pb = src + b + done + 16 * lane;
+    const uint4 x0 = g_ld16(pa), x1 = g_ld16(pa + 1024);
+    const uint4 y0 = g_ld16(pb), y1 = g_ld16(pb + 1024);
+    const uint32_t q = done + 16u * (uint32_t)lane;                 // this lane's first byte in row 0 (relative)
+    uint32_t e0 = common16(x0, y0), e1 = common16(x1, y1);
+    const uint32_t r0 = q < maxlen ? maxlen - q : 0u;               // bytes this lane may count
+    const uint32_t r1 = q + 1024u < maxlen ? maxlen - q - 1024u : 0u;
+    if (e0 > r0) e0 = r0;
+    if (e1 > r1) e1 = r1;
+    const uint64_t s0 = __ballot(e0 < 16u);
+    if (s0) { const int f = __builtin_ctzll(s0); return done + 16u * (uint32_t)f + (uint32_t)__builtin_amdgcn_readlane((int)e0, f); }
+    const uint64_t s1 = __ballot(e1 < 16u);
+    if (s1) { const int f = __builtin_ctzll(s1); return done + 1024u + 16u * (uint32_t)f + (uint32_t)__builtin_amdgcn_readlane((int)e1, f); }
+    done += 2048u;
+  }
   while (done < maxlen) {
     const uint32_t q = done + 8u * (uint32_t)lane;     // this lane's first byte (relative)
     uint32_t vb = 0;                                     // bytes this lane may compare
@@ -57,14 +97,6 @@ __device__ __forceinline__ uint32_t wave_common_fwd(const gu8* src, uint32_t n, 
     done += 512u;
   }
   return maxlen;
-}
-
-// number of equal bytes going backwards from src[a-1], src[b-1]; at most maxlen (<= 64)
-__device__ __forceinline__ uint32_t wave_common_bwd(const gu8* src, uint32_t a, uint32_t b, uint32_t maxlen, int lane) {
-  bool ne = true;
-  if ((uint32_t)lane < maxlen) ne = src[a - 1u - lane] != src[b - 1u - lane];
-  const uint64_t m = __ballot(ne);
-  return m ? (uint32_t)__builtin_ctzll(m) : 64u;  // lanes >= maxlen always vote "differs"
 }
 
 // write `v` as LZ4's 255-run length extension starting at p; returns bytes written
@@ -203,15 +235,62 @@ __device__ __forceinline__ uint32_t runlen20(const Bytes20& x, uint32_t v) {
   Bytes20 y; y.a = rep; y.b = rep; y.c = (uint32_t)rep;
   return common20(x, y);
 }
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) { uint32_t t = (uint32_t)__shfl_xor((int)v, o, 64); v = t > v ? t : v; }
-  return v;
+template <int N> __device__ __forceinline__ uint32_t dpp_row_shr0(uint32_t v) {   // lane i <- lane i-N of its 16-lane row, 0 outside
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + N, 0xf, 0xf, true);
 }
+// wave-wide unsigned max, uniform result: four DPP steps inside each 16-lane row, then the four row
+// maxima through SGPRs (no LDS-pipe traffic, unlike a butterfly of ds_bpermutes)
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+  uint32_t t;
+  t = dpp_row_shr0<1>(v); v = t > v ? t : v;
+  t = dpp_row_shr0<2>(v); v = t > v ? t : v;
+  t = dpp_row_shr0<4>(v); v = t > v ? t : v;
+  t = dpp_row_shr0<8>(v); v = t > v ? t : v;
+  const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 15), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 31);
+  const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 47), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+  const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
+  return ab > cd ? ab : cd;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Input window: 768 bytes of the stream in three VGPRs (lane L of w_i holds the dword at
+// wbase + 256 i + 4 L).  The positions a step looks at always lie in w0/w1; w2 is fetched one
+// 256-byte stride ahead, so its latency is hidden behind the steps in between.  A step gets its
+// own 20 bytes per lane with ds_bpermutes from here instead of a memory round trip.
+// ---------------------------------------------------------------------------------------------
+struct EncWindow {
+  uint32_t w0, w1, w2;
+  uint32_t wbase;          // uniform, multiple of 256
+  const gu8* src;
+  uint32_t n;
+
+  // dword at stream offset base + 4*lane; bytes at or beyond n read as zero.  Branch-free: a dword that
+  // would cross the end is read at n-4 instead and shifted down (n >= 13 here).
+  __device__ __forceinline__ uint32_t fetch(uint32_t base, int lane) const {
+    const uint32_t off = base + 4u * (uint32_t)lane;
+    const uint32_t a = off < n - 4u ? off : n - 4u;
+    const uint32_t sh = off - a;                       // 0 in the body of the stream
+    const uint32_t v = g_ld4(src + a);
+    return sh < 4u ? v >> (8u * sh) : 0u;
+  }
+  __device__ __forceinline__ void init(const gu8* s, uint32_t n_, int lane) {
+    src = s; n = n_; wbase = 0;
+    w0 = fetch(0u, lane); w1 = fetch(256u, lane); w2 = fetch(512u, lane);
+  }
+  // make [lo, lo + 256 + 92) resident in w0/w1, lo = max(ip - 4, 0); ip only moves forward
+  __device__ __forceinline__ void seek(uint32_t ip, int lane) {
+    const uint32_t lo = ip >= 4u ? ip - 4u : 0u;
+    const uint32_t d = lo - wbase;
+    if (d < 256u) return;
+    if (d < 512u) { w0 = w1; w1 = w2; wbase += 256u; w2 = fetch(wbase + 512u, lane); }
+    else if (d < 768u) { w0 = w2; wbase += 512u; w1 = fetch(wbase + 256u, lane); w2 = fetch(wbase + 512u, lane); }
+    else { wbase = lo & ~255u; w0 = fetch(wbase, lane); w1 = fetch(wbase + 256u, lane); w2 = fetch(wbase + 512u, lane); }
+  }
+};
 
 template <int FMT>
 __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8* __restrict__ dst, uint32_t cap,
-                                   int clevel, uint16_t* tab_generic, int lane) {
+                                   int clevel, uint16_t* tab_generic, int lane EPROF_ARG) {
   // the table lives in LDS; say so explicitly (a generic pointer in a non-inlined function would make
   // every probe a flat_load)
   __attribute__((address_space(3))) uint16_t* tab = (__attribute__((address_space(3))) uint16_t*)tab_generic;
@@ -224,24 +303,58 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
 
   for (int k = lane; k < ENC_TAB / 2; k += 64) ((__attribute__((address_space(3))) uint32_t*)tab)[k] = 0u;
 
+  EncWindow win;
+  win.init(src, n, lane);
   uint32_t ip = 0, anchor = 0, op = 0, nfail = 0;
+  bool ins_pending = false;                       // position ip-2 still has to enter the table (lz4.c:1236-1242)
   while (ip <= last_start) {
     const uint32_t p = ip + (uint32_t)lane;
     const bool live = p <= last_start;
-    // ---- round 1: own bytes + table probe ----
-    Bytes20 own = {0, 0, 0};
-    uint32_t prev = 0x100u;                       // "no previous byte"
+    // ---- round 1 (registers + LDS only): own bytes from the window, table probe ----
+    win.seek(ip, lane);
+    const uint32_t lo = ip >= 4u ? ip - 4u : 0u;
+    const uint32_t rb = lo & ~3u;                                   // stream offset of r's lane 0
+    const uint32_t D = (rb - win.wbase) >> 2;                       // < 64
+    const int gsel = (int)((D + (uint32_t)lane) << 2);
+    const uint32_t ra = (uint32_t)__builtin_amdgcn_ds_bpermute(gsel, (int)win.w0);
+    const uint32_t rc = (uint32_t)__builtin_amdgcn_ds_bpermute(gsel, (int)win.w1);
+    const uint32_t r = (D + (uint32_t)lane < 64u) ? ra : rc;        // lane j: dword at rb + 4j (j <= 23 is all that is used)
+    const uint32_t bo0 = ip - rb;                                   // 4..7 (or ip when ip < 4)
+    const uint32_t bo = bo0 + (uint32_t)lane;
+    const int ksel = (int)((bo >> 2) << 2);
+    const uint32_t x0 = (uint32_t)__builtin_amdgcn_ds_bpermute(ksel, (int)r);
+    const uint32_t x1 = (uint32_t)__builtin_amdgcn_ds_bpermute(ksel + 4, (int)r);
+    const uint32_t x2 = (uint32_t)__builtin_amdgcn_ds_bpermute(ksel + 8, (int)r);
+    const uint32_t x3 = (uint32_t)__builtin_amdgcn_ds_bpermute(ksel + 12, (int)r);
+    const uint32_t x4 = (uint32_t)__builtin_amdgcn_ds_bpermute(ksel + 16, (int)r);
+    const uint32_t x5 = (uint32_t)__builtin_amdgcn_ds_bpermute(ksel + 20, (int)r);
+    const uint32_t sh = bo & 3u;
+    const uint32_t o0 = __builtin_amdgcn_alignbyte(x1, x0, sh), o1 = __builtin_amdgcn_alignbyte(x2, x1, sh);
+    const uint32_t o2 = __builtin_amdgcn_alignbyte(x3, x2, sh), o3 = __builtin_amdgcn_alignbyte(x4, x3, sh);
+    const uint32_t o4 = __builtin_amdgcn_alignbyte(x5, x4, sh);
+    Bytes20 own;
+    own.a = ((uint64_t)o1 << 32) | o0; own.b = ((uint64_t)o3 << 32) | o2; own.c = o4;
+    // the two bytes before ip (uniform): r's lanes 0/1 hold them
+    const uint64_t r01 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)r, 1) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)r, 0);
+    const uint32_t before2 = bo0 >= 2u ? (uint32_t)(r01 >> (8u * (bo0 - 2u))) & 0xffffu : 0u;   // src[ip-2] | src[ip-1] << 8
+    uint32_t prev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane - 1u) & 63u) << 2, (int)(o0 & 0xffu));
+    if (lane == 0) prev = ip ? (bo0 >= 2u ? before2 >> 8 : (uint32_t)(r01 >> (8u * (bo0 - 1u))) & 0xffu) : 0x100u;
+    if (ins_pending) {
+      if (lane == 0) tab[enc_hash(before2 | (o0 << 16))] = (uint16_t)(ip - 2u);
+      ins_pending = false;
+    }
     uint32_t h = 0, cand = 0, limit = 0;
     bool tab_ok = false;
     if (live) {
-      own = load20(src, p, n);
-      if (p > 0u) prev = src[p - 1u];
       limit = mlimit - p; if (limit > RANK_CAP) limit = RANK_CAP;     // bytes of a match starting at p that may be counted
-      h = enc_hash((uint32_t)own.a);
+      h = enc_hash(o0);
       const uint32_t e = tab[h];
       const uint32_t d = (p - e) & 0xffffu;
       if (d != 0u && d <= p) { cand = p - d; tab_ok = true; }
+    } else {
+      prev = 0x100u;
     }
+    PROF_LAP(8); PROF_ADD(0, 1);
     // ---- round 2: candidate bytes, exact lengths up to RANK_CAP ----
     uint32_t len = 0;
     if (tab_ok) {
@@ -259,7 +372,9 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
     // ---- select: maximise (len - lane), ties to the lower lane ----
     const uint32_t key = len ? (((len + 64u - (uint32_t)lane) << 6) | (63u - (uint32_t)lane)) : 0u;
     const uint32_t best = wave_max_u32(key);
+    PROF_LAP(9);
     if (best == 0u) {
+      PROF_ADD(1, 1);
       if (live) tab[h] = (uint16_t)p;
       nfail++;
       uint32_t adv = 1u + (nfail * (uint32_t)accel) / 16u;   // skip faster through incompressible data
@@ -277,11 +392,17 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
     uint32_t maxb = pm - anchor;
     if (cm < maxb) maxb = cm;
     if (maxb > 64u) maxb = 64u;
-    uint32_t back = 0;
-    if (maxb) { back = wave_common_bwd(src, pm, cm, maxb, lane); if (back > maxb) back = maxb; }
+    // backward bytes are requested first and looked at last, so that they travel together with the
+    // forward rows (one memory round trip for both directions)
+    uint32_t bx = 0, by = 1;
+    if ((uint32_t)lane < maxb) { bx = src[pm - 1u - (uint32_t)lane]; by = src[cm - 1u - (uint32_t)lane]; }
+    asm volatile("" ::: "memory");
     uint32_t mlen = len_f;
     if (len_f == RANK_CAP && pm + RANK_CAP < mlimit)
       mlen += wave_common_fwd(src, n, pm + RANK_CAP, cm + RANK_CAP, mlimit - (pm + RANK_CAP), lane);
+    const uint64_t bm = __ballot(bx != by);          // lanes >= maxb always vote "differs"
+    const uint32_t back = bm ? (uint32_t)__builtin_ctzll(bm) : 64u;
+    PROF_LAP(10); PROF_ADD(2, len_f == RANK_CAP); PROF_ADD(3, anchor < ip && pm > anchor);
     pm -= back; cm -= back; mlen += back;
     const uint32_t ll = pm - anchor;
     const uint32_t dist = pm - cm;
@@ -297,7 +418,9 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
     anchor = pm + mlen;
     ip = anchor;
     // like the reference, remember the position two bytes before the new anchor (lz4.c:1236-1242)
-    if (lane == 0 && anchor >= 2u && anchor - 2u <= last_start) tab[enc_hash(g_ld4(src + anchor - 2u))] = (uint16_t)(anchor - 2u);
+    // (done at the top of the next step, where those bytes are in registers)
+    ins_pending = true;
+    PROF_LAP(11);
   }
   // closing literals
   if (FMT == EF_LZ4) {
@@ -314,17 +437,27 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
     const float floor_ratio[10] = {0.f, 2.f, 1.5f, 1.2f, 1.2f, 1.2f, 1.2f, 1.15f, 1.1f, 1.0f};
     if ((float)n < floor_ratio[clevel] * (float)op) return 0u;
   }
+  PROF_LAP(12);
   return op < n ? op : 0u;
 }
 
 // one stream, not inlined into the queue loop (see decode_one_stream in k_decode.hip for why)
-__device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, uint16_t* tab, int lane) {
+__device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, uint16_t* tab, int lane
+#ifdef BAMD_PROFILE_DECODE
+                                                            , uint32_t* profslot
+#endif
+                                                            ) {
+  PROF_DECL
   const uint32_t n = uni((uint32_t)sd->in_size), cap = uni((uint32_t)sd->out_size);
   const int clevel = (int)uni((uint32_t)sd->aux);
   uint32_t r;
-  if (sd->fmt == FMT_LZ4) r = lz_encode_wave<EF_LZ4>(as_global(sd->in), n, as_global(sd->out), cap, clevel, tab, lane);
-  else r = lz_encode_wave<EF_BLOSCLZ>(as_global(sd->in), n, as_global(sd->out), cap, clevel, tab, lane);
+  if (sd->fmt == FMT_LZ4) r = lz_encode_wave<EF_LZ4>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, lane EPROF_PASS);
+  else r = lz_encode_wave<EF_BLOSCLZ>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, lane EPROF_PASS);
   if (lane == 0) sd->result = (int32_t)r;
+#ifdef BAMD_PROFILE_DECODE
+  prof_.c[15] = (uint32_t)(prof_.t0 >> 6);
+  if (lane == 0 && profslot) for (int i_ = 0; i_ < 16; i_++) profslot[i_] = prof_.c[i_];
+#endif
 }
 
 // persistent waves + ticket queue, like k_decode_streams (stream costs differ by orders of magnitude)
@@ -332,13 +465,21 @@ __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, uint
 #define BAMD_ENC_MINWAVES 8   // waves per SIMD the register allocator must leave room for (tuned on MI355X: 8 > 6 > 4)
 #endif
 __global__ __launch_bounds__(64 * ENC_WAVES, BAMD_ENC_MINWAVES) void k_encode_streams(StreamDesc* __restrict__ streams, int nstreams,
-                                                                   uint32_t* __restrict__ ticket) {
+                                                                   uint32_t* __restrict__ ticket
+#ifdef BAMD_PROFILE_DECODE
+                                                                   , uint32_t* __restrict__ profbuf
+#endif
+                                                                   ) {
   __shared__ uint16_t tabs[ENC_WAVES][ENC_TAB];
   static_assert(ENC_WAVES == 1, "one stream per wave, one wave per workgroup");
   const int lane = threadIdx.x & 63;
   uint32_t sid = take_ticket(ticket, lane);
   while (sid < (uint32_t)nstreams) {
+#ifdef BAMD_PROFILE_DECODE
+    encode_one_stream(streams + sid, tabs[0], lane, profbuf ? profbuf + (size_t)sid * 16 : nullptr);
+#else
     encode_one_stream(streams + sid, tabs[0], lane);
+#endif
     sid = take_ticket(ticket, lane);
   }
 }

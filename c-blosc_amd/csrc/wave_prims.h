@@ -18,6 +18,16 @@
 namespace bamd {
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+// a pointer every lane agrees on, moved into SGPRs: accesses off it become `global_* v, voffset32, s[base]`
+// instead of 64-bit VALU address arithmetic (function arguments and loaded pointers arrive in VGPRs)
+__device__ __forceinline__ const gu8* uni_ptr(const gu8* p) {
+  const uint64_t v = (uint64_t)p;
+  return (const gu8*)(((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v));
+}
+__device__ __forceinline__ gu8* uni_ptr(gu8* p) {
+  const uint64_t v = (uint64_t)p;
+  return (gu8*)(((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v));
+}
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // Workgroup -> work-item remap for one-stream-per-workgroup kernels.  Workgroup b runs on XCD b % 8
