@@ -24,6 +24,7 @@ namespace bamd {
 
 // Optional phase profiling of the encoder (prof build, scripts/enc_phase.py); same slot layout as k_decode.hip's.
 // slots: 0 steps, 1 steps without a match, 2 forward extensions, 3 literal runs copied from memory, 6 window refills
+//        6 sequences
 //        8 cycles: window+probe, 9 candidates+select, 10 extension, 11 emit, 12 tail
 #ifdef BAMD_PROFILE_DECODE
 #define EPROF_ARG , DecProf& prof_
@@ -204,6 +205,9 @@ __device__ __forceinline__ uint32_t blz_emit_match(gu8* dst, uint32_t op, uint32
 //            findable
 //   round 3  backward + forward extension loads are issued together; then the sequence is emitted.
 // ---------------------------------------------------------------------------------------------
+#ifndef BAMD_ENC_BWD
+#define BAMD_ENC_BWD 2
+#endif
 constexpr uint32_t RANK_CAP = 20u;   // 4 verified + 16 ranked bytes
 
 struct Bytes20 { uint64_t a, b; uint32_t c; };
@@ -369,11 +373,63 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
       if (rl > limit) rl = limit;
       if (rl >= 4u && rl > len) { len = rl; cand = p - 1u; }
     }
-    // ---- select: maximise (len - lane), ties to the lower lane ----
-    const uint32_t key = len ? (((len + 64u - (uint32_t)lane) << 6) | (63u - (uint32_t)lane)) : 0u;
-    const uint32_t best = wave_max_u32(key);
+    // ---- select + emit.  The winner maximises (len - lane), ties to the lower lane.  When its match
+    // ends inside this step's 64 positions, the lanes behind it still hold valid candidates: pick
+    // again among them instead of paying a new probe + candidate round trip for a short advance. ----
+    const uint32_t step_end = ip + 64u;
+    uint32_t lane_lo = 0;                         // first lane not covered by a sequence emitted in this step
+    bool any = false;
     PROF_LAP(9);
-    if (best == 0u) {
+    for (;;) {
+      const uint32_t key = (len && (uint32_t)lane >= lane_lo) ? (((len + 64u - (uint32_t)lane) << 6) | (63u - (uint32_t)lane)) : 0u;
+      const uint32_t best = wave_max_u32(key);
+      if (best == 0u) break;
+      any = true;
+      const int f = 63 - (int)(best & 63u);
+      if (live && (uint32_t)lane >= lane_lo && lane <= f) tab[h] = (uint16_t)p;
+      uint32_t pm = ip + (uint32_t)f;
+      uint32_t cm = (uint32_t)__builtin_amdgcn_readlane((int)cand, f);
+      const uint32_t len_f = (uint32_t)__builtin_amdgcn_readlane((int)len, f);
+      // ---- round 3: extensions ----
+      uint32_t maxb = pm - anchor;
+      if (cm < maxb) maxb = cm;
+      if (maxb > 64u) maxb = 64u;
+#if BAMD_ENC_BWD == 0
+      maxb = 0;
+#elif BAMD_ENC_BWD == 1
+      if (lane_lo) maxb = 0;
+#endif
+      // backward bytes are requested first and looked at last, so that they travel together with the
+      // forward rows (one memory round trip for both directions)
+      uint32_t bx = 0, by = 1;
+      if ((uint32_t)lane < maxb) { bx = src[pm - 1u - (uint32_t)lane]; by = src[cm - 1u - (uint32_t)lane]; }
+      asm volatile("" ::: "memory");
+      uint32_t mlen = len_f;
+      if (len_f == RANK_CAP && pm + RANK_CAP < mlimit)
+        mlen += wave_common_fwd(src, n, pm + RANK_CAP, cm + RANK_CAP, mlimit - (pm + RANK_CAP), lane);
+      const uint64_t bm = __ballot(bx != by);          // lanes >= maxb always vote "differs"
+      const uint32_t back = bm ? (uint32_t)__builtin_ctzll(bm) : 64u;
+      PROF_LAP(10); PROF_ADD(2, len_f == RANK_CAP); PROF_ADD(3, anchor < ip && pm > anchor); PROF_ADD(6, 1); PROF_ADD(7, back > 0); PROF_ADD(4, back > 4); PROF_ADD(5, maxb > 0);
+      pm -= back; cm -= back; mlen += back;
+      const uint32_t ll = pm - anchor;
+      const uint32_t dist = pm - cm;
+      if (FMT == EF_LZ4) {
+        op = lz4_emit_seq(dst, op, cap, src + anchor, ll, dist, mlen, anchor >= ip ? (int)(anchor - ip) : -1, (uint32_t)own.a & 0xffu, lane);
+        if (op == 0xffffffffu) return 0u;
+      } else {
+        op = blz_emit_literals(dst, op, cap, src + anchor, ll, lane);
+        if (op == 0xffffffffu) return 0u;
+        op = blz_emit_match(dst, op, cap, dist, mlen, lane);
+        if (op == 0xffffffffu) return 0u;
+      }
+      anchor = pm + mlen;
+      PROF_LAP(11);
+      if (anchor >= step_end) break;
+      lane_lo = anchor - ip;                      // >= 4
+      // like the reference, remember the position two bytes before the new anchor (lz4.c:1236-1242)
+      if (live && (uint32_t)lane + 2u == lane_lo) tab[h] = (uint16_t)p;
+    }
+    if (!any) {
       PROF_ADD(1, 1);
       if (live) tab[h] = (uint16_t)p;
       nfail++;
@@ -383,44 +439,13 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
       continue;
     }
     nfail = 0;
-    const int f = 63 - (int)(best & 63u);
-    if (live && lane <= f) tab[h] = (uint16_t)p;
-    uint32_t pm = ip + (uint32_t)f;
-    uint32_t cm = (uint32_t)__builtin_amdgcn_readlane((int)cand, f);
-    const uint32_t len_f = (uint32_t)__builtin_amdgcn_readlane((int)len, f);
-    // ---- round 3: extensions ----
-    uint32_t maxb = pm - anchor;
-    if (cm < maxb) maxb = cm;
-    if (maxb > 64u) maxb = 64u;
-    // backward bytes are requested first and looked at last, so that they travel together with the
-    // forward rows (one memory round trip for both directions)
-    uint32_t bx = 0, by = 1;
-    if ((uint32_t)lane < maxb) { bx = src[pm - 1u - (uint32_t)lane]; by = src[cm - 1u - (uint32_t)lane]; }
-    asm volatile("" ::: "memory");
-    uint32_t mlen = len_f;
-    if (len_f == RANK_CAP && pm + RANK_CAP < mlimit)
-      mlen += wave_common_fwd(src, n, pm + RANK_CAP, cm + RANK_CAP, mlimit - (pm + RANK_CAP), lane);
-    const uint64_t bm = __ballot(bx != by);          // lanes >= maxb always vote "differs"
-    const uint32_t back = bm ? (uint32_t)__builtin_ctzll(bm) : 64u;
-    PROF_LAP(10); PROF_ADD(2, len_f == RANK_CAP); PROF_ADD(3, anchor < ip && pm > anchor);
-    pm -= back; cm -= back; mlen += back;
-    const uint32_t ll = pm - anchor;
-    const uint32_t dist = pm - cm;
-    if (FMT == EF_LZ4) {
-      op = lz4_emit_seq(dst, op, cap, src + anchor, ll, dist, mlen, anchor >= ip ? (int)(anchor - ip) : -1, (uint32_t)own.a & 0xffu, lane);
-      if (op == 0xffffffffu) return 0u;
+    if (anchor >= step_end) {
+      ip = anchor;
+      ins_pending = true;                         // anchor-2 enters the table at the top of the next step (bytes in registers there)
     } else {
-      op = blz_emit_literals(dst, op, cap, src + anchor, ll, lane);
-      if (op == 0xffffffffu) return 0u;
-      op = blz_emit_match(dst, op, cap, dist, mlen, lane);
-      if (op == 0xffffffffu) return 0u;
+      if (live && (uint32_t)lane >= lane_lo) tab[h] = (uint16_t)p;   // nothing more to find behind the last match
+      ip = step_end;
     }
-    anchor = pm + mlen;
-    ip = anchor;
-    // like the reference, remember the position two bytes before the new anchor (lz4.c:1236-1242)
-    // (done at the top of the next step, where those bytes are in registers)
-    ins_pending = true;
-    PROF_LAP(11);
   }
   // closing literals
   if (FMT == EF_LZ4) {
@@ -448,6 +473,9 @@ __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, uint
 #endif
                                                             ) {
   PROF_DECL
+#ifdef BAMD_PROFILE_DECODE
+  prof_.c[4] = 0; prof_.c[5] = 0;
+#endif
   const uint32_t n = uni((uint32_t)sd->in_size), cap = uni((uint32_t)sd->out_size);
   const int clevel = (int)uni((uint32_t)sd->aux);
   uint32_t r;

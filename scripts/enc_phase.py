@@ -22,7 +22,7 @@ lib.blosc_gpu_profile(0)
 d = mod.profile_get("k_encode_streams")
 p = np.fromfile("/tmp/encprof.bin", np.uint32).reshape(-1, 16).astype(np.float64)
 print(f"{dname} {codec.decode()}: kernel {d[0]/d[1]:.3f} ms (instrumented), streams {p.shape[0]}, ratio {csz/bc.results()[0]:.2f}")
-names = {0: "steps", 1: "nomatch", 2: "fwd_ext", 3: "lit_mem", 8: "cyc_probe", 9: "cyc_cand", 10: "cyc_ext", 11: "cyc_emit", 12: "cyc_tail"}
+names = {0: "steps", 1: "nomatch", 6: "seqs", 2: "fwd_ext", 5: "bwd_tried", 7: "bwd>0", 4: "bwd>4", 3: "lit_mem", 8: "cyc_probe", 9: "cyc_cand", 10: "cyc_ext", 11: "cyc_emit", 12: "cyc_tail"}
 for plane in range(8):
     q = p[plane::8].mean(axis=0)
     tot = q[8:13].sum()
