@@ -21,6 +21,7 @@ enum : uint32_t {
   CH_MEMCPYED = 4u,    // payload is the raw input after the 16-byte header (flag bit1)
   CH_SKIP = 8u,        // chunk needs no device work (error found on host, or empty)
   CH_FUSED_UNSHUF = 16u,  // decompress: the decode kernel itself unshuffles each block when its last stream is done
+  CH_FUSED_SHUF = 32u,    // compress: the encode kernel itself shuffles each block (queue task) before its streams are encoded
 };
 
 struct ChunkDesc {
@@ -61,7 +62,7 @@ struct StreamDesc {
   int32_t out_size;     // decode: neblock (must be produced exactly).  encode: slot capacity
   int32_t chunk;
   int32_t fmt;          // FMT_*
-  int32_t aux;          // encode: clevel / accel.  decode: global index of the owning block
+  int32_t aux;          // encode: clevel | (global block index << 4).  decode: global index of the owning block
   int32_t result;       // encode: compressed size (0 = store raw).  decode: bytes produced or <0
 };
 

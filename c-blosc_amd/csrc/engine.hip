@@ -138,7 +138,9 @@ static unsigned persistent_grid(size_t nitems, int waves_per_cu) {
   static int cus = 0;
   if (!cus) { hipDeviceProp_t pr; int dev = 0; (void)hipGetDevice(&dev); if (hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount; if (cus <= 0) cus = 256; }
   size_t g = (size_t)cus * (size_t)waves_per_cu;
-  return (unsigned)(nitems < g ? nitems : g);
+  if (nitems < g) g = nitems;
+  // workgroups are dealt round-robin to the 8 XCDs and every XCD serves only its own queue: never fewer than 8
+  return (unsigned)(g < 8 ? 8 : g);
 }
 
 static dim3 grid1(size_t n, int per) { return dim3((unsigned)((n + per - 1) / per)); }
@@ -146,6 +148,37 @@ static dim3 grid1(size_t n, int per) { return dim3((unsigned)((n + per - 1) / pe
 // ---------------------------------------------------------------------------------------------
 // compress
 // ---------------------------------------------------------------------------------------------
+// BLOSC_AMD_FUSE=0 keeps the byte (un)shuffle in kernels of its own (k_shuffle / k_unshuffle) instead of
+// running it as work of the encode / decode kernels
+static bool fuse_enabled() { static const bool on = !(getenv("BLOSC_AMD_FUSE") && atoi(getenv("BLOSC_AMD_FUSE")) == 0); return on; }
+
+// Per-XCD task queues of the encode kernel: out = off[9] | entries.  Block g belongs to XCD g & 7; an
+// entry >= 0 is a stream index, an entry < 0 the shuffle task of block -(entry+1).  A block's shuffle
+// task is queued kEncLookahead blocks ahead of its streams: by the time a wave draws one of the streams
+// the transpose is normally finished, and it is always already owned by a running wave (no deadlock).
+constexpr size_t kEncLookahead = 32;
+static void build_encode_queues(const std::vector<BlockDesc>& blocks, const std::vector<ChunkDesc>& chunks, std::vector<int32_t>& out) {
+  std::vector<int32_t> q[8];
+  std::vector<uint32_t> mine[8];
+  for (size_t g = 0; g < blocks.size(); g++) if (blocks[g].nstreams > 0) mine[g & 7].push_back((uint32_t)g);
+  for (int x = 0; x < 8; x++) {
+    const std::vector<uint32_t>& B = mine[x];
+    auto push_shuffle = [&](size_t i) {
+      if (chunks[(size_t)blocks[B[i]].chunk].mode & CH_FUSED_SHUF) q[x].push_back(-(int32_t)B[i] - 1);
+    };
+    for (size_t i = 0; i < B.size() && i < kEncLookahead; i++) push_shuffle(i);
+    for (size_t i = 0; i < B.size(); i++) {
+      if (i + kEncLookahead < B.size()) push_shuffle(i + kEncLookahead);
+      const BlockDesc& b = blocks[B[i]];
+      for (int32_t k = 0; k < b.nstreams; k++) q[x].push_back(b.first_stream + k);
+    }
+  }
+  out.assign(9, 0);
+  for (int x = 0; x < 8; x++) { out[(size_t)x + 1] = out[(size_t)x] + (int32_t)q[x].size(); }
+  for (int x = 0; x < 8; x++) out.insert(out.end(), q[x].begin(), q[x].end());
+  if (out.size() == 9) out.push_back(0);
+}
+
 int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* results, bool device_ptrs,
                           hipStream_t stream) {
   EngineState& st = S();
@@ -198,7 +231,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
     c.mode = 0;
     c.first_block = (int32_t)blocks.size(); c.first_stream = (int32_t)streams.size();
     if (memcpyed) c.mode |= CH_MEMCPYED;
-    else if (p.doshuffle == 1 && T > 1) c.mode |= CH_SHUFFLE;
+    else if (p.doshuffle == 1 && T > 1) { c.mode |= CH_SHUFFLE; if ((T == 8 || T == 4) && fuse_enabled()) c.mode |= CH_FUSED_SHUF; }
     else if (p.doshuffle == 2) c.mode |= CH_BITSHUFFLE;
     live[(size_t)i] = 1;
     results[i] = 0;
@@ -206,7 +239,8 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
     const bool filtered = (c.mode & (CH_SHUFFLE | CH_BITSHUFFLE)) != 0;
     if (filtered) {
       const int32_t N = bs / T;
-      if (c.mode & CH_SHUFFLE) { any_shuf = true; int t = (N + shuffle_tile_elems(T) - 1) / shuffle_tile_elems(T); if (t > tiles_shuf) tiles_shuf = t; }
+      if (c.mode & CH_FUSED_SHUF) { /* shuffled by tasks of the encode kernel */ }
+      else if (c.mode & CH_SHUFFLE) { any_shuf = true; int t = (N + shuffle_tile_elems(T) - 1) / shuffle_tile_elems(T); if (t > tiles_shuf) tiles_shuf = t; }
       else { any_bit = true; int t = (N + bitshuffle_tile_elems(T) - 1) / bitshuffle_tile_elems(T); if (t < 1) t = 1; if (t > tiles_bit) tiles_bit = t; }
     }
     // blocks + streams; pointers are patched once the arenas are placed (offsets stored for now)
@@ -223,7 +257,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
         memset(&sd, 0, sizeof sd);
         sd.in = (const uint8_t*)(uintptr_t)((size_t)j * bs + (size_t)s * neblock);   // offset, patched below
         sd.out = (uint8_t*)(uintptr_t)((size_t)j * bs + (size_t)s * neblock);
-        sd.in_size = neblock; sd.out_size = neblock; sd.chunk = i; sd.fmt = c.fmt; sd.aux = c.clevel;
+        sd.in_size = neblock; sd.out_size = neblock; sd.chunk = i; sd.fmt = c.fmt; sd.aux = c.clevel | (int32_t)(blocks.size() << 4);
         streams.push_back(sd);
       }
       blocks.push_back(b);
@@ -241,7 +275,11 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   const size_t o_blocks = cv.take(sizeof(BlockDesc) * (nblk ? nblk : 1));
   const size_t o_streams = cv.take(sizeof(StreamDesc) * (nstr ? nstr : 1));
   const size_t o_blkoff = cv.take(sizeof(int32_t) * (nblk ? nblk : 1));
-  const size_t o_results = cv.take(sizeof(int32_t) * (size_t)n + 64);   // + ticket counter of the encode queue
+  const size_t o_results = cv.take(sizeof(int32_t) * (size_t)n + 64);   // + the 8 ticket counters of the encode queues
+  std::vector<int32_t> queues;
+  build_encode_queues(blocks, chunks, queues);
+  const size_t o_queues = cv.take(sizeof(int32_t) * queues.size());
+  const size_t o_ready = cv.take(sizeof(uint32_t) * (nblk ? nblk : 1));
   const size_t o_filt = cv.take(filt_bytes + 256);
   const size_t o_stage = cv.take(stage_bytes + 256);
   if (st.dev.ensure(cv.off)) return -1;
@@ -284,11 +322,15 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   const size_t p_blocks = pc.take(sizeof(BlockDesc) * (nblk ? nblk : 1));
   const size_t p_streams = pc.take(sizeof(StreamDesc) * (nstr ? nstr : 1));
   const size_t p_results = pc.take(sizeof(int32_t) * (size_t)n);
+  const size_t p_queues = pc.take(sizeof(int32_t) * queues.size());
   if (st.pin.ensure(pc.off)) return -1;
   uint8_t* P = st.pin.base;
   memcpy(P + p_chunks, chunks.data(), sizeof(ChunkDesc) * (size_t)n);
   if (nblk) memcpy(P + p_blocks, blocks.data(), sizeof(BlockDesc) * nblk);
   if (nstr) memcpy(P + p_streams, streams.data(), sizeof(StreamDesc) * nstr);
+  memcpy(P + p_queues, queues.data(), sizeof(int32_t) * queues.size());
+  HIP_TRY(hipMemcpyAsync(D + o_queues, P + p_queues, sizeof(int32_t) * queues.size(), hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemsetAsync(D + o_ready, 0, sizeof(uint32_t) * (nblk ? nblk : 1), stream));
   HIP_TRY(hipMemcpyAsync(D + o_chunks, P + p_chunks, sizeof(ChunkDesc) * (size_t)n, hipMemcpyHostToDevice, stream));
   if (nblk) HIP_TRY(hipMemcpyAsync(D + o_blocks, P + p_blocks, sizeof(BlockDesc) * nblk, hipMemcpyHostToDevice, stream));
   if (nstr) HIP_TRY(hipMemcpyAsync(D + o_streams, P + p_streams, sizeof(StreamDesc) * nstr, hipMemcpyHostToDevice, stream));
@@ -313,10 +355,13 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   if (nstr) {
     ProfScope ps(st, stream, "k_encode_streams");
     static const int enc_wpc = getenv("BLOSC_AMD_ENC_WPC") ? atoi(getenv("BLOSC_AMD_ENC_WPC")) : 32;
+    const int32_t* d_qoff = (const int32_t*)(D + o_queues); const int32_t* d_qlist = d_qoff + 9;
+    uint32_t* d_ready = (uint32_t*)(D + o_ready);
+    const size_t ntasks = queues.size() - 9;
 #ifdef BAMD_PROFILE_DECODE
     uint32_t* d_prof = nullptr;
     if (getenv("BLOSC_AMD_ENC_PROFILE")) { (void)hipMalloc((void**)&d_prof, nstr * 64); (void)hipMemsetAsync(d_prof, 0, nstr * 64, stream); }
-    hipLaunchKernelGGL(k_encode_streams, dim3(persistent_grid(nstr, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, (int)nstr, d_ticket, d_prof);
+    hipLaunchKernelGGL(k_encode_streams, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, d_prof);
     if (d_prof) {
       std::vector<uint32_t> h(nstr * 16);
       (void)hipStreamSynchronize(stream);
@@ -326,7 +371,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
       (void)hipFree(d_prof);
     }
 #else
-    hipLaunchKernelGGL(k_encode_streams, dim3(persistent_grid(nstr, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, (int)nstr, d_ticket);
+    hipLaunchKernelGGL(k_encode_streams, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready);
 #endif
   }
   {
@@ -513,11 +558,10 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
   return 0;
 }
 
-static bool fuse_unshuffle_enabled() { static const bool on = !(getenv("BLOSC_AMD_FUSE") && atoi(getenv("BLOSC_AMD_FUSE")) == 0); return on; }
 
 static void filter_tiles(ChunkDesc& c, bool& any_shuf, bool& any_bit, int& tiles_shuf, int& tiles_bit) {
   const int32_t T = c.typesize, N = c.blocksize / T;
-  if ((c.mode & CH_SHUFFLE) && (T == 8 || T == 4) && fuse_unshuffle_enabled()) { c.mode |= CH_FUSED_UNSHUF; return; }
+  if ((c.mode & CH_SHUFFLE) && (T == 8 || T == 4) && fuse_enabled()) { c.mode |= CH_FUSED_UNSHUF; return; }
   if (c.mode & CH_SHUFFLE) {
     any_shuf = true;
     int t = (N + shuffle_tile_elems(T) - 1) / shuffle_tile_elems(T); if (t < 1) t = 1;

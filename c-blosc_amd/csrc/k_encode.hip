@@ -25,6 +25,7 @@ namespace bamd {
 // Optional phase profiling of the encoder (prof build, scripts/enc_phase.py); same slot layout as k_decode.hip's.
 // slots: 0 steps, 1 steps without a match, 2 forward extensions, 3 literal runs copied from memory, 6 window refills
 //        6 sequences
+//        13 cycles: waiting for the block's shuffle task
 //        8 cycles: window+probe, 9 candidates+select, 10 extension, 11 emit, 12 tail
 #ifdef BAMD_PROFILE_DECODE
 #define EPROF_ARG , DecProf& prof_
@@ -466,8 +467,72 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
   return op < n ? op : 0u;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused byte shuffle of one block by ONE wavefront (typesize 4 or 8): element-major source -> plane-major
+// scratch (blosc/shuffle-generic.h:27-58).  The mirror image of unshuffle_block_wave in k_decode.hip: per
+// step lane l loads the T*4 contiguous bytes of elements e+4l..e+4l+3 (coalesced 16-byte loads), transposes
+// bytes in registers and stores 4 bytes into every plane (each wave store writes 256 contiguous bytes).
+// ---------------------------------------------------------------------------------------------
+template <int T>
+struct ElemRows { uint4 a, b; };
+
+template <int T>
+__device__ __forceinline__ ElemRows<T> shuffle_load(const gu8* src, uint32_t e, int lane) {
+  ElemRows<T> x;
+  const gu8* in = src + (size_t)(e + 4u * (uint32_t)lane) * T;
+  x.a = g_ld16(in);
+  if (T == 8) x.b = g_ld16(in + 16); else x.b = make_uint4(0, 0, 0, 0);
+  return x;
+}
+template <int T>
+__device__ __forceinline__ void shuffle_store(gu8* dst, uint32_t N, uint32_t e, int lane, const ElemRows<T>& x) {
+  gu8* o = dst + e + 4u * (uint32_t)lane;
+  uint32_t r0, r1, r2, r3;
+  if (T == 8) {
+    // a = (lo0, hi0, lo1, hi1), b = (lo2, hi2, lo3, hi3): low / high dword of elements 0..3
+    transpose4x4(x.a.x, x.a.z, x.b.x, x.b.z, r0, r1, r2, r3);
+    g_st4(o, r0); g_st4(o + (size_t)N, r1); g_st4(o + 2 * (size_t)N, r2); g_st4(o + 3 * (size_t)N, r3);
+    transpose4x4(x.a.y, x.a.w, x.b.y, x.b.w, r0, r1, r2, r3);
+    g_st4(o + 4 * (size_t)N, r0); g_st4(o + 5 * (size_t)N, r1); g_st4(o + 6 * (size_t)N, r2); g_st4(o + 7 * (size_t)N, r3);
+  } else {
+    transpose4x4(x.a.x, x.a.y, x.a.z, x.a.w, r0, r1, r2, r3);
+    g_st4(o, r0); g_st4(o + (size_t)N, r1); g_st4(o + 2 * (size_t)N, r2); g_st4(o + 3 * (size_t)N, r3);
+  }
+}
+template <int T>
+__device__ void shuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize, int lane) {
+  const uint32_t N = bsize / T;
+  uint32_t e = 0;
+  for (; e + 1024u <= N; e += 1024u) {   // 4 steps per iteration: all loads are issued before the first store
+    const ElemRows<T> a = shuffle_load<T>(src, e, lane), b = shuffle_load<T>(src, e + 256u, lane);
+    const ElemRows<T> c = shuffle_load<T>(src, e + 512u, lane), d = shuffle_load<T>(src, e + 768u, lane);
+    shuffle_store<T>(dst, N, e, lane, a); shuffle_store<T>(dst, N, e + 256u, lane, b);
+    shuffle_store<T>(dst, N, e + 512u, lane, c); shuffle_store<T>(dst, N, e + 768u, lane, d);
+  }
+  for (; e + 256u <= N; e += 256u) shuffle_store<T>(dst, N, e, lane, shuffle_load<T>(src, e, lane));
+  // tail: fewer than 256 elements, then the bytes that do not form a whole element (copied as they are)
+  for (uint32_t k = e * T + (uint32_t)lane; k < N * T; k += 64u) { const uint32_t el = k / T, j = k - el * T; dst[(size_t)j * N + el] = src[k]; }
+  for (uint32_t k = N * T + (uint32_t)lane; k < bsize; k += 64u) dst[k] = src[k];
+}
+
+// queue task "shuffle block gb": afterwards the block's flag tells the encoders of its streams to go ahead.
+// Producer and consumers run on the same XCD (per-XCD queues), so the hand-off goes through that XCD's L2:
+// drain the stores, then a relaxed agent-scope flag store - no L2 write-back needed.
+__device__ __attribute__((noinline)) void shuffle_block_task(const ChunkDesc* chunks, const BlockDesc* blocks, uint32_t gb,
+                                                             uint32_t* blk_ready, int lane) {
+  const BlockDesc* b = blocks + gb;
+  const ChunkDesc* c = chunks + uni((uint32_t)b->chunk);
+  const uint32_t blk = uni((uint32_t)b->blk), bsize = uni((uint32_t)b->bsize), bs = uni((uint32_t)c->blocksize);
+  const gu8* src = uni_ptr(as_global(c->src)) + (size_t)blk * bs;
+  gu8* dst = uni_ptr(as_global(c->filt)) + (size_t)blk * bs;
+  if (uni((uint32_t)c->typesize) == 8u) shuffle_block_wave_T<8>(src, dst, bsize, lane);
+  else shuffle_block_wave_T<4>(src, dst, bsize, lane);
+  __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): every store of this wave has reached L2
+  if (lane == 0) __hip_atomic_store(&blk_ready[gb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // one stream, not inlined into the queue loop (see decode_one_stream in k_decode.hip for why)
-__device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, uint16_t* tab, int lane
+__device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, uint16_t* tab, const ChunkDesc* chunks, uint32_t* blk_ready, int lane
 #ifdef BAMD_PROFILE_DECODE
                                                             , uint32_t* profslot
 #endif
@@ -477,7 +542,15 @@ __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, uint
   prof_.c[4] = 0; prof_.c[5] = 0;
 #endif
   const uint32_t n = uni((uint32_t)sd->in_size), cap = uni((uint32_t)sd->out_size);
-  const int clevel = (int)uni((uint32_t)sd->aux);
+  const uint32_t aux = uni((uint32_t)sd->aux);
+  const int clevel = (int)(aux & 15u);
+  if (uni(chunks[uni((uint32_t)sd->chunk)].mode) & CH_FUSED_SHUF) {
+    // the block's shuffle task sits earlier in this XCD's queue, so a running wave already owns it
+    const uint32_t gb = aux >> 4;
+    while (__hip_atomic_load(&blk_ready[gb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(16);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  PROF_LAP(13);
   uint32_t r;
   if (sd->fmt == FMT_LZ4) r = lz_encode_wave<EF_LZ4>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, lane EPROF_PASS);
   else r = lz_encode_wave<EF_BLOSCLZ>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, lane EPROF_PASS);
@@ -488,27 +561,40 @@ __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, uint
 #endif
 }
 
-// persistent waves + ticket queue, like k_decode_streams (stream costs differ by orders of magnitude)
+// Persistent waves + per-XCD ticket queues, like k_decode_streams (stream costs differ by orders of
+// magnitude).  A queue entry >= 0 is a stream to encode; an entry < 0 is "shuffle block -(entry+1)".  The
+// host puts every block's shuffle task a few dozen entries ahead of its streams (engine.hip:
+// build_encode_queues), so the bandwidth-bound transposes run underneath the latency/issue-bound match
+// finding of other waves instead of in a kernel of their own.
 #ifndef BAMD_ENC_MINWAVES
 #define BAMD_ENC_MINWAVES 8   // waves per SIMD the register allocator must leave room for (tuned on MI355X: 8 > 6 > 4)
 #endif
-__global__ __launch_bounds__(64 * ENC_WAVES, BAMD_ENC_MINWAVES) void k_encode_streams(StreamDesc* __restrict__ streams, int nstreams,
-                                                                   uint32_t* __restrict__ ticket
+__global__ __launch_bounds__(64 * ENC_WAVES, BAMD_ENC_MINWAVES) void k_encode_streams(
+    StreamDesc* __restrict__ streams, uint32_t* __restrict__ tickets /*[8]*/, const int32_t* __restrict__ qlist,
+    const int32_t* __restrict__ qoff /*[9]*/, const ChunkDesc* __restrict__ chunks, const BlockDesc* __restrict__ blocks,
+    uint32_t* __restrict__ blk_ready
 #ifdef BAMD_PROFILE_DECODE
-                                                                   , uint32_t* __restrict__ profbuf
+    , uint32_t* __restrict__ profbuf
 #endif
-                                                                   ) {
+    ) {
   __shared__ uint16_t tabs[ENC_WAVES][ENC_TAB];
   static_assert(ENC_WAVES == 1, "one stream per wave, one wave per workgroup");
   const int lane = threadIdx.x & 63;
-  uint32_t sid = take_ticket(ticket, lane);
-  while (sid < (uint32_t)nstreams) {
+  const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;   // HW_REG_XCC_ID[3:0]
+  const uint32_t qbase = (uint32_t)qoff[xcc], qlen = (uint32_t)qoff[xcc + 1] - qbase;
+  uint32_t t = take_ticket(tickets + xcc, lane);
+  while (t < qlen) {
+    const int32_t task = (int32_t)uni((uint32_t)qlist[qbase + t]);
+    if (task < 0) {
+      shuffle_block_task(chunks, blocks, (uint32_t)(-(task + 1)), blk_ready, lane);
+    } else {
 #ifdef BAMD_PROFILE_DECODE
-    encode_one_stream(streams + sid, tabs[0], lane, profbuf ? profbuf + (size_t)sid * 16 : nullptr);
+      encode_one_stream(streams + task, tabs[0], chunks, blk_ready, lane, profbuf ? profbuf + (size_t)task * 16 : nullptr);
 #else
-    encode_one_stream(streams + sid, tabs[0], lane);
+      encode_one_stream(streams + task, tabs[0], chunks, blk_ready, lane);
 #endif
-    sid = take_ticket(ticket, lane);
+    }
+    t = take_ticket(tickets + xcc, lane);
   }
 }
 

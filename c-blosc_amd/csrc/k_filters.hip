@@ -268,7 +268,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_shuffle(const ChunkDesc* __restr
   __shared__ __attribute__((aligned(16))) uint8_t lds[FT_TILE_BYTES + 255 * FT_PAD];
   const BlockDesc b = blocks[blockIdx.x];
   const ChunkDesc& c = chunks[b.chunk];
-  if (!(c.mode & CH_SHUFFLE) || (c.mode & (CH_MEMCPYED | CH_SKIP))) return;
+  if (!(c.mode & CH_SHUFFLE) || (c.mode & (CH_MEMCPYED | CH_SKIP | CH_FUSED_SHUF))) return;
   int bsize; block_geom(c, b, bsize);
   const int T = c.typesize, N = bsize / T;
   const int E = shuffle_tile_elems(T);
