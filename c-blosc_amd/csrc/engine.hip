@@ -354,7 +354,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   }
   if (nstr) {
     ProfScope ps(st, stream, "k_encode_streams");
-    static const int enc_wpc = getenv("BLOSC_AMD_ENC_WPC") ? atoi(getenv("BLOSC_AMD_ENC_WPC")) : 32;
+    static const int enc_wpc = getenv("BLOSC_AMD_ENC_WPC") ? atoi(getenv("BLOSC_AMD_ENC_WPC")) : ENC_WAVES_PER_CU;
     const int32_t* d_qoff = (const int32_t*)(D + o_queues); const int32_t* d_qlist = d_qoff + 9;
     uint32_t* d_ready = (uint32_t*)(D + o_ready);
     const size_t ntasks = queues.size() - 9;

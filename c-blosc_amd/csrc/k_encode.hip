@@ -36,10 +36,25 @@ namespace bamd {
 #endif
 
 constexpr int ENC_WAVES = 1;       // one stream per workgroup: a slot frees up as soon as ITS stream is done
-constexpr int ENC_HASH_BITS = 11;   // 2048 x u16 = 4 KiB of LDS per wave -> 32 waves per CU
+// Table entry = position mod 65536 | 16 further hash bits as a tag << 16.  The tag lets a lane reject a
+// stale or colliding entry WITHOUT touching memory: untagged, nearly every lane of every step fetched 20
+// bytes from a random place in the last 64 KiB (a full cache line each, mostly L2 misses with a thousand
+// streams in flight per XCD) - rocprofv3 FETCH_SIZE showed 6.8x the input being read.
+#ifndef BAMD_ENC_DMAX
+#define BAMD_ENC_DMAX 65535
+#endif
+#ifndef BAMD_ENC_HASH_BITS
+#define BAMD_ENC_HASH_BITS 11
+#endif
+constexpr int ENC_HASH_BITS = BAMD_ENC_HASH_BITS;   // 2048 x u32 = 8 KiB of LDS per wave -> 20 waves per CU
 constexpr int ENC_TAB = 1 << ENC_HASH_BITS;
+typedef uint32_t enc_entry_t;
+constexpr int ENC_WAVES_PER_CU = (160 * 1024) / (ENC_TAB * 4) > 32 ? 32 : (160 * 1024) / (ENC_TAB * 4);   // persistent grid size per CU
 
-__device__ __forceinline__ uint32_t enc_hash(uint32_t seq) { return (seq * 2654435761u) >> (32 - ENC_HASH_BITS); }
+__device__ __forceinline__ uint32_t enc_mix(uint32_t seq) { return seq * 2654435761u; }
+__device__ __forceinline__ uint32_t enc_slot(uint32_t mix) { return mix >> (32 - ENC_HASH_BITS); }
+// table entry for position p whose 4 bytes hash to `mix`: the 16 bits below the slot bits are the tag
+__device__ __forceinline__ uint32_t enc_entry(uint32_t mix, uint32_t p) { return ((mix << ENC_HASH_BITS) & 0xffff0000u) | (p & 0xffffu); }
 
 __device__ __forceinline__ uint64_t ld8u(const gu8* p) { return g_ld8(p); }
 
@@ -209,14 +224,20 @@ __device__ __forceinline__ uint32_t blz_emit_match(gu8* dst, uint32_t op, uint32
 #ifndef BAMD_ENC_BWD
 #define BAMD_ENC_BWD 2
 #endif
-constexpr uint32_t RANK_CAP = 20u;   // 4 verified + 16 ranked bytes
+#ifndef BAMD_ENC_RANK16
+#define BAMD_ENC_RANK16 0
+#endif
+constexpr uint32_t RANK_CAP = BAMD_ENC_RANK16 == 1 ? 16u : 20u;   // bytes of a candidate that are compared for ranking
 
 struct Bytes20 { uint64_t a, b; uint32_t c; };
 
 // 20 bytes at src[pos..], zero beyond n (only the last step of a stream takes the slow branch)
 __device__ __forceinline__ Bytes20 load20(const gu8* src, uint32_t pos, uint32_t n) {
   Bytes20 r;
-  if (pos + 20u <= n) { r.a = g_ld8(src + pos); r.b = g_ld8(src + pos + 8u); r.c = g_ld4(src + pos + 16u); }
+  if (pos + 20u <= n) {
+    if (BAMD_ENC_RANK16) { const uint4 v = g_ld16(src + pos); r.a = ((uint64_t)v.y << 32) | v.x; r.b = ((uint64_t)v.w << 32) | v.z; r.c = BAMD_ENC_RANK16 == 2 ? g_ld4(src + pos + 16u) : 0u; }
+    else { r.a = g_ld8(src + pos); r.b = g_ld8(src + pos + 8u); r.c = g_ld4(src + pos + 16u); }
+  }
   else {
     r.a = 0; r.b = 0; r.c = 0;
     for (uint32_t k = 0; k < 20u && pos + k < n; k++) {
@@ -231,6 +252,7 @@ __device__ __forceinline__ uint32_t common20(const Bytes20& x, const Bytes20& y)
   if (d) return (uint32_t)__builtin_ctzll(d) >> 3;
   d = x.b ^ y.b;
   if (d) return 8u + ((uint32_t)__builtin_ctzll(d) >> 3);
+  if (BAMD_ENC_RANK16 == 1) return 16u;
   const uint32_t e = x.c ^ y.c;
   return e ? 16u + ((uint32_t)__builtin_ctz(e) >> 3) : 20u;
 }
@@ -295,10 +317,10 @@ struct EncWindow {
 
 template <int FMT>
 __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8* __restrict__ dst, uint32_t cap,
-                                   int clevel, uint16_t* tab_generic, int lane EPROF_ARG) {
+                                   int clevel, enc_entry_t* tab_generic, int lane EPROF_ARG) {
   // the table lives in LDS; say so explicitly (a generic pointer in a non-inlined function would make
   // every probe a flat_load)
-  __attribute__((address_space(3))) uint16_t* tab = (__attribute__((address_space(3))) uint16_t*)tab_generic;
+  __attribute__((address_space(3))) enc_entry_t* tab = (__attribute__((address_space(3))) enc_entry_t*)tab_generic;
   // stream-end rules.  LZ4: last match starts <= n-12, ends <= n-5 (lz4.c:245-246, :963-964).
   // BloscLZ: matches start < n-12 (blosclz.c:465), stream must end with >= 1 literal (blosclz.c:708-710).
   if (FMT == EF_LZ4 ? (n < 13u) : (n < 16u || cap < 66u)) return 0u;
@@ -306,7 +328,7 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
   const uint32_t mlimit = (FMT == EF_LZ4) ? n - 5u : n - 2u;  // matches end at or before this position
   const int accel = 10 - clevel;                              // blosc/blosc.c:577-587
 
-  for (int k = lane; k < ENC_TAB / 2; k += 64) ((__attribute__((address_space(3))) uint32_t*)tab)[k] = 0u;
+  for (int k = lane; k < ENC_TAB; k += 64) tab[k] = 0u;
 
   EncWindow win;
   win.init(src, n, lane);
@@ -345,17 +367,20 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
     uint32_t prev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane - 1u) & 63u) << 2, (int)(o0 & 0xffu));
     if (lane == 0) prev = ip ? (bo0 >= 2u ? before2 >> 8 : (uint32_t)(r01 >> (8u * (bo0 - 1u))) & 0xffu) : 0x100u;
     if (ins_pending) {
-      if (lane == 0) tab[enc_hash(before2 | (o0 << 16))] = (uint16_t)(ip - 2u);
+      const uint32_t m2 = enc_mix(before2 | (o0 << 16));
+      if (lane == 0) tab[enc_slot(m2)] = enc_entry(m2, ip - 2u);
       ins_pending = false;
     }
-    uint32_t h = 0, cand = 0, limit = 0;
+    uint32_t h = 0, cand = 0, limit = 0, mine = 0;   // mine: this lane's own table entry
     bool tab_ok = false;
     if (live) {
       limit = mlimit - p; if (limit > RANK_CAP) limit = RANK_CAP;     // bytes of a match starting at p that may be counted
-      h = enc_hash(o0);
+      const uint32_t mix = enc_mix(o0);
+      h = enc_slot(mix);
+      mine = enc_entry(mix, p);
       const uint32_t e = tab[h];
       const uint32_t d = (p - e) & 0xffffu;
-      if (d != 0u && d <= p) { cand = p - d; tab_ok = true; }
+      if (d != 0u && d <= p && d <= (uint32_t)BAMD_ENC_DMAX && ((e ^ mine) >> 16) == 0u) { cand = p - d; tab_ok = true; }
     } else {
       prev = 0x100u;
     }
@@ -387,7 +412,7 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
       if (best == 0u) break;
       any = true;
       const int f = 63 - (int)(best & 63u);
-      if (live && (uint32_t)lane >= lane_lo && lane <= f) tab[h] = (uint16_t)p;
+      if (live && (uint32_t)lane >= lane_lo && lane <= f) tab[h] = mine;
       uint32_t pm = ip + (uint32_t)f;
       uint32_t cm = (uint32_t)__builtin_amdgcn_readlane((int)cand, f);
       const uint32_t len_f = (uint32_t)__builtin_amdgcn_readlane((int)len, f);
@@ -428,11 +453,11 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
       if (anchor >= step_end) break;
       lane_lo = anchor - ip;                      // >= 4
       // like the reference, remember the position two bytes before the new anchor (lz4.c:1236-1242)
-      if (live && (uint32_t)lane + 2u == lane_lo) tab[h] = (uint16_t)p;
+      if (live && (uint32_t)lane + 2u == lane_lo) tab[h] = mine;
     }
     if (!any) {
       PROF_ADD(1, 1);
-      if (live) tab[h] = (uint16_t)p;
+      if (live) tab[h] = mine;
       nfail++;
       uint32_t adv = 1u + (nfail * (uint32_t)accel) / 16u;   // skip faster through incompressible data
       if (adv > 16u) adv = 16u;
@@ -444,7 +469,7 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
       ip = anchor;
       ins_pending = true;                         // anchor-2 enters the table at the top of the next step (bytes in registers there)
     } else {
-      if (live && (uint32_t)lane >= lane_lo) tab[h] = (uint16_t)p;   // nothing more to find behind the last match
+      if (live && (uint32_t)lane >= lane_lo) tab[h] = mine;   // nothing more to find behind the last match
       ip = step_end;
     }
   }
@@ -532,7 +557,7 @@ __device__ __attribute__((noinline)) void shuffle_block_task(const ChunkDesc* ch
 }
 
 // one stream, not inlined into the queue loop (see decode_one_stream in k_decode.hip for why)
-__device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, uint16_t* tab, const ChunkDesc* chunks, uint32_t* blk_ready, int lane
+__device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, enc_entry_t* tab, const ChunkDesc* chunks, uint32_t* blk_ready, int lane
 #ifdef BAMD_PROFILE_DECODE
                                                             , uint32_t* profslot
 #endif
@@ -567,7 +592,7 @@ __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, uint
 // build_encode_queues), so the bandwidth-bound transposes run underneath the latency/issue-bound match
 // finding of other waves instead of in a kernel of their own.
 #ifndef BAMD_ENC_MINWAVES
-#define BAMD_ENC_MINWAVES 8   // waves per SIMD the register allocator must leave room for (tuned on MI355X: 8 > 6 > 4)
+#define BAMD_ENC_MINWAVES 5   // waves per SIMD: the 8 KiB table per wave allows 20 per CU
 #endif
 __global__ __launch_bounds__(64 * ENC_WAVES, BAMD_ENC_MINWAVES) void k_encode_streams(
     StreamDesc* __restrict__ streams, uint32_t* __restrict__ tickets /*[8]*/, const int32_t* __restrict__ qlist,
@@ -577,7 +602,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES, BAMD_ENC_MINWAVES) void k_encode_st
     , uint32_t* __restrict__ profbuf
 #endif
     ) {
-  __shared__ uint16_t tabs[ENC_WAVES][ENC_TAB];
+  __shared__ enc_entry_t tabs[ENC_WAVES][ENC_TAB];
   static_assert(ENC_WAVES == 1, "one stream per wave, one wave per workgroup");
   const int lane = threadIdx.x & 63;
   const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;   // HW_REG_XCC_ID[3:0]
