@@ -150,6 +150,8 @@ static dim3 grid1(size_t n, int per) { return dim3((unsigned)((n + per - 1) / pe
 // ---------------------------------------------------------------------------------------------
 // BLOSC_AMD_FUSE=0 keeps the byte (un)shuffle in kernels of its own (k_shuffle / k_unshuffle) instead of
 // running it as work of the encode / decode kernels
+// BLOSC_AMD_SPANS=0: decoded periodic planes go through the scratch like every other plane
+static bool span_enabled() { static const bool on = !(getenv("BLOSC_AMD_SPANS") && atoi(getenv("BLOSC_AMD_SPANS")) == 0); return on; }
 static bool fuse_enabled() { static const bool on = !(getenv("BLOSC_AMD_FUSE") && atoi(getenv("BLOSC_AMD_FUSE")) == 0); return on; }
 
 // Per-XCD task queues of the encode kernel: out = off[9] | entries.  Block g belongs to XCD g & 7; an
@@ -508,6 +510,7 @@ static void build_xcd_queues(const std::vector<BlockDesc>& blocks, size_t nstr, 
 
 struct DecodeLaunch {
   ChunkDesc* d_chunks; BlockDesc* d_blocks; StreamDesc* d_streams; int32_t* d_status; uint32_t* d_ticket; uint32_t* d_blkdone;
+  uint32_t* d_spans; uint8_t* d_pat;             // periodic spans of the fused unshuffle (k_decode.hip: SpanCtx)
   const int32_t* d_qlist; const int32_t* d_qoff;   // per-XCD stream queues
   size_t nblk, nstr; int nchunks;
   bool any_shuf, any_bit, any_copy; int tiles_shuf, tiles_bit;
@@ -528,7 +531,7 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
 #ifdef BAMD_PROFILE_DECODE
       uint32_t* d_prof = nullptr;
       if (getenv("BLOSC_AMD_DEC_PROFILE")) { (void)hipMalloc((void**)&d_prof, L.nstr * 64); (void)hipMemsetAsync(d_prof, 0, L.nstr * 64, stream); }
-      hipLaunchKernelGGL(k_decode_streams, dgrid, dim3(64 * DEC_WAVES), (size_t)dec_lds, stream, L.d_streams, L.d_status, L.d_ticket, L.d_qlist, L.d_qoff, L.d_chunks, L.d_blocks, L.d_blkdone, d_prof);
+      hipLaunchKernelGGL(k_decode_streams, dgrid, dim3(64 * DEC_WAVES), (size_t)dec_lds, stream, L.d_streams, L.d_status, L.d_ticket, L.d_qlist, L.d_qoff, L.d_chunks, L.d_blocks, L.d_blkdone, L.d_spans, L.d_pat, d_prof);
       if (d_prof) {
         std::vector<uint32_t> h(L.nstr * 16);
         (void)hipStreamSynchronize(stream);
@@ -538,7 +541,7 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
         (void)hipFree(d_prof);
       }
 #else
-      hipLaunchKernelGGL(k_decode_streams, dgrid, dim3(64 * DEC_WAVES), (size_t)dec_lds, stream, L.d_streams, L.d_status, L.d_ticket, L.d_qlist, L.d_qoff, L.d_chunks, L.d_blocks, L.d_blkdone);
+      hipLaunchKernelGGL(k_decode_streams, dgrid, dim3(64 * DEC_WAVES), (size_t)dec_lds, stream, L.d_streams, L.d_status, L.d_ticket, L.d_qlist, L.d_qoff, L.d_chunks, L.d_blocks, L.d_blkdone, L.d_spans, L.d_pat);
 #endif
     }
     if (L.any_shuf) {
@@ -611,6 +614,8 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   const size_t o_streams = cv.take(sizeof(StreamDesc) * (nstr ? nstr : 1));
   const size_t o_status = cv.take(sizeof(int32_t) * (size_t)n + 64 + sizeof(uint32_t) * (nblk ? nblk : 1));   // + 8 tickets + per-block arrival counters
   const size_t o_queues = cv.take(sizeof(int32_t) * (9 + (nstr ? nstr : 1)));
+  const size_t o_spans = cv.take(8 * (nstr ? nstr : 1));
+  const size_t o_pat = cv.take(span_enabled() ? (size_t)2048 * (nstr ? nstr : 1) : 256);
   const size_t o_filt = cv.take(filt_bytes + 256);
   if (st.dev.ensure(cv.off)) return -1;
   uint8_t* D = st.dev.base;
@@ -655,6 +660,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   L.d_ticket = (uint32_t*)(D + o_status + sizeof(int32_t) * (size_t)n + 32);
   L.d_blkdone = (uint32_t*)(D + o_status + sizeof(int32_t) * (size_t)n + 64);
   L.d_qoff = (const int32_t*)(D + o_queues); L.d_qlist = L.d_qoff + 9;
+  L.d_spans = span_enabled() ? (uint32_t*)(D + o_spans) : nullptr; L.d_pat = D + o_pat;
   L.nblk = nblk; L.nstr = nstr; L.nchunks = n;
   if (launch_decode(st, L, stream)) return -1;
   HIP_TRY(hipMemcpyAsync(P + p_status, D + o_status, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, stream));
@@ -733,6 +739,8 @@ int engine_getitem(const void* src, int start, int nitems, void* dest, bool src_
   const size_t o_streams = cv.take(sizeof(StreamDesc) * nstr);
   const size_t o_status = cv.take(sizeof(int32_t) + 64 + sizeof(uint32_t) * nblk);
   const size_t o_queues = cv.take(sizeof(int32_t) * (9 + nstr));
+  const size_t o_spans = cv.take(8 * nstr);
+  const size_t o_pat = cv.take(span_enabled() ? (size_t)2048 * nstr : 256);
   const size_t o_out = cv.take(span + 256);
   const size_t o_filt = cv.take(span + 256);
   if (st.dev.ensure(cv.off)) return -1;
@@ -764,6 +772,7 @@ int engine_getitem(const void* src, int start, int nitems, void* dest, bool src_
   L.d_ticket = (uint32_t*)(D + o_status + 32);
   L.d_blkdone = (uint32_t*)(D + o_status + 68);
   L.d_qoff = (const int32_t*)(D + o_queues); L.d_qlist = L.d_qoff + 9;
+  L.d_spans = span_enabled() ? (uint32_t*)(D + o_spans) : nullptr; L.d_pat = D + o_pat;
   L.nblk = nblk; L.nstr = nstr; L.nchunks = 1;
   if (launch_decode(st, L, stream)) return -1;
   HIP_TRY(hipMemcpyAsync(P + p_status, D + o_status, sizeof(int32_t), hipMemcpyDeviceToHost, stream));

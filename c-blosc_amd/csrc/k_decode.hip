@@ -113,8 +113,48 @@ __device__ __forceinline__ uint32_t hop(uint32_t table, uint32_t x) {
   return x >= 64u ? 64u : t;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Periodic spans.  After a byte shuffle the planes of the high-order bytes are typically constant or
+// repeat with a short power-of-two period; their whole stream is "a few literals + one match that runs
+// to the end".  Writing such a plane to the scratch only to read it back in the unshuffle is two wasted
+// passes over HBM.  When a match is long (>= 16 KiB) and its distance a power of two <= 2048, the decoder
+// therefore writes only the part up to the next 1 KiB boundary and the part behind the last one, stores
+// the 2 KiB pattern table pat[i] = plane[q], q = i (mod 2048), and records the skipped range [lo, hi).
+// The fused unshuffle (unshuffle_block_wave) reads those positions from the table (L1/L2-resident)
+// instead of the scratch.  A later match that reaches back into the skipped range makes the decoder
+// fill it in after all ("materialise"); only split blocks of fused chunks use spans.
+// ---------------------------------------------------------------------------------------------
+struct SpanCtx { uint32_t enabled, lo, hi, off; gu8* pat; };
+constexpr uint32_t SPAN_PAT = 2048u;
+
+__device__ __forceinline__ void span_materialize(gu8* out, int lane, SpanCtx& sp) {
+  if (sp.hi) wave_match_copy(out, sp.lo, sp.off, sp.hi - sp.lo, lane);   // out[lo - off, lo) was written by the head copy
+  sp.lo = 0; sp.hi = 0; sp.enabled = 0;
+}
+// returns true when the match was handled here (head, pattern table and tail written, middle skipped)
+__device__ __forceinline__ bool span_long_match(gu8* out, uint32_t mpos, uint32_t off, uint32_t ml, int lane, SpanCtx& sp) {
+  if (!sp.enabled || sp.hi || ml < 16384u || off > SPAN_PAT || (off & (off - 1u))) return false;
+  const uint32_t lo = (mpos + 1023u) & ~1023u, hi = (mpos + ml) & ~1023u;
+  if (hi < lo + 8192u) return false;
+  if (lo > mpos) wave_match_copy(out, mpos, off, lo - mpos, lane);
+  const uint32_t base = mpos - off, pm = off - 1u;         // plane[q] = out[base + ((q - base) & pm)] for q >= base
+  uint32_t v[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {                            // lane writes dwords lane, lane + 64, ...: all 32 byte loads first
+    const uint32_t i = 4u * ((uint32_t)lane + 64u * (uint32_t)k);
+    const uint32_t b0 = out[base + ((i - base) & pm)], b1 = out[base + ((i + 1u - base) & pm)];
+    const uint32_t b2 = out[base + ((i + 2u - base) & pm)], b3 = out[base + ((i + 3u - base) & pm)];
+    v[k] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) g_st4(sp.pat + 4u * ((uint32_t)lane + 64u * (uint32_t)k), v[k]);
+  for (uint32_t q = hi + (uint32_t)lane; q < mpos + ml; q += 64u) out[q] = out[base + ((q - base) & pm)];
+  sp.lo = lo; sp.hi = hi; sp.off = off;
+  return true;
+}
+
 __device__ __forceinline__ uint32_t lz4_batch_step(const Window& w, gu8* out, volatile uint32_t* scr_generic, uint32_t& ip, uint32_t& op,
-                                                   uint32_t cap, int lane PROF_ARG) {
+                                                   uint32_t cap, int lane, SpanCtx& sp PROF_ARG) {
   volatile __attribute__((address_space(3))) uint32_t* scr = (volatile __attribute__((address_space(3))) uint32_t*)scr_generic;   // LDS
   const uint32_t B = w.gather_bytes(ip);                       // stream byte ip + lane
   // ---- 1. speculative parse: every lane reads "its" byte as a token ----
@@ -154,6 +194,8 @@ __device__ __forceinline__ uint32_t lz4_batch_step(const Window& w, gu8* out, vo
   const uint32_t cnt = (uint32_t)__builtin_ctz(~okmask);       // leading accepted sequences (<= 16)
   PROF_LAP(9);
   if (cnt == 0u) return 0u;
+  // a source inside a skipped periodic span: fill the span in first (rare)
+  if (sp.hi && __ballot((uint32_t)lane < cnt && op + mrel_r - off_r < sp.hi)) span_materialize(out, lane, sp);
   const uint32_t consumed = (uint32_t)__builtin_amdgcn_readlane((int)nxt_r, (int)(cnt - 1u));
   const uint32_t acc = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(cnt - 1u));
   // ---- 3. literals: token info goes back to byte-lane space through a 64-dword LDS scratch, then one
@@ -221,7 +263,7 @@ __device__ __forceinline__ uint32_t lz4_batch_step(const Window& w, gu8* out, vo
 //   least 5 bytes before the output end.  Offset 0 (accepted by the reference with unspecified
 //   output) is rejected here.
 // ---------------------------------------------------------------------------------------------
-__device__ int lz4_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* out, int32_t cap_, volatile uint32_t* scr, int lane PROF_ARG) {
+__device__ int lz4_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* out, int32_t cap_, volatile uint32_t* scr, int lane, SpanCtx& sp PROF_ARG) {
   if (cap_ == 0) return (n_ == 1 && in[0] == 0) ? 0 : -1;
   if (n_ <= 0) return -1;
   const uint32_t n = (uint32_t)n_, cap = (uint32_t)cap_;
@@ -230,7 +272,7 @@ __device__ int lz4_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* out,
   uint32_t ip = 0, op = 0;
   for (;;) {
     w.seek(ip);
-    if (ip + 72u <= n && lz4_batch_step(w, out, scr, ip, op, cap, lane PROF_PASS)) continue;
+    if (ip + 72u <= n && lz4_batch_step(w, out, scr, ip, op, cap, lane, sp PROF_PASS)) continue;
     PROF_ADD(3, 1);
     const uint32_t hdr = w.peek32(ip);
     const uint32_t token = hdr & 0xffu;
@@ -273,6 +315,7 @@ __device__ int lz4_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* out,
     const uint32_t mpos = op + ll;
     if (off == 0u || off > mpos) return -5;
     if (mpos + ml + 5u > cap) return -6;
+    if (sp.hi && mpos - off < sp.hi) span_materialize(out, lane, sp);
 
     if (lit_in_win && ll + ml <= 64u && off >= ml && (ll == 0u || off >= ll + ml)) {
       // short sequence whose match cannot see its own literals: one gather, one 64-lane store
@@ -285,7 +328,7 @@ __device__ int lz4_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* out,
         if (lit_in_win) { if ((uint32_t)lane < ll) out[op + lane] = (uint8_t)litv; }
         else wave_copy_disjoint(out + op, in + lit_src, ll, lane);
       }
-      wave_match_copy(out, mpos, off, ml, lane);
+      if (!span_long_match(out, mpos, off, ml, lane, sp)) wave_match_copy(out, mpos, off, ml, lane);
     }
     op = mpos + ml;
     PROF_LAP(12);
@@ -299,7 +342,7 @@ __device__ int lz4_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* out,
 // like the reference.  Kept quirks: the first control byte is masked with 31; a match is executed
 // only if at least one more input byte follows it (otherwise decoding stops BEFORE the copy).
 // ---------------------------------------------------------------------------------------------
-__device__ int blosclz_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* out, int32_t cap_, int lane) {
+__device__ int blosclz_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* out, int32_t cap_, int lane, SpanCtx& sp) {
   if (n_ <= 0) return 0;
   const uint32_t n = (uint32_t)n_, cap = (uint32_t)cap_;
   Window w;
@@ -333,7 +376,8 @@ __device__ int blosclz_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* 
       if (dist + 1u > op) return 0;           // reference: ref - 1 < output
       if (ip >= n) break;                     // quirk: the pending match is dropped
       ctrl = w.byte_at(ip); ip++;
-      wave_match_copy(out, op, dist + 1u, len, lane);
+      if (sp.hi && op - (dist + 1u) < sp.hi) span_materialize(out, lane, sp);
+      if (!span_long_match(out, op, dist + 1u, len, lane, sp)) wave_match_copy(out, op, dist + 1u, len, lane);
       op += len;
     } else {
       const uint32_t run = ctrl + 1u;         // 1..32 literal bytes
@@ -376,11 +420,13 @@ template <int T>
 struct Rows { uint32_t r[T]; };
 
 template <int T>
-__device__ __forceinline__ Rows<T> unshuffle_load(const gu8* src, uint32_t N, uint32_t e, int lane) {
+struct PlanePtrs { const gu8* p[T]; };
+
+template <int T>
+__device__ __forceinline__ Rows<T> unshuffle_load(const PlanePtrs<T>& pp, uint32_t rel, int lane) {
   Rows<T> x;
-  const uint32_t el = e + 4u * (uint32_t)lane;
 #pragma unroll
-  for (int j = 0; j < T; j++) x.r[j] = g_ld4(src + (size_t)j * N + el);
+  for (int j = 0; j < T; j++) x.r[j] = g_ld4(pp.p[j] + rel + 4u * (uint32_t)lane);
   return x;
 }
 template <int T>
@@ -398,33 +444,49 @@ __device__ __forceinline__ void unshuffle_store(gu8* dst, uint32_t e, int lane, 
   }
 }
 
+// spans: {lo, hi} per plane (nullptr: none), pat: SPAN_PAT bytes per plane - see SpanCtx above
 template <int T>
-__device__ void unshuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize, int lane) {
+__device__ void unshuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize, int lane, const uint32_t* spans, const gu8* pat) {
   const uint32_t N = bsize / T;
+  uint32_t lo[T], hi[T];
+#pragma unroll
+  for (int j = 0; j < T; j++) { lo[j] = spans ? uni(spans[2 * j]) : 0u; hi[j] = spans ? uni(spans[2 * j + 1]) : 0u; }
   uint32_t e = 0;
-  // 4 steps (1024 elements) per iteration: all loads are issued before the first store
+  // 4 steps (1024 elements) per iteration: all loads are issued before the first store.  Span bounds are
+  // multiples of 1024, so one decision per plane and iteration picks the scratch or the pattern table.
   for (; e + 1024u <= N; e += 1024u) {
-    const Rows<T> a = unshuffle_load<T>(src, N, e, lane), b = unshuffle_load<T>(src, N, e + 256u, lane);
-    const Rows<T> c = unshuffle_load<T>(src, N, e + 512u, lane), d = unshuffle_load<T>(src, N, e + 768u, lane);
+    PlanePtrs<T> pp;
+#pragma unroll
+    for (int j = 0; j < T; j++)
+      pp.p[j] = (e >= lo[j] && e < hi[j]) ? pat + (size_t)j * SPAN_PAT + (e & (SPAN_PAT - 1u)) : src + (size_t)j * N + e;
+    const Rows<T> a = unshuffle_load<T>(pp, 0u, lane), b = unshuffle_load<T>(pp, 256u, lane);
+    const Rows<T> c = unshuffle_load<T>(pp, 512u, lane), d = unshuffle_load<T>(pp, 768u, lane);
     unshuffle_store<T>(dst, e, lane, a); unshuffle_store<T>(dst, e + 256u, lane, b);
     unshuffle_store<T>(dst, e + 512u, lane, c); unshuffle_store<T>(dst, e + 768u, lane, d);
   }
-  for (; e + 256u <= N; e += 256u) unshuffle_store<T>(dst, e, lane, unshuffle_load<T>(src, N, e, lane));
+  {
+    PlanePtrs<T> pp;   // behind the last multiple of 1024 nothing is skipped
+#pragma unroll
+    for (int j = 0; j < T; j++) pp.p[j] = src + (size_t)j * N;
+    for (; e + 256u <= N; e += 256u) unshuffle_store<T>(dst, e, lane, unshuffle_load<T>(pp, e, lane));
+  }
   // tail: fewer than 256 elements, then the bytes that do not form a whole element
   for (uint32_t k = e * T + (uint32_t)lane; k < N * T; k += 64u) { const uint32_t el = k / T, j = k - el * T; dst[k] = src[(size_t)j * N + el]; }
   for (uint32_t k = N * T + (uint32_t)lane; k < bsize; k += 64u) dst[k] = src[k];
 }
 
-__device__ __attribute__((noinline)) void unshuffle_block_wave(const uint8_t* src, uint8_t* dst, uint32_t bsize, int typesize, int lane) {
-  if (typesize == 8) unshuffle_block_wave_T<8>(as_global(src), as_global(dst), bsize, lane);
-  else unshuffle_block_wave_T<4>(as_global(src), as_global(dst), bsize, lane);
+__device__ __attribute__((noinline)) void unshuffle_block_wave(const uint8_t* src, uint8_t* dst, uint32_t bsize, int typesize, int lane,
+                                                               const uint32_t* spans, const uint8_t* pat) {
+  if (typesize == 8) unshuffle_block_wave_T<8>(uni_ptr(as_global(src)), uni_ptr(as_global(dst)), bsize, lane, spans, uni_ptr(as_global(pat)));
+  else unshuffle_block_wave_T<4>(uni_ptr(as_global(src)), uni_ptr(as_global(dst)), bsize, lane, spans, uni_ptr(as_global(pat)));
 }
 
 // One stream, start to finish.  Deliberately NOT inlined into the queue loop below: with the decoders
 // inlined, the compiler restructured the loop with partial exec masks and re-read the ticket with lane 0
 // masked off (an endless loop on stream 0).  A real call keeps the loop's control flow trivial.
 __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int32_t* status, volatile uint32_t* scr,
-                                                            const ChunkDesc* chunks, const BlockDesc* blocks, uint32_t* blk_done, int lane
+                                                            const ChunkDesc* chunks, const BlockDesc* blocks, uint32_t* blk_done, int lane,
+                                                            uint32_t sid, uint32_t* spans, uint8_t* pat
 #ifdef BAMD_PROFILE_DECODE
                                                             , uint32_t* profslot
 #endif
@@ -435,14 +497,22 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
   const int32_t want = (int32_t)uni((uint32_t)sd->out_size);
   gu8* out = as_global(sd->out);
   if (csize < 0) return;  // chain error already recorded by the plan kernel
+  const ChunkDesc* c = chunks + uni((uint32_t)sd->chunk);
+  const uint32_t mode = uni(c->mode);
+  const uint32_t gb = uni((uint32_t)sd->aux);
+  const BlockDesc* b = blocks + gb;
+  const uint32_t nstreams = uni((uint32_t)b->nstreams);
+  SpanCtx sp;
+  sp.enabled = ((mode & CH_FUSED_UNSHUF) && nstreams == uni((uint32_t)c->typesize) && spans) ? 1u : 0u;
+  sp.lo = 0; sp.hi = 0; sp.off = 0; sp.pat = uni_ptr(as_global(pat)) + (size_t)sid * SPAN_PAT;
   int got;
   if (csize == want) {    // split stored raw (blosc/blosc.c:773-776)
     wave_copy_disjoint(out, in, (uint32_t)want, lane);
     got = want;
   } else if (sd->fmt == FMT_LZ4) {
-    got = lz4_decode_wave(in, csize, out, want, scr, lane PROF_PASS);
+    got = lz4_decode_wave(in, csize, out, want, scr, lane, sp PROF_PASS);
   } else {
-    got = blosclz_decode_wave(in, csize, out, want, lane);
+    got = blosclz_decode_wave(in, csize, out, want, lane, sp);
   }
 #ifdef BAMD_PROFILE_DECODE
   PROF_LAP(13);
@@ -454,11 +524,8 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
     if (got != want) atomicMin(&status[sd->chunk], (int32_t)ST_BADCODEC);  // blosc.c:780-782
   }
   // ---- fused unshuffle: the wave that completes a block's LAST stream transposes the block ----
-  const ChunkDesc* c = chunks + sd->chunk;
-  const uint32_t mode = uni(c->mode);
   if (!(mode & CH_FUSED_UNSHUF) || got != want) return;
-  const uint32_t gb = uni((uint32_t)sd->aux);
-  const BlockDesc* b = blocks + gb;
+  if (spans && lane == 0) { spans[2 * (size_t)sid] = sp.lo; spans[2 * (size_t)sid + 1] = sp.hi; }
   // All streams of one block are handed out from the SAME per-XCD queue (see k_decode_streams), so the
   // producers and this consumer share one L2: a store that has completed (vmcnt) is in that L2, and the
   // consumer only has to drop its own L1 lines.  No L2 write-back (`buffer_wbl2`) is needed - with 65 536
@@ -467,10 +534,13 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
   uint32_t old = 0;
   if (lane == 0) old = __hip_atomic_fetch_add(&blk_done[gb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   old = (uint32_t)__builtin_amdgcn_readlane((int)old, 0);
-  if (old + 1u != (uint32_t)uni((uint32_t)b->nstreams)) return;
+  if (old + 1u != nstreams) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // buffer_inv sc1: this CU's L1 forgets the block's scratch lines
   const size_t boff = (size_t)uni((uint32_t)b->blk) * (size_t)uni((uint32_t)c->blocksize);
-  unshuffle_block_wave(c->filt + boff, c->dst + boff, uni((uint32_t)b->bsize), (int)uni((uint32_t)c->typesize), lane);
+  const bool split = spans && nstreams == uni((uint32_t)c->typesize);
+  const uint32_t fs = uni((uint32_t)b->first_stream);
+  unshuffle_block_wave(c->filt + boff, c->dst + boff, uni((uint32_t)b->bsize), (int)uni((uint32_t)c->typesize), lane,
+                       split ? spans + 2 * (size_t)fs : nullptr, pat + (size_t)fs * SPAN_PAT);
 }
 
 #ifndef BAMD_DEC_MINWAVES
@@ -487,7 +557,8 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
 __global__ __launch_bounds__(64 * DEC_WAVES, BAMD_DEC_MINWAVES) void k_decode_streams(
     StreamDesc* __restrict__ streams, int32_t* __restrict__ status, uint32_t* __restrict__ tickets /*[8]*/,
     const int32_t* __restrict__ qlist, const int32_t* __restrict__ qoff /*[9]*/,
-    const ChunkDesc* __restrict__ chunks, const BlockDesc* __restrict__ blocks, uint32_t* __restrict__ blk_done
+    const ChunkDesc* __restrict__ chunks, const BlockDesc* __restrict__ blocks, uint32_t* __restrict__ blk_done,
+    uint32_t* __restrict__ spans, uint8_t* __restrict__ pat
 #ifdef BAMD_PROFILE_DECODE
     , uint32_t* __restrict__ profbuf
 #endif
@@ -501,9 +572,9 @@ __global__ __launch_bounds__(64 * DEC_WAVES, BAMD_DEC_MINWAVES) void k_decode_st
   while (t < qlen) {
     const uint32_t sid = (uint32_t)qlist[qbase + t];
 #ifdef BAMD_PROFILE_DECODE
-    decode_one_stream(streams + sid, status, scr[0], chunks, blocks, blk_done, lane, profbuf ? profbuf + (size_t)sid * 16 : nullptr);
+    decode_one_stream(streams + sid, status, scr[0], chunks, blocks, blk_done, lane, sid, spans, pat, profbuf ? profbuf + (size_t)sid * 16 : nullptr);
 #else
-    decode_one_stream(streams + sid, status, scr[0], chunks, blocks, blk_done, lane);
+    decode_one_stream(streams + sid, status, scr[0], chunks, blocks, blk_done, lane, sid, spans, pat);
 #endif
     t = take_ticket(tickets + xcc, lane);
   }
