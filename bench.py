@@ -47,6 +47,21 @@ def make_chunk(kind, nbytes):
     return DATASETS[kind](nbytes)
 
 
+def measured_traffic(kernel, args):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of THIS workload
+    (profiles/r01_final_traffic.json, made by scripts/final_profile.sh + scripts/make_traffic_json.py:
+    FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 corrections applied).  PMC counters cannot be
+    read from inside a timed run, so other workloads than the default one report null."""
+    default = (args.chunks == 128 and args.chunk_mib == 64 and args.typesize == 8 and args.clevel == 5 and
+               args.shuffle == 1 and args.codec == "lz4" and args.data == "bench19")
+    path = os.path.join(ROOT, "profiles", "r01_final_traffic.json")
+    if not default or not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        k = json.load(fh)["kernels"].get(kernel)
+    return k["hbm_bytes"] if k else None
+
+
 def cpu_baseline(chunk_host, typesize, clevel, shuffle, cname, budget_passes):
     """The reference's own SSE2/AVX2 multi-threaded path (oracle/_ref/libblosc_ref.so, built from the
     reference sources) on this box's host cores; falls back to the single-threaded oracle port."""
@@ -253,7 +268,7 @@ def main():
     alg_bytes = total + sum_cb                      # nbytes + cbytes per chunk, x chunks per launch
     ach = alg_bytes / (prof[dom]["ms_avg"] / 1e3) / 1e9
     roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+            "frac": ach / HBM_PEAK_GBPS, "traffic": measured_traffic(dom, args),
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": prof[dom]["ms_avg"]}
     out = {
         "metric": "compress+decompress GB/s (uncompressed) at 1/2/4/8 GPUs vs HBM roofline; ratio",

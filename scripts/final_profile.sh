@@ -7,7 +7,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 TAG=${TAG:-r01_final}
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_trace -o trace -- python bench.py --no-cpu-baseline > gpurun_out/${TAG}_bench_under_trace.log 2>&1
-tail -1 gpurun_out/${TAG}_bench_under_trace.log > gpurun_out/${TAG}_bench_under_trace.json
+grep '^{' gpurun_out/${TAG}_bench_under_trace.log | tail -1 > gpurun_out/${TAG}_bench_under_trace.json
 f=$(find gpurun_out/${TAG}_trace -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" gpurun_out/${TAG}_kernel_stats.csv && head -12 "$f" | cut -c1-200
 rm -rf gpurun_out/${TAG}_trace
