@@ -95,3 +95,24 @@ def wrap_stream_as_chunk(stream, nbytes, fmt):
     c[20:24] = np.array([stream.size], "<i4").view(np.uint8)
     c[24:] = stream
     return c
+
+
+def wrap_planes_as_chunk(streams, neblock, fmt, shuffle_flag=1):
+    """A one-block chunk whose block is SPLIT into len(streams) codec streams (typesize = len(streams),
+    byte-shuffle flag set): what blosc_c writes for a shuffled block (blosc/blosc.c:635-719), with every
+    stream hand-built.  Each stream must decode to exactly `neblock` bytes."""
+    T = len(streams)
+    nbytes = T * neblock
+    body = bytearray()
+    for s in streams:
+        s = bytes(s)
+        body += np.array([len(s)], "<i4").tobytes() + s
+    total = 16 + 4 + len(body)
+    c = np.zeros(total, np.uint8)
+    c[0] = 2; c[1] = 1; c[2] = shuffle_flag | (fmt << 5); c[3] = T
+    c[4:8] = np.array([nbytes], "<i4").view(np.uint8)
+    c[8:12] = np.array([nbytes], "<i4").view(np.uint8)
+    c[12:16] = np.array([total], "<i4").view(np.uint8)
+    c[16:20] = np.array([20], "<i4").view(np.uint8)
+    c[20:] = np.frombuffer(bytes(body), np.uint8)
+    return c

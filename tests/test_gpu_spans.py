@@ -1,0 +1,83 @@
+"""Periodic spans of the fused decode+unshuffle (c-blosc_amd/csrc/k_decode.hip: SpanCtx): planes whose
+stream is "literals + one long match with a power-of-two distance" are not written to the scratch.
+Hand-built LZ4 streams drive every branch: spans taken / refused, later matches that reach back into the
+skipped range (materialise), sources at the span edges, a second long match, every alignment of the
+match start.  The oracle decodes the same chunk; results must be bit-exact."""
+import numpy as np
+import pytest
+
+from helpers import ptr, wrap_planes_as_chunk
+from test_gpu_decompress import _lz4_seq, _lz4_tail
+
+pytestmark = pytest.mark.gpu
+
+NEB = 128 << 10   # bytes per plane
+
+
+def _plane_stream(rng, period, pre_extra, mlen, follow):
+    """literals (period + pre_extra random bytes), a match of `mlen` at distance `period`, optional
+    follow-up sequences, then the closing literals; decodes to exactly NEB bytes."""
+    s = bytearray()
+    produced = 0
+    lit = rng.integers(0, 256, period + pre_extra, dtype=np.uint8).tobytes()
+    s += _lz4_seq(lit, period, mlen); produced += len(lit) + mlen
+    for (nlit, off, ml) in follow:
+        off = min(off, produced + nlit, 65535)
+        s += _lz4_seq(rng.integers(0, 256, nlit, dtype=np.uint8).tobytes(), off, ml); produced += nlit + ml
+    tail = NEB - produced
+    assert tail >= 12, (produced, tail)
+    s += _lz4_tail(rng.integers(0, 256, tail, dtype=np.uint8).tobytes())
+    return bytes(s)
+
+
+def _check(pkg, oracle, streams):
+    chunk = wrap_planes_as_chunk(streams, NEB, 1)
+    n = len(streams) * NEB
+    want = np.zeros(n, np.uint8)
+    assert oracle.orc_decompress(ptr(chunk), ptr(want), n) == n
+    r, out = pkg.decompress(chunk, n)
+    assert r == n
+    return np.array_equal(out, want)
+
+
+FOLLOW = {
+    "none": [],
+    "into_span": [(7, 30000, 300)],                 # source far inside the skipped range
+    "into_span_long": [(0, 50000, 20000)],
+    "short_after": [(3, 5, 40), (0, 1, 30)],        # sources in the freshly written tail
+    "edge_lo": [(5, 0, 64)],                        # patched below: source straddles `lo`
+    "second_long": [(9, 256, 20000)],               # another span-able match while one span exists
+    "many": [(1, 40000, 5), (2, 2049, 70), (0, 17000, 1024), (4, 64, 64)],
+}
+
+
+@pytest.mark.parametrize("period", [1, 2, 4, 8, 64, 256, 1024, 2048, 3, 100, 4096])
+@pytest.mark.parametrize("follow", list(FOLLOW))
+def test_span_streams(pkg, oracle, period, follow):
+    rng = np.random.default_rng(period * 131 + len(follow))
+    bad = []
+    for pre_extra in (0, 1, 5, 1023, 1024, 1500):
+        for mlen in (16383, 16384, 24577, 65536):
+            fl = list(FOLLOW[follow])
+            mpos = period + pre_extra
+            if follow == "edge_lo":
+                lo = (mpos + 1023) & ~1023
+                end = mpos + mlen + 5
+                fl = [(5, end - (lo - 20), 64)]     # source = [lo - 20, lo + 44)
+            streams = [_plane_stream(rng, period, pre_extra, mlen, fl) for _ in range(2)]
+            # the other planes: one plain noisy plane, constant planes, a short-period plane
+            streams.append(_plane_stream(rng, 1, 0, NEB - 1 - 40, []))
+            streams.append(_plane_stream(rng, 256, 3, 100000, [(2, 70000, 12)]))
+            streams += [_plane_stream(rng, 7, 2, 500, [(100, 33, 900)]) for _ in range(2)]
+            streams.append(_plane_stream(rng, 2048, 0, 120000, []))
+            streams.append(_plane_stream(rng, 16, 1, 16400, [(0, 16, 100000)]))
+            if not _check(pkg, oracle, streams):
+                bad.append((pre_extra, mlen))
+    assert not bad, bad
+
+
+def test_span_typesize4(pkg, oracle):
+    rng = np.random.default_rng(5)
+    streams = [_plane_stream(rng, 1, 0, NEB - 100, []), _plane_stream(rng, 512, 9, 90000, [(3, 60000, 33)]),
+               _plane_stream(rng, 5, 0, 20000, []), _plane_stream(rng, 4, 0, 131000, [])]
+    assert _check(pkg, oracle, streams)
