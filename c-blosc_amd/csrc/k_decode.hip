@@ -148,7 +148,8 @@ __device__ __forceinline__ bool span_long_match(gu8* out, uint32_t mpos, uint32_
   }
 #pragma unroll
   for (int k = 0; k < 8; k++) g_st4(sp.pat + 4u * ((uint32_t)lane + 64u * (uint32_t)k), v[k]);
-  for (uint32_t q = hi + (uint32_t)lane; q < mpos + ml; q += 64u) out[q] = out[base + ((q - base) & pm)];
+  // behind the span: < 1 KiB, contiguous in the table just written (hi is a multiple of 1024, so no wrap)
+  wave_copy_disjoint(out + hi, sp.pat + (hi & (SPAN_PAT - 1u)), mpos + ml - hi, lane);
   sp.lo = lo; sp.hi = hi; sp.off = off;
   return true;
 }
@@ -263,6 +264,26 @@ __device__ __forceinline__ uint32_t lz4_batch_step(const Window& w, gu8* out, vo
 //   least 5 bytes before the output end.  Offset 0 (accepted by the reference with unspecified
 //   output) is rejected here.
 // ---------------------------------------------------------------------------------------------
+// LZ4's 255-run length extension (lz4.c:2240-2250 / :2330-2342), 64 stream bytes per step instead of one:
+// value += 255 * (number of leading 0xFF bytes) + the first other byte; ip ends behind that byte.
+// Bytes beyond the stream read as zero (Window::fetch), i.e. as a terminator: the caller's bound check on
+// the final ip (monotonic, so equivalent to the reference's per-byte check) catches a run into the end.
+__device__ __forceinline__ void lz4_ext_run(Window& w, uint32_t& ip, uint32_t& value, uint32_t cap, int lane) {
+  for (;;) {
+    w.seek(ip);
+    const uint32_t B = w.gather_bytes(ip);
+    const uint64_t m = __ballot(B != 255u);
+    if (m) {
+      const uint32_t k = (uint32_t)__builtin_ctzll(m);
+      value += 255u * k + (uint32_t)__builtin_amdgcn_readlane((int)B, (int)k);
+      ip += k + 1u;
+      return;
+    }
+    value += 255u * 64u; ip += 64u;
+    if (value > cap) return;                       // the caller rejects; keeps the loop bounded by cap
+  }
+}
+
 __device__ int lz4_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* out, int32_t cap_, volatile uint32_t* scr, int lane, SpanCtx& sp PROF_ARG) {
   if (cap_ == 0) return (n_ == 1 && in[0] == 0) ? 0 : -1;
   if (n_ <= 0) return -1;
@@ -272,16 +293,22 @@ __device__ int lz4_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* out,
   uint32_t ip = 0, op = 0;
   for (;;) {
     w.seek(ip);
-    if (ip + 72u <= n && lz4_batch_step(w, out, scr, ip, op, cap, lane, sp PROF_PASS)) continue;
+    uint32_t hdr = w.peek32(ip);
+    if (ip + 72u <= n) {
+      // the batched step needs a first token it can take: < 15 literals and at most one match-length byte
+      const uint32_t tk = hdr & 0xffu;
+      bool try_batch = (tk >> 4) != 15u;
+      if (try_batch && (tk & 15u) == 15u) try_batch = (w.peek32(ip + 3u + (tk >> 4)) & 0xffu) != 255u;
+      if (try_batch && lz4_batch_step(w, out, scr, ip, op, cap, lane, sp PROF_PASS)) continue;
+    }
     PROF_ADD(3, 1);
-    const uint32_t hdr = w.peek32(ip);
     const uint32_t token = hdr & 0xffu;
     ip += 1;
     uint32_t ll = token >> 4;
     if (ll == 15u) {
       if (n < 15u || ip >= n - 15u) return -2;
-      uint32_t s;
-      do { s = w.byte_at(ip); ip++; ll += s; if (ip > n - 15u || ll > cap) return -2; } while (s == 255u);
+      lz4_ext_run(w, ip, ll, cap, lane);
+      if (ip > n - 15u || ll > cap) return -2;
     }
     // ---- literals ----
     if (op + ll + 12u > cap || ip + ll + 8u > n) {
@@ -292,10 +319,19 @@ __device__ int lz4_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* out,
       break;
     }
     const uint32_t lit_src = ip;
-    // literal bytes are taken out of the register window BEFORE it may slide for the offset
+    // Literal bytes are fetched BEFORE the window may slide for the offset, and stored after the offset has
+    // been parsed: the loads of a long run and the window fetch behind it travel together (one memory
+    // round trip instead of two).  <= 64 bytes inside the window: a register gather; 16..1024 bytes: one
+    // 16-byte load per lane (the last piece overlaps its neighbour); anything else: copied right away.
     const bool lit_in_win = ll <= 64u && lit_src + ll <= w.base + 512u;
+    const bool lit_early = !lit_in_win && ll >= 16u && ll <= 1024u;
     uint32_t litv = 0;
+    uint4 lit16 = make_uint4(0, 0, 0, 0);
+    uint32_t lit_off = 16u * (uint32_t)lane;
+    const bool lit_mine = lit_early && lit_off < ll;
     if (ll && lit_in_win) litv = w.gather_bytes(lit_src);
+    else if (lit_early) { if (lit_off + 16u > ll) lit_off = ll - 16u; if (lit_mine) lit16 = g_ld16(in + lit_src + lit_off); }
+    else if (ll) wave_copy_disjoint(out + op, in + lit_src, ll, lane);
     ip += ll;
     w.seek(ip);
     uint32_t t2 = w.peek32(ip);
@@ -303,11 +339,11 @@ __device__ int lz4_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* out,
     ip += 2;
     uint32_t ml = token & 15u;
     if (ml == 15u) {
-      uint32_t s = (t2 >> 16) & 0xffu;   // first extension byte is already in the peeked word
-      ip++; ml += s;
+      const uint32_t s0 = (t2 >> 16) & 0xffu;   // first extension byte is already in the peeked word
+      ip++; ml += s0;
       if (ip > n - 4u) return -4;
-      while (s == 255u) {
-        s = w.byte_at(ip); ip++; ml += s;
+      if (s0 == 255u) {
+        lz4_ext_run(w, ip, ml, cap, lane);
         if (ip > n - 4u || ml > cap) return -4;
       }
     }
@@ -326,7 +362,7 @@ __device__ int lz4_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* out,
     } else {
       if (ll) {
         if (lit_in_win) { if ((uint32_t)lane < ll) out[op + lane] = (uint8_t)litv; }
-        else wave_copy_disjoint(out + op, in + lit_src, ll, lane);
+        else if (lit_mine) g_st16(out + op + lit_off, lit16);
       }
       if (!span_long_match(out, mpos, off, ml, lane, sp)) wave_match_copy(out, mpos, off, ml, lane);
     }
