@@ -378,7 +378,107 @@ __device__ int lz4_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* out,
 // like the reference.  Kept quirks: the first control byte is masked with 31; a match is executed
 // only if at least one more input byte follows it (otherwise decoding stops BEFORE the copy).
 // ---------------------------------------------------------------------------------------------
-__device__ int blosclz_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* out, int32_t cap_, int lane, SpanCtx& sp) {
+// Batched BloscLZ step: the LZ4 step's machinery (speculative per-lane parse, pointer doubling in rank
+// space, one scattered literal store, 4-lane match pieces) over BloscLZ's token grammar
+// (blosclz.c:679-789): a control byte < 32 starts a literal run of ctrl+1 bytes; otherwise it is a match
+// with len = (ctrl>>5)-1 (+ one extension byte when that field is 7; longer extensions go to the scalar
+// path) + 3, distance-1 = ((ctrl&31)<<8) + next byte, or a 16-bit big-endian value + 8191 behind the
+// escape 31/255.  `tp` is the position of the current control byte; only called when tp + 72 <= n, so
+// every token taken here is followed by more input (the reference's end-of-input quirks cannot apply).
+__device__ __forceinline__ uint32_t blz_batch_step(const Window& w, gu8* out, volatile uint32_t* scr_generic, uint32_t& tp, uint32_t& op,
+                                                   uint32_t cap, int lane, SpanCtx& sp) {
+  volatile __attribute__((address_space(3))) uint32_t* scr = (volatile __attribute__((address_space(3))) uint32_t*)scr_generic;   // LDS
+  const uint32_t B = w.gather_bytes(tp);                       // stream byte tp + lane
+  const uint32_t b1 = bperm(((uint32_t)lane + 1u) & 63u, B), b2 = bperm(((uint32_t)lane + 2u) & 63u, B);
+  const uint32_t b3 = bperm(((uint32_t)lane + 3u) & 63u, B), b4 = bperm(((uint32_t)lane + 4u) & 63u, B);
+  const bool is_lit = B < 32u;
+  const uint32_t l3 = B >> 5;
+  const bool has_ext = l3 == 7u;
+  const uint32_t code = has_ext ? b2 : b1;
+  const bool far = !is_lit && code == 255u && (B & 31u) == 31u;
+  const uint32_t f0 = has_ext ? b3 : b2, f1 = has_ext ? b4 : b3;
+  const uint32_t ll = is_lit ? B + 1u : 0u;                                       // 1..32
+  const uint32_t ml = is_lit ? 0u : l3 + 2u + (has_ext ? b1 : 0u);                 // 3..263
+  const uint32_t off = far ? ((f0 << 8) | f1) + 8192u : ((B & 31u) << 8) + code + 1u;   // true distance
+  const uint32_t size = is_lit ? B + 2u : 2u + (has_ext ? 1u : 0u) + (far ? 2u : 0u);
+  const bool complete = (is_lit || !(has_ext && b1 == 255u)) && (uint32_t)lane + size <= 64u;
+  const uint32_t nxt = complete ? (uint32_t)lane + size : 64u;
+  // ---- token chain in rank space (see lz4_batch_step) ----
+  const uint32_t J0 = nxt;
+  const uint32_t J1 = hop(J0, J0), J2 = hop(J1, J1), J3 = hop(J2, J2);
+  uint32_t c = 0;
+  { const uint32_t t = hop(J0, c); c = (lane & 1) ? t : c; }
+  { const uint32_t t = hop(J1, c); c = (lane & 2) ? t : c; }
+  { const uint32_t t = hop(J2, c); c = (lane & 4) ? t : c; }
+  { const uint32_t t = hop(J3, c); c = (lane & 8) ? t : c; }
+  const uint32_t pk = bperm(c & 63u, ll | (ml << 6) | ((complete ? 1u : 0u) << 15) | (nxt << 16));
+  const uint32_t off_r = bperm(c & 63u, off);
+  const uint32_t ll_r = pk & 63u, ml_r = (pk >> 6) & 0x1ffu, nxt_r = pk >> 16;
+  const bool valid = lane < (int)BATCH_MAXSEQ && c < 64u && ((pk >> 15) & 1u);
+  const uint32_t tot_r = valid ? ll_r + ml_r : 0u;
+  uint32_t incl = tot_r;
+  incl += row_shr<1>(incl); incl += row_shr<2>(incl); incl += row_shr<4>(incl); incl += row_shr<8>(incl);
+  const uint32_t excl = incl - tot_r;                          // output offset of token r relative to op
+  // acceptance (blosclz.c:730-735): distance inside the produced data, output within bounds
+  const bool ok = valid && (ml_r == 0u || off_r <= op + excl) && op + excl + tot_r <= cap;
+  const uint32_t okmask = (uint32_t)__ballot(ok) & 0xffffu;
+  const uint32_t cnt = (uint32_t)__builtin_ctz(~okmask);
+  if (cnt == 0u) return 0u;
+  if (sp.hi && __ballot((uint32_t)lane < cnt && ml_r != 0u && op + excl - off_r < sp.hi)) span_materialize(out, lane, sp);
+  const uint32_t consumed = (uint32_t)__builtin_amdgcn_readlane((int)nxt_r, (int)(cnt - 1u));
+  const uint32_t acc = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(cnt - 1u));
+  // ---- literals of every accepted run in one scattered byte store ----
+  scr[lane] = 0u;
+  if ((uint32_t)lane < cnt) scr[c] = 0x80000000u | excl | (ll_r << 16);
+  const uint64_t mask = __ballot(scr[lane] >> 31);
+  {
+    const uint64_t below = mask & ((2ull << lane) - 1ull);
+    const uint32_t s = 63u - (uint32_t)__builtin_clzll(below | 1ull);
+    const uint32_t inf = scr[s];
+    const uint32_t k = (uint32_t)lane - s - 1u;
+    if ((uint32_t)lane < consumed && (uint32_t)lane > s && k < ((inf >> 16) & 63u)) out[op + (inf & 0xffffu) + k] = (uint8_t)B;
+  }
+  // ---- short independent matches: 4 lanes each, overlapping 4/8/16-byte pieces (len 3 goes to the rest) ----
+  const bool is_match_r = (uint32_t)lane < cnt && ml_r != 0u;
+  const bool fast_r = is_match_r && ml_r >= 4u && ml_r <= 64u && off_r >= excl + ml_r;   // source ends at or before op
+  {
+    const uint32_t r = (uint32_t)lane >> 2, q = (uint32_t)lane & 3u;
+    const uint32_t fA = bperm(r, fast_r ? (ml_r | 0x200u | (excl << 10)) : 0u);
+    const uint32_t fB = bperm(r, off_r);
+    const uint32_t mlen = fA & 0x1ffu;
+    const bool go = (fA & 0x200u) != 0u;
+    gu8* d = out + op + (fA >> 10);
+    const gu8* sp_ = d - fB;
+    const bool w16 = go && mlen >= 16u && q < ((mlen + 15u) >> 4);
+    const bool w8 = go && mlen >= 8u && mlen < 16u && q < 2u;
+    const bool w4 = go && mlen < 8u && q < 2u;
+    const uint32_t np16 = (mlen + 15u) >> 4;
+    const uint32_t po16 = (q == np16 - 1u) ? mlen - 16u : 16u * q;
+    const uint32_t po8 = q ? mlen - 8u : 0u, po4 = q ? mlen - 4u : 0u;
+    uint4 v16 = make_uint4(0, 0, 0, 0); uint64_t v8 = 0; uint32_t v4 = 0;
+    if (w16) v16 = g_ld16(sp_ + po16);
+    if (w8) v8 = g_ld8(sp_ + po8);
+    if (w4) v4 = g_ld4(sp_ + po4);
+    if (w16) g_st16(d + po16, v16);
+    if (w8) *(BAMD_GAS u64una*)(d + po8) = v8;
+    if (w4) g_st4(d + po4, v4);
+  }
+  // ---- everything else in stream order ----
+  uint32_t rest = (uint32_t)__ballot(is_match_r && !fast_r);
+  while (rest) {
+    const int sl = __builtin_ctz(rest);
+    rest &= rest - 1u;
+    const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)ml_r, sl);
+    const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)off_r, sl);
+    const uint32_t mr = (uint32_t)__builtin_amdgcn_readlane((int)excl, sl);
+    wave_match_copy(out, op + mr, o, m, lane);
+  }
+  tp += consumed;
+  op += acc;
+  return cnt;
+}
+
+__device__ int blosclz_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* out, int32_t cap_, volatile uint32_t* scr, int lane, SpanCtx& sp) {
   if (n_ <= 0) return 0;
   const uint32_t n = (uint32_t)n_, cap = (uint32_t)cap_;
   Window w;
@@ -386,6 +486,17 @@ __device__ int blosclz_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* 
   uint32_t ip = 1, op = 0;
   uint32_t ctrl = w.peek32(0) & 31u;
   for (;;) {
+    // batched step from the current control byte (at ip - 1); not for the stream's first byte (masked above)
+    if (ip > 1u && ip + 71u <= n) {
+      uint32_t tp = ip - 1u;
+      w.seek(tp);
+      bool try_batch = true;
+      if (ctrl >= 224u) try_batch = (w.peek32(ip) & 0xffu) != 255u;     // longer length extensions: scalar path
+      if (try_batch && blz_batch_step(w, out, scr, tp, op, cap, lane, sp)) {
+        ctrl = w.byte_at(tp); ip = tp + 1u;
+        continue;
+      }
+    }
     if (ctrl >= 32u) {
       uint32_t len = (ctrl >> 5) - 1u;
       uint32_t ofs = (ctrl & 31u) << 8;
@@ -548,7 +659,7 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
   } else if (sd->fmt == FMT_LZ4) {
     got = lz4_decode_wave(in, csize, out, want, scr, lane, sp PROF_PASS);
   } else {
-    got = blosclz_decode_wave(in, csize, out, want, lane, sp);
+    got = blosclz_decode_wave(in, csize, out, want, scr, lane, sp);
   }
 #ifdef BAMD_PROFILE_DECODE
   PROF_LAP(13);

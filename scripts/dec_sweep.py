@@ -12,7 +12,7 @@ host = DATASETS[dname](csz)
 R = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libblosc_ref.so"))
 R.blosc_compress_ctx.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int]
 tmp = np.empty(csz + 16, np.uint8)
-r = R.blosc_compress_ctx(5, 1, 8, csz, host.ctypes.data, tmp.ctypes.data, csz + 16, b"lz4", 0, 1)
+r = R.blosc_compress_ctx(5, 1, int(os.environ.get("TYPESIZE", "8")), csz, host.ctypes.data, tmp.ctypes.data, csz + 16, os.environ.get("CODEC", "lz4").encode(), 0, 1)
 dev = torch.device("cuda:0")
 comp = torch.empty((nchunks, csz + 256), dtype=torch.uint8, device=dev)
 comp[:, :r].copy_(torch.from_numpy(tmp[:r].copy()).to(dev).unsqueeze(0).expand(nchunks, r))
