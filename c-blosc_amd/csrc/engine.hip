@@ -526,7 +526,7 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
       ProfScope ps(st, stream, "k_decode_streams");
       // Occupancy knob: unused dynamic LDS caps how many decoder waves share a CU (and its L2 slice).
       static const int dec_lds = getenv("BLOSC_AMD_DEC_LDS") ? atoi(getenv("BLOSC_AMD_DEC_LDS")) : 0;
-      static const int dec_wpc = getenv("BLOSC_AMD_DEC_WPC") ? atoi(getenv("BLOSC_AMD_DEC_WPC")) : 32;
+      static const int dec_wpc = getenv("BLOSC_AMD_DEC_WPC") ? atoi(getenv("BLOSC_AMD_DEC_WPC")) : DEC_WAVES_PER_CU;
       const dim3 dgrid(persistent_grid(L.nstr, dec_wpc));
 #ifdef BAMD_PROFILE_DECODE
       uint32_t* d_prof = nullptr;

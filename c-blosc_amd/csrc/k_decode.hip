@@ -691,8 +691,9 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
 }
 
 #ifndef BAMD_DEC_MINWAVES
-#define BAMD_DEC_MINWAVES 7
-#endif
+#define BAMD_DEC_MINWAVES 6   // waves per SIMD (80 VGPRs).  Same-session A/B on MI355X with both batched decoders in:
+#endif                       // 6 = 5 (5.90 / 5.95 ms) < 7 (6.33) < 8 (7.0): spills cost more than occupancy gives
+constexpr int DEC_WAVES_PER_CU = 4 * BAMD_DEC_MINWAVES;
 // Persistent launch: the grid is sized to what the chip can hold (engine.hip) and every wave pulls stream
 // indices from a ticket queue until it is empty.  Streams of one batch differ by 1000x in cost (a byte
 // plane of zeros is two sequences, a noisy plane thousands); with one workgroup per stream the dispatcher
