@@ -9,6 +9,7 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include <algorithm>
 
 #include "blosc_format.h"
 #include "dev_types.h"
@@ -76,6 +77,11 @@ struct EngineState {
   struct Pending { std::string name; hipEvent_t a, b; };
   std::vector<Pending> prof_pending;
   std::vector<hipEvent_t> ev_pool;
+  // Scheduling feedback: cycles the previous batch spent per plane index (stream index inside its block),
+  // summed by the kernels.  Streams of one batch differ by 100x in cost and the expensive ones are, call
+  // after call, the same byte planes; the queue builders use this to keep them out of the kernels' tails.
+  uint32_t enc_cost[256] = {0}, dec_cost[256] = {0};
+  bool enc_cost_valid = false, dec_cost_valid = false;
 };
 static EngineState& S() { static EngineState s; return s; }
 
@@ -159,21 +165,54 @@ static bool fuse_enabled() { static const bool on = !(getenv("BLOSC_AMD_FUSE") &
 // task is queued kEncLookahead blocks ahead of its streams: by the time a wave draws one of the streams
 // the transpose is normally finished, and it is always already owned by a running wave (no deadlock).
 constexpr size_t kEncLookahead = 32;
-static void build_encode_queues(const std::vector<BlockDesc>& blocks, const std::vector<ChunkDesc>& chunks, std::vector<int32_t>& out) {
+// BLOSC_AMD_SCHED=0: plain block order (no cost feedback)
+static bool sched_enabled() { static const bool on = !(getenv("BLOSC_AMD_SCHED") && atoi(getenv("BLOSC_AMD_SCHED")) == 0); return on; }
+
+// plane indices 0..T-1 in descending cost; *nheavy = how many of them count as expensive (> max/2)
+static void plane_order(const uint32_t* cost, bool valid, int T, std::vector<int>& order, int* nheavy) {
+  order.resize((size_t)T);
+  for (int j = 0; j < T; j++) order[(size_t)j] = j;
+  *nheavy = T;
+  if (!valid || T <= 1 || T > 256) return;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+  const uint32_t mx = cost[order[0]];
+  if (mx == 0) return;
+  int h = 0;
+  while (h < T && cost[order[(size_t)h]] > mx / 2) h++;
+  *nheavy = h;
+}
+
+// With cost feedback the queue has two passes: the first, in block order, carries the shuffle tasks and the
+// streams of the expensive planes; the second carries the cheap planes, plane by plane in descending cost.
+// The kernel's tail (waves finishing their last stream while the queue is already empty) then consists of
+// cheap streams instead of 3 ms ones.
+static void build_encode_queues(const std::vector<BlockDesc>& blocks, const std::vector<ChunkDesc>& chunks,
+                                const uint32_t* cost, bool cost_valid, std::vector<int32_t>& out) {
   std::vector<int32_t> q[8];
   std::vector<uint32_t> mine[8];
   for (size_t g = 0; g < blocks.size(); g++) if (blocks[g].nstreams > 0) mine[g & 7].push_back((uint32_t)g);
+  std::vector<int> order; int nheavy = 0, lastT = -1;
   for (int x = 0; x < 8; x++) {
     const std::vector<uint32_t>& B = mine[x];
     auto push_shuffle = [&](size_t i) {
       if (chunks[(size_t)blocks[B[i]].chunk].mode & CH_FUSED_SHUF) q[x].push_back(-(int32_t)B[i] - 1);
     };
+    int maxT = 1;
     for (size_t i = 0; i < B.size() && i < kEncLookahead; i++) push_shuffle(i);
     for (size_t i = 0; i < B.size(); i++) {
       if (i + kEncLookahead < B.size()) push_shuffle(i + kEncLookahead);
       const BlockDesc& b = blocks[B[i]];
-      for (int32_t k = 0; k < b.nstreams; k++) q[x].push_back(b.first_stream + k);
+      if (b.nstreams != lastT) { plane_order(cost, cost_valid && sched_enabled(), b.nstreams, order, &nheavy); lastT = b.nstreams; }
+      if (b.nstreams > maxT) maxT = b.nstreams;
+      for (int k = 0; k < nheavy; k++) q[x].push_back(b.first_stream + order[(size_t)k]);
     }
+    // second pass: the cheap planes, most expensive first (rank k of each block's own order)
+    for (int k = 1; k < maxT; k++)
+      for (size_t i = 0; i < B.size(); i++) {
+        const BlockDesc& b = blocks[B[i]];
+        if (b.nstreams != lastT) { plane_order(cost, cost_valid && sched_enabled(), b.nstreams, order, &nheavy); lastT = b.nstreams; }
+        if (k >= nheavy && k < b.nstreams) q[x].push_back(b.first_stream + order[(size_t)k]);
+      }
   }
   out.assign(9, 0);
   for (int x = 0; x < 8; x++) { out[(size_t)x + 1] = out[(size_t)x] + (int32_t)q[x].size(); }
@@ -279,9 +318,10 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   const size_t o_blkoff = cv.take(sizeof(int32_t) * (nblk ? nblk : 1));
   const size_t o_results = cv.take(sizeof(int32_t) * (size_t)n + 64);   // + the 8 ticket counters of the encode queues
   std::vector<int32_t> queues;
-  build_encode_queues(blocks, chunks, queues);
+  build_encode_queues(blocks, chunks, st.enc_cost, st.enc_cost_valid, queues);
   const size_t o_queues = cv.take(sizeof(int32_t) * queues.size());
   const size_t o_ready = cv.take(sizeof(uint32_t) * (nblk ? nblk : 1));
+  const size_t o_cost = cv.take(sizeof(uint32_t) * 256);
   const size_t o_filt = cv.take(filt_bytes + 256);
   const size_t o_stage = cv.take(stage_bytes + 256);
   if (st.dev.ensure(cv.off)) return -1;
@@ -325,6 +365,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   const size_t p_streams = pc.take(sizeof(StreamDesc) * (nstr ? nstr : 1));
   const size_t p_results = pc.take(sizeof(int32_t) * (size_t)n);
   const size_t p_queues = pc.take(sizeof(int32_t) * queues.size());
+  const size_t p_cost = pc.take(sizeof(uint32_t) * 256);
   if (st.pin.ensure(pc.off)) return -1;
   uint8_t* P = st.pin.base;
   memcpy(P + p_chunks, chunks.data(), sizeof(ChunkDesc) * (size_t)n);
@@ -333,6 +374,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   memcpy(P + p_queues, queues.data(), sizeof(int32_t) * queues.size());
   HIP_TRY(hipMemcpyAsync(D + o_queues, P + p_queues, sizeof(int32_t) * queues.size(), hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemsetAsync(D + o_ready, 0, sizeof(uint32_t) * (nblk ? nblk : 1), stream));
+  HIP_TRY(hipMemsetAsync(D + o_cost, 0, sizeof(uint32_t) * 256, stream));
   HIP_TRY(hipMemcpyAsync(D + o_chunks, P + p_chunks, sizeof(ChunkDesc) * (size_t)n, hipMemcpyHostToDevice, stream));
   if (nblk) HIP_TRY(hipMemcpyAsync(D + o_blocks, P + p_blocks, sizeof(BlockDesc) * nblk, hipMemcpyHostToDevice, stream));
   if (nstr) HIP_TRY(hipMemcpyAsync(D + o_streams, P + p_streams, sizeof(StreamDesc) * nstr, hipMemcpyHostToDevice, stream));
@@ -363,7 +405,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
 #ifdef BAMD_PROFILE_DECODE
     uint32_t* d_prof = nullptr;
     if (getenv("BLOSC_AMD_ENC_PROFILE")) { (void)hipMalloc((void**)&d_prof, nstr * 64); (void)hipMemsetAsync(d_prof, 0, nstr * 64, stream); }
-    hipLaunchKernelGGL(k_encode_streams, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, d_prof);
+    hipLaunchKernelGGL(k_encode_streams, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), d_prof);
     if (d_prof) {
       std::vector<uint32_t> h(nstr * 16);
       (void)hipStreamSynchronize(stream);
@@ -373,7 +415,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
       (void)hipFree(d_prof);
     }
 #else
-    hipLaunchKernelGGL(k_encode_streams, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready);
+    hipLaunchKernelGGL(k_encode_streams, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost));
 #endif
   }
   {
@@ -386,8 +428,10 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(P + p_results, d_results, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipMemcpyAsync(P + p_cost, D + o_cost, sizeof(uint32_t) * 256, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   prof_collect(st);
+  if (nstr >= 4096) { memcpy(st.enc_cost, P + p_cost, sizeof st.enc_cost); st.enc_cost_valid = true; }   // small calls say little
   const int32_t* r = (const int32_t*)(P + p_results);
   for (int i = 0; i < n; i++) if (live[(size_t)i]) results[i] = r[i];
   if (getenv("BLOSC_AMD_DEBUG")) {
@@ -495,22 +539,44 @@ static void add_decode_chunk(const Header& h, int fmt, int chunk_index, int32_t 
 
 // Deals whole blocks round-robin to 8 per-XCD queues; queue x lists the stream ids of its blocks.
 // Layout: qoff[9] (int32) followed by qlist[nstr].
-static void build_xcd_queues(const std::vector<BlockDesc>& blocks, size_t nstr, std::vector<int32_t>& out) {
-  out.assign(9 + (nstr ? nstr : 1), 0);
-  int32_t cnt[8] = {0};
-  for (size_t g = 0; g < blocks.size(); g++) cnt[g & 7] += blocks[g].nstreams;
-  int32_t off[9]; off[0] = 0;
-  for (int x = 0; x < 8; x++) off[x + 1] = off[x] + cnt[x];
-  for (int x = 0; x <= 8; x++) out[(size_t)x] = off[x];
-  int32_t fill[8];
-  for (int x = 0; x < 8; x++) fill[x] = off[x];
-  for (size_t g = 0; g < blocks.size(); g++)
-    for (int32_t s = 0; s < blocks[g].nstreams; s++) out[9 + (size_t)fill[g & 7]++] = blocks[g].first_stream + s;
+// Per-XCD stream queues of the decode kernel: out = off[9] | stream indices.  Block g belongs to XCD g & 7
+// (all streams of a block on one XCD: the fused unshuffle hands over through that XCD's L2).
+// With cost feedback the expensive planes of block i + kDecLead are queued together with the cheap planes of
+// block i: blocks still complete in order (the unshuffles stay spread over the whole kernel), but the
+// streams drawn last - the kernel's tail - are cheap ones.
+constexpr size_t kDecLead = 256;
+static void build_xcd_queues(const std::vector<BlockDesc>& blocks, size_t nstr, const uint32_t* cost, bool cost_valid,
+                             std::vector<int32_t>& out) {
+  std::vector<int32_t> q[8];
+  std::vector<uint32_t> mine[8];
+  for (size_t g = 0; g < blocks.size(); g++) if (blocks[g].nstreams > 0) mine[g & 7].push_back((uint32_t)g);
+  std::vector<int> order; int nheavy = 0, lastT = -1;
+  auto prep = [&](const BlockDesc& b) {
+    if (b.nstreams != lastT) { plane_order(cost, cost_valid && sched_enabled(), b.nstreams, order, &nheavy); lastT = b.nstreams; }
+  };
+  for (int x = 0; x < 8; x++) {
+    const std::vector<uint32_t>& B = mine[x];
+    const size_t lead = B.size() > 2 * kDecLead ? kDecLead : B.size() / 4;
+    auto push_heavy = [&](size_t i) { const BlockDesc& b = blocks[B[i]]; prep(b); if (nheavy < b.nstreams) for (int k = 0; k < nheavy; k++) q[x].push_back(b.first_stream + order[(size_t)k]); };
+    for (size_t i = 0; i < B.size() && i < lead; i++) push_heavy(i);
+    for (size_t i = 0; i < B.size(); i++) {
+      if (i + lead < B.size()) push_heavy(i + lead);
+      const BlockDesc& b = blocks[B[i]];
+      prep(b);
+      if (nheavy < b.nstreams) { for (int k = nheavy; k < b.nstreams; k++) q[x].push_back(b.first_stream + order[(size_t)k]); }
+      else for (int k = 0; k < b.nstreams; k++) q[x].push_back(b.first_stream + k);   // no feedback: plain order
+    }
+  }
+  out.assign(9, 0);
+  for (int x = 0; x < 8; x++) out[(size_t)x + 1] = out[(size_t)x] + (int32_t)q[x].size();
+  for (int x = 0; x < 8; x++) out.insert(out.end(), q[x].begin(), q[x].end());
+  out.resize(9 + (nstr ? nstr : 1), 0);
 }
 
 struct DecodeLaunch {
   ChunkDesc* d_chunks; BlockDesc* d_blocks; StreamDesc* d_streams; int32_t* d_status; uint32_t* d_ticket; uint32_t* d_blkdone;
   uint32_t* d_spans; uint8_t* d_pat;             // periodic spans of the fused unshuffle (k_decode.hip: SpanCtx)
+  uint32_t* d_cost;                              // [256] cycles per plane index (scheduling feedback)
   const int32_t* d_qlist; const int32_t* d_qoff;   // per-XCD stream queues
   size_t nblk, nstr; int nchunks;
   bool any_shuf, any_bit, any_copy; int tiles_shuf, tiles_bit;
@@ -531,7 +597,7 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
 #ifdef BAMD_PROFILE_DECODE
       uint32_t* d_prof = nullptr;
       if (getenv("BLOSC_AMD_DEC_PROFILE")) { (void)hipMalloc((void**)&d_prof, L.nstr * 64); (void)hipMemsetAsync(d_prof, 0, L.nstr * 64, stream); }
-      hipLaunchKernelGGL(k_decode_streams, dgrid, dim3(64 * DEC_WAVES), (size_t)dec_lds, stream, L.d_streams, L.d_status, L.d_ticket, L.d_qlist, L.d_qoff, L.d_chunks, L.d_blocks, L.d_blkdone, L.d_spans, L.d_pat, d_prof);
+      hipLaunchKernelGGL(k_decode_streams, dgrid, dim3(64 * DEC_WAVES), (size_t)dec_lds, stream, L.d_streams, L.d_status, L.d_ticket, L.d_qlist, L.d_qoff, L.d_chunks, L.d_blocks, L.d_blkdone, L.d_spans, L.d_pat, L.d_cost, d_prof);
       if (d_prof) {
         std::vector<uint32_t> h(L.nstr * 16);
         (void)hipStreamSynchronize(stream);
@@ -541,7 +607,7 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
         (void)hipFree(d_prof);
       }
 #else
-      hipLaunchKernelGGL(k_decode_streams, dgrid, dim3(64 * DEC_WAVES), (size_t)dec_lds, stream, L.d_streams, L.d_status, L.d_ticket, L.d_qlist, L.d_qoff, L.d_chunks, L.d_blocks, L.d_blkdone, L.d_spans, L.d_pat);
+      hipLaunchKernelGGL(k_decode_streams, dgrid, dim3(64 * DEC_WAVES), (size_t)dec_lds, stream, L.d_streams, L.d_status, L.d_ticket, L.d_qlist, L.d_qoff, L.d_chunks, L.d_blocks, L.d_blkdone, L.d_spans, L.d_pat, L.d_cost);
 #endif
     }
     if (L.any_shuf) {
@@ -614,6 +680,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   const size_t o_streams = cv.take(sizeof(StreamDesc) * (nstr ? nstr : 1));
   const size_t o_status = cv.take(sizeof(int32_t) * (size_t)n + 64 + sizeof(uint32_t) * (nblk ? nblk : 1));   // + 8 tickets + per-block arrival counters
   const size_t o_queues = cv.take(sizeof(int32_t) * (9 + (nstr ? nstr : 1)));
+  const size_t o_cost = cv.take(sizeof(uint32_t) * 256);
   const size_t o_spans = cv.take(8 * (nstr ? nstr : 1));
   const size_t o_pat = cv.take(span_enabled() ? (size_t)2048 * (nstr ? nstr : 1) : 256);
   const size_t o_filt = cv.take(filt_bytes + 256);
@@ -639,12 +706,13 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
     }
   }
   std::vector<int32_t> queues;
-  build_xcd_queues(blocks, nstr, queues);
+  build_xcd_queues(blocks, nstr, st.dec_cost, st.dec_cost_valid, queues);
   Carver pc;
   const size_t p_chunks = pc.take(sizeof(ChunkDesc) * (size_t)n);
   const size_t p_blocks = pc.take(sizeof(BlockDesc) * (nblk ? nblk : 1));
   const size_t p_status = pc.take(sizeof(int32_t) * (size_t)n);
   const size_t p_queues = pc.take(sizeof(int32_t) * queues.size());
+  const size_t p_cost = pc.take(sizeof(uint32_t) * 256);
   if (st.pin.ensure(pc.off)) return -1;
   uint8_t* P = st.pin.base;
   memcpy(P + p_chunks, chunks.data(), sizeof(ChunkDesc) * (size_t)n);
@@ -661,11 +729,15 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   L.d_blkdone = (uint32_t*)(D + o_status + sizeof(int32_t) * (size_t)n + 64);
   L.d_qoff = (const int32_t*)(D + o_queues); L.d_qlist = L.d_qoff + 9;
   L.d_spans = span_enabled() ? (uint32_t*)(D + o_spans) : nullptr; L.d_pat = D + o_pat;
+  L.d_cost = (uint32_t*)(D + o_cost);
+  HIP_TRY(hipMemsetAsync(D + o_cost, 0, sizeof(uint32_t) * 256, stream));
   L.nblk = nblk; L.nstr = nstr; L.nchunks = n;
   if (launch_decode(st, L, stream)) return -1;
   HIP_TRY(hipMemcpyAsync(P + p_status, D + o_status, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipMemcpyAsync(P + p_cost, D + o_cost, sizeof(uint32_t) * 256, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   prof_collect(st);
+  if (nstr >= 4096) { memcpy(st.dec_cost, P + p_cost, sizeof st.dec_cost); st.dec_cost_valid = true; }
   const int32_t* stt = (const int32_t*)(P + p_status);
   for (int i = 0; i < n; i++) {
     if (!live[(size_t)i]) continue;
@@ -739,6 +811,7 @@ int engine_getitem(const void* src, int start, int nitems, void* dest, bool src_
   const size_t o_streams = cv.take(sizeof(StreamDesc) * nstr);
   const size_t o_status = cv.take(sizeof(int32_t) + 64 + sizeof(uint32_t) * nblk);
   const size_t o_queues = cv.take(sizeof(int32_t) * (9 + nstr));
+  const size_t o_cost = cv.take(sizeof(uint32_t) * 256);
   const size_t o_spans = cv.take(8 * nstr);
   const size_t o_pat = cv.take(span_enabled() ? (size_t)2048 * nstr : 256);
   const size_t o_out = cv.take(span + 256);
@@ -756,7 +829,7 @@ int engine_getitem(const void* src, int start, int nitems, void* dest, bool src_
   const size_t p_blocks = pc.take(sizeof(BlockDesc) * nblk);
   const size_t p_status = pc.take(sizeof(int32_t));
   std::vector<int32_t> queues;
-  build_xcd_queues(blocks, nstr, queues);
+  build_xcd_queues(blocks, nstr, st.dec_cost, st.dec_cost_valid, queues);
   const size_t p_queues = pc.take(sizeof(int32_t) * queues.size());
   if (st.pin.ensure(pc.off)) return -1;
   uint8_t* P = st.pin.base;
@@ -773,6 +846,7 @@ int engine_getitem(const void* src, int start, int nitems, void* dest, bool src_
   L.d_blkdone = (uint32_t*)(D + o_status + 68);
   L.d_qoff = (const int32_t*)(D + o_queues); L.d_qlist = L.d_qoff + 9;
   L.d_spans = span_enabled() ? (uint32_t*)(D + o_spans) : nullptr; L.d_pat = D + o_pat;
+  L.d_cost = nullptr;   // a handful of blocks: no feedback
   L.nblk = nblk; L.nstr = nstr; L.nchunks = 1;
   if (launch_decode(st, L, stream)) return -1;
   HIP_TRY(hipMemcpyAsync(P + p_status, D + o_status, sizeof(int32_t), hipMemcpyDeviceToHost, stream));

@@ -633,7 +633,7 @@ __device__ __attribute__((noinline)) void unshuffle_block_wave(const uint8_t* sr
 // masked off (an endless loop on stream 0).  A real call keeps the loop's control flow trivial.
 __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int32_t* status, volatile uint32_t* scr,
                                                             const ChunkDesc* chunks, const BlockDesc* blocks, uint32_t* blk_done, int lane,
-                                                            uint32_t sid, uint32_t* spans, uint8_t* pat
+                                                            uint32_t sid, uint32_t* spans, uint8_t* pat, uint32_t* plane_cost
 #ifdef BAMD_PROFILE_DECODE
                                                             , uint32_t* profslot
 #endif
@@ -652,6 +652,7 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
   SpanCtx sp;
   sp.enabled = ((mode & CH_FUSED_UNSHUF) && nstreams == uni((uint32_t)c->typesize) && spans) ? 1u : 0u;
   sp.lo = 0; sp.hi = 0; sp.off = 0; sp.pat = uni_ptr(as_global(pat)) + (size_t)sid * SPAN_PAT;
+  const uint64_t cost_t0 = __builtin_amdgcn_s_memtime();
   int got;
   if (csize == want) {    // split stored raw (blosc/blosc.c:773-776)
     wave_copy_disjoint(out, in, (uint32_t)want, lane);
@@ -669,6 +670,8 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
   if (lane == 0) {
     sd->result = got;
     if (got != want) atomicMin(&status[sd->chunk], (int32_t)ST_BADCODEC);  // blosc.c:780-782
+    // cost feedback for the host's queue order (engine.hip: build_xcd_queues): cycles per plane index
+    if (plane_cost) atomicAdd(plane_cost + ((sid - (uint32_t)b->first_stream) & 255u), (uint32_t)((__builtin_amdgcn_s_memtime() - cost_t0) >> 10));
   }
   // ---- fused unshuffle: the wave that completes a block's LAST stream transposes the block ----
   if (!(mode & CH_FUSED_UNSHUF) || got != want) return;
@@ -706,7 +709,7 @@ __global__ __launch_bounds__(64 * DEC_WAVES, BAMD_DEC_MINWAVES) void k_decode_st
     StreamDesc* __restrict__ streams, int32_t* __restrict__ status, uint32_t* __restrict__ tickets /*[8]*/,
     const int32_t* __restrict__ qlist, const int32_t* __restrict__ qoff /*[9]*/,
     const ChunkDesc* __restrict__ chunks, const BlockDesc* __restrict__ blocks, uint32_t* __restrict__ blk_done,
-    uint32_t* __restrict__ spans, uint8_t* __restrict__ pat
+    uint32_t* __restrict__ spans, uint8_t* __restrict__ pat, uint32_t* __restrict__ plane_cost
 #ifdef BAMD_PROFILE_DECODE
     , uint32_t* __restrict__ profbuf
 #endif
@@ -720,9 +723,9 @@ __global__ __launch_bounds__(64 * DEC_WAVES, BAMD_DEC_MINWAVES) void k_decode_st
   while (t < qlen) {
     const uint32_t sid = (uint32_t)qlist[qbase + t];
 #ifdef BAMD_PROFILE_DECODE
-    decode_one_stream(streams + sid, status, scr[0], chunks, blocks, blk_done, lane, sid, spans, pat, profbuf ? profbuf + (size_t)sid * 16 : nullptr);
+    decode_one_stream(streams + sid, status, scr[0], chunks, blocks, blk_done, lane, sid, spans, pat, plane_cost, profbuf ? profbuf + (size_t)sid * 16 : nullptr);
 #else
-    decode_one_stream(streams + sid, status, scr[0], chunks, blocks, blk_done, lane, sid, spans, pat);
+    decode_one_stream(streams + sid, status, scr[0], chunks, blocks, blk_done, lane, sid, spans, pat, plane_cost);
 #endif
     t = take_ticket(tickets + xcc, lane);
   }

@@ -557,7 +557,8 @@ __device__ __attribute__((noinline)) void shuffle_block_task(const ChunkDesc* ch
 }
 
 // one stream, not inlined into the queue loop (see decode_one_stream in k_decode.hip for why)
-__device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, enc_entry_t* tab, const ChunkDesc* chunks, uint32_t* blk_ready, int lane
+__device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, enc_entry_t* tab, const ChunkDesc* chunks, uint32_t* blk_ready, int lane,
+                                                            const BlockDesc* blocks, uint32_t sid, uint32_t* plane_cost
 #ifdef BAMD_PROFILE_DECODE
                                                             , uint32_t* profslot
 #endif
@@ -576,10 +577,16 @@ __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, enc_
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   PROF_LAP(13);
+  const uint64_t cost_t0 = __builtin_amdgcn_s_memtime();
   uint32_t r;
   if (sd->fmt == FMT_LZ4) r = lz_encode_wave<EF_LZ4>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, lane EPROF_PASS);
   else r = lz_encode_wave<EF_BLOSCLZ>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, lane EPROF_PASS);
   if (lane == 0) sd->result = (int32_t)r;
+  // cost feedback for the host's queue order (engine.hip: build_encode_queues): cycles per plane index
+  if (plane_cost && lane == 0) {
+    const uint32_t j = sid - (uint32_t)blocks[aux >> 4].first_stream;
+    atomicAdd(plane_cost + (j & 255u), (uint32_t)((__builtin_amdgcn_s_memtime() - cost_t0) >> 10));
+  }
 #ifdef BAMD_PROFILE_DECODE
   prof_.c[15] = (uint32_t)(prof_.t0 >> 6);
   if (lane == 0 && profslot) for (int i_ = 0; i_ < 16; i_++) profslot[i_] = prof_.c[i_];
@@ -597,7 +604,7 @@ __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, enc_
 __global__ __launch_bounds__(64 * ENC_WAVES, BAMD_ENC_MINWAVES) void k_encode_streams(
     StreamDesc* __restrict__ streams, uint32_t* __restrict__ tickets /*[8]*/, const int32_t* __restrict__ qlist,
     const int32_t* __restrict__ qoff /*[9]*/, const ChunkDesc* __restrict__ chunks, const BlockDesc* __restrict__ blocks,
-    uint32_t* __restrict__ blk_ready
+    uint32_t* __restrict__ blk_ready, uint32_t* __restrict__ plane_cost
 #ifdef BAMD_PROFILE_DECODE
     , uint32_t* __restrict__ profbuf
 #endif
@@ -614,9 +621,9 @@ __global__ __launch_bounds__(64 * ENC_WAVES, BAMD_ENC_MINWAVES) void k_encode_st
       shuffle_block_task(chunks, blocks, (uint32_t)(-(task + 1)), blk_ready, lane);
     } else {
 #ifdef BAMD_PROFILE_DECODE
-      encode_one_stream(streams + task, tabs[0], chunks, blk_ready, lane, profbuf ? profbuf + (size_t)task * 16 : nullptr);
+      encode_one_stream(streams + task, tabs[0], chunks, blk_ready, lane, blocks, (uint32_t)task, plane_cost, profbuf ? profbuf + (size_t)task * 16 : nullptr);
 #else
-      encode_one_stream(streams + task, tabs[0], chunks, blk_ready, lane);
+      encode_one_stream(streams + task, tabs[0], chunks, blk_ready, lane, blocks, (uint32_t)task, plane_cost);
 #endif
     }
     t = take_ticket(tickets + xcc, lane);
