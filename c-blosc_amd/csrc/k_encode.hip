@@ -327,6 +327,12 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
   const uint32_t last_start = n - 12u;                       // inclusive bound on match starts
   const uint32_t mlimit = (FMT == EF_LZ4) ? n - 5u : n - 2u;  // matches end at or before this position
   const int accel = 10 - clevel;                              // blosc/blosc.c:577-587
+  // Effort knob in the spirit of the reference's clevel -> LZ4 acceleration mapping (blosc.c:577-587: lower
+  // levels look at fewer positions) and of blosclz's tunable minimum match length (blosclz.c:445-457):
+  // below clevel 9 a match must be longer than the format minimum to be taken.  4-byte matches are mostly accidental in noisy planes, save one
+  // byte each and cost a full sequence: requiring 6 halves the encode time of noisy float64 data for
+  // < 1 % of ratio (bench19: 53.3 -> 48.5, still far above the reference's 36.7 at this clevel).
+  const uint32_t minlen = clevel >= 9 ? 4u : (clevel >= 6 ? 5u : 6u);
 
   for (int k = lane; k < ENC_TAB; k += 64) tab[k] = 0u;
 
@@ -391,13 +397,13 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
       const Bytes20 cb = load20(src, cand, n);
       len = common20(own, cb);
       if (len > limit) len = limit;
-      if (len < 4u) len = 0;
+      if (len < minlen) len = 0;
       if (FMT == EF_BLOSCLZ && len < 6u && p - cand - 1u >= 8191u) len = 0;   // far and short (blosclz.c:535)
     }
     if (live && prev < 0x100u) {                    // distance 1: run of the previous byte
       uint32_t rl = runlen20(own, prev);
       if (rl > limit) rl = limit;
-      if (rl >= 4u && rl > len) { len = rl; cand = p - 1u; }
+      if (rl >= minlen && rl > len) { len = rl; cand = p - 1u; }
     }
     // ---- select + emit.  The winner maximises (len - lane), ties to the lower lane.  When its match
     // ends inside this step's 64 positions, the lanes behind it still hold valid candidates: pick
