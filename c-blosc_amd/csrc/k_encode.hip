@@ -11,10 +11,13 @@
 // FORMAT: every stream written here decodes with stock LZ4_decompress_safe /
 // blosclz_decompress, every chunk with stock blosc_decompress (tests/ check exactly that).
 //
-// Match finder (one wavefront per stream): the 64 lanes probe 64 consecutive positions at once
-// against a 2048-entry u16 hash table in LDS (LZ4's 4-byte multiplicative hash) plus distance 1,
-// rank the candidates by exact match length (up to 20 bytes), extend the winner backwards and
-// forwards 512 bytes per step with ballots, and emit the sequence with the whole wave.
+// One kernel per batch (k_encode_streams): persistent wavefronts draw tasks from per-XCD queues - "shuffle
+// block b" (typesize 4 / 8; the transposes run underneath the match finding of other waves) or "encode
+// stream s".  Match finder, one wavefront per stream: the 64 lanes look at 64 consecutive positions at once
+// (own bytes out of a 768-byte register window), probe a 2048-entry tagged hash table in LDS (LZ4's 4-byte
+// multiplicative hash) plus distance 1, rank the candidates by exact match length (up to 20 bytes), extend
+// the winner backwards and forwards with ballots, emit the sequence with the whole wave, and pick again
+// among the lanes behind the match while it ends inside the step.  DESIGN.md 3.3 has the measurements.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "dev_types.h"
@@ -23,8 +26,8 @@
 namespace bamd {
 
 // Optional phase profiling of the encoder (prof build, scripts/enc_phase.py); same slot layout as k_decode.hip's.
-// slots: 0 steps, 1 steps without a match, 2 forward extensions, 3 literal runs copied from memory, 6 window refills
-//        6 sequences
+// slots: 0 steps, 1 steps without a match, 2 forward extensions, 3 literal runs copied from memory, 6 sequences,
+//        5 backward extensions tried, 7 of those > 0 bytes, 4 of those > 4 bytes
 //        13 cycles: waiting for the block's shuffle task
 //        8 cycles: window+probe, 9 candidates+select, 10 extension, 11 emit, 12 tail
 #ifdef BAMD_PROFILE_DECODE
@@ -40,9 +43,6 @@ constexpr int ENC_WAVES = 1;       // one stream per workgroup: a slot frees up 
 // stale or colliding entry WITHOUT touching memory: untagged, nearly every lane of every step fetched 20
 // bytes from a random place in the last 64 KiB (a full cache line each, mostly L2 misses with a thousand
 // streams in flight per XCD) - rocprofv3 FETCH_SIZE showed 6.8x the input being read.
-#ifndef BAMD_ENC_DMAX
-#define BAMD_ENC_DMAX 65535
-#endif
 #ifndef BAMD_ENC_HASH_BITS
 #define BAMD_ENC_HASH_BITS 11
 #endif
@@ -221,23 +221,14 @@ __device__ __forceinline__ uint32_t blz_emit_match(gu8* dst, uint32_t op, uint32
 //            findable
 //   round 3  backward + forward extension loads are issued together; then the sequence is emitted.
 // ---------------------------------------------------------------------------------------------
-#ifndef BAMD_ENC_BWD
-#define BAMD_ENC_BWD 2
-#endif
-#ifndef BAMD_ENC_RANK16
-#define BAMD_ENC_RANK16 0
-#endif
-constexpr uint32_t RANK_CAP = BAMD_ENC_RANK16 == 1 ? 16u : 20u;   // bytes of a candidate that are compared for ranking
+constexpr uint32_t RANK_CAP = 20u;   // bytes of a candidate that are compared for ranking (16 instead: more extensions, lower ratio, no faster)
 
 struct Bytes20 { uint64_t a, b; uint32_t c; };
 
 // 20 bytes at src[pos..], zero beyond n (only the last step of a stream takes the slow branch)
 __device__ __forceinline__ Bytes20 load20(const gu8* src, uint32_t pos, uint32_t n) {
   Bytes20 r;
-  if (pos + 20u <= n) {
-    if (BAMD_ENC_RANK16) { const uint4 v = g_ld16(src + pos); r.a = ((uint64_t)v.y << 32) | v.x; r.b = ((uint64_t)v.w << 32) | v.z; r.c = BAMD_ENC_RANK16 == 2 ? g_ld4(src + pos + 16u) : 0u; }
-    else { r.a = g_ld8(src + pos); r.b = g_ld8(src + pos + 8u); r.c = g_ld4(src + pos + 16u); }
-  }
+  if (pos + 20u <= n) { r.a = g_ld8(src + pos); r.b = g_ld8(src + pos + 8u); r.c = g_ld4(src + pos + 16u); }
   else {
     r.a = 0; r.b = 0; r.c = 0;
     for (uint32_t k = 0; k < 20u && pos + k < n; k++) {
@@ -252,7 +243,6 @@ __device__ __forceinline__ uint32_t common20(const Bytes20& x, const Bytes20& y)
   if (d) return (uint32_t)__builtin_ctzll(d) >> 3;
   d = x.b ^ y.b;
   if (d) return 8u + ((uint32_t)__builtin_ctzll(d) >> 3);
-  if (BAMD_ENC_RANK16 == 1) return 16u;
   const uint32_t e = x.c ^ y.c;
   return e ? 16u + ((uint32_t)__builtin_ctz(e) >> 3) : 20u;
 }
@@ -386,7 +376,7 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
       mine = enc_entry(mix, p);
       const uint32_t e = tab[h];
       const uint32_t d = (p - e) & 0xffffu;
-      if (d != 0u && d <= p && d <= (uint32_t)BAMD_ENC_DMAX && ((e ^ mine) >> 16) == 0u) { cand = p - d; tab_ok = true; }
+      if (d != 0u && d <= p && ((e ^ mine) >> 16) == 0u) { cand = p - d; tab_ok = true; }
     } else {
       prev = 0x100u;
     }
@@ -426,11 +416,6 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
       uint32_t maxb = pm - anchor;
       if (cm < maxb) maxb = cm;
       if (maxb > 64u) maxb = 64u;
-#if BAMD_ENC_BWD == 0
-      maxb = 0;
-#elif BAMD_ENC_BWD == 1
-      if (lane_lo) maxb = 0;
-#endif
       // backward bytes are requested first and looked at last, so that they travel together with the
       // forward rows (one memory round trip for both directions)
       uint32_t bx = 0, by = 1;

@@ -30,17 +30,6 @@ __device__ __forceinline__ gu8* uni_ptr(gu8* p) {
 }
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
-// Workgroup -> work-item remap for one-stream-per-workgroup kernels.  Workgroup b runs on XCD b % 8
-// (observed placement, used for balance only - never for correctness).  Streams are laid out
-// plane after plane inside each block, so "stream index mod 8" correlates with "how heavy": with the
-// identity mapping two XCDs would receive every heavy byte plane.  This bijection hands each XCD a
-// CONTIGUOUS slice of the stream list instead (all plane kinds in equal shares).
-__device__ __forceinline__ uint32_t xcd_spread(uint32_t b, uint32_t n) {
-  const uint32_t q = n >> 3, r = n & 7u;
-  const uint32_t xcd = b & 7u, idx = b >> 3;
-  return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + idx;
-}
-
 // Next index of a global work queue, the same value in every lane.  Lane 0 draws the ticket; the value
 // is then read from lane 0 EXPLICITLY (v_readlane ignores the exec mask), so the result is right even if
 // the compiler has restructured the surrounding loop with partial exec masks.
