@@ -46,10 +46,46 @@ constexpr int ENC_WAVES = 1;       // one stream per workgroup: a slot frees up 
 #ifndef BAMD_ENC_HASH_BITS
 #define BAMD_ENC_HASH_BITS 11
 #endif
-constexpr int ENC_HASH_BITS = BAMD_ENC_HASH_BITS;   // 2048 x u32 = 8 KiB of LDS per wave -> 20 waves per CU
+constexpr int ENC_HASH_BITS = BAMD_ENC_HASH_BITS;   // 2048 entries
 constexpr int ENC_TAB = 1 << ENC_HASH_BITS;
 typedef uint32_t enc_entry_t;
-constexpr int ENC_WAVES_PER_CU = (160 * 1024) / (ENC_TAB * 4) > 32 ? 32 : (160 * 1024) / (ENC_TAB * 4);   // persistent grid size per CU
+#ifndef BAMD_ENC_SPLIT_TAB
+#define BAMD_ENC_SPLIT_TAB 1   // positions (u16) and 8-bit tags in separate arrays: 6 KiB instead of 8 KiB per wave, 24 instead
+                               // of 20 waves per CU (same-session A/B: bench19 10.9 -> 10.3 ms); 0 = one u32 array, 16-bit tags
+#endif
+constexpr int ENC_TAB_BYTES = BAMD_ENC_SPLIT_TAB ? ENC_TAB * 3 : ENC_TAB * 4;
+#ifndef BAMD_ENC_MINWAVES
+#define BAMD_ENC_MINWAVES (BAMD_ENC_SPLIT_TAB ? 6 : 5)   // waves per SIMD the register allocator leaves room for
+#endif
+constexpr int ENC_LDS_WAVES = (160 * 1024) / ENC_TAB_BYTES;
+constexpr int ENC_WAVES_PER_CU = ENC_LDS_WAVES < 4 * BAMD_ENC_MINWAVES ? ENC_LDS_WAVES : 4 * BAMD_ENC_MINWAVES;   // persistent grid size per CU
+
+// the table of one wave (LDS)
+struct EncTable {
+  __attribute__((address_space(3))) uint32_t* w;     // unified: entry words;  split: unused
+  __attribute__((address_space(3))) uint16_t* pos;   // split: positions
+  __attribute__((address_space(3))) uint8_t* tag;    // split: top 8 bits of the tag
+  __device__ __forceinline__ void init(void* base) {
+    w = (__attribute__((address_space(3))) uint32_t*)base;
+    pos = (__attribute__((address_space(3))) uint16_t*)base;
+    tag = (__attribute__((address_space(3))) uint8_t*)base + 2 * ENC_TAB;
+  }
+  __device__ __forceinline__ void clear(int lane) {
+    for (int k = lane; k < ENC_TAB_BYTES / 4; k += 64) w[k] = 0u;
+  }
+  __device__ __forceinline__ void put(uint32_t h, uint32_t entry) {
+    if (BAMD_ENC_SPLIT_TAB) { pos[h] = (uint16_t)entry; tag[h] = (uint8_t)(entry >> 24); }
+    else w[h] = entry;
+  }
+  // entry with the same layout as enc_entry(); in split mode only the top 8 tag bits are kept
+  __device__ __forceinline__ uint32_t get(uint32_t h) const {
+    if (BAMD_ENC_SPLIT_TAB) return (uint32_t)pos[h] | ((uint32_t)tag[h] << 24);
+    return w[h];
+  }
+  __device__ __forceinline__ static bool tag_equal(uint32_t a, uint32_t b) {
+    return BAMD_ENC_SPLIT_TAB ? ((a ^ b) >> 24) == 0u : ((a ^ b) >> 16) == 0u;
+  }
+};
 
 __device__ __forceinline__ uint32_t enc_mix(uint32_t seq) { return seq * 2654435761u; }
 __device__ __forceinline__ uint32_t enc_slot(uint32_t mix) { return mix >> (32 - ENC_HASH_BITS); }
@@ -310,7 +346,8 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
                                    int clevel, enc_entry_t* tab_generic, int lane EPROF_ARG) {
   // the table lives in LDS; say so explicitly (a generic pointer in a non-inlined function would make
   // every probe a flat_load)
-  __attribute__((address_space(3))) enc_entry_t* tab = (__attribute__((address_space(3))) enc_entry_t*)tab_generic;
+  EncTable tab;
+  tab.init((void*)tab_generic);
   // stream-end rules.  LZ4: last match starts <= n-12, ends <= n-5 (lz4.c:245-246, :963-964).
   // BloscLZ: matches start < n-12 (blosclz.c:465), stream must end with >= 1 literal (blosclz.c:708-710).
   if (FMT == EF_LZ4 ? (n < 13u) : (n < 16u || cap < 66u)) return 0u;
@@ -324,7 +361,7 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
   // < 1 % of ratio (bench19: 53.3 -> 48.5, still far above the reference's 36.7 at this clevel).
   const uint32_t minlen = clevel >= 9 ? 4u : (clevel >= 6 ? 5u : 6u);
 
-  for (int k = lane; k < ENC_TAB; k += 64) tab[k] = 0u;
+  tab.clear(lane);
 
   EncWindow win;
   win.init(src, n, lane);
@@ -364,7 +401,7 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
     if (lane == 0) prev = ip ? (bo0 >= 2u ? before2 >> 8 : (uint32_t)(r01 >> (8u * (bo0 - 1u))) & 0xffu) : 0x100u;
     if (ins_pending) {
       const uint32_t m2 = enc_mix(before2 | (o0 << 16));
-      if (lane == 0) tab[enc_slot(m2)] = enc_entry(m2, ip - 2u);
+      if (lane == 0) tab.put(enc_slot(m2), enc_entry(m2, ip - 2u));
       ins_pending = false;
     }
     uint32_t h = 0, cand = 0, limit = 0, mine = 0;   // mine: this lane's own table entry
@@ -374,9 +411,9 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
       const uint32_t mix = enc_mix(o0);
       h = enc_slot(mix);
       mine = enc_entry(mix, p);
-      const uint32_t e = tab[h];
+      const uint32_t e = tab.get(h);
       const uint32_t d = (p - e) & 0xffffu;
-      if (d != 0u && d <= p && ((e ^ mine) >> 16) == 0u) { cand = p - d; tab_ok = true; }
+      if (d != 0u && d <= p && EncTable::tag_equal(e, mine)) { cand = p - d; tab_ok = true; }
     } else {
       prev = 0x100u;
     }
@@ -408,7 +445,7 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
       if (best == 0u) break;
       any = true;
       const int f = 63 - (int)(best & 63u);
-      if (live && (uint32_t)lane >= lane_lo && lane <= f) tab[h] = mine;
+      if (live && (uint32_t)lane >= lane_lo && lane <= f) tab.put(h, mine);
       uint32_t pm = ip + (uint32_t)f;
       uint32_t cm = (uint32_t)__builtin_amdgcn_readlane((int)cand, f);
       const uint32_t len_f = (uint32_t)__builtin_amdgcn_readlane((int)len, f);
@@ -444,11 +481,11 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
       if (anchor >= step_end) break;
       lane_lo = anchor - ip;                      // >= 4
       // like the reference, remember the position two bytes before the new anchor (lz4.c:1236-1242)
-      if (live && (uint32_t)lane + 2u == lane_lo) tab[h] = mine;
+      if (live && (uint32_t)lane + 2u == lane_lo) tab.put(h, mine);
     }
     if (!any) {
       PROF_ADD(1, 1);
-      if (live) tab[h] = mine;
+      if (live) tab.put(h, mine);
       nfail++;
       uint32_t adv = 1u + (nfail * (uint32_t)accel) / 16u;   // skip faster through incompressible data
       if (adv > 16u) adv = 16u;
@@ -460,7 +497,7 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
       ip = anchor;
       ins_pending = true;                         // anchor-2 enters the table at the top of the next step (bytes in registers there)
     } else {
-      if (live && (uint32_t)lane >= lane_lo) tab[h] = mine;   // nothing more to find behind the last match
+      if (live && (uint32_t)lane >= lane_lo) tab.put(h, mine);   // nothing more to find behind the last match
       ip = step_end;
     }
   }
@@ -589,9 +626,6 @@ __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, enc_
 // host puts every block's shuffle task a few dozen entries ahead of its streams (engine.hip:
 // build_encode_queues), so the bandwidth-bound transposes run underneath the latency/issue-bound match
 // finding of other waves instead of in a kernel of their own.
-#ifndef BAMD_ENC_MINWAVES
-#define BAMD_ENC_MINWAVES 5   // waves per SIMD: the 8 KiB table per wave allows 20 per CU
-#endif
 __global__ __launch_bounds__(64 * ENC_WAVES, BAMD_ENC_MINWAVES) void k_encode_streams(
     StreamDesc* __restrict__ streams, uint32_t* __restrict__ tickets /*[8]*/, const int32_t* __restrict__ qlist,
     const int32_t* __restrict__ qoff /*[9]*/, const ChunkDesc* __restrict__ chunks, const BlockDesc* __restrict__ blocks,
@@ -600,7 +634,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES, BAMD_ENC_MINWAVES) void k_encode_st
     , uint32_t* __restrict__ profbuf
 #endif
     ) {
-  __shared__ enc_entry_t tabs[ENC_WAVES][ENC_TAB];
+  __shared__ enc_entry_t tabs[ENC_WAVES][ENC_TAB_BYTES / 4];
   static_assert(ENC_WAVES == 1, "one stream per wave, one wave per workgroup");
   const int lane = threadIdx.x & 63;
   const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;   // HW_REG_XCC_ID[3:0]
