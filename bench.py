@@ -291,7 +291,7 @@ def main():
         "roofline": roof,
         "verified": verified,
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:      # the host-core baseline is a 1-GPU artefact (rank 0, N = 1)
         out["cpu_baseline"] = cpu_baseline(host_chunk, args.typesize, args.clevel, args.shuffle, cname, args.cpu_passes)
     print(json.dumps(out))
     if dist is not None:
