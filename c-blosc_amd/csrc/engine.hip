@@ -13,6 +13,7 @@
 
 #include "blosc_format.h"
 #include "dev_types.h"
+#include "queue_order.h"
 
 #include "k_filters.hip"
 #include "k_decode.hip"
@@ -159,66 +160,6 @@ static dim3 grid1(size_t n, int per) { return dim3((unsigned)((n + per - 1) / pe
 // BLOSC_AMD_SPANS=0: decoded periodic planes go through the scratch like every other plane
 static bool span_enabled() { static const bool on = !(getenv("BLOSC_AMD_SPANS") && atoi(getenv("BLOSC_AMD_SPANS")) == 0); return on; }
 static bool fuse_enabled() { static const bool on = !(getenv("BLOSC_AMD_FUSE") && atoi(getenv("BLOSC_AMD_FUSE")) == 0); return on; }
-
-// Per-XCD task queues of the encode kernel: out = off[9] | entries.  Block g belongs to XCD g & 7; an
-// entry >= 0 is a stream index, an entry < 0 the shuffle task of block -(entry+1).  A block's shuffle
-// task is queued kEncLookahead blocks ahead of its streams: by the time a wave draws one of the streams
-// the transpose is normally finished, and it is always already owned by a running wave (no deadlock).
-constexpr size_t kEncLookahead = 32;
-// BLOSC_AMD_SCHED=0: plain block order (no cost feedback)
-static bool sched_enabled() { static const bool on = !(getenv("BLOSC_AMD_SCHED") && atoi(getenv("BLOSC_AMD_SCHED")) == 0); return on; }
-
-// plane indices 0..T-1 in descending cost; *nheavy = how many of them count as expensive (> max/2)
-static void plane_order(const uint32_t* cost, bool valid, int T, std::vector<int>& order, int* nheavy) {
-  order.resize((size_t)T);
-  for (int j = 0; j < T; j++) order[(size_t)j] = j;
-  *nheavy = T;
-  if (!valid || T <= 1 || T > 256) return;
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
-  const uint32_t mx = cost[order[0]];
-  if (mx == 0) return;
-  int h = 0;
-  while (h < T && cost[order[(size_t)h]] > mx / 2) h++;
-  *nheavy = h;
-}
-
-// With cost feedback the queue has two passes: the first, in block order, carries the shuffle tasks and the
-// streams of the expensive planes; the second carries the cheap planes, plane by plane in descending cost.
-// The kernel's tail (waves finishing their last stream while the queue is already empty) then consists of
-// cheap streams instead of 3 ms ones.
-static void build_encode_queues(const std::vector<BlockDesc>& blocks, const std::vector<ChunkDesc>& chunks,
-                                const uint32_t* cost, bool cost_valid, std::vector<int32_t>& out) {
-  std::vector<int32_t> q[8];
-  std::vector<uint32_t> mine[8];
-  for (size_t g = 0; g < blocks.size(); g++) if (blocks[g].nstreams > 0) mine[g & 7].push_back((uint32_t)g);
-  std::vector<int> order; int nheavy = 0, lastT = -1;
-  for (int x = 0; x < 8; x++) {
-    const std::vector<uint32_t>& B = mine[x];
-    auto push_shuffle = [&](size_t i) {
-      if (chunks[(size_t)blocks[B[i]].chunk].mode & CH_FUSED_SHUF) q[x].push_back(-(int32_t)B[i] - 1);
-    };
-    int maxT = 1;
-    for (size_t i = 0; i < B.size() && i < kEncLookahead; i++) push_shuffle(i);
-    for (size_t i = 0; i < B.size(); i++) {
-      if (i + kEncLookahead < B.size()) push_shuffle(i + kEncLookahead);
-      const BlockDesc& b = blocks[B[i]];
-      if (b.nstreams != lastT) { plane_order(cost, cost_valid && sched_enabled(), b.nstreams, order, &nheavy); lastT = b.nstreams; }
-      if (b.nstreams > maxT) maxT = b.nstreams;
-      for (int k = 0; k < nheavy; k++) q[x].push_back(b.first_stream + order[(size_t)k]);
-    }
-    // second pass: the cheap planes, most expensive first (rank k of each block's own order)
-    for (int k = 1; k < maxT; k++)
-      for (size_t i = 0; i < B.size(); i++) {
-        const BlockDesc& b = blocks[B[i]];
-        if (b.nstreams != lastT) { plane_order(cost, cost_valid && sched_enabled(), b.nstreams, order, &nheavy); lastT = b.nstreams; }
-        if (k >= nheavy && k < b.nstreams) q[x].push_back(b.first_stream + order[(size_t)k]);
-      }
-  }
-  out.assign(9, 0);
-  for (int x = 0; x < 8; x++) { out[(size_t)x + 1] = out[(size_t)x] + (int32_t)q[x].size(); }
-  for (int x = 0; x < 8; x++) out.insert(out.end(), q[x].begin(), q[x].end());
-  if (out.size() == 9) out.push_back(0);
-}
 
 int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* results, bool device_ptrs,
                           hipStream_t stream) {
@@ -539,40 +480,6 @@ static void add_decode_chunk(const Header& h, int fmt, int chunk_index, int32_t 
 
 // Deals whole blocks round-robin to 8 per-XCD queues; queue x lists the stream ids of its blocks.
 // Layout: qoff[9] (int32) followed by qlist[nstr].
-// Per-XCD stream queues of the decode kernel: out = off[9] | stream indices.  Block g belongs to XCD g & 7
-// (all streams of a block on one XCD: the fused unshuffle hands over through that XCD's L2).
-// With cost feedback the expensive planes of block i + kDecLead are queued together with the cheap planes of
-// block i: blocks still complete in order (the unshuffles stay spread over the whole kernel), but the
-// streams drawn last - the kernel's tail - are cheap ones.
-constexpr size_t kDecLead = 256;
-static void build_xcd_queues(const std::vector<BlockDesc>& blocks, size_t nstr, const uint32_t* cost, bool cost_valid,
-                             std::vector<int32_t>& out) {
-  std::vector<int32_t> q[8];
-  std::vector<uint32_t> mine[8];
-  for (size_t g = 0; g < blocks.size(); g++) if (blocks[g].nstreams > 0) mine[g & 7].push_back((uint32_t)g);
-  std::vector<int> order; int nheavy = 0, lastT = -1;
-  auto prep = [&](const BlockDesc& b) {
-    if (b.nstreams != lastT) { plane_order(cost, cost_valid && sched_enabled(), b.nstreams, order, &nheavy); lastT = b.nstreams; }
-  };
-  for (int x = 0; x < 8; x++) {
-    const std::vector<uint32_t>& B = mine[x];
-    const size_t lead = B.size() > 2 * kDecLead ? kDecLead : B.size() / 4;
-    auto push_heavy = [&](size_t i) { const BlockDesc& b = blocks[B[i]]; prep(b); if (nheavy < b.nstreams) for (int k = 0; k < nheavy; k++) q[x].push_back(b.first_stream + order[(size_t)k]); };
-    for (size_t i = 0; i < B.size() && i < lead; i++) push_heavy(i);
-    for (size_t i = 0; i < B.size(); i++) {
-      if (i + lead < B.size()) push_heavy(i + lead);
-      const BlockDesc& b = blocks[B[i]];
-      prep(b);
-      if (nheavy < b.nstreams) { for (int k = nheavy; k < b.nstreams; k++) q[x].push_back(b.first_stream + order[(size_t)k]); }
-      else for (int k = 0; k < b.nstreams; k++) q[x].push_back(b.first_stream + k);   // no feedback: plain order
-    }
-  }
-  out.assign(9, 0);
-  for (int x = 0; x < 8; x++) out[(size_t)x + 1] = out[(size_t)x] + (int32_t)q[x].size();
-  for (int x = 0; x < 8; x++) out.insert(out.end(), q[x].begin(), q[x].end());
-  out.resize(9 + (nstr ? nstr : 1), 0);
-}
-
 struct DecodeLaunch {
   ChunkDesc* d_chunks; BlockDesc* d_blocks; StreamDesc* d_streams; int32_t* d_status; uint32_t* d_ticket; uint32_t* d_blkdone;
   uint32_t* d_spans; uint8_t* d_pat;             // periodic spans of the fused unshuffle (k_decode.hip: SpanCtx)

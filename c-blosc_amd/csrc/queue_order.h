@@ -1,0 +1,109 @@
+// queue_order.h — host-side queue builders of the two persistent kernels (plain C++, no HIP): which XCD serves
+// which block, where a block's shuffle task sits relative to its streams, and the order that keeps the
+// expensive byte planes out of the kernels' tails.  Replaces the reference's static block -> thread
+// partition (blosc/blosc.c:1706-1887 t_blosc: contiguous block ranges per pthread).
+// Compiled into engine.hip; tests/tools/sched_check.cpp checks the invariants with g++ on the CPU.
+#pragma once
+#include <stdint.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <vector>
+#include "dev_types.h"
+
+namespace bamd {
+
+// Per-XCD task queues of the encode kernel: out = off[9] | entries.  Block g belongs to XCD g & 7; an
+// entry >= 0 is a stream index, an entry < 0 the shuffle task of block -(entry+1).  A block's shuffle
+// task is queued kEncLookahead blocks ahead of its streams: by the time a wave draws one of the streams
+// the transpose is normally finished, and it is always already owned by a running wave (no deadlock).
+constexpr size_t kEncLookahead = 32;
+// BLOSC_AMD_SCHED=0: plain block order (no cost feedback)
+inline bool sched_enabled() { static const bool on = !(getenv("BLOSC_AMD_SCHED") && atoi(getenv("BLOSC_AMD_SCHED")) == 0); return on; }
+
+// plane indices 0..T-1 in descending cost; *nheavy = how many of them count as expensive (> max/2)
+inline void plane_order(const uint32_t* cost, bool valid, int T, std::vector<int>& order, int* nheavy) {
+  order.resize((size_t)T);
+  for (int j = 0; j < T; j++) order[(size_t)j] = j;
+  *nheavy = T;
+  if (!valid || T <= 1 || T > 256) return;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+  const uint32_t mx = cost[order[0]];
+  if (mx == 0) return;
+  int h = 0;
+  while (h < T && cost[order[(size_t)h]] > mx / 2) h++;
+  *nheavy = h;
+}
+
+// With cost feedback the queue has two passes: the first, in block order, carries the shuffle tasks and the
+// streams of the expensive planes; the second carries the cheap planes, plane by plane in descending cost.
+// The kernel's tail (waves finishing their last stream while the queue is already empty) then consists of
+// cheap streams instead of 3 ms ones.
+inline void build_encode_queues(const std::vector<BlockDesc>& blocks, const std::vector<ChunkDesc>& chunks,
+                                const uint32_t* cost, bool cost_valid, std::vector<int32_t>& out) {
+  std::vector<int32_t> q[8];
+  std::vector<uint32_t> mine[8];
+  for (size_t g = 0; g < blocks.size(); g++) if (blocks[g].nstreams > 0) mine[g & 7].push_back((uint32_t)g);
+  std::vector<int> order; int nheavy = 0, lastT = -1;
+  for (int x = 0; x < 8; x++) {
+    const std::vector<uint32_t>& B = mine[x];
+    auto push_shuffle = [&](size_t i) {
+      if (chunks[(size_t)blocks[B[i]].chunk].mode & CH_FUSED_SHUF) q[x].push_back(-(int32_t)B[i] - 1);
+    };
+    int maxT = 1;
+    for (size_t i = 0; i < B.size() && i < kEncLookahead; i++) push_shuffle(i);
+    for (size_t i = 0; i < B.size(); i++) {
+      if (i + kEncLookahead < B.size()) push_shuffle(i + kEncLookahead);
+      const BlockDesc& b = blocks[B[i]];
+      if (b.nstreams != lastT) { plane_order(cost, cost_valid && sched_enabled(), b.nstreams, order, &nheavy); lastT = b.nstreams; }
+      if (b.nstreams > maxT) maxT = b.nstreams;
+      for (int k = 0; k < nheavy; k++) q[x].push_back(b.first_stream + order[(size_t)k]);
+    }
+    // second pass: the cheap planes, most expensive first (rank k of each block's own order)
+    for (int k = 1; k < maxT; k++)
+      for (size_t i = 0; i < B.size(); i++) {
+        const BlockDesc& b = blocks[B[i]];
+        if (b.nstreams != lastT) { plane_order(cost, cost_valid && sched_enabled(), b.nstreams, order, &nheavy); lastT = b.nstreams; }
+        if (k >= nheavy && k < b.nstreams) q[x].push_back(b.first_stream + order[(size_t)k]);
+      }
+  }
+  out.assign(9, 0);
+  for (int x = 0; x < 8; x++) { out[(size_t)x + 1] = out[(size_t)x] + (int32_t)q[x].size(); }
+  for (int x = 0; x < 8; x++) out.insert(out.end(), q[x].begin(), q[x].end());
+  if (out.size() == 9) out.push_back(0);
+}
+
+// Per-XCD stream queues of the decode kernel: out = off[9] | stream indices.  Block g belongs to XCD g & 7
+// (all streams of a block on one XCD: the fused unshuffle hands over through that XCD's L2).
+// With cost feedback the expensive planes of block i + kDecLead are queued together with the cheap planes of
+// block i: blocks still complete in order (the unshuffles stay spread over the whole kernel), but the
+// streams drawn last - the kernel's tail - are cheap ones.
+constexpr size_t kDecLead = 256;
+inline void build_xcd_queues(const std::vector<BlockDesc>& blocks, size_t nstr, const uint32_t* cost, bool cost_valid,
+                             std::vector<int32_t>& out) {
+  std::vector<int32_t> q[8];
+  std::vector<uint32_t> mine[8];
+  for (size_t g = 0; g < blocks.size(); g++) if (blocks[g].nstreams > 0) mine[g & 7].push_back((uint32_t)g);
+  std::vector<int> order; int nheavy = 0, lastT = -1;
+  auto prep = [&](const BlockDesc& b) {
+    if (b.nstreams != lastT) { plane_order(cost, cost_valid && sched_enabled(), b.nstreams, order, &nheavy); lastT = b.nstreams; }
+  };
+  for (int x = 0; x < 8; x++) {
+    const std::vector<uint32_t>& B = mine[x];
+    const size_t lead = B.size() > 2 * kDecLead ? kDecLead : B.size() / 4;
+    auto push_heavy = [&](size_t i) { const BlockDesc& b = blocks[B[i]]; prep(b); if (nheavy < b.nstreams) for (int k = 0; k < nheavy; k++) q[x].push_back(b.first_stream + order[(size_t)k]); };
+    for (size_t i = 0; i < B.size() && i < lead; i++) push_heavy(i);
+    for (size_t i = 0; i < B.size(); i++) {
+      if (i + lead < B.size()) push_heavy(i + lead);
+      const BlockDesc& b = blocks[B[i]];
+      prep(b);
+      if (nheavy < b.nstreams) { for (int k = nheavy; k < b.nstreams; k++) q[x].push_back(b.first_stream + order[(size_t)k]); }
+      else for (int k = 0; k < b.nstreams; k++) q[x].push_back(b.first_stream + k);   // no feedback: plain order
+    }
+  }
+  out.assign(9, 0);
+  for (int x = 0; x < 8; x++) out[(size_t)x + 1] = out[(size_t)x] + (int32_t)q[x].size();
+  for (int x = 0; x < 8; x++) out.insert(out.end(), q[x].begin(), q[x].end());
+  out.resize(9 + (nstr ? nstr : 1), 0);
+}
+
+}  // namespace bamd
