@@ -670,7 +670,7 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
   if (lane == 0) {
     sd->result = got;
     if (got != want) atomicMin(&status[sd->chunk], (int32_t)ST_BADCODEC);  // blosc.c:780-782
-    // cost feedback for the host's queue order (engine.hip: build_xcd_queues): cycles per plane index
+    // cost feedback for the host's queue order (queue_order.h: build_xcd_queues): cycles per plane index
     if (plane_cost) atomicAdd(plane_cost + ((sid - (uint32_t)b->first_stream) & 255u), (uint32_t)((__builtin_amdgcn_s_memtime() - cost_t0) >> 10));
   }
   // ---- fused unshuffle: the wave that completes a block's LAST stream transposes the block ----

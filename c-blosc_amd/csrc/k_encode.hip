@@ -610,7 +610,7 @@ __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, enc_
   if (sd->fmt == FMT_LZ4) r = lz_encode_wave<EF_LZ4>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, lane EPROF_PASS);
   else r = lz_encode_wave<EF_BLOSCLZ>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, lane EPROF_PASS);
   if (lane == 0) sd->result = (int32_t)r;
-  // cost feedback for the host's queue order (engine.hip: build_encode_queues): cycles per plane index
+  // cost feedback for the host's queue order (queue_order.h: build_encode_queues): cycles per plane index
   if (plane_cost && lane == 0) {
     const uint32_t j = sid - (uint32_t)blocks[aux >> 4].first_stream;
     atomicAdd(plane_cost + (j & 255u), (uint32_t)((__builtin_amdgcn_s_memtime() - cost_t0) >> 10));
@@ -623,7 +623,7 @@ __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, enc_
 
 // Persistent waves + per-XCD ticket queues, like k_decode_streams (stream costs differ by orders of
 // magnitude).  A queue entry >= 0 is a stream to encode; an entry < 0 is "shuffle block -(entry+1)".  The
-// host puts every block's shuffle task a few dozen entries ahead of its streams (engine.hip:
+// host puts every block's shuffle task a few dozen entries ahead of its streams (queue_order.h:
 // build_encode_queues), so the bandwidth-bound transposes run underneath the latency/issue-bound match
 // finding of other waves instead of in a kernel of their own.
 __global__ __launch_bounds__(64 * ENC_WAVES, BAMD_ENC_MINWAVES) void k_encode_streams(
