@@ -83,8 +83,33 @@ struct EngineState {
   // after call, the same byte planes; the queue builders use this to keep them out of the kernels' tails.
   uint32_t enc_cost[256] = {0}, dec_cost[256] = {0};
   bool enc_cost_valid = false, dec_cost_valid = false;
+  // false: the device deals workgroups round-robin to 8 XCDs whose ids the kernels can read (SPX-mode MI355X),
+  // so per-XCD queues and in-kernel hand-offs through one XCD's L2 are valid.  true: anything else (probe below,
+  // or BLOSC_AMD_SINGLE_QUEUE=1) - one queue, shuffle / unshuffle in kernels of their own.
+  bool single_queue = false;
 };
 static EngineState& S() { static EngineState s; return s; }
+
+// Where do 64 consecutive workgroups land?  Expected on an SPX-mode MI355X: XCC ids 0..7, eight workgroups each.
+__global__ void k_probe_xcc(uint32_t* hist) {
+  if (threadIdx.x == 0) atomicAdd(&hist[__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u], 1u);
+}
+static void probe_topology(EngineState& st) {
+  st.single_queue = getenv("BLOSC_AMD_SINGLE_QUEUE") && atoi(getenv("BLOSC_AMD_SINGLE_QUEUE")) != 0;
+  if (st.single_queue) return;
+  uint32_t* d = nullptr; uint32_t h[16] = {0};
+  bool ok = hipMalloc((void**)&d, sizeof h) == hipSuccess && hipMemset(d, 0, sizeof h) == hipSuccess;
+  if (ok) {
+    hipLaunchKernelGGL(k_probe_xcc, dim3(64), dim3(64), 0, 0, d);
+    ok = hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess;
+  }
+  if (d) (void)hipFree(d);
+  for (int x = 0; ok && x < 16; x++) ok = h[x] == (x < 8 ? 8u : 0u);
+  if (!ok) {
+    st.single_queue = true;
+    if (getenv("BLOSC_AMD_DEBUG")) fprintf(stderr, "blosc_amd: workgroups are not dealt round-robin to 8 XCDs here; using one task queue and unfused filters\n");
+  }
+}
 
 static int ensure_device(EngineState& st) {
   if (st.device_ok) return 0;
@@ -100,6 +125,7 @@ static int ensure_device(EngineState& st) {
   }
   if (st.device >= 0) HIP_TRY(hipSetDevice(st.device));
   else HIP_TRY(hipGetDevice(&st.device));
+  probe_topology(st);
   st.device_ok = true;
   return 0;
 }
@@ -213,7 +239,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
     c.mode = 0;
     c.first_block = (int32_t)blocks.size(); c.first_stream = (int32_t)streams.size();
     if (memcpyed) c.mode |= CH_MEMCPYED;
-    else if (p.doshuffle == 1 && T > 1) { c.mode |= CH_SHUFFLE; if ((T == 8 || T == 4) && fuse_enabled()) c.mode |= CH_FUSED_SHUF; }
+    else if (p.doshuffle == 1 && T > 1) { c.mode |= CH_SHUFFLE; if ((T == 8 || T == 4) && fuse_enabled() && !st.single_queue) c.mode |= CH_FUSED_SHUF; }
     else if (p.doshuffle == 2) c.mode |= CH_BITSHUFFLE;
     live[(size_t)i] = 1;
     results[i] = 0;
@@ -259,7 +285,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   const size_t o_blkoff = cv.take(sizeof(int32_t) * (nblk ? nblk : 1));
   const size_t o_results = cv.take(sizeof(int32_t) * (size_t)n + 64);   // + the 8 ticket counters of the encode queues
   std::vector<int32_t> queues;
-  build_encode_queues(blocks, chunks, st.enc_cost, st.enc_cost_valid, queues);
+  build_encode_queues(blocks, chunks, st.enc_cost, st.enc_cost_valid, queues, st.single_queue ? 1 : 8);
   const size_t o_queues = cv.take(sizeof(int32_t) * queues.size());
   const size_t o_ready = cv.take(sizeof(uint32_t) * (nblk ? nblk : 1));
   const size_t o_cost = cv.take(sizeof(uint32_t) * 256);
@@ -346,7 +372,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
 #ifdef BAMD_PROFILE_DECODE
     uint32_t* d_prof = nullptr;
     if (getenv("BLOSC_AMD_ENC_PROFILE")) { (void)hipMalloc((void**)&d_prof, nstr * 64); (void)hipMemsetAsync(d_prof, 0, nstr * 64, stream); }
-    hipLaunchKernelGGL(k_encode_streams, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), d_prof);
+    hipLaunchKernelGGL(k_encode_streams, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, d_prof);
     if (d_prof) {
       std::vector<uint32_t> h(nstr * 16);
       (void)hipStreamSynchronize(stream);
@@ -356,7 +382,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
       (void)hipFree(d_prof);
     }
 #else
-    hipLaunchKernelGGL(k_encode_streams, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost));
+    hipLaunchKernelGGL(k_encode_streams, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0);
 #endif
   }
   {
@@ -375,21 +401,6 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   if (nstr >= 4096) { memcpy(st.enc_cost, P + p_cost, sizeof st.enc_cost); st.enc_cost_valid = true; }   // small calls say little
   const int32_t* r = (const int32_t*)(P + p_results);
   for (int i = 0; i < n; i++) if (live[(size_t)i]) results[i] = r[i];
-  if (getenv("BLOSC_AMD_DEBUG")) {
-    std::vector<ChunkDesc> cd((size_t)n); std::vector<StreamDesc> sd(nstr ? nstr : 1); std::vector<int32_t> bo(nblk ? nblk : 1);
-    (void)hipMemcpy(cd.data(), d_chunks, sizeof(ChunkDesc) * (size_t)n, hipMemcpyDeviceToHost);
-    if (nstr) (void)hipMemcpy(sd.data(), d_streams, sizeof(StreamDesc) * nstr, hipMemcpyDeviceToHost);
-    if (nblk) (void)hipMemcpy(bo.data(), d_blkoff, sizeof(int32_t) * nblk, hipMemcpyDeviceToHost);
-    for (int i = 0; i < n && i < 4; i++) {
-      uint8_t a[32] = {0}, b2[48] = {0};
-      (void)hipMemcpy(a, cd[i].src, 32, hipMemcpyDeviceToHost); (void)hipMemcpy(b2, cd[i].dst, 48, hipMemcpyDeviceToHost);
-      fprintf(stderr, "[dbg] src:"); for (int k = 0; k < 32; k++) fprintf(stderr, " %d", a[k]);
-      fprintf(stderr, "\n[dbg] dst:"); for (int k = 0; k < 48; k++) fprintf(stderr, " %d", b2[k]); fprintf(stderr, "\n");
-    }
-    for (int i = 0; i < n && i < 4; i++)
-      fprintf(stderr, "[dbg] chunk %d mode=%u res=%d nblocks=%d nbytes=%d max=%d src=%p dst=%p | blk_off0=%d | s0.result=%d in=%p insize=%d\n", i, cd[i].mode, r[i],
-              cd[i].nblocks, cd[i].nbytes, cd[i].cbytes, (void*)cd[i].src, (void*)cd[i].dst, nblk ? bo[0] : -1, nstr ? sd[0].result : -1, nstr ? (void*)sd[0].in : nullptr, nstr ? sd[0].in_size : -1);
-  }
   if (!device_ptrs) {
     for (int i = 0; i < n; i++) {
       if (!live[(size_t)i] || results[i] <= 0) continue;
@@ -504,7 +515,7 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
 #ifdef BAMD_PROFILE_DECODE
       uint32_t* d_prof = nullptr;
       if (getenv("BLOSC_AMD_DEC_PROFILE")) { (void)hipMalloc((void**)&d_prof, L.nstr * 64); (void)hipMemsetAsync(d_prof, 0, L.nstr * 64, stream); }
-      hipLaunchKernelGGL(k_decode_streams, dgrid, dim3(64 * DEC_WAVES), (size_t)dec_lds, stream, L.d_streams, L.d_status, L.d_ticket, L.d_qlist, L.d_qoff, L.d_chunks, L.d_blocks, L.d_blkdone, L.d_spans, L.d_pat, L.d_cost, d_prof);
+      hipLaunchKernelGGL(k_decode_streams, dgrid, dim3(64 * DEC_WAVES), (size_t)dec_lds, stream, L.d_streams, L.d_status, L.d_ticket, L.d_qlist, L.d_qoff, L.d_chunks, L.d_blocks, L.d_blkdone, L.d_spans, L.d_pat, L.d_cost, st.single_queue ? 1 : 0, d_prof);
       if (d_prof) {
         std::vector<uint32_t> h(L.nstr * 16);
         (void)hipStreamSynchronize(stream);
@@ -514,7 +525,7 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
         (void)hipFree(d_prof);
       }
 #else
-      hipLaunchKernelGGL(k_decode_streams, dgrid, dim3(64 * DEC_WAVES), (size_t)dec_lds, stream, L.d_streams, L.d_status, L.d_ticket, L.d_qlist, L.d_qoff, L.d_chunks, L.d_blocks, L.d_blkdone, L.d_spans, L.d_pat, L.d_cost);
+      hipLaunchKernelGGL(k_decode_streams, dgrid, dim3(64 * DEC_WAVES), (size_t)dec_lds, stream, L.d_streams, L.d_status, L.d_ticket, L.d_qlist, L.d_qoff, L.d_chunks, L.d_blocks, L.d_blkdone, L.d_spans, L.d_pat, L.d_cost, st.single_queue ? 1 : 0);
 #endif
     }
     if (L.any_shuf) {
@@ -535,9 +546,9 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
 }
 
 
-static void filter_tiles(ChunkDesc& c, bool& any_shuf, bool& any_bit, int& tiles_shuf, int& tiles_bit) {
+static void filter_tiles(ChunkDesc& c, bool& any_shuf, bool& any_bit, int& tiles_shuf, int& tiles_bit, bool may_fuse) {
   const int32_t T = c.typesize, N = c.blocksize / T;
-  if ((c.mode & CH_SHUFFLE) && (T == 8 || T == 4) && fuse_enabled()) { c.mode |= CH_FUSED_UNSHUF; return; }
+  if ((c.mode & CH_SHUFFLE) && (T == 8 || T == 4) && fuse_enabled() && may_fuse) { c.mode |= CH_FUSED_UNSHUF; return; }
   if (c.mode & CH_SHUFFLE) {
     any_shuf = true;
     int t = (N + shuffle_tile_elems(T) - 1) / shuffle_tile_elems(T); if (t < 1) t = 1;
@@ -575,7 +586,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
     live[(size_t)i] = 1;
     results[i] = c.nbytes;
     if (c.mode & CH_MEMCPYED) L.any_copy = true;
-    filter_tiles(c, L.any_shuf, L.any_bit, L.tiles_shuf, L.tiles_bit);
+    filter_tiles(c, L.any_shuf, L.any_bit, L.tiles_shuf, L.tiles_bit, !st.single_queue);
     if (c.mode & (CH_SHUFFLE | CH_BITSHUFFLE)) filt_bytes = align_up(filt_bytes, 256) + (size_t)c.nbytes;
     if (!device_ptrs) { io_src = align_up(io_src, 256) + (size_t)c.cbytes; io_dst = align_up(io_dst, 256) + (size_t)c.nbytes; }
   }
@@ -613,7 +624,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
     }
   }
   std::vector<int32_t> queues;
-  build_xcd_queues(blocks, nstr, st.dec_cost, st.dec_cost_valid, queues);
+  build_xcd_queues(blocks, nstr, st.dec_cost, st.dec_cost_valid, queues, st.single_queue ? 1 : 8);
   Carver pc;
   const size_t p_chunks = pc.take(sizeof(ChunkDesc) * (size_t)n);
   const size_t p_blocks = pc.take(sizeof(BlockDesc) * (nblk ? nblk : 1));
@@ -730,13 +741,13 @@ int engine_getitem(const void* src, int start, int nitems, void* dest, bool src_
   c.dst = D + o_out - (size_t)j0 * bs;
   c.filt = (c.mode & (CH_SHUFFLE | CH_BITSHUFFLE)) ? D + o_filt - (size_t)j0 * bs : nullptr;
   DecodeLaunch L{};
-  filter_tiles(c, L.any_shuf, L.any_bit, L.tiles_shuf, L.tiles_bit);   // may set CH_FUSED_UNSHUF: before the upload
+  filter_tiles(c, L.any_shuf, L.any_bit, L.tiles_shuf, L.tiles_bit, !st.single_queue);   // may set CH_FUSED_UNSHUF: before the upload
   Carver pc;
   const size_t p_chunks = pc.take(sizeof(ChunkDesc));
   const size_t p_blocks = pc.take(sizeof(BlockDesc) * nblk);
   const size_t p_status = pc.take(sizeof(int32_t));
   std::vector<int32_t> queues;
-  build_xcd_queues(blocks, nstr, st.dec_cost, st.dec_cost_valid, queues);
+  build_xcd_queues(blocks, nstr, st.dec_cost, st.dec_cost_valid, queues, st.single_queue ? 1 : 8);
   const size_t p_queues = pc.take(sizeof(int32_t) * queues.size());
   if (st.pin.ensure(pc.off)) return -1;
   uint8_t* P = st.pin.base;

@@ -629,7 +629,7 @@ __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, enc_
 __global__ __launch_bounds__(64 * ENC_WAVES, BAMD_ENC_MINWAVES) void k_encode_streams(
     StreamDesc* __restrict__ streams, uint32_t* __restrict__ tickets /*[8]*/, const int32_t* __restrict__ qlist,
     const int32_t* __restrict__ qoff /*[9]*/, const ChunkDesc* __restrict__ chunks, const BlockDesc* __restrict__ blocks,
-    uint32_t* __restrict__ blk_ready, uint32_t* __restrict__ plane_cost
+    uint32_t* __restrict__ blk_ready, uint32_t* __restrict__ plane_cost, int single_queue
 #ifdef BAMD_PROFILE_DECODE
     , uint32_t* __restrict__ profbuf
 #endif
@@ -637,7 +637,8 @@ __global__ __launch_bounds__(64 * ENC_WAVES, BAMD_ENC_MINWAVES) void k_encode_st
   __shared__ enc_entry_t tabs[ENC_WAVES][ENC_TAB_BYTES / 4];
   static_assert(ENC_WAVES == 1, "one stream per wave, one wave per workgroup");
   const int lane = threadIdx.x & 63;
-  const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;   // HW_REG_XCC_ID[3:0]
+  // HW_REG_XCC_ID[3:0]; queue 0 for everybody in the single-queue fallback (no in-kernel hand-offs there)
+  const uint32_t xcc = single_queue ? 0u : (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);
   const uint32_t qbase = (uint32_t)qoff[xcc], qlen = (uint32_t)qoff[xcc + 1] - qbase;
   uint32_t t = take_ticket(tickets + xcc, lane);
   while (t < qlen) {

@@ -12,7 +12,8 @@
 
 namespace bamd {
 
-// Per-XCD task queues of the encode kernel: out = off[9] | entries.  Block g belongs to XCD g & 7; an
+// Per-XCD task queues of the encode kernel: out = off[9] | entries.  Block g belongs to queue g % nq (nq = 8:
+// one queue per XCD; nq = 1: the single-queue fallback of engine.hip, which also switches the fusion off); an
 // entry >= 0 is a stream index, an entry < 0 the shuffle task of block -(entry+1).  A block's shuffle
 // task is queued kEncLookahead blocks ahead of its streams: by the time a wave draws one of the streams
 // the transpose is normally finished, and it is always already owned by a running wave (no deadlock).
@@ -39,10 +40,10 @@ inline void plane_order(const uint32_t* cost, bool valid, int T, std::vector<int
 // The kernel's tail (waves finishing their last stream while the queue is already empty) then consists of
 // cheap streams instead of 3 ms ones.
 inline void build_encode_queues(const std::vector<BlockDesc>& blocks, const std::vector<ChunkDesc>& chunks,
-                                const uint32_t* cost, bool cost_valid, std::vector<int32_t>& out) {
+                                const uint32_t* cost, bool cost_valid, std::vector<int32_t>& out, int nq = 8) {
   std::vector<int32_t> q[8];
   std::vector<uint32_t> mine[8];
-  for (size_t g = 0; g < blocks.size(); g++) if (blocks[g].nstreams > 0) mine[g & 7].push_back((uint32_t)g);
+  for (size_t g = 0; g < blocks.size(); g++) if (blocks[g].nstreams > 0) mine[g % (size_t)nq].push_back((uint32_t)g);
   std::vector<int> order; int nheavy = 0, lastT = -1;
   for (int x = 0; x < 8; x++) {
     const std::vector<uint32_t>& B = mine[x];
@@ -79,10 +80,10 @@ inline void build_encode_queues(const std::vector<BlockDesc>& blocks, const std:
 // streams drawn last - the kernel's tail - are cheap ones.
 constexpr size_t kDecLead = 256;
 inline void build_xcd_queues(const std::vector<BlockDesc>& blocks, size_t nstr, const uint32_t* cost, bool cost_valid,
-                             std::vector<int32_t>& out) {
+                             std::vector<int32_t>& out, int nq = 8) {
   std::vector<int32_t> q[8];
   std::vector<uint32_t> mine[8];
-  for (size_t g = 0; g < blocks.size(); g++) if (blocks[g].nstreams > 0) mine[g & 7].push_back((uint32_t)g);
+  for (size_t g = 0; g < blocks.size(); g++) if (blocks[g].nstreams > 0) mine[g % (size_t)nq].push_back((uint32_t)g);
   std::vector<int> order; int nheavy = 0, lastT = -1;
   auto prep = [&](const BlockDesc& b) {
     if (b.nstreams != lastT) { plane_order(cost, cost_valid && sched_enabled(), b.nstreams, order, &nheavy); lastT = b.nstreams; }

@@ -39,9 +39,10 @@ int main() {
     uint32_t cost[256];
     for (int k = 0; k < 256; k++) cost[k] = (rng() % 3 == 0) ? 0u : (uint32_t)(rng() % 100000);
     const bool valid = trial % 2;
+    const int nq = (trial % 5 == 4) ? 1 : 8;     // 1: the single-queue fallback
     // ---- encode queues ----
     std::vector<int32_t> q;
-    build_encode_queues(blocks, chunks, cost, valid, q);
+    build_encode_queues(blocks, chunks, cost, valid, q, nq);
     if (q.size() < 10 || q[0] != 0) return fail("enc: header", trial);
     for (int x = 0; x < 8; x++) if (q[x + 1] < q[x]) return fail("enc: offsets not monotone", trial);
     size_t nfused = 0;
@@ -56,13 +57,13 @@ int main() {
         const int32_t t = q[9 + i];
         if (t < 0) {
           const size_t g = (size_t)(-(t + 1));
-          if (g >= blocks.size() || (int)(g & 7) != x) return fail("enc: shuffle task on the wrong XCD", trial);
+          if (g >= blocks.size() || (int)(g % (size_t)nq) != x) return fail("enc: shuffle task on the wrong XCD", trial);
           if (!(chunks[blocks[g].chunk].mode & CH_FUSED_SHUF) || blocks[g].nstreams == 0) return fail("enc: shuffle task for a non-fused block", trial);
           if (shuffled[g]++) return fail("enc: shuffle task twice", trial);
         } else {
           if (t >= nstr) return fail("enc: stream index out of range", trial);
           const int g = owner[(size_t)t];
-          if ((g & 7) != x) return fail("enc: stream on the wrong XCD", trial);
+          if ((g % nq) != x) return fail("enc: stream on the wrong XCD", trial);
           if (seen[(size_t)t]++) return fail("enc: stream twice", trial);
           if ((chunks[blocks[(size_t)g].chunk].mode & CH_FUSED_SHUF) && !shuffled[(size_t)g]) return fail("enc: stream queued before its block's shuffle task", trial);
         }
@@ -72,7 +73,7 @@ int main() {
       if ((blocks[g].nstreams > 0 && (chunks[blocks[g].chunk].mode & CH_FUSED_SHUF)) != (shuffled[g] == 1)) return fail("enc: shuffle task missing", trial);
     // ---- decode queues ----
     std::vector<int32_t> d;
-    build_xcd_queues(blocks, (size_t)nstr, cost, valid, d);
+    build_xcd_queues(blocks, (size_t)nstr, cost, valid, d, nq);
     if (d.size() != (size_t)9 + (nstr ? (size_t)nstr : 1) || d[0] != 0 || d[8] != nstr) return fail("dec: header", trial);
     std::fill(seen.begin(), seen.end(), 0);
     for (int x = 0; x < 8; x++) {
@@ -80,7 +81,7 @@ int main() {
       for (int i = d[x]; i < d[x + 1]; i++) {
         const int32_t t = d[9 + i];
         if (t < 0 || t >= nstr) return fail("dec: stream index out of range", trial);
-        if ((owner[(size_t)t] & 7) != x) return fail("dec: stream on the wrong XCD", trial);
+        if ((owner[(size_t)t] % nq) != x) return fail("dec: stream on the wrong XCD", trial);
         if (seen[(size_t)t]++) return fail("dec: stream twice", trial);
       }
     }
