@@ -1,0 +1,399 @@
+/* oracle/zstd_oracle.c — CPU restatement of the Zstandard FRAME DECODER, the part of codec row K8
+ *  that blosc_d reaches through zstd_wrap_decompress (blosc/blosc.c:515-522 ->
+ * ZSTD_decompress, internal-complibs/zstd-1.5.6/lib/decompress/zstd_decompress.c:1201).
+ *
+ * TEST INFRASTRUCTURE ONLY (see blosc_oracle.h): nothing in the product links or loads this file.
+ * Written from the format (RFC 8878; the vendored decoder is the only spec in the reference tree):
+ *   frame header            zstd_decompress.c:447   ZSTD_getFrameHeader_advanced
+ *   block loop              zstd_decompress.c:951   ZSTD_decompressFrame
+ *   literals section        zstd_decompress_block.c:134   ZSTD_decodeLiteralsBlock
+ *   Huffman table / decode  common/huf... HUF_readDTableX1_wksp, HUF_decompress4X1
+ *   sequence headers        zstd_decompress_block.c:695   ZSTD_decodeSeqHeaders
+ *   FSE table build         zstd_decompress_block.c:485   ZSTD_buildFSETable
+ *   sequence decode / exec  zstd_decompress_block.c:1229 / :1001
+ * Every blosc block is ONE frame with one block; the decoder below is nevertheless the general
+ * single-frame decoder (several blocks, raw / RLE / compressed, treeless literals, repeat tables).  Not
+ * supported, like a blosc caller never produces them: dictionaries, skippable frames; a content checksum is
+ * skipped, not verified.  Pinned by tests/test_oracle_zstd.py against the real reference (oracle/_ref).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ZO_ERR 0   /* zstd_wrap_decompress maps every ZSTD error to 0 (blosc.c:518-521) */
+
+static int hb32(uint32_t v) { return 31 - __builtin_clz(v); }   /* v != 0 */
+
+/* nbits (<= 32) bits starting at bit `off` of a little-endian bit array; bits below 0 read as 0 */
+static uint32_t bits_le(const uint8_t* p, int64_t off, int n) {
+  uint64_t v = 0;
+  if (n == 0) return 0;
+  int shift = 0;
+  if (off < 0) { shift = (int)(-off); if (shift >= n) return 0; n -= shift; off = 0; }
+  int64_t byte = off >> 3; int sub = (int)(off & 7);
+  for (int k = 0; k < 6; k++) v |= (uint64_t)p[byte + k] << (8 * k);   /* callers keep 8 readable bytes of slack */
+  v >>= sub;
+  v &= (n >= 32) ? 0xffffffffull : ((1ull << n) - 1);
+  return (uint32_t)(v << shift);
+}
+
+/* ---- forward bit reader (FSE table descriptions) ---- */
+typedef struct { const uint8_t* p; int64_t pos, end; } FwdBits;
+static uint32_t fwd_read(FwdBits* b, int n) { uint32_t v = bits_le(b->p, b->pos, n); b->pos += n; return v; }
+
+/* ---- backward bit stream (Huffman, FSE payloads): starts below the end marker, runs towards bit 0 ---- */
+typedef struct { const uint8_t* p; int64_t off; } BackBits;
+static int back_init(BackBits* b, const uint8_t* p, int len) {
+  if (len <= 0 || p[len - 1] == 0) return -1;
+  b->p = p; b->off = (int64_t)len * 8 - (8 - hb32(p[len - 1]));
+  return 0;
+}
+static uint32_t back_read(BackBits* b, int n) { b->off -= n; return bits_le(b->p, b->off, n); }
+
+/* ---- FSE ---- */
+typedef struct { uint8_t sym[512]; uint8_t nb[512]; uint16_t base[512]; int al; } FseTab;
+
+/* normalized counts -> decoding table (zstd_decompress_block.c:485-592) */
+static int fse_build(FseTab* t, const int16_t* norm, int nsym, int al) {
+  const int size = 1 << al;
+  uint16_t next[256];
+  int high = size - 1;
+  t->al = al;
+  for (int s = 0; s < nsym; s++) {
+    if (norm[s] == -1) { t->sym[high--] = (uint8_t)s; next[s] = 1; }
+    else next[s] = (uint16_t)norm[s];
+  }
+  const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
+  int pos = 0;
+  for (int s = 0; s < nsym; s++) {
+    if (norm[s] <= 0) continue;
+    for (int i = 0; i < norm[s]; i++) {
+      t->sym[pos] = (uint8_t)s;
+      do { pos = (pos + step) & mask; } while (pos > high);
+    }
+  }
+  if (pos != 0) return -1;
+  for (int i = 0; i < size; i++) {
+    const int s = t->sym[i];
+    const uint32_t x = next[s]++;
+    t->nb[i] = (uint8_t)(al - hb32(x));
+    t->base[i] = (uint16_t)((x << t->nb[i]) - size);
+  }
+  return 0;
+}
+static void fse_rle(FseTab* t, int sym) { t->al = 0; t->sym[0] = (uint8_t)sym; t->nb[0] = 0; t->base[0] = 0; }
+
+/* FSE table description (FSE_readNCount): returns bytes consumed or -1 */
+static int fse_read_ncount(const uint8_t* src, int srcsize, int max_al, int max_sym, int16_t* norm, int* nsym_out, int* al_out) {
+  uint8_t pad[128 + 16];                                   /* a description is far shorter than 128 bytes; bits_le slack */
+  const int m = srcsize < 128 ? srcsize : 128;
+  memset(pad, 0, sizeof pad); memcpy(pad, src, (size_t)m);
+  FwdBits b = {pad, 0, (int64_t)m * 8};
+  const int al = 5 + (int)fwd_read(&b, 4);
+  if (al > max_al) return -1;
+  int remaining = 1 << al, s = 0;
+  while (remaining > 0 && s <= max_sym) {
+    const int nbits = hb32((uint32_t)remaining + 1) + 1;
+    uint32_t val = fwd_read(&b, nbits);
+    const uint32_t lower = (1u << (nbits - 1)) - 1;
+    const uint32_t thresh = (1u << nbits) - 1 - ((uint32_t)remaining + 1);
+    if ((val & lower) < thresh) { b.pos--; val &= lower; }
+    else if (val > lower) val -= thresh;
+    const int proba = (int)val - 1;
+    remaining -= proba < 0 ? -proba : proba;
+    norm[s++] = (int16_t)proba;
+    if (proba == 0) {
+      int rep = (int)fwd_read(&b, 2);
+      for (;;) {
+        for (int i = 0; i < rep && s <= max_sym; i++) norm[s++] = 0;
+        if (rep != 3) break;
+        rep = (int)fwd_read(&b, 2);
+      }
+    }
+    if (b.pos > b.end) return -1;
+  }
+  if (remaining != 0 || s > max_sym + 1) return -1;
+  *nsym_out = s; *al_out = al;
+  const int used = (int)((b.pos + 7) >> 3);
+  return used <= srcsize ? used : -1;
+}
+
+/* ---- Huffman ---- */
+typedef struct { uint8_t sym[2048]; uint8_t nb[2048]; int maxbits; int valid; } HufTab;
+
+static int huf_build(HufTab* t, const uint8_t* weights, int nw) {   /* nw weights given, the last one is implied */
+  uint32_t total = 0;
+  uint8_t w[256];
+  if (nw < 1 || nw > 255) return -1;
+  for (int i = 0; i < nw; i++) { if (weights[i] > 11) return -1; w[i] = weights[i]; if (w[i]) total += 1u << (w[i] - 1); }
+  if (total == 0) return -1;
+  const int maxbits = hb32(total) + 1;
+  if (maxbits > 11) return -1;
+  const uint32_t left = (1u << maxbits) - total;
+  if (left & (left - 1)) return -1;                      /* the implied weight must complete a power of two */
+  w[nw] = (uint8_t)(hb32(left) + 1);
+  const int n = nw + 1;
+  uint8_t bits[256]; uint32_t rank_count[13] = {0}, rank_idx[13];
+  for (int i = 0; i < n; i++) { bits[i] = w[i] ? (uint8_t)(maxbits + 1 - w[i]) : 0; rank_count[bits[i]]++; }
+  rank_idx[maxbits] = 0;
+  for (int i = maxbits; i >= 1; i--) {
+    rank_idx[i - 1] = rank_idx[i] + rank_count[i] * (1u << (maxbits - i));
+    memset(t->nb + rank_idx[i], i, rank_idx[i - 1] - rank_idx[i]);
+  }
+  if (rank_idx[0] != (1u << maxbits)) return -1;
+  for (int i = 0; i < n; i++) {
+    if (!bits[i]) continue;
+    const uint32_t len = 1u << (maxbits - bits[i]);
+    memset(t->sym + rank_idx[bits[i]], i, len);
+    rank_idx[bits[i]] += len;
+  }
+  t->maxbits = maxbits; t->valid = 1;
+  return 0;
+}
+
+/* Huffman tree description (HUF_readStats): returns bytes consumed or -1 */
+static int huf_read_table(HufTab* t, const uint8_t* src, int srcsize) {
+  uint8_t weights[256];
+  if (srcsize < 1) return -1;
+  const int hb = src[0];
+  int nw = 0, used;
+  if (hb >= 128) {                                         /* direct: 4 bits per weight */
+    nw = hb - 127;
+    used = 1 + (nw + 1) / 2;
+    if (used > srcsize) return -1;
+    for (int i = 0; i < nw; i++) weights[i] = (i & 1) ? (src[1 + i / 2] & 15) : (src[1 + i / 2] >> 4);
+  } else {                                                 /* FSE-compressed weights, two interleaved states */
+    used = 1 + hb;
+    if (hb == 0 || used > srcsize) return -1;
+    int16_t norm[16]; int nsym, al;
+    const int h = fse_read_ncount(src + 1, hb, 6, 12, norm, &nsym, &al);
+    if (h < 0) return -1;
+    FseTab ft;
+    if (fse_build(&ft, norm, nsym, al)) return -1;
+    uint8_t* buf = (uint8_t*)calloc((size_t)hb + 16, 1);   /* bits_le slack */
+    memcpy(buf + 8, src + 1 + h, (size_t)(hb - h));
+    BackBits b;
+    if (back_init(&b, buf + 8, hb - h)) { free(buf); return -1; }
+    uint32_t s1 = back_read(&b, al), s2 = back_read(&b, al);
+    for (;;) {
+      if (nw >= 254) { free(buf); return -1; }
+      weights[nw++] = ft.sym[s1];
+      s1 = ft.base[s1] + back_read(&b, ft.nb[s1]);
+      if (b.off < 0) { weights[nw++] = ft.sym[s2]; break; }
+      if (nw >= 254) { free(buf); return -1; }
+      weights[nw++] = ft.sym[s2];
+      s2 = ft.base[s2] + back_read(&b, ft.nb[s2]);
+      if (b.off < 0) { weights[nw++] = ft.sym[s1]; break; }
+    }
+    free(buf);
+  }
+  if (huf_build(t, weights, nw)) return -1;
+  return used;
+}
+
+/* one Huffman stream: src[0..len) -> exactly `n` symbols */
+static int huf_decode_stream(const HufTab* t, const uint8_t* src, int len, uint8_t* out, int n) {
+  uint8_t* buf = (uint8_t*)calloc((size_t)len + 16, 1);
+  memcpy(buf + 8, src, (size_t)len);
+  BackBits b;
+  if (back_init(&b, buf + 8, len)) { free(buf); return -1; }
+  const int mb = t->maxbits; const uint32_t mask = (1u << mb) - 1;
+  uint32_t state = back_read(&b, mb);
+  int i = 0;
+  for (; i < n && b.off > -mb; i++) {
+    out[i] = t->sym[state];
+    const int nb = t->nb[state];
+    state = ((state << nb) & mask) | back_read(&b, nb);
+  }
+  const int ok = (i == n && b.off == -mb);
+  free(buf);
+  return ok ? 0 : -1;
+}
+
+/* ---- sequence code tables (RFC 8878 3.1.1.3.2.1.1) ---- */
+static const uint32_t LL_BASE[36] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 28, 32, 40, 48, 64,
+                                     128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536};
+static const uint8_t LL_BITS[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+static const uint32_t ML_BASE[53] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30,
+                                     31, 32, 33, 34, 35, 37, 39, 41, 43, 47, 51, 59, 67, 83, 99, 131, 259, 515, 1027, 2051, 4099, 8195, 16387, 32771, 65539};
+static const uint8_t ML_BITS[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                    1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+static const int16_t LL_DEF[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
+static const int16_t ML_DEF[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                   1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
+static const int16_t OF_DEF[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
+
+typedef struct {
+  HufTab huf;
+  FseTab ll, of, ml;
+  int have_ll, have_of, have_ml;
+  uint32_t rep[3];
+} FrameCtx;
+
+/* one of the three sequence tables: mode 0 predefined, 1 RLE, 2 described, 3 repeat.  Returns bytes used or -1 */
+static int seq_table(FseTab* t, int* have, int mode, const uint8_t* src, int srcsize, const int16_t* def, int ndef, int def_al,
+                     int max_al, int max_sym) {
+  if (mode == 0) { if (fse_build(t, def, ndef, def_al)) return -1; *have = 1; return 0; }
+  if (mode == 1) { if (srcsize < 1 || src[0] > max_sym) return -1; fse_rle(t, src[0]); *have = 1; return 1; }
+  if (mode == 2) {
+    int16_t norm[64]; int nsym, al;
+    const int h = fse_read_ncount(src, srcsize, max_al, max_sym, norm, &nsym, &al);
+    if (h < 0 || fse_build(t, norm, nsym, al)) return -1;
+    *have = 1; return h;
+  }
+  return *have ? 0 : -1;
+}
+
+/* compressed block: literals + sequences, executed into dst[*op..]; history = everything before *op */
+static int block_compressed(FrameCtx* c, const uint8_t* src, int size, uint8_t* dst, int cap, int* op_io) {
+  if (size < 1) return -1;
+  /* ---- literals section ---- */
+  const int ltype = src[0] & 3, sf = (src[0] >> 2) & 3;
+  int regen, csz = 0, hdr, nstreams = 1;
+  if (ltype < 2) {
+    if (sf == 0 || sf == 2) { hdr = 1; regen = src[0] >> 3; }
+    else if (sf == 1) { if (size < 2) return -1; hdr = 2; regen = (src[0] >> 4) | (src[1] << 4); }
+    else { if (size < 3) return -1; hdr = 3; regen = (src[0] >> 4) | (src[1] << 4) | (src[2] << 12); }
+  } else {
+    if (size < 5) return -1;
+    const uint64_t v = (uint64_t)src[0] | ((uint64_t)src[1] << 8) | ((uint64_t)src[2] << 16) | ((uint64_t)src[3] << 24) | ((uint64_t)src[4] << 32);
+    if (sf == 0 || sf == 1) { hdr = 3; regen = (int)((v >> 4) & 0x3ff); csz = (int)((v >> 14) & 0x3ff); nstreams = sf == 0 ? 1 : 4; }
+    else if (sf == 2) { hdr = 4; regen = (int)((v >> 4) & 0x3fff); csz = (int)((v >> 18) & 0x3fff); nstreams = 4; }
+    else { hdr = 5; regen = (int)((v >> 4) & 0x3ffff); csz = (int)((v >> 22) & 0x3ffff); nstreams = 4; }
+  }
+  if (regen > (1 << 17)) return -1;                       /* a block regenerates at most 128 KiB */
+  uint8_t* lit = (uint8_t*)malloc((size_t)regen + 1);
+  int ip = hdr, rc = -1;
+  if (ltype == 0) { if (ip + regen > size) goto done; memcpy(lit, src + ip, (size_t)regen); ip += regen; }
+  else if (ltype == 1) { if (ip + 1 > size) goto done; memset(lit, src[ip], (size_t)regen); ip += 1; }
+  else {
+    if (ip + csz > size) goto done;
+    const uint8_t* hs = src + ip; int hlen = csz;
+    if (ltype == 2) { const int used = huf_read_table(&c->huf, hs, hlen); if (used < 0) goto done; hs += used; hlen -= used; }
+    else if (!c->huf.valid) goto done;
+    if (nstreams == 1) { if (huf_decode_stream(&c->huf, hs, hlen, lit, regen)) goto done; }
+    else {
+      if (hlen < 6) goto done;
+      const int s1 = hs[0] | (hs[1] << 8), s2 = hs[2] | (hs[3] << 8), s3 = hs[4] | (hs[5] << 8);
+      const int s4 = hlen - 6 - s1 - s2 - s3;
+      if (s4 < 1) goto done;
+      const int q = (regen + 3) / 4;
+      if (3 * q > regen) goto done;
+      const uint8_t* p = hs + 6;
+      if (huf_decode_stream(&c->huf, p, s1, lit, q)) goto done;
+      if (huf_decode_stream(&c->huf, p + s1, s2, lit + q, q)) goto done;
+      if (huf_decode_stream(&c->huf, p + s1 + s2, s3, lit + 2 * q, q)) goto done;
+      if (huf_decode_stream(&c->huf, p + s1 + s2 + s3, s4, lit + 3 * q, regen - 3 * q)) goto done;
+    }
+    ip += csz;
+  }
+  /* ---- sequences section ---- */
+  if (ip >= size) goto done;
+  int nseq = src[ip++];
+  if (nseq >= 128) {
+    if (nseq == 255) { if (ip + 2 > size) goto done; nseq = src[ip] + (src[ip + 1] << 8) + 0x7f00; ip += 2; }
+    else { if (ip + 1 > size) goto done; nseq = ((nseq - 128) << 8) + src[ip]; ip += 1; }
+  }
+  int op = *op_io, lp = 0;
+  if (nseq > 0) {
+    if (ip >= size) goto done;
+    const int modes = src[ip++];
+    if (modes & 3) goto done;
+    int u;
+    if ((u = seq_table(&c->ll, &c->have_ll, modes >> 6, src + ip, size - ip, LL_DEF, 36, 6, 9, 35)) < 0) goto done;
+    ip += u;
+    if ((u = seq_table(&c->of, &c->have_of, (modes >> 4) & 3, src + ip, size - ip, OF_DEF, 29, 5, 8, 31)) < 0) goto done;
+    ip += u;
+    if ((u = seq_table(&c->ml, &c->have_ml, (modes >> 2) & 3, src + ip, size - ip, ML_DEF, 53, 6, 9, 52)) < 0) goto done;
+    ip += u;
+    const int blen = size - ip;
+    if (blen < 1) goto done;
+    uint8_t* buf = (uint8_t*)calloc((size_t)blen + 16, 1);
+    memcpy(buf + 8, src + ip, (size_t)blen);
+    BackBits b;
+    if (back_init(&b, buf + 8, blen)) { free(buf); goto done; }
+    uint32_t sl = back_read(&b, c->ll.al), so = back_read(&b, c->of.al), sm = back_read(&b, c->ml.al);
+    int bad = 0;
+    for (int i = 0; i < nseq; i++) {
+      const int oc = c->of.sym[so], mc = c->ml.sym[sm], lc = c->ll.sym[sl];
+      if (oc > 31 || mc > 52 || lc > 35) { bad = 1; break; }
+      const uint32_t ov = (1u << oc) + (oc ? back_read(&b, oc) : 0);     /* offset bits first, then match, then literal length */
+      const uint32_t ml = ML_BASE[mc] + (ML_BITS[mc] ? back_read(&b, ML_BITS[mc]) : 0);
+      const uint32_t ll = LL_BASE[lc] + (LL_BITS[lc] ? back_read(&b, LL_BITS[lc]) : 0);
+      if (i + 1 < nseq) {                                                /* state updates: LL, ML, OF */
+        sl = c->ll.base[sl] + back_read(&b, c->ll.nb[sl]);
+        sm = c->ml.base[sm] + back_read(&b, c->ml.nb[sm]);
+        so = c->of.base[so] + back_read(&b, c->of.nb[so]);
+      }
+      if (b.off < 0) { bad = 1; break; }
+      /* offset value -> distance, repeat-offset history (zstd_decompress_block.c:1258-1301) */
+      uint32_t off;
+      if (ov > 3) { off = ov - 3; c->rep[2] = c->rep[1]; c->rep[1] = c->rep[0]; c->rep[0] = off; }
+      else {
+        uint32_t idx = ov - 1;
+        if (ll == 0) idx++;
+        if (idx == 0) off = c->rep[0];
+        else {
+          off = idx < 3 ? c->rep[idx] : c->rep[0] - 1;
+          if (off == 0) { bad = 1; break; }
+          if (idx > 1) c->rep[2] = c->rep[1];
+          c->rep[1] = c->rep[0]; c->rep[0] = off;
+        }
+      }
+      if ((uint64_t)lp + ll > (uint64_t)regen || (uint64_t)op + ll + ml > (uint64_t)cap || off > (uint32_t)op + ll) { bad = 1; break; }
+      memcpy(dst + op, lit + lp, ll); op += (int)ll; lp += (int)ll;
+      for (uint32_t k = 0; k < ml; k++) dst[op + k] = dst[op + k - off];   /* byte-wise: distances below the length overlap */
+      op += (int)ml;
+    }
+    if (!bad && b.off != 0) bad = 1;                                      /* the bitstream must be consumed exactly */
+    free(buf);
+    if (bad) goto done;
+  }
+  if (op + (regen - lp) > cap) goto done;
+  memcpy(dst + op, lit + lp, (size_t)(regen - lp)); op += regen - lp;
+  *op_io = op; rc = 0;
+done:
+  free(lit);
+  return rc;
+}
+
+/* One frame -> dst.  Returns the decoded size, 0 on any error (zstd_wrap_decompress's contract). */
+int orc_zstd_decompress(const void* src_, int srcsize, void* dst_, int cap) {
+  const uint8_t* src = (const uint8_t*)src_;
+  uint8_t* dst = (uint8_t*)dst_;
+  if (srcsize < 6) return ZO_ERR;
+  if (!(src[0] == 0x28 && src[1] == 0xB5 && src[2] == 0x2F && src[3] == 0xFD)) return ZO_ERR;
+  const int fhd = src[4];
+  const int fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, checksum = (fhd >> 2) & 1, did = fhd & 3;
+  if (fhd & 0x08) return ZO_ERR;                           /* reserved bit */
+  int ip = 5;
+  if (!single) ip += 1;                                    /* window descriptor: the output buffer is the window here */
+  if (did) return ZO_ERR;                                  /* dictionaries: never produced through blosc */
+  const int fcs_bytes = fcs_flag == 0 ? single : (fcs_flag == 1 ? 2 : (fcs_flag == 2 ? 4 : 8));
+  if (ip + fcs_bytes > srcsize) return ZO_ERR;
+  uint64_t fcs = 0; int have_fcs = fcs_bytes != 0;
+  for (int k = 0; k < fcs_bytes; k++) fcs |= (uint64_t)src[ip + k] << (8 * k);
+  if (fcs_bytes == 2) fcs += 256;
+  ip += fcs_bytes;
+  if (have_fcs && fcs > (uint64_t)cap) return ZO_ERR;
+  FrameCtx* c = (FrameCtx*)calloc(1, sizeof(FrameCtx));
+  c->rep[0] = 1; c->rep[1] = 4; c->rep[2] = 8;
+  int op = 0, ok = 0;
+  for (;;) {
+    if (ip + 3 > srcsize) break;
+    const uint32_t bh = (uint32_t)src[ip] | ((uint32_t)src[ip + 1] << 8) | ((uint32_t)src[ip + 2] << 16);
+    ip += 3;
+    const int last = bh & 1, type = (bh >> 1) & 3, bsize = (int)(bh >> 3);
+    if (type == 0) { if (ip + bsize > srcsize || op + bsize > cap) break; memcpy(dst + op, src + ip, (size_t)bsize); op += bsize; ip += bsize; }
+    else if (type == 1) { if (ip + 1 > srcsize || op + bsize > cap) break; memset(dst + op, src[ip], (size_t)bsize); op += bsize; ip += 1; }
+    else if (type == 2) { if (bsize > (1 << 17) || ip + bsize > srcsize) break; if (block_compressed(c, src + ip, bsize, dst, cap, &op)) break; ip += bsize; }
+    else break;
+    if (last) { ok = 1; break; }
+  }
+  free(c);
+  if (!ok) return ZO_ERR;
+  if (checksum) ip += 4;
+  if (ip != srcsize) return ZO_ERR;                        /* ZSTD_decompress wants the input consumed: trailing bytes are an error */
+  if (have_fcs && fcs != (uint64_t)op) return ZO_ERR;
+  return op;
+}
