@@ -13,6 +13,7 @@ namespace bamd {
 enum : int32_t {
   FMT_BLOSCLZ = 0,  // header flag bits 5-7 (blosc/blosc.h:93-99)
   FMT_LZ4 = 1,
+  FMT_ZSTD = 4,     // decode only (k_zstd.hip)
 };
 
 enum : uint32_t {

@@ -18,6 +18,7 @@
 #include "k_filters.hip"
 #include "k_decode.hip"
 #include "k_encode.hip"
+#include "k_zstd.hip"
 
 namespace bamd {
 
@@ -428,7 +429,7 @@ static int classify_for_decompress(const Header& h, size_t srcsize, size_t dests
     return 1;
   }
   const int f = (h.flags & 0xe0) >> 5;                                         // blosc.c:525-574
-  if (f != FMT_BLOSCLZ && f != FMT_LZ4) { *res = -5; return 0; }
+  if (f != FMT_BLOSCLZ && f != FMT_LZ4 && f != FMT_ZSTD) { *res = -5; return 0; }   // Zstd: decode only (k_zstd.hip)
   if (h.versionlz != 1) { *res = -9; return 0; }
   *fmt = f;
   int32_t nblocks = h.nbytes / h.blocksize + ((h.nbytes % h.blocksize) ? 1 : 0);
@@ -495,6 +496,7 @@ struct DecodeLaunch {
   ChunkDesc* d_chunks; BlockDesc* d_blocks; StreamDesc* d_streams; int32_t* d_status; uint32_t* d_ticket; uint32_t* d_blkdone;
   uint32_t* d_spans; uint8_t* d_pat;             // periodic spans of the fused unshuffle (k_decode.hip: SpanCtx)
   uint32_t* d_cost;                              // [256] cycles per plane index (scheduling feedback)
+  uint32_t* d_zticket; bool any_zstd;            // Zstd frames go through k_zstd_streams
   const int32_t* d_qlist; const int32_t* d_qoff;   // per-XCD stream queues
   size_t nblk, nstr; int nchunks;
   bool any_shuf, any_bit, any_copy; int tiles_shuf, tiles_bit;
@@ -528,6 +530,11 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
       hipLaunchKernelGGL(k_decode_streams, dgrid, dim3(64 * DEC_WAVES), (size_t)dec_lds, stream, L.d_streams, L.d_status, L.d_ticket, L.d_qlist, L.d_qoff, L.d_chunks, L.d_blocks, L.d_blkdone, L.d_spans, L.d_pat, L.d_cost, st.single_queue ? 1 : 0);
 #endif
     }
+    if (L.any_zstd) {
+      ProfScope ps(st, stream, "k_zstd_streams");
+      hipLaunchKernelGGL(k_zstd_streams, dim3(persistent_grid(L.nstr, ZSTD_WAVES_PER_CU)), dim3(64), 0, stream, L.d_streams, (int)L.nstr, L.d_status,
+                         L.d_zticket, L.d_chunks, L.d_blocks);
+    }
     if (L.any_shuf) {
       ProfScope ps(st, stream, "k_unshuffle");
       hipLaunchKernelGGL(k_unshuffle, dim3((unsigned)L.nblk, (unsigned)L.tiles_shuf), dim3(FT_THREADS), 0, stream, L.d_chunks, L.d_blocks);
@@ -548,7 +555,7 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
 
 static void filter_tiles(ChunkDesc& c, bool& any_shuf, bool& any_bit, int& tiles_shuf, int& tiles_bit, bool may_fuse) {
   const int32_t T = c.typesize, N = c.blocksize / T;
-  if ((c.mode & CH_SHUFFLE) && (T == 8 || T == 4) && fuse_enabled() && may_fuse) { c.mode |= CH_FUSED_UNSHUF; return; }
+  if ((c.mode & CH_SHUFFLE) && (T == 8 || T == 4) && fuse_enabled() && may_fuse && c.fmt != FMT_ZSTD) { c.mode |= CH_FUSED_UNSHUF; return; }
   if (c.mode & CH_SHUFFLE) {
     any_shuf = true;
     int t = (N + shuffle_tile_elems(T) - 1) / shuffle_tile_elems(T); if (t < 1) t = 1;
@@ -572,7 +579,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   std::vector<ChunkDesc> chunks((size_t)n);
   std::vector<BlockDesc> blocks;
   std::vector<uint8_t> live((size_t)n, 0);
-  size_t nstr = 0, filt_bytes = 0, io_src = 0, io_dst = 0;
+  size_t nstr = 0, filt_bytes = 0, zlit_bytes = 0, io_src = 0, io_dst = 0;
   DecodeLaunch L{};
   for (int i = 0; i < n; i++) {
     ChunkDesc& c = chunks[(size_t)i];
@@ -588,6 +595,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
     if (c.mode & CH_MEMCPYED) L.any_copy = true;
     filter_tiles(c, L.any_shuf, L.any_bit, L.tiles_shuf, L.tiles_bit, !st.single_queue);
     if (c.mode & (CH_SHUFFLE | CH_BITSHUFFLE)) filt_bytes = align_up(filt_bytes, 256) + (size_t)c.nbytes;
+    if (c.fmt == FMT_ZSTD && !(c.mode & CH_MEMCPYED)) { L.any_zstd = true; zlit_bytes = align_up(zlit_bytes, 256) + (size_t)c.nbytes; }
     if (!device_ptrs) { io_src = align_up(io_src, 256) + (size_t)c.cbytes; io_dst = align_up(io_dst, 256) + (size_t)c.nbytes; }
   }
   const size_t nblk = blocks.size();
@@ -602,6 +610,8 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   const size_t o_spans = cv.take(8 * (nstr ? nstr : 1));
   const size_t o_pat = cv.take(span_enabled() ? (size_t)2048 * (nstr ? nstr : 1) : 256);
   const size_t o_filt = cv.take(filt_bytes + 256);
+  const size_t o_zlit = cv.take(zlit_bytes + 256);      // literal scratch of the Zstd chunks
+  const size_t o_zticket = cv.take(64);
   if (st.dev.ensure(cv.off)) return -1;
   uint8_t* D = st.dev.base;
   uint8_t *io_s = nullptr, *io_d = nullptr;
@@ -610,7 +620,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
     io_s = st.io.base; io_d = st.io.base + align_up(io_src + 256, 256);
   }
   {
-    size_t fo = 0, is = 0, id = 0;
+    size_t fo = 0, zo = 0, is = 0, id = 0;
     for (int i = 0; i < n; i++) {
       if (!live[(size_t)i]) continue;
       ChunkDesc& c = chunks[(size_t)i];
@@ -621,6 +631,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
         is += (size_t)c.cbytes; id += (size_t)c.nbytes;
       }
       if (c.mode & (CH_SHUFFLE | CH_BITSHUFFLE)) { fo = align_up(fo, 256); c.filt = D + o_filt + fo; fo += (size_t)c.nbytes; }
+      if (c.fmt == FMT_ZSTD && !(c.mode & CH_MEMCPYED)) { zo = align_up(zo, 256); c.stage = D + o_zlit + zo; zo += (size_t)c.nbytes; }
     }
   }
   std::vector<int32_t> queues;
@@ -649,6 +660,8 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   L.d_spans = span_enabled() ? (uint32_t*)(D + o_spans) : nullptr; L.d_pat = D + o_pat;
   L.d_cost = (uint32_t*)(D + o_cost);
   HIP_TRY(hipMemsetAsync(D + o_cost, 0, sizeof(uint32_t) * 256, stream));
+  L.d_zticket = (uint32_t*)(D + o_zticket);
+  if (L.any_zstd) HIP_TRY(hipMemsetAsync(D + o_zticket, 0, 64, stream));
   L.nblk = nblk; L.nstr = nstr; L.nchunks = n;
   if (launch_decode(st, L, stream)) return -1;
   HIP_TRY(hipMemcpyAsync(P + p_status, D + o_status, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, stream));
@@ -692,7 +705,7 @@ int engine_getitem(const void* src, int start, int nitems, void* dest, bool src_
     if (h.nbytes + kMaxOverhead != h.cbytes) return -1;
   } else {
     const int f = (h.flags & 0xe0) >> 5;
-    if (f != FMT_BLOSCLZ && f != FMT_LZ4) return -5;
+    if (f != FMT_BLOSCLZ && f != FMT_LZ4 && f != FMT_ZSTD) return -5;
     if (h.versionlz != 1) return -9;
     fmt = f;
     if (nblocks >= (h.cbytes - 16) / 4) return -1;                               // blosc.c:1630-1632 (sic: >=)
@@ -734,12 +747,15 @@ int engine_getitem(const void* src, int start, int nitems, void* dest, bool src_
   const size_t o_pat = cv.take(span_enabled() ? (size_t)2048 * nstr : 256);
   const size_t o_out = cv.take(span + 256);
   const size_t o_filt = cv.take(span + 256);
+  const size_t o_zlit = cv.take((fmt == FMT_ZSTD ? span : 0) + 256);
+  const size_t o_zticket = cv.take(64);
   if (st.dev.ensure(cv.off)) return -1;
   uint8_t* D = st.dev.base;
   c.src = dsrc;
   // kernels address block j at base + j*blocksize: bias the bases so that block j0 lands at offset 0
   c.dst = D + o_out - (size_t)j0 * bs;
   c.filt = (c.mode & (CH_SHUFFLE | CH_BITSHUFFLE)) ? D + o_filt - (size_t)j0 * bs : nullptr;
+  c.stage = (fmt == FMT_ZSTD) ? D + o_zlit - (size_t)j0 * bs : nullptr;
   DecodeLaunch L{};
   filter_tiles(c, L.any_shuf, L.any_bit, L.tiles_shuf, L.tiles_bit, !st.single_queue);   // may set CH_FUSED_UNSHUF: before the upload
   Carver pc;
@@ -765,6 +781,8 @@ int engine_getitem(const void* src, int start, int nitems, void* dest, bool src_
   L.d_qoff = (const int32_t*)(D + o_queues); L.d_qlist = L.d_qoff + 9;
   L.d_spans = span_enabled() ? (uint32_t*)(D + o_spans) : nullptr; L.d_pat = D + o_pat;
   L.d_cost = nullptr;   // a handful of blocks: no feedback
+  L.any_zstd = fmt == FMT_ZSTD; L.d_zticket = (uint32_t*)(D + o_zticket);
+  if (L.any_zstd) HIP_TRY(hipMemsetAsync(D + o_zticket, 0, 64, stream));
   L.nblk = nblk; L.nstr = nstr; L.nchunks = 1;
   if (launch_decode(st, L, stream)) return -1;
   HIP_TRY(hipMemcpyAsync(P + p_status, D + o_status, sizeof(int32_t), hipMemcpyDeviceToHost, stream));

@@ -657,6 +657,8 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
   if (csize == want) {    // split stored raw (blosc/blosc.c:773-776)
     wave_copy_disjoint(out, in, (uint32_t)want, lane);
     got = want;
+  } else if (sd->fmt == FMT_ZSTD) {
+    return;               // k_zstd_streams owns the frames of Zstd chunks
   } else if (sd->fmt == FMT_LZ4) {
     got = lz4_decode_wave(in, csize, out, want, scr, lane, sp PROF_PASS);
   } else {

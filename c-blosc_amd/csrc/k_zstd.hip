@@ -1,0 +1,218 @@
+// k_zstd.hip — Zstandard frame decode on the GPU (codec row K8 of SURVEY §8a, decode direction):
+// zstd_wrap_decompress (blosc/blosc.c:515-522) -> ZSTD_decompress for every stream of a Zstd chunk.  blosc
+// writes one frame with one <= 128 KiB block per blosc block; the decoder is nevertheless the
+// general single-frame one (several blocks; raw / RLE / compressed; treeless literals; repeat tables).
+//
+// First version, correctness before speed.  One wavefront per frame, persistent waves + ticket queue:
+//   * the inherently serial parts - headers, FSE / Huffman table builds, the Huffman literal streams (four
+//     lanes, one per stream), the FSE sequence stream - run the plain-C++ primitives of zstd_serial.h on single
+//     lanes with their tables in LDS (12 KiB per wave); tests/test_zstd_serial_cpu.py checks exactly that
+//     code on the CPU;
+//   * lane 0 decodes the sequences 64 at a time into LDS; the whole wave then EXECUTES them with the same
+//     wave-cooperative copies as the LZ4 decoder (wave_copy_disjoint for literals, wave_match_copy for
+//     matches: byte-exact forward semantics for overlapping distances).
+// The literals of a block are regenerated into a per-stream scratch (ChunkDesc::stage) first.
+// Chunks of this codec are never "fused": k_unshuffle / k_bitunshuffle run afterwards as kernels of their own.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "dev_types.h"
+#include "wave_prims.h"
+#include "zstd_serial.h"
+
+namespace bamd {
+
+struct ZstdLds {
+  uint16_t huf[2048];
+  uint32_t ll[512], of[512], ml[512];
+  uint32_t ftab[64];
+  uint16_t next[256];
+  int16_t norm[64];
+  uint8_t w[256];
+  uint32_t seq[3 * 64];
+};
+
+__device__ __forceinline__ uint32_t lane0_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 0); }
+
+// fill n bytes with v
+__device__ __forceinline__ void wave_fill(gu8* dst, uint32_t v, uint32_t n, int lane) {
+  for (uint32_t k = (uint32_t)lane; k < n; k += 64u) dst[k] = (uint8_t)v;
+}
+
+// one compressed block.  Returns true and advances op on success.  huf_valid / tabs state persist over the frame.
+__device__ bool zstd_block_wave(const uint8_t* b, int size, uint8_t* out, uint32_t cap, uint32_t& op, uint8_t* lit, ZstdLds* L,
+                                zd::Huf& huf, bool& huf_valid, zd::SeqTabs& tb, uint32_t* rep, int lane) {
+  // ---- literals section header (lane 0, broadcast) ----
+  zd::LitHdr lh = {0, 0, 0, 1, 0};
+  uint32_t ok = 0;
+  if (lane == 0) ok = zd::lit_header(b, size, lh) ? 1u : 0u;
+  if (!lane0_u32(ok)) return false;
+  const int ltype = (int)lane0_u32((uint32_t)lh.type), regen = (int)lane0_u32((uint32_t)lh.regen), csize = (int)lane0_u32((uint32_t)lh.csize);
+  const int nstreams = (int)lane0_u32((uint32_t)lh.nstreams);
+  int p = (int)lane0_u32((uint32_t)lh.hdr);
+  if (ltype == 0) {
+    if (p + regen > size) return false;
+    wave_copy_disjoint(as_global(lit), as_global(b + p), (uint32_t)regen, lane);
+    p += regen;
+  } else if (ltype == 1) {
+    if (p + 1 > size) return false;
+    wave_fill(as_global(lit), b[p], (uint32_t)regen, lane);
+    p += 1;
+  } else {
+    if (p + csize > size) return false;
+    const uint8_t* hs = b + p; int hlen = csize;
+    if (ltype == 2) {
+      int used = -1;
+      if (lane == 0) { used = zd::huf_read_table(huf, hs, hlen, L->w, L->ftab, L->next, L->norm); }
+      used = (int)lane0_u32((uint32_t)used);
+      if (used < 0) return false;
+      huf.maxbits = (int)lane0_u32((uint32_t)huf.maxbits);
+      huf_valid = true;
+      hs += used; hlen -= used;
+    } else if (!huf_valid) return false;
+    uint32_t good = 1;
+    if (nstreams == 1) {
+      if (lane == 0) good = zd::huf_decode_stream(huf, hs, hlen, lit, regen) ? 1u : 0u;
+    } else {
+      if (hlen < 6) return false;
+      const int s1 = hs[0] | (hs[1] << 8), s2 = hs[2] | (hs[3] << 8), s3 = hs[4] | (hs[5] << 8), s4 = hlen - 6 - s1 - s2 - s3;
+      const int q = (regen + 3) / 4;
+      if (s4 < 1 || 3 * q > regen) return false;
+      if (lane < 4) {                                          // four independent backward bit streams: one lane each
+        const int so = lane == 0 ? 0 : (lane == 1 ? s1 : (lane == 2 ? s1 + s2 : s1 + s2 + s3));
+        const int sl = lane == 0 ? s1 : (lane == 1 ? s2 : (lane == 2 ? s3 : s4));
+        const int n = lane < 3 ? q : regen - 3 * q;
+        good = zd::huf_decode_stream(huf, hs + 6 + so, sl, lit + lane * q, n) ? 1u : 0u;
+      }
+    }
+    if (__ballot(good == 0u)) return false;
+    p += csize;
+  }
+  // ---- sequences section ----
+  int nseq = 0, u0 = -1;
+  if (lane == 0) u0 = zd::seq_count(b + p, size - p, &nseq);
+  u0 = (int)lane0_u32((uint32_t)u0); nseq = (int)lane0_u32((uint32_t)nseq);
+  if (u0 < 0) return false;
+  p += u0;
+  uint32_t lp = 0;
+  if (nseq > 0) {
+    if (p >= size) return false;
+    const int modes = b[p++];
+    if (modes & 3) return false;
+    int used = -1;
+    zd::SeqState st;
+    if (lane == 0) {
+      int q = p, u;
+      bool fine = true;
+      if (fine && (u = zd::seq_table(tb.ll, tb.have_ll, 0, modes >> 6, b + q, size - q, L->norm, L->next)) >= 0) q += u; else fine = false;
+      if (fine && (u = zd::seq_table(tb.of, tb.have_of, 1, (modes >> 4) & 3, b + q, size - q, L->norm, L->next)) >= 0) q += u; else fine = false;
+      if (fine && (u = zd::seq_table(tb.ml, tb.have_ml, 2, (modes >> 2) & 3, b + q, size - q, L->norm, L->next)) >= 0) q += u; else fine = false;
+      st.rep[0] = rep[0]; st.rep[1] = rep[1]; st.rep[2] = rep[2];
+      if (fine && size - q >= 1 && zd::seq_begin(st, tb, b + q, size - q)) used = q;
+    }
+    used = (int)lane0_u32((uint32_t)used);
+    if (used < 0) return false;
+    for (int done = 0; done < nseq; done += 64) {
+      const int m = nseq - done < 64 ? nseq - done : 64;
+      uint32_t fine = 1;
+      if (lane == 0) {                                         // serial: the FSE sequence stream
+        for (int i = 0; i < m; i++) {
+          zd::Seq q;
+          if (!zd::seq_next(st, tb, done + i + 1 == nseq, q)) { fine = 0; break; }
+          L->seq[3 * i] = q.ll; L->seq[3 * i + 1] = q.ml; L->seq[3 * i + 2] = q.off;
+        }
+        if (fine && done + m == nseq && st.b.off != 0) fine = 0;   // the bit stream must be consumed exactly
+      }
+      if (!lane0_u32(fine)) return false;
+      for (int i = 0; i < m; i++) {                            // wave-parallel execution, in order
+        const uint32_t ll = uni(L->seq[3 * i]), ml = uni(L->seq[3 * i + 1]), off = uni(L->seq[3 * i + 2]);
+        if ((uint64_t)lp + ll > (uint64_t)regen || (uint64_t)op + ll + ml > (uint64_t)cap || off > op + ll) return false;
+        if (ll) wave_copy_disjoint(as_global(out) + op, as_global(lit) + lp, ll, lane);
+        wave_match_copy(as_global(out), op + ll, off, ml, lane);
+        op += ll + ml; lp += ll;
+      }
+    }
+    if (lane == 0) { rep[0] = st.rep[0]; rep[1] = st.rep[1]; rep[2] = st.rep[2]; }
+    rep[0] = lane0_u32(rep[0]); rep[1] = lane0_u32(rep[1]); rep[2] = lane0_u32(rep[2]);
+  }
+  const uint32_t rest = (uint32_t)regen - lp;
+  if ((uint64_t)op + rest > (uint64_t)cap) return false;
+  if (rest) wave_copy_disjoint(as_global(out) + op, as_global(lit) + lp, rest, lane);
+  op += rest;
+  return true;
+}
+
+// one frame -> out[0..cap); returns bytes produced, 0 on any error (zstd_wrap_decompress's contract)
+__device__ __attribute__((noinline)) int zstd_decode_wave(const uint8_t* in, int n, uint8_t* out, int cap, uint8_t* lit, ZstdLds* L, int lane) {
+  long long fcs = -1; bool checksum = false;
+  int ip = -1;
+  if (lane == 0) ip = zd::frame_header(in, n, &fcs, &checksum);
+  ip = (int)lane0_u32((uint32_t)ip);
+  if (ip < 0) return 0;
+  const uint32_t fcs_lo = lane0_u32((uint32_t)fcs), fcs_hi = lane0_u32((uint32_t)((unsigned long long)fcs >> 32));
+  const long long fcs_u = (long long)(((unsigned long long)fcs_hi << 32) | fcs_lo);
+  const bool has_checksum = lane0_u32(checksum ? 1u : 0u) != 0u;
+  if (fcs_u >= 0 && fcs_u > cap) return 0;
+  zd::Huf huf = {L->huf, 0}; bool huf_valid = false;
+  zd::SeqTabs tb = {{L->ll, 0}, {L->of, 0}, {L->ml, 0}, false, false, false};
+  uint32_t rep[3] = {1u, 4u, 8u};
+  uint32_t op = 0;
+  bool ok = false;
+  for (;;) {
+    if (ip + 3 > n) break;
+    const uint32_t bh = (uint32_t)in[ip] | ((uint32_t)in[ip + 1] << 8) | ((uint32_t)in[ip + 2] << 16);   // same address in every lane
+    ip += 3;
+    const int last = bh & 1u, type = (bh >> 1) & 3u, bsize = (int)(bh >> 3);
+    if (type == 0) {
+      if (ip + bsize > n || op + (uint32_t)bsize > (uint32_t)cap) break;
+      wave_copy_disjoint(as_global(out) + op, as_global(in + ip), (uint32_t)bsize, lane);
+      op += (uint32_t)bsize; ip += bsize;
+    } else if (type == 1) {
+      if (ip + 1 > n || op + (uint32_t)bsize > (uint32_t)cap) break;
+      wave_fill(as_global(out) + op, in[ip], (uint32_t)bsize, lane);
+      op += (uint32_t)bsize; ip += 1;
+    } else if (type == 2) {
+      if (bsize > (1 << 17) || ip + bsize > n) break;
+      // the table state lives in lane 0's registers + LDS; al / have flags are broadcast after each block
+      if (!zstd_block_wave(in + ip, bsize, out, (uint32_t)cap, op, lit, L, huf, huf_valid, tb, rep, lane)) break;
+      tb.ll.al = (int)lane0_u32((uint32_t)tb.ll.al); tb.of.al = (int)lane0_u32((uint32_t)tb.of.al); tb.ml.al = (int)lane0_u32((uint32_t)tb.ml.al);
+      tb.have_ll = lane0_u32(tb.have_ll) != 0u; tb.have_of = lane0_u32(tb.have_of) != 0u; tb.have_ml = lane0_u32(tb.have_ml) != 0u;
+      ip += bsize;
+    } else break;
+    if (last) { ok = true; break; }
+  }
+  if (!ok) return 0;
+  if (has_checksum) ip += 4;
+  if (ip != n) return 0;
+  if (fcs_u >= 0 && fcs_u != (long long)op) return 0;
+  return (int)op;
+}
+
+// Persistent waves over ALL streams of the launch; only the non-raw streams of Zstd chunks are taken here
+// (k_decode_streams copies the raw ones and leaves these alone).
+constexpr int ZSTD_WAVES_PER_CU = 12;
+__global__ __launch_bounds__(64, 3) void k_zstd_streams(StreamDesc* __restrict__ streams, int nstreams, int32_t* __restrict__ status,
+                                                     uint32_t* __restrict__ ticket, const ChunkDesc* __restrict__ chunks,
+                                                     const BlockDesc* __restrict__ blocks) {
+  __shared__ ZstdLds lds;
+  const int lane = threadIdx.x & 63;
+  uint32_t sid = take_ticket(ticket, lane);
+  while (sid < (uint32_t)nstreams) {
+    StreamDesc* sd = streams + sid;
+    const int32_t csize = (int32_t)uni((uint32_t)sd->in_size), want = (int32_t)uni((uint32_t)sd->out_size);
+    if (uni((uint32_t)sd->fmt) == (uint32_t)FMT_ZSTD && csize >= 0 && csize != want) {
+      const ChunkDesc* c = chunks + uni((uint32_t)sd->chunk);
+      const BlockDesc* b = blocks + uni((uint32_t)sd->aux);
+      // literal scratch: this stream's slice of the chunk's `stage` area (same offset as its output)
+      const size_t boff = (size_t)uni((uint32_t)b->blk) * (size_t)uni((uint32_t)c->blocksize) +
+                          (size_t)(sid - uni((uint32_t)b->first_stream)) * (size_t)want;
+      const int got = zstd_decode_wave(sd->in, csize, sd->out, want, c->stage + boff, &lds, lane);
+      if (lane == 0) {
+        sd->result = got;
+        if (got != want) atomicMin(&status[sd->chunk], (int32_t)ST_BADCODEC);   // blosc.c:780-782
+      }
+    }
+    sid = take_ticket(ticket, lane);
+  }
+}
+
+}  // namespace bamd
