@@ -8,7 +8,7 @@
 //
 // The file is plain C++ and compiles for BOTH sides: k_zstd.hip runs these functions on one lane (four for
 // the Huffman streams) of the wave that owns the frame and does the sequence EXECUTION wave-parallel;
-// tests/tools/zstd_serial_check.cpp compiles the same code with g++ and decodes whole frames with it on the
+// tests/tools/zstd_serial_frame.cpp compiles the same code with g++ and decodes whole frames with it on the
 // CPU, so everything here is checked against the oracle and the reference without a GPU.
 #pragma once
 #include <stdint.h>
@@ -50,7 +50,11 @@ ZD_FN bool back_init(Back& b, const uint8_t* p, int len) {
 }
 ZD_FN uint32_t back_read(Back& b, int n) {          // n <= 32
   if (n == 0) return 0u;
-  while (b.nacc < n && b.bytepos > 0) { b.bytepos--; b.acc = (b.acc << 8) | b.p[b.bytepos]; b.nacc += 8; }
+  if (b.nacc < n && b.bytepos >= 4) {                 // refill four bytes at a time (one unaligned load) ...
+    uint32_t v; __builtin_memcpy(&v, b.p + b.bytepos - 4, 4);
+    b.bytepos -= 4; b.acc = (b.acc << 32) | v; b.nacc += 32;
+  }
+  while (b.nacc < n && b.bytepos > 0) { b.bytepos--; b.acc = (b.acc << 8) | b.p[b.bytepos]; b.nacc += 8; }   // ... single bytes near the start
   if (b.nacc < n) { b.acc <<= (n - b.nacc); b.nacc = n; }       // past the start: zero bits
   const uint32_t v = (uint32_t)(b.acc >> (b.nacc - n)) & (n >= 32 ? 0xffffffffu : ((1u << n) - 1u));
   b.nacc -= n;

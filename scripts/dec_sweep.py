@@ -12,7 +12,7 @@ host = DATASETS[dname](csz)
 R = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libblosc_ref.so"))
 R.blosc_compress_ctx.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int]
 tmp = np.empty(csz + 16, np.uint8)
-r = R.blosc_compress_ctx(5, 1, int(os.environ.get("TYPESIZE", "8")), csz, host.ctypes.data, tmp.ctypes.data, csz + 16, os.environ.get("CODEC", "lz4").encode(), 0, 1)
+r = R.blosc_compress_ctx(int(os.environ.get("CLEVEL", "5")), 1, int(os.environ.get("TYPESIZE", "8")), csz, host.ctypes.data, tmp.ctypes.data, csz + 16, os.environ.get("CODEC", "lz4").encode(), 0, 1)
 dev = torch.device("cuda:0")
 comp = torch.empty((nchunks, csz + 256), dtype=torch.uint8, device=dev)
 comp[:, :r].copy_(torch.from_numpy(tmp[:r].copy()).to(dev).unsqueeze(0).expand(nchunks, r))
@@ -24,5 +24,5 @@ for _ in range(3): bd.decompress()
 lib.blosc_gpu_profile(0)
 assert bd.results() == [csz] * nchunks
 ok = bool((back[0] == torch.from_numpy(host).to(dev)).all())
-d = mod.profile_get("k_decode_streams"); u = mod.profile_get("k_unshuffle")
-print(f"DEC_LDS={os.environ.get('BLOSC_AMD_DEC_LDS','0'):>6s} data={dname} chunks={nchunks} ratio={csz/r:.1f}: k_decode_streams {d[0]/d[1]:8.3f} ms  k_unshuffle {u[0]/max(u[1],1):7.3f} ms  ok={ok}", flush=True)
+d = mod.profile_get("k_decode_streams"); u = mod.profile_get("k_unshuffle"); zz = mod.profile_get("k_zstd_streams")
+print(f"DEC_LDS={os.environ.get('BLOSC_AMD_DEC_LDS','0'):>6s} data={dname} chunks={nchunks} ratio={csz/r:.1f}: k_decode_streams {d[0]/d[1]:8.3f} ms  k_unshuffle {u[0]/max(u[1],1):7.3f} ms  k_zstd_streams {zz[0]/max(zz[1],1):8.3f} ms  ok={ok}", flush=True)
