@@ -49,6 +49,9 @@ __device__ bool zstd_block_wave(const uint8_t* b, int size, uint8_t* out, uint32
   const int ltype = (int)lane0_u32((uint32_t)lh.type), regen = (int)lane0_u32((uint32_t)lh.regen), csize = (int)lane0_u32((uint32_t)lh.csize);
   const int nstreams = (int)lane0_u32((uint32_t)lh.nstreams);
   int p = (int)lane0_u32((uint32_t)lh.hdr);
+  // every literal ends up in the output: more literals than output room left is corruption - and the literal
+  // scratch of this stream is only as large as its output
+  if ((uint32_t)regen > cap - op) return false;
   if (ltype == 0) {
     if (p + regen > size) return false;
     wave_copy_disjoint(as_global(lit), as_global(b + p), (uint32_t)regen, lane);
