@@ -38,6 +38,61 @@ __device__ __forceinline__ void wave_fill(gu8* dst, uint32_t v, uint32_t n, int 
   for (uint32_t k = (uint32_t)lane; k < n; k += 64u) dst[k] = (uint8_t)v;
 }
 
+// Executes the sequences seq[base .. base + m), m <= 16; lane r < m owns sequence r (the scheme of the LZ4
+// decoder's batched step, k_decode.hip): a DPP row scan gives every sequence its literal source and its output
+// position; every lane copies its own literals; matches whose source ends before this group's output are
+// independent of the group and are copied by their lanes at once; the others - long, or reading what this
+// group produces - follow in stream order through wave_match_copy.
+#ifndef BAMD_ZSTD_EXEC16
+#define BAMD_ZSTD_EXEC16 1
+#endif
+__device__ __forceinline__ bool zstd_exec16(const ZstdLds* L, int base, int m, uint8_t* out_, uint32_t cap, uint32_t& op,
+                                            const uint8_t* lit_, uint32_t& lp, uint32_t regen, int lane) {
+  gu8* out = as_global(out_); const gu8* lit = as_global(lit_);
+  const bool mine = lane < m;
+  const uint32_t ll = mine ? L->seq[3 * (base + lane)] : 0u, ml = mine ? L->seq[3 * (base + lane) + 1] : 0u;
+  const uint32_t off = mine ? L->seq[3 * (base + lane) + 2] : 1u;
+  const uint32_t tot = ll + ml;
+  uint32_t incl = tot, lincl = ll;                       // inclusive prefix sums over the 16 rank lanes (one DPP row)
+  incl += row_shr<1>(incl); incl += row_shr<2>(incl); incl += row_shr<4>(incl); incl += row_shr<8>(incl);
+  lincl += row_shr<1>(lincl); lincl += row_shr<2>(lincl); lincl += row_shr<4>(lincl); lincl += row_shr<8>(lincl);
+  const uint32_t excl = incl - tot, lexcl = lincl - ll;
+  const uint32_t total_out = (uint32_t)__builtin_amdgcn_readlane((int)incl, m - 1);
+  const uint32_t total_lit = (uint32_t)__builtin_amdgcn_readlane((int)lincl, m - 1);
+  if ((uint64_t)lp + total_lit > (uint64_t)regen || (uint64_t)op + total_out > (uint64_t)cap) return false;
+  if (__ballot(mine && (off == 0u || off > op + excl + ll))) return false;     // a source before the start of the output
+  uint32_t biglit = (uint32_t)__ballot(mine && ll > 256u) & 0xffffu;      // long runs: the whole wave copies them
+  while (biglit) {
+    const int sl = __builtin_ctz(biglit);
+    biglit &= biglit - 1u;
+    wave_copy_disjoint(out + op + (uint32_t)__builtin_amdgcn_readlane((int)excl, sl), lit + lp + (uint32_t)__builtin_amdgcn_readlane((int)lexcl, sl),
+                       (uint32_t)__builtin_amdgcn_readlane((int)ll, sl), lane);
+  }
+  if (mine && ll && ll <= 256u) {                         // literals: disjoint buffers, every lane its own run
+    const gu8* s = lit + lp + lexcl; gu8* d = out + op + excl;
+    uint32_t k = 0;
+    for (; k + 16u <= ll; k += 16u) g_st16(d + k, g_ld16(s + k));
+    for (; k < ll; k++) d[k] = s[k];
+  }
+  const bool indep = mine && ml <= 128u && off >= excl + tot;      // source ends at or before op: nothing of this group in it
+  if (indep) {
+    gu8* d = out + op + excl + ll; const gu8* s = d - off;          // off >= ml: source and destination do not overlap
+    uint32_t k = 0;
+    for (; k + 16u <= ml; k += 16u) g_st16(d + k, g_ld16(s + k));
+    for (; k < ml; k++) d[k] = s[k];
+  }
+  uint32_t rest = (uint32_t)__ballot(mine && !indep) & 0xffffu;
+  while (rest) {
+    const int sl = __builtin_ctz(rest);
+    rest &= rest - 1u;
+    const uint32_t mm = (uint32_t)__builtin_amdgcn_readlane((int)ml, sl), oo = (uint32_t)__builtin_amdgcn_readlane((int)off, sl);
+    const uint32_t pos = op + (uint32_t)__builtin_amdgcn_readlane((int)excl, sl) + (uint32_t)__builtin_amdgcn_readlane((int)ll, sl);
+    wave_match_copy(out, pos, oo, mm, lane);
+  }
+  op += total_out; lp += total_lit;
+  return true;
+}
+
 // one compressed block.  Returns true and advances op on success.  huf_valid / tabs state persist over the frame.
 __device__ bool zstd_block_wave(const uint8_t* b, int size, uint8_t* out, uint32_t cap, uint32_t& op, uint8_t* lit, ZstdLds* L,
                                 zd::Huf& huf, bool& huf_valid, zd::SeqTabs& tb, uint32_t* rep, int lane) {
@@ -126,6 +181,10 @@ __device__ bool zstd_block_wave(const uint8_t* b, int size, uint8_t* out, uint32
         if (fine && done + m == nseq && st.b.off != 0) fine = 0;   // the bit stream must be consumed exactly
       }
       if (!lane0_u32(fine)) return false;
+#if BAMD_ZSTD_EXEC16
+      for (int g = 0; g < m; g += 16)                          // wave-parallel execution, 16 sequences per group
+        if (!zstd_exec16(L, g, m - g < 16 ? m - g : 16, out, cap, op, lit, lp, (uint32_t)regen, lane)) return false;
+#else
       for (int i = 0; i < m; i++) {                            // wave-parallel execution, in order
         const uint32_t ll = uni(L->seq[3 * i]), ml = uni(L->seq[3 * i + 1]), off = uni(L->seq[3 * i + 2]);
         if ((uint64_t)lp + ll > (uint64_t)regen || (uint64_t)op + ll + ml > (uint64_t)cap || off > op + ll) return false;
@@ -133,6 +192,7 @@ __device__ bool zstd_block_wave(const uint8_t* b, int size, uint8_t* out, uint32
         wave_match_copy(as_global(out), op + ll, off, ml, lane);
         op += ll + ml; lp += ll;
       }
+#endif
     }
     if (lane == 0) { rep[0] = st.rep[0]; rep[1] = st.rep[1]; rep[2] = st.rep[2]; }
     rep[0] = lane0_u32(rep[0]); rep[1] = lane0_u32(rep[1]); rep[2] = lane0_u32(rep[2]);
