@@ -59,3 +59,44 @@ def test_fresh_reference_chunks(oracle, ref):
                 got = np.zeros(nitems * T, np.uint8)
                 assert oracle.orc_getitem(ptr(chunk), start, nitems, ptr(got)) == nitems * T
                 assert np.array_equal(got, data[start * T:(start + nitems) * T])
+
+
+def _direct_frames(ref):
+    """frames written by the reference's own ZSTD_compress (exported by oracle/_ref): sizes 1 .. 700 000 (several
+    blocks per frame), levels -5 .. 22, constant / random / low-entropy / text / random-walk / periodic data"""
+    import ctypes as C
+    ref.ZSTD_compress.restype = C.c_size_t
+    ref.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+    ref.ZSTD_compressBound.restype = C.c_size_t
+    ref.ZSTD_compressBound.argtypes = [C.c_size_t]
+    ref.ZSTD_isError.argtypes = [C.c_size_t]
+    rng = np.random.default_rng(0)
+
+    def gens(n):
+        yield np.full(n, 7, np.uint8)
+        yield rng.integers(0, 256, n, dtype=np.uint8)
+        yield rng.integers(0, 4, n, dtype=np.uint8)
+        yield np.frombuffer((b"the quick brown fox jumps over the lazy dog. " * (n // 44 + 1))[:n], np.uint8).copy()
+        yield np.cumsum(rng.integers(-2, 3, n // 4 + 1)).astype("<i4").view(np.uint8)[:n].copy()
+        p = np.tile(rng.integers(0, 256, 97, dtype=np.uint8), n // 97 + 1)[:n].copy(); p[::501] ^= 1
+        yield p
+
+    for n in [1, 2, 3, 5, 16, 63, 64, 255, 256, 257, 1000, 4096, 5000, 65536, 131072, 131073, 300000, 700000]:
+        for data in gens(n):
+            for lvl in (1, 3, 5, 9, 15, 19, 22, -5):
+                cap = ref.ZSTD_compressBound(n); buf = np.empty(cap, np.uint8)
+                r = ref.ZSTD_compress(ptr(buf), cap, ptr(data), n, lvl)
+                assert not ref.ZSTD_isError(r)
+                yield buf[:r].copy(), data
+
+
+def test_direct_reference_frames(oracle, ref):
+    import ctypes as C
+    oracle.orc_zstd_decompress.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    count = 0
+    for frame, data in _direct_frames(ref):
+        out = np.zeros(data.size, np.uint8)
+        assert oracle.orc_zstd_decompress(ptr(frame), frame.size, ptr(out), data.size) == data.size
+        assert np.array_equal(out, data)
+        count += 1
+    assert count == 864

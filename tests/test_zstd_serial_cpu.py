@@ -78,3 +78,12 @@ def test_serial_primitives_survive_corruption(zs, oracle):
             assert ra == rb, (ra, rb)
             if ra > 0:
                 assert np.array_equal(a[:ra], b[:rb])
+
+
+def test_serial_primitives_on_direct_reference_frames(zs, ref):
+    """the same 864 frames as tests/test_oracle_zstd.py::test_direct_reference_frames (only where oracle/_ref exists)"""
+    from test_oracle_zstd import _direct_frames
+    for frame, data in _direct_frames(ref):
+        out = np.zeros(data.size, np.uint8)
+        assert zs.zs_decompress(ptr(frame), frame.size, ptr(out), data.size) == data.size
+        assert np.array_equal(out, data)
