@@ -1,19 +1,28 @@
 #!/usr/bin/env python3
 """bench.py — the reference's headline benchmark (bench/bench.c "single" suite: compress then
-decompress a 64 MiB chunk of the synthetic bench19 generator, report MB/s and ratio) scaled to the
-MI355X configuration of BASELINE.json configs[1]:
+decompress 64 MiB chunks of a synthetic generator, report MB/s and ratio; protocol bench.c:250-320)
+scaled to the MI355X configurations of BASELINE.json / SURVEY.md §8d:
 
-    byte-shuffle + LZ4, clevel 5, typesize 8, 8 GiB synthetic (128 chunks x 64 MiB) on 1 x MI355X
+    --config 2   byte-shuffle + LZ4  clevel 5, typesize 8, bench19   (default; BASELINE.json configs[1])
+    --config 2b / 2c / 2d            same call on linspace / random-walk float64 / incompressible bytes
+    --config 3   bitshuffle + LZ4    clevel 5, typesize 4, bench19   (3b: arange, 3c: small random ints)
+    --config 4   byte-shuffle + Zstd clevel 3, typesize 8, bench19   (4b/4c/4d: the other float64 sets)
+    --config 1g  byte-shuffle + BloscLZ clevel 5, typesize 8, bench19 (config #1's call, on the GPU)
 
-One STEP = one compress pass + one decompress pass over the whole batch, all buffers resident in
+every one as 128 chunks x 64 MiB = 8 GiB per GPU (512 chunks = 32 GiB per GPU when N > 1: config #5).
+
+One STEP = one compress pass + one decompress pass over the rank's chunks, all buffers resident in
 HBM, through the C ABI of libblosc_amd (blosc_gpu_compress_batch / blosc_gpu_decompress_batch).
-`value` = uncompressed bytes taken through that round trip per second, summed over all GPUs
-(weak scaling: every rank owns its own 8 GiB; chunks are independent, no data-path collective).
-Per-direction rates, per-kernel HIP-event times, the roofline of the dominant kernel, the
-whole-direction roofline fractions ((nbytes + cbytes) / t / 8 TB/s) and the
-reference's own multi-threaded CPU path on this box's host cores are reported in the same line.
+`value` = uncompressed bytes taken through that round trip per second, summed over all GPUs.
+Multi-GPU: ONE logical list of `chunks_per_gpu x N` chunks is partitioned into contiguous
+ranges (c-blosc_amd/multigpu.py: chunk_range); chunks are independent, so there is no data-path
+collective - the only exchange is the all_gather of the per-chunk cbytes table over RCCL
+(gather_cbytes, backend "nccl", also with a communicator of size 1), timed separately as
+`consolidation_ms`.  The JSON line also carries per-direction rates, per-kernel HIP-event times, the
+roofline of the dominant kernel, decompression of chunks written by the reference itself (the drop-in
+direction) and the reference's own multi-threaded CPU path on this box's host cores.
 
-Run:  python bench.py [--gpus N --steps K --warmup W]          (N>1: under torch.distributed.run)
+Run:  python bench.py [--config C --gpus N --steps K --warmup W]      (N>1: under torch.distributed.run)
 """
 import argparse
 import ctypes as C
@@ -21,6 +30,8 @@ import importlib.util
 import json
 import os
 import sys
+import tempfile
+import threading
 import time
 
 import numpy as np
@@ -28,10 +39,28 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (6.29 TB/s measured copy)
-KERNELS = ["k_shuffle", "k_bitshuffle", "k_encode_streams", "k_chunk_scan", "k_chunk_compact",
-           "k_decode_plan", "k_decode_streams", "k_unshuffle", "k_bitunshuffle", "k_copy_chunks"]
-COMPRESS_KERNELS = KERNELS[:5]
-DECOMPRESS_KERNELS = KERNELS[5:]
+COMPRESS_KERNELS = ["k_shuffle", "k_bitshuffle", "k_encode_streams", "k_zstd_encode", "k_chunk_scan", "k_chunk_compact"]
+DECOMPRESS_KERNELS = ["k_decode_plan", "k_decode_streams", "k_decode_blocks", "k_zstd_streams", "k_unshuffle",
+                      "k_bitunshuffle", "k_copy_chunks"]
+KERNELS = COMPRESS_KERNELS + DECOMPRESS_KERNELS
+REFSO = os.path.join(ROOT, "oracle", "_ref", "libblosc_ref.so")
+
+# SURVEY.md §8d "Concrete inputs"
+CONFIGS = {
+    "2":  dict(codec="lz4", shuffle=1, typesize=8, clevel=5, data="bench19"),
+    "2b": dict(codec="lz4", shuffle=1, typesize=8, clevel=5, data="linspace"),
+    "2c": dict(codec="lz4", shuffle=1, typesize=8, clevel=5, data="randwalk"),
+    "2d": dict(codec="lz4", shuffle=1, typesize=8, clevel=5, data="random"),
+    "3":  dict(codec="lz4", shuffle=2, typesize=4, clevel=5, data="bench19"),
+    "3b": dict(codec="lz4", shuffle=2, typesize=4, clevel=5, data="arange"),
+    "3c": dict(codec="lz4", shuffle=2, typesize=4, clevel=5, data="smallints"),
+    "4":  dict(codec="zstd", shuffle=1, typesize=8, clevel=3, data="bench19"),
+    "4b": dict(codec="zstd", shuffle=1, typesize=8, clevel=3, data="linspace"),
+    "4c": dict(codec="zstd", shuffle=1, typesize=8, clevel=3, data="randwalk"),
+    "4d": dict(codec="zstd", shuffle=1, typesize=8, clevel=3, data="random"),
+    "1g": dict(codec="blosclz", shuffle=1, typesize=8, clevel=5, data="bench19"),
+}
+FILTER_NAME = {0: "no filter", 1: "byte-shuffle", 2: "bitshuffle"}
 
 
 def load_pkg():
@@ -47,75 +76,159 @@ def make_chunk(kind, nbytes):
     return DATASETS[kind](nbytes)
 
 
-def measured_traffic(kernel, args):
+def measured_traffic(kernel, config_name, nchunks, chunk_mib):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of THIS workload
-    (profiles/r01_final_traffic.json, made by scripts/final_profile.sh + scripts/make_traffic_json.py:
+    (profiles/r02_traffic_cfg<config>.json, made by scripts/profile_config.sh + scripts/make_traffic_json.py:
     FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 corrections applied).  PMC counters cannot be
-    read from inside a timed run, so other workloads than the default one report null."""
-    default = (args.chunks == 128 and args.chunk_mib == 64 and args.typesize == 8 and args.clevel == 5 and
-               args.shuffle == 1 and args.codec == "lz4" and args.data == "bench19")
-    path = os.path.join(ROOT, "profiles", "r01_final_traffic.json")
-    if not default or not os.path.exists(path):
+    read from inside a timed run, so a workload without a committed pass reports null."""
+    if nchunks != 128 or chunk_mib != 64:
         return None
-    with open(path) as fh:
-        k = json.load(fh)["kernels"].get(kernel)
-    return k["hbm_bytes"] if k else None
+    for rnd in ("r02",):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_traffic_cfg{config_name}.json")
+        if os.path.exists(path):
+            with open(path) as fh:
+                k = json.load(fh)["kernels"].get(kernel)
+            return k["hbm_bytes"] if k else None
+    return None
 
 
-def cpu_baseline(chunk_host, typesize, clevel, shuffle, cname, budget_passes):
-    """The reference's own SSE2/AVX2 multi-threaded path (oracle/_ref/libblosc_ref.so, built from the
-    reference sources) on this box's host cores; falls back to the single-threaded oracle port."""
+# ---------------------------------------------------------------------------------------------
+# CPU baseline: the reference itself (oracle/_ref, built from /root/reference's sources) on this box's cores
+# ---------------------------------------------------------------------------------------------
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _capture_stdout(fn):
+    """Runs fn() with file descriptor 1 redirected to a temp file (the reference prints its shuffle
+    implementation with printf when BLOSC_PRINT_SHUFFLE_ACCEL is set, shuffle.c:258-273)."""
+    libc = C.CDLL(None)
+    sys.stdout.flush()
+    saved = os.dup(1)
+    with tempfile.TemporaryFile() as tf:
+        os.dup2(tf.fileno(), 1)
+        try:
+            fn()
+            libc.fflush(None)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+        tf.seek(0)
+        return tf.read().decode(errors="replace").strip()
+
+
+def cpu_baseline(chunk_host, typesize, clevel, shuffle, cname, budget_s=20.0):
+    """SURVEY §8d / BASELINE.md §4: nthreads = 1, a sweep up to nproc (cap 256, blosc.h:51) and — because one
+    64 MiB chunk has only 64-128 blocks for the pool to share — `P` independent blosc_compress_ctx /
+    blosc_decompress_ctx calls running in parallel on P chunks (the chunk-parallel use the GPU batch mirrors).
+    `value` is the best round-trip rate found; every arm is listed."""
     n = chunk_host.size
-    refso = os.path.join(ROOT, "oracle", "_ref", "libblosc_ref.so")
     ncores = os.cpu_count() or 1
-    out = {}
-    if os.path.exists(refso):
-        R = C.CDLL(refso)
-        R.blosc_compress.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
-        R.blosc_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
-        R.blosc_init()
-        nth = min(ncores, 256)
-        R.blosc_set_nthreads(nth)
-        R.blosc_set_compressor(cname)
-        dests = [np.empty(n + 16, np.uint8) for _ in range(4)]     # bench.c uses several destination chunks
-        back = np.empty(n, np.uint8)
-        cb = R.blosc_compress(clevel, shuffle, typesize, n, chunk_host.ctypes.data, dests[0].ctypes.data, n + 16)  # warm-up
-        R.blosc_decompress(dests[0].ctypes.data, back.ctypes.data, n)
-        t0 = time.perf_counter()
-        for i in range(budget_passes):
-            cb = R.blosc_compress(clevel, shuffle, typesize, n, chunk_host.ctypes.data, dests[i % 4].ctypes.data, n + 16)
-        t1 = time.perf_counter()
-        for i in range(4):
-            R.blosc_compress(clevel, shuffle, typesize, n, chunk_host.ctypes.data, dests[i].ctypes.data, n + 16)
-        t2 = time.perf_counter()
-        for i in range(budget_passes):
-            R.blosc_decompress(dests[i % 4].ctypes.data, back.ctypes.data, n)
-        t3 = time.perf_counter()
-        assert np.array_equal(back, chunk_host)
-        tc, td = (t1 - t0) / budget_passes, (t3 - t2) / budget_passes
-        out = {"value": n / (tc + td) / 1e9, "unit": "GB/s", "cores": nth, "kind": "reference",
-               "compress_GBps": n / tc / 1e9, "decompress_GBps": n / td / 1e9, "ratio": n / cb,
-               "sample": f"{budget_passes} passes of one {n >> 20} MiB chunk each way through blosc_compress/"
-                         f"blosc_decompress of the reference built from its own sources, nthreads={nth}"}
-        R.blosc_destroy()
-    else:
+    info = {"nproc": ncores, "cpu_model": _cpu_model()}
+    if not os.path.exists(REFSO):
         from helpers import orc_compress, orc_decompress
         O = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
         O.orc_compress.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_int]
         O.orc_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
-        passes = max(1, budget_passes // 32)
         t0 = time.perf_counter()
-        for _ in range(passes):
-            r, ch = orc_compress(O, chunk_host, typesize, clevel, shuffle, cname.decode())
+        r, ch = orc_compress(O, chunk_host, typesize, clevel, shuffle, cname.decode())
         t1 = time.perf_counter()
-        for _ in range(passes):
-            orc_decompress(O, ch, n)
+        orc_decompress(O, ch, n)
         t2 = time.perf_counter()
-        tc, td = (t1 - t0) / passes, (t2 - t1) / passes
-        out = {"value": n / (tc + td) / 1e9, "unit": "GB/s", "cores": 1, "kind": "port",
-               "compress_GBps": n / tc / 1e9, "decompress_GBps": n / td / 1e9, "ratio": n / r,
-               "sample": f"{passes} passes of one {n >> 20} MiB chunk through the scalar oracle port"}
-    return out
+        tc, td = t1 - t0, t2 - t1
+        return {"value": n / (tc + td) / 1e9, "unit": "GB/s", "cores": 1, "kind": "port",
+                "compress_GBps": n / tc / 1e9, "decompress_GBps": n / td / 1e9, "ratio": n / r, **info,
+                "sample": f"one pass of one {n >> 20} MiB chunk through the scalar oracle port"}
+    os.environ["BLOSC_PRINT_SHUFFLE_ACCEL"] = "1"
+    R = C.CDLL(REFSO)
+    sz, i, vp = C.c_size_t, C.c_int, C.c_void_p
+    R.blosc_compress_ctx.argtypes = [i, i, sz, sz, vp, vp, sz, C.c_char_p, sz, i]
+    R.blosc_decompress_ctx.argtypes = [vp, vp, sz, i]
+    dests = [np.empty(n + 16, np.uint8) for _ in range(4)]     # bench.c uses several destination chunks
+    back = np.empty(n, np.uint8)
+    cb = [0]
+
+    def one_c(k, nth):
+        cb[0] = R.blosc_compress_ctx(clevel, shuffle, typesize, n, chunk_host.ctypes.data, dests[k % 4].ctypes.data, n + 16, cname, 0, nth)
+
+    def one_d(k, nth):
+        r = R.blosc_decompress_ctx(dests[k % 4].ctypes.data, back.ctypes.data, n, nth)
+        assert r == n
+
+    info["shuffle_accel"] = _capture_stdout(lambda: one_c(0, 1))
+    os.environ.pop("BLOSC_PRINT_SHUFFLE_ACCEL", None)
+    for k in range(4):
+        one_c(k, 1)
+    one_d(0, 1)
+    assert np.array_equal(back, chunk_host)
+    ratio = n / cb[0]
+    arms = []
+    sweep = sorted({t for t in (1, 2, 4, 8, 16, 32, 64, 128, 256) if t <= ncores} | {min(ncores, 256)})
+    per_arm = budget_s / (2 * (len(sweep) + 1))
+
+    def timed(fn, nth):
+        fn(0, nth)
+        cnt, t0 = 0, time.perf_counter()
+        best = 1e9
+        while True:
+            ta = time.perf_counter()
+            fn(cnt, nth)
+            best = min(best, time.perf_counter() - ta)
+            cnt += 1
+            if cnt >= 3 and (time.perf_counter() - t0 > per_arm or cnt >= 200):
+                break
+        return best, (time.perf_counter() - t0) / cnt, cnt
+
+    for nth in sweep:
+        bc_, mc, kc = timed(one_c, nth)
+        bd_, md, kd = timed(one_d, nth)
+        arms.append({"mode": "one chunk, internal threads", "threads": nth, "compress_GBps": n / mc / 1e9, "decompress_GBps": n / md / 1e9,
+                     "roundtrip_GBps": n / (mc + md) / 1e9, "compress_best_GBps": n / bc_ / 1e9, "decompress_best_GBps": n / bd_ / 1e9,
+                     "passes": [kc, kd]})
+    # chunk-parallel arm: P threads, one chunk each, nthreads = 1 inside (ctypes releases the GIL)
+    P = min(ncores, 64)
+    pd = [np.empty(n + 16, np.uint8) for _ in range(P)]
+    pb = [np.empty(n, np.uint8) for _ in range(P)]
+    reps = 4
+
+    def par(fn):
+        ths = [threading.Thread(target=fn, args=(k,)) for k in range(P)]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        return time.perf_counter() - t0
+
+    def pc_(k):
+        for _ in range(reps):
+            R.blosc_compress_ctx(clevel, shuffle, typesize, n, chunk_host.ctypes.data, pd[k].ctypes.data, n + 16, cname, 0, 1)
+
+    def pd_(k):
+        for _ in range(reps):
+            R.blosc_decompress_ctx(pd[k].ctypes.data, pb[k].ctypes.data, n, 1)
+
+    par(pc_)
+    tc = par(pc_) / reps
+    td = par(pd_) / reps
+    assert np.array_equal(pb[P - 1], chunk_host)
+    arms.append({"mode": f"{P} chunks in parallel, 1 thread each (_ctx calls)", "threads": P, "compress_GBps": P * n / tc / 1e9,
+                 "decompress_GBps": P * n / td / 1e9, "roundtrip_GBps": P * n / (tc + td) / 1e9, "passes": [reps, reps]})
+    best = max(arms, key=lambda a: a["roundtrip_GBps"])
+    one = arms[0]
+    return {"value": best["roundtrip_GBps"], "unit": "GB/s", "cores": best["threads"], "kind": "reference",
+            "compress_GBps": best["compress_GBps"], "decompress_GBps": best["decompress_GBps"], "ratio": ratio,
+            "best_arm": best["mode"], "nthreads1": {k: one[k] for k in ("compress_GBps", "decompress_GBps", "roundtrip_GBps")},
+            "arms": arms, **info,
+            "sample": f"{n >> 20} MiB chunk(s) of the same data through blosc_compress_ctx/blosc_decompress_ctx of the reference built "
+                      f"from its own sources; mean over >= 3 passes per arm, about {budget_s:.0f} s in total"}
 
 
 def main():
@@ -123,36 +236,56 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--chunks", type=int, default=128, help="chunks per GPU")
+    ap.add_argument("--config", default="2", choices=sorted(CONFIGS))
+    ap.add_argument("--chunks", type=int, default=0, help="chunks per GPU (default 128; 512 when N > 1 = config #5's share)")
     ap.add_argument("--chunk-mib", type=int, default=64)
-    ap.add_argument("--typesize", type=int, default=8)
-    ap.add_argument("--clevel", type=int, default=5)
-    ap.add_argument("--shuffle", type=int, default=1)
-    ap.add_argument("--codec", default="lz4")
-    ap.add_argument("--data", default="bench19")
-    ap.add_argument("--cpu-passes", type=int, default=192)
+    ap.add_argument("--typesize", type=int, default=None)
+    ap.add_argument("--clevel", type=int, default=None)
+    ap.add_argument("--shuffle", type=int, default=None)
+    ap.add_argument("--codec", default=None)
+    ap.add_argument("--data", default=None)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-stock", action="store_true", help="skip the decompression of reference-written chunks")
     args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    for k in ("typesize", "clevel", "shuffle", "codec", "data"):
+        if getattr(args, k) is not None:
+            cfg[k] = getattr(args, k)
+    overridden = any(getattr(args, k) is not None for k in ("typesize", "clevel", "shuffle", "codec", "data"))
 
     import torch
+    import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
+    # RCCL communicator also at N = 1 (size 1): the code path is the same for every N
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        rdv = tempfile.NamedTemporaryFile(prefix="bamd_rdv_", delete=False)
+        rdv.close()
+        os.unlink(rdv.name)
+        dist.init_process_group("nccl", init_method=f"file://{rdv.name}", rank=0, world_size=1, device_id=dev)
     mod = load_pkg()
     lib = mod.load()
+    mspec = importlib.util.spec_from_file_location("c_blosc_amd_multigpu", os.path.join(ROOT, "c-blosc_amd", "multigpu.py"))
+    multigpu = importlib.util.module_from_spec(mspec)
+    mspec.loader.exec_module(multigpu)
     assert lib.blosc_gpu_set_device(local) == 0
-    cname = args.codec.encode()
+    cname = cfg["codec"].encode()
+    T, clevel, shuffle = cfg["typesize"], cfg["clevel"], cfg["shuffle"]
+    gpu_can_encode = lib.blosc_compname_to_compcode(cname) >= 0
 
-    nchunks, csz = args.chunks, args.chunk_mib << 20
+    per_gpu = args.chunks or (128 if world == 1 else 512)
+    nchunks_total = per_gpu * world
+    lo, hi = multigpu.chunk_range(nchunks_total, world, rank)
+    nchunks, csz = hi - lo, args.chunk_mib << 20
     total = nchunks * csz
-    host_chunk = make_chunk(args.data, csz)
+    host_chunk = make_chunk(cfg["data"], csz)
     d_chunk = torch.from_numpy(host_chunk).to(dev)
     # distinct buffers per chunk (identical content, like bench.c's "i from 0 per chunk"): real HBM traffic
     src = torch.empty((nchunks, csz), dtype=torch.uint8, device=dev)
@@ -167,19 +300,38 @@ def main():
     bd = mod.DeviceBatch([comp[i].data_ptr() for i in range(nchunks)], [csz + 16] * nchunks,
                          [back[i].data_ptr() for i in range(nchunks)], [csz] * nchunks)
 
+    # the reference's own chunk of this data (drop-in direction; the only source of chunks for a codec the GPU
+    # cannot encode yet)
+    ref_chunk = None
+    if os.path.exists(REFSO) and not (args.no_stock and gpu_can_encode):
+        R = C.CDLL(REFSO)
+        R.blosc_compress_ctx.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int]
+        tmp = np.empty(csz + 16, np.uint8)
+        r = R.blosc_compress_ctx(clevel, shuffle, T, csz, host_chunk.ctypes.data, tmp.ctypes.data, csz + 16, cname, 0, min(os.cpu_count() or 1, 16))
+        if r > 0:
+            ref_chunk = tmp[:r].copy()
+
+    def load_stock_chunks():
+        comp[:, :ref_chunk.size].copy_(torch.from_numpy(ref_chunk).to(dev).unsqueeze(0).expand(nchunks, ref_chunk.size))
+
+    decode_only = not gpu_can_encode
+    if decode_only:
+        assert ref_chunk is not None, f"the GPU cannot encode '{cfg['codec']}' and oracle/_ref is not built: nothing to decode"
+        load_stock_chunks()
+
     def step():
-        assert bc.compress(args.typesize, args.clevel, args.shuffle, cname, 0, stream) == 0
+        if not decode_only:
+            assert bc.compress(T, clevel, shuffle, cname, 0, stream) == 0
         assert bd.decompress(stream) == 0
 
     def sync_all():
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
-    cbytes = bc.results()
+    cbytes = [ref_chunk.size] * nchunks if decode_only else bc.results()
     assert all(c > 0 for c in cbytes), cbytes[:4]
     assert bd.results() == [csz] * nchunks, bd.results()[:4]
 
@@ -192,10 +344,18 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     lib.blosc_gpu_profile(0)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    # ---- consolidation: every rank learns the global cbytes table (RCCL all_gather, 4 bytes per chunk) ----
+    torch.cuda.synchronize()
+    tg = time.perf_counter()
+    table, offsets = multigpu.gather_cbytes(cbytes, nchunks_total, device=dev)
+    torch.cuda.synchronize()
+    consolidation_ms = (time.perf_counter() - tg) * 1e3
+    assert len(table) == nchunks_total and table[lo:hi] == list(cbytes)
+    sum_cb_global = float(sum(table))
 
     prof = {}
     for k in KERNELS:
@@ -210,66 +370,60 @@ def main():
     verified = None
     if not args.no_verify:
         ok = bool(torch.equal(back, src))
-        ch0 = comp[0][:cbytes[0]].cpu().numpy()
-        refso = os.path.join(ROOT, "oracle", "_ref", "libblosc_ref.so")
-        chk = np.empty(csz, np.uint8)
-        if os.path.exists(refso):
-            R = C.CDLL(refso)
-            R.blosc_decompress_ctx.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-            r = R.blosc_decompress_ctx(ch0.ctypes.data, chk.ctypes.data, csz, 4)
-            who = "stock c-blosc (oracle/_ref)"
-        else:
-            O = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
-            O.orc_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
-            r = O.orc_decompress(ch0.ctypes.data, chk.ctypes.data, csz)
-            who = "oracle"
-        ok = ok and r == csz and np.array_equal(chk, host_chunk)
+        who = None
+        if not decode_only:
+            ch0 = comp[0][:cbytes[0]].cpu().numpy()
+            chk = np.empty(csz, np.uint8)
+            if os.path.exists(REFSO):
+                R = C.CDLL(REFSO)
+                R.blosc_decompress_ctx.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+                r = R.blosc_decompress_ctx(ch0.ctypes.data, chk.ctypes.data, csz, 4)
+                who = "stock c-blosc (oracle/_ref)"
+            else:
+                O = C.CDLL(os.path.join(ROOT, "oracle", "liboracle.so"))
+                O.orc_decompress.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+                r = O.orc_decompress(ch0.ctypes.data, chk.ctypes.data, csz)
+                who = "oracle"
+            ok = ok and r == csz and np.array_equal(chk, host_chunk)
         verified = {"roundtrip_bit_exact": ok, "gpu_chunk_decoded_by": who}
         assert ok, "verification failed"
 
     # ---- decompress of chunks written by the reference itself (drop-in direction) ----
     stock = None
-    if rank == 0 or True:
-        refso = os.path.join(ROOT, "oracle", "_ref", "libblosc_ref.so")
-        ref_chunk = None
-        if os.path.exists(refso):
-            R = C.CDLL(refso)
-            R.blosc_compress_ctx.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int]
-            tmp = np.empty(csz + 16, np.uint8)
-            r = R.blosc_compress_ctx(args.clevel, args.shuffle, args.typesize, csz, host_chunk.ctypes.data, tmp.ctypes.data, csz + 16, cname, 0, 1)
-            if r > 0:
-                ref_chunk = tmp[:r].copy()
-        if ref_chunk is not None:
-            comp[:, :ref_chunk.size].copy_(torch.from_numpy(ref_chunk).to(dev).unsqueeze(0).expand(nchunks, ref_chunk.size))
-            back.zero_()
-            assert bd.decompress(stream) == 0     # warm
-            lib.blosc_gpu_profile(1); lib.blosc_gpu_profile_reset()
-            torch.cuda.synchronize(); ts = time.perf_counter()
-            for _ in range(max(2, args.steps)):
-                assert bd.decompress(stream) == 0
-            torch.cuda.synchronize(); te = time.perf_counter()
-            lib.blosc_gpu_profile(0)
-            assert bd.results() == [csz] * nchunks
-            assert torch.equal(back, src)
-            tk = sum(mod.profile_get(k)[0] / max(mod.profile_get(k)[1], 1) for k in DECOMPRESS_KERNELS) / 1e3
-            wall = (te - ts) / max(2, args.steps)
-            stock = {"GBps_wall": total / wall / 1e9, "GBps_kernels": total / tk / 1e9, "ratio": csz / ref_chunk.size,
-                     "roofline_frac": (total + nchunks * ref_chunk.size) / tk / 1e9 / HBM_PEAK_GBPS,
-                     "k_decode_streams_ms": mod.profile_get("k_decode_streams")[0] / max(mod.profile_get("k_decode_streams")[1], 1),
-                     "k_unshuffle_ms": mod.profile_get("k_unshuffle")[0] / max(mod.profile_get("k_unshuffle")[1], 1)}
+    if ref_chunk is not None and not args.no_stock:
+        if not decode_only:
+            load_stock_chunks()
+        back.zero_()
+        assert bd.decompress(stream) == 0     # warm
+        lib.blosc_gpu_profile(1); lib.blosc_gpu_profile_reset()
+        torch.cuda.synchronize(); ts = time.perf_counter()
+        reps = max(2, args.steps)
+        for _ in range(reps):
+            assert bd.decompress(stream) == 0
+        torch.cuda.synchronize(); te = time.perf_counter()
+        lib.blosc_gpu_profile(0)
+        assert bd.results() == [csz] * nchunks
+        assert torch.equal(back, src)
+        kms = {k: mod.profile_get(k)[0] / max(mod.profile_get(k)[1], 1) for k in DECOMPRESS_KERNELS if mod.profile_get(k)[1]}
+        tk = sum(kms.values()) / 1e3
+        wall = (te - ts) / reps
+        stock = {"GBps_wall": total / wall / 1e9, "GBps_kernels": total / tk / 1e9, "ratio": csz / ref_chunk.size,
+                 "roofline_frac": (total + nchunks * ref_chunk.size) / tk / 1e9 / HBM_PEAK_GBPS, "kernels_ms": kms}
 
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     # ---- roofline of the dominant kernel ----
     dom = max(prof, key=lambda k: prof[k]["ms_avg"])
-    alg_bytes = total + sum_cb                      # nbytes + cbytes per chunk, x chunks per launch
+    filt_only = dom in ("k_shuffle", "k_unshuffle", "k_bitshuffle", "k_bitunshuffle")
+    # nbytes + cbytes per chunk for a codec (or fused) kernel, 2 x nbytes for a filter-only kernel
+    alg_bytes = 2.0 * total if filt_only else total + sum_cb
     ach = alg_bytes / (prof[dom]["ms_avg"] / 1e3) / 1e9
     roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": ach / HBM_PEAK_GBPS, "traffic": measured_traffic(dom, args),
+            "frac": ach / HBM_PEAK_GBPS, "traffic": None if overridden else measured_traffic(dom, args.config, nchunks, args.chunk_mib),
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": prof[dom]["ms_avg"]}
+    what = "decompress pass of reference-written chunks (the GPU does not encode this codec)" if decode_only else "compress pass + decompress pass"
     out = {
         "metric": "compress+decompress GB/s (uncompressed) at 1/2/4/8 GPUs vs HBM roofline; ratio",
         "value": world * args.steps * total / elapsed / 1e9,
@@ -278,24 +432,28 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
-        "config": {"workload": f"byte-shuffle + {args.codec} clevel={args.clevel} typesize={args.typesize}, "
-                               f"{nchunks} x {args.chunk_mib} MiB {args.data} chunks per GPU ({total / 2**30:.0f} GiB), "
-                               "step = compress pass + decompress pass, device-resident",
-                   "codec": args.codec, "shuffle": args.shuffle, "typesize": args.typesize, "clevel": args.clevel,
-                   "chunks_per_gpu": nchunks, "chunk_bytes": csz, "dataset": args.data},
-        "ratio": total / sum_cb,
-        "compress": {"GBps_kernels": total / t_c / 1e9, "roofline_frac_path": (total + sum_cb) / t_c / 1e9 / HBM_PEAK_GBPS},
+        "config": {"workload": f"config #{args.config}: {FILTER_NAME[shuffle]} + {cfg['codec']} clevel={clevel} typesize={T}, "
+                               f"{nchunks} x {args.chunk_mib} MiB {cfg['data']} chunks per GPU ({total / 2**30:.0f} GiB), "
+                               f"step = {what}, device-resident",
+                   "name": args.config, "codec": cfg["codec"], "shuffle": shuffle, "typesize": T, "clevel": clevel,
+                   "chunks_per_gpu": nchunks, "chunks_total": nchunks_total, "chunk_bytes": csz, "dataset": cfg["data"],
+                   "direction": "decompress" if decode_only else "compress+decompress"},
+        "ratio": nchunks_total * csz / sum_cb_global,
         "decompress": {"GBps_kernels": total / t_d / 1e9, "roofline_frac_path": (total + sum_cb) / t_d / 1e9 / HBM_PEAK_GBPS},
         "decompress_stock_chunks": stock,
+        "multi_gpu": {"partition": "contiguous chunk ranges, no data-path collective", "consolidation": "all_gather of the cbytes table, backend nccl (RCCL)",
+                      "consolidation_ms": consolidation_ms, "world": world,
+                      "note": None if world > 1 else "communicator of size 1: no N > 1 line exists until the driver has a multi-GPU node"},
         "kernels": prof,
         "roofline": roof,
         "verified": verified,
     }
+    if not decode_only:
+        out["compress"] = {"GBps_kernels": total / t_c / 1e9, "roofline_frac_path": (total + sum_cb) / t_c / 1e9 / HBM_PEAK_GBPS}
     if not args.no_cpu_baseline and world == 1:      # the host-core baseline is a 1-GPU artefact (rank 0, N = 1)
-        out["cpu_baseline"] = cpu_baseline(host_chunk, args.typesize, args.clevel, args.shuffle, cname, args.cpu_passes)
+        out["cpu_baseline"] = cpu_baseline(host_chunk, T, clevel, shuffle, cname, args.cpu_seconds)
     print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

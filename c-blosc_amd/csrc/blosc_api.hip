@@ -288,6 +288,16 @@ __attribute__((visibility("default"))) void blosc_internal_unshuffle(const size_
                                                                      const uint8_t* src, const uint8_t* dest) {
   if (engine_filter(1, typesize, blocksize, src, (void*)dest) != 0) fprintf(stderr, "blosc_amd: unshuffle failed (no GPU?)\n");
 }
+// the "generic" entry points the reference's tests/test_shuffle_roundtrip_generic.c links (blosc/shuffle-generic.h:86-93):
+// same byte transposition, there is only one implementation here
+__attribute__((visibility("default"))) void blosc_internal_shuffle_generic(const size_t typesize, const size_t blocksize,
+                                                                           const uint8_t* const src, uint8_t* const dest) {
+  blosc_internal_shuffle(typesize, blocksize, src, dest);
+}
+__attribute__((visibility("default"))) void blosc_internal_unshuffle_generic(const size_t typesize, const size_t blocksize,
+                                                                             const uint8_t* const src, uint8_t* const dest) {
+  blosc_internal_unshuffle(typesize, blocksize, src, dest);
+}
 __attribute__((visibility("default"))) int blosc_internal_bitshuffle(const size_t typesize, const size_t blocksize,
                                                                      const uint8_t* src, const uint8_t* dest,
                                                                      const uint8_t* tmp) {

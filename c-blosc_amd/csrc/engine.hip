@@ -1,6 +1,7 @@
 // engine.hip — host engine implementation (see engine.h).  Compiled together with the kernels.
 #include "engine.h"
 
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -66,6 +67,16 @@ struct PinnedArena {
 
 struct ProfEntry { double ms = 0; int launches = 0; };
 
+// per-launch feedback words of the persistent kernels: [0,256) cycles per plane index, [256] tasks taken by the
+// stream kernel, [257] streams taken by the Zstd kernel - the host compares both with what it queued
+constexpr size_t kCostWords = 264;
+static int check_done(const uint32_t* fb, size_t expect, size_t expect_zstd, const char* what) {
+  if (fb[256] == expect && fb[257] == expect_zstd) return 0;
+  fprintf(stderr, "blosc_amd: %s: the device took %u of %zu queued tasks (Zstd: %u of %zu) - results discarded\n",
+          what, fb[256], expect, fb[257], expect_zstd);
+  return -1;
+}
+
 struct EngineState {
   std::mutex mu;
   bool device_ok = false;
@@ -88,6 +99,7 @@ struct EngineState {
   // so per-XCD queues and in-kernel hand-offs through one XCD's L2 are valid.  true: anything else (probe below,
   // or BLOSC_AMD_SINGLE_QUEUE=1) - one queue, shuffle / unshuffle in kernels of their own.
   bool single_queue = false;
+  int cus = 0;          // compute units of the selected device (persistent grids)
 };
 static EngineState& S() { static EngineState s; return s; }
 
@@ -112,8 +124,25 @@ static void probe_topology(EngineState& st) {
   }
 }
 
+// fork(): the reference re-creates its thread pool in the child (blosc/blosc.c:2210-2221 blosc_atfork_child).  A HIP
+// context does not survive fork(), so there is nothing to re-create here: the child is marked and every compute call
+// in it fails loudly (-1) instead of touching the parent's device state.  prepare/parent keep the engine mutex
+// consistent across the fork (a forking thread never inherits it locked by somebody else).
+static bool g_forked = false;
+static void atfork_prepare() { S().mu.lock(); }
+static void atfork_parent() { S().mu.unlock(); }
+static void atfork_child() { S().mu.unlock(); g_forked = true; }
+
 static int ensure_device(EngineState& st) {
-  if (st.device_ok) return 0;
+  if (g_forked) {
+    fprintf(stderr, "blosc_amd: this process was forked after the library had initialised its HIP device; a device context does not survive fork() - call exec() or use the library only in the parent\n");
+    return -1;
+  }
+  static bool atfork_set = false;
+  if (!atfork_set) { atfork_set = true; (void)pthread_atfork(atfork_prepare, atfork_parent, atfork_child); }
+  // the HIP current device is per host thread: every entry point (they all come through here, under the
+  // engine lock) re-selects the engine's device for the calling thread
+  if (st.device_ok) { HIP_TRY(hipSetDevice(st.device)); return 0; }
   int cnt = 0;
   hipError_t e = hipGetDeviceCount(&cnt);
   if (e != hipSuccess || cnt <= 0) {
@@ -127,6 +156,9 @@ static int ensure_device(EngineState& st) {
   if (st.device >= 0) HIP_TRY(hipSetDevice(st.device));
   else HIP_TRY(hipGetDevice(&st.device));
   probe_topology(st);
+  hipDeviceProp_t pr;
+  st.cus = (hipGetDeviceProperties(&pr, st.device) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+  st.enc_cost_valid = st.dec_cost_valid = false;
   st.device_ok = true;
   return 0;
 }
@@ -169,8 +201,7 @@ struct Carver {
 
 // grid of a persistent one-wave-per-workgroup kernel: as many waves as the device keeps resident
 static unsigned persistent_grid(size_t nitems, int waves_per_cu) {
-  static int cus = 0;
-  if (!cus) { hipDeviceProp_t pr; int dev = 0; (void)hipGetDevice(&dev); if (hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount; if (cus <= 0) cus = 256; }
+  const int cus = S().cus > 0 ? S().cus : 256;
   size_t g = (size_t)cus * (size_t)waves_per_cu;
   if (nitems < g) g = nitems;
   // workgroups are dealt round-robin to the 8 XCDs and every XCD serves only its own queue: never fewer than 8
@@ -249,7 +280,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
     if (filtered) {
       const int32_t N = bs / T;
       if (c.mode & CH_FUSED_SHUF) { /* shuffled by tasks of the encode kernel */ }
-      else if (c.mode & CH_SHUFFLE) { any_shuf = true; int t = (N + shuffle_tile_elems(T) - 1) / shuffle_tile_elems(T); if (t > tiles_shuf) tiles_shuf = t; }
+      else if (c.mode & CH_SHUFFLE) { any_shuf = true; int t = (N + shuffle_tile_elems(T) - 1) / shuffle_tile_elems(T); if (t < 1) t = 1; if (t > tiles_shuf) tiles_shuf = t; }
       else { any_bit = true; int t = (N + bitshuffle_tile_elems(T) - 1) / bitshuffle_tile_elems(T); if (t < 1) t = 1; if (t > tiles_bit) tiles_bit = t; }
     }
     // blocks + streams; pointers are patched once the arenas are placed (offsets stored for now)
@@ -289,7 +320,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   build_encode_queues(blocks, chunks, st.enc_cost, st.enc_cost_valid, queues, st.single_queue ? 1 : 8);
   const size_t o_queues = cv.take(sizeof(int32_t) * queues.size());
   const size_t o_ready = cv.take(sizeof(uint32_t) * (nblk ? nblk : 1));
-  const size_t o_cost = cv.take(sizeof(uint32_t) * 256);
+  const size_t o_cost = cv.take(sizeof(uint32_t) * kCostWords);
   const size_t o_filt = cv.take(filt_bytes + 256);
   const size_t o_stage = cv.take(stage_bytes + 256);
   if (st.dev.ensure(cv.off)) return -1;
@@ -333,7 +364,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   const size_t p_streams = pc.take(sizeof(StreamDesc) * (nstr ? nstr : 1));
   const size_t p_results = pc.take(sizeof(int32_t) * (size_t)n);
   const size_t p_queues = pc.take(sizeof(int32_t) * queues.size());
-  const size_t p_cost = pc.take(sizeof(uint32_t) * 256);
+  const size_t p_cost = pc.take(sizeof(uint32_t) * kCostWords);
   if (st.pin.ensure(pc.off)) return -1;
   uint8_t* P = st.pin.base;
   memcpy(P + p_chunks, chunks.data(), sizeof(ChunkDesc) * (size_t)n);
@@ -342,7 +373,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   memcpy(P + p_queues, queues.data(), sizeof(int32_t) * queues.size());
   HIP_TRY(hipMemcpyAsync(D + o_queues, P + p_queues, sizeof(int32_t) * queues.size(), hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemsetAsync(D + o_ready, 0, sizeof(uint32_t) * (nblk ? nblk : 1), stream));
-  HIP_TRY(hipMemsetAsync(D + o_cost, 0, sizeof(uint32_t) * 256, stream));
+  HIP_TRY(hipMemsetAsync(D + o_cost, 0, sizeof(uint32_t) * kCostWords, stream));
   HIP_TRY(hipMemcpyAsync(D + o_chunks, P + p_chunks, sizeof(ChunkDesc) * (size_t)n, hipMemcpyHostToDevice, stream));
   if (nblk) HIP_TRY(hipMemcpyAsync(D + o_blocks, P + p_blocks, sizeof(BlockDesc) * nblk, hipMemcpyHostToDevice, stream));
   if (nstr) HIP_TRY(hipMemcpyAsync(D + o_streams, P + p_streams, sizeof(StreamDesc) * nstr, hipMemcpyHostToDevice, stream));
@@ -396,9 +427,10 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(P + p_results, d_results, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, stream));
-  HIP_TRY(hipMemcpyAsync(P + p_cost, D + o_cost, sizeof(uint32_t) * 256, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipMemcpyAsync(P + p_cost, D + o_cost, sizeof(uint32_t) * kCostWords, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   prof_collect(st);
+  if (nstr && check_done((const uint32_t*)(P + p_cost), queues.size() - 9, 0, "compress")) return -1;
   if (nstr >= 4096) { memcpy(st.enc_cost, P + p_cost, sizeof st.enc_cost); st.enc_cost_valid = true; }   // small calls say little
   const int32_t* r = (const int32_t*)(P + p_results);
   for (int i = 0; i < n; i++) if (live[(size_t)i]) results[i] = r[i];
@@ -450,13 +482,18 @@ static int fetch_headers(EngineState& st, int n, const Job* jobs, bool device_pt
   if (st.dev.ensure(cv.off)) return -1;
   if (st.pin.ensure(cv.off)) return -1;
   const void** pp = (const void**)(st.pin.base + o_ptrs);
-  for (int i = 0; i < n; i++) pp[i] = jobs[i].src;
+  // an entry whose caller-stated size cannot hold a header is never dereferenced: it reads the (zeroed) slot 0 of
+  // the header area instead and is rejected by classify_for_decompress (cbytes 0 > ... version 0)
+  bool any_short = false;
+  for (int i = 0; i < n; i++) { const bool sh = jobs[i].srcsize && jobs[i].srcsize < (size_t)kMaxOverhead; any_short |= sh; pp[i] = sh ? (const void*)(st.dev.base + o_hdr) : jobs[i].src; }
+  if (any_short) HIP_TRY(hipMemsetAsync(st.dev.base + o_hdr, 0, 16, stream));
   HIP_TRY(hipMemcpyAsync(st.dev.base + o_ptrs, pp, sizeof(void*) * (size_t)n, hipMemcpyHostToDevice, stream));
   hipLaunchKernelGGL(k_gather_headers, grid1((size_t)n * 16, 256), dim3(256), 0, stream,
                      (const uint8_t* const*)(st.dev.base + o_ptrs), st.dev.base + o_hdr, n);
   HIP_TRY(hipMemcpyAsync(st.pin.base + o_hdr, st.dev.base + o_hdr, 16 * (size_t)n, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   for (int i = 0; i < n; i++) hdrs[(size_t)i] = parse_header(st.pin.base + o_hdr + 16 * (size_t)i);
+  for (int i = 0; i < n; i++) if (jobs[i].srcsize && jobs[i].srcsize < (size_t)kMaxOverhead) { hdrs[(size_t)i] = Header{}; hdrs[(size_t)i].nbytes = -1; hdrs[(size_t)i].version = -1; }
   return 0;
 }
 
@@ -533,7 +570,7 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
     if (L.any_zstd) {
       ProfScope ps(st, stream, "k_zstd_streams");
       hipLaunchKernelGGL(k_zstd_streams, dim3(persistent_grid(L.nstr, ZSTD_WAVES_PER_CU)), dim3(64), 0, stream, L.d_streams, (int)L.nstr, L.d_status,
-                         L.d_zticket, L.d_chunks, L.d_blocks);
+                         L.d_zticket, L.d_chunks, L.d_blocks, L.d_cost + 257);
     }
     if (L.any_shuf) {
       ProfScope ps(st, stream, "k_unshuffle");
@@ -606,7 +643,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   const size_t o_streams = cv.take(sizeof(StreamDesc) * (nstr ? nstr : 1));
   const size_t o_status = cv.take(sizeof(int32_t) * (size_t)n + 64 + sizeof(uint32_t) * (nblk ? nblk : 1));   // + 8 tickets + per-block arrival counters
   const size_t o_queues = cv.take(sizeof(int32_t) * (9 + (nstr ? nstr : 1)));
-  const size_t o_cost = cv.take(sizeof(uint32_t) * 256);
+  const size_t o_cost = cv.take(sizeof(uint32_t) * kCostWords);
   const size_t o_spans = cv.take(8 * (nstr ? nstr : 1));
   const size_t o_pat = cv.take(span_enabled() ? (size_t)2048 * (nstr ? nstr : 1) : 256);
   const size_t o_filt = cv.take(filt_bytes + 256);
@@ -641,7 +678,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   const size_t p_blocks = pc.take(sizeof(BlockDesc) * (nblk ? nblk : 1));
   const size_t p_status = pc.take(sizeof(int32_t) * (size_t)n);
   const size_t p_queues = pc.take(sizeof(int32_t) * queues.size());
-  const size_t p_cost = pc.take(sizeof(uint32_t) * 256);
+  const size_t p_cost = pc.take(sizeof(uint32_t) * kCostWords);
   if (st.pin.ensure(pc.off)) return -1;
   uint8_t* P = st.pin.base;
   memcpy(P + p_chunks, chunks.data(), sizeof(ChunkDesc) * (size_t)n);
@@ -659,15 +696,16 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   L.d_qoff = (const int32_t*)(D + o_queues); L.d_qlist = L.d_qoff + 9;
   L.d_spans = span_enabled() ? (uint32_t*)(D + o_spans) : nullptr; L.d_pat = D + o_pat;
   L.d_cost = (uint32_t*)(D + o_cost);
-  HIP_TRY(hipMemsetAsync(D + o_cost, 0, sizeof(uint32_t) * 256, stream));
+  HIP_TRY(hipMemsetAsync(D + o_cost, 0, sizeof(uint32_t) * kCostWords, stream));
   L.d_zticket = (uint32_t*)(D + o_zticket);
   if (L.any_zstd) HIP_TRY(hipMemsetAsync(D + o_zticket, 0, 64, stream));
   L.nblk = nblk; L.nstr = nstr; L.nchunks = n;
   if (launch_decode(st, L, stream)) return -1;
   HIP_TRY(hipMemcpyAsync(P + p_status, D + o_status, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, stream));
-  HIP_TRY(hipMemcpyAsync(P + p_cost, D + o_cost, sizeof(uint32_t) * 256, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipMemcpyAsync(P + p_cost, D + o_cost, sizeof(uint32_t) * kCostWords, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   prof_collect(st);
+  if (nblk && check_done((const uint32_t*)(P + p_cost), nstr, L.any_zstd ? nstr : 0, "decompress")) return -1;
   if (nstr >= 4096) { memcpy(st.dec_cost, P + p_cost, sizeof st.dec_cost); st.dec_cost_valid = true; }
   const int32_t* stt = (const int32_t*)(P + p_status);
   for (int i = 0; i < n; i++) {
@@ -742,7 +780,7 @@ int engine_getitem(const void* src, int start, int nitems, void* dest, bool src_
   const size_t o_streams = cv.take(sizeof(StreamDesc) * nstr);
   const size_t o_status = cv.take(sizeof(int32_t) + 64 + sizeof(uint32_t) * nblk);
   const size_t o_queues = cv.take(sizeof(int32_t) * (9 + nstr));
-  const size_t o_cost = cv.take(sizeof(uint32_t) * 256);
+  const size_t o_cost = cv.take(sizeof(uint32_t) * kCostWords);
   const size_t o_spans = cv.take(8 * nstr);
   const size_t o_pat = cv.take(span_enabled() ? (size_t)2048 * nstr : 256);
   const size_t o_out = cv.take(span + 256);
@@ -762,6 +800,7 @@ int engine_getitem(const void* src, int start, int nitems, void* dest, bool src_
   const size_t p_chunks = pc.take(sizeof(ChunkDesc));
   const size_t p_blocks = pc.take(sizeof(BlockDesc) * nblk);
   const size_t p_status = pc.take(sizeof(int32_t));
+  const size_t p_cost = pc.take(sizeof(uint32_t) * kCostWords);
   std::vector<int32_t> queues;
   build_xcd_queues(blocks, nstr, st.dec_cost, st.dec_cost_valid, queues, st.single_queue ? 1 : 8);
   const size_t p_queues = pc.take(sizeof(int32_t) * queues.size());
@@ -780,14 +819,17 @@ int engine_getitem(const void* src, int start, int nitems, void* dest, bool src_
   L.d_blkdone = (uint32_t*)(D + o_status + 68);
   L.d_qoff = (const int32_t*)(D + o_queues); L.d_qlist = L.d_qoff + 9;
   L.d_spans = span_enabled() ? (uint32_t*)(D + o_spans) : nullptr; L.d_pat = D + o_pat;
-  L.d_cost = nullptr;   // a handful of blocks: no feedback
+  L.d_cost = (uint32_t*)(D + o_cost);   // a handful of blocks: the plane costs are not fed back, only the task count is checked
+  HIP_TRY(hipMemsetAsync(D + o_cost, 0, sizeof(uint32_t) * kCostWords, stream));
   L.any_zstd = fmt == FMT_ZSTD; L.d_zticket = (uint32_t*)(D + o_zticket);
   if (L.any_zstd) HIP_TRY(hipMemsetAsync(D + o_zticket, 0, 64, stream));
   L.nblk = nblk; L.nstr = nstr; L.nchunks = 1;
   if (launch_decode(st, L, stream)) return -1;
   HIP_TRY(hipMemcpyAsync(P + p_status, D + o_status, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipMemcpyAsync(P + p_cost, D + o_cost, sizeof(uint32_t) * kCostWords, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   prof_collect(st);
+  if (check_done((const uint32_t*)(P + p_cost), nstr, L.any_zstd ? nstr : 0, "getitem")) return -1;
   const int32_t stt = *(const int32_t*)(P + p_status);
   if (stt < 0) return stt;                                                        // blosc.c:1689-1692: blosc_d's code is returned as is
   HIP_TRY(hipMemcpyAsync(dest, D + o_out + (size_t)(lo - (int64_t)j0 * bs), want, out_kind, stream));
@@ -854,16 +896,18 @@ int engine_set_device(int dev) {
   std::lock_guard<std::mutex> lock(st.mu);
   int cnt = 0;
   if (hipGetDeviceCount(&cnt) != hipSuccess || dev < 0 || dev >= cnt) return -1;
-  if (st.device_ok && st.device != dev) { st.dev.release(); st.io.release(); }
-  HIP_TRY(hipSetDevice(dev));
-  st.device = dev; st.device_ok = true;
-  return 0;
+  if (st.device_ok && st.device == dev) { HIP_TRY(hipSetDevice(dev)); return 0; }
+  if (st.device_ok) { st.dev.release(); st.io.release(); }   // arenas belong to the device they were allocated on
+  // not "ok" yet: ensure_device() probes the topology of THIS device (per-XCD queues are only valid where the
+  // probe says so) and resets everything cached about the previous one
+  st.device = dev; st.device_ok = false;
+  return ensure_device(st);
 }
 
 void engine_release() {
   EngineState& st = S();
   std::lock_guard<std::mutex> lock(st.mu);
-  if (!st.device_ok) return;
+  if (!st.device_ok || g_forked) return;
   st.dev.release(); st.io.release(); st.pin.release();
 }
 

@@ -261,8 +261,8 @@ __device__ __forceinline__ uint32_t lz4_batch_step(const Window& w, gu8* out, vo
 //   literal-length extension stops reading at n-15, match-length extension at n-4;
 //   a literal run reaching within 12 bytes of the output end or 8 of the input end must be the
 //   last one and end exactly at the input end; offset <= bytes produced; a match must end at
-//   least 5 bytes before the output end.  Offset 0 (accepted by the reference with unspecified
-//   output) is rejected here.
+//   least 5 bytes before the output end.  Offset 0 is accepted like the reference does (the match bytes
+//   are then whatever the output buffer held).
 // ---------------------------------------------------------------------------------------------
 // LZ4's 255-run length extension (lz4.c:2240-2250 / :2330-2342), 64 stream bytes per step instead of one:
 // value += 255 * (number of leading 0xFF bytes) + the first other byte; ip ends behind that byte.
@@ -349,8 +349,19 @@ __device__ int lz4_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* out,
     }
     ml += 4u;
     const uint32_t mpos = op + ll;
-    if (off == 0u || off > mpos) return -5;
+    if (off > mpos) return -5;
     if (mpos + ml + 5u > cap) return -6;
+    if (off == 0u) {
+      // The reference does not reject offset 0 (lz4.c:2356 only checks the lower bound): it "copies" the match from
+      // its own destination, i.e. leaves whatever the output buffer held.  Same verdict here: literals are stored,
+      // the match bytes stay as they are (unspecified content, exactly as with stock LZ4).
+      if (ll) {
+        if (lit_in_win) { if ((uint32_t)lane < ll) out[op + lane] = (uint8_t)litv; }
+        else if (lit_mine) g_st16(out + op + lit_off, lit16);
+      }
+      op = mpos + ml;
+      continue;
+    }
     if (sp.hi && mpos - off < sp.hi) span_materialize(out, lane, sp);
 
     if (lit_in_win && ll + ml <= 64u && off >= ml && (ll == 0u || off >= ll + ml)) {
@@ -723,6 +734,7 @@ __global__ __launch_bounds__(64 * DEC_WAVES, BAMD_DEC_MINWAVES) void k_decode_st
   const uint32_t xcc = single_queue ? 0u : (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);
   const uint32_t qbase = (uint32_t)qoff[xcc], qlen = (uint32_t)qoff[xcc + 1] - qbase;
   uint32_t t = take_ticket(tickets + xcc, lane);
+  uint32_t ndone = 0;      // streams this wave took: summed into plane_cost[256], the host checks the total
   while (t < qlen) {
     const uint32_t sid = (uint32_t)qlist[qbase + t];
 #ifdef BAMD_PROFILE_DECODE
@@ -730,8 +742,10 @@ __global__ __launch_bounds__(64 * DEC_WAVES, BAMD_DEC_MINWAVES) void k_decode_st
 #else
     decode_one_stream(streams + sid, status, scr[0], chunks, blocks, blk_done, lane, sid, spans, pat, plane_cost);
 #endif
+    ndone++;
     t = take_ticket(tickets + xcc, lane);
   }
+  if (lane == 0 && ndone) atomicAdd(plane_cost + 256, ndone);
 }
 
 }  // namespace bamd

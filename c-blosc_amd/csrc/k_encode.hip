@@ -641,6 +641,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES, BAMD_ENC_MINWAVES) void k_encode_st
   const uint32_t xcc = single_queue ? 0u : (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);
   const uint32_t qbase = (uint32_t)qoff[xcc], qlen = (uint32_t)qoff[xcc + 1] - qbase;
   uint32_t t = take_ticket(tickets + xcc, lane);
+  uint32_t ndone = 0;      // tasks this wave took: summed into plane_cost[256], the host checks the total
   while (t < qlen) {
     const int32_t task = (int32_t)uni((uint32_t)qlist[qbase + t]);
     if (task < 0) {
@@ -652,8 +653,10 @@ __global__ __launch_bounds__(64 * ENC_WAVES, BAMD_ENC_MINWAVES) void k_encode_st
       encode_one_stream(streams + task, tabs[0], chunks, blk_ready, lane, blocks, (uint32_t)task, plane_cost);
 #endif
     }
+    ndone++;
     t = take_ticket(tickets + xcc, lane);
   }
+  if (lane == 0 && ndone) atomicAdd(plane_cost + 256, ndone);
 }
 
 // ---------------------------------------------------------------------------------------------

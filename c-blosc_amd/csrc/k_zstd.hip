@@ -255,10 +255,11 @@ __device__ __attribute__((noinline)) int zstd_decode_wave(const uint8_t* in, int
 constexpr int ZSTD_WAVES_PER_CU = 12;
 __global__ __launch_bounds__(64, 3) void k_zstd_streams(StreamDesc* __restrict__ streams, int nstreams, int32_t* __restrict__ status,
                                                      uint32_t* __restrict__ ticket, const ChunkDesc* __restrict__ chunks,
-                                                     const BlockDesc* __restrict__ blocks) {
+                                                     const BlockDesc* __restrict__ blocks, uint32_t* __restrict__ done) {
   __shared__ ZstdLds lds;
   const int lane = threadIdx.x & 63;
   uint32_t sid = take_ticket(ticket, lane);
+  uint32_t ndone = 0;
   while (sid < (uint32_t)nstreams) {
     StreamDesc* sd = streams + sid;
     const int32_t csize = (int32_t)uni((uint32_t)sd->in_size), want = (int32_t)uni((uint32_t)sd->out_size);
@@ -274,8 +275,10 @@ __global__ __launch_bounds__(64, 3) void k_zstd_streams(StreamDesc* __restrict__
         if (got != want) atomicMin(&status[sd->chunk], (int32_t)ST_BADCODEC);   // blosc.c:780-782
       }
     }
+    ndone++;
     sid = take_ticket(ticket, lane);
   }
+  if (lane == 0 && ndone) atomicAdd(done, ndone);
 }
 
 }  // namespace bamd

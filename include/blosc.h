@@ -37,6 +37,8 @@ extern "C" {
 #define BLOSC_VERSION_MINOR 21
 #define BLOSC_VERSION_RELEASE 7
 #define BLOSC_VERSION_STRING "1.21.7.dev"
+#define BLOSC_VERSION_REVISION "$Rev$"                   /* blosc/blosc.h:25 */
+#define BLOSC_VERSION_DATE "$Date:: 2024-06-24 #$"       /* blosc/blosc.h:26 */
 #define BLOSC_VERSION_FORMAT 2
 
 /* blosc/blosc.h:32-51 */

@@ -229,6 +229,9 @@ tail:
  * (lz4.c:2356); match-length extension may not read past iend-4 (lz4.c:2346); a match may not end
  * within the last 5 output bytes (lz4.c:2423).  Offset 0 is not rejected by the reference (output
  * then unspecified); here it copies from the current position like a byte-wise forward copy. */
+static long g_lz4_offset0_seen = 0;   /* test aid: how many offset-0 matches the decoder has executed */
+long orc_lz4_offset0_seen(int reset) { long v = g_lz4_offset0_seen; if (reset) g_lz4_offset0_seen = 0; return v; }
+
 int orc_lz4_decompress(const uint8_t* src, int n, uint8_t* dst, int cap) {
   if (src == NULL || cap < 0) return -1;
   if (cap == 0) return (n == 1 && src[0] == 0) ? 0 : -1;
@@ -262,6 +265,7 @@ int orc_lz4_decompress(const uint8_t* src, int n, uint8_t* dst, int cap) {
     len += LZ4_MINMATCH;
     if (off > op) return -ip - 1;
     if (op + len > cap - LZ4_LASTLITERALS) return -ip - 1;
+    if (off == 0) g_lz4_offset0_seen++;
     for (long k = 0; k < len; k++) dst[op + k] = dst[op - off + k]; /* forward, overlap-safe */
     op += (int)len;
   }

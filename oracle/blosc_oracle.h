@@ -40,6 +40,7 @@ int  orc_bitunshuffle(size_t typesize, size_t blocksize, const uint8_t* src, uin
 int orc_lz4_compress(const uint8_t* src, int srclen, uint8_t* dst, int dstcap, int accel);
 /* LZ4_decompress_safe semantics, safe-loop rules (lz4.c:2215-2445): >=0 bytes written, <0 error */
 int orc_lz4_decompress(const uint8_t* src, int srclen, uint8_t* dst, int dstcap);
+long orc_lz4_offset0_seen(int reset);   /* test aid: offset-0 matches executed so far (output unspecified in the reference) */
 /* blosclz.c:421-613 / 679-789 */
 int orc_blosclz_compress(int clevel, const uint8_t* src, int srclen, uint8_t* dst, int dstcap,
                          int split_block);

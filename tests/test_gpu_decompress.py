@@ -3,10 +3,12 @@ reference algorithm (oracle, pinned to the real reference) and on the reference'
 import glob
 import os
 
+import ctypes as C
+
 import numpy as np
 import pytest
 
-from helpers import DATASETS, orc_compress, header, ptr, wrap_stream_as_chunk
+from helpers import DATASETS, orc_compress, orc_decompress, header, ptr, wrap_stream_as_chunk
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
@@ -100,23 +102,47 @@ def test_error_returns_match_oracle(pkg, oracle, lib):
     assert got == -1
 
 
-def test_corrupt_payload_never_crashes(pkg, oracle):
-    """Memory-safety promise (blosc.h:258-263): random damage gives an error or garbage, never a fault,
-    and an intact chunk still decodes afterwards."""
+def test_corrupt_payload_same_verdict_and_bytes_as_oracle(pkg, oracle):
+    """Random damage to LZ4 / BloscLZ chunks, device-resident, output in canary-padded buffers: the verdict equals
+    the oracle's (itself pinned to the reference), accepted chunks carry the oracle's bytes, and nothing is
+    written outside [dest, dest + nbytes).  (blosc.h:258-263 promises memory safety; parity asks for more.)"""
+    import torch
+    dev = torch.device("cuda:0")
     rng = np.random.default_rng(3)
-    data = DATASETS["bench19"](1 << 20)
-    for codec in ["lz4", "blosclz"]:
-        _, good = orc_compress(oracle, data, 8, 5, 1, codec)
-        first = 16 + 4 * ((data.size + header(good)["blocksize"] - 1) // header(good)["blocksize"])
-        for trial in range(60):
-            c = good.copy()
-            k = rng.integers(1, 20)
-            pos = rng.integers(first, c.size, k)
-            c[pos] = rng.integers(0, 256, k, dtype=np.uint8)
-            r, out = pkg.decompress(c, data.size)
-            assert r == data.size or r < 0
-        r, out = pkg.decompress(good, data.size)
-        assert r == data.size and np.array_equal(out, data)
+    PAD = 4096
+    oracle.orc_lz4_offset0_seen.restype = C.c_long
+    for dname, T, shuffle in [("bench19", 8, 1), ("bench19", 4, 0), ("linspace", 8, 1), ("smallints", 4, 2)]:
+        data = DATASETS[dname](1 << 20)
+        for codec in ["lz4", "blosclz"]:
+            _, good = orc_compress(oracle, data, T, 5, shuffle, codec)
+            first = 16 + 4 * ((data.size + header(good)["blocksize"] - 1) // header(good)["blocksize"])
+            chunks, want = [], []
+            for trial in range(40):
+                c = good.copy()
+                k = int(rng.integers(1, 12))
+                pos = rng.integers(first, c.size, k)
+                c[pos] = rng.integers(0, 256, k, dtype=np.uint8)
+                oracle.orc_lz4_offset0_seen(1)
+                ro, oo = orc_decompress(oracle, c, data.size)
+                want.append((ro, oo.copy(), oracle.orc_lz4_offset0_seen(1)))
+                chunks.append(c)
+            d_src = [torch.from_numpy(c).to(dev) for c in chunks]
+            d_dst = [torch.full((data.size + 2 * PAD,), 0xA5, dtype=torch.uint8, device=dev) for _ in chunks]
+            b = pkg.DeviceBatch([t.data_ptr() for t in d_src], [c.size for c in chunks],
+                                [t.data_ptr() + PAD for t in d_dst], [data.size] * len(chunks))
+            assert b.decompress() == 0
+            for i, (rg, (ro, oo, off0)) in enumerate(zip(b.results(), want)):
+                out = d_dst[i].cpu().numpy()
+                assert (out[:PAD] == 0xA5).all() and (out[PAD + data.size:] == 0xA5).all(), (dname, codec, i, "canary")
+                if ro == data.size:
+                    assert rg == data.size, (dname, codec, i, rg, ro)
+                    if not off0:       # an offset-0 LZ4 match leaves unspecified bytes in the reference too (lz4.c:2356)
+                        assert np.array_equal(out[PAD:PAD + data.size], oo), (dname, codec, i)
+                else:
+                    assert rg < 0, (dname, codec, i, rg, ro)
+            # an intact chunk still decodes afterwards
+            r, out = pkg.decompress(good, data.size)
+            assert r == data.size and np.array_equal(out, data)
 
 
 def _lz4_seq(lit, off, mlen):
@@ -186,4 +212,100 @@ def test_handbuilt_lz4_streams(pkg, oracle):
         r, out = pkg.decompress(chunk, n)
         if r != n or not np.array_equal(out, want):
             bad.append((i, r, n))
+    assert not bad, bad[:20]
+
+
+# ---- hand-built BloscLZ streams (grammar of blosclz.c:679-789) --------------------------------------------
+def _blz_lits(b):
+    """literal runs of at most 32 bytes: control byte n-1, then the bytes"""
+    out = bytearray()
+    b = bytes(b)
+    for k in range(0, len(b), 32):
+        run = b[k:k + 32]
+        out.append(len(run) - 1)
+        out += run
+    return out
+
+
+def _blz_match(dist, length):
+    """one match: total length = (ctrl>>5) + 2 (+ extension bytes when the field is 7), distance-1 in 13 bits, or
+    the escape 31/255 followed by a big-endian 16-bit value + 8191 (blosclz.c:700-733)"""
+    assert length >= 3 and 1 <= dist <= 65535 + 8191 + 1
+    out = bytearray()
+    d = dist - 1
+    far = d >= 8191
+    hi = 31 if far else d >> 8
+    if length <= 8:
+        out.append(((length - 2) << 5) | hi)
+    else:
+        out.append((7 << 5) | hi)
+        v = length - 9
+        while v >= 255:
+            out.append(255); v -= 255
+        out.append(v)
+    if far:
+        out.append(255)
+        out += bytes([(d - 8191) >> 8, (d - 8191) & 255])
+    else:
+        out.append(d & 255)
+    return out
+
+
+def test_handbuilt_blosclz_streams(pkg, oracle):
+    """Adversarial BloscLZ streams for the batched step and the scalar path of blosclz_decode_wave: distance-1
+    runs, overlapping matches at every small distance, the 8191/8192 boundary of the far-distance escape, length
+    fields 3..9 and every extension-chain shape (9, 263, 264, 265, 519 ...), literal runs of 1..32, a match that
+    reads the literals just emitted, and the 'pending match dropped at end of input' quirk (blosclz.c:688-736)."""
+    rng = np.random.default_rng(12)
+    streams = []
+    dists = list(range(1, 70)) + [127, 128, 255, 256, 257, 1023, 1024, 4096, 8190, 8191, 8192, 8193, 9000, 20000, 65535, 65535 + 8191 + 1]
+    lens = [3, 4, 5, 8, 9, 10, 16, 17, 31, 63, 64, 65, 100, 263, 264, 265, 300, 519, 1024, 1025, 2049, 5000, 70000]
+    for dist in dists:
+        for mlen in lens:
+            s = bytearray()
+            pre = rng.integers(0, 256, max(dist, 4) + int(rng.integers(0, 5)), dtype=np.uint8).tobytes()
+            s += _blz_lits(pre)
+            s += _blz_match(dist, mlen)
+            s += _blz_lits(rng.integers(0, 256, int(rng.integers(1, 33)), dtype=np.uint8).tobytes())
+            s += _blz_match(3, 9)            # reads the literals just emitted
+            s += _blz_match(1, 40)           # distance-1 run
+            s += _blz_lits(rng.integers(0, 256, 7, dtype=np.uint8).tobytes())
+            streams.append(bytes(s))
+    # dense short tokens: what the batched step sees on real data
+    for trial in range(60):
+        s = bytearray(_blz_lits(rng.integers(0, 256, 40, dtype=np.uint8).tobytes()))
+        produced = 40
+        for _ in range(int(rng.integers(20, 300))):
+            if rng.random() < 0.35:
+                k = int(rng.integers(1, 6)); s += _blz_lits(rng.integers(0, 256, k, dtype=np.uint8).tobytes()); produced += k
+            else:
+                d = int(rng.integers(1, min(produced, 300) + 1)); m = int(rng.choice([3, 4, 5, 6, 7, 8, 9, 12, 20, 70]))
+                s += _blz_match(d, m); produced += m
+        s += _blz_lits(rng.integers(0, 256, 9, dtype=np.uint8).tobytes())
+        streams.append(bytes(s))
+    # the end-of-input quirk: a stream that ENDS with a match (no byte behind it) drops that match
+    for dist, mlen in [(1, 3), (5, 9), (300, 264), (9000, 20)]:
+        s = bytearray(_blz_lits(rng.integers(0, 256, max(dist, 16), dtype=np.uint8).tobytes()))
+        s += _blz_match(2, 10)
+        s += _blz_match(dist, mlen)
+        streams.append(bytes(s))
+    bad = []
+    for i, s in enumerate(streams):
+        s = np.frombuffer(s, np.uint8)
+        cap = 1 << 20
+        tmp = np.zeros(cap, np.uint8)
+        n = oracle.orc_blosclz_decompress(ptr(s), s.size, ptr(tmp), cap)
+        assert n > 0, i
+        chunk = wrap_stream_as_chunk(s, n, 0)
+        r, out = pkg.decompress(chunk, n)
+        if r != n or not np.array_equal(out, tmp[:n]):
+            bad.append((i, r, n))
+        # one byte short / one byte long: blosc_d requires exactly neblock bytes (blosc.c:780-782)
+        for wrong in (n - 1, n + 1):
+            if wrong <= 0:
+                continue
+            r2, _ = pkg.decompress(wrap_stream_as_chunk(s, wrong, 0), wrong)
+            ro, _ = orc_decompress(oracle, wrap_stream_as_chunk(s, wrong, 0), wrong)
+            if (r2 < 0) != (ro < 0):
+                bad.append((i, "size", wrong, r2, ro))
     assert not bad, bad[:20]

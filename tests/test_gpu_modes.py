@@ -1,0 +1,39 @@
+"""GPU: the fallback switches of the engine are part of the product, so they are part of the
+suite: BLOSC_AMD_SINGLE_QUEUE (one task queue, stand-alone filters: what a partitioned device gets),
+BLOSC_AMD_FUSE (filters in kernels of their own), BLOSC_AMD_SPANS (periodic planes through the scratch),
+BLOSC_AMD_SCHED (plain block order), BLOSC_AMD_BLOCKDEC (LDS-resident block decoder off).  The switches are read
+once per process, so every combination runs tests/tools/mode_check.py in a process of its own."""
+import itertools
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SWITCHES = ["BLOSC_AMD_SINGLE_QUEUE", "BLOSC_AMD_FUSE", "BLOSC_AMD_SPANS", "BLOSC_AMD_SCHED", "BLOSC_AMD_BLOCKDEC"]
+DEFAULTS = {"BLOSC_AMD_SINGLE_QUEUE": "0", "BLOSC_AMD_FUSE": "1", "BLOSC_AMD_SPANS": "1", "BLOSC_AMD_SCHED": "1", "BLOSC_AMD_BLOCKDEC": "1"}
+
+
+def _combos():
+    # every single switch flipped, every pair flipped, and everything flipped at once
+    seen = []
+    for k in range(0, 3):
+        for flip in itertools.combinations(SWITCHES, k):
+            seen.append(flip)
+    seen.append(tuple(SWITCHES))
+    return seen
+
+
+@pytest.mark.parametrize("flip", _combos(), ids=lambda f: "+".join(s.replace("BLOSC_AMD_", "") for s in f) or "defaults")
+def test_mode_combination(flip):
+    env = dict(os.environ)
+    for s in SWITCHES:
+        v = DEFAULTS[s]
+        if s in flip:
+            v = "1" if v == "0" else "0"
+        env[s] = v
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "mode_check.py")], env=env, timeout=600,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 0 and "modes ok" in p.stdout, (flip, p.stdout[-2000:], p.stderr[-3000:])
