@@ -53,7 +53,10 @@ struct BlockDesc {
   int32_t bsize;        // bytes in this block: blocksize, or `leftover` for a short last block.  Computed
                         // on the host: selecting between two ChunkDesc fields on the device tripped an
                         // AMDGPU backend miscompile (ROCm 7.2, the `leftover > 0` test was dropped).
-  int32_t pad_;
+  int32_t flags;        // BLK_* bits
+};
+enum : int32_t {
+  BLK_LDS = 1,          // decompress: the block is decoded by k_decode_blocks (one workgroup, LDS-resident planes), not by k_decode_streams
 };
 
 struct StreamDesc {

@@ -18,6 +18,7 @@
 
 #include "k_filters.hip"
 #include "k_decode.hip"
+#include "k_decode_blocks.hip"
 #include "k_encode.hip"
 #include "k_zstd.hip"
 
@@ -68,12 +69,13 @@ struct PinnedArena {
 struct ProfEntry { double ms = 0; int launches = 0; };
 
 // per-launch feedback words of the persistent kernels: [0,256) cycles per plane index, [256] tasks taken by the
-// stream kernel, [257] streams taken by the Zstd kernel - the host compares both with what it queued
+// stream kernel, [257] streams taken by the Zstd kernel, [258] blocks taken by k_decode_blocks - the host compares them
+// with what it queued
 constexpr size_t kCostWords = 264;
-static int check_done(const uint32_t* fb, size_t expect, size_t expect_zstd, const char* what) {
-  if (fb[256] == expect && fb[257] == expect_zstd) return 0;
-  fprintf(stderr, "blosc_amd: %s: the device took %u of %zu queued tasks (Zstd: %u of %zu) - results discarded\n",
-          what, fb[256], expect, fb[257], expect_zstd);
+static int check_done(const uint32_t* fb, size_t expect, size_t expect_zstd, const char* what, size_t expect_blocks = 0) {
+  if (fb[256] == expect && fb[257] == expect_zstd && fb[258] == expect_blocks) return 0;
+  fprintf(stderr, "blosc_amd: %s: the device took %u of %zu queued tasks (Zstd: %u of %zu, blocks: %u of %zu) - results discarded\n",
+          what, fb[256], expect, fb[257], expect_zstd, fb[258], expect_blocks);
   return -1;
 }
 
@@ -217,6 +219,8 @@ static dim3 grid1(size_t n, int per) { return dim3((unsigned)((n + per - 1) / pe
 // running it as work of the encode / decode kernels
 // BLOSC_AMD_SPANS=0: decoded periodic planes go through the scratch like every other plane
 static bool span_enabled() { static const bool on = !(getenv("BLOSC_AMD_SPANS") && atoi(getenv("BLOSC_AMD_SPANS")) == 0); return on; }
+// BLOSC_AMD_BLOCKDEC=0: split byte-shuffled LZ4 blocks go through k_decode_streams + scratch like everything else
+static bool blockdec_enabled() { static const bool on = !(getenv("BLOSC_AMD_BLOCKDEC") && atoi(getenv("BLOSC_AMD_BLOCKDEC")) == 0); return on; }
 static bool fuse_enabled() { static const bool on = !(getenv("BLOSC_AMD_FUSE") && atoi(getenv("BLOSC_AMD_FUSE")) == 0); return on; }
 
 int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* results, bool device_ptrs,
@@ -290,7 +294,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
       const bool last = (j == nblocks - 1) && leftover > 0;
       b.nstreams = memcpyed ? 0 : ((split && !last) ? T : 1);
       const int32_t bsize = last ? leftover : bs;
-      b.bsize = bsize; b.pad_ = 0;
+      b.bsize = bsize; b.flags = 0;
       const int32_t neblock = b.nstreams ? bsize / b.nstreams : 0;
       for (int32_t s = 0; s < b.nstreams; s++) {
         StreamDesc sd;
@@ -521,7 +525,7 @@ static void add_decode_chunk(const Header& h, int fmt, int chunk_index, int32_t 
     b.chunk = chunk_index; b.blk = j; b.first_stream = (int32_t)nstreams;
     const bool last = (j == c.nblocks - 1) && c.leftover > 0;
     b.nstreams = (split && !last) ? T : 1;
-    b.bsize = last ? c.leftover : bs; b.pad_ = 0;
+    b.bsize = last ? c.leftover : bs; b.flags = 0;
     nstreams += (size_t)b.nstreams;
     blocks.push_back(b);
   }
@@ -537,7 +541,29 @@ struct DecodeLaunch {
   const int32_t* d_qlist; const int32_t* d_qoff;   // per-XCD stream queues
   size_t nblk, nstr; int nchunks;
   bool any_shuf, any_bit, any_copy; int tiles_shuf, tiles_bit;
+  // k_decode_blocks: block lists per typesize (4, 8), one far area per persistent workgroup
+  const int32_t* d_blist[2]; uint32_t nlist[2]; uint32_t* d_bticket; uint8_t* d_far; size_t far_stride;
+  size_t nstr_queued;                              // streams left to k_decode_streams
 };
+
+// Marks the blocks k_decode_blocks takes (split byte-shuffled LZ4 blocks of fused chunks, typesize 4 or 8) and lists
+// them per typesize; returns the far-area bytes one workgroup needs.
+static size_t pick_lds_blocks(const std::vector<ChunkDesc>& chunks, std::vector<BlockDesc>& blocks, std::vector<int32_t> list[2], size_t* nstr_lds) {
+  size_t far = 0; *nstr_lds = 0;
+  if (!blockdec_enabled()) return 0;
+  for (size_t g = 0; g < blocks.size(); g++) {
+    BlockDesc& b = blocks[g];
+    const ChunkDesc& c = chunks[(size_t)b.chunk];
+    if (!(c.mode & CH_FUSED_UNSHUF) || c.fmt != FMT_LZ4) continue;
+    const int T = c.typesize;
+    if ((T != 4 && T != 8) || b.nstreams != T || b.bsize % T || b.bsize / T < 256) continue;
+    b.flags |= BLK_LDS;
+    list[T == 8].push_back((int32_t)g);
+    *nstr_lds += (size_t)T;
+    if ((size_t)b.bsize > far) far = (size_t)b.bsize;
+  }
+  return align_up(far, 256);
+}
 
 static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t stream) {
   if (L.nblk) {
@@ -545,12 +571,12 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
       ProfScope ps(st, stream, "k_decode_plan");
       hipLaunchKernelGGL(k_decode_plan, grid1(L.nblk, 256), dim3(256), 0, stream, L.d_chunks, L.d_blocks, L.d_streams, L.d_status, (int)L.nblk);
     }
-    {
+    if (L.nstr_queued) {
       ProfScope ps(st, stream, "k_decode_streams");
       // Occupancy knob: unused dynamic LDS caps how many decoder waves share a CU (and its L2 slice).
       static const int dec_lds = getenv("BLOSC_AMD_DEC_LDS") ? atoi(getenv("BLOSC_AMD_DEC_LDS")) : 0;
       static const int dec_wpc = getenv("BLOSC_AMD_DEC_WPC") ? atoi(getenv("BLOSC_AMD_DEC_WPC")) : DEC_WAVES_PER_CU;
-      const dim3 dgrid(persistent_grid(L.nstr, dec_wpc));
+      const dim3 dgrid(persistent_grid(L.nstr_queued ? L.nstr_queued : 1, dec_wpc));
 #ifdef BAMD_PROFILE_DECODE
       uint32_t* d_prof = nullptr;
       if (getenv("BLOSC_AMD_DEC_PROFILE")) { (void)hipMalloc((void**)&d_prof, L.nstr * 64); (void)hipMemsetAsync(d_prof, 0, L.nstr * 64, stream); }
@@ -566,6 +592,15 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
 #else
       hipLaunchKernelGGL(k_decode_streams, dgrid, dim3(64 * DEC_WAVES), (size_t)dec_lds, stream, L.d_streams, L.d_status, L.d_ticket, L.d_qlist, L.d_qoff, L.d_chunks, L.d_blocks, L.d_blkdone, L.d_spans, L.d_pat, L.d_cost, st.single_queue ? 1 : 0);
 #endif
+    }
+    for (int which = 0; which < 2; which++) {
+      if (!L.nlist[which]) continue;
+      ProfScope ps(st, stream, "k_decode_blocks");
+      const unsigned grid = (unsigned)std::min<size_t>((size_t)st.cus * BD_WG_PER_CU * (which ? 1 : 2), L.nlist[which]);
+      if (which) hipLaunchKernelGGL(k_decode_blocks<8>, dim3(grid), dim3(512), 0, stream, L.d_streams, L.d_status, L.d_bticket + 1, L.d_blist[1], L.nlist[1],
+                                    L.d_chunks, L.d_blocks, L.d_far, L.far_stride, L.d_cost + 258);
+      else hipLaunchKernelGGL(k_decode_blocks<4>, dim3(grid), dim3(256), 0, stream, L.d_streams, L.d_status, L.d_bticket, L.d_blist[0], L.nlist[0],
+                              L.d_chunks, L.d_blocks, L.d_far, L.far_stride, L.d_cost + 258);
     }
     if (L.any_zstd) {
       ProfScope ps(st, stream, "k_zstd_streams");
@@ -636,6 +671,10 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
     if (!device_ptrs) { io_src = align_up(io_src, 256) + (size_t)c.cbytes; io_dst = align_up(io_dst, 256) + (size_t)c.nbytes; }
   }
   const size_t nblk = blocks.size();
+  std::vector<int32_t> blist[2];
+  size_t nstr_lds = 0;
+  const size_t far_stride = pick_lds_blocks(chunks, blocks, blist, &nstr_lds);
+  const size_t far_wgs = (size_t)st.cus * BD_WG_PER_CU * 2;       // the typesize-4 kernel runs twice as many (half-size) workgroups
 
   Carver cv;
   const size_t o_chunks = cv.take(sizeof(ChunkDesc) * (size_t)n);
@@ -643,12 +682,14 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   const size_t o_streams = cv.take(sizeof(StreamDesc) * (nstr ? nstr : 1));
   const size_t o_status = cv.take(sizeof(int32_t) * (size_t)n + 64 + sizeof(uint32_t) * (nblk ? nblk : 1));   // + 8 tickets + per-block arrival counters
   const size_t o_queues = cv.take(sizeof(int32_t) * (9 + (nstr ? nstr : 1)));
+  const size_t o_blist = cv.take(sizeof(int32_t) * (blist[0].size() + blist[1].size() + 1) + 64);   // 2 tickets + the two block lists
   const size_t o_cost = cv.take(sizeof(uint32_t) * kCostWords);
   const size_t o_spans = cv.take(8 * (nstr ? nstr : 1));
   const size_t o_pat = cv.take(span_enabled() ? (size_t)2048 * (nstr ? nstr : 1) : 256);
   const size_t o_filt = cv.take(filt_bytes + 256);
   const size_t o_zlit = cv.take(zlit_bytes + 256);      // literal scratch of the Zstd chunks
   const size_t o_zticket = cv.take(64);
+  const size_t o_far = cv.take(far_stride ? far_stride * far_wgs : 256);
   if (st.dev.ensure(cv.off)) return -1;
   uint8_t* D = st.dev.base;
   uint8_t *io_s = nullptr, *io_d = nullptr;
@@ -679,11 +720,16 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   const size_t p_status = pc.take(sizeof(int32_t) * (size_t)n);
   const size_t p_queues = pc.take(sizeof(int32_t) * queues.size());
   const size_t p_cost = pc.take(sizeof(uint32_t) * kCostWords);
+  const size_t p_blist = pc.take(sizeof(int32_t) * (blist[0].size() + blist[1].size() + 1) + 64);
   if (st.pin.ensure(pc.off)) return -1;
   uint8_t* P = st.pin.base;
   memcpy(P + p_chunks, chunks.data(), sizeof(ChunkDesc) * (size_t)n);
   if (nblk) memcpy(P + p_blocks, blocks.data(), sizeof(BlockDesc) * nblk);
   memcpy(P + p_queues, queues.data(), sizeof(int32_t) * queues.size());
+  memset(P + p_blist, 0, 64);
+  if (!blist[0].empty()) memcpy(P + p_blist + 64, blist[0].data(), sizeof(int32_t) * blist[0].size());
+  if (!blist[1].empty()) memcpy(P + p_blist + 64 + sizeof(int32_t) * blist[0].size(), blist[1].data(), sizeof(int32_t) * blist[1].size());
+  HIP_TRY(hipMemcpyAsync(D + o_blist, P + p_blist, sizeof(int32_t) * (blist[0].size() + blist[1].size()) + 64, hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemcpyAsync(D + o_chunks, P + p_chunks, sizeof(ChunkDesc) * (size_t)n, hipMemcpyHostToDevice, stream));
   if (nblk) HIP_TRY(hipMemcpyAsync(D + o_blocks, P + p_blocks, sizeof(BlockDesc) * nblk, hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemcpyAsync(D + o_queues, P + p_queues, sizeof(int32_t) * queues.size(), hipMemcpyHostToDevice, stream));
@@ -700,12 +746,16 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   L.d_zticket = (uint32_t*)(D + o_zticket);
   if (L.any_zstd) HIP_TRY(hipMemsetAsync(D + o_zticket, 0, 64, stream));
   L.nblk = nblk; L.nstr = nstr; L.nchunks = n;
+  L.d_bticket = (uint32_t*)(D + o_blist);
+  L.d_blist[0] = (const int32_t*)(D + o_blist + 64); L.d_blist[1] = L.d_blist[0] + blist[0].size();
+  L.nlist[0] = (uint32_t)blist[0].size(); L.nlist[1] = (uint32_t)blist[1].size();
+  L.d_far = D + o_far; L.far_stride = far_stride; L.nstr_queued = nstr - nstr_lds;
   if (launch_decode(st, L, stream)) return -1;
   HIP_TRY(hipMemcpyAsync(P + p_status, D + o_status, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipMemcpyAsync(P + p_cost, D + o_cost, sizeof(uint32_t) * kCostWords, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   prof_collect(st);
-  if (nblk && check_done((const uint32_t*)(P + p_cost), nstr, L.any_zstd ? nstr : 0, "decompress")) return -1;
+  if (nblk && check_done((const uint32_t*)(P + p_cost), nstr - nstr_lds, L.any_zstd ? nstr : 0, "decompress", blist[0].size() + blist[1].size())) return -1;
   if (nstr >= 4096) { memcpy(st.dec_cost, P + p_cost, sizeof st.dec_cost); st.dec_cost_valid = true; }
   const int32_t* stt = (const int32_t*)(P + p_status);
   for (int i = 0; i < n; i++) {
@@ -823,7 +873,7 @@ int engine_getitem(const void* src, int start, int nitems, void* dest, bool src_
   HIP_TRY(hipMemsetAsync(D + o_cost, 0, sizeof(uint32_t) * kCostWords, stream));
   L.any_zstd = fmt == FMT_ZSTD; L.d_zticket = (uint32_t*)(D + o_zticket);
   if (L.any_zstd) HIP_TRY(hipMemsetAsync(D + o_zticket, 0, 64, stream));
-  L.nblk = nblk; L.nstr = nstr; L.nchunks = 1;
+  L.nblk = nblk; L.nstr = nstr; L.nchunks = 1; L.nstr_queued = nstr;    // a handful of blocks: always through k_decode_streams
   if (launch_decode(st, L, stream)) return -1;
   HIP_TRY(hipMemcpyAsync(P + p_status, D + o_status, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipMemcpyAsync(P + p_cost, D + o_cost, sizeof(uint32_t) * kCostWords, hipMemcpyDeviceToHost, stream));

@@ -1,0 +1,428 @@
+// k_decode_blocks.hip — LDS-resident decode of byte-shuffled, split blocks: LZ decode + unshuffle of one block by
+// ONE workgroup, no plane-major image of the block in HBM (rows D1 + K2 + K5/K7 of SURVEY §8a fused).
+//
+// Replaces, for blocks written with the byte shuffle and split into `typesize` streams (the BASELINE geometry),
+//   blosc_d's split loop + blosc_internal_unshuffle    blosc/blosc.c:725-800, blosc/shuffle-generic.h:61-81
+//   LZ4_decompress_safe                                  lz4.c:2023-2451
+// and k_decode_streams' scratch round trip (k_decode.hip), which moved 26 GB per 8 GiB (profiles/r01_final_traffic.json).
+//
+// One workgroup = one block, wave j = byte plane j (stream j of the block).  Every wave keeps the most recent
+// R = 8 KiB of its plane in an LDS ring; all waves advance in lock-step SLICES of S = 4 KiB of plane positions:
+//   decode plane j up to the slice end (matches read their source from the ring: ~64-cycle LDS round trips instead of
+//   L2 / HBM ones)  ->  s_barrier  ->  the workgroup transposes the slice out of the T rings straight into the
+//   destination (coalesced 16-byte stores)  ->  next slice into the other half of the ring (R = 2 S: one barrier
+//   per slice is enough, see decode_block).
+// A match whose source lies further back than the ring reads it from `far`, a plane-major copy of the slices
+// already written out that every wave keeps of ITS OWN plane (same wave stores and loads: no cross-wave ordering
+// needed); a plane whose stream ends in one long periodic match (constant / short-period planes: half of bench19)
+// writes no far copy at all and, once the ring holds a whole number of periods, costs nothing per slice.
+//
+// Algorithmic HBM bytes per block: csize read + bsize written.  Real traffic adds the far copy of the planes that
+// need one (write once, read only by far matches).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "dev_types.h"
+#include "wave_prims.h"
+
+namespace bamd {
+
+constexpr uint32_t BD_R = 8192u;          // ring bytes per plane (power of two)
+constexpr uint32_t BD_S = BD_R / 2u;      // slice: plane positions between two barriers
+constexpr uint32_t BD_MASK = BD_R - 1u;
+
+#define BAMD_LAS __attribute__((address_space(3)))
+typedef BAMD_LAS uint8_t lu8;
+// compiler-level ordering between LDS phases in which lanes read what OTHER lanes wrote (the hardware runs one
+// wave's DS operations in order; this keeps the compiler from reordering them on per-thread alias reasoning)
+#define LDS_ORDER() asm volatile("" ::: "memory")
+
+__device__ __forceinline__ uint4 l_ld16(const lu8* p) { v4u32 t = *(const BAMD_LAS v4u32_una*)p; return make_uint4(t.x, t.y, t.z, t.w); }
+__device__ __forceinline__ void l_st16(lu8* p, uint4 v) { v4u32 t = {v.x, v.y, v.z, v.w}; *(BAMD_LAS v4u32_una*)p = t; }
+__device__ __forceinline__ uint64_t l_ld8(const lu8* p) { return *(const BAMD_LAS u64una*)p; }
+__device__ __forceinline__ void l_st8(lu8* p, uint64_t v) { *(BAMD_LAS u64una*)p = v; }
+__device__ __forceinline__ uint32_t l_ld4(const lu8* p) { return *(const BAMD_LAS u32una*)p; }
+__device__ __forceinline__ void l_st4(lu8* p, uint32_t v) { *(BAMD_LAS u32una*)p = v; }
+
+// One plane's output: the LDS ring (positions [W - R, W) of the plane, W = write frontier) and the far copy
+// (positions [0, flushed), plane-major in global memory).
+struct PlaneOut {
+  lu8* ring;            // BD_R bytes
+  gu8* far;             // this plane's slice of the workgroup's far area
+  uint32_t flushed;     // slice start: every position below it is in `far`
+};
+
+// n <= 1024 bytes from the compressed stream (global) to plane positions [pos, pos + n): the destination lies in
+// one slice, so its ring image is contiguous
+__device__ __forceinline__ void ring_put_global(const PlaneOut& o, uint32_t pos, const gu8* src, uint32_t n, int lane) {
+  lu8* d = o.ring + (pos & BD_MASK);
+  const uint32_t n16 = n >> 4;
+  if ((uint32_t)lane < n16) l_st16(d + 16u * (uint32_t)lane, g_ld16(src + 16u * (uint32_t)lane));
+  const uint32_t done = n16 << 4;
+  if ((uint32_t)lane < n - done) d[done + lane] = src[done + lane];
+}
+__device__ __forceinline__ void ring_put_global_long(const PlaneOut& o, uint32_t pos, const gu8* src, uint32_t n, int lane) {
+  uint32_t done = 0;
+  while (n - done > 1024u) { ring_put_global(o, pos + done, src + done, 1024u, lane); done += 1024u; }
+  ring_put_global(o, pos + done, src + done, n - done, lane);
+}
+
+// History chunk: plane positions [src, src + n) -> [dst, dst + n), n <= 1024, n <= dst - src (no overlap inside the
+// chunk), W = write frontier of the ring (>= dst; everything at or above W - R is still in the ring, everything
+// below is in `far` because W - R <= flushed).  16 bytes per lane; a piece that wraps around the ring end or
+// straddles the ring / far border goes byte by byte (rare).
+__device__ __forceinline__ void hist_copy(const PlaneOut& o, uint32_t dst, uint32_t src, uint32_t n, uint32_t W, int lane) {
+  const uint32_t off16 = 16u * (uint32_t)lane;
+  if (off16 >= n) return;
+  const uint32_t q = src + off16, cnt = n - off16 < 16u ? n - off16 : 16u;
+  const int32_t lo = (int32_t)W - (int32_t)BD_R;           // first position still in the ring (may be negative)
+  lu8* d = o.ring + ((dst + off16) & BD_MASK);
+  const uint32_t qi = q & BD_MASK;
+  if (cnt == 16u && (int32_t)q >= lo && qi <= BD_R - 16u) { l_st16(d, l_ld16(o.ring + qi)); return; }
+  if (cnt == 16u && (int32_t)(q + 16u) <= lo) { l_st16(d, g_ld16(o.far + q)); return; }
+  for (uint32_t b = 0; b < cnt; b++) {
+    const uint32_t qq = q + b;
+    d[b] = ((int32_t)qq >= lo) ? o.ring[qq & BD_MASK] : (uint8_t)o.far[qq];
+  }
+}
+
+// LZ match out[pos + k] = out[pos - off + k], k < len, byte-wise forward semantics (lz4.c:2387-2434,
+// blosc/fastcopy.c:530-639), destination inside one slice.  All arguments wave-uniform; off >= 1, off <= pos.
+__device__ __forceinline__ void ring_match(const PlaneOut& o, uint32_t pos, uint32_t off, uint32_t len, uint32_t W, int lane) {
+  uint32_t done = 0, off_e = off;
+  if (off < 64u && off < len) {
+    // short period: fetch the pattern once (always in the ring: off < 64), lane i holds pattern byte i mod off, then
+    // store G = off * floor(64 / off) bytes per step without further loads
+    const uint32_t pat = ((uint32_t)lane < off) ? (uint32_t)o.ring[(pos - off + (uint32_t)lane) & BD_MASK] : 0u;
+    const uint32_t M = 65536u / off + 1u;
+    const uint32_t reps = (64u * M) >> 16, G = reps * off;
+    const uint32_t i_mod = (uint32_t)lane - (((uint32_t)lane * M) >> 16) * off;
+    const uint32_t val = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(i_mod << 2), (int)pat);
+    lu8* d = o.ring + (pos & BD_MASK);
+    const uint32_t head = len < 256u ? len : 128u;         // long runs switch to 16-byte copies below
+    while (done < head) {
+      const uint32_t chunk = head - done < G ? head - done : G;
+      if ((uint32_t)lane < chunk) d[done + lane] = (uint8_t)val;
+      done += chunk;
+    }
+    if (done >= len) return;
+    LDS_ORDER();
+    off_e = G;                                             // the prefix written so far is periodic with period off | G
+  }
+  while (done < len) {
+    const uint32_t rem = len - done;
+    while (off_e < 1024u && 2u * off_e <= off + done) off_e *= 2u;   // history grew: lengthen the stride
+    uint32_t chunk = rem < 1024u ? rem : 1024u;
+    if (chunk > off_e) chunk = off_e;
+    hist_copy(o, pos + done, pos + done - off_e, chunk, W > pos + done ? W : pos + done, lane);
+    LDS_ORDER();
+    done += chunk;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// resumable LZ4 block decoder of one plane (rules of lz4.c:2215-2445 as in lz4_decode_wave, k_decode.hip)
+// ---------------------------------------------------------------------------------------------
+enum : uint32_t { PH_TOKEN = 0, PH_LIT = 1, PH_FINAL_LIT = 2, PH_MATCHHDR = 3, PH_MATCH = 4, PH_DONE = 5, PH_ERROR = 6, PH_RAW = 7 };
+
+struct PlaneDec {
+  Window w;
+  const gu8* in;
+  uint32_t n, cap;        // compressed size, plane size (neblock)
+  uint32_t ip, op;
+  uint32_t phase;
+  uint32_t pend_lit;      // literal bytes of the current sequence still to copy
+  uint32_t pend_ml, pend_off, mdone;   // current match: bytes left, distance, bytes already written
+  uint32_t mlnib;
+  uint32_t last_match;    // the current match is the stream's last one and its source stays in the ring: no far copy needed
+};
+
+// Batched step (see lz4_batch_step in k_decode.hip for the parse): up to 16 sequences whose tokens, literals,
+// offsets and at most one length byte lie in the 64 stream bytes at ip, accepted only while their output stays
+// inside the slice (`limit`).  Literals go to the ring in one scattered byte store; short matches whose source is in
+// the ring, does not wrap and lies before the step's output are copied by 4 lanes each; the rest in stream order.
+__device__ __forceinline__ uint32_t lz4_batch_step_ring(const Window& w, const PlaneOut& o, volatile BAMD_LAS uint32_t* scr, uint32_t& ip, uint32_t& op,
+                                                        uint32_t cap, uint32_t limit, int lane) {
+  const uint32_t B = w.gather_bytes(ip);
+  const uint32_t ll = B >> 4, mlc = B & 15u;
+  const uint32_t offpos = (uint32_t)lane + 1u + ll;
+  const uint32_t o_lo = bperm(offpos & 63u, B), o_hi = bperm((offpos + 1u) & 63u, B), e1 = bperm((offpos + 2u) & 63u, B);
+  const bool has_ext = mlc == 15u;
+  const uint32_t ml = has_ext ? 19u + e1 : mlc + 4u;
+  const uint32_t size = 3u + ll + (has_ext ? 1u : 0u);
+  const bool complete = ll != 15u && !(has_ext && e1 == 255u) && (uint32_t)lane + size <= 64u;
+  const uint32_t off = o_lo | (o_hi << 8);
+  const uint32_t nxt = complete ? (uint32_t)lane + size : 64u;
+  const uint32_t J0 = nxt;
+  const uint32_t J1 = hop(J0, J0), J2 = hop(J1, J1), J3 = hop(J2, J2);
+  uint32_t c = 0;
+  { const uint32_t t = hop(J0, c); c = (lane & 1) ? t : c; }
+  { const uint32_t t = hop(J1, c); c = (lane & 2) ? t : c; }
+  { const uint32_t t = hop(J2, c); c = (lane & 4) ? t : c; }
+  { const uint32_t t = hop(J3, c); c = (lane & 8) ? t : c; }
+  const uint32_t pk = bperm(c & 63u, ll | (ml << 4) | ((complete ? 1u : 0u) << 13) | (nxt << 14));
+  const uint32_t off_r = bperm(c & 63u, off);
+  const uint32_t ll_r = pk & 15u, ml_r = (pk >> 4) & 0x1ffu, nxt_r = pk >> 14;
+  const bool valid = lane < (int)BATCH_MAXSEQ && c < 64u && ((pk >> 13) & 1u);
+  const uint32_t tot_r = valid ? ll_r + ml_r : 0u;
+  uint32_t incl = tot_r;
+  incl += row_shr<1>(incl); incl += row_shr<2>(incl); incl += row_shr<4>(incl); incl += row_shr<8>(incl);
+  const uint32_t excl = incl - tot_r;
+  const uint32_t mrel_r = excl + ll_r;
+  const bool ok = valid && off_r != 0u && off_r <= op + mrel_r && op + excl + tot_r + 12u <= cap && op + excl + tot_r <= limit;
+  const uint32_t okmask = (uint32_t)__ballot(ok) & 0xffffu;
+  const uint32_t cnt = (uint32_t)__builtin_ctz(~okmask);
+  if (cnt == 0u) return 0u;
+  const uint32_t consumed = (uint32_t)__builtin_amdgcn_readlane((int)nxt_r, (int)(cnt - 1u));
+  const uint32_t acc = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(cnt - 1u));
+  const uint32_t W = op + acc;                                  // ring frontier once this step's literals are out
+  // ---- literals of every accepted sequence: one scattered byte store ----
+  scr[lane] = 0u;
+  if ((uint32_t)lane < cnt) scr[c] = 0x80000000u | excl | (ll_r << 16);
+  const uint64_t mask = __ballot(scr[lane] >> 31);
+  {
+    const uint64_t below = mask & ((2ull << lane) - 1ull);
+    const uint32_t s = 63u - (uint32_t)__builtin_clzll(below | 1ull);
+    const uint32_t inf = scr[s];
+    const uint32_t k = (uint32_t)lane - s - 1u;
+    if ((uint32_t)lane < consumed && (uint32_t)lane > s && k < ((inf >> 16) & 15u)) o.ring[(op + (inf & 0xffffu) + k) & BD_MASK] = (uint8_t)B;
+  }
+  LDS_ORDER();
+  // ---- short matches, source in the ring (not overwritten by this step), before the step's output, no wrap ----
+  const uint32_t src_r = op + mrel_r - off_r;                   // source position (valid lanes only)
+  const bool fast_r = (uint32_t)lane < cnt && ml_r <= 64u && off_r >= mrel_r + ml_r &&
+                      (int32_t)src_r >= (int32_t)W - (int32_t)BD_R && (src_r & BD_MASK) + ml_r <= BD_R;
+  {
+    const uint32_t r = (uint32_t)lane >> 2, q = (uint32_t)lane & 3u;
+    const uint32_t fA = bperm(r, fast_r ? (ml_r | 0x200u | (mrel_r << 10)) : 0u);
+    const uint32_t fB = bperm(r, off_r);
+    const uint32_t mlen = fA & 0x1ffu;
+    const bool go = (fA & 0x200u) != 0u;
+    const uint32_t dpos = op + (fA >> 10);
+    lu8* d = o.ring + (dpos & BD_MASK);
+    const lu8* sp = o.ring + ((dpos - fB) & BD_MASK);
+    const uint32_t np16 = (mlen + 15u) >> 4;
+    const bool w16 = go && mlen >= 16u && q < np16;
+    const bool w8 = go && mlen >= 8u && mlen < 16u && q < 2u;
+    const bool w4 = go && mlen < 8u && q < 2u;
+    const uint32_t po16 = (q == np16 - 1u) ? mlen - 16u : 16u * q;
+    const uint32_t po8 = q ? mlen - 8u : 0u, po4 = q ? mlen - 4u : 0u;
+    uint4 v16 = make_uint4(0, 0, 0, 0); uint64_t v8 = 0; uint32_t v4 = 0;
+    if (w16) v16 = l_ld16(sp + po16);
+    if (w8) v8 = l_ld8(sp + po8);
+    if (w4) v4 = l_ld4(sp + po4);
+    if (w16) l_st16(d + po16, v16);
+    if (w8) l_st8(d + po8, v8);
+    if (w4) l_st4(d + po4, v4);
+  }
+  LDS_ORDER();
+  // ---- everything else in stream order ----
+  uint32_t rest = (uint32_t)__ballot((uint32_t)lane < cnt && !fast_r);
+  while (rest) {
+    const int sl = __builtin_ctz(rest);
+    rest &= rest - 1u;
+    const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)ml_r, sl);
+    const uint32_t of = (uint32_t)__builtin_amdgcn_readlane((int)off_r, sl);
+    const uint32_t mr = (uint32_t)__builtin_amdgcn_readlane((int)mrel_r, sl);
+    ring_match(o, op + mr, of, m, W, lane);
+  }
+  ip += consumed;
+  op += acc;
+  return cnt;
+}
+
+__device__ __forceinline__ void lz4_plane_init(PlaneDec& s, const gu8* in, int32_t n, uint32_t cap, int lane) {
+  s.in = in; s.n = (uint32_t)(n > 0 ? n : 0); s.cap = cap; s.ip = 0; s.op = 0;
+  s.pend_lit = 0; s.pend_ml = 0; s.pend_off = 0; s.mdone = 0; s.mlnib = 0; s.last_match = 0;
+  s.phase = n > 0 ? PH_TOKEN : PH_ERROR;
+  s.w.init(in, s.n, lane);
+}
+
+// decode until op == limit (a slice end, <= cap), the stream ends or an error is found
+__device__ __forceinline__ void lz4_plane_run(PlaneDec& s, const PlaneOut& o, volatile BAMD_LAS uint32_t* scr, uint32_t limit, int lane) {
+  const uint32_t n = s.n, cap = s.cap;
+  for (;;) {
+    if (s.phase >= PH_DONE || s.op >= limit) return;
+    if (s.phase == PH_TOKEN) {
+      if (s.ip >= n) { s.phase = PH_ERROR; return; }
+      s.w.seek(s.ip);
+      const uint32_t hdr = s.w.peek32(s.ip);
+      if (s.ip + 72u <= n) {
+        const uint32_t tk = hdr & 0xffu;
+        bool try_batch = (tk >> 4) != 15u;
+        if (try_batch && (tk & 15u) == 15u) try_batch = (s.w.peek32(s.ip + 3u + (tk >> 4)) & 0xffu) != 255u;
+        if (try_batch && lz4_batch_step_ring(s.w, o, scr, s.ip, s.op, cap, limit, lane)) continue;
+      }
+      const uint32_t token = hdr & 0xffu;
+      s.ip += 1;
+      uint32_t ll = token >> 4;
+      if (ll == 15u) {
+        if (n < 15u || s.ip >= n - 15u) { s.phase = PH_ERROR; return; }
+        lz4_ext_run(s.w, s.ip, ll, cap, lane);
+        if (s.ip > n - 15u || ll > cap) { s.phase = PH_ERROR; return; }
+      }
+      s.pend_lit = ll; s.mlnib = token & 15u;
+      if (s.op + ll + 12u > cap || s.ip + ll + 8u > n) {
+        if (s.ip + ll != n || s.op + ll > cap) { s.phase = PH_ERROR; return; }
+        s.phase = PH_FINAL_LIT;
+      } else s.phase = PH_LIT;
+      continue;
+    }
+    if (s.phase == PH_LIT || s.phase == PH_FINAL_LIT) {
+      uint32_t c = s.pend_lit < limit - s.op ? s.pend_lit : limit - s.op;
+      if (c) {
+        if (c <= 64u) {
+          s.w.seek(s.ip);
+          if (s.ip + c <= s.w.base + 512u) {
+            const uint32_t v = s.w.gather_bytes(s.ip);
+            if ((uint32_t)lane < c) o.ring[(s.op + (uint32_t)lane) & BD_MASK] = (uint8_t)v;
+          } else ring_put_global(o, s.op, s.in + s.ip, c, lane);
+        } else ring_put_global_long(o, s.op, s.in + s.ip, c, lane);
+        LDS_ORDER();
+        s.ip += c; s.op += c; s.pend_lit -= c;
+      }
+      if (s.pend_lit) return;                       // slice full
+      s.phase = (s.phase == PH_FINAL_LIT) ? PH_DONE : PH_MATCHHDR;
+      continue;
+    }
+    if (s.phase == PH_MATCHHDR) {
+      s.w.seek(s.ip);
+      const uint32_t t2 = s.w.peek32(s.ip);
+      const uint32_t off = t2 & 0xffffu;
+      s.ip += 2;
+      uint32_t ml = s.mlnib;
+      if (ml == 15u) {
+        const uint32_t s0 = (t2 >> 16) & 0xffu;
+        s.ip++; ml += s0;
+        if (s.ip > n - 4u) { s.phase = PH_ERROR; return; }
+        if (s0 == 255u) {
+          lz4_ext_run(s.w, s.ip, ml, cap, lane);
+          if (s.ip > n - 4u || ml > cap) { s.phase = PH_ERROR; return; }
+        }
+      }
+      ml += 4u;
+      if (off > s.op || s.op + ml + 5u > cap) { s.phase = PH_ERROR; return; }
+      s.pend_ml = ml; s.pend_off = off; s.mdone = 0; s.phase = PH_MATCH;
+      // the stream's last match (only the final literal run follows) whose source never leaves the ring: the plane
+      // needs no far copy from here on (nothing can ask for older history any more)
+      {
+        const uint32_t restout = cap - (s.op + ml);
+        s.w.seek(s.ip);
+        bool last = false;
+        if (restout < 15u && s.ip + 1u + restout == n) last = ((s.w.peek32(s.ip) & 0xffu) == (restout << 4));
+        s.last_match = (last && off <= BD_R - 1024u) ? 1u : 0u;
+      }
+      continue;
+    }
+    // PH_MATCH
+    {
+      const uint32_t c = s.pend_ml < limit - s.op ? s.pend_ml : limit - s.op;
+      const uint32_t off = s.pend_off;
+      // offset 0: accepted like the reference, bytes unspecified (lz4.c:2356).  A power-of-two period that divides the
+      // ring: once R bytes of the match are out the ring already holds every later byte of it - nothing to write.
+      const bool idem = (off & (off - 1u)) == 0u && off <= BD_R && s.mdone >= BD_R;
+      if (off != 0u && !idem) ring_match(o, s.op, off, c, s.op, lane);
+      s.op += c; s.pend_ml -= c; s.mdone += c;
+      if (s.pend_ml) return;
+      s.phase = PH_TOKEN;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// write-out of one slice: T rings -> element-major destination (blosc/shuffle-generic.h:61-81)
+// ---------------------------------------------------------------------------------------------
+template <int T>
+__device__ __forceinline__ void slice_writeout(const lu8* rings, gu8* dst, uint32_t p0, uint32_t p1, int wave, int lane) {
+  // positions [p0, p1) of every plane; steps of 256 positions, lane l owns 4 consecutive positions
+  const uint32_t nfull = (p1 - p0) >> 8;
+  for (uint32_t st = (uint32_t)wave; st < nfull; st += (uint32_t)T) {
+    const uint32_t p = p0 + (st << 8) + 4u * (uint32_t)lane;
+    Rows<T> x;
+#pragma unroll
+    for (int j = 0; j < T; j++) x.r[j] = *(const BAMD_LAS uint32_t*)(rings + (uint32_t)j * BD_R + (p & BD_MASK));
+    unshuffle_store<T>(dst, p - 4u * (uint32_t)lane, lane, x);
+  }
+  // fewer than 256 positions left (only when the plane size is not a multiple of 256): byte by byte, wave 0
+  const uint32_t tail0 = p0 + (nfull << 8);
+  if (wave == 0)
+    for (uint32_t k = tail0 * T + (uint32_t)lane; k < p1 * T; k += 64u) {
+      const uint32_t el = k / T, j = k - el * T;
+      dst[k] = rings[j * BD_R + (el & BD_MASK)];
+    }
+}
+
+// One block.  Slice k occupies ring half k & 1 (R = 2 S), so ONE barrier per slice is enough: a wave that has
+// written out its share of slice k goes on decoding slice k + 1 into the other half while slower waves still read
+// half k & 1; nobody writes that half again before the barrier of slice k + 1, which every wave reaches only after
+// its share of write-out k.  Between blocks the ticket broadcast supplies the barrier.
+template <int T>
+__device__ __forceinline__ void decode_block(StreamDesc* sd, const ChunkDesc* c, const BlockDesc* b, int32_t* status, lu8* rings,
+                                             volatile BAMD_LAS uint32_t* scr, gu8* far_wg, int wave, int lane) {
+  const uint32_t bsize = uni((uint32_t)b->bsize), neblock = bsize / (uint32_t)T;
+  const int32_t csize = (int32_t)uni((uint32_t)sd->in_size);
+  const gu8* in = uni_ptr(as_global(sd->in));
+  gu8* dst = uni_ptr(as_global(c->dst)) + (size_t)uni((uint32_t)b->blk) * (size_t)uni((uint32_t)c->blocksize);
+  PlaneOut o;
+  o.ring = rings + (uint32_t)wave * BD_R;
+  o.far = far_wg + (size_t)wave * neblock;
+  o.flushed = 0;
+  PlaneDec s;
+  const bool raw = csize == (int32_t)neblock;                  // split stored raw (blosc/blosc.c:773-776)
+  if (raw) { s.phase = PH_RAW; s.op = 0; s.cap = neblock; s.in = in; s.last_match = 1; }
+  else lz4_plane_init(s, in, csize, neblock, lane);
+  const uint32_t nsl = (neblock + BD_S - 1u) / BD_S;
+  for (uint32_t k = 0; k < nsl; k++) {
+    const uint32_t p0 = k * BD_S, p1 = p0 + BD_S < neblock ? p0 + BD_S : neblock;
+    o.flushed = p0;
+    if (raw) { ring_put_global_long(o, p0, in + p0, p1 - p0, lane); s.op = p1; }
+    else lz4_plane_run(s, o, scr, p1, lane);
+    __syncthreads();
+    slice_writeout<T>(rings, dst, p0, p1, wave, lane);
+    // this wave's own plane, plane-major, for its own far matches of later slices (same wave stores and loads)
+    if (!s.last_match && p1 < neblock) {
+      const lu8* r = o.ring + (p0 & BD_MASK);
+      for (uint32_t q = 16u * (uint32_t)lane; q < p1 - p0; q += 1024u) g_st16(o.far + p0 + q, l_ld16(r + q));
+    }
+  }
+  const bool good = raw || (s.phase == PH_DONE && s.op == neblock);
+  if (lane == 0) {
+    sd->result = good ? (int32_t)neblock : -1;
+    if (!good) atomicMin(&status[uni((uint32_t)sd->chunk)], (int32_t)ST_BADCODEC);      // blosc.c:780-782
+  }
+}
+
+constexpr int BD_WG_PER_CU = 2;
+// LDS per workgroup: T rings + 256 bytes of step scratch per wave + the ticket word
+template <int T>
+constexpr uint32_t bd_lds_bytes() { return (uint32_t)T * BD_R + (uint32_t)T * 256u + 64u; }
+
+// Persistent workgroups; `blist` holds the global indices of the blocks to decode (engine.hip: blocks of fused
+// byte-shuffle chunks that are split into T LZ4 streams), `far` one area of `far_stride` bytes per workgroup.
+template <int T>
+__global__ __launch_bounds__(64 * T, 4) void k_decode_blocks(StreamDesc* __restrict__ streams, int32_t* __restrict__ status,
+                                                          uint32_t* __restrict__ ticket, const int32_t* __restrict__ blist, uint32_t nlist,
+                                                          const ChunkDesc* __restrict__ chunks, const BlockDesc* __restrict__ blocks,
+                                                          uint8_t* __restrict__ far, size_t far_stride, uint32_t* __restrict__ done) {
+  __shared__ __attribute__((aligned(16))) uint8_t bd_lds[bd_lds_bytes<T>()];   // static: 66 KiB for T = 8 (gfx950: up to 160 KiB per workgroup)
+  lu8* rings = (lu8*)bd_lds;
+  const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+  volatile BAMD_LAS uint32_t* scr = (volatile BAMD_LAS uint32_t*)(rings + (uint32_t)T * BD_R + (uint32_t)wave * 256u);
+  volatile BAMD_LAS uint32_t* ctl = (volatile BAMD_LAS uint32_t*)(rings + (uint32_t)T * BD_R + (uint32_t)T * 256u);
+  gu8* far_wg = as_global(far) + (size_t)blockIdx.x * far_stride;
+  uint32_t ndone = 0;
+  for (;;) {
+    if (threadIdx.x == 0) ctl[0] = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t t = uni(ctl[0]);
+    __syncthreads();                       // everybody has the ticket (and is done with the previous block's rings)
+    if (t >= nlist) break;
+    const uint32_t gb = (uint32_t)blist[t];
+    const BlockDesc* b = blocks + gb;
+    const ChunkDesc* c = chunks + uni((uint32_t)b->chunk);
+    decode_block<T>(streams + (uni((uint32_t)b->first_stream) + (uint32_t)wave), c, b, status, rings, scr, far_wg, wave, lane);
+    ndone++;
+  }
+  if (threadIdx.x == 0 && ndone) atomicAdd(done, ndone);
+}
+
+}  // namespace bamd

@@ -295,7 +295,14 @@ def test_handbuilt_blosclz_streams(pkg, oracle):
         cap = 1 << 20
         tmp = np.zeros(cap, np.uint8)
         n = oracle.orc_blosclz_decompress(ptr(s), s.size, ptr(tmp), cap)
-        assert n > 0, i
+        if n <= 0:       # e.g. a 2-byte match token as the stream's last bytes (blosclz.c:707-710): rejected by both
+            assert i >= len(streams) - 4, i
+            ch = wrap_stream_as_chunk(s, 4096, 0)
+            r0, _ = pkg.decompress(ch, 4096)
+            ro, _ = orc_decompress(oracle, ch, 4096)
+            if not (r0 < 0 and ro < 0):
+                bad.append((i, "rejected stream", r0, ro))
+            continue
         chunk = wrap_stream_as_chunk(s, n, 0)
         r, out = pkg.decompress(chunk, n)
         if r != n or not np.array_equal(out, tmp[:n]):
