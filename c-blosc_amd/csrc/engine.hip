@@ -219,8 +219,11 @@ static dim3 grid1(size_t n, int per) { return dim3((unsigned)((n + per - 1) / pe
 // running it as work of the encode / decode kernels
 // BLOSC_AMD_SPANS=0: decoded periodic planes go through the scratch like every other plane
 static bool span_enabled() { static const bool on = !(getenv("BLOSC_AMD_SPANS") && atoi(getenv("BLOSC_AMD_SPANS")) == 0); return on; }
-// BLOSC_AMD_BLOCKDEC=0: split byte-shuffled LZ4 blocks go through k_decode_streams + scratch like everything else
-static bool blockdec_enabled() { static const bool on = !(getenv("BLOSC_AMD_BLOCKDEC") && atoi(getenv("BLOSC_AMD_BLOCKDEC")) == 0); return on; }
+// BLOSC_AMD_BLOCKDEC=1: split byte-shuffled LZ4 blocks are decoded by k_decode_blocks (one workgroup per block, planes
+// in LDS rings, no scratch image in HBM) instead of k_decode_streams.  Off by default: it moves a third of the bytes
+// but its concurrency is bound by LDS (8 KiB of ring per plane with real LZ work) and it is slower on every SURVEY §8d
+// data set so far (profiles/r02_b_block_decoder.md); the whole GPU suite passes with it on (tests/test_gpu_modes.py).
+static bool blockdec_enabled() { static const bool on = getenv("BLOSC_AMD_BLOCKDEC") && atoi(getenv("BLOSC_AMD_BLOCKDEC")) != 0; return on; }
 static bool fuse_enabled() { static const bool on = !(getenv("BLOSC_AMD_FUSE") && atoi(getenv("BLOSC_AMD_FUSE")) == 0); return on; }
 
 int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* results, bool device_ptrs,
@@ -541,8 +544,9 @@ struct DecodeLaunch {
   const int32_t* d_qlist; const int32_t* d_qoff;   // per-XCD stream queues
   size_t nblk, nstr; int nchunks;
   bool any_shuf, any_bit, any_copy; int tiles_shuf, tiles_bit;
-  // k_decode_blocks: block lists per typesize (4, 8), one far area per persistent workgroup
-  const int32_t* d_blist[2]; uint32_t nlist[2]; uint32_t* d_bticket; uint8_t* d_far; size_t far_stride;
+  // k_decode_blocks: per typesize group g (0: 4, 1: 8) the candidate blocks, the two lists k_classify_blocks sorts them
+  // into (2 x nlist[g] entries), counters cnt[2g + v] / tickets [4 + 2g + v] in d_bctl, one far area per workgroup
+  const int32_t* d_bcand[2]; int32_t* d_blists[2]; uint32_t nlist[2]; uint32_t* d_bctl; uint32_t* d_skind; uint8_t* d_far; size_t far_stride;
   size_t nstr_queued;                              // streams left to k_decode_streams
 };
 
@@ -593,14 +597,45 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
       hipLaunchKernelGGL(k_decode_streams, dgrid, dim3(64 * DEC_WAVES), (size_t)dec_lds, stream, L.d_streams, L.d_status, L.d_ticket, L.d_qlist, L.d_qoff, L.d_chunks, L.d_blocks, L.d_blkdone, L.d_spans, L.d_pat, L.d_cost, st.single_queue ? 1 : 0);
 #endif
     }
-    for (int which = 0; which < 2; which++) {
-      if (!L.nlist[which]) continue;
-      ProfScope ps(st, stream, "k_decode_blocks");
-      const unsigned grid = (unsigned)std::min<size_t>((size_t)st.cus * BD_WG_PER_CU * (which ? 1 : 2), L.nlist[which]);
-      if (which) hipLaunchKernelGGL(k_decode_blocks<8>, dim3(grid), dim3(512), 0, stream, L.d_streams, L.d_status, L.d_bticket + 1, L.d_blist[1], L.nlist[1],
-                                    L.d_chunks, L.d_blocks, L.d_far, L.far_stride, L.d_cost + 258);
-      else hipLaunchKernelGGL(k_decode_blocks<4>, dim3(grid), dim3(256), 0, stream, L.d_streams, L.d_status, L.d_bticket, L.d_blist[0], L.nlist[0],
-                              L.d_chunks, L.d_blocks, L.d_far, L.far_stride, L.d_cost + 258);
+    for (int g = 0; g < 2; g++) {
+      if (!L.nlist[g]) continue;
+      {
+        ProfScope ps(st, stream, "k_classify_blocks");
+        hipLaunchKernelGGL(k_classify_blocks, grid1(L.nlist[g], 64), dim3(64), 0, stream, L.d_streams, L.d_blocks, L.d_bcand[g], L.nlist[g], L.d_skind,
+                           L.d_blists[g], L.d_bctl + 2 * g);
+      }
+      // the lists are filled on the device: both variants get a full persistent grid (workgroups of an empty list leave at once)
+      for (int v = 0; v < (g ? 2 : 1); v++) {
+        ProfScope ps(st, stream, v ? "k_decode_blocks8" : "k_decode_blocks");   // 4 / 8 waves per block (<= 4 / more planes with real LZ work)
+        const int W = v ? 8 : 4;
+        const unsigned grid = (unsigned)std::min<size_t>((size_t)st.cus * (BD_WAVES_PER_CU / W), L.nlist[g]);
+        uint32_t* d_prof = nullptr;
+#ifdef BAMD_PROFILE_DECODE
+        const size_t profn = (size_t)grid * W * 16;
+        if (getenv("BLOSC_AMD_BD_PROFILE")) { (void)hipMalloc((void**)&d_prof, profn * 4); (void)hipMemsetAsync(d_prof, 0, profn * 4, stream); }
+#define BD_PROF_ARG , d_prof
+#else
+#define BD_PROF_ARG
+#endif
+        const int32_t* lst = L.d_blists[g] + (size_t)v * L.nlist[g];
+        uint32_t* tick = L.d_bctl + 4 + 2 * g + v;
+        const uint32_t* cnt = L.d_bctl + 2 * g + v;
+        if (g == 0) hipLaunchKernelGGL((k_decode_blocks<4, 4>), dim3(grid), dim3(256), 0, stream, L.d_streams, L.d_skind, L.d_status, tick, lst, cnt, L.d_chunks, L.d_blocks, L.d_far, L.far_stride, L.d_cost + 258 BD_PROF_ARG);
+        else if (v == 0) hipLaunchKernelGGL((k_decode_blocks<8, 4>), dim3(grid), dim3(256), 0, stream, L.d_streams, L.d_skind, L.d_status, tick, lst, cnt, L.d_chunks, L.d_blocks, L.d_far, L.far_stride, L.d_cost + 258 BD_PROF_ARG);
+        else hipLaunchKernelGGL((k_decode_blocks<8, 8>), dim3(grid), dim3(512), 0, stream, L.d_streams, L.d_skind, L.d_status, tick, lst, cnt, L.d_chunks, L.d_blocks, L.d_far, L.far_stride, L.d_cost + 258 BD_PROF_ARG);
+#undef BD_PROF_ARG
+#ifdef BAMD_PROFILE_DECODE
+        if (d_prof) {
+          std::vector<uint32_t> h(profn);
+          (void)hipStreamSynchronize(stream);
+          (void)hipMemcpy(h.data(), d_prof, profn * 4, hipMemcpyDeviceToHost);
+          char nm[512]; snprintf(nm, sizeof nm, "%s.T%dW%d", getenv("BLOSC_AMD_BD_PROFILE"), g ? 8 : 4, W);
+          FILE* f = fopen(nm, "wb");
+          if (f) { fwrite(h.data(), 4, h.size(), f); fclose(f); }
+          (void)hipFree(d_prof);
+        }
+#endif
+      }
     }
     if (L.any_zstd) {
       ProfScope ps(st, stream, "k_zstd_streams");
@@ -674,7 +709,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   std::vector<int32_t> blist[2];
   size_t nstr_lds = 0;
   const size_t far_stride = pick_lds_blocks(chunks, blocks, blist, &nstr_lds);
-  const size_t far_wgs = (size_t)st.cus * BD_WG_PER_CU * 2;       // the typesize-4 kernel runs twice as many (half-size) workgroups
+  const size_t far_wgs = (size_t)st.cus * (BD_WAVES_PER_CU / 4);  // most workgroups any variant launches
 
   Carver cv;
   const size_t o_chunks = cv.take(sizeof(ChunkDesc) * (size_t)n);
@@ -682,7 +717,9 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   const size_t o_streams = cv.take(sizeof(StreamDesc) * (nstr ? nstr : 1));
   const size_t o_status = cv.take(sizeof(int32_t) * (size_t)n + 64 + sizeof(uint32_t) * (nblk ? nblk : 1));   // + 8 tickets + per-block arrival counters
   const size_t o_queues = cv.take(sizeof(int32_t) * (9 + (nstr ? nstr : 1)));
-  const size_t o_blist = cv.take(sizeof(int32_t) * (blist[0].size() + blist[1].size() + 1) + 64);   // 2 tickets + the two block lists
+  const size_t nbl = blist[0].size() + blist[1].size();
+  const size_t o_blist = cv.take(sizeof(int32_t) * (3 * nbl + 1) + 64);   // counters + tickets | per group: candidates, two sorted lists
+  const size_t o_skind = cv.take(sizeof(uint32_t) * (nstr ? nstr : 1));
   const size_t o_cost = cv.take(sizeof(uint32_t) * kCostWords);
   const size_t o_spans = cv.take(8 * (nstr ? nstr : 1));
   const size_t o_pat = cv.take(span_enabled() ? (size_t)2048 * (nstr ? nstr : 1) : 256);
@@ -720,7 +757,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   const size_t p_status = pc.take(sizeof(int32_t) * (size_t)n);
   const size_t p_queues = pc.take(sizeof(int32_t) * queues.size());
   const size_t p_cost = pc.take(sizeof(uint32_t) * kCostWords);
-  const size_t p_blist = pc.take(sizeof(int32_t) * (blist[0].size() + blist[1].size() + 1) + 64);
+  const size_t p_blist = pc.take(sizeof(int32_t) * (nbl + 1) + 64);
   if (st.pin.ensure(pc.off)) return -1;
   uint8_t* P = st.pin.base;
   memcpy(P + p_chunks, chunks.data(), sizeof(ChunkDesc) * (size_t)n);
@@ -729,7 +766,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   memset(P + p_blist, 0, 64);
   if (!blist[0].empty()) memcpy(P + p_blist + 64, blist[0].data(), sizeof(int32_t) * blist[0].size());
   if (!blist[1].empty()) memcpy(P + p_blist + 64 + sizeof(int32_t) * blist[0].size(), blist[1].data(), sizeof(int32_t) * blist[1].size());
-  HIP_TRY(hipMemcpyAsync(D + o_blist, P + p_blist, sizeof(int32_t) * (blist[0].size() + blist[1].size()) + 64, hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipMemcpyAsync(D + o_blist, P + p_blist, sizeof(int32_t) * nbl + 64, hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemcpyAsync(D + o_chunks, P + p_chunks, sizeof(ChunkDesc) * (size_t)n, hipMemcpyHostToDevice, stream));
   if (nblk) HIP_TRY(hipMemcpyAsync(D + o_blocks, P + p_blocks, sizeof(BlockDesc) * nblk, hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemcpyAsync(D + o_queues, P + p_queues, sizeof(int32_t) * queues.size(), hipMemcpyHostToDevice, stream));
@@ -746,8 +783,10 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   L.d_zticket = (uint32_t*)(D + o_zticket);
   if (L.any_zstd) HIP_TRY(hipMemsetAsync(D + o_zticket, 0, 64, stream));
   L.nblk = nblk; L.nstr = nstr; L.nchunks = n;
-  L.d_bticket = (uint32_t*)(D + o_blist);
-  L.d_blist[0] = (const int32_t*)(D + o_blist + 64); L.d_blist[1] = L.d_blist[0] + blist[0].size();
+  L.d_bctl = (uint32_t*)(D + o_blist);
+  L.d_bcand[0] = (const int32_t*)(D + o_blist + 64); L.d_bcand[1] = L.d_bcand[0] + blist[0].size();
+  L.d_blists[0] = (int32_t*)(D + o_blist + 64) + nbl; L.d_blists[1] = L.d_blists[0] + 2 * blist[0].size();
+  L.d_skind = (uint32_t*)(D + o_skind);
   L.nlist[0] = (uint32_t)blist[0].size(); L.nlist[1] = (uint32_t)blist[1].size();
   L.d_far = D + o_far; L.far_stride = far_stride; L.nstr_queued = nstr - nstr_lds;
   if (launch_decode(st, L, stream)) return -1;

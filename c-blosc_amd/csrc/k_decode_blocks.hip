@@ -29,6 +29,11 @@ namespace bamd {
 constexpr uint32_t BD_R = 8192u;          // ring bytes per plane (power of two)
 constexpr uint32_t BD_S = BD_R / 2u;      // slice: plane positions between two barriers
 constexpr uint32_t BD_MASK = BD_R - 1u;
+// History within BD_NEAR bytes of the write frontier is read from the ring, anything older from the far copy.  The gap
+// to R keeps a history chunk (<= 1024 bytes + one 16-byte piece + the slack of a step's literal scatter) from
+// overwriting ring slots that lanes of the SAME chunk still have to read: lanes of one chunk take different code paths
+// (16-byte pieces, byte loops) and their loads and stores are not ordered against each other.
+constexpr uint32_t BD_NEAR = BD_R - 1088u;
 
 #define BAMD_LAS __attribute__((address_space(3)))
 typedef BAMD_LAS uint8_t lu8;
@@ -42,6 +47,26 @@ __device__ __forceinline__ uint64_t l_ld8(const lu8* p) { return *(const BAMD_LA
 __device__ __forceinline__ void l_st8(lu8* p, uint64_t v) { *(BAMD_LAS u64una*)p = v; }
 __device__ __forceinline__ uint32_t l_ld4(const lu8* p) { return *(const BAMD_LAS u32una*)p; }
 __device__ __forceinline__ void l_st4(lu8* p, uint32_t v) { *(BAMD_LAS u32una*)p = v; }
+
+// Optional phase profiling (-DBAMD_PROFILE_DECODE -> libblosc_amd_prof.so, scripts/bd_phase.py): wave-uniform counters,
+// cycles from s_memtime.  slots: 0 batch steps, 1 sequences in them, 2 of those done one by one ("rest"), 3 tokens parsed by
+// the scalar path, 4 cycles write-out + far copy, 5 history chunks with a far piece, 6 cycles window seek (fetch waited for),
+// 7 cycles parse + chain of a step, 8 cycles decoding, 9 waiting at the slice barrier, 10 cycles of a step up to its rest loop,
+// 11 rest loops, 12 far chunks, 13 scalar match phase
+#ifdef BAMD_PROFILE_DECODE
+struct BdProf { uint32_t c[16]; };
+#define BDP_ARG , BdProf& bp
+#define BDP_PASS , bp
+#define BDP_ADD(i, v) bp.c[i] += (uint32_t)(v)
+#define BDP_T0(t) const uint64_t t = __builtin_amdgcn_s_memtime()
+#define BDP_LAP(i, t) bp.c[i] += (uint32_t)(__builtin_amdgcn_s_memtime() - t)
+#else
+#define BDP_ARG
+#define BDP_PASS
+#define BDP_ADD(i, v)
+#define BDP_T0(t)
+#define BDP_LAP(i, t)
+#endif
 
 // One plane's output: the LDS ring (positions [W - R, W) of the plane, W = write frontier) and the far copy
 // (positions [0, flushed), plane-major in global memory).
@@ -67,27 +92,36 @@ __device__ __forceinline__ void ring_put_global_long(const PlaneOut& o, uint32_t
 }
 
 // History chunk: plane positions [src, src + n) -> [dst, dst + n), n <= 1024, n <= dst - src (no overlap inside the
-// chunk), W = write frontier of the ring (>= dst; everything at or above W - R is still in the ring, everything
-// below is in `far` because W - R <= flushed).  16 bytes per lane; a piece that wraps around the ring end or
+// chunk), W = write frontier of the ring (>= dst; everything at or above W - BD_NEAR is read from the ring, everything
+// below from `far`: W - BD_NEAR <= flushed - 960).  16 bytes per lane; a piece that wraps around the ring end or
 // straddles the ring / far border goes byte by byte (rare).
-__device__ __forceinline__ void hist_copy(const PlaneOut& o, uint32_t dst, uint32_t src, uint32_t n, uint32_t W, int lane) {
+__device__ __forceinline__ void hist_copy(const PlaneOut& o, uint32_t dst, uint32_t src, uint32_t n, uint32_t W, int lane BDP_ARG) {
   const uint32_t off16 = 16u * (uint32_t)lane;
-  if (off16 >= n) return;
+#ifdef BAMD_PROFILE_DECODE
+  const bool anyfar = (int32_t)src < (int32_t)W - (int32_t)BD_NEAR;
+  BDP_ADD(5, anyfar ? 1 : 0);
+  BDP_T0(tfar);
+#endif
+  if (off16 < n) {
   const uint32_t q = src + off16, cnt = n - off16 < 16u ? n - off16 : 16u;
-  const int32_t lo = (int32_t)W - (int32_t)BD_R;           // first position still in the ring (may be negative)
+  const int32_t lo = (int32_t)W - (int32_t)BD_NEAR;        // first position read from the ring (may be negative); older ones come from `far`
   lu8* d = o.ring + ((dst + off16) & BD_MASK);
   const uint32_t qi = q & BD_MASK;
-  if (cnt == 16u && (int32_t)q >= lo && qi <= BD_R - 16u) { l_st16(d, l_ld16(o.ring + qi)); return; }
-  if (cnt == 16u && (int32_t)(q + 16u) <= lo) { l_st16(d, g_ld16(o.far + q)); return; }
-  for (uint32_t b = 0; b < cnt; b++) {
+  if (cnt == 16u && (int32_t)q >= lo && qi <= BD_R - 16u) l_st16(d, l_ld16(o.ring + qi));
+  else if (cnt == 16u && (int32_t)(q + 16u) <= lo) l_st16(d, g_ld16(o.far + q));
+  else for (uint32_t b = 0; b < cnt; b++) {
     const uint32_t qq = q + b;
     d[b] = ((int32_t)qq >= lo) ? o.ring[qq & BD_MASK] : (uint8_t)o.far[qq];
   }
+  }
+#ifdef BAMD_PROFILE_DECODE
+  if (anyfar) { __builtin_amdgcn_s_waitcnt(0); BDP_LAP(12, tfar); }
+#endif
 }
 
 // LZ match out[pos + k] = out[pos - off + k], k < len, byte-wise forward semantics (lz4.c:2387-2434,
 // blosc/fastcopy.c:530-639), destination inside one slice.  All arguments wave-uniform; off >= 1, off <= pos.
-__device__ __forceinline__ void ring_match(const PlaneOut& o, uint32_t pos, uint32_t off, uint32_t len, uint32_t W, int lane) {
+__device__ __forceinline__ void ring_match(const PlaneOut& o, uint32_t pos, uint32_t off, uint32_t len, uint32_t W, int lane BDP_ARG) {
   uint32_t done = 0, off_e = off;
   if (off < 64u && off < len) {
     // short period: fetch the pattern once (always in the ring: off < 64), lane i holds pattern byte i mod off, then
@@ -113,7 +147,7 @@ __device__ __forceinline__ void ring_match(const PlaneOut& o, uint32_t pos, uint
     while (off_e < 1024u && 2u * off_e <= off + done) off_e *= 2u;   // history grew: lengthen the stride
     uint32_t chunk = rem < 1024u ? rem : 1024u;
     if (chunk > off_e) chunk = off_e;
-    hist_copy(o, pos + done, pos + done - off_e, chunk, W > pos + done ? W : pos + done, lane);
+    hist_copy(o, pos + done, pos + done - off_e, chunk, W > pos + done ? W : pos + done, lane BDP_PASS);
     LDS_ORDER();
     done += chunk;
   }
@@ -141,7 +175,8 @@ struct PlaneDec {
 // inside the slice (`limit`).  Literals go to the ring in one scattered byte store; short matches whose source is in
 // the ring, does not wrap and lies before the step's output are copied by 4 lanes each; the rest in stream order.
 __device__ __forceinline__ uint32_t lz4_batch_step_ring(const Window& w, const PlaneOut& o, volatile BAMD_LAS uint32_t* scr, uint32_t& ip, uint32_t& op,
-                                                        uint32_t cap, uint32_t limit, int lane) {
+                                                        uint32_t cap, uint32_t limit, int lane BDP_ARG) {
+  BDP_T0(tstep);
   const uint32_t B = w.gather_bytes(ip);
   const uint32_t ll = B >> 4, mlc = B & 15u;
   const uint32_t offpos = (uint32_t)lane + 1u + ll;
@@ -171,6 +206,7 @@ __device__ __forceinline__ uint32_t lz4_batch_step_ring(const Window& w, const P
   const bool ok = valid && off_r != 0u && off_r <= op + mrel_r && op + excl + tot_r + 12u <= cap && op + excl + tot_r <= limit;
   const uint32_t okmask = (uint32_t)__ballot(ok) & 0xffffu;
   const uint32_t cnt = (uint32_t)__builtin_ctz(~okmask);
+  BDP_LAP(7, tstep);
   if (cnt == 0u) return 0u;
   const uint32_t consumed = (uint32_t)__builtin_amdgcn_readlane((int)nxt_r, (int)(cnt - 1u));
   const uint32_t acc = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(cnt - 1u));
@@ -190,7 +226,7 @@ __device__ __forceinline__ uint32_t lz4_batch_step_ring(const Window& w, const P
   // ---- short matches, source in the ring (not overwritten by this step), before the step's output, no wrap ----
   const uint32_t src_r = op + mrel_r - off_r;                   // source position (valid lanes only)
   const bool fast_r = (uint32_t)lane < cnt && ml_r <= 64u && off_r >= mrel_r + ml_r &&
-                      (int32_t)src_r >= (int32_t)W - (int32_t)BD_R && (src_r & BD_MASK) + ml_r <= BD_R;
+                      (int32_t)src_r >= (int32_t)W - (int32_t)BD_NEAR && (src_r & BD_MASK) + ml_r <= BD_R;
   {
     const uint32_t r = (uint32_t)lane >> 2, q = (uint32_t)lane & 3u;
     const uint32_t fA = bperm(r, fast_r ? (ml_r | 0x200u | (mrel_r << 10)) : 0u);
@@ -217,14 +253,21 @@ __device__ __forceinline__ uint32_t lz4_batch_step_ring(const Window& w, const P
   LDS_ORDER();
   // ---- everything else in stream order ----
   uint32_t rest = (uint32_t)__ballot((uint32_t)lane < cnt && !fast_r);
+#ifdef BAMD_PROFILE_DECODE
+  __builtin_amdgcn_s_waitcnt(0);
+  bp.c[10] += (uint32_t)(__builtin_amdgcn_s_memtime() - tstep);     // slot 10 (profile build): whole step up to the rest loop
+#endif
+  BDP_ADD(0, 1); BDP_ADD(1, cnt); BDP_ADD(2, __builtin_popcount(rest));
+  BDP_T0(trest);
   while (rest) {
     const int sl = __builtin_ctz(rest);
     rest &= rest - 1u;
     const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)ml_r, sl);
     const uint32_t of = (uint32_t)__builtin_amdgcn_readlane((int)off_r, sl);
     const uint32_t mr = (uint32_t)__builtin_amdgcn_readlane((int)mrel_r, sl);
-    ring_match(o, op + mr, of, m, W, lane);
+    ring_match(o, op + mr, of, m, W, lane BDP_PASS);
   }
+  BDP_LAP(11, trest);
   ip += consumed;
   op += acc;
   return cnt;
@@ -238,20 +281,26 @@ __device__ __forceinline__ void lz4_plane_init(PlaneDec& s, const gu8* in, int32
 }
 
 // decode until op == limit (a slice end, <= cap), the stream ends or an error is found
-__device__ __forceinline__ void lz4_plane_run(PlaneDec& s, const PlaneOut& o, volatile BAMD_LAS uint32_t* scr, uint32_t limit, int lane) {
+__device__ __forceinline__ void lz4_plane_run(PlaneDec& s, const PlaneOut& o, volatile BAMD_LAS uint32_t* scr, uint32_t limit, int lane BDP_ARG) {
   const uint32_t n = s.n, cap = s.cap;
   for (;;) {
     if (s.phase >= PH_DONE || s.op >= limit) return;
     if (s.phase == PH_TOKEN) {
       if (s.ip >= n) { s.phase = PH_ERROR; return; }
+      BDP_T0(tsk);
       s.w.seek(s.ip);
       const uint32_t hdr = s.w.peek32(s.ip);
+#ifdef BAMD_PROFILE_DECODE
+      if (s.ip - s.w.base + 72u > 256u) __builtin_amdgcn_s_waitcnt(0);   // attribute the window fetch to slot 6 (the step needs `hi` only then)
+      BDP_LAP(6, tsk);
+#endif
       if (s.ip + 72u <= n) {
         const uint32_t tk = hdr & 0xffu;
         bool try_batch = (tk >> 4) != 15u;
         if (try_batch && (tk & 15u) == 15u) try_batch = (s.w.peek32(s.ip + 3u + (tk >> 4)) & 0xffu) != 255u;
-        if (try_batch && lz4_batch_step_ring(s.w, o, scr, s.ip, s.op, cap, limit, lane)) continue;
+        if (try_batch && lz4_batch_step_ring(s.w, o, scr, s.ip, s.op, cap, limit, lane BDP_PASS)) continue;
       }
+      BDP_ADD(3, 1);
       const uint32_t token = hdr & 0xffu;
       s.ip += 1;
       uint32_t ll = token >> 4;
@@ -309,7 +358,7 @@ __device__ __forceinline__ void lz4_plane_run(PlaneDec& s, const PlaneOut& o, vo
         s.w.seek(s.ip);
         bool last = false;
         if (restout < 15u && s.ip + 1u + restout == n) last = ((s.w.peek32(s.ip) & 0xffu) == (restout << 4));
-        s.last_match = (last && off <= BD_R - 1024u) ? 1u : 0u;
+        s.last_match = (last && off <= BD_NEAR - 1024u) ? 1u : 0u;
       }
       continue;
     }
@@ -320,7 +369,9 @@ __device__ __forceinline__ void lz4_plane_run(PlaneDec& s, const PlaneOut& o, vo
       // offset 0: accepted like the reference, bytes unspecified (lz4.c:2356).  A power-of-two period that divides the
       // ring: once R bytes of the match are out the ring already holds every later byte of it - nothing to write.
       const bool idem = (off & (off - 1u)) == 0u && off <= BD_R && s.mdone >= BD_R;
-      if (off != 0u && !idem) ring_match(o, s.op, off, c, s.op, lane);
+      BDP_T0(tm);
+      if (off != 0u && !idem) ring_match(o, s.op, off, c, s.op, lane BDP_PASS);
+      BDP_LAP(13, tm);
       s.op += c; s.pend_ml -= c; s.mdone += c;
       if (s.pend_ml) return;
       s.phase = PH_TOKEN;
@@ -329,17 +380,100 @@ __device__ __forceinline__ void lz4_plane_run(PlaneDec& s, const PlaneOut& o, vo
 }
 
 // ---------------------------------------------------------------------------------------------
-// write-out of one slice: T rings -> element-major destination (blosc/shuffle-generic.h:61-81)
+// plane kinds.  Only planes that really need sequential LZ work get a wave and a ring:
+//   PK_RING      decoded by a wave into an LDS ring (everything above)
+//   PK_RAW       the split was stored raw (csize == neblock, blosc/blosc.c:773-776): the write-out reads the bytes
+//                straight from the compressed chunk
+//   PK_PERIODIC  the whole stream is "some literals, ONE match with a power-of-two distance <= 256 that runs to the
+//                last literals" (constant and short-period byte planes: 4 of the 8 planes of bench19): the plane is a
+//                256-byte pattern; the write-out reads the pattern, the bytes in front of the periodic part and the
+//                final literals are patched in afterwards
+// k_classify_blocks decides per stream (it verifies every byte of such a stream, so the shortcut produces exactly what
+// the LZ4 decoder would) and sorts the blocks into two lists by their number of PK_RING planes: <= 4 and more.
+// ---------------------------------------------------------------------------------------------
+enum : uint32_t { PK_RING = 0, PK_RAW = 1, PK_PERIODIC = 2 };
+constexpr uint32_t BD_PAT = 256u;          // pattern bytes per periodic plane: the distance must divide it
+// skind word of a PERIODIC plane: kind | log2(distance) << 8 | final literals << 12 | index of the first literal << 16 | literal count << 20
+__device__ __forceinline__ uint32_t pk_off(uint32_t k) { return 1u << ((k >> 8) & 15u); }
+__device__ __forceinline__ uint32_t pk_r(uint32_t k) { return (k >> 12) & 15u; }
+__device__ __forceinline__ uint32_t pk_ls(uint32_t k) { return (k >> 16) & 15u; }
+__device__ __forceinline__ uint32_t pk_ll(uint32_t k) { return k >> 20; }
+
+__device__ __forceinline__ uint32_t classify_stream(const gu8* in, int32_t n_, uint32_t neblock) {
+  if (n_ == (int32_t)neblock) return PK_RAW;
+  if (n_ < 16) return PK_RING;
+  const uint32_t n = (uint32_t)n_;
+  const uint32_t t0 = in[0];
+  if ((t0 & 15u) != 15u) return PK_RING;
+  uint32_t ll = t0 >> 4, ls = 1u;                            // literal count (lz4.c:2240-2250), index of the first literal
+  if (ll == 15u) {
+    for (;;) {
+      if (ls >= 5u || ls + 16u > n) return PK_RING;
+      const uint32_t e = in[ls++];
+      ll += e;
+      if (e != 255u) break;
+    }
+  }
+  if (ll == 0u || ll > 1023u || ls + ll + 8u > n) return PK_RING;
+  const uint32_t off = (uint32_t)in[ls + ll] | ((uint32_t)in[ls + ll + 1u] << 8);
+  if (off == 0u || off > ll || off > BD_PAT || (off & (off - 1u))) return PK_RING;
+  const uint32_t e0 = ls + ll + 2u;                          // first match-length extension byte
+  for (uint32_t r = 5u; r <= 14u; r++) {                    // final literal run (lz4.c:2423: a match ends >= 5 bytes before the end)
+    if (neblock < ll + r + 19u) break;
+    const uint32_t ml = neblock - ll - r, k = (ml - 19u) / 255u, x = (ml - 19u) % 255u;
+    if (n != e0 + k + 2u + r) continue;
+    if (in[e0 + k] != x || in[e0 + k + 1u] != (r << 4)) continue;
+    bool all255 = true;
+    for (uint32_t i = 0; i < k; i++) if (in[e0 + i] != 255u) { all255 = false; break; }
+    if (!all255) continue;
+    return PK_PERIODIC | ((uint32_t)__builtin_ctz(off) << 8) | (r << 12) | (ls << 16) | (ll << 20);
+  }
+  return PK_RING;
+}
+
+// one thread per candidate block (blist: the blocks engine.hip marked BLK_LDS); out: skind[stream], lists[2][nlist] and
+// their counters cnt[0..1] (cnt[v] blocks in lists + v * nlist)
+__global__ void k_classify_blocks(const StreamDesc* __restrict__ streams, const BlockDesc* __restrict__ blocks, const int32_t* __restrict__ blist,
+                                  uint32_t nlist, uint32_t* __restrict__ skind, int32_t* __restrict__ lists, uint32_t* __restrict__ cnt) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nlist) return;
+  const int32_t gb = blist[t];
+  const BlockDesc b = blocks[gb];
+  const uint32_t neblock = (uint32_t)b.bsize / (uint32_t)b.nstreams;
+  uint32_t nring = 0;
+  for (int j = 0; j < b.nstreams; j++) {
+    const StreamDesc& sd = streams[b.first_stream + j];
+    uint32_t k = PK_RING;
+    if (sd.in_size >= 0) k = classify_stream(as_global(sd.in), sd.in_size, neblock);
+    skind[b.first_stream + j] = k;
+    nring += (k & 255u) == PK_RING;
+  }
+  const uint32_t v = nring > 4u ? 1u : 0u;
+  lists[(size_t)v * nlist + atomicAdd(&cnt[v], 1u)] = gb;
+}
+
+// ---------------------------------------------------------------------------------------------
+// write-out of one slice: T planes -> element-major destination (blosc/shuffle-generic.h:61-81)
 // ---------------------------------------------------------------------------------------------
 template <int T>
-__device__ __forceinline__ void slice_writeout(const lu8* rings, gu8* dst, uint32_t p0, uint32_t p1, int wave, int lane) {
+struct PlaneTab {            // wave-uniform description of the block's planes
+  uint32_t lbase[T];         // RING / PERIODIC: LDS byte offset of the ring / the 64-byte pattern
+  uint32_t lmask[T];         // BD_MASK / 63
+  const gu8* raw[T];         // RAW: the bytes in the compressed chunk (nullptr otherwise)
+};
+
+template <int T, int W>
+__device__ __forceinline__ void slice_writeout(const PlaneTab<T>& pt, const lu8* lds, gu8* dst, uint32_t p0, uint32_t p1, int wave, int lane) {
   // positions [p0, p1) of every plane; steps of 256 positions, lane l owns 4 consecutive positions
   const uint32_t nfull = (p1 - p0) >> 8;
-  for (uint32_t st = (uint32_t)wave; st < nfull; st += (uint32_t)T) {
+  for (uint32_t st = (uint32_t)wave; st < nfull; st += (uint32_t)W) {
     const uint32_t p = p0 + (st << 8) + 4u * (uint32_t)lane;
     Rows<T> x;
 #pragma unroll
-    for (int j = 0; j < T; j++) x.r[j] = *(const BAMD_LAS uint32_t*)(rings + (uint32_t)j * BD_R + (p & BD_MASK));
+    for (int j = 0; j < T; j++) {
+      if (pt.raw[j]) x.r[j] = g_ld4(pt.raw[j] + p);
+      else x.r[j] = *(const BAMD_LAS uint32_t*)(lds + pt.lbase[j] + (p & pt.lmask[j]));
+    }
     unshuffle_store<T>(dst, p - 4u * (uint32_t)lane, lane, x);
   }
   // fewer than 256 positions left (only when the plane size is not a multiple of 256): byte by byte, wave 0
@@ -347,82 +481,156 @@ __device__ __forceinline__ void slice_writeout(const lu8* rings, gu8* dst, uint3
   if (wave == 0)
     for (uint32_t k = tail0 * T + (uint32_t)lane; k < p1 * T; k += 64u) {
       const uint32_t el = k / T, j = k - el * T;
-      dst[k] = rings[j * BD_R + (el & BD_MASK)];
+      uint32_t v = 0;
+#pragma unroll
+      for (int jj = 0; jj < T; jj++)
+        if ((uint32_t)jj == j) v = pt.raw[jj] ? (uint32_t)pt.raw[jj][el] : (uint32_t)lds[pt.lbase[jj] + (el & pt.lmask[jj])];
+      dst[k] = (uint8_t)v;
     }
 }
 
-// One block.  Slice k occupies ring half k & 1 (R = 2 S), so ONE barrier per slice is enough: a wave that has
-// written out its share of slice k goes on decoding slice k + 1 into the other half while slower waves still read
-// half k & 1; nobody writes that half again before the barrier of slice k + 1, which every wave reaches only after
-// its share of write-out k.  Between blocks the ticket broadcast supplies the barrier.
-template <int T>
-__device__ __forceinline__ void decode_block(StreamDesc* sd, const ChunkDesc* c, const BlockDesc* b, int32_t* status, lu8* rings,
-                                             volatile BAMD_LAS uint32_t* scr, gu8* far_wg, int wave, int lane) {
+// LDS of a workgroup: W rings | W x 256 bytes of step scratch | T x 256 bytes of patterns | control words
+template <int T, int W> constexpr uint32_t bd_lds_bytes() { return (uint32_t)W * BD_R + (uint32_t)W * 256u + (uint32_t)T * BD_PAT + 64u; }
+
+// One block by W waves.  Wave w decodes the w-th PK_RING plane (waves beyond the number of such planes only help
+// with the write-out).  Slice k occupies ring half k & 1 (R = 2 S), so ONE barrier per slice is enough: a wave that
+// has written out its share of slice k goes on decoding slice k + 1 into the other half while slower waves still
+// read half k & 1; nobody writes that half again before the barrier of slice k + 1, which every wave reaches only
+// after its share of write-out k.  Between blocks the ticket broadcast supplies the barrier.
+template <int T, int W>
+__device__ __forceinline__ void decode_block(StreamDesc* sds, const uint32_t* skind, const ChunkDesc* c, const BlockDesc* b, int32_t* status,
+                                             lu8* lds, volatile BAMD_LAS uint32_t* scr, gu8* far_wg, int wave, int lane BDP_ARG) {
   const uint32_t bsize = uni((uint32_t)b->bsize), neblock = bsize / (uint32_t)T;
-  const int32_t csize = (int32_t)uni((uint32_t)sd->in_size);
-  const gu8* in = uni_ptr(as_global(sd->in));
   gu8* dst = uni_ptr(as_global(c->dst)) + (size_t)uni((uint32_t)b->blk) * (size_t)uni((uint32_t)c->blocksize);
+  // ---- plane table (every wave builds the same one) ----
+  PlaneTab<T> pt;
+  uint32_t kinds[T];
+  int my_plane = -1;
+  {
+    uint32_t nr = 0;
+#pragma unroll
+    for (int j = 0; j < T; j++) {
+      kinds[j] = uni(skind[j]);
+      const uint32_t kd = kinds[j] & 255u;
+      pt.raw[j] = nullptr; pt.lbase[j] = 0; pt.lmask[j] = BD_MASK;
+      if (kd == PK_RING) { if ((int)nr == wave) my_plane = j; pt.lbase[j] = nr * BD_R; nr++; }
+      else if (kd == PK_RAW) pt.raw[j] = uni_ptr(as_global(sds[j].in));
+      else { pt.lbase[j] = (uint32_t)W * BD_R + (uint32_t)W * 256u + (uint32_t)j * BD_PAT; pt.lmask[j] = BD_PAT - 1u; }
+    }
+  }
+  // ---- patterns of the periodic planes: wave j % W writes plane j's 256 bytes ----
+#pragma unroll
+  for (int j = 0; j < T; j++) {
+    if ((kinds[j] & 255u) != PK_PERIODIC || (j % W) != wave) continue;
+    const uint32_t ll = pk_ll(kinds[j]), off = pk_off(kinds[j]), ls = pk_ls(kinds[j]);
+    const gu8* lit = uni_ptr(as_global(sds[j].in)) + ls;     // L = the literals
+    // plane[p] = L[(ll - off) + ((p - (ll - off)) mod off)] for p >= ll - off; pattern index = p mod 256 (off divides 256)
+#pragma unroll
+    for (uint32_t q = 0; q < BD_PAT; q += 64u) {
+      const uint32_t i = q + (uint32_t)lane;
+      lds[pt.lbase[j] + i] = lit[(ll - off) + ((i + 1024u - (ll - off)) & (off - 1u))];
+    }
+  }
+  // ---- this wave's plane ----
   PlaneOut o;
-  o.ring = rings + (uint32_t)wave * BD_R;
-  o.far = far_wg + (size_t)wave * neblock;
-  o.flushed = 0;
   PlaneDec s;
-  const bool raw = csize == (int32_t)neblock;                  // split stored raw (blosc/blosc.c:773-776)
-  if (raw) { s.phase = PH_RAW; s.op = 0; s.cap = neblock; s.in = in; s.last_match = 1; }
-  else lz4_plane_init(s, in, csize, neblock, lane);
+  s.phase = PH_DONE; s.op = neblock; s.last_match = 1;
+  if (my_plane >= 0) {
+    const StreamDesc* sd = sds + my_plane;
+    o.ring = lds + (uint32_t)wave * BD_R;
+    o.far = far_wg + (size_t)wave * neblock;
+    o.flushed = 0;
+    lz4_plane_init(s, uni_ptr(as_global(sd->in)), (int32_t)uni((uint32_t)sd->in_size), neblock, lane);
+  }
   const uint32_t nsl = (neblock + BD_S - 1u) / BD_S;
   for (uint32_t k = 0; k < nsl; k++) {
     const uint32_t p0 = k * BD_S, p1 = p0 + BD_S < neblock ? p0 + BD_S : neblock;
-    o.flushed = p0;
-    if (raw) { ring_put_global_long(o, p0, in + p0, p1 - p0, lane); s.op = p1; }
-    else lz4_plane_run(s, o, scr, p1, lane);
+    BDP_T0(td);
+    if (my_plane >= 0) { o.flushed = p0; lz4_plane_run(s, o, scr, p1, lane BDP_PASS); }
+    BDP_LAP(8, td);
+    BDP_T0(tb);
     __syncthreads();
-    slice_writeout<T>(rings, dst, p0, p1, wave, lane);
+    BDP_LAP(9, tb);
+    BDP_T0(tw);
+    slice_writeout<T, W>(pt, lds, dst, p0, p1, wave, lane);
     // this wave's own plane, plane-major, for its own far matches of later slices (same wave stores and loads)
-    if (!s.last_match && p1 < neblock) {
+    if (my_plane >= 0 && !s.last_match && p1 < neblock) {
       const lu8* r = o.ring + (p0 & BD_MASK);
       for (uint32_t q = 16u * (uint32_t)lane; q < p1 - p0; q += 1024u) g_st16(o.far + p0 + q, l_ld16(r + q));
     }
+    BDP_LAP(4, tw);
   }
-  const bool good = raw || (s.phase == PH_DONE && s.op == neblock);
-  if (lane == 0) {
-    sd->result = good ? (int32_t)neblock : -1;
-    if (!good) atomicMin(&status[uni((uint32_t)sd->chunk)], (int32_t)ST_BADCODEC);      // blosc.c:780-782
+  if (my_plane >= 0) {
+    const bool good = s.phase == PH_DONE && s.op == neblock;
+    if (lane == 0) {
+      sds[my_plane].result = good ? (int32_t)neblock : -1;
+      if (!good) atomicMin(&status[uni((uint32_t)sds[my_plane].chunk)], (int32_t)ST_BADCODEC);      // blosc.c:780-782
+    }
   }
+  // ---- periodic planes: the bytes in front of the periodic part and the final literals (<= 14 + 14 bytes per plane) ----
+  bool any_per = false;
+#pragma unroll
+  for (int j = 0; j < T; j++) any_per |= (kinds[j] & 255u) == PK_PERIODIC;
+  if (any_per) {
+    __syncthreads();                       // every write-out store of the block has been performed (the barrier waits for vmcnt)
+#pragma unroll
+    for (int j = 0; j < T; j++) {
+      if ((kinds[j] & 255u) != PK_PERIODIC || (j % W) != wave) continue;
+      const uint32_t ll = pk_ll(kinds[j]), off = pk_off(kinds[j]), r = pk_r(kinds[j]), ls = pk_ls(kinds[j]);
+      const gu8* in = uni_ptr(as_global(sds[j].in));
+      const uint32_t n = uni((uint32_t)sds[j].in_size);
+      for (uint32_t i = (uint32_t)lane; i < ll - off; i += 64u) dst[(size_t)i * T + (uint32_t)j] = in[ls + i];
+      if ((uint32_t)lane < r) dst[(size_t)(neblock - r + (uint32_t)lane) * T + (uint32_t)j] = in[n - r + (uint32_t)lane];
+      if (lane == 0) sds[j].result = (int32_t)neblock;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < T; j++) if ((kinds[j] & 255u) == PK_RAW && (j % W) == wave && lane == 0) sds[j].result = (int32_t)neblock;
 }
 
-constexpr int BD_WG_PER_CU = 2;
-// LDS per workgroup: T rings + 256 bytes of step scratch per wave + the ticket word
-template <int T>
-constexpr uint32_t bd_lds_bytes() { return (uint32_t)T * BD_R + (uint32_t)T * 256u + 64u; }
+constexpr int BD_WAVES_PER_CU = 16;        // LDS-bound: 4 rings of 8 KiB per 4 waves
 
-// Persistent workgroups; `blist` holds the global indices of the blocks to decode (engine.hip: blocks of fused
-// byte-shuffle chunks that are split into T LZ4 streams), `far` one area of `far_stride` bytes per workgroup.
-template <int T>
-__global__ __launch_bounds__(64 * T, 4) void k_decode_blocks(StreamDesc* __restrict__ streams, int32_t* __restrict__ status,
-                                                          uint32_t* __restrict__ ticket, const int32_t* __restrict__ blist, uint32_t nlist,
-                                                          const ChunkDesc* __restrict__ chunks, const BlockDesc* __restrict__ blocks,
-                                                          uint8_t* __restrict__ far, size_t far_stride, uint32_t* __restrict__ done) {
-  __shared__ __attribute__((aligned(16))) uint8_t bd_lds[bd_lds_bytes<T>()];   // static: 66 KiB for T = 8 (gfx950: up to 160 KiB per workgroup)
-  lu8* rings = (lu8*)bd_lds;
+// Persistent workgroups of W waves; `blist` / `nlist_p` = one of the two lists k_classify_blocks filled, `far` one area
+// of `far_stride` bytes per workgroup.
+template <int T, int W>
+__global__ __launch_bounds__(64 * W, 4) void k_decode_blocks(StreamDesc* __restrict__ streams, const uint32_t* __restrict__ skind, int32_t* __restrict__ status,
+                                                             uint32_t* __restrict__ ticket, const int32_t* __restrict__ blist, const uint32_t* __restrict__ nlist_p,
+                                                             const ChunkDesc* __restrict__ chunks, const BlockDesc* __restrict__ blocks,
+                                                             uint8_t* __restrict__ far, size_t far_stride, uint32_t* __restrict__ done
+#ifdef BAMD_PROFILE_DECODE
+                                                             , uint32_t* __restrict__ profbuf
+#endif
+                                                             ) {
+  __shared__ __attribute__((aligned(16))) uint8_t bd_lds[bd_lds_bytes<T, W>()];
+  lu8* lds = (lu8*)bd_lds;
   const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
-  volatile BAMD_LAS uint32_t* scr = (volatile BAMD_LAS uint32_t*)(rings + (uint32_t)T * BD_R + (uint32_t)wave * 256u);
-  volatile BAMD_LAS uint32_t* ctl = (volatile BAMD_LAS uint32_t*)(rings + (uint32_t)T * BD_R + (uint32_t)T * 256u);
+  volatile BAMD_LAS uint32_t* scr = (volatile BAMD_LAS uint32_t*)(lds + (uint32_t)W * BD_R + (uint32_t)wave * 256u);
+  volatile BAMD_LAS uint32_t* ctl = (volatile BAMD_LAS uint32_t*)(lds + (uint32_t)W * BD_R + (uint32_t)W * 256u + (uint32_t)T * BD_PAT);
   gu8* far_wg = as_global(far) + (size_t)blockIdx.x * far_stride;
+  const uint32_t nlist = uni(*nlist_p);
   uint32_t ndone = 0;
+#ifdef BAMD_PROFILE_DECODE
+  BdProf bp; for (int i_ = 0; i_ < 16; i_++) bp.c[i_] = 0;
+  const uint64_t tk0 = __builtin_amdgcn_s_memtime();
+#endif
   for (;;) {
     if (threadIdx.x == 0) ctl[0] = atomicAdd(ticket, 1u);
     __syncthreads();
     const uint32_t t = uni(ctl[0]);
-    __syncthreads();                       // everybody has the ticket (and is done with the previous block's rings)
+    __syncthreads();                       // everybody has the ticket (and is done with the previous block's LDS)
     if (t >= nlist) break;
     const uint32_t gb = (uint32_t)blist[t];
     const BlockDesc* b = blocks + gb;
     const ChunkDesc* c = chunks + uni((uint32_t)b->chunk);
-    decode_block<T>(streams + (uni((uint32_t)b->first_stream) + (uint32_t)wave), c, b, status, rings, scr, far_wg, wave, lane);
+    const uint32_t fs = uni((uint32_t)b->first_stream);
+    decode_block<T, W>(streams + fs, skind + fs, c, b, status, lds, scr, far_wg, wave, lane BDP_PASS);
     ndone++;
   }
   if (threadIdx.x == 0 && ndone) atomicAdd(done, ndone);
+#ifdef BAMD_PROFILE_DECODE
+  bp.c[14] = (uint32_t)(__builtin_amdgcn_s_memtime() - tk0); bp.c[15] = ndone;
+  if (profbuf && lane == 0) for (int i_ = 0; i_ < 16; i_++) profbuf[((size_t)blockIdx.x * W + wave) * 16 + i_] = bp.c[i_];
+#endif
 }
 
 }  // namespace bamd

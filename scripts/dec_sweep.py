@@ -23,6 +23,10 @@ lib.blosc_gpu_profile(1); lib.blosc_gpu_profile_reset()
 for _ in range(3): bd.decompress()
 lib.blosc_gpu_profile(0)
 assert bd.results() == [csz] * nchunks
-ok = bool((back[0] == torch.from_numpy(host).to(dev)).all())
-d = mod.profile_get("k_decode_streams"); u = mod.profile_get("k_unshuffle"); zz = mod.profile_get("k_zstd_streams")
-print(f"DEC_LDS={os.environ.get('BLOSC_AMD_DEC_LDS','0'):>6s} data={dname} chunks={nchunks} ratio={csz/r:.1f}: k_decode_streams {d[0]/d[1]:8.3f} ms  k_unshuffle {u[0]/max(u[1],1):7.3f} ms  k_zstd_streams {zz[0]/max(zz[1],1):8.3f} ms  ok={ok}", flush=True)
+ok = bool((back[0] == torch.from_numpy(host).to(dev)).all()) and bool((back[-1] == torch.from_numpy(host).to(dev)).all())
+names = ["k_decode_plan", "k_classify_blocks", "k_decode_streams", "k_decode_blocks", "k_decode_blocks8", "k_unshuffle", "k_zstd_streams"]
+tot = 0.0; parts = []
+for k in names:
+    ms, cnt = mod.profile_get(k)
+    if cnt: parts.append(f"{k} {ms / 3:.3f}"); tot += ms / 3
+print(f"data={dname} chunks={nchunks} ratio={csz/r:.1f}: decompress kernels {tot:.3f} ms/call  [" + "  ".join(parts) + f"]  ok={ok}", flush=True)

@@ -303,10 +303,14 @@ def test_handbuilt_blosclz_streams(pkg, oracle):
             if not (r0 < 0 and ro < 0):
                 bad.append((i, "rejected stream", r0, ro))
             continue
+        # chunk level (blosc_d hands the codec exactly neblock bytes of room, blosc.c:777-782): verdict and bytes of the oracle
         chunk = wrap_stream_as_chunk(s, n, 0)
         r, out = pkg.decompress(chunk, n)
-        if r != n or not np.array_equal(out, tmp[:n]):
-            bad.append((i, r, n))
+        ro, oo = orc_decompress(oracle, chunk, n)
+        if i < len(streams) - 4:
+            assert ro == n and np.array_equal(oo, tmp[:n]), i
+        if r != ro or (ro == n and not np.array_equal(out, oo)):
+            bad.append((i, r, ro, n))
         # one byte short / one byte long: blosc_d requires exactly neblock bytes (blosc.c:780-782)
         for wrong in (n - 1, n + 1):
             if wrong <= 0:
