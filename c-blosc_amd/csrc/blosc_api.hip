@@ -27,7 +27,7 @@ static int g_splitmode = BLOSC_FORWARD_COMPAT_SPLIT;
 
 static const char* const kNames[6] = {BLOSC_BLOSCLZ_COMPNAME, BLOSC_LZ4_COMPNAME, BLOSC_LZ4HC_COMPNAME,
                                       BLOSC_SNAPPY_COMPNAME, BLOSC_ZLIB_COMPNAME, BLOSC_ZSTD_COMPNAME};
-static bool codec_built(int code) { return code == BLOSC_BLOSCLZ || code == BLOSC_LZ4 || code == BLOSC_LZ4HC; }
+static bool codec_built(int code) { return code == BLOSC_BLOSCLZ || code == BLOSC_LZ4 || code == BLOSC_LZ4HC || code == BLOSC_ZSTD; }
 
 extern "C" {
 
@@ -80,7 +80,7 @@ int blosc_set_compressor(const char* compname) {                        // blosc
   return code;
 }
 
-const char* blosc_list_compressors(void) { return "blosclz,lz4,lz4hc"; }
+const char* blosc_list_compressors(void) { return "blosclz,lz4,lz4hc,zstd"; }
 
 const char* blosc_get_version_string(void) { return BLOSC_VERSION_STRING; }
 
@@ -92,7 +92,8 @@ int blosc_get_complib_info(const char* compname, char** complib, char** version)
   else if (strcmp(compname, BLOSC_LZ4_COMPNAME) == 0 || strcmp(compname, BLOSC_LZ4HC_COMPNAME) == 0) {
     clib = BLOSC_LZ4_LIB; libname = BLOSC_LZ4_LIBNAME; ver = "1.10.0";   // block format implemented, lz4.h:LZ4_VERSION_*
   }
-  if (clib < 0) {   // Snappy / Zlib / Zstd are not built in: same answer as a stock build without them
+  else if (strcmp(compname, BLOSC_ZSTD_COMPNAME) == 0) { clib = BLOSC_ZSTD_LIB; libname = BLOSC_ZSTD_LIBNAME; ver = "1.5.6"; }   // frame format written / read, zstd.h:ZSTD_VERSION_*
+  if (clib < 0) {   // Snappy / Zlib are not built in: same answer as a stock build without them
     if (complib) *complib = NULL;
     if (version) *version = NULL;
     return -1;

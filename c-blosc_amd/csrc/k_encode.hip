@@ -22,6 +22,7 @@
 #include <stdint.h>
 #include "dev_types.h"
 #include "wave_prims.h"
+#include "zstd_enc.h"
 
 namespace bamd {
 
@@ -160,7 +161,18 @@ __device__ __forceinline__ uint32_t emit_ext255(gu8* p, uint32_t v, int lane) {
   return n255 + 1u;
 }
 
-enum { EF_LZ4 = 0, EF_BLOSCLZ = 1 };
+enum { EF_LZ4 = 0, EF_BLOSCLZ = 1, EF_ZSTD = 2 };
+
+// Where the match finder puts its findings when the target is a Zstd block (zstd_enc.h): literals go straight to
+// their final place in the block being written, (literal length, match length, offset) triples to a scratch of the
+// persistent wave; the sequence section is coded afterwards (zs_write_sequences).
+struct ZsSink {
+  gu8* lit;                       // literal bytes of the block
+  uint32_t nlit, litcap;
+  BAMD_GAS uint64_t* seq;         // zenc::pack_seq triples
+  uint32_t nseq, seqcap;
+};
+__device__ __forceinline__ uint32_t zs_emit_seq(ZsSink& z, const gu8* lit, uint32_t ll, uint32_t off, uint32_t mlen, int lit_lane0, uint32_t ownbyte, int lane);
 
 // ---- emitters --------------------------------------------------------------------------------
 // LZ4 sequence (lz4.c:1111-1226): token | litlen ext | literals | offset LE16 | matchlen ext.
@@ -341,16 +353,20 @@ struct EncWindow {
   }
 };
 
+// [start, n): the part of the stream this call covers (Zstd: one block of a frame; the table and earlier positions stay
+// valid candidates); LZ4 / BloscLZ always start at 0.  `zs` is only used by EF_ZSTD, which returns the position up to
+// which sequences were emitted (the caller appends the literals behind it) or 0xffffffff when the sink is full.
 template <int FMT>
 __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8* __restrict__ dst, uint32_t cap,
-                                   int clevel, enc_entry_t* tab_generic, int lane EPROF_ARG) {
+                                   int clevel, enc_entry_t* tab_generic, int lane EPROF_ARG, uint32_t start = 0, ZsSink* zs = nullptr) {
   // the table lives in LDS; say so explicitly (a generic pointer in a non-inlined function would make
   // every probe a flat_load)
   EncTable tab;
   tab.init((void*)tab_generic);
   // stream-end rules.  LZ4: last match starts <= n-12, ends <= n-5 (lz4.c:245-246, :963-964).
   // BloscLZ: matches start < n-12 (blosclz.c:465), stream must end with >= 1 literal (blosclz.c:708-710).
-  if (FMT == EF_LZ4 ? (n < 13u) : (n < 16u || cap < 66u)) return 0u;
+  if (FMT == EF_ZSTD) { if (n < start + 16u) return start; }
+  else if (FMT == EF_LZ4 ? (n < 13u) : (n < 16u || cap < 66u)) return 0u;
   const uint32_t last_start = n - 12u;                       // inclusive bound on match starts
   const uint32_t mlimit = (FMT == EF_LZ4) ? n - 5u : n - 2u;  // matches end at or before this position
   const int accel = 10 - clevel;                              // blosc/blosc.c:577-587
@@ -359,13 +375,16 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
   // below clevel 9 a match must be longer than the format minimum to be taken.  4-byte matches are mostly accidental in noisy planes, save one
   // byte each and cost a full sequence: requiring 6 halves the encode time of noisy float64 data for
   // < 1 % of ratio (bench19: 53.3 -> 48.5, still far above the reference's 36.7 at this clevel).
-  const uint32_t minlen = clevel >= 9 ? 4u : (clevel >= 6 ? 5u : 6u);
+  // (Zstd sequences are cheaper than LZ4's - a repeated distance costs 5 bits - so short matches pay off there.)
+  static_assert(EF_ZSTD == 2, "");
+  const uint32_t zmin = (uint32_t)__builtin_amdgcn_readfirstlane(4);
+  const uint32_t minlen = FMT == EF_ZSTD ? zmin : (clevel >= 9 ? 4u : (clevel >= 6 ? 5u : 6u));
 
-  tab.clear(lane);
+  if (start == 0u) tab.clear(lane);
 
   EncWindow win;
   win.init(src, n, lane);
-  uint32_t ip = 0, anchor = 0, op = 0, nfail = 0;
+  uint32_t ip = start, anchor = start, op = 0, nfail = 0;
   bool ins_pending = false;                       // position ip-2 still has to enter the table (lz4.c:1236-1242)
   while (ip <= last_start) {
     const uint32_t p = ip + (uint32_t)lane;
@@ -470,6 +489,8 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
       if (FMT == EF_LZ4) {
         op = lz4_emit_seq(dst, op, cap, src + anchor, ll, dist, mlen, anchor >= ip ? (int)(anchor - ip) : -1, (uint32_t)own.a & 0xffu, lane);
         if (op == 0xffffffffu) return 0u;
+      } else if (FMT == EF_ZSTD) {
+        if (zs_emit_seq(*zs, src + anchor, ll, dist, mlen, anchor >= ip ? (int)(anchor - ip) : -1, (uint32_t)own.a & 0xffu, lane) == 0xffffffffu) return 0xffffffffu;
       } else {
         op = blz_emit_literals(dst, op, cap, src + anchor, ll, lane);
         if (op == 0xffffffffu) return 0u;
@@ -502,6 +523,7 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
     }
   }
   // closing literals
+  if (FMT == EF_ZSTD) return anchor;
   if (FMT == EF_LZ4) {
     op = lz4_emit_tail(dst, op, cap, src + anchor, n - anchor, lane);
     if (op == 0xffffffffu) return 0u;
@@ -517,6 +539,153 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
     if ((float)n < floor_ratio[clevel] * (float)op) return 0u;
   }
   PROF_LAP(12);
+  return op < n ? op : 0u;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Zstd frames (zstd_enc.h has the format; this is its wave-parallel use).  One frame per stream, blocks of at most
+// 128 KiB; per block the match finder above fills a ZsSink, then the sequence section is coded: code numbers and extra
+// bits of 64 sequences at a time in the lanes, the three FSE state chains and the bit writer as a wave-uniform
+// (scalar) loop over them, tables in the wave's LDS (the hash table is rebuilt per stream anyway).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t zs_emit_seq(ZsSink& z, const gu8* lit, uint32_t ll, uint32_t off, uint32_t mlen, int lit_lane0, uint32_t ownbyte, int lane) {
+  if (z.nlit + ll > z.litcap || z.nseq >= z.seqcap) return 0xffffffffu;
+  emit_literals(z.lit + z.nlit, lit, ll, lit_lane0, ownbyte, lane);
+  if (lane == 0) z.seq[z.nseq] = zenc::pack_seq(ll, mlen, off);
+  z.nlit += ll; z.nseq++;
+  return 0u;
+}
+
+// distances -> Offset_Values (repeat codes, zstd_enc.h: rep_value), in stream order: 64 sequences per load, the history
+// as wave-uniform state
+__device__ __forceinline__ void zs_assign_offset_values(BAMD_GAS uint64_t* seqs, uint32_t nseq, zenc::RepState& rep, int lane) {
+  for (uint32_t base = 0; base < nseq; base += 64u) {
+    const uint32_t cnt = nseq - base < 64u ? nseq - base : 64u;
+    const uint64_t q = (uint32_t)lane < cnt ? seqs[base + (uint32_t)lane] : 0ull;
+    const uint32_t off_l = zenc::seq_off(q), ll_l = zenc::seq_ll(q);
+    uint32_t val_l = 0;
+    for (uint32_t k = 0; k < cnt; k++) {
+      const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)off_l, (int)k), ll = (uint32_t)__builtin_amdgcn_readlane((int)ll_l, (int)k);
+      const uint32_t v = zenc::rep_value(rep, off, ll);
+      val_l = (uint32_t)lane == k ? v : val_l;
+    }
+    if ((uint32_t)lane < cnt) seqs[base + (uint32_t)lane] = zenc::pack_seq(ll_l, zenc::seq_ml(q), val_l);
+  }
+}
+
+typedef BAMD_LAS const zenc::CTab LdsCTab;
+__device__ __forceinline__ uint32_t zs_tab_u32(const BAMD_LAS uint32_t* p, uint32_t i) { return uni(p[i]); }
+
+// out: start of the Sequences_Section, room: bytes available.  Returns the section size or 0xffffffff.
+__device__ __forceinline__ uint32_t zs_write_sequences(gu8* out, uint32_t room, const BAMD_GAS uint64_t* seqs, uint32_t nseq,
+                                                       const BAMD_LAS zenc::CTabs* T, int lane) {
+  if (room < 8u) return 0xffffffffu;
+  uint32_t pos = 0;
+  if (nseq == 0u) { if (lane == 0) out[0] = 0; return 1u; }
+  if (nseq < 128u) { if (lane == 0) out[0] = (uint8_t)nseq; pos = 1; }
+  else if (nseq < 0x7f00u) { if (lane == 0) { out[0] = (uint8_t)((nseq >> 8) + 128u); out[1] = (uint8_t)nseq; } pos = 2; }
+  else { if (lane == 0) { out[0] = 255u; out[1] = (uint8_t)(nseq - 0x7f00u); out[2] = (uint8_t)((nseq - 0x7f00u) >> 8); } pos = 3; }
+  if (lane == 0) out[pos] = 0;                               // three predefined tables
+  pos += 1;
+  const BAMD_LAS uint32_t* ll_dnb = (const BAMD_LAS uint32_t*)T->ll.dnb; const BAMD_LAS int32_t* ll_dfs = (const BAMD_LAS int32_t*)T->ll.dfs; const BAMD_LAS uint16_t* ll_st = (const BAMD_LAS uint16_t*)T->ll.st;
+  const BAMD_LAS uint32_t* ml_dnb = (const BAMD_LAS uint32_t*)T->ml.dnb; const BAMD_LAS int32_t* ml_dfs = (const BAMD_LAS int32_t*)T->ml.dfs; const BAMD_LAS uint16_t* ml_st = (const BAMD_LAS uint16_t*)T->ml.st;
+  const BAMD_LAS uint32_t* of_dnb = (const BAMD_LAS uint32_t*)T->of.dnb; const BAMD_LAS int32_t* of_dfs = (const BAMD_LAS int32_t*)T->of.dfs; const BAMD_LAS uint16_t* of_st = (const BAMD_LAS uint16_t*)T->of.st;
+  uint64_t acc = 0; uint32_t nb = 0; bool ovf = false;
+  auto add = [&](uint32_t v, uint32_t n) {
+    acc |= (uint64_t)v << nb; nb += n;
+    if (nb >= 32u) {
+      if (pos + 4u > room) ovf = true; else if (lane == 0) g_st4(out + pos, (uint32_t)acc);
+      pos += 4u; acc >>= 32; nb -= 32u;
+    }
+  };
+  uint32_t sll = 0, sml = 0, sof = 0;
+  bool first = true;
+  for (uint32_t base = ((nseq - 1u) >> 6) << 6;; base -= 64u) {
+    const uint32_t cnt = nseq - base < 64u ? nseq - base : 64u;
+    const uint64_t q = (uint32_t)lane < cnt ? seqs[base + (uint32_t)lane] : zenc::pack_seq(0, 3, 4);
+    const zenc::Code l = zenc::ll_code(zenc::seq_ll(q)), m = zenc::ml_code(zenc::seq_ml(q)), o = zenc::of_code_value(zenc::seq_off(q));
+    const uint32_t pk = l.code | (m.code << 6) | (o.code << 12) | (l.bits << 17) | (m.bits << 22);
+    for (int k = (int)cnt - 1; k >= 0; k--) {
+      const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)pk, k);
+      const uint32_t ell = (uint32_t)__builtin_amdgcn_readlane((int)l.extra, k), eml = (uint32_t)__builtin_amdgcn_readlane((int)m.extra, k);
+      const uint32_t eof = (uint32_t)__builtin_amdgcn_readlane((int)o.extra, k);
+      const uint32_t lc = c & 63u, mc = (c >> 6) & 63u, oc = (c >> 12) & 31u, lb = (c >> 17) & 31u, mb = (c >> 22) & 31u;
+      const uint32_t dl = uni(ll_dnb[lc]), dm = uni(ml_dnb[mc]), dO = uni(of_dnb[oc]);
+      const int32_t fl = (int32_t)uni((uint32_t)ll_dfs[lc]), fm = (int32_t)uni((uint32_t)ml_dfs[mc]), fo = (int32_t)uni((uint32_t)of_dfs[oc]);
+      if (first) {
+        first = false;
+        const uint32_t nm = (dm + (1u << 15)) >> 16, nO = (dO + (1u << 15)) >> 16, nl = (dl + (1u << 15)) >> 16;
+        sml = uni((uint32_t)ml_st[(int32_t)(((nm << 16) - dm) >> nm) + fm]);
+        sof = uni((uint32_t)of_st[(int32_t)(((nO << 16) - dO) >> nO) + fo]);
+        sll = uni((uint32_t)ll_st[(int32_t)(((nl << 16) - dl) >> nl) + fl]);
+      } else {
+        const uint32_t nO = (sof + dO) >> 16; add(sof & ((1u << nO) - 1u), nO); sof = uni((uint32_t)of_st[(int32_t)(sof >> nO) + fo]);
+        const uint32_t nm = (sml + dm) >> 16; add(sml & ((1u << nm) - 1u), nm); sml = uni((uint32_t)ml_st[(int32_t)(sml >> nm) + fm]);
+        const uint32_t nl = (sll + dl) >> 16; add(sll & ((1u << nl) - 1u), nl); sll = uni((uint32_t)ll_st[(int32_t)(sll >> nl) + fl]);
+      }
+      add(ell, lb); add(eml, mb); add(eof, oc);            // offsets stay below 2^17 here: at most 17 extra bits
+    }
+    if (base == 0u) break;
+  }
+  add(sml & 63u, (uint32_t)zenc::kMLLog); add(sof & 31u, (uint32_t)zenc::kOFLog); add(sll & 63u, (uint32_t)zenc::kLLLog);
+  add(1u, 1u);
+  while (nb > 0u) {
+    if (pos >= room) { ovf = true; break; }
+    if (lane == 0) out[pos] = (uint8_t)acc;
+    pos++; acc >>= 8; nb = nb > 8u ? nb - 8u : 0u;
+  }
+  return ovf ? 0xffffffffu : pos;
+}
+
+// One stream -> one frame.  Returns the frame size, or 0 when it would not be smaller than the input (the split is
+// then stored raw by blosc's own rule, blosc.c:703-717).  `seqbuf`: zenc::kBlockMax / 4 entries of this wave.
+constexpr uint32_t ZS_SEQCAP = zenc::kBlockMax / 4u;
+constexpr int ZS_LDS_BYTES = (int)((sizeof(zenc::CTabs) + 15) / 16 * 16);
+__device__ uint32_t zstd_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8* __restrict__ dst, uint32_t cap, int clevel,
+                                     enc_entry_t* tab_generic, BAMD_GAS uint64_t* seqbuf, int lane EPROF_ARG) {
+  if (n < 32u || cap < 64u) return 0u;
+  if (lane == 0) {
+    uint8_t h[16];
+    zenc::write_frame_header(h, n);
+    for (int i = 0; i < 9; i++) dst[i] = h[i];
+  }
+  uint32_t op = zenc::kFrameHeader;
+  zenc::RepState rep;
+  zenc::rep_init(rep);
+  for (uint32_t s0 = 0; s0 < n; s0 += zenc::kBlockMax) {
+    const uint32_t s1 = s0 + zenc::kBlockMax < n ? s0 + zenc::kBlockMax : n;
+    const bool last = s1 == n;
+    const uint32_t seg = s1 - s0;
+    if (op + zenc::kBlockHeader + zenc::kLitHeader + 16u >= cap) return 0u;
+    gu8* bh = dst + op;
+    ZsSink z;
+    z.lit = bh + zenc::kBlockHeader + zenc::kLitHeader; z.nlit = 0;
+    z.litcap = cap - (op + zenc::kBlockHeader + zenc::kLitHeader);
+    z.seq = seqbuf; z.nseq = 0; z.seqcap = ZS_SEQCAP;
+    const uint32_t covered = lz_encode_wave<EF_ZSTD>(src, s1, dst, cap, clevel, tab_generic, lane EPROF_PASS, s0, &z);
+    uint32_t bsize = 0xffffffffu;
+    const zenc::RepState rep_before = rep;
+    if (covered != 0xffffffffu && z.nlit + (s1 - covered) <= z.litcap) {
+      wave_copy_disjoint(z.lit + z.nlit, src + covered, s1 - covered, lane);
+      z.nlit += s1 - covered;
+      if (lane == 0) { uint8_t h[4]; zenc::write_raw_literals_header(h, z.nlit); bh[3] = h[0]; bh[4] = h[1]; bh[5] = h[2]; }
+      // the FSE tables sit behind this wave's hash table in LDS (k_encode_streams_t<true> puts them there once)
+      const BAMD_LAS zenc::CTabs* T = (const BAMD_LAS zenc::CTabs*)((BAMD_LAS uint8_t*)(void*)tab_generic + ENC_TAB_BYTES);
+      __builtin_amdgcn_s_waitcnt(0);      // this wave's sequence triples are in memory before other lanes load them
+      zs_assign_offset_values(seqbuf, z.nseq, rep, lane);
+      __builtin_amdgcn_s_waitcnt(0);
+      const uint32_t ss = zs_write_sequences(z.lit + z.nlit, z.litcap - z.nlit, seqbuf, z.nseq, T, lane);
+      if (ss != 0xffffffffu) bsize = zenc::kLitHeader + z.nlit + ss;
+    }
+    if (bsize >= seg) {                   // no gain: Raw_Block
+      if (op + zenc::kBlockHeader + seg >= cap) return 0u;
+      wave_copy_disjoint(bh + zenc::kBlockHeader, src + s0, seg, lane);
+      bsize = seg;
+      rep = rep_before;                   // a raw block leaves the decoder's repeat offsets alone
+      if (lane == 0) { uint8_t h[4]; zenc::write_block_header(h, last, 0u, bsize); bh[0] = h[0]; bh[1] = h[1]; bh[2] = h[2]; }
+    } else if (lane == 0) { uint8_t h[4]; zenc::write_block_header(h, last, 2u, bsize); bh[0] = h[0]; bh[1] = h[1]; bh[2] = h[2]; }
+    op += zenc::kBlockHeader + bsize;
+  }
   return op < n ? op : 0u;
 }
 
@@ -586,7 +755,7 @@ __device__ __attribute__((noinline)) void shuffle_block_task(const ChunkDesc* ch
 
 // one stream, not inlined into the queue loop (see decode_one_stream in k_decode.hip for why)
 __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, enc_entry_t* tab, const ChunkDesc* chunks, uint32_t* blk_ready, int lane,
-                                                            const BlockDesc* blocks, uint32_t sid, uint32_t* plane_cost
+                                                            const BlockDesc* blocks, uint32_t sid, uint32_t* plane_cost, uint64_t* seqbuf
 #ifdef BAMD_PROFILE_DECODE
                                                             , uint32_t* profslot
 #endif
@@ -608,6 +777,7 @@ __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, enc_
   const uint64_t cost_t0 = __builtin_amdgcn_s_memtime();
   uint32_t r;
   if (sd->fmt == FMT_LZ4) r = lz_encode_wave<EF_LZ4>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, lane EPROF_PASS);
+  else if (sd->fmt == FMT_ZSTD) r = seqbuf ? zstd_encode_wave(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, (BAMD_GAS uint64_t*)seqbuf, lane EPROF_PASS) : 0u;
   else r = lz_encode_wave<EF_BLOSCLZ>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, lane EPROF_PASS);
   if (lane == 0) sd->result = (int32_t)r;
   // cost feedback for the host's queue order (queue_order.h: build_encode_queues): cycles per plane index
@@ -626,17 +796,25 @@ __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, enc_
 // host puts every block's shuffle task a few dozen entries ahead of its streams (queue_order.h:
 // build_encode_queues), so the bandwidth-bound transposes run underneath the latency/issue-bound match
 // finding of other waves instead of in a kernel of their own.
-__global__ __launch_bounds__(64 * ENC_WAVES, BAMD_ENC_MINWAVES) void k_encode_streams(
+template <bool ZSTD>
+__global__ __launch_bounds__(64 * ENC_WAVES, BAMD_ENC_MINWAVES) void k_encode_streams_t(
     StreamDesc* __restrict__ streams, uint32_t* __restrict__ tickets /*[8]*/, const int32_t* __restrict__ qlist,
     const int32_t* __restrict__ qoff /*[9]*/, const ChunkDesc* __restrict__ chunks, const BlockDesc* __restrict__ blocks,
-    uint32_t* __restrict__ blk_ready, uint32_t* __restrict__ plane_cost, int single_queue
+    uint32_t* __restrict__ blk_ready, uint32_t* __restrict__ plane_cost, int single_queue,
+    uint64_t* __restrict__ seqbufs, const zenc::CTabs* __restrict__ ctabs
 #ifdef BAMD_PROFILE_DECODE
     , uint32_t* __restrict__ profbuf
 #endif
     ) {
-  __shared__ enc_entry_t tabs[ENC_WAVES][ENC_TAB_BYTES / 4];
+  __shared__ enc_entry_t tabs[ENC_WAVES][(ENC_TAB_BYTES + (ZSTD ? ZS_LDS_BYTES : 0)) / 4];
   static_assert(ENC_WAVES == 1, "one stream per wave, one wave per workgroup");
   const int lane = threadIdx.x & 63;
+  uint64_t* seqbuf = nullptr;
+  if (ZSTD) {       // the predefined FSE tables of the sequence coder, once per persistent wave
+    const uint32_t* g = (const uint32_t*)ctabs;
+    for (uint32_t k = (uint32_t)lane; k < sizeof(zenc::CTabs) / 4u; k += 64u) tabs[0][ENC_TAB_BYTES / 4 + k] = g[k];
+    seqbuf = seqbufs + (size_t)blockIdx.x * ZS_SEQCAP;
+  }
   // HW_REG_XCC_ID[3:0]; queue 0 for everybody in the single-queue fallback (no in-kernel hand-offs there)
   const uint32_t xcc = single_queue ? 0u : (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);
   const uint32_t qbase = (uint32_t)qoff[xcc], qlen = (uint32_t)qoff[xcc + 1] - qbase;
@@ -648,9 +826,9 @@ __global__ __launch_bounds__(64 * ENC_WAVES, BAMD_ENC_MINWAVES) void k_encode_st
       shuffle_block_task(chunks, blocks, (uint32_t)(-(task + 1)), blk_ready, lane);
     } else {
 #ifdef BAMD_PROFILE_DECODE
-      encode_one_stream(streams + task, tabs[0], chunks, blk_ready, lane, blocks, (uint32_t)task, plane_cost, profbuf ? profbuf + (size_t)task * 16 : nullptr);
+      encode_one_stream(streams + task, tabs[0], chunks, blk_ready, lane, blocks, (uint32_t)task, plane_cost, seqbuf, profbuf ? profbuf + (size_t)task * 16 : nullptr);
 #else
-      encode_one_stream(streams + task, tabs[0], chunks, blk_ready, lane, blocks, (uint32_t)task, plane_cost);
+      encode_one_stream(streams + task, tabs[0], chunks, blk_ready, lane, blocks, (uint32_t)task, plane_cost, seqbuf);
 #endif
     }
     ndone++;

@@ -21,7 +21,7 @@ CASES = [  # name, codec, shuffle, typesize, clevel, dataset, GPU encodes it
     ("blosclz-shuffle-T8", "blosclz", 1, 8, 5, "bench19", True),
     ("lz4-shuffle-T8-linspace", "lz4", 1, 8, 5, "linspace", True),
     ("lz4-shuffle-T8-randwalk", "lz4", 1, 8, 5, "randwalk", True),
-    ("zstd-shuffle-T8", "zstd", 1, 8, 3, "bench19", None),      # None: ask the library
+    ("zstd-shuffle-T8", "zstd", 1, 8, 3, "bench19", True),
 ]
 
 
