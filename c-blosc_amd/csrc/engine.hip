@@ -411,8 +411,10 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
     hipLaunchKernelGGL(k_shuffle, dim3((unsigned)nblk, (unsigned)tiles_shuf), dim3(FT_THREADS), 0, stream, d_chunks, d_blocks);
   }
   if (any_bit && nblk) {
+    static const bool bitfast = !(getenv("BLOSC_AMD_BITFAST") && atoi(getenv("BLOSC_AMD_BITFAST")) == 0);
     ProfScope ps(st, stream, "k_bitshuffle");
-    hipLaunchKernelGGL(k_bitshuffle, dim3((unsigned)nblk, (unsigned)tiles_bit), dim3(FT_THREADS), 0, stream, d_chunks, d_blocks);
+    if (bitfast) hipLaunchKernelGGL(k_bitfilter_fast<0>, dim3((unsigned)nblk, (unsigned)tiles_bit), dim3(FT_THREADS), 0, stream, d_chunks, d_blocks);
+    hipLaunchKernelGGL(k_bitshuffle, dim3((unsigned)nblk, (unsigned)tiles_bit), dim3(FT_THREADS), 0, stream, d_chunks, d_blocks, bitfast ? 1 : 0);
   }
   if (nstr) {
     ProfScope ps(st, stream, zstd ? "k_zstd_encode" : "k_encode_streams");
@@ -659,8 +661,10 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
       hipLaunchKernelGGL(k_unshuffle, dim3((unsigned)L.nblk, (unsigned)L.tiles_shuf), dim3(FT_THREADS), 0, stream, L.d_chunks, L.d_blocks);
     }
     if (L.any_bit) {
+      static const bool bitfast = !(getenv("BLOSC_AMD_BITFAST") && atoi(getenv("BLOSC_AMD_BITFAST")) == 0);
       ProfScope ps(st, stream, "k_bitunshuffle");
-      hipLaunchKernelGGL(k_bitunshuffle, dim3((unsigned)L.nblk, (unsigned)L.tiles_bit), dim3(FT_THREADS), 0, stream, L.d_chunks, L.d_blocks);
+      if (bitfast) hipLaunchKernelGGL(k_bitfilter_fast<1>, dim3((unsigned)L.nblk, (unsigned)L.tiles_bit), dim3(FT_THREADS), 0, stream, L.d_chunks, L.d_blocks);
+      hipLaunchKernelGGL(k_bitunshuffle, dim3((unsigned)L.nblk, (unsigned)L.tiles_bit), dim3(FT_THREADS), 0, stream, L.d_chunks, L.d_blocks, bitfast ? 1 : 0);
     }
   }
   if (L.any_copy) {
@@ -980,8 +984,10 @@ int engine_filter(int kind, size_t typesize, size_t blocksize, const void* src, 
   switch (kind) {
     case 0: hipLaunchKernelGGL(k_shuffle, dim3(1, (unsigned)tiles), dim3(FT_THREADS), 0, stream, dc, db); break;
     case 1: hipLaunchKernelGGL(k_unshuffle, dim3(1, (unsigned)tiles), dim3(FT_THREADS), 0, stream, dc, db); break;
-    case 2: hipLaunchKernelGGL(k_bitshuffle, dim3(1, (unsigned)tiles), dim3(FT_THREADS), 0, stream, dc, db); break;
-    default: hipLaunchKernelGGL(k_bitunshuffle, dim3(1, (unsigned)tiles), dim3(FT_THREADS), 0, stream, dc, db); break;
+    case 2: hipLaunchKernelGGL(k_bitfilter_fast<0>, dim3(1, (unsigned)tiles), dim3(FT_THREADS), 0, stream, dc, db);
+            hipLaunchKernelGGL(k_bitshuffle, dim3(1, (unsigned)tiles), dim3(FT_THREADS), 0, stream, dc, db, 1); break;
+    default: hipLaunchKernelGGL(k_bitfilter_fast<1>, dim3(1, (unsigned)tiles), dim3(FT_THREADS), 0, stream, dc, db);
+             hipLaunchKernelGGL(k_bitunshuffle, dim3(1, (unsigned)tiles), dim3(FT_THREADS), 0, stream, dc, db, 1); break;
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(dst, D + o_out, blocksize, hipMemcpyDeviceToHost, stream));
