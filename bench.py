@@ -40,7 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (6.29 TB/s measured copy)
 COMPRESS_KERNELS = ["k_shuffle", "k_bitshuffle", "k_encode_streams", "k_zstd_encode", "k_chunk_scan", "k_chunk_compact"]
-DECOMPRESS_KERNELS = ["k_decode_plan", "k_classify_blocks", "k_decode_streams", "k_decode_blocks", "k_decode_blocks8", "k_zstd_streams", "k_unshuffle",
+DECOMPRESS_KERNELS = ["k_decode_plan", "k_classify_blocks", "k_decode_streams", "k_decode_blocks", "k_decode_blocks8", "k_zstd_entropy", "k_zstd_exec", "k_zstd_streams", "k_unshuffle",
                       "k_bitunshuffle", "k_copy_chunks"]
 KERNELS = COMPRESS_KERNELS + DECOMPRESS_KERNELS
 REFSO = os.path.join(ROOT, "oracle", "_ref", "libblosc_ref.so")

@@ -21,6 +21,7 @@
 #include "k_decode_blocks.hip"
 #include "k_encode.hip"
 #include "k_zstd.hip"
+#include "k_zstd2.hip"
 
 namespace bamd {
 
@@ -554,7 +555,8 @@ struct DecodeLaunch {
   ChunkDesc* d_chunks; BlockDesc* d_blocks; StreamDesc* d_streams; int32_t* d_status; uint32_t* d_ticket; uint32_t* d_blkdone;
   uint32_t* d_spans; uint8_t* d_pat;             // periodic spans of the fused unshuffle (k_decode.hip: SpanCtx)
   uint32_t* d_cost;                              // [256] cycles per plane index (scheduling feedback)
-  uint32_t* d_zticket; bool any_zstd;            // Zstd frames go through k_zstd_streams
+  uint32_t* d_zticket; bool any_zstd;            // Zstd frames: k_zstd_entropy + k_zstd_exec (two-phase), the rest through k_zstd_streams
+  ZMeta* d_zmeta; ptrdiff_t zseq_delta;          // nullptr: everything through k_zstd_streams
   const int32_t* d_qlist; const int32_t* d_qoff;   // per-XCD stream queues
   size_t nblk, nstr; int nchunks;
   bool any_shuf, any_bit, any_copy; int tiles_shuf, tiles_bit;
@@ -651,10 +653,43 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
 #endif
       }
     }
+    // BLOSC_AMD_ZSTD2=1: single-block frames through k_zstd_entropy (16 frames per wave) + k_zstd_exec.  Off by default:
+    // faster on sequence-heavy frames (bench19: 112 vs 130 ms per 8 GiB) but its per-frame start-up (table descriptions
+    // and builds on single lanes, one wave per CU for LDS reasons) costs 40 ms per 65 536 frames, which loses on data
+    // with few sequences (linspace 54 vs 16 ms) - profiles/r02_e_zstd_decode.md
+    static const bool zstd2 = getenv("BLOSC_AMD_ZSTD2") && atoi(getenv("BLOSC_AMD_ZSTD2")) != 0;
+    const uint32_t* d_taken = nullptr;
+    if (L.any_zstd && L.d_zmeta && zstd2) {
+      {
+        ProfScope ps(st, stream, "k_zstd_entropy");
+        hipLaunchKernelGGL(k_zstd_entropy, grid1(L.nstr, ZG_FRAMES), dim3(64), 0, stream, L.d_streams, (int)L.nstr, L.d_chunks, L.d_blocks, L.d_zmeta, L.zseq_delta);
+      }
+      {
+        ProfScope ps(st, stream, "k_zstd_exec");
+        hipLaunchKernelGGL(k_zstd_exec, dim3(persistent_grid(L.nstr, ZEXEC_WAVES_PER_CU)), dim3(64), 0, stream, L.d_streams, (int)L.nstr, L.d_status, L.d_zticket + 1,
+                           L.d_chunks, L.d_blocks, L.d_zmeta, L.zseq_delta);
+      }
+      d_taken = (const uint32_t*)L.d_zmeta;
+    }
     if (L.any_zstd) {
       ProfScope ps(st, stream, "k_zstd_streams");
+#ifdef BAMD_PROFILE_DECODE
+      uint32_t* d_zprof = nullptr;
+      if (getenv("BLOSC_AMD_ZSTD_PROFILE")) { (void)hipMalloc((void**)&d_zprof, L.nstr * 64); (void)hipMemsetAsync(d_zprof, 0, L.nstr * 64, stream); }
       hipLaunchKernelGGL(k_zstd_streams, dim3(persistent_grid(L.nstr, ZSTD_WAVES_PER_CU)), dim3(64), 0, stream, L.d_streams, (int)L.nstr, L.d_status,
-                         L.d_zticket, L.d_chunks, L.d_blocks, L.d_cost + 257);
+                         L.d_zticket, L.d_chunks, L.d_blocks, L.d_cost + 257, d_taken, d_zprof);
+      if (d_zprof) {
+        std::vector<uint32_t> h(L.nstr * 16);
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(h.data(), d_zprof, L.nstr * 64, hipMemcpyDeviceToHost);
+        FILE* f = fopen(getenv("BLOSC_AMD_ZSTD_PROFILE"), "wb");
+        if (f) { fwrite(h.data(), 4, h.size(), f); fclose(f); }
+        (void)hipFree(d_zprof);
+      }
+#else
+      hipLaunchKernelGGL(k_zstd_streams, dim3(persistent_grid(L.nstr, ZSTD_WAVES_PER_CU)), dim3(64), 0, stream, L.d_streams, (int)L.nstr, L.d_status,
+                         L.d_zticket, L.d_chunks, L.d_blocks, L.d_cost + 257, d_taken);
+#endif
     }
     if (L.any_shuf) {
       ProfScope ps(st, stream, "k_unshuffle");
@@ -741,6 +776,8 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   const size_t o_pat = cv.take(span_enabled() ? (size_t)2048 * (nstr ? nstr : 1) : 256);
   const size_t o_filt = cv.take(filt_bytes + 256);
   const size_t o_zlit = cv.take(zlit_bytes + 256);      // literal scratch of the Zstd chunks
+  const size_t o_zseq = cv.take(zlit_bytes + 512);      // sequence triples of the two-phase Zstd path, same layout as the literal scratch
+  const size_t o_zmeta = cv.take(L.any_zstd ? sizeof(ZMeta) * (nstr ? nstr : 1) : 64);
   const size_t o_zticket = cv.take(64);
   const size_t o_far = cv.take(far_stride ? far_stride * far_wgs : 256);
   if (st.dev.ensure(cv.off)) return -1;
@@ -798,6 +835,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   HIP_TRY(hipMemsetAsync(D + o_cost, 0, sizeof(uint32_t) * kCostWords, stream));
   L.d_zticket = (uint32_t*)(D + o_zticket);
   if (L.any_zstd) HIP_TRY(hipMemsetAsync(D + o_zticket, 0, 64, stream));
+  L.d_zmeta = L.any_zstd ? (ZMeta*)(D + o_zmeta) : nullptr; L.zseq_delta = (ptrdiff_t)o_zseq - (ptrdiff_t)o_zlit + 8;
   L.nblk = nblk; L.nstr = nstr; L.nchunks = n;
   L.d_bctl = (uint32_t*)(D + o_blist);
   L.d_bcand[0] = (const int32_t*)(D + o_blist + 64); L.d_bcand[1] = L.d_bcand[0] + blist[0].size();

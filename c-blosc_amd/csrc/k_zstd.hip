@@ -21,6 +21,22 @@
 
 namespace bamd {
 
+// phase profiling (prof build, scripts/zstd_phase.py): cycles per frame in
+// 0 literal header + Huffman table, 1 Huffman streams, 2 sequence tables + stream init, 3 sequence decode (lane 0),
+// 4 sequence execution, 5 rest (block copies, tails); 8 sequences, 9 literals, 10 blocks
+#ifdef BAMD_PROFILE_DECODE
+struct ZProf { uint64_t t; uint32_t c[16]; };
+#define ZP_ARG , ZProf& zp
+#define ZP_PASS , zp
+#define ZP_LAP(i) do { __builtin_amdgcn_s_waitcnt(0); const uint64_t t_ = __builtin_amdgcn_s_memtime(); zp.c[i] += (uint32_t)(t_ - zp.t); zp.t = t_; } while (0)
+#define ZP_ADD(i, v) zp.c[i] += (uint32_t)(v)
+#else
+#define ZP_ARG
+#define ZP_PASS
+#define ZP_LAP(i)
+#define ZP_ADD(i, v)
+#endif
+
 struct ZstdLds {
   uint16_t huf[2048];
   uint32_t ll[512], of[512], ml[512];
@@ -46,12 +62,15 @@ __device__ __forceinline__ void wave_fill(gu8* dst, uint32_t v, uint32_t n, int 
 #ifndef BAMD_ZSTD_EXEC16
 #define BAMD_ZSTD_EXEC16 1
 #endif
-__device__ __forceinline__ bool zstd_exec16(const ZstdLds* L, int base, int m, uint8_t* out_, uint32_t cap, uint32_t& op,
+// (ll_b, ml_b, off_b: lane i of the batch holds sequence i; this group is sequences base .. base + m)
+__device__ __forceinline__ bool zstd_exec16(uint32_t ll_b, uint32_t ml_b, uint32_t off_b, int base, int m, uint8_t* out_, uint32_t cap, uint32_t& op,
                                             const uint8_t* lit_, uint32_t& lp, uint32_t regen, int lane) {
   gu8* out = as_global(out_); const gu8* lit = as_global(lit_);
   const bool mine = lane < m;
-  const uint32_t ll = mine ? L->seq[3 * (base + lane)] : 0u, ml = mine ? L->seq[3 * (base + lane) + 1] : 0u;
-  const uint32_t off = mine ? L->seq[3 * (base + lane) + 2] : 1u;
+  const uint32_t sel = (uint32_t)(base + lane) & 63u;
+  const uint32_t ll_g = bperm(sel, ll_b), ml_g = bperm(sel, ml_b), off_g = bperm(sel, off_b);
+  const uint32_t ll = mine ? ll_g : 0u, ml = mine ? ml_g : 0u;
+  const uint32_t off = mine ? off_g : 1u;
   const uint32_t tot = ll + ml;
   uint32_t incl = tot, lincl = ll;                       // inclusive prefix sums over the 16 rank lanes (one DPP row)
   incl += row_shr<1>(incl); incl += row_shr<2>(incl); incl += row_shr<4>(incl); incl += row_shr<8>(incl);
@@ -93,9 +112,119 @@ __device__ __forceinline__ bool zstd_exec16(const ZstdLds* L, int base, int m, u
   return true;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wave-uniform sequence decoding.  The FSE sequence stream is serial, but nothing says it has to run on ONE LANE
+// with its bytes fetched from memory one load at a time (the first version: 2200 cycles per sequence,
+// profiles/r02_e_zstd_decode_phases.txt).  Here every lane runs the same scalar program: the stream lives in a
+// 256-byte register window (one dword per lane, refilled with one coalesced load as the reader moves towards the
+// start), bits come out of a 64-bit accumulator refilled with v_readlane, table entries are uniform LDS reads, and
+// lane i keeps the fields of the batch's i-th sequence in its own registers for the execution step.
+// Same rules as zd::seq_begin / zd::seq_next (zstd_serial.h), which stay the CPU-checked statement of the format.
+// ---------------------------------------------------------------------------------------------
+struct WBack {
+  const gu8* p; int len;
+  uint32_t win; int wbase;           // lane l holds stream bytes [wbase + 4 l, + 4); wbase is a multiple of 4, may be negative
+  uint64_t acc; int nacc; int off; int bytepos;
+};
+__device__ __forceinline__ void wb_fetch(WBack& b, int lane) {
+  const int q = b.wbase + 4 * lane;
+  uint32_t v = 0;
+  if (q >= 0 && q + 4 <= b.len) v = g_ld4(b.p + q);
+  else for (int k = 0; k < 4; k++) if (q + k >= 0 && q + k < b.len) v |= (uint32_t)b.p[q + k] << (8 * k);
+  b.win = v;
+}
+// 4 stream bytes at pos .. pos + 3 (little endian), 0 <= pos, pos + 4 <= len
+__device__ __forceinline__ uint32_t wb_get4(WBack& b, int pos, int lane) {
+  if (pos < b.wbase) { b.wbase = (pos - 192) & ~3; wb_fetch(b, lane); }
+  const int r = pos - b.wbase, i = r >> 2, sh = (r & 3) * 8;
+  const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)b.win, i);
+  const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)b.win, (i + 1) & 63);
+  return (uint32_t)((((uint64_t)c << 32) | a) >> sh);
+}
+__device__ __forceinline__ uint32_t wb_get1(WBack& b, int pos, int lane) {
+  if (pos < b.wbase) { b.wbase = (pos - 192) & ~3; wb_fetch(b, lane); }
+  const int r = pos - b.wbase;
+  return ((uint32_t)__builtin_amdgcn_readlane((int)b.win, r >> 2) >> ((r & 3) * 8)) & 0xffu;
+}
+// The accumulator keeps its `nacc` valid bits at the TOP of the 64-bit word: a read is two shifts, bits past the
+// start of the stream read as zero by themselves (`off` going negative is what the callers check).
+__device__ __forceinline__ void wb_refill(WBack& b, int lane) {      // afterwards nacc > 32 unless the stream start is near
+  if (b.nacc > 32) return;
+  if (b.bytepos >= 4) {
+    const uint32_t v = wb_get4(b, b.bytepos - 4, lane);
+    b.bytepos -= 4; b.acc |= (uint64_t)v << (32 - b.nacc); b.nacc += 32;
+    return;
+  }
+  while (b.nacc <= 56 && b.bytepos > 0) { b.bytepos--; b.acc |= (uint64_t)wb_get1(b, b.bytepos, lane) << (56 - b.nacc); b.nacc += 8; }
+}
+__device__ __forceinline__ bool wb_init(WBack& b, const gu8* p_, int len_, int lane) {
+  // arguments of a real (non-inlined) device function count as divergent: without these two readfirstlanes the whole
+  // decoder below is compiled as exec-masked VALU code instead of a scalar program
+  const gu8* p = uni_ptr(p_); const int len = (int)uni((uint32_t)len_);
+  if (len <= 0) return false;
+  b.p = p; b.len = len; b.wbase = (len - 252) & ~3;      // the last byte sits at window offset <= 254
+  wb_fetch(b, lane);
+  const uint32_t lastb = wb_get1(b, len - 1, lane);
+  if (lastb == 0u) return false;
+  const int top = 31 - __builtin_clz(lastb);
+  b.bytepos = len - 1;
+  b.nacc = top;
+  b.acc = top ? (uint64_t)(lastb & ((1u << top) - 1u)) << (64 - top) : 0ull;
+  b.off = (len - 1) * 8 + top;
+  return true;
+}
+// n <= 32 bits, caller has refilled (nacc > 32 or the stream start reached)
+__device__ __forceinline__ uint32_t wb_take(WBack& b, int n) {
+  const uint32_t v = n ? (uint32_t)(b.acc >> (64 - n)) : 0u;
+  b.acc = n ? b.acc << n : b.acc;
+  b.nacc = b.nacc > n ? b.nacc - n : 0;
+  b.off -= n;
+  return v;
+}
+__device__ __forceinline__ uint32_t wb_read(WBack& b, int n, int lane) { wb_refill(b, lane); return wb_take(b, n); }
+struct WSeqState { WBack b; uint32_t sl, so, sm; uint32_t rep[3]; };
+__device__ __forceinline__ bool wseq_begin(WSeqState& st, int al_ll, int al_of, int al_ml, const gu8* src, int len, int lane) {
+  if (!wb_init(st.b, src, len, lane)) return false;
+  st.sl = wb_read(st.b, (int)uni((uint32_t)al_ll), lane); st.so = wb_read(st.b, (int)uni((uint32_t)al_of), lane); st.sm = wb_read(st.b, (int)uni((uint32_t)al_ml), lane);
+  return true;
+}
+// the tables are in LDS and their addresses in registers: through zd::SeqTabs (a struct the caller holds by reference,
+// i.e. in scratch memory) every sequence paid three scratch loads and three flat loads
+typedef __attribute__((address_space(3))) const uint32_t* lds_u32p;
+__device__ __forceinline__ bool wseq_next(WSeqState& st, lds_u32p lle, lds_u32p ofe, lds_u32p mle, bool last, zd::Seq& q, int lane) {
+  const uint32_t el = uni(lle[st.sl]), eo = uni(ofe[st.so]), em = uni(mle[st.sm]);
+  const int lc = zd::fse_sym(el), oc = zd::fse_sym(eo), mc = zd::fse_sym(em);
+  if (oc > 31 || mc > 52 || lc > 35) return false;
+  const uint32_t ov = (1u << oc) + wb_read(st.b, oc, lane);          // <= 31 bits
+  wb_refill(st.b, lane);                                              // <= 16 + 16 bits
+  q.ml = zd::ml_base(mc) + wb_take(st.b, zd::ml_bits(mc));
+  q.ll = zd::ll_base(lc) + wb_take(st.b, zd::ll_bits(lc));
+  if (!last) {
+    wb_refill(st.b, lane);                                            // <= 9 + 9 + 8 bits
+    st.sl = zd::fse_base(el) + wb_take(st.b, zd::fse_nb(el));
+    st.sm = zd::fse_base(em) + wb_take(st.b, zd::fse_nb(em));
+    st.so = zd::fse_base(eo) + wb_take(st.b, zd::fse_nb(eo));
+  }
+  if (st.b.off < 0) return false;
+  if (ov > 3) { q.off = ov - 3u; st.rep[2] = st.rep[1]; st.rep[1] = st.rep[0]; st.rep[0] = q.off; }
+  else {
+    uint32_t idx = ov - 1u;
+    if (q.ll == 0) idx++;
+    if (idx == 0) q.off = st.rep[0];
+    else {
+      q.off = idx < 3 ? (idx == 1 ? st.rep[1] : st.rep[2]) : st.rep[0] - 1u;
+      if (q.off == 0) return false;
+      if (idx > 1) st.rep[2] = st.rep[1];
+      st.rep[1] = st.rep[0]; st.rep[0] = q.off;
+    }
+  }
+  return true;
+}
+
 // one compressed block.  Returns true and advances op on success.  huf_valid / tabs state persist over the frame.
 __device__ bool zstd_block_wave(const uint8_t* b, int size, uint8_t* out, uint32_t cap, uint32_t& op, uint8_t* lit, ZstdLds* L,
-                                zd::Huf& huf, bool& huf_valid, zd::SeqTabs& tb, uint32_t* rep, int lane) {
+                                zd::Huf& huf, bool& huf_valid, zd::SeqTabs& tb, uint32_t* rep, int lane ZP_ARG) {
+  ZP_LAP(5);
   // ---- literals section header (lane 0, broadcast) ----
   zd::LitHdr lh = {0, 0, 0, 1, 0};
   uint32_t ok = 0;
@@ -127,6 +256,7 @@ __device__ bool zstd_block_wave(const uint8_t* b, int size, uint8_t* out, uint32
       huf_valid = true;
       hs += used; hlen -= used;
     } else if (!huf_valid) return false;
+    ZP_LAP(0);
     uint32_t good = 1;
     if (nstreams == 1) {
       if (lane == 0) good = zd::huf_decode_stream(huf, hs, hlen, lit, regen) ? 1u : 0u;
@@ -144,7 +274,9 @@ __device__ bool zstd_block_wave(const uint8_t* b, int size, uint8_t* out, uint32
     }
     if (__ballot(good == 0u)) return false;
     p += csize;
+    ZP_LAP(1);
   }
+  ZP_ADD(9, regen); ZP_ADD(10, 1);
   // ---- sequences section ----
   int nseq = 0, u0 = -1;
   if (lane == 0) u0 = zd::seq_count(b + p, size - p, &nseq);
@@ -157,45 +289,41 @@ __device__ bool zstd_block_wave(const uint8_t* b, int size, uint8_t* out, uint32
     const int modes = b[p++];
     if (modes & 3) return false;
     int used = -1;
-    zd::SeqState st;
     if (lane == 0) {
       int q = p, u;
       bool fine = true;
       if (fine && (u = zd::seq_table(tb.ll, tb.have_ll, 0, modes >> 6, b + q, size - q, L->norm, L->next)) >= 0) q += u; else fine = false;
       if (fine && (u = zd::seq_table(tb.of, tb.have_of, 1, (modes >> 4) & 3, b + q, size - q, L->norm, L->next)) >= 0) q += u; else fine = false;
       if (fine && (u = zd::seq_table(tb.ml, tb.have_ml, 2, (modes >> 2) & 3, b + q, size - q, L->norm, L->next)) >= 0) q += u; else fine = false;
-      st.rep[0] = rep[0]; st.rep[1] = rep[1]; st.rep[2] = rep[2];
-      if (fine && size - q >= 1 && zd::seq_begin(st, tb, b + q, size - q)) used = q;
+      if (fine && size - q >= 1) used = q;
     }
     used = (int)lane0_u32((uint32_t)used);
     if (used < 0) return false;
+    // the accuracy logs were set by lane 0: every lane needs them for the uniform decoder
+    tb.ll.al = (int)lane0_u32((uint32_t)tb.ll.al); tb.of.al = (int)lane0_u32((uint32_t)tb.of.al); tb.ml.al = (int)lane0_u32((uint32_t)tb.ml.al);
+    WSeqState st;
+    st.rep[0] = uni(rep[0]); st.rep[1] = uni(rep[1]); st.rep[2] = uni(rep[2]);
+    const lds_u32p lle = (lds_u32p)L->ll, ofe = (lds_u32p)L->of, mle = (lds_u32p)L->ml;
+    if (!wseq_begin(st, tb.ll.al, tb.of.al, tb.ml.al, as_global(b + used), size - used, lane)) return false;
+    ZP_LAP(2); ZP_ADD(8, nseq);
     for (int done = 0; done < nseq; done += 64) {
       const int m = nseq - done < 64 ? nseq - done : 64;
-      uint32_t fine = 1;
-      if (lane == 0) {                                         // serial: the FSE sequence stream
-        for (int i = 0; i < m; i++) {
-          zd::Seq q;
-          if (!zd::seq_next(st, tb, done + i + 1 == nseq, q)) { fine = 0; break; }
-          L->seq[3 * i] = q.ll; L->seq[3 * i + 1] = q.ml; L->seq[3 * i + 2] = q.off;
-        }
-        if (fine && done + m == nseq && st.b.off != 0) fine = 0;   // the bit stream must be consumed exactly
+      uint32_t ll_b = 0, ml_b = 0, off_b = 1;
+      bool fine = true;
+      for (int i = 0; i < m; i++) {                            // serial in the stream, uniform across the wave
+        zd::Seq q;
+        if (!wseq_next(st, lle, ofe, mle, done + i + 1 == nseq, q, lane)) { fine = false; break; }
+        if (lane == i) { ll_b = q.ll; ml_b = q.ml; off_b = q.off; }
       }
-      if (!lane0_u32(fine)) return false;
-#if BAMD_ZSTD_EXEC16
+      if (fine && done + m == nseq && st.b.off != 0) fine = false;   // the bit stream must be consumed exactly
+      if (!fine) return false;
+      ZP_LAP(3);
       for (int g = 0; g < m; g += 16)                          // wave-parallel execution, 16 sequences per group
-        if (!zstd_exec16(L, g, m - g < 16 ? m - g : 16, out, cap, op, lit, lp, (uint32_t)regen, lane)) return false;
-#else
-      for (int i = 0; i < m; i++) {                            // wave-parallel execution, in order
-        const uint32_t ll = uni(L->seq[3 * i]), ml = uni(L->seq[3 * i + 1]), off = uni(L->seq[3 * i + 2]);
-        if ((uint64_t)lp + ll > (uint64_t)regen || (uint64_t)op + ll + ml > (uint64_t)cap || off > op + ll) return false;
-        if (ll) wave_copy_disjoint(as_global(out) + op, as_global(lit) + lp, ll, lane);
-        wave_match_copy(as_global(out), op + ll, off, ml, lane);
-        op += ll + ml; lp += ll;
-      }
-#endif
+        if (!zstd_exec16(ll_b, ml_b, off_b, g, m - g < 16 ? m - g : 16, out, cap, op, lit, lp, (uint32_t)regen, lane)) return false;
+      ZP_LAP(4);
     }
-    if (lane == 0) { rep[0] = st.rep[0]; rep[1] = st.rep[1]; rep[2] = st.rep[2]; }
-    rep[0] = lane0_u32(rep[0]); rep[1] = lane0_u32(rep[1]); rep[2] = lane0_u32(rep[2]);
+    rep[0] = st.rep[0]; rep[1] = st.rep[1]; rep[2] = st.rep[2];
+
   }
   const uint32_t rest = (uint32_t)regen - lp;
   if ((uint64_t)op + rest > (uint64_t)cap) return false;
@@ -205,7 +333,7 @@ __device__ bool zstd_block_wave(const uint8_t* b, int size, uint8_t* out, uint32
 }
 
 // one frame -> out[0..cap); returns bytes produced, 0 on any error (zstd_wrap_decompress's contract)
-__device__ __attribute__((noinline)) int zstd_decode_wave(const uint8_t* in, int n, uint8_t* out, int cap, uint8_t* lit, ZstdLds* L, int lane) {
+__device__ __attribute__((noinline)) int zstd_decode_wave(const uint8_t* in, int n, uint8_t* out, int cap, uint8_t* lit, ZstdLds* L, int lane ZP_ARG) {
   long long fcs = -1; bool checksum = false;
   int ip = -1;
   if (lane == 0) ip = zd::frame_header(in, n, &fcs, &checksum);
@@ -236,7 +364,7 @@ __device__ __attribute__((noinline)) int zstd_decode_wave(const uint8_t* in, int
     } else if (type == 2) {
       if (bsize > (1 << 17) || ip + bsize > n) break;
       // the table state lives in lane 0's registers + LDS; al / have flags are broadcast after each block
-      if (!zstd_block_wave(in + ip, bsize, out, (uint32_t)cap, op, lit, L, huf, huf_valid, tb, rep, lane)) break;
+      if (!zstd_block_wave(in + ip, bsize, out, (uint32_t)cap, op, lit, L, huf, huf_valid, tb, rep, lane ZP_PASS)) break;
       tb.ll.al = (int)lane0_u32((uint32_t)tb.ll.al); tb.of.al = (int)lane0_u32((uint32_t)tb.of.al); tb.ml.al = (int)lane0_u32((uint32_t)tb.ml.al);
       tb.have_ll = lane0_u32(tb.have_ll) != 0u; tb.have_of = lane0_u32(tb.have_of) != 0u; tb.have_ml = lane0_u32(tb.have_ml) != 0u;
       ip += bsize;
@@ -255,7 +383,12 @@ __device__ __attribute__((noinline)) int zstd_decode_wave(const uint8_t* in, int
 constexpr int ZSTD_WAVES_PER_CU = 12;
 __global__ __launch_bounds__(64, 3) void k_zstd_streams(StreamDesc* __restrict__ streams, int nstreams, int32_t* __restrict__ status,
                                                      uint32_t* __restrict__ ticket, const ChunkDesc* __restrict__ chunks,
-                                                     const BlockDesc* __restrict__ blocks, uint32_t* __restrict__ done) {
+                                                     const BlockDesc* __restrict__ blocks, uint32_t* __restrict__ done,
+                                                     const uint32_t* __restrict__ taken /* ZMeta words (k_zstd2.hip), 8 per stream; nullptr: take everything */
+#ifdef BAMD_PROFILE_DECODE
+                                                     , uint32_t* __restrict__ profbuf
+#endif
+                                                     ) {
   __shared__ ZstdLds lds;
   const int lane = threadIdx.x & 63;
   uint32_t sid = take_ticket(ticket, lane);
@@ -263,13 +396,21 @@ __global__ __launch_bounds__(64, 3) void k_zstd_streams(StreamDesc* __restrict__
   while (sid < (uint32_t)nstreams) {
     StreamDesc* sd = streams + sid;
     const int32_t csize = (int32_t)uni((uint32_t)sd->in_size), want = (int32_t)uni((uint32_t)sd->out_size);
-    if (uni((uint32_t)sd->fmt) == (uint32_t)FMT_ZSTD && csize >= 0 && csize != want) {
+    const bool mine = !taken || uni(taken[8 * (size_t)sid]) == 0u;     // 0 = ZM_FALLBACK: the two-phase path left this frame alone
+    if (mine && uni((uint32_t)sd->fmt) == (uint32_t)FMT_ZSTD && csize >= 0 && csize != want) {
       const ChunkDesc* c = chunks + uni((uint32_t)sd->chunk);
       const BlockDesc* b = blocks + uni((uint32_t)sd->aux);
       // literal scratch: this stream's slice of the chunk's `stage` area (same offset as its output)
       const size_t boff = (size_t)uni((uint32_t)b->blk) * (size_t)uni((uint32_t)c->blocksize) +
                           (size_t)(sid - uni((uint32_t)b->first_stream)) * (size_t)want;
-      const int got = zstd_decode_wave(sd->in, csize, sd->out, want, c->stage + boff, &lds, lane);
+#ifdef BAMD_PROFILE_DECODE
+      ZProf zp; for (int i_ = 0; i_ < 16; i_++) zp.c[i_] = 0; zp.t = __builtin_amdgcn_s_memtime();
+#endif
+      const int got = zstd_decode_wave(sd->in, csize, sd->out, want, c->stage + boff, &lds, lane ZP_PASS);
+#ifdef BAMD_PROFILE_DECODE
+      ZP_LAP(5);
+      if (profbuf && lane == 0) for (int i_ = 0; i_ < 16; i_++) profbuf[(size_t)sid * 16 + i_] = zp.c[i_];
+#endif
       if (lane == 0) {
         sd->result = got;
         if (got != want) atomicMin(&status[sd->chunk], (int32_t)ST_BADCODEC);   // blosc.c:780-782

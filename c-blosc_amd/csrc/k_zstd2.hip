@@ -1,0 +1,261 @@
+// k_zstd2.hip — two-phase Zstd decode for the common frame shape (one compressed block per frame: what blosc writes
+// for blocks of at most 128 KiB).
+//
+// Why: with one wavefront per frame (k_zstd.hip) the entropy decoding - 4000 dependent FSE steps per frame on bench19 -
+// is a scalar program, and ALL waves of a CU share its one scalar unit (or, as vector code, its four SIMDs): ~120
+// instructions per sequence x 12 waves = 1500 cycles per sequence and wave (profiles/r02_e_zstd_decode_phases.txt).
+// The instruction count per sequence is what it is; the way to use the machine is to let the LANES of a wave work on
+// DIFFERENT frames.
+//
+//   phase A  k_zstd_entropy: 16 frames per wavefront, 4 lanes per frame.  Lane 0 of a group runs the serial pieces of
+//            zstd_serial.h (headers, table builds, the FSE sequence stream) with the frame's tables in the group's own
+//            LDS slice; the four Huffman streams of the literals run on the group's four lanes.  Output: the literals
+//            (scratch), the sequences as packed (literal length, match length, offset) triples, and a small record.
+//   phase B  k_zstd_exec: one wavefront per frame, no tables, no LDS: 64 triples per load, executed 16 at a time with
+//            the wave-cooperative copies of k_zstd.hip (zstd_exec16).
+// Frames of any other shape (several blocks, raw / RLE blocks, treeless literals, more sequences than the triple
+// scratch holds) are left to k_zstd_streams, which skips the frames phase A has taken.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "dev_types.h"
+#include "wave_prims.h"
+#include "zstd_serial.h"
+
+namespace bamd {
+
+enum : uint32_t { ZM_FALLBACK = 0, ZM_READY = 1, ZM_ERROR = 2 };
+struct ZMeta {
+  uint32_t state;
+  uint32_t nseq, regen;
+  uint32_t lit_mode;     // 0: decoded into the literal scratch, 1: raw at in + lit_src, 2: RLE byte lit_src
+  uint32_t lit_src;
+  uint32_t pad_[3];
+};
+
+// LDS of one frame group: the Huffman table and the three FSE tables are never needed at the same time
+struct ZgLds {
+  union { uint16_t huf[2048]; uint32_t fse[3][512]; } t;
+  uint32_t ftab[64];
+  uint16_t next[3][256];     // one table-build scratch per table: the three FSE tables are built by three lanes at once
+  int16_t norm[3][64];
+  uint8_t w[256];
+};
+constexpr int ZG_FRAMES = 16;        // frames per wavefront (4 lanes each)
+
+__device__ __forceinline__ uint64_t zpack(uint32_t ll, uint32_t ml, uint32_t off) { return (uint64_t)ll | ((uint64_t)ml << 18) | ((uint64_t)off << 36); }
+
+// where the triples of a stream live: same offset as its literal scratch, in the arena `zseq_delta` bytes further on
+__device__ __forceinline__ uint64_t* zseq_ptr(const uint8_t* lit, ptrdiff_t zseq_delta) {
+  return (uint64_t*)(((uintptr_t)lit + (uintptr_t)zseq_delta) & ~(uintptr_t)7);
+}
+
+__global__ __launch_bounds__(64) void k_zstd_entropy(const StreamDesc* __restrict__ streams, int nstreams, const ChunkDesc* __restrict__ chunks,
+                                                     const BlockDesc* __restrict__ blocks, ZMeta* __restrict__ meta, ptrdiff_t zseq_delta) {
+  __shared__ ZgLds lds[ZG_FRAMES];
+  const int lane = threadIdx.x & 63, g = lane >> 2, sub = lane & 3;
+  const int sid = (int)blockIdx.x * ZG_FRAMES + g;
+  ZgLds* L = &lds[g];
+  // ---- lane 0 of the group: everything up to the literal streams ----
+  uint32_t state = ZM_FALLBACK;
+  bool take = false;
+  const uint8_t* in = nullptr; int n = 0, want = 0;
+  uint8_t* lit = nullptr;
+  const uint8_t* b = nullptr; int size = 0, p = 0;
+  zd::LitHdr lh = {0, 0, 0, 1, 0};
+  zd::Huf huf = {L->t.huf, 0};
+  uint32_t lit_mode = 0, lit_src = 0;
+  int hs_off = 0, hlen = 0;                 // Huffman payload (behind the table description)
+  if (sid < nstreams) {
+    const StreamDesc& sd = streams[sid];
+    in = sd.in; n = sd.in_size; want = sd.out_size;
+    take = sd.fmt == FMT_ZSTD && n >= 0 && n != want;
+    if (take) {
+      const ChunkDesc& c = chunks[sd.chunk];
+      const BlockDesc& bk = blocks[sd.aux];
+      lit = c.stage + (size_t)bk.blk * (size_t)c.blocksize + (size_t)(sid - bk.first_stream) * (size_t)want;
+    }
+  }
+  if (take && sub == 0) {
+    long long fcs = -1; bool checksum = false;
+    const int ip = zd::frame_header(in, n, &fcs, &checksum);
+    if (ip < 0 || (fcs >= 0 && fcs != (long long)want)) state = ZM_ERROR;
+    else if (ip + 3 <= n) {
+      const uint32_t bh = (uint32_t)in[ip] | ((uint32_t)in[ip + 1] << 8) | ((uint32_t)in[ip + 2] << 16);
+      const int last = bh & 1u, type = (bh >> 1) & 3u, bsize = (int)(bh >> 3);
+      // exactly one compressed block that fills the frame: everything else goes the general way
+      if (last && type == 2 && bsize <= (1 << 17) && ip + 3 + bsize + (checksum ? 4 : 0) == n) {
+        b = in + ip + 3; size = bsize;
+        if (!zd::lit_header(b, size, lh) || lh.regen > want) state = ZM_ERROR;
+        else {
+          p = lh.hdr;
+          state = ZM_READY;
+          if (lh.type == 0) {
+            if (p + lh.regen > size) state = ZM_ERROR;
+            lit_mode = 1; lit_src = (uint32_t)(ip + 3 + p); p += lh.regen;
+          } else if (lh.type == 1) {
+            if (p + 1 > size) state = ZM_ERROR; else { lit_mode = 2; lit_src = b[p]; p += 1; }
+          } else if (lh.type == 2) {
+            if (p + lh.csize > size) state = ZM_ERROR;
+            else {
+              const int used = zd::huf_read_table(huf, b + p, lh.csize, L->w, L->ftab, L->next[0], L->norm[0]);
+              if (used < 0) state = ZM_ERROR; else { hs_off = p + used; hlen = lh.csize - used; }
+            }
+          } else state = ZM_FALLBACK;          // treeless literals need the previous block's table
+        }
+      }
+    }
+  }
+  // ---- the group's four lanes: Huffman streams ----
+  const int src0 = (lane & ~3) << 2;          // ds_bpermute address of the group's lane 0
+  const uint32_t gstate = (uint32_t)__builtin_amdgcn_ds_bpermute(src0, (int)state);
+  const int gtype = __builtin_amdgcn_ds_bpermute(src0, lh.type);
+  uint32_t lit_ok = 1;
+  if (take && gstate == ZM_READY && gtype == 2) {
+    const int g_regen = __builtin_amdgcn_ds_bpermute(src0, lh.regen), g_nstreams = __builtin_amdgcn_ds_bpermute(src0, lh.nstreams);
+    const int g_hs = __builtin_amdgcn_ds_bpermute(src0, hs_off), g_hlen = __builtin_amdgcn_ds_bpermute(src0, hlen);
+    const int g_mb = __builtin_amdgcn_ds_bpermute(src0, huf.maxbits);
+    const int g_boff = __builtin_amdgcn_ds_bpermute(src0, (int)(b - in));
+    const uint8_t* hs = in + g_boff + g_hs;
+    zd::Huf h2 = {L->t.huf, g_mb};
+    if (g_nstreams == 1) {
+      if (sub == 0) lit_ok = zd::huf_decode_stream(h2, hs, g_hlen, lit, g_regen) ? 1u : 0u;
+    } else if (g_hlen < 6) lit_ok = 0;
+    else {
+      const int s1 = hs[0] | (hs[1] << 8), s2 = hs[2] | (hs[3] << 8), s3 = hs[4] | (hs[5] << 8), s4 = g_hlen - 6 - s1 - s2 - s3;
+      const int q = (g_regen + 3) / 4;
+      if (s4 < 1 || 3 * q > g_regen) lit_ok = 0;
+      else {
+        const int so = sub == 0 ? 0 : (sub == 1 ? s1 : (sub == 2 ? s1 + s2 : s1 + s2 + s3));
+        const int sl = sub == 0 ? s1 : (sub == 1 ? s2 : (sub == 2 ? s3 : s4));
+        const int cnt = sub < 3 ? q : g_regen - 3 * q;
+        lit_ok = zd::huf_decode_stream(h2, hs + 6 + so, sl, lit + sub * q, cnt) ? 1u : 0u;
+      }
+    }
+  }
+  // all four verdicts to lane 0 of the group
+  const uint32_t v1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src0 + 4, (int)lit_ok), v2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src0 + 8, (int)lit_ok);
+  const uint32_t v3 = (uint32_t)__builtin_amdgcn_ds_bpermute(src0 + 12, (int)lit_ok);
+  // ---- lane 0 again: sequence count and the three table descriptions ----
+  int nseq = 0;
+  int t_nsym[3] = {0, 0, 0}, t_al[3] = {0, 0, 0}, t_kind[3] = {-1, -1, -1};    // kind: 0 / 2 build from norm, 1 RLE (done), -1 nothing to build
+  if (take && sub == 0 && state == ZM_READY) {
+    if (!(lit_ok & v1 & v2 & v3)) state = ZM_ERROR;
+    if (lh.type == 2) p += lh.csize;
+    if (state == ZM_READY) {
+      const int u0 = zd::seq_count(b + p, size - p, &nseq);
+      if (u0 < 0) state = ZM_ERROR; else p += u0;
+    }
+    if (state == ZM_READY && nseq > want / 8) state = ZM_FALLBACK;       // the triple scratch of this stream is `want` bytes
+    if (state == ZM_READY && nseq > 0) {
+      bool fine = p < size;
+      int modes = 0;
+      if (fine) { modes = b[p++]; fine = (modes & 3) == 0; }
+      for (int k = 0; fine && k < 3; k++) {                               // table order in the stream: LL, OF, ML
+        const int mode = (modes >> (6 - 2 * k)) & 3;
+        const int max_sym = k == 0 ? 35 : (k == 1 ? 31 : 52), max_al = k == 1 ? 8 : 9;
+        if (mode == 0) {
+          t_nsym[k] = k == 0 ? 36 : (k == 1 ? 29 : 53); t_al[k] = k == 1 ? 5 : 6; t_kind[k] = 0;
+          for (int s_ = 0; s_ < t_nsym[k]; s_++) L->norm[k][s_] = k == 0 ? zd::ll_default(s_) : (k == 1 ? zd::of_default(s_) : zd::ml_default(s_));
+        } else if (mode == 1) {
+          if (size - p < 1 || b[p] > max_sym) fine = false;
+          else { L->t.fse[k][0] = (uint32_t)b[p]; t_al[k] = 0; t_kind[k] = 1; p += 1; }
+        } else if (mode == 2) {
+          const int h = zd::fse_read_ncount(b + p, size - p, max_al, max_sym, L->norm[k], &t_nsym[k], &t_al[k]);
+          if (h < 0) fine = false; else { t_kind[k] = 2; p += h; }
+        } else fine = false;                                               // repeat mode: there is no previous block in these frames
+      }
+      if (!fine) state = ZM_ERROR;
+    } else if (state == ZM_READY && p != size) state = ZM_ERROR;            // no sequences: nothing may follow the count byte
+  }
+  // ---- lanes 0 / 1 / 2 of the group build the LL / OF / ML tables side by side ----
+  uint32_t built = 1;
+  {
+    const uint32_t gs = (uint32_t)__builtin_amdgcn_ds_bpermute(src0, (int)state);
+    const int gn = __builtin_amdgcn_ds_bpermute(src0, nseq);
+    int kd = -1, ns = 0, al = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int a = __builtin_amdgcn_ds_bpermute(src0, t_kind[k]), bb = __builtin_amdgcn_ds_bpermute(src0, t_nsym[k]), c2 = __builtin_amdgcn_ds_bpermute(src0, t_al[k]);
+      if (sub == k) { kd = a; ns = bb; al = c2; }
+    }
+    if (take && gs == ZM_READY && gn > 0 && sub < 3 && (kd == 0 || kd == 2)) {
+      zd::Fse ft = {L->t.fse[sub], 0};
+      built = zd::fse_build(ft, L->norm[sub], ns, al, L->next[sub]) ? 1u : 0u;
+    }
+  }
+  const uint32_t b1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src0 + 4, (int)built), b2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src0 + 8, (int)built);
+  // ---- lane 0: the FSE sequence stream ----
+  if (take && sub == 0) {
+    if (state == ZM_READY && nseq > 0) {
+      bool fine = (built & b1 & b2) != 0u;
+      uint64_t* sq = zseq_ptr(lit, zseq_delta);
+      zd::SeqTabs tb = {{L->t.fse[0], t_al[0]}, {L->t.fse[1], t_al[1]}, {L->t.fse[2], t_al[2]}, true, true, true};
+      zd::SeqState st;
+      st.rep[0] = 1u; st.rep[1] = 4u; st.rep[2] = 8u;
+      if (fine) fine = size - p >= 1 && zd::seq_begin(st, tb, b + p, size - p);
+      for (int i = 0; fine && i < nseq; i++) {
+        zd::Seq q;
+        if (!zd::seq_next(st, tb, i + 1 == nseq, q)) { fine = false; break; }
+        sq[i] = zpack(q.ll, q.ml, q.off);
+      }
+      if (fine && st.b.off != 0) fine = false;                              // the bit stream must be consumed exactly
+      if (!fine) state = ZM_ERROR;
+    }
+    ZMeta m;
+    m.state = state; m.nseq = (uint32_t)nseq; m.regen = (uint32_t)lh.regen; m.lit_mode = lit_mode; m.lit_src = lit_src;
+    m.pad_[0] = m.pad_[1] = m.pad_[2] = 0;
+    meta[sid] = m;
+  } else if (sid < nstreams && sub == 0) {
+    ZMeta m;
+    m.state = ZM_FALLBACK; m.nseq = 0; m.regen = 0; m.lit_mode = 0; m.lit_src = 0; m.pad_[0] = m.pad_[1] = m.pad_[2] = 0;
+    meta[sid] = m;
+  }
+}
+
+// phase B: one wavefront per frame, persistent + ticket
+constexpr int ZEXEC_WAVES_PER_CU = 32;
+__global__ __launch_bounds__(64, 8) void k_zstd_exec(StreamDesc* __restrict__ streams, int nstreams, int32_t* __restrict__ status, uint32_t* __restrict__ ticket,
+                                                     const ChunkDesc* __restrict__ chunks, const BlockDesc* __restrict__ blocks,
+                                                     const ZMeta* __restrict__ meta, ptrdiff_t zseq_delta) {
+  const int lane = threadIdx.x & 63;
+  uint32_t sid = take_ticket(ticket, lane);
+  while (sid < (uint32_t)nstreams) {
+    const uint32_t state = uni(meta[sid].state);
+    StreamDesc* sd = streams + sid;
+    if (state == ZM_ERROR) {
+      if (lane == 0) { sd->result = 0; atomicMin(&status[sd->chunk], (int32_t)ST_BADCODEC); }
+    } else if (state == ZM_READY) {
+      const uint32_t want = uni((uint32_t)sd->out_size);
+      const ChunkDesc* c = chunks + uni((uint32_t)sd->chunk);
+      const BlockDesc* bk = blocks + uni((uint32_t)sd->aux);
+      uint8_t* litbuf = c->stage + (size_t)uni((uint32_t)bk->blk) * (size_t)uni((uint32_t)c->blocksize) +
+                        (size_t)(sid - uni((uint32_t)bk->first_stream)) * (size_t)want;
+      const uint64_t* sq = zseq_ptr(litbuf, zseq_delta);
+      const uint32_t nseq = uni(meta[sid].nseq), regen = uni(meta[sid].regen), lmode = uni(meta[sid].lit_mode), lsrc = uni(meta[sid].lit_src);
+      const uint8_t* lit = litbuf;
+      if (lmode == 1u) lit = sd->in + lsrc;
+      else if (lmode == 2u) wave_fill(as_global(litbuf), lsrc, regen, lane);
+      uint32_t op = 0, lp = 0;
+      bool ok = true;
+      for (uint32_t done = 0; ok && done < nseq; done += 64u) {
+        const uint32_t m = nseq - done < 64u ? nseq - done : 64u;
+        const uint64_t q = (uint32_t)lane < m ? sq[done + (uint32_t)lane] : 0ull;
+        const uint32_t ll_b = (uint32_t)q & 0x3ffffu, ml_b = (uint32_t)(q >> 18) & 0x3ffffu, off_b = (uint32_t)(q >> 36);
+        for (uint32_t g = 0; ok && g < m; g += 16u)
+          ok = zstd_exec16(ll_b, ml_b, off_b, (int)g, (int)(m - g < 16u ? m - g : 16u), sd->out, want, op, lit, lp, regen, lane);
+      }
+      if (ok) {
+        const uint32_t rest = regen - lp;
+        if ((uint64_t)op + rest > (uint64_t)want) ok = false;
+        else { if (rest) wave_copy_disjoint(as_global(sd->out) + op, as_global(lit) + lp, rest, lane); op += rest; }
+      }
+      if (lane == 0) {
+        sd->result = ok ? (int32_t)op : 0;
+        if (!ok || op != want) atomicMin(&status[sd->chunk], (int32_t)ST_BADCODEC);   // blosc.c:780-782
+      }
+    }
+    sid = take_ticket(ticket, lane);
+  }
+}
+
+}  // namespace bamd

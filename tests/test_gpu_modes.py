@@ -37,3 +37,13 @@ def test_mode_combination(flip):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "mode_check.py")], env=env, timeout=600,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert p.returncode == 0 and "modes ok" in p.stdout, (flip, p.stdout[-2000:], p.stderr[-3000:])
+
+
+def test_zstd_two_phase_decoder():
+    """BLOSC_AMD_ZSTD2=1 (k_zstd_entropy + k_zstd_exec, off by default): the whole Zstd decode suite - reference-written
+    frames, corrupted frames with the oracle's verdict, getitem, mixed batches - in a process of its own."""
+    env = dict(os.environ)
+    env["BLOSC_AMD_ZSTD2"] = "1"
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_zstd.py"), "-m", "gpu", "-q", "-x", "--no-header",
+                        "-p", "no:cacheprovider"], env=env, timeout=900, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 0 and " passed" in p.stdout and "failed" not in p.stdout, (p.stdout[-3000:], p.stderr[-2000:])
