@@ -316,7 +316,7 @@ __attribute__((visibility("default"))) int blosc_internal_bitunshuffle(const siz
   return (int)((n % 8) ? n : n * typesize);
 }
 
-// test hooks for the host policy (tests/test_host_policy.py compares them with the oracle)
+// test hooks for the host policy (tests/test_host_abi.py::test_policy_equals_oracle compares them with the oracle)
 __attribute__((visibility("default"))) int blosc_amd_policy_blocksize(int clevel, int typesize, int nbytes, int forced,
                                                                       int codec, int splitmode) {
   return compute_blocksize(clevel, typesize, nbytes, forced, codec, splitmode);

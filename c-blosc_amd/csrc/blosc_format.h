@@ -5,7 +5,7 @@
 //   header layout            blosc/blosc.c:1148-1247, README_CHUNK_FORMAT.rst:15-76
 //   compute_blocksize        blosc/blosc.c:962-1060
 //   split_block              blosc/blosc.c:929-959
-// tests/test_host_policy.py checks them against the oracle (itself pinned to the reference).
+// tests/test_host_abi.py::test_policy_equals_oracle checks them against the oracle (itself pinned to the reference).
 #pragma once
 #include <limits.h>
 #include <stdint.h>

@@ -37,16 +37,6 @@ __host__ __device__ inline int shuffle_tile_elems(int T) {
   return e;
 }
 
-struct BlockGeom {
-  const uint8_t* shuf;  // plane-major side
-  uint8_t* nat;         // element-major side (as byte pointer; const-ness handled by caller)
-  int T, N, bsize;
-};
-
-__device__ __forceinline__ bool block_geom(const ChunkDesc& c, const BlockDesc& b, int& bsize) {
-  bsize = b.bsize;
-  return true;
-}
 
 // ---------------------------------------------------------------------------------------------
 // byte unshuffle: plane-major (src) -> element-major (dst)
@@ -157,7 +147,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_unshuffle(const ChunkDesc* __res
   const BlockDesc b = blocks[blockIdx.x];
   const ChunkDesc& c = chunks[b.chunk];
   if (!(c.mode & CH_SHUFFLE) || (c.mode & (CH_MEMCPYED | CH_SKIP | CH_FUSED_UNSHUF))) return;
-  int bsize; block_geom(c, b, bsize);
+  const int bsize = b.bsize;
   const int T = c.typesize, N = bsize / T;
   const int E = shuffle_tile_elems(T);
   const int e0 = blockIdx.y * E;
@@ -269,7 +259,7 @@ __global__ __launch_bounds__(FT_THREADS) void k_shuffle(const ChunkDesc* __restr
   const BlockDesc b = blocks[blockIdx.x];
   const ChunkDesc& c = chunks[b.chunk];
   if (!(c.mode & CH_SHUFFLE) || (c.mode & (CH_MEMCPYED | CH_SKIP | CH_FUSED_SHUF))) return;
-  int bsize; block_geom(c, b, bsize);
+  const int bsize = b.bsize;
   const int T = c.typesize, N = bsize / T;
   const int E = shuffle_tile_elems(T);
   const int e0 = blockIdx.y * E;
@@ -389,7 +379,7 @@ __device__ void bitfilter_block(const ChunkDesc* chunks, const BlockDesc* blocks
   const BlockDesc b = blocks[blockIdx.x];
   const ChunkDesc& c = chunks[b.chunk];
   if (!(c.mode & CH_BITSHUFFLE) || (c.mode & (CH_MEMCPYED | CH_SKIP))) return;
-  int bsize; block_geom(c, b, bsize);
+  const int bsize = b.bsize;
   const int T = c.typesize;
   const size_t boff = (size_t)b.blk * c.blocksize;
   const gu8* src = as_global(DIR == 0 ? c.src : (const uint8_t*)c.filt) + boff;

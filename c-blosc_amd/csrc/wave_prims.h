@@ -9,7 +9,7 @@
 // no cache maintenance: one wave lives on one CU and uses that CU's L1).  A load issued after a
 // store of the same wave therefore observes the stored bytes, also when another lane wrote them.
 // That is what makes "store literal bytes, then gather match bytes that may overlap them"
-// correct without fences; tests/test_gpu_lz_decode.py has adversarial streams for it.
+// correct without fences; tests/test_gpu_decompress.py (test_handbuilt_lz4_streams, test_handbuilt_blosclz_streams) has adversarial streams for it.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

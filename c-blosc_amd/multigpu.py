@@ -11,7 +11,6 @@ from typing import List, Tuple
 
 def chunk_range(nchunks: int, world: int, rank: int) -> Tuple[int, int]:
     """Contiguous slice [lo, hi) of chunk indices owned by `rank` (chunk c -> GPU floor(c*G/nchunks))."""
-    lo = (rank * nchunks + world - 1) // world if rank else 0
     # smallest c with floor(c*world/nchunks) >= rank
     lo = -(-rank * nchunks // world)
     hi = -(-(rank + 1) * nchunks // world)

@@ -1,0 +1,58 @@
+"""GPU: the multi-GPU path of SURVEY §8e with the code that runs on a node - backend "nccl" (RCCL) - at the one
+world size this box has: ONE logical chunk list, multigpu.chunk_range() for this rank, the batched call on that range,
+gather_cbytes() over RCCL (communicator of size 1), and the checks a consumer of the consolidated table makes.
+The world-size-2 logic (ragged ranges, padding of the all_gather) is covered on CPU with gloo in
+tests/test_multigpu_gloo.py; bench.py --gpus N runs exactly this sequence per rank."""
+import importlib.util
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from helpers import DATASETS, orc_decompress
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_partition_batch_and_rccl_gather(pkg, oracle):
+    import torch
+    import torch.distributed as dist
+    spec = importlib.util.spec_from_file_location("c_blosc_amd_multigpu", os.path.join(ROOT, "c-blosc_amd", "multigpu.py"))
+    multigpu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(multigpu)
+    dev = torch.device("cuda:0")
+    rdv = tempfile.NamedTemporaryFile(prefix="bamd_rdv_", delete=False)
+    rdv.close()
+    os.unlink(rdv.name)
+    dist.init_process_group("nccl", init_method=f"file://{rdv.name}", rank=0, world_size=1, device_id=dev)
+    try:
+        nchunks, csz = 24, 4 << 20
+        kinds = ["bench19", "linspace", "randwalk", "zeros"]
+        host = [DATASETS[kinds[i % 4]](csz) for i in range(nchunks)]          # the logical chunk list
+        lo, hi = multigpu.chunk_range(nchunks, dist.get_world_size(), dist.get_rank())
+        assert (lo, hi) == (0, nchunks)
+        src = torch.stack([torch.from_numpy(h) for h in host[lo:hi]]).to(dev)
+        comp = torch.zeros((hi - lo, csz + 16), dtype=torch.uint8, device=dev)
+        back = torch.zeros((hi - lo, csz), dtype=torch.uint8, device=dev)
+        bc = pkg.DeviceBatch([src[i].data_ptr() for i in range(hi - lo)], [csz] * (hi - lo), [comp[i].data_ptr() for i in range(hi - lo)], [csz + 16] * (hi - lo))
+        assert bc.compress(8, 5, 1, b"lz4") == 0
+        cb = bc.results()
+        assert all(c > 0 for c in cb)
+        table, offsets = multigpu.gather_cbytes(cb, nchunks, device=dev)          # RCCL all_gather
+        assert table == cb and offsets[0] == 0 and all(offsets[i + 1] == offsets[i] + cb[i] for i in range(nchunks - 1))
+        assert all(multigpu.owner_of(c, nchunks, 1) == 0 for c in range(nchunks))
+        # the consolidated view is enough to find and decode any chunk
+        for i in (0, 7, nchunks - 1):
+            r, out = orc_decompress(oracle, comp[i][:table[i]].cpu().numpy(), csz)
+            assert r == csz and np.array_equal(out, host[i])
+        bd = pkg.DeviceBatch([comp[i].data_ptr() for i in range(hi - lo)], table[lo:hi], [back[i].data_ptr() for i in range(hi - lo)], [csz] * (hi - lo))
+        assert bd.decompress() == 0 and bd.results() == [csz] * (hi - lo)
+        assert torch.equal(back, src)
+        # byte counters / elapsed time are reduced the way bench.py does it
+        t = torch.tensor([float(sum(cb))], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        assert float(t.item()) == float(sum(table))
+    finally:
+        dist.destroy_process_group()
