@@ -587,6 +587,10 @@ __device__ __forceinline__ Rows<T> unshuffle_load(const PlanePtrs<T>& pp, uint32
   for (int j = 0; j < T; j++) x.r[j] = g_ld4(pp.p[j] + rel + 4u * (uint32_t)lane);
   return x;
 }
+#ifndef BAMD_DST_STREAM
+#define BAMD_DST_STREAM 0     // 1: final output of the fused unshuffle written through and dropped from L2 (g_st16_stream): measured 8.2 ms instead of 5.4 (bench19), off
+#endif
+__device__ __forceinline__ void st16_dst(gu8* p, uint4 v) { if (BAMD_DST_STREAM) g_st16_stream(p, v); else g_st16(p, v); }
 template <int T>
 __device__ __forceinline__ void unshuffle_store(gu8* dst, uint32_t e, int lane, const Rows<T>& x) {
   gu8* o = dst + (size_t)(e + 4u * (uint32_t)lane) * T;
@@ -595,10 +599,10 @@ __device__ __forceinline__ void unshuffle_store(gu8* dst, uint32_t e, int lane, 
   if (T == 8) {
     uint32_t u0, u1, u2, u3;
     transpose4x4(x.r[4], x.r[5], x.r[6], x.r[7], u0, u1, u2, u3);
-    g_st16(o, make_uint4(t0, u0, t1, u1));         // elements 0, 1 (8 bytes each)
-    g_st16(o + 16, make_uint4(t2, u2, t3, u3));    // elements 2, 3
+    st16_dst(o, make_uint4(t0, u0, t1, u1));         // elements 0, 1 (8 bytes each)
+    st16_dst(o + 16, make_uint4(t2, u2, t3, u3));    // elements 2, 3
   } else {
-    g_st16(o, make_uint4(t0, t1, t2, t3));         // elements 0..3 (4 bytes each)
+    st16_dst(o, make_uint4(t0, t1, t2, t3));         // elements 0..3 (4 bytes each)
   }
 }
 

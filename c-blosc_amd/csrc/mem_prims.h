@@ -31,6 +31,12 @@ __device__ __forceinline__ void g_st16(gu8* p, uint4 v) {
   v4u32 t = {v.x, v.y, v.z, v.w};
   *(BAMD_GAS v4u32_una*)p = t;
 }
+// 16-byte store that does not stay in the XCD's L2 (sc0 sc1: written through and dropped, MI355X_MICROARCH.md "stores of
+// each flavour"): for final output nobody on the chip reads again, so that it does not push scratch lines out of L2
+__device__ __forceinline__ void g_st16_stream(gu8* p, uint4 v) {
+  v4u32 t = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(t) : "memory");
+}
 __device__ __forceinline__ uint32_t g_ld4(const gu8* p) { return *(const BAMD_GAS u32una*)p; }
 __device__ __forceinline__ uint64_t g_ld8(const gu8* p) { return *(const BAMD_GAS u64una*)p; }
 __device__ __forceinline__ void g_st4(gu8* p, uint32_t v) { *(BAMD_GAS u32una*)p = v; }
