@@ -624,7 +624,7 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
       for (int v = 0; v < (g ? 2 : 1); v++) {
         ProfScope ps(st, stream, v ? "k_decode_blocks8" : "k_decode_blocks");   // 4 / 8 waves per block (<= 4 / more planes with real LZ work)
         const int W = v ? 8 : 4;
-        const unsigned grid = (unsigned)std::min<size_t>((size_t)st.cus * (BD_WAVES_PER_CU / W), L.nlist[g]);
+        const unsigned grid = (unsigned)std::min<size_t>((size_t)st.cus * (W == 4 ? BD_WG4_PER_CU : BD_WG8_PER_CU), L.nlist[g]);
         uint32_t* d_prof = nullptr;
 #ifdef BAMD_PROFILE_DECODE
         const size_t profn = (size_t)grid * W * 16;
@@ -760,7 +760,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   std::vector<int32_t> blist[2];
   size_t nstr_lds = 0;
   const size_t far_stride = pick_lds_blocks(chunks, blocks, blist, &nstr_lds);
-  const size_t far_wgs = (size_t)st.cus * (BD_WAVES_PER_CU / 4);  // most workgroups any variant launches
+  const size_t far_wgs = (size_t)st.cus * BD_WG4_PER_CU;         // most workgroups any variant launches
 
   Carver cv;
   const size_t o_chunks = cv.take(sizeof(ChunkDesc) * (size_t)n);

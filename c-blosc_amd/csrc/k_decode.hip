@@ -155,17 +155,24 @@ __device__ __forceinline__ bool span_long_match(gu8* out, uint32_t mpos, uint32_
 }
 
 __device__ __forceinline__ uint32_t lz4_batch_step(const Window& w, gu8* out, volatile uint32_t* scr_generic, uint32_t& ip, uint32_t& op,
-                                                   uint32_t cap, int lane, SpanCtx& sp PROF_ARG) {
+                                                   uint32_t cap, uint32_t n, int lane, SpanCtx& sp PROF_ARG) {
   volatile __attribute__((address_space(3))) uint32_t* scr = (volatile __attribute__((address_space(3))) uint32_t*)scr_generic;   // LDS
   const uint32_t B = w.gather_bytes(ip);                       // stream byte ip + lane
   // ---- 1. speculative parse: every lane reads "its" byte as a token ----
-  const uint32_t ll = B >> 4, mlc = B & 15u;
-  const uint32_t offpos = (uint32_t)lane + 1u + ll;            // where this token's offset would start
+  // A literal length of 15 takes ONE extension byte here (runs of 15 .. 269 bytes, as long as they end inside the 64
+  // bytes): on bench19 those are 3 % of the sequences but were a third of the memory round trips when each of them
+  // went through the scalar path.
+  const uint32_t ll0 = B >> 4, mlc = B & 15u;
+  const uint32_t e_ll = bperm(((uint32_t)lane + 1u) & 63u, B);
+  const bool ll_ext = ll0 == 15u;
+  const uint32_t ll = ll_ext ? 15u + e_ll : ll0;
+  const uint32_t offpos = (uint32_t)lane + 1u + (ll_ext ? 1u : 0u) + ll;   // where this token's offset would start
   const uint32_t o_lo = bperm(offpos & 63u, B), o_hi = bperm((offpos + 1u) & 63u, B), e1 = bperm((offpos + 2u) & 63u, B);
   const bool has_ext = mlc == 15u;
   const uint32_t ml = has_ext ? 19u + e1 : mlc + 4u;           // <= 273
-  const uint32_t size = 3u + ll + (has_ext ? 1u : 0u);         // token + literals + offset (+ ext)
-  const bool complete = ll != 15u && !(has_ext && e1 == 255u) && (uint32_t)lane + size <= 64u;
+  const uint32_t size = 3u + ll + (has_ext ? 1u : 0u) + (ll_ext ? 1u : 0u);   // token (+ ext) + literals + offset (+ ext)
+  // lz4.c:2240-2250: the length extension may not be read at or behind n - 15
+  const bool complete = !(ll_ext && (e_ll == 255u || ip + (uint32_t)lane + 16u >= n)) && !(has_ext && e1 == 255u) && (uint32_t)lane + size <= 64u;
   const uint32_t off = o_lo | (o_hi << 8);
   const uint32_t nxt = complete ? (uint32_t)lane + size : 64u; // position of the following token, 64 = stop here
   PROF_LAP(8);
@@ -178,11 +185,11 @@ __device__ __forceinline__ uint32_t lz4_batch_step(const Window& w, gu8* out, vo
   { const uint32_t t = hop(J1, c); c = (lane & 2) ? t : c; }
   { const uint32_t t = hop(J2, c); c = (lane & 4) ? t : c; }
   { const uint32_t t = hop(J3, c); c = (lane & 8) ? t : c; }
-  // fields of the token at c, fetched into the rank lane
-  const uint32_t pk = bperm(c & 63u, ll | (ml << 4) | ((complete ? 1u : 0u) << 13) | (nxt << 14));
+  // fields of the token at c, fetched into the rank lane: ll (9 bits) | ml (9) | complete | length-extension flag | nxt (7)
+  const uint32_t pk = bperm(c & 63u, ll | (ml << 9) | ((complete ? 1u : 0u) << 18) | ((ll_ext ? 1u : 0u) << 19) | (nxt << 20));
   const uint32_t off_r = bperm(c & 63u, off);
-  const uint32_t ll_r = pk & 15u, ml_r = (pk >> 4) & 0x1ffu, nxt_r = pk >> 14;
-  const bool valid = lane < (int)BATCH_MAXSEQ && c < 64u && ((pk >> 13) & 1u);
+  const uint32_t ll_r = pk & 0x1ffu, ml_r = (pk >> 9) & 0x1ffu, nxt_r = pk >> 20, ext_r = (pk >> 19) & 1u;
+  const bool valid = lane < (int)BATCH_MAXSEQ && c < 64u && ((pk >> 18) & 1u);
   const uint32_t tot_r = valid ? ll_r + ml_r : 0u;
   uint32_t incl = tot_r;                                       // inclusive prefix sum over the 16 rank lanes (one DPP row)
   incl += row_shr<1>(incl); incl += row_shr<2>(incl); incl += row_shr<4>(incl); incl += row_shr<8>(incl);
@@ -203,15 +210,16 @@ __device__ __forceinline__ uint32_t lz4_batch_step(const Window& w, gu8* out, vo
   //         scattered byte store covers the literals of every accepted sequence ----
   // (volatile: lanes talk to each other through this scratch; without it the compiler forwards a lane's
   //  own "= 0" store to its later load, which is legal for unsynchronised memory and wrong here)
+  // scratch word of a token: valid | length-extension flag << 25 | literal count << 16 | output offset (< 2^16: 16 x 542)
   scr[lane] = 0u;
-  if ((uint32_t)lane < cnt) scr[c] = 0x80000000u | excl | (ll_r << 16);
+  if ((uint32_t)lane < cnt) scr[c] = 0x80000000u | excl | (ll_r << 16) | (ext_r << 25);
   const uint64_t mask = __ballot(scr[lane] >> 31);
   {
     const uint64_t below = mask & ((2ull << lane) - 1ull);     // accepted tokens at or before this byte lane
     const uint32_t s = 63u - (uint32_t)__builtin_clzll(below | 1ull);
     const uint32_t inf = scr[s];
-    const uint32_t k = (uint32_t)lane - s - 1u;
-    if ((uint32_t)lane < consumed && (uint32_t)lane > s && k < ((inf >> 16) & 15u)) out[op + (inf & 0xffffu) + k] = (uint8_t)B;
+    const uint32_t k = (uint32_t)lane - s - 1u - ((inf >> 25) & 1u);
+    if ((uint32_t)lane < consumed && (uint32_t)lane > s + ((inf >> 25) & 1u) && k < ((inf >> 16) & 0x1ffu)) out[op + (inf & 0xffffu) + k] = (uint8_t)B;
   }
   // ---- 4. short independent matches: 4 lanes per sequence, overlapping 4/8/16-byte pieces ----
   const bool fast_r = (uint32_t)lane < cnt && ml_r <= 64u && off_r >= mrel_r + ml_r;   // source ends at or before op
@@ -295,11 +303,13 @@ __device__ int lz4_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* out,
     w.seek(ip);
     uint32_t hdr = w.peek32(ip);
     if (ip + 72u <= n) {
-      // the batched step needs a first token it can take: < 15 literals and at most one match-length byte
       const uint32_t tk = hdr & 0xffu;
-      bool try_batch = (tk >> 4) != 15u;
-      if (try_batch && (tk & 15u) == 15u) try_batch = (w.peek32(ip + 3u + (tk >> 4)) & 0xffu) != 255u;
-      if (try_batch && lz4_batch_step(w, out, scr, ip, op, cap, lane, sp PROF_PASS)) continue;
+      // the batched step needs a first token it can take: at most one extension byte per length
+      bool try_batch = true;
+      uint32_t ll1 = tk >> 4, tpos = ip + 1u;
+      if (ll1 == 15u) { const uint32_t e = (hdr >> 8) & 0xffu; try_batch = e != 255u && 17u + e + 3u <= 64u; ll1 = 15u + e; tpos++; }
+      if (try_batch && (tk & 15u) == 15u) try_batch = (w.peek32(tpos + ll1 + 2u) & 0xffu) != 255u;
+      if (try_batch && lz4_batch_step(w, out, scr, ip, op, cap, n, lane, sp PROF_PASS)) continue;
     }
     PROF_ADD(3, 1);
     const uint32_t token = hdr & 0xffu;

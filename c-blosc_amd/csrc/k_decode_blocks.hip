@@ -26,14 +26,16 @@
 
 namespace bamd {
 
-constexpr uint32_t BD_R = 8192u;          // ring bytes per plane (power of two)
-constexpr uint32_t BD_S = BD_R / 2u;      // slice: plane positions between two barriers
-constexpr uint32_t BD_MASK = BD_R - 1u;
+// Rings come in two sizes: the planes with the most compressed bytes - the ones with real LZ work - get BD_RBIG, the
+// others BD_RSMALL (decode_block); a slice is half the small ring, so that every ring holds two slices.
+constexpr uint32_t BD_RBIG = 8192u, BD_RSMALL = 4096u;
+constexpr uint32_t BD_NBIG = 2u;          // big rings per workgroup
+constexpr uint32_t BD_S = BD_RSMALL / 2u; // slice: plane positions between two barriers
 // History within BD_NEAR bytes of the write frontier is read from the ring, anything older from the far copy.  The gap
 // to R keeps a history chunk (<= 1024 bytes + one 16-byte piece + the slack of a step's literal scatter) from
 // overwriting ring slots that lanes of the SAME chunk still have to read: lanes of one chunk take different code paths
 // (16-byte pieces, byte loops) and their loads and stores are not ordered against each other.
-constexpr uint32_t BD_NEAR = BD_R - 1088u;
+constexpr uint32_t BD_NEAR_GAP = 1088u;
 
 #define BAMD_LAS __attribute__((address_space(3)))
 typedef BAMD_LAS uint8_t lu8;
@@ -71,7 +73,9 @@ struct BdProf { uint32_t c[16]; };
 // One plane's output: the LDS ring (positions [W - R, W) of the plane, W = write frontier) and the far copy
 // (positions [0, flushed), plane-major in global memory).
 struct PlaneOut {
-  lu8* ring;            // BD_R bytes
+  lu8* ring;            // `mask` + 1 bytes
+  uint32_t mask;        // ring size - 1
+  uint32_t near;        // ring size - BD_NEAR_GAP
   gu8* far;             // this plane's slice of the workgroup's far area
   uint32_t flushed;     // slice start: every position below it is in `far`
 };
@@ -79,7 +83,7 @@ struct PlaneOut {
 // n <= 1024 bytes from the compressed stream (global) to plane positions [pos, pos + n): the destination lies in
 // one slice, so its ring image is contiguous
 __device__ __forceinline__ void ring_put_global(const PlaneOut& o, uint32_t pos, const gu8* src, uint32_t n, int lane) {
-  lu8* d = o.ring + (pos & BD_MASK);
+  lu8* d = o.ring + (pos & o.mask);
   const uint32_t n16 = n >> 4;
   if ((uint32_t)lane < n16) l_st16(d + 16u * (uint32_t)lane, g_ld16(src + 16u * (uint32_t)lane));
   const uint32_t done = n16 << 4;
@@ -98,20 +102,20 @@ __device__ __forceinline__ void ring_put_global_long(const PlaneOut& o, uint32_t
 __device__ __forceinline__ void hist_copy(const PlaneOut& o, uint32_t dst, uint32_t src, uint32_t n, uint32_t W, int lane BDP_ARG) {
   const uint32_t off16 = 16u * (uint32_t)lane;
 #ifdef BAMD_PROFILE_DECODE
-  const bool anyfar = (int32_t)src < (int32_t)W - (int32_t)BD_NEAR;
+  const bool anyfar = (int32_t)src < (int32_t)W - (int32_t)o.near;
   BDP_ADD(5, anyfar ? 1 : 0);
   BDP_T0(tfar);
 #endif
   if (off16 < n) {
   const uint32_t q = src + off16, cnt = n - off16 < 16u ? n - off16 : 16u;
-  const int32_t lo = (int32_t)W - (int32_t)BD_NEAR;        // first position read from the ring (may be negative); older ones come from `far`
-  lu8* d = o.ring + ((dst + off16) & BD_MASK);
-  const uint32_t qi = q & BD_MASK;
-  if (cnt == 16u && (int32_t)q >= lo && qi <= BD_R - 16u) l_st16(d, l_ld16(o.ring + qi));
+  const int32_t lo = (int32_t)W - (int32_t)o.near;        // first position read from the ring (may be negative); older ones come from `far`
+  lu8* d = o.ring + ((dst + off16) & o.mask);
+  const uint32_t qi = q & o.mask;
+  if (cnt == 16u && (int32_t)q >= lo && qi <= o.mask - 15u) l_st16(d, l_ld16(o.ring + qi));
   else if (cnt == 16u && (int32_t)(q + 16u) <= lo) l_st16(d, g_ld16(o.far + q));
   else for (uint32_t b = 0; b < cnt; b++) {
     const uint32_t qq = q + b;
-    d[b] = ((int32_t)qq >= lo) ? o.ring[qq & BD_MASK] : (uint8_t)o.far[qq];
+    d[b] = ((int32_t)qq >= lo) ? o.ring[qq & o.mask] : (uint8_t)o.far[qq];
   }
   }
 #ifdef BAMD_PROFILE_DECODE
@@ -126,12 +130,12 @@ __device__ __forceinline__ void ring_match(const PlaneOut& o, uint32_t pos, uint
   if (off < 64u && off < len) {
     // short period: fetch the pattern once (always in the ring: off < 64), lane i holds pattern byte i mod off, then
     // store G = off * floor(64 / off) bytes per step without further loads
-    const uint32_t pat = ((uint32_t)lane < off) ? (uint32_t)o.ring[(pos - off + (uint32_t)lane) & BD_MASK] : 0u;
+    const uint32_t pat = ((uint32_t)lane < off) ? (uint32_t)o.ring[(pos - off + (uint32_t)lane) & o.mask] : 0u;
     const uint32_t M = 65536u / off + 1u;
     const uint32_t reps = (64u * M) >> 16, G = reps * off;
     const uint32_t i_mod = (uint32_t)lane - (((uint32_t)lane * M) >> 16) * off;
     const uint32_t val = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(i_mod << 2), (int)pat);
-    lu8* d = o.ring + (pos & BD_MASK);
+    lu8* d = o.ring + (pos & o.mask);
     const uint32_t head = len < 256u ? len : 128u;         // long runs switch to 16-byte copies below
     while (done < head) {
       const uint32_t chunk = head - done < G ? head - done : G;
@@ -175,16 +179,20 @@ struct PlaneDec {
 // inside the slice (`limit`).  Literals go to the ring in one scattered byte store; short matches whose source is in
 // the ring, does not wrap and lies before the step's output are copied by 4 lanes each; the rest in stream order.
 __device__ __forceinline__ uint32_t lz4_batch_step_ring(const Window& w, const PlaneOut& o, volatile BAMD_LAS uint32_t* scr, uint32_t& ip, uint32_t& op,
-                                                        uint32_t cap, uint32_t limit, int lane BDP_ARG) {
+                                                        uint32_t cap, uint32_t limit, uint32_t n, int lane BDP_ARG) {
   BDP_T0(tstep);
   const uint32_t B = w.gather_bytes(ip);
-  const uint32_t ll = B >> 4, mlc = B & 15u;
-  const uint32_t offpos = (uint32_t)lane + 1u + ll;
+  // (a literal length of 15 takes one extension byte, see lz4_batch_step in k_decode.hip)
+  const uint32_t ll0 = B >> 4, mlc = B & 15u;
+  const uint32_t e_ll = bperm(((uint32_t)lane + 1u) & 63u, B);
+  const bool ll_ext = ll0 == 15u;
+  const uint32_t ll = ll_ext ? 15u + e_ll : ll0;
+  const uint32_t offpos = (uint32_t)lane + 1u + (ll_ext ? 1u : 0u) + ll;
   const uint32_t o_lo = bperm(offpos & 63u, B), o_hi = bperm((offpos + 1u) & 63u, B), e1 = bperm((offpos + 2u) & 63u, B);
   const bool has_ext = mlc == 15u;
   const uint32_t ml = has_ext ? 19u + e1 : mlc + 4u;
-  const uint32_t size = 3u + ll + (has_ext ? 1u : 0u);
-  const bool complete = ll != 15u && !(has_ext && e1 == 255u) && (uint32_t)lane + size <= 64u;
+  const uint32_t size = 3u + ll + (has_ext ? 1u : 0u) + (ll_ext ? 1u : 0u);
+  const bool complete = !(ll_ext && (e_ll == 255u || ip + (uint32_t)lane + 16u >= n)) && !(has_ext && e1 == 255u) && (uint32_t)lane + size <= 64u;
   const uint32_t off = o_lo | (o_hi << 8);
   const uint32_t nxt = complete ? (uint32_t)lane + size : 64u;
   const uint32_t J0 = nxt;
@@ -194,10 +202,10 @@ __device__ __forceinline__ uint32_t lz4_batch_step_ring(const Window& w, const P
   { const uint32_t t = hop(J1, c); c = (lane & 2) ? t : c; }
   { const uint32_t t = hop(J2, c); c = (lane & 4) ? t : c; }
   { const uint32_t t = hop(J3, c); c = (lane & 8) ? t : c; }
-  const uint32_t pk = bperm(c & 63u, ll | (ml << 4) | ((complete ? 1u : 0u) << 13) | (nxt << 14));
+  const uint32_t pk = bperm(c & 63u, ll | (ml << 9) | ((complete ? 1u : 0u) << 18) | ((ll_ext ? 1u : 0u) << 19) | (nxt << 20));
   const uint32_t off_r = bperm(c & 63u, off);
-  const uint32_t ll_r = pk & 15u, ml_r = (pk >> 4) & 0x1ffu, nxt_r = pk >> 14;
-  const bool valid = lane < (int)BATCH_MAXSEQ && c < 64u && ((pk >> 13) & 1u);
+  const uint32_t ll_r = pk & 0x1ffu, ml_r = (pk >> 9) & 0x1ffu, nxt_r = pk >> 20, ext_r = (pk >> 19) & 1u;
+  const bool valid = lane < (int)BATCH_MAXSEQ && c < 64u && ((pk >> 18) & 1u);
   const uint32_t tot_r = valid ? ll_r + ml_r : 0u;
   uint32_t incl = tot_r;
   incl += row_shr<1>(incl); incl += row_shr<2>(incl); incl += row_shr<4>(incl); incl += row_shr<8>(incl);
@@ -213,29 +221,36 @@ __device__ __forceinline__ uint32_t lz4_batch_step_ring(const Window& w, const P
   const uint32_t W = op + acc;                                  // ring frontier once this step's literals are out
   // ---- literals of every accepted sequence: one scattered byte store ----
   scr[lane] = 0u;
-  if ((uint32_t)lane < cnt) scr[c] = 0x80000000u | excl | (ll_r << 16);
+  if ((uint32_t)lane < cnt) scr[c] = 0x80000000u | excl | (ll_r << 16) | (ext_r << 25);
   const uint64_t mask = __ballot(scr[lane] >> 31);
   {
     const uint64_t below = mask & ((2ull << lane) - 1ull);
     const uint32_t s = 63u - (uint32_t)__builtin_clzll(below | 1ull);
     const uint32_t inf = scr[s];
-    const uint32_t k = (uint32_t)lane - s - 1u;
-    if ((uint32_t)lane < consumed && (uint32_t)lane > s && k < ((inf >> 16) & 15u)) o.ring[(op + (inf & 0xffffu) + k) & BD_MASK] = (uint8_t)B;
+    const uint32_t xe = (inf >> 25) & 1u;
+    const uint32_t k = (uint32_t)lane - s - 1u - xe;
+    if ((uint32_t)lane < consumed && (uint32_t)lane > s + xe && k < ((inf >> 16) & 0x1ffu)) o.ring[(op + (inf & 0xffffu) + k) & o.mask] = (uint8_t)B;
   }
   LDS_ORDER();
-  // ---- short matches, source in the ring (not overwritten by this step), before the step's output, no wrap ----
+  // ---- short matches whose source lies before the step's output: 4 lanes each, all of them in one go.  The source is
+  //      either in the ring (not overwritten by this step, not wrapping) or entirely in the far copy - the far ones of a
+  //      step travel together in ONE global load instruction instead of one round trip each ----
   const uint32_t src_r = op + mrel_r - off_r;                   // source position (valid lanes only)
-  const bool fast_r = (uint32_t)lane < cnt && ml_r <= 64u && off_r >= mrel_r + ml_r &&
-                      (int32_t)src_r >= (int32_t)W - (int32_t)BD_NEAR && (src_r & BD_MASK) + ml_r <= BD_R;
+  const int32_t lo_r = (int32_t)W - (int32_t)o.near;
+  const bool near_r = (int32_t)src_r >= lo_r && (src_r & o.mask) + ml_r <= o.mask + 1u;
+  const bool far_r = (int32_t)(src_r + ml_r) <= lo_r;
+  const bool fast_r = (uint32_t)lane < cnt && ml_r <= 64u && off_r >= mrel_r + ml_r && (near_r || far_r);
   {
     const uint32_t r = (uint32_t)lane >> 2, q = (uint32_t)lane & 3u;
-    const uint32_t fA = bperm(r, fast_r ? (ml_r | 0x200u | (mrel_r << 10)) : 0u);
+    const uint32_t fA = bperm(r, fast_r ? (ml_r | 0x200u | (mrel_r << 10) | (far_r ? 0x40000000u : 0u)) : 0u);
     const uint32_t fB = bperm(r, off_r);
     const uint32_t mlen = fA & 0x1ffu;
-    const bool go = (fA & 0x200u) != 0u;
-    const uint32_t dpos = op + (fA >> 10);
-    lu8* d = o.ring + (dpos & BD_MASK);
-    const lu8* sp = o.ring + ((dpos - fB) & BD_MASK);
+    const bool go = (fA & 0x200u) != 0u, isfar = (fA & 0x40000000u) != 0u;
+    const uint32_t dpos = op + ((fA >> 10) & 0xfffffu);
+    lu8* d = o.ring + (dpos & o.mask);
+    const uint32_t spos = dpos - fB;
+    const lu8* sp = o.ring + (spos & o.mask);
+    const gu8* sg = o.far + spos;
     const uint32_t np16 = (mlen + 15u) >> 4;
     const bool w16 = go && mlen >= 16u && q < np16;
     const bool w8 = go && mlen >= 8u && mlen < 16u && q < 2u;
@@ -243,9 +258,9 @@ __device__ __forceinline__ uint32_t lz4_batch_step_ring(const Window& w, const P
     const uint32_t po16 = (q == np16 - 1u) ? mlen - 16u : 16u * q;
     const uint32_t po8 = q ? mlen - 8u : 0u, po4 = q ? mlen - 4u : 0u;
     uint4 v16 = make_uint4(0, 0, 0, 0); uint64_t v8 = 0; uint32_t v4 = 0;
-    if (w16) v16 = l_ld16(sp + po16);
-    if (w8) v8 = l_ld8(sp + po8);
-    if (w4) v4 = l_ld4(sp + po4);
+    if (w16) v16 = isfar ? g_ld16(sg + po16) : l_ld16(sp + po16);
+    if (w8) v8 = isfar ? g_ld8(sg + po8) : l_ld8(sp + po8);
+    if (w4) v4 = isfar ? g_ld4(sg + po4) : l_ld4(sp + po4);
     if (w16) l_st16(d + po16, v16);
     if (w8) l_st8(d + po8, v8);
     if (w4) l_st4(d + po4, v4);
@@ -296,9 +311,11 @@ __device__ __forceinline__ void lz4_plane_run(PlaneDec& s, const PlaneOut& o, vo
 #endif
       if (s.ip + 72u <= n) {
         const uint32_t tk = hdr & 0xffu;
-        bool try_batch = (tk >> 4) != 15u;
-        if (try_batch && (tk & 15u) == 15u) try_batch = (s.w.peek32(s.ip + 3u + (tk >> 4)) & 0xffu) != 255u;
-        if (try_batch && lz4_batch_step_ring(s.w, o, scr, s.ip, s.op, cap, limit, lane BDP_PASS)) continue;
+        bool try_batch = true;
+        uint32_t ll1 = tk >> 4, tpos = s.ip + 1u;
+        if (ll1 == 15u) { const uint32_t e = (hdr >> 8) & 0xffu; try_batch = e != 255u && 17u + e + 3u <= 64u; ll1 = 15u + e; tpos++; }
+        if (try_batch && (tk & 15u) == 15u) try_batch = (s.w.peek32(tpos + ll1 + 2u) & 0xffu) != 255u;
+        if (try_batch && lz4_batch_step_ring(s.w, o, scr, s.ip, s.op, cap, limit, n, lane BDP_PASS)) continue;
       }
       BDP_ADD(3, 1);
       const uint32_t token = hdr & 0xffu;
@@ -323,7 +340,7 @@ __device__ __forceinline__ void lz4_plane_run(PlaneDec& s, const PlaneOut& o, vo
           s.w.seek(s.ip);
           if (s.ip + c <= s.w.base + 512u) {
             const uint32_t v = s.w.gather_bytes(s.ip);
-            if ((uint32_t)lane < c) o.ring[(s.op + (uint32_t)lane) & BD_MASK] = (uint8_t)v;
+            if ((uint32_t)lane < c) o.ring[(s.op + (uint32_t)lane) & o.mask] = (uint8_t)v;
           } else ring_put_global(o, s.op, s.in + s.ip, c, lane);
         } else ring_put_global_long(o, s.op, s.in + s.ip, c, lane);
         LDS_ORDER();
@@ -358,7 +375,7 @@ __device__ __forceinline__ void lz4_plane_run(PlaneDec& s, const PlaneOut& o, vo
         s.w.seek(s.ip);
         bool last = false;
         if (restout < 15u && s.ip + 1u + restout == n) last = ((s.w.peek32(s.ip) & 0xffu) == (restout << 4));
-        s.last_match = (last && off <= BD_NEAR - 1024u) ? 1u : 0u;
+        s.last_match = (last && off <= o.near - 1024u) ? 1u : 0u;
       }
       continue;
     }
@@ -368,7 +385,7 @@ __device__ __forceinline__ void lz4_plane_run(PlaneDec& s, const PlaneOut& o, vo
       const uint32_t off = s.pend_off;
       // offset 0: accepted like the reference, bytes unspecified (lz4.c:2356).  A power-of-two period that divides the
       // ring: once R bytes of the match are out the ring already holds every later byte of it - nothing to write.
-      const bool idem = (off & (off - 1u)) == 0u && off <= BD_R && s.mdone >= BD_R;
+      const bool idem = (off & (off - 1u)) == 0u && off <= o.mask + 1u && s.mdone >= o.mask + 1u;
       BDP_T0(tm);
       if (off != 0u && !idem) ring_match(o, s.op, off, c, s.op, lane BDP_PASS);
       BDP_LAP(13, tm);
@@ -458,15 +475,18 @@ __global__ void k_classify_blocks(const StreamDesc* __restrict__ streams, const 
 template <int T>
 struct PlaneTab {            // wave-uniform description of the block's planes
   uint32_t lbase[T];         // RING / PERIODIC: LDS byte offset of the ring / the 64-byte pattern
-  uint32_t lmask[T];         // BD_MASK / 63
+  uint32_t lmask[T];         // ring size - 1 / BD_PAT - 1
   const gu8* raw[T];         // RAW: the bytes in the compressed chunk (nullptr otherwise)
 };
 
+// `wo_rank` / `wo_n`: this wave is the wo_rank-th of the wo_n waves that share the write-out (the waves that own a big
+// ring - the busy planes - are left out when there are others: they are the block's critical path)
 template <int T, int W>
-__device__ __forceinline__ void slice_writeout(const PlaneTab<T>& pt, const lu8* lds, gu8* dst, uint32_t p0, uint32_t p1, int wave, int lane) {
+__device__ __forceinline__ void slice_writeout(const PlaneTab<T>& pt, const lu8* lds, gu8* dst, uint32_t p0, uint32_t p1, int wave, int lane, int wo_rank, int wo_n) {
   // positions [p0, p1) of every plane; steps of 256 positions, lane l owns 4 consecutive positions
   const uint32_t nfull = (p1 - p0) >> 8;
-  for (uint32_t st = (uint32_t)wave; st < nfull; st += (uint32_t)W) {
+  if (wo_rank >= 0)
+  for (uint32_t st = (uint32_t)wo_rank; st < nfull; st += (uint32_t)wo_n) {
     const uint32_t p = p0 + (st << 8) + 4u * (uint32_t)lane;
     Rows<T> x;
 #pragma unroll
@@ -476,9 +496,9 @@ __device__ __forceinline__ void slice_writeout(const PlaneTab<T>& pt, const lu8*
     }
     unshuffle_store<T>(dst, p - 4u * (uint32_t)lane, lane, x);
   }
-  // fewer than 256 positions left (only when the plane size is not a multiple of 256): byte by byte, wave 0
+  // fewer than 256 positions left (only when the plane size is not a multiple of 256): byte by byte, first write-out wave
   const uint32_t tail0 = p0 + (nfull << 8);
-  if (wave == 0)
+  if (wo_rank == 0)
     for (uint32_t k = tail0 * T + (uint32_t)lane; k < p1 * T; k += 64u) {
       const uint32_t el = k / T, j = k - el * T;
       uint32_t v = 0;
@@ -490,7 +510,8 @@ __device__ __forceinline__ void slice_writeout(const PlaneTab<T>& pt, const lu8*
 }
 
 // LDS of a workgroup: W rings | W x 256 bytes of step scratch | T x 256 bytes of patterns | control words
-template <int T, int W> constexpr uint32_t bd_lds_bytes() { return (uint32_t)W * BD_R + (uint32_t)W * 256u + (uint32_t)T * BD_PAT + 64u; }
+template <int W> constexpr uint32_t bd_pool_bytes() { return BD_NBIG * BD_RBIG + ((uint32_t)W - BD_NBIG) * BD_RSMALL; }
+template <int T, int W> constexpr uint32_t bd_lds_bytes() { return bd_pool_bytes<W>() + (uint32_t)W * 256u + (uint32_t)T * BD_PAT + 128u; }
 
 // One block by W waves.  Wave w decodes the w-th PK_RING plane (waves beyond the number of such planes only help
 // with the write-out).  Slice k occupies ring half k & 1 (R = 2 S), so ONE barrier per slice is enough: a wave that
@@ -499,23 +520,37 @@ template <int T, int W> constexpr uint32_t bd_lds_bytes() { return (uint32_t)W *
 // after its share of write-out k.  Between blocks the ticket broadcast supplies the barrier.
 template <int T, int W>
 __device__ __forceinline__ void decode_block(StreamDesc* sds, const uint32_t* skind, const ChunkDesc* c, const BlockDesc* b, int32_t* status,
-                                             lu8* lds, volatile BAMD_LAS uint32_t* scr, gu8* far_wg, int wave, int lane BDP_ARG) {
+                                             lu8* lds, volatile BAMD_LAS uint32_t* scr, volatile BAMD_LAS uint32_t* ctl, gu8* far_wg, int wave, int lane BDP_ARG) {
   const uint32_t bsize = uni((uint32_t)b->bsize), neblock = bsize / (uint32_t)T;
   gu8* dst = uni_ptr(as_global(c->dst)) + (size_t)uni((uint32_t)b->blk) * (size_t)uni((uint32_t)c->blocksize);
   // ---- plane table (every wave builds the same one) ----
+  // The BD_NBIG ring planes with the most compressed bytes get the big rings: the compressed size is what says, before
+  // any decoding, which planes carry the sequences (bench19: 11.6 KB for the two busy planes, 1.4 KB and 0.8 KB for the others).
   PlaneTab<T> pt;
   uint32_t kinds[T];
   int my_plane = -1;
+  uint32_t my_ring = 0, my_rbytes = BD_RSMALL;
   {
-    uint32_t nr = 0;
+    uint32_t cs[T];
+    uint32_t big1 = 0, big2 = 0;            // the two largest compressed sizes among the ring planes (with their plane index as tie-break)
 #pragma unroll
     for (int j = 0; j < T; j++) {
       kinds[j] = uni(skind[j]);
+      cs[j] = ((kinds[j] & 255u) == PK_RING) ? ((uni((uint32_t)sds[j].in_size) << 4) | (uint32_t)(15 - j)) : 0u;
+      if (cs[j] > big1) { big2 = big1; big1 = cs[j]; } else if (cs[j] > big2) big2 = cs[j];
+    }
+    uint32_t nr = 0, base = 0;
+#pragma unroll
+    for (int j = 0; j < T; j++) {
       const uint32_t kd = kinds[j] & 255u;
-      pt.raw[j] = nullptr; pt.lbase[j] = 0; pt.lmask[j] = BD_MASK;
-      if (kd == PK_RING) { if ((int)nr == wave) my_plane = j; pt.lbase[j] = nr * BD_R; nr++; }
-      else if (kd == PK_RAW) pt.raw[j] = uni_ptr(as_global(sds[j].in));
-      else { pt.lbase[j] = (uint32_t)W * BD_R + (uint32_t)W * 256u + (uint32_t)j * BD_PAT; pt.lmask[j] = BD_PAT - 1u; }
+      pt.raw[j] = nullptr; pt.lbase[j] = 0; pt.lmask[j] = BD_RSMALL - 1u;
+      if (kd == PK_RING) {
+        const uint32_t rb = (cs[j] != 0u && cs[j] >= big2) ? BD_RBIG : BD_RSMALL;     // at most BD_NBIG = 2 planes qualify
+        if ((int)nr == wave) { my_plane = j; my_ring = base; my_rbytes = rb; }
+        pt.lbase[j] = base; pt.lmask[j] = rb - 1u;
+        base += rb; nr++;
+      } else if (kd == PK_RAW) pt.raw[j] = uni_ptr(as_global(sds[j].in));
+      else { pt.lbase[j] = bd_pool_bytes<W>() + (uint32_t)W * 256u + (uint32_t)j * BD_PAT; pt.lmask[j] = BD_PAT - 1u; }
     }
   }
   // ---- patterns of the periodic planes: wave j % W writes plane j's 256 bytes ----
@@ -537,29 +572,86 @@ __device__ __forceinline__ void decode_block(StreamDesc* sds, const uint32_t* sk
   s.phase = PH_DONE; s.op = neblock; s.last_match = 1;
   if (my_plane >= 0) {
     const StreamDesc* sd = sds + my_plane;
-    o.ring = lds + (uint32_t)wave * BD_R;
+    o.ring = lds + my_ring; o.mask = my_rbytes - 1u; o.near = my_rbytes - BD_NEAR_GAP;
     o.far = far_wg + (size_t)wave * neblock;
     o.flushed = 0;
     lz4_plane_init(s, uni_ptr(as_global(sd->in)), (int32_t)uni((uint32_t)sd->in_size), neblock, lane);
   }
+  // who writes out: waves without a big ring (idle waves and the planes with little work), all waves if there are none
+  int wo_rank, wo_n;
+  {
+    uint32_t nbig = 0;
+#pragma unroll
+    for (int j = 0; j < T; j++) nbig += ((kinds[j] & 255u) == PK_RING && pt.lmask[j] == BD_RBIG - 1u) ? 1u : 0u;
+    // ring planes are numbered in plane order = wave order; big-ring waves are those whose plane has a big ring
+    uint32_t bigwaves = 0, nr2 = 0;
+#pragma unroll
+    for (int j = 0; j < T; j++) if ((kinds[j] & 255u) == PK_RING) { if (pt.lmask[j] == BD_RBIG - 1u) bigwaves |= 1u << nr2; nr2++; }
+    const uint32_t light = ~bigwaves & ((1u << W) - 1u);
+    if (light == 0u) { wo_rank = wave; wo_n = W; }
+    else { wo_n = __builtin_popcount(light); wo_rank = (light >> wave) & 1u ? __builtin_popcount(light & ((1u << wave) - 1u)) : -1; }
+    (void)nbig;
+  }
+  // ---- slices.  No lock-step: every wave publishes how far it is in LDS (in-order DS pipeline: a flag written after
+  //      the data is seen after the data), a plane may run ahead of the write-out by as many slices as its ring holds
+  //      (4 for the big rings), and the write-out of slice k starts when every plane has published k + 1.  With a
+  //      barrier per slice the two busy planes of a bench19 block waited for each other a third of the time (a slice is
+  //      two to four batched steps; profiles/r02_b_block_decoder.md).
+  volatile BAMD_LAS uint32_t* prog = ctl + 4;           // [T] slices decoded per plane (0xffffffff: nothing to decode)
+  volatile BAMD_LAS uint32_t* wprog = ctl + 4 + T;      // [W] slices written out per wave (0xffffffff: takes no part)
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < T; j++) if ((j % W) == wave) prog[j] = ((kinds[j] & 255u) == PK_RING) ? 0u : 0xffffffffu;
+    wprog[wave] = wo_rank >= 0 ? 0u : 0xffffffffu;
+  }
+  __syncthreads();
   const uint32_t nsl = (neblock + BD_S - 1u) / BD_S;
+  const uint32_t cap_slices = my_rbytes / BD_S;
   for (uint32_t k = 0; k < nsl; k++) {
     const uint32_t p0 = k * BD_S, p1 = p0 + BD_S < neblock ? p0 + BD_S : neblock;
-    BDP_T0(td);
-    if (my_plane >= 0) { o.flushed = p0; lz4_plane_run(s, o, scr, p1, lane BDP_PASS); }
-    BDP_LAP(8, td);
-    BDP_T0(tb);
-    __syncthreads();
-    BDP_LAP(9, tb);
-    BDP_T0(tw);
-    slice_writeout<T, W>(pt, lds, dst, p0, p1, wave, lane);
-    // this wave's own plane, plane-major, for its own far matches of later slices (same wave stores and loads)
-    if (my_plane >= 0 && !s.last_match && p1 < neblock) {
-      const lu8* r = o.ring + (p0 & BD_MASK);
-      for (uint32_t q = 16u * (uint32_t)lane; q < p1 - p0; q += 1024u) g_st16(o.far + p0 + q, l_ld16(r + q));
+    if (my_plane >= 0) {
+      BDP_T0(tb);
+      if (k >= cap_slices) {                             // the ring slot of slice k still holds slice k - cap_slices: written out?
+        const uint32_t need = k - cap_slices + 1u;
+        for (;;) {
+          uint32_t m = 0xffffffffu;
+#pragma unroll
+          for (int w2 = 0; w2 < W; w2++) { const uint32_t v = uni(wprog[w2]); m = v < m ? v : m; }
+          if (m >= need) break;
+          __builtin_amdgcn_s_sleep(4);
+        }
+      }
+      BDP_LAP(9, tb);
+      BDP_T0(td);
+      o.flushed = p0;
+      lz4_plane_run(s, o, scr, p1, lane BDP_PASS);
+      // this wave's own plane, plane-major, for its own far matches of later slices (same wave stores and loads)
+      if (!s.last_match && p1 < neblock) {
+        const lu8* r = o.ring + (p0 & o.mask);
+        for (uint32_t q = 16u * (uint32_t)lane; q < p1 - p0; q += 1024u) g_st16(o.far + p0 + q, l_ld16(r + q));
+      }
+      LDS_ORDER();
+      if (lane == 0) prog[my_plane] = k + 1u;
+      BDP_LAP(8, td);
     }
-    BDP_LAP(4, tw);
+    if (wo_rank >= 0) {
+      BDP_T0(tb2);
+      for (;;) {
+        uint32_t m = 0xffffffffu;
+#pragma unroll
+        for (int j = 0; j < T; j++) { const uint32_t v = uni(prog[j]); m = v < m ? v : m; }
+        if (m >= k + 1u) break;
+        __builtin_amdgcn_s_sleep(4);
+      }
+      BDP_LAP(9, tb2);
+      BDP_T0(tw);
+      slice_writeout<T, W>(pt, lds, dst, p0, p1, wave, lane, wo_rank, wo_n);
+      LDS_ORDER();
+      if (lane == 0) wprog[wave] = k + 1u;
+      BDP_LAP(4, tw);
+    }
   }
+  __syncthreads();                         // the block is complete (and every store of it has been performed)
   if (my_plane >= 0) {
     const bool good = s.phase == PH_DONE && s.op == neblock;
     if (lane == 0) {
@@ -572,7 +664,6 @@ __device__ __forceinline__ void decode_block(StreamDesc* sds, const uint32_t* sk
 #pragma unroll
   for (int j = 0; j < T; j++) any_per |= (kinds[j] & 255u) == PK_PERIODIC;
   if (any_per) {
-    __syncthreads();                       // every write-out store of the block has been performed (the barrier waits for vmcnt)
 #pragma unroll
     for (int j = 0; j < T; j++) {
       if ((kinds[j] & 255u) != PK_PERIODIC || (j % W) != wave) continue;
@@ -588,12 +679,13 @@ __device__ __forceinline__ void decode_block(StreamDesc* sds, const uint32_t* sk
   for (int j = 0; j < T; j++) if ((kinds[j] & 255u) == PK_RAW && (j % W) == wave && lane == 0) sds[j].result = (int32_t)neblock;
 }
 
-constexpr int BD_WAVES_PER_CU = 16;        // LDS-bound: 4 rings of 8 KiB per 4 waves
+constexpr int BD_WG4_PER_CU = 5;           // 4-wave workgroups per CU: 27.7 KiB of LDS each
+constexpr int BD_WG8_PER_CU = 2;           // 8-wave workgroups per CU: 45 KiB of LDS each, 128 VGPRs
 
 // Persistent workgroups of W waves; `blist` / `nlist_p` = one of the two lists k_classify_blocks filled, `far` one area
 // of `far_stride` bytes per workgroup.
 template <int T, int W>
-__global__ __launch_bounds__(64 * W, 4) void k_decode_blocks(StreamDesc* __restrict__ streams, const uint32_t* __restrict__ skind, int32_t* __restrict__ status,
+__global__ __launch_bounds__(64 * W, W == 4 ? 5 : 4) void k_decode_blocks(StreamDesc* __restrict__ streams, const uint32_t* __restrict__ skind, int32_t* __restrict__ status,
                                                              uint32_t* __restrict__ ticket, const int32_t* __restrict__ blist, const uint32_t* __restrict__ nlist_p,
                                                              const ChunkDesc* __restrict__ chunks, const BlockDesc* __restrict__ blocks,
                                                              uint8_t* __restrict__ far, size_t far_stride, uint32_t* __restrict__ done
@@ -604,8 +696,8 @@ __global__ __launch_bounds__(64 * W, 4) void k_decode_blocks(StreamDesc* __restr
   __shared__ __attribute__((aligned(16))) uint8_t bd_lds[bd_lds_bytes<T, W>()];
   lu8* lds = (lu8*)bd_lds;
   const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
-  volatile BAMD_LAS uint32_t* scr = (volatile BAMD_LAS uint32_t*)(lds + (uint32_t)W * BD_R + (uint32_t)wave * 256u);
-  volatile BAMD_LAS uint32_t* ctl = (volatile BAMD_LAS uint32_t*)(lds + (uint32_t)W * BD_R + (uint32_t)W * 256u + (uint32_t)T * BD_PAT);
+  volatile BAMD_LAS uint32_t* scr = (volatile BAMD_LAS uint32_t*)(lds + bd_pool_bytes<W>() + (uint32_t)wave * 256u);
+  volatile BAMD_LAS uint32_t* ctl = (volatile BAMD_LAS uint32_t*)(lds + bd_pool_bytes<W>() + (uint32_t)W * 256u + (uint32_t)T * BD_PAT);
   gu8* far_wg = as_global(far) + (size_t)blockIdx.x * far_stride;
   const uint32_t nlist = uni(*nlist_p);
   uint32_t ndone = 0;
@@ -623,7 +715,7 @@ __global__ __launch_bounds__(64 * W, 4) void k_decode_blocks(StreamDesc* __restr
     const BlockDesc* b = blocks + gb;
     const ChunkDesc* c = chunks + uni((uint32_t)b->chunk);
     const uint32_t fs = uni((uint32_t)b->first_stream);
-    decode_block<T, W>(streams + fs, skind + fs, c, b, status, lds, scr, far_wg, wave, lane BDP_PASS);
+    decode_block<T, W>(streams + fs, skind + fs, c, b, status, lds, scr, ctl, far_wg, wave, lane BDP_PASS);
     ndone++;
   }
   if (threadIdx.x == 0 && ndone) atomicAdd(done, ndone);
