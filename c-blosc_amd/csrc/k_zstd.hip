@@ -284,6 +284,7 @@ __device__ bool zstd_block_wave(const uint8_t* b, int size, uint8_t* out, uint32
   if (u0 < 0) return false;
   p += u0;
   uint32_t lp = 0;
+  if (nseq == 0 && p != size) return false;       // nothing may follow the count of an empty sequences section
   if (nseq > 0) {
     if (p >= size) return false;
     const int modes = b[p++];
@@ -372,7 +373,17 @@ __device__ __attribute__((noinline)) int zstd_decode_wave(const uint8_t* in, int
     if (last) { ok = true; break; }
   }
   if (!ok) return 0;
-  if (has_checksum) ip += 4;
+  if (has_checksum) {              // low 32 bits of XXH64 of the content (lane 0, serial: blosc itself never writes such frames)
+    if (ip + 4 > n) return 0;
+    uint32_t good = 0;
+    if (lane == 0) {
+      const uint32_t want = (uint32_t)in[ip] | ((uint32_t)in[ip + 1] << 8) | ((uint32_t)in[ip + 2] << 16) | ((uint32_t)in[ip + 3] << 24);
+      __builtin_amdgcn_s_waitcnt(0);
+      good = (uint32_t)zd::xxh64(out, op) == want ? 1u : 0u;
+    }
+    if (!lane0_u32(good)) return 0;
+    ip += 4;
+  }
   if (ip != n) return 0;
   if (fcs_u >= 0 && fcs_u != (long long)op) return 0;
   return (int)op;

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(64) void k_zstd_entropy(const StreamDesc* __restric
       const uint32_t bh = (uint32_t)in[ip] | ((uint32_t)in[ip + 1] << 8) | ((uint32_t)in[ip + 2] << 16);
       const int last = bh & 1u, type = (bh >> 1) & 3u, bsize = (int)(bh >> 3);
       // exactly one compressed block that fills the frame: everything else goes the general way
-      if (last && type == 2 && bsize <= (1 << 17) && ip + 3 + bsize + (checksum ? 4 : 0) == n) {
+      if (last && type == 2 && bsize <= (1 << 17) && !checksum && ip + 3 + bsize == n) {      // (frames with a content checksum: general path)
         b = in + ip + 3; size = bsize;
         if (!zd::lit_header(b, size, lh) || lh.regen > want) state = ZM_ERROR;
         else {

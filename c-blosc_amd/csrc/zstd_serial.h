@@ -347,4 +347,32 @@ ZD_FN int frame_header(const uint8_t* src, int srcsize, long long* fcs, bool* ch
   return ip + nb;
 }
 
+// ---------------- content checksum ----------------
+// XXH64 (seed 0) from the published algorithm; a frame's Content_Checksum is its low 32 bits (RFC 8878 3.1.1)
+ZD_FN uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+ZD_FN uint64_t rd64(const uint8_t* p) { uint64_t v = 0; for (int k = 7; k >= 0; k--) v = (v << 8) | p[k]; return v; }
+ZD_FN uint64_t xxh64(const uint8_t* p, uint32_t len) {
+  const uint64_t P1 = 11400714785074694791ull, P2 = 14029467366897019727ull, P3 = 1609587929392839161ull,
+                 P4 = 9650029242287828579ull, P5 = 2870177450012600261ull;
+  const uint8_t* end = p + len;
+  uint64_t h;
+  if (len >= 32u) {
+    uint64_t v1 = P1 + P2, v2 = P2, v3 = 0, v4 = 0 - P1;
+    while (p + 32 <= end) {
+      v1 = rotl64(v1 + rd64(p) * P2, 31) * P1; v2 = rotl64(v2 + rd64(p + 8) * P2, 31) * P1;
+      v3 = rotl64(v3 + rd64(p + 16) * P2, 31) * P1; v4 = rotl64(v4 + rd64(p + 24) * P2, 31) * P1;
+      p += 32;
+    }
+    h = rotl64(v1, 1) + rotl64(v2, 7) + rotl64(v3, 12) + rotl64(v4, 18);
+    h = (h ^ (rotl64(v1 * P2, 31) * P1)) * P1 + P4; h = (h ^ (rotl64(v2 * P2, 31) * P1)) * P1 + P4;
+    h = (h ^ (rotl64(v3 * P2, 31) * P1)) * P1 + P4; h = (h ^ (rotl64(v4 * P2, 31) * P1)) * P1 + P4;
+  } else h = P5;
+  h += (uint64_t)len;
+  while (p + 8 <= end) { h ^= rotl64(rd64(p) * P2, 31) * P1; h = rotl64(h, 27) * P1 + P4; p += 8; }
+  if (p + 4 <= end) { h ^= (uint64_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)) * P1; h = rotl64(h, 23) * P2 + P3; p += 4; }
+  while (p < end) { h ^= (uint64_t)(*p++) * P5; h = rotl64(h, 11) * P1; }
+  h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+  return h;
+}
+
 }  // namespace zd

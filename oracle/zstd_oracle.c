@@ -295,6 +295,7 @@ static int block_compressed(FrameCtx* c, const uint8_t* src, int size, uint8_t* 
     else { if (ip + 1 > size) goto done; nseq = ((nseq - 128) << 8) + src[ip]; ip += 1; }
   }
   int op = *op_io, lp = 0;
+  if (nseq == 0 && ip != size) goto done;                  /* nothing may follow the count of an empty sequences section */
   if (nseq > 0) {
     if (ip >= size) goto done;
     const int modes = src[ip++];
@@ -358,6 +359,34 @@ done:
 }
 
 /* One frame -> dst.  Returns the decoded size, 0 on any error (zstd_wrap_decompress's contract). */
+/* XXH64 (seed 0) of the decoded content, from the published algorithm: Zstandard's content checksum is its low 32 bits
+ * (RFC 8878 section 3.1.1: Content_Checksum). */
+static uint64_t zo_rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+static uint64_t zo_rd64(const uint8_t* p) { uint64_t v = 0; for (int k = 7; k >= 0; k--) v = (v << 8) | p[k]; return v; }
+static uint64_t zo_xxh64(const uint8_t* p, size_t len) {
+  const uint64_t P1 = 11400714785074694791ull, P2 = 14029467366897019727ull, P3 = 1609587929392839161ull,
+                 P4 = 9650029242287828579ull, P5 = 2870177450012600261ull;
+  const uint8_t* end = p + len;
+  uint64_t h;
+  if (len >= 32) {
+    uint64_t v1 = P1 + P2, v2 = P2, v3 = 0, v4 = 0 - P1;
+    while (p + 32 <= end) {
+      v1 = zo_rotl64(v1 + zo_rd64(p) * P2, 31) * P1; v2 = zo_rotl64(v2 + zo_rd64(p + 8) * P2, 31) * P1;
+      v3 = zo_rotl64(v3 + zo_rd64(p + 16) * P2, 31) * P1; v4 = zo_rotl64(v4 + zo_rd64(p + 24) * P2, 31) * P1;
+      p += 32;
+    }
+    h = zo_rotl64(v1, 1) + zo_rotl64(v2, 7) + zo_rotl64(v3, 12) + zo_rotl64(v4, 18);
+    h = (h ^ (zo_rotl64(v1 * P2, 31) * P1)) * P1 + P4; h = (h ^ (zo_rotl64(v2 * P2, 31) * P1)) * P1 + P4;
+    h = (h ^ (zo_rotl64(v3 * P2, 31) * P1)) * P1 + P4; h = (h ^ (zo_rotl64(v4 * P2, 31) * P1)) * P1 + P4;
+  } else h = P5;
+  h += (uint64_t)len;
+  while (p + 8 <= end) { h ^= zo_rotl64(zo_rd64(p) * P2, 31) * P1; h = zo_rotl64(h, 27) * P1 + P4; p += 8; }
+  if (p + 4 <= end) { h ^= (uint64_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24)) * P1; h = zo_rotl64(h, 23) * P2 + P3; p += 4; }
+  while (p < end) { h ^= (uint64_t)(*p++) * P5; h = zo_rotl64(h, 11) * P1; }
+  h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+  return h;
+}
+
 int orc_zstd_decompress(const void* src_, int srcsize, void* dst_, int cap) {
   const uint8_t* src = (const uint8_t*)src_;
   uint8_t* dst = (uint8_t*)dst_;
@@ -392,7 +421,12 @@ int orc_zstd_decompress(const void* src_, int srcsize, void* dst_, int cap) {
   }
   free(c);
   if (!ok) return ZO_ERR;
-  if (checksum) ip += 4;
+  if (checksum) {                                          /* low 32 bits of XXH64 of the content, verified like the reference does */
+    if (ip + 4 > srcsize) return ZO_ERR;
+    const uint32_t want = (uint32_t)src[ip] | ((uint32_t)src[ip + 1] << 8) | ((uint32_t)src[ip + 2] << 16) | ((uint32_t)src[ip + 3] << 24);
+    if ((uint32_t)zo_xxh64(dst, (size_t)op) != want) return ZO_ERR;
+    ip += 4;
+  }
   if (ip != srcsize) return ZO_ERR;                        /* ZSTD_decompress wants the input consumed: trailing bytes are an error */
   if (have_fcs && fcs != (uint64_t)op) return ZO_ERR;
   return op;

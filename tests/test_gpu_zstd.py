@@ -68,3 +68,32 @@ def test_corrupt_zstd_chunks_same_verdict_as_oracle(pkg, oracle):
             assert rg == n and np.array_equal(og, oo), (trial, pos)
         else:
             assert rg < 0, (trial, pos, ro, rg)
+
+
+def test_content_checksum_frames(pkg, oracle, ref):
+    """frames that carry a Content_Checksum (blosc never writes them, a caller's pre-made chunk may): decoded when the
+    checksum fits, rejected (-1) when it does not - the reference's verdicts."""
+    if ref is None:
+        pytest.skip("needs oracle/_ref to write frames with a checksum")
+    from test_oracle_zstd import _checksum_frames
+    for data, frame in _checksum_frames(ref):
+        n = data.size
+        if n < 128:
+            continue
+        for damage in (False, True):
+            f = frame.copy()
+            if damage:
+                f[-2] ^= 0x10
+            total = 16 + 4 + 4 + f.size                      # one unsplit block: header, bstarts[1], csize, frame
+            c = np.zeros(total, np.uint8)
+            c[0] = 2; c[1] = 1; c[2] = 0x10 | (4 << 5); c[3] = 1
+            c[4:8] = np.array([n], "<i4").view(np.uint8); c[8:12] = np.array([n], "<i4").view(np.uint8)
+            c[12:16] = np.array([total], "<i4").view(np.uint8)
+            c[16:20] = np.array([20], "<i4").view(np.uint8); c[20:24] = np.array([f.size], "<i4").view(np.uint8)
+            c[24:] = f
+            ro, oo = orc_decompress(oracle, c, n)
+            rg, og = pkg.decompress(c, n)
+            if damage:
+                assert ro < 0 and rg < 0, (n, ro, rg)
+            else:
+                assert ro == n and rg == n and np.array_equal(og, data), (n, ro, rg)

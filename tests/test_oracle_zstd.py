@@ -1,8 +1,8 @@
 """CPU: oracle/zstd_oracle.c (Zstd frame decoder restated from the format) pinned against the reference:
 the compat/*zstd*.cdata golden vectors, committed chunks written by the real reference
 (tests/golden/ref_zstd_chunks.npz, made by make_ref_zstd_chunks.py) and, where oracle/_ref exists, a sweep of
-freshly written chunks incl. getitem.  Groundwork for codec row K8: the GPU product still answers
--5 for Zstd chunks."""
+freshly written chunks incl. getitem.  The GPU decoder (k_zstd.hip) is checked against this oracle and the same fixtures in
+tests/test_gpu_zstd.py."""
 import glob
 import os
 
@@ -100,3 +100,45 @@ def test_direct_reference_frames(oracle, ref):
         assert np.array_equal(out, data)
         count += 1
     assert count == 864
+
+
+def _checksum_frames(ref):
+    """frames with a Content_Checksum, written by the reference's advanced API"""
+    import ctypes as C
+    ref.ZSTD_createCCtx.restype = C.c_void_p
+    ref.ZSTD_CCtx_setParameter.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    ref.ZSTD_CCtx_setParameter.restype = C.c_size_t
+    ref.ZSTD_compress2.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    ref.ZSTD_compress2.restype = C.c_size_t
+    ref.ZSTD_freeCCtx.argtypes = [C.c_void_p]
+    ref.ZSTD_isError.argtypes = [C.c_size_t]
+    out = []
+    for dname, n in [("bench19", 100000), ("linspace", 131072), ("random", 5000), ("zeros", 31), ("smallints", 300000)]:
+        data = DATASETS[dname](n)
+        cctx = ref.ZSTD_createCCtx()
+        assert not ref.ZSTD_isError(ref.ZSTD_CCtx_setParameter(cctx, 201, 1))       # ZSTD_c_checksumFlag
+        assert not ref.ZSTD_isError(ref.ZSTD_CCtx_setParameter(cctx, 100, 3))       # ZSTD_c_compressionLevel
+        buf = np.zeros(n + n // 4 + 128, np.uint8)
+        r = ref.ZSTD_compress2(cctx, ptr(buf), buf.size, ptr(data), n)
+        ref.ZSTD_freeCCtx(cctx)
+        assert not ref.ZSTD_isError(r)
+        out.append((data, buf[:r].copy()))
+    return out
+
+
+def test_content_checksum_is_verified(oracle, ref):
+    """RFC 8878 3.1.1 Content_Checksum (low 32 bits of XXH64): the reference verifies it, so does the oracle."""
+    import ctypes as C
+    if ref is None:
+        pytest.skip("needs oracle/_ref to write frames with a checksum")
+    oracle.orc_zstd_decompress.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    ref.ZSTD_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    ref.ZSTD_decompress.restype = C.c_size_t
+    for data, frame in _checksum_frames(ref):
+        assert frame[4] & 4                                                           # checksum flag of the frame header descriptor
+        back = np.zeros(data.size + 8, np.uint8)
+        assert oracle.orc_zstd_decompress(ptr(frame), frame.size, ptr(back), data.size) == data.size and np.array_equal(back[:data.size], data)
+        bad = frame.copy(); bad[-2] ^= 0x10                                           # damage the checksum itself
+        d = ref.ZSTD_decompress(ptr(back), data.size, ptr(bad), bad.size)
+        assert ref.ZSTD_isError(d)
+        assert oracle.orc_zstd_decompress(ptr(bad), bad.size, ptr(back), data.size) <= 0          # 0 = error (zstd_wrap_decompress, blosc.c:515-522)

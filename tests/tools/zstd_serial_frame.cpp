@@ -53,6 +53,7 @@ extern "C" int zs_decompress(const uint8_t* src, int srcsize, uint8_t* dst, int 
       if (u0 < 0) break;
       p += u0;
       int lp = 0; bool bad = false;
+      if (nseq == 0 && p != size) break;
       if (nseq > 0) {
         if (p >= size) break;
         const int modes = b[p++];
@@ -86,7 +87,12 @@ extern "C" int zs_decompress(const uint8_t* src, int srcsize, uint8_t* dst, int 
   }
   free(lit);
   if (!ok) return 0;
-  if (checksum) ip += 4;
+  if (checksum) {
+    if (ip + 4 > srcsize) return 0;
+    const uint32_t want = (uint32_t)src[ip] | ((uint32_t)src[ip + 1] << 8) | ((uint32_t)src[ip + 2] << 16) | ((uint32_t)src[ip + 3] << 24);
+    if ((uint32_t)zd::xxh64(dst, (uint32_t)op) != want) return 0;
+    ip += 4;
+  }
   if (ip != srcsize) return 0;
   if (fcs >= 0 && fcs != op) return 0;
   return op;
