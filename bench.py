@@ -262,14 +262,27 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
-    # RCCL communicator also at N = 1 (size 1): the code path is the same for every N
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
-    else:
-        rdv = tempfile.NamedTemporaryFile(prefix="bamd_rdv_", delete=False)
-        rdv.close()
-        os.unlink(rdv.name)
-        dist.init_process_group("nccl", init_method=f"file://{rdv.name}", rank=0, world_size=1, device_id=dev)
+    # RCCL communicator also at N = 1 (size 1): the code path is the same for every N.
+    # RCCL prints a version banner through C stdio when the communicator comes up; stdout is for the one JSON line, so
+    # fd 1 points at stderr until the first collective is through and C stdio is flushed.
+    libc = C.CDLL(None)
+    sys.stdout.flush()
+    saved_fd1 = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        if world > 1:
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            rdv = tempfile.NamedTemporaryFile(prefix="bamd_rdv_", delete=False)
+            rdv.close()
+            os.unlink(rdv.name)
+            dist.init_process_group("nccl", init_method=f"file://{rdv.name}", rank=0, world_size=1, device_id=dev)
+        dist.barrier()
+        torch.cuda.synchronize()
+        libc.fflush(None)
+    finally:
+        os.dup2(saved_fd1, 1)
+        os.close(saved_fd1)
     mod = load_pkg()
     lib = mod.load()
     mspec = importlib.util.spec_from_file_location("c_blosc_amd_multigpu", os.path.join(ROOT, "c-blosc_amd", "multigpu.py"))

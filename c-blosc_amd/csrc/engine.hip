@@ -225,6 +225,8 @@ static bool span_enabled() { static const bool on = !(getenv("BLOSC_AMD_SPANS") 
 // but its concurrency is bound by LDS (8 KiB of ring per plane with real LZ work) and it is slower on every SURVEY §8d
 // data set so far (profiles/r02_b_block_decoder.md); the whole GPU suite passes with it on (tests/test_gpu_modes.py).
 static bool blockdec_enabled() { static const bool on = getenv("BLOSC_AMD_BLOCKDEC") && atoi(getenv("BLOSC_AMD_BLOCKDEC")) != 0; return on; }
+// BLOSC_AMD_PERIODIC=0: every plane goes through the match finder (A/B switch for the periodic-plane shortcut of the fused shuffle)
+static bool periodic_enabled() { static const bool on = !(getenv("BLOSC_AMD_PERIODIC") && atoi(getenv("BLOSC_AMD_PERIODIC")) == 0); return on; }
 static bool fuse_enabled() { static const bool on = !(getenv("BLOSC_AMD_FUSE") && atoi(getenv("BLOSC_AMD_FUSE")) == 0); return on; }
 
 int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* results, bool device_ptrs,
@@ -425,7 +427,8 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
 #ifdef BAMD_PROFILE_DECODE
     uint32_t* d_prof = nullptr;
     if (getenv("BLOSC_AMD_ENC_PROFILE")) { (void)hipMalloc((void**)&d_prof, nstr * 64); (void)hipMemsetAsync(d_prof, 0, nstr * 64, stream); }
-    hipLaunchKernelGGL(k_encode_streams_t<false>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)nullptr, (const zenc::CTabs*)nullptr, d_prof);
+    if (zstd) hipLaunchKernelGGL(k_encode_streams_t<true>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)(D + o_seqbufs), (const zenc::CTabs*)(D + o_ctabs), 0, d_prof);
+    else hipLaunchKernelGGL(k_encode_streams_t<false>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)nullptr, (const zenc::CTabs*)nullptr, periodic_enabled() ? 1 : 0, d_prof);
     if (d_prof) {
       std::vector<uint32_t> h(nstr * 16);
       (void)hipStreamSynchronize(stream);
@@ -435,8 +438,8 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
       (void)hipFree(d_prof);
     }
 #else
-    if (zstd) hipLaunchKernelGGL(k_encode_streams_t<true>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)(D + o_seqbufs), (const zenc::CTabs*)(D + o_ctabs));
-    else hipLaunchKernelGGL(k_encode_streams_t<false>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)nullptr, (const zenc::CTabs*)nullptr);
+    if (zstd) hipLaunchKernelGGL(k_encode_streams_t<true>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)(D + o_seqbufs), (const zenc::CTabs*)(D + o_ctabs), 0);
+    else hipLaunchKernelGGL(k_encode_streams_t<false>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)nullptr, (const zenc::CTabs*)nullptr, periodic_enabled() ? 1 : 0);
 #endif
   }
   {

@@ -29,6 +29,7 @@ namespace bamd {
 // Optional phase profiling of the encoder (prof build, scripts/enc_phase.py); same slot layout as k_decode.hip's.
 // slots: 0 steps, 1 steps without a match, 2 forward extensions, 3 literal runs copied from memory, 6 sequences,
 //        5 backward extensions tried, 7 of those > 0 bytes, 4 of those > 4 bytes
+//        (Zstd: 4 cycles tail literals + offset values, 5 cycles sequences section)
 //        13 cycles: waiting for the block's shuffle task
 //        8 cycles: window+probe, 9 candidates+select, 10 extension, 11 emit, 12 tail
 #ifdef BAMD_PROFILE_DECODE
@@ -162,6 +163,9 @@ __device__ __forceinline__ uint32_t emit_ext255(gu8* p, uint32_t v, int lane) {
 }
 
 enum { EF_LZ4 = 0, EF_BLOSCLZ = 1, EF_ZSTD = 2 };
+#ifndef BAMD_ZSTD_MINLEN
+#define BAMD_ZSTD_MINLEN 4     // shortest match the Zstd path takes (5 and 6: bench19 ratio and time in DESIGN.md 3.6)
+#endif
 
 // Where the match finder puts its findings when the target is a Zstd block (zstd_enc.h): literals go straight to
 // their final place in the block being written, (literal length, match length, offset) triples to a scratch of the
@@ -377,7 +381,7 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
   // < 1 % of ratio (bench19: 53.3 -> 48.5, still far above the reference's 36.7 at this clevel).
   // (Zstd sequences are cheaper than LZ4's - a repeated distance costs 5 bits - so short matches pay off there.)
   static_assert(EF_ZSTD == 2, "");
-  const uint32_t zmin = (uint32_t)__builtin_amdgcn_readfirstlane(4);
+  const uint32_t zmin = (uint32_t)__builtin_amdgcn_readfirstlane(BAMD_ZSTD_MINLEN);
   const uint32_t minlen = FMT == EF_ZSTD ? zmin : (clevel >= 9 ? 4u : (clevel >= 6 ? 5u : 6u));
 
   if (start == 0u) tab.clear(lane);
@@ -482,7 +486,7 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
         mlen += wave_common_fwd(src, n, pm + RANK_CAP, cm + RANK_CAP, mlimit - (pm + RANK_CAP), lane);
       const uint64_t bm = __ballot(bx != by);          // lanes >= maxb always vote "differs"
       const uint32_t back = bm ? (uint32_t)__builtin_ctzll(bm) : 64u;
-      PROF_LAP(10); PROF_ADD(2, len_f == RANK_CAP); PROF_ADD(3, anchor < ip && pm > anchor); PROF_ADD(6, 1); PROF_ADD(7, back > 0); PROF_ADD(4, back > 4); PROF_ADD(5, maxb > 0);
+      PROF_LAP(10); PROF_ADD(2, len_f == RANK_CAP); PROF_ADD(3, anchor < ip && pm > anchor); PROF_ADD(6, 1); PROF_ADD(7, back > 0); if (FMT != EF_ZSTD) { PROF_ADD(4, back > 4); PROF_ADD(5, maxb > 0); }
       pm -= back; cm -= back; mlen += back;
       const uint32_t ll = pm - anchor;
       const uint32_t dist = pm - cm;
@@ -604,14 +608,20 @@ __device__ __forceinline__ uint32_t zs_write_sequences(gu8* out, uint32_t room, 
     const uint32_t cnt = nseq - base < 64u ? nseq - base : 64u;
     const uint64_t q = (uint32_t)lane < cnt ? seqs[base + (uint32_t)lane] : zenc::pack_seq(0, 3, 4);
     const zenc::Code l = zenc::ll_code(zenc::seq_ll(q)), m = zenc::ml_code(zenc::seq_ml(q)), o = zenc::of_code_value(zenc::seq_off(q));
-    const uint32_t pk = l.code | (m.code << 6) | (o.code << 12) | (l.bits << 17) | (m.bits << 22);
+    // everything that does not depend on the FSE states is prepared per lane, 64 sequences at once: the table rows of the
+    // sequence's three codes and its extra bits as ONE field (literal-length | match-length | offset bits, <= 49 bits).
+    // The serial loop below - a scalar program, and all waves of a CU share one scalar unit - only walks the states.
+    const uint32_t dl_v = ll_dnb[l.code], dm_v = ml_dnb[m.code], do_v = of_dnb[o.code];
+    const uint32_t nbx_v = l.bits + m.bits + o.bits;
+    const uint32_t fpk_v = ((uint32_t)ll_dfs[l.code] & 0xffu) | (((uint32_t)ml_dfs[m.code] & 0xffu) << 8) | (((uint32_t)of_dfs[o.code] & 0xffu) << 16) | (nbx_v << 24);
+    const uint64_t ext_v = (uint64_t)l.extra | ((uint64_t)m.extra << l.bits) | ((uint64_t)o.extra << (l.bits + m.bits));
+    const uint32_t exl_v = (uint32_t)ext_v, exh_v = (uint32_t)(ext_v >> 32);
     for (int k = (int)cnt - 1; k >= 0; k--) {
-      const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)pk, k);
-      const uint32_t ell = (uint32_t)__builtin_amdgcn_readlane((int)l.extra, k), eml = (uint32_t)__builtin_amdgcn_readlane((int)m.extra, k);
-      const uint32_t eof = (uint32_t)__builtin_amdgcn_readlane((int)o.extra, k);
-      const uint32_t lc = c & 63u, mc = (c >> 6) & 63u, oc = (c >> 12) & 31u, lb = (c >> 17) & 31u, mb = (c >> 22) & 31u;
-      const uint32_t dl = uni(ll_dnb[lc]), dm = uni(ml_dnb[mc]), dO = uni(of_dnb[oc]);
-      const int32_t fl = (int32_t)uni((uint32_t)ll_dfs[lc]), fm = (int32_t)uni((uint32_t)ml_dfs[mc]), fo = (int32_t)uni((uint32_t)of_dfs[oc]);
+      const uint32_t dl = (uint32_t)__builtin_amdgcn_readlane((int)dl_v, k), dm = (uint32_t)__builtin_amdgcn_readlane((int)dm_v, k);
+      const uint32_t dO = (uint32_t)__builtin_amdgcn_readlane((int)do_v, k), fpk = (uint32_t)__builtin_amdgcn_readlane((int)fpk_v, k);
+      const uint32_t exl = (uint32_t)__builtin_amdgcn_readlane((int)exl_v, k), exh = (uint32_t)__builtin_amdgcn_readlane((int)exh_v, k);
+      const int32_t fl = (int32_t)(int8_t)(fpk & 0xffu), fm = (int32_t)(int8_t)((fpk >> 8) & 0xffu), fo = (int32_t)(int8_t)((fpk >> 16) & 0xffu);
+      const uint32_t nbx = fpk >> 24;
       if (first) {
         first = false;
         const uint32_t nm = (dm + (1u << 15)) >> 16, nO = (dO + (1u << 15)) >> 16, nl = (dl + (1u << 15)) >> 16;
@@ -619,11 +629,16 @@ __device__ __forceinline__ uint32_t zs_write_sequences(gu8* out, uint32_t room, 
         sof = uni((uint32_t)of_st[(int32_t)(((nO << 16) - dO) >> nO) + fo]);
         sll = uni((uint32_t)ll_st[(int32_t)(((nl << 16) - dl) >> nl) + fl]);
       } else {
-        const uint32_t nO = (sof + dO) >> 16; add(sof & ((1u << nO) - 1u), nO); sof = uni((uint32_t)of_st[(int32_t)(sof >> nO) + fo]);
-        const uint32_t nm = (sml + dm) >> 16; add(sml & ((1u << nm) - 1u), nm); sml = uni((uint32_t)ml_st[(int32_t)(sml >> nm) + fm]);
-        const uint32_t nl = (sll + dl) >> 16; add(sll & ((1u << nl) - 1u), nl); sll = uni((uint32_t)ll_st[(int32_t)(sll >> nl) + fl]);
+        // the three state transitions: their bits (<= 5 + 6 + 6) go out as one field
+        const uint32_t nO = (sof + dO) >> 16, nm = (sml + dm) >> 16, nl = (sll + dl) >> 16;
+        const uint32_t bitsv = (sof & ((1u << nO) - 1u)) | ((sml & ((1u << nm) - 1u)) << nO) | ((sll & ((1u << nl) - 1u)) << (nO + nm));
+        const uint32_t nxo = uni((uint32_t)of_st[(int32_t)(sof >> nO) + fo]), nxm = uni((uint32_t)ml_st[(int32_t)(sml >> nm) + fm]);
+        const uint32_t nxl = uni((uint32_t)ll_st[(int32_t)(sll >> nl) + fl]);
+        add(bitsv, nO + nm + nl);
+        sof = nxo; sml = nxm; sll = nxl;
       }
-      add(ell, lb); add(eml, mb); add(eof, oc);            // offsets stay below 2^17 here: at most 17 extra bits
+      if (nbx > 24u) { add(exl & 0xffffffu, 24u); add((exl >> 24) | (exh << 8), nbx - 24u); }      // <= 49 bits: two pieces of <= 25
+      else add(exl, nbx);
     }
     if (base == 0u) break;
   }
@@ -674,7 +689,9 @@ __device__ uint32_t zstd_encode_wave(const gu8* __restrict__ src, uint32_t n, gu
       __builtin_amdgcn_s_waitcnt(0);      // this wave's sequence triples are in memory before other lanes load them
       zs_assign_offset_values(seqbuf, z.nseq, rep, lane);
       __builtin_amdgcn_s_waitcnt(0);
+      PROF_LAP(4);                        // Zstd: slot 4 = tail literals + offset values, slot 5 = sequences section
       const uint32_t ss = zs_write_sequences(z.lit + z.nlit, z.litcap - z.nlit, seqbuf, z.nseq, T, lane);
+      PROF_LAP(5);
       if (ss != 0xffffffffu) bsize = zenc::kLitHeader + z.nlit + ss;
     }
     if (bsize >= seg) {                   // no gain: Raw_Block
@@ -737,20 +754,127 @@ __device__ void shuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize, i
   for (uint32_t k = N * T + (uint32_t)lane; k < bsize; k += 64u) dst[k] = src[k];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Periodic planes.  A byte plane whose every 256-byte row equals its first row - a constant byte, a counter's low
+// byte, the zero top bytes of small integers: the planes shuffling exists to produce - needs no match finder and no
+// trip through the scratch: its stream is "first period as literals + one match over the rest".  The shuffle wave
+// notices them for free (it holds each row in a register): as long as a plane's rows keep repeating, nothing is
+// stored; the first row that differs back-fills the rows skipped so far (copies of row 0) and the plane is an
+// ordinary one from there on.  A plane that stays periodic to the end gets its first row stored (the literals' source)
+// and its period p (smallest power of two, 1..256) left in its stream's `result` as -p; encode_one_stream turns that
+// into the stream (emit_periodic_stream).  The mirror image of the decoder's periodic spans (k_decode.hip).
+// Only whole-row blocks (N % 256 == 0, N >= 1024) whose planes are streams of their own (split blocks).
+// ---------------------------------------------------------------------------------------------
+template <int T>
+__device__ __forceinline__ void shuffle_rows(const ElemRows<T>& x, uint32_t (&r)[8]) {
+  if (T == 8) {
+    transpose4x4(x.a.x, x.a.z, x.b.x, x.b.z, r[0], r[1], r[2], r[3]);
+    transpose4x4(x.a.y, x.a.w, x.b.y, x.b.w, r[4], r[5], r[6], r[7]);
+  } else {
+    transpose4x4(x.a.x, x.a.y, x.a.z, x.a.w, r[0], r[1], r[2], r[3]);
+    r[4] = r[5] = r[6] = r[7] = 0;
+  }
+}
+// smallest power-of-two period (bytes) of a 256-byte row held one dword per lane; 256 when there is none below
+__device__ __forceinline__ uint32_t row_period(uint32_t w, int lane) {
+  uint32_t p = 256u;
+  for (uint32_t sh = 32u; sh >= 1u; sh >>= 1) {
+    const uint32_t other = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((uint32_t)lane + sh) & 63u) << 2), (int)w);
+    if (__ballot(other != w) != 0ull) return p;
+    p = 4u * sh;
+  }
+  const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);       // all lanes hold the same dword here
+  if ((w0 >> 16) != (w0 & 0xffffu)) return 4u;
+  return ((w0 >> 8) & 0xffu) == (w0 & 0xffu) ? 1u : 2u;
+}
+// returns the mask of planes that stayed periodic; their period goes to period[k]
+template <int T>
+__device__ uint32_t shuffle_block_wave_detect(const gu8* src, gu8* dst, uint32_t bsize, int lane, uint32_t (&period)[8]) {
+  const uint32_t N = bsize / T;
+  uint32_t row0[8], r[8];
+  uint32_t per = (1u << T) - 1u;                       // wave-uniform: planes whose rows all equalled row 0 so far
+  shuffle_rows<T>(shuffle_load<T>(src, 0u, lane), row0);
+  auto step = [&](const ElemRows<T>& x, uint32_t e) {
+    if (per == 0u) { shuffle_store<T>(dst, N, e, lane, x); return; }
+    shuffle_rows<T>(x, r);
+    gu8* o = dst + e + 4u * (uint32_t)lane;
+#pragma unroll
+    for (int k = 0; k < T; k++) {
+      if (per & (1u << k)) {
+        if (__ballot(r[k] != row0[k]) == 0ull) continue;
+        per &= ~(1u << k);
+        for (uint32_t t = 0; t < e; t += 256u) g_st4(dst + (size_t)k * N + t + 4u * (uint32_t)lane, row0[k]);
+      }
+      g_st4(o + (size_t)k * N, r[k]);
+    }
+  };
+  uint32_t e = 256u;
+  for (; e + 1024u <= N; e += 1024u) {
+    const ElemRows<T> a = shuffle_load<T>(src, e, lane), b = shuffle_load<T>(src, e + 256u, lane);
+    const ElemRows<T> c = shuffle_load<T>(src, e + 512u, lane), d = shuffle_load<T>(src, e + 768u, lane);
+    step(a, e); step(b, e + 256u); step(c, e + 512u); step(d, e + 768u);
+  }
+  for (; e + 256u <= N; e += 256u) step(shuffle_load<T>(src, e, lane), e);
+#pragma unroll
+  for (int k = 0; k < T; k++) {
+    period[k] = 0u;
+    if (per & (1u << k)) {
+      g_st4(dst + (size_t)k * N + 4u * (uint32_t)lane, row0[k]);
+      period[k] = row_period(row0[k], lane);
+    }
+  }
+  return per;
+}
+
 // queue task "shuffle block gb": afterwards the block's flag tells the encoders of its streams to go ahead.
 // Producer and consumers run on the same XCD (per-XCD queues), so the hand-off goes through that XCD's L2:
 // drain the stores, then a relaxed agent-scope flag store - no L2 write-back needed.
+template <int T>
+__device__ __forceinline__ void shuffle_block_detect_T(const gu8* src, gu8* dst, uint32_t bsize, StreamDesc* planes, int lane) {
+  uint32_t period[8];
+  const uint32_t per = shuffle_block_wave_detect<T>(src, dst, bsize, lane, period);
+#pragma unroll
+  for (int k = 0; k < T; k++)
+    if ((per & (1u << k)) && lane == 0) planes[k].result = -(int32_t)period[k];
+}
 __device__ __attribute__((noinline)) void shuffle_block_task(const ChunkDesc* chunks, const BlockDesc* blocks, uint32_t gb,
-                                                             uint32_t* blk_ready, int lane) {
+                                                             uint32_t* blk_ready, StreamDesc* streams, int detect, int lane) {
   const BlockDesc* b = blocks + gb;
   const ChunkDesc* c = chunks + uni((uint32_t)b->chunk);
   const uint32_t blk = uni((uint32_t)b->blk), bsize = uni((uint32_t)b->bsize), bs = uni((uint32_t)c->blocksize);
   const gu8* src = uni_ptr(as_global(c->src)) + (size_t)blk * bs;
   gu8* dst = uni_ptr(as_global(c->filt)) + (size_t)blk * bs;
-  if (uni((uint32_t)c->typesize) == 8u) shuffle_block_wave_T<8>(src, dst, bsize, lane);
-  else shuffle_block_wave_T<4>(src, dst, bsize, lane);
+  const uint32_t T = uni((uint32_t)c->typesize), N = bsize / T;
+  // periodic planes (see above): whole rows only, planes that are streams of their own, LZ4 / BloscLZ streams
+  const bool det = detect && uni((uint32_t)b->nstreams) == T && N * T == bsize && (N & 255u) == 0u && N >= 1024u &&
+                   (uni((uint32_t)c->fmt) == (uint32_t)FMT_LZ4 || uni((uint32_t)c->fmt) == (uint32_t)FMT_BLOSCLZ);
+  StreamDesc* planes = streams + uni((uint32_t)b->first_stream);
+  if (T == 8u) { if (det) shuffle_block_detect_T<8>(src, dst, bsize, planes, lane); else shuffle_block_wave_T<8>(src, dst, bsize, lane); }
+  else { if (det) shuffle_block_detect_T<4>(src, dst, bsize, planes, lane); else shuffle_block_wave_T<4>(src, dst, bsize, lane); }
   __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): every store of this wave has reached L2
   if (lane == 0) __hip_atomic_store(&blk_ready[gb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The stream of a plane of n bytes (n % 256 == 0, n >= 1024) that repeats with period p <= 256; `in` holds its first 256
+// bytes.  LZ4: p literals, one match at distance p up to n - 5, the last five bytes as literals (lz4.c:245-246 end
+// rules).  BloscLZ: the same with the match ending at n - 2 (the encoder's own limit above) and the marker bit of
+// blosclz.c:607.  Always smaller than n, so the "store raw" fallback - which would need the plane in memory - cannot hit.
+__device__ __forceinline__ uint32_t emit_periodic_stream(const gu8* in, uint32_t n, gu8* out, uint32_t cap, uint32_t p, bool lz4, int lane) {
+  uint32_t op;
+  if (lz4) {
+    op = lz4_emit_seq(out, 0u, cap, in, p, p, n - 5u - p, -1, 0u, lane);
+    if (op == 0xffffffffu) return 0u;
+    op = lz4_emit_tail(out, op, cap, in + 251u, 5u, lane);
+    return op == 0xffffffffu ? 0u : op;
+  }
+  op = blz_emit_literals(out, 0u, cap, in, p, lane);
+  if (op == 0xffffffffu) return 0u;
+  op = blz_emit_match(out, op, cap, p, n - 2u - p, lane);
+  if (op == 0xffffffffu) return 0u;
+  op = blz_emit_literals(out, op, cap, in + 254u, 2u, lane);
+  if (op == 0xffffffffu) return 0u;
+  if (lane == 0) out[0] |= 0x20u;
+  return op;
 }
 
 // one stream, not inlined into the queue loop (see decode_one_stream in k_decode.hip for why)
@@ -776,7 +900,9 @@ __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, enc_
   PROF_LAP(13);
   const uint64_t cost_t0 = __builtin_amdgcn_s_memtime();
   uint32_t r;
-  if (sd->fmt == FMT_LZ4) r = lz_encode_wave<EF_LZ4>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, lane EPROF_PASS);
+  const int32_t hint = (int32_t)uni((uint32_t)sd->result);      // < 0: the shuffle task found this plane periodic (period -hint)
+  if (hint < 0) r = emit_periodic_stream(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, (uint32_t)-hint, uni((uint32_t)sd->fmt) == (uint32_t)FMT_LZ4, lane);
+  else if (sd->fmt == FMT_LZ4) r = lz_encode_wave<EF_LZ4>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, lane EPROF_PASS);
   else if (sd->fmt == FMT_ZSTD) r = seqbuf ? zstd_encode_wave(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, (BAMD_GAS uint64_t*)seqbuf, lane EPROF_PASS) : 0u;
   else r = lz_encode_wave<EF_BLOSCLZ>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, lane EPROF_PASS);
   if (lane == 0) sd->result = (int32_t)r;
@@ -801,7 +927,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES, BAMD_ENC_MINWAVES) void k_encode_st
     StreamDesc* __restrict__ streams, uint32_t* __restrict__ tickets /*[8]*/, const int32_t* __restrict__ qlist,
     const int32_t* __restrict__ qoff /*[9]*/, const ChunkDesc* __restrict__ chunks, const BlockDesc* __restrict__ blocks,
     uint32_t* __restrict__ blk_ready, uint32_t* __restrict__ plane_cost, int single_queue,
-    uint64_t* __restrict__ seqbufs, const zenc::CTabs* __restrict__ ctabs
+    uint64_t* __restrict__ seqbufs, const zenc::CTabs* __restrict__ ctabs, int detect_periodic
 #ifdef BAMD_PROFILE_DECODE
     , uint32_t* __restrict__ profbuf
 #endif
@@ -823,7 +949,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES, BAMD_ENC_MINWAVES) void k_encode_st
   while (t < qlen) {
     const int32_t task = (int32_t)uni((uint32_t)qlist[qbase + t]);
     if (task < 0) {
-      shuffle_block_task(chunks, blocks, (uint32_t)(-(task + 1)), blk_ready, lane);
+      shuffle_block_task(chunks, blocks, (uint32_t)(-(task + 1)), blk_ready, streams, detect_periodic, lane);
     } else {
 #ifdef BAMD_PROFILE_DECODE
       encode_one_stream(streams + task, tabs[0], chunks, blk_ready, lane, blocks, (uint32_t)task, plane_cost, seqbuf, profbuf ? profbuf + (size_t)task * 16 : nullptr);

@@ -7,6 +7,7 @@ from helpers import DATASETS
 spec = importlib.util.spec_from_file_location("c_blosc_amd", os.path.join(ROOT, "c-blosc_amd", "__init__.py")); mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
 lib = mod.load()
 nchunks = int(os.environ.get("CHUNKS", "128")); csz = 64 << 20
+CL = int(os.environ.get("CLEVEL", "5"))
 dev = torch.device("cuda:0")
 comp = torch.empty((nchunks, csz + 16), dtype=torch.uint8, device=dev)
 back = torch.empty((nchunks, csz), dtype=torch.uint8, device=dev)
@@ -16,12 +17,12 @@ for dname in os.environ.get("DATA", "bench19,linspace,randwalk,random,zeros").sp
     src.copy_(torch.from_numpy(host).to(dev).unsqueeze(0).expand(nchunks, csz))
     for codec in os.environ.get("CODECS", "lz4").split(","):
         bc = mod.DeviceBatch([src[i].data_ptr() for i in range(nchunks)], [csz] * nchunks, [comp[i].data_ptr() for i in range(nchunks)], [csz + 16] * nchunks)
-        bc.compress(8, 5, 1, codec.encode(), 0)
+        bc.compress(8, CL, 1, codec.encode(), 0)
         lib.blosc_gpu_profile(1); lib.blosc_gpu_profile_reset()
-        for _ in range(2): bc.compress(8, 5, 1, codec.encode(), 0)
+        for _ in range(2): bc.compress(8, CL, 1, codec.encode(), 0)
         lib.blosc_gpu_profile(0)
         cb = bc.results()
-        e = mod.profile_get("k_encode_streams"); s = mod.profile_get("k_shuffle")
+        e = mod.profile_get("k_zstd_encode" if codec == "zstd" else "k_encode_streams"); s = mod.profile_get("k_shuffle")
         bd = mod.DeviceBatch([comp[i].data_ptr() for i in range(nchunks)], cb, [back[i].data_ptr() for i in range(nchunks)], [csz] * nchunks)
         bd.decompress()
         ok = bool((back == src).all())
