@@ -616,23 +616,43 @@ __device__ __forceinline__ void unshuffle_store(gu8* dst, uint32_t e, int lane, 
   }
 }
 
-// spans: {lo, hi} per plane (nullptr: none), pat: SPAN_PAT bytes per plane - see SpanCtx above
+// spans: {lo | small, hi} per plane (nullptr: none), pat: SPAN_PAT bytes per plane - see SpanCtx above.
+// `small` (bit 0 of the first word): the span's period divides 256.  A lane's dword of such a plane is then the same in
+// every 256-element step (element e + 4 lane, e a multiple of 256), so it is loaded ONCE per block and kept in a
+// register.  That matters more than it looks: the pattern tables of the blocks in flight (16 KiB per block, 768 blocks
+// per XCD) do not fit the 4 MiB L2, so table reads come from HBM / Infinity Cache like the scratch itself (all-zero
+// input: 8 GiB written AND 8 GiB "read" per launch, 3.1 ms; scripts/micro/fronts.hip: a plain 8 GiB fill takes 1.6 ms).
 template <int T>
 __device__ void unshuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize, int lane, const uint32_t* spans, const gu8* pat) {
   const uint32_t N = bsize / T;
-  uint32_t lo[T], hi[T];
+  uint32_t lo[T], hi[T], pr[T];
+  uint32_t small = 0;                                    // wave-uniform plane mask
 #pragma unroll
-  for (int j = 0; j < T; j++) { lo[j] = spans ? uni(spans[2 * j]) : 0u; hi[j] = spans ? uni(spans[2 * j + 1]) : 0u; }
+  for (int j = 0; j < T; j++) {
+    const uint32_t w = spans ? uni(spans[2 * j]) : 0u;
+    lo[j] = w & ~1023u; hi[j] = spans ? uni(spans[2 * j + 1]) : 0u;
+    pr[j] = 0u;
+    if ((w & 1u) && hi[j] > lo[j]) { small |= 1u << j; pr[j] = g_ld4(pat + (size_t)j * SPAN_PAT + 4u * (uint32_t)lane); }
+  }
+  // the register rows are in before the loop: otherwise the compiler, which cannot tell whether they are still in flight,
+  // waits for vmcnt(0) at the top of EVERY iteration - i.e. for the previous iteration's stores
+  __builtin_amdgcn_s_waitcnt(0);
   uint32_t e = 0;
   // 4 steps (1024 elements) per iteration: all loads are issued before the first store.  Span bounds are
-  // multiples of 1024, so one decision per plane and iteration picks the scratch or the pattern table.
+  // multiples of 1024, so one decision per plane and iteration picks the scratch, the pattern table or the register.
   for (; e + 1024u <= N; e += 1024u) {
-    PlanePtrs<T> pp;
+    Rows<T> a, b, c, d;
+    const uint32_t l4 = 4u * (uint32_t)lane;
 #pragma unroll
-    for (int j = 0; j < T; j++)
-      pp.p[j] = (e >= lo[j] && e < hi[j]) ? pat + (size_t)j * SPAN_PAT + (e & (SPAN_PAT - 1u)) : src + (size_t)j * N + e;
-    const Rows<T> a = unshuffle_load<T>(pp, 0u, lane), b = unshuffle_load<T>(pp, 256u, lane);
-    const Rows<T> c = unshuffle_load<T>(pp, 512u, lane), d = unshuffle_load<T>(pp, 768u, lane);
+    for (int j = 0; j < T; j++) {
+      const bool in_span = e >= lo[j] && e < hi[j];            // wave-uniform
+      const bool reg = in_span && ((small >> j) & 1u);
+      if (reg) { a.r[j] = b.r[j] = c.r[j] = d.r[j] = pr[j]; }   // scalar branch: no load at all
+      else {
+        const gu8* p = in_span ? pat + (size_t)j * SPAN_PAT + (e & (SPAN_PAT - 1u)) : src + (size_t)j * N + e;
+        a.r[j] = g_ld4(p + l4); b.r[j] = g_ld4(p + l4 + 256u); c.r[j] = g_ld4(p + l4 + 512u); d.r[j] = g_ld4(p + l4 + 768u);
+      }
+    }
     unshuffle_store<T>(dst, e, lane, a); unshuffle_store<T>(dst, e + 256u, lane, b);
     unshuffle_store<T>(dst, e + 512u, lane, c); unshuffle_store<T>(dst, e + 768u, lane, d);
   }
@@ -647,8 +667,13 @@ __device__ void unshuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize,
   for (uint32_t k = N * T + (uint32_t)lane; k < bsize; k += 64u) dst[k] = src[k];
 }
 
-__device__ __attribute__((noinline)) void unshuffle_block_wave(const uint8_t* src, uint8_t* dst, uint32_t bsize, int typesize, int lane,
-                                                               const uint32_t* spans, const uint8_t* pat) {
+__device__ __attribute__((noinline)) void unshuffle_block_wave(const uint8_t* src, uint8_t* dst, uint32_t bsize_, int typesize_, int lane,
+                                                               const uint32_t* spans_, const uint8_t* pat) {
+  // arguments of a real (non-inlined) call count as divergent for the compiler: without the readfirstlanes below the loop
+  // bounds, the span decisions and the plane pointers all lived in VGPRs (64-bit pointer pairs spilled inside the loop)
+  const uint32_t bsize = uni(bsize_); const int typesize = (int)uni((uint32_t)typesize_);
+  const uint64_t sv = (uint64_t)spans_;
+  const uint32_t* spans = (const uint32_t*)(((uint64_t)uni((uint32_t)(sv >> 32)) << 32) | uni((uint32_t)sv));
   if (typesize == 8) unshuffle_block_wave_T<8>(uni_ptr(as_global(src)), uni_ptr(as_global(dst)), bsize, lane, spans, uni_ptr(as_global(pat)));
   else unshuffle_block_wave_T<4>(uni_ptr(as_global(src)), uni_ptr(as_global(dst)), bsize, lane, spans, uni_ptr(as_global(pat)));
 }
@@ -702,7 +727,7 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
   }
   // ---- fused unshuffle: the wave that completes a block's LAST stream transposes the block ----
   if (!(mode & CH_FUSED_UNSHUF) || got != want) return;
-  if (spans && lane == 0) { spans[2 * (size_t)sid] = sp.lo; spans[2 * (size_t)sid + 1] = sp.hi; }
+  if (spans && lane == 0) { spans[2 * (size_t)sid] = sp.lo | ((sp.hi && sp.off <= 256u) ? 1u : 0u); spans[2 * (size_t)sid + 1] = sp.hi; }   // bit 0: period divides 256
   // All streams of one block are handed out from the SAME per-XCD queue (see k_decode_streams), so the
   // producers and this consumer share one L2: a store that has completed (vmcnt) is in that L2, and the
   // consumer only has to drop its own L1 lines.  No L2 write-back (`buffer_wbl2`) is needed - with 65 536
