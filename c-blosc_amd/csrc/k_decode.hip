@@ -616,30 +616,37 @@ __device__ __forceinline__ void unshuffle_store(gu8* dst, uint32_t e, int lane, 
   }
 }
 
-// spans: {lo | small, hi} per plane (nullptr: none), pat: SPAN_PAT bytes per plane - see SpanCtx above.
-// `small` (bit 0 of the first word): the span's period divides 256.  A lane's dword of such a plane is then the same in
-// every 256-element step (element e + 4 lane, e a multiple of 256), so it is loaded ONCE per block and kept in a
-// register.  That matters more than it looks: the pattern tables of the blocks in flight (16 KiB per block, 768 blocks
-// per XCD) do not fit the 4 MiB L2, so table reads come from HBM / Infinity Cache like the scratch itself (all-zero
-// input: 8 GiB written AND 8 GiB "read" per launch, 3.1 ms; scripts/micro/fronts.hip: a plain 8 GiB fill takes 1.6 ms).
+// spans: {lo | flags, hi} per plane (nullptr: none), pat: SPAN_PAT bytes per plane - see SpanCtx above.
+// Flag bit 0, `small`: the span's period divides 256.  A lane's dword of such a plane is then the same in every
+// 256-element step (element e + 4 lane, e a multiple of 256), so it is loaded ONCE per block and kept in a register.
+// That matters more than it looks: the pattern tables of the blocks in flight (16 KiB per block, 768 blocks per XCD) do
+// not fit the 4 MiB L2, so table reads come from HBM / Infinity Cache like the scratch itself (all-zero input: 8 GiB
+// written AND 8 GiB "read" per launch, 3.1 ms; scripts/micro/fronts.hip: a plain 8 GiB fill takes 1.6 ms).
+// Flag bit 1, `raw`: the split was stored raw (blosc/blosc.c:773-776) and has NOT been copied to the scratch: the plane is
+// read where it lies in the chunk (raw[j], any byte alignment).  Noisy float64 data stores 3 of 4 planes raw: the copy
+// was a read and a write of the plane for nothing.
+constexpr uint32_t SPAN_SMALL = 1u, SPAN_RAW = 2u;
 template <int T>
-__device__ void unshuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize, int lane, const uint32_t* spans, const gu8* pat) {
+__device__ void unshuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize, int lane, const uint32_t* spans, const gu8* pat, const StreamDesc* sds) {
   const uint32_t N = bsize / T;
   uint32_t lo[T], hi[T], pr[T];
+  const gu8* pl[T];                                      // where plane j lies: the scratch, or the chunk itself (raw)
   uint32_t small = 0;                                    // wave-uniform plane mask
 #pragma unroll
   for (int j = 0; j < T; j++) {
     const uint32_t w = spans ? uni(spans[2 * j]) : 0u;
     lo[j] = w & ~1023u; hi[j] = spans ? uni(spans[2 * j + 1]) : 0u;
     pr[j] = 0u;
-    if ((w & 1u) && hi[j] > lo[j]) { small |= 1u << j; pr[j] = g_ld4(pat + (size_t)j * SPAN_PAT + 4u * (uint32_t)lane); }
+    pl[j] = src + (size_t)j * N;
+    if (w & SPAN_RAW) { pl[j] = uni_ptr(as_global(sds[j].in)); hi[j] = 0u; }
+    else if ((w & SPAN_SMALL) && hi[j] > lo[j]) { small |= 1u << j; pr[j] = g_ld4(pat + (size_t)j * SPAN_PAT + 4u * (uint32_t)lane); }
   }
   // the register rows are in before the loop: otherwise the compiler, which cannot tell whether they are still in flight,
   // waits for vmcnt(0) at the top of EVERY iteration - i.e. for the previous iteration's stores
   __builtin_amdgcn_s_waitcnt(0);
   uint32_t e = 0;
   // 4 steps (1024 elements) per iteration: all loads are issued before the first store.  Span bounds are
-  // multiples of 1024, so one decision per plane and iteration picks the scratch, the pattern table or the register.
+  // multiples of 1024, so one decision per plane and iteration picks the plane, the pattern table or the register.
   for (; e + 1024u <= N; e += 1024u) {
     Rows<T> a, b, c, d;
     const uint32_t l4 = 4u * (uint32_t)lane;
@@ -649,33 +656,37 @@ __device__ void unshuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize,
       const bool reg = in_span && ((small >> j) & 1u);
       if (reg) { a.r[j] = b.r[j] = c.r[j] = d.r[j] = pr[j]; }   // scalar branch: no load at all
       else {
-        const gu8* p = in_span ? pat + (size_t)j * SPAN_PAT + (e & (SPAN_PAT - 1u)) : src + (size_t)j * N + e;
+        const gu8* p = in_span ? pat + (size_t)j * SPAN_PAT + (e & (SPAN_PAT - 1u)) : pl[j] + e;
         a.r[j] = g_ld4(p + l4); b.r[j] = g_ld4(p + l4 + 256u); c.r[j] = g_ld4(p + l4 + 512u); d.r[j] = g_ld4(p + l4 + 768u);
       }
     }
     unshuffle_store<T>(dst, e, lane, a); unshuffle_store<T>(dst, e + 256u, lane, b);
     unshuffle_store<T>(dst, e + 512u, lane, c); unshuffle_store<T>(dst, e + 768u, lane, d);
   }
-  {
-    PlanePtrs<T> pp;   // behind the last multiple of 1024 nothing is skipped
+  // behind the last multiple of 1024 nothing is skipped
+  for (; e + 256u <= N; e += 256u) {
+    Rows<T> x;
 #pragma unroll
-    for (int j = 0; j < T; j++) pp.p[j] = src + (size_t)j * N;
-    for (; e + 256u <= N; e += 256u) unshuffle_store<T>(dst, e, lane, unshuffle_load<T>(pp, e, lane));
+    for (int j = 0; j < T; j++) x.r[j] = g_ld4(pl[j] + e + 4u * (uint32_t)lane);
+    unshuffle_store<T>(dst, e, lane, x);
   }
-  // tail: fewer than 256 elements, then the bytes that do not form a whole element
-  for (uint32_t k = e * T + (uint32_t)lane; k < N * T; k += 64u) { const uint32_t el = k / T, j = k - el * T; dst[k] = src[(size_t)j * N + el]; }
+  // tail: fewer than 256 elements, then the bytes that do not form a whole element (never a split block: src is the scratch)
+#pragma unroll
+  for (int j = 0; j < T; j++)
+    for (uint32_t el = e + (uint32_t)lane; el < N; el += 64u) dst[(size_t)el * T + j] = pl[j][el];
   for (uint32_t k = N * T + (uint32_t)lane; k < bsize; k += 64u) dst[k] = src[k];
 }
 
 __device__ __attribute__((noinline)) void unshuffle_block_wave(const uint8_t* src, uint8_t* dst, uint32_t bsize_, int typesize_, int lane,
-                                                               const uint32_t* spans_, const uint8_t* pat) {
+                                                               const uint32_t* spans_, const uint8_t* pat, const StreamDesc* sds_) {
   // arguments of a real (non-inlined) call count as divergent for the compiler: without the readfirstlanes below the loop
   // bounds, the span decisions and the plane pointers all lived in VGPRs (64-bit pointer pairs spilled inside the loop)
   const uint32_t bsize = uni(bsize_); const int typesize = (int)uni((uint32_t)typesize_);
-  const uint64_t sv = (uint64_t)spans_;
+  const uint64_t sv = (uint64_t)spans_, dv = (uint64_t)sds_;
   const uint32_t* spans = (const uint32_t*)(((uint64_t)uni((uint32_t)(sv >> 32)) << 32) | uni((uint32_t)sv));
-  if (typesize == 8) unshuffle_block_wave_T<8>(uni_ptr(as_global(src)), uni_ptr(as_global(dst)), bsize, lane, spans, uni_ptr(as_global(pat)));
-  else unshuffle_block_wave_T<4>(uni_ptr(as_global(src)), uni_ptr(as_global(dst)), bsize, lane, spans, uni_ptr(as_global(pat)));
+  const StreamDesc* sds = (const StreamDesc*)(((uint64_t)uni((uint32_t)(dv >> 32)) << 32) | uni((uint32_t)dv));
+  if (typesize == 8) unshuffle_block_wave_T<8>(uni_ptr(as_global(src)), uni_ptr(as_global(dst)), bsize, lane, spans, uni_ptr(as_global(pat)), sds);
+  else unshuffle_block_wave_T<4>(uni_ptr(as_global(src)), uni_ptr(as_global(dst)), bsize, lane, spans, uni_ptr(as_global(pat)), sds);
 }
 
 // One stream, start to finish.  Deliberately NOT inlined into the queue loop below: with the decoders
@@ -704,8 +715,11 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
   sp.lo = 0; sp.hi = 0; sp.off = 0; sp.pat = uni_ptr(as_global(pat)) + (size_t)sid * SPAN_PAT;
   const uint64_t cost_t0 = __builtin_amdgcn_s_memtime();
   int got;
+  bool raw_in_place = false;
   if (csize == want) {    // split stored raw (blosc/blosc.c:773-776)
-    wave_copy_disjoint(out, in, (uint32_t)want, lane);
+    // fused split blocks: the unshuffle reads the plane where it lies in the chunk (SPAN_RAW), no copy to the scratch
+    raw_in_place = sp.enabled != 0u;
+    if (!raw_in_place) wave_copy_disjoint(out, in, (uint32_t)want, lane);
     got = want;
   } else if (sd->fmt == FMT_ZSTD) {
     return;               // k_zstd_streams owns the frames of Zstd chunks
@@ -727,7 +741,10 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
   }
   // ---- fused unshuffle: the wave that completes a block's LAST stream transposes the block ----
   if (!(mode & CH_FUSED_UNSHUF) || got != want) return;
-  if (spans && lane == 0) { spans[2 * (size_t)sid] = sp.lo | ((sp.hi && sp.off <= 256u) ? 1u : 0u); spans[2 * (size_t)sid + 1] = sp.hi; }   // bit 0: period divides 256
+  if (spans && lane == 0) {
+    spans[2 * (size_t)sid] = raw_in_place ? SPAN_RAW : (sp.lo | ((sp.hi && sp.off <= 256u) ? SPAN_SMALL : 0u));
+    spans[2 * (size_t)sid + 1] = sp.hi;
+  }
   // All streams of one block are handed out from the SAME per-XCD queue (see k_decode_streams), so the
   // producers and this consumer share one L2: a store that has completed (vmcnt) is in that L2, and the
   // consumer only has to drop its own L1 lines.  No L2 write-back (`buffer_wbl2`) is needed - with 65 536
@@ -742,7 +759,7 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
   const bool split = spans && nstreams == uni((uint32_t)c->typesize);
   const uint32_t fs = uni((uint32_t)b->first_stream);
   unshuffle_block_wave(c->filt + boff, c->dst + boff, uni((uint32_t)b->bsize), (int)uni((uint32_t)c->typesize), lane,
-                       split ? spans + 2 * (size_t)fs : nullptr, pat + (size_t)fs * SPAN_PAT);
+                       split ? spans + 2 * (size_t)fs : nullptr, pat + (size_t)fs * SPAN_PAT, sd - (sid - fs));
 }
 
 #ifndef BAMD_DEC_MINWAVES
