@@ -1,0 +1,210 @@
+// inflate_serial.h — the inherently SERIAL parts of reading a zlib stream (codec row "Zlib" of SURVEY §8f-3:
+// zlib_wrap_decompress blosc/blosc.c:484-495 -> uncompress -> inflate, internal-complibs/zlib-1.3.1/inflate.c:590-1270,
+// inftrees.c:32-299): the LSB-first bit reader, the zlib header, block headers, the code-length code, canonical Huffman
+// table builds and the symbol decoder.  Written from the formats (RFC 1950, RFC 1951) with the reference's acceptance
+// rules where the RFC leaves room:
+//   * an over-subscribed set of code lengths is an error; an incomplete one is an error too, EXCEPT a literal/length or
+//     distance code whose longest code is one bit long (inftrees.c:130-135), and a distance code without any symbol;
+//   * the code-length code must be complete (inftrees.c:134, type == CODES);
+//   * a dynamic block must give symbol 256 a code (inflate.c:1003-1007); HLIT > 286 or HDIST > 30 is an error (:929-935);
+//   * literal/length symbols 286 / 287 and distance symbols 30 / 31 are invalid when they are decoded (fixed tables);
+//   * bits missing at the end of the input are an error (uncompress turns Z_BUF_ERROR into a failure, uncompr.c:79-84).
+// No malloc, every read bounded by the stream, all tables in caller-provided memory (LDS on the GPU).
+//
+// Plain C++ for BOTH sides (like zstd_serial.h): k_zlib.hip runs these functions wave-uniformly (every lane computes the
+// same values) and does the byte moving wave-parallel; tests/tools/inflate_serial_stream.cpp compiles the same code with
+// g++ and is compared with the real zlib of the reference on valid and corrupted streams (tests/test_inflate_serial_cpu.py).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define ZI_FN __device__ __forceinline__
+#else
+#define ZI_FN static inline
+#endif
+
+namespace zi {
+
+// ---------------- bit reader: LSB first, never touches a byte outside [p, p + n) ----------------
+struct Bits { const uint8_t* p; uint32_t n; uint32_t pos; uint64_t acc; uint32_t nacc; uint32_t used; };   // used: bits consumed so far
+ZI_FN void bits_init(Bits& b, const uint8_t* p, uint32_t n) { b.p = p; b.n = n; b.pos = 0; b.acc = 0; b.nacc = 0; b.used = 0; }
+// at least 32 valid bits in the accumulator (zeros beyond the end of the input: the callers compare `used` with 8 n)
+ZI_FN void bits_fill(Bits& b) {
+  if (b.nacc >= 32u) return;
+  if (b.pos + 4u <= b.n) {
+    uint32_t v; __builtin_memcpy(&v, b.p + b.pos, 4);
+    b.acc |= (uint64_t)v << b.nacc; b.nacc += 32u; b.pos += 4u;
+  } else {
+    while (b.nacc < 32u) { const uint32_t v = b.pos < b.n ? b.p[b.pos] : 0u; b.pos++; b.acc |= (uint64_t)v << b.nacc; b.nacc += 8u; }
+  }
+}
+ZI_FN uint32_t bits_peek(Bits& b, uint32_t k) { bits_fill(b); return (uint32_t)b.acc & ((1u << k) - 1u); }     // k <= 16
+ZI_FN void bits_drop(Bits& b, uint32_t k) { b.acc >>= k; b.nacc -= k; b.used += k; }
+ZI_FN uint32_t bits_get(Bits& b, uint32_t k) { const uint32_t v = bits_peek(b, k); bits_drop(b, k); return v; }
+ZI_FN bool bits_overrun(const Bits& b) { return b.used > 8u * b.n; }
+ZI_FN void bits_align(Bits& b) { const uint32_t k = (8u - (b.used & 7u)) & 7u; bits_drop(b, k); }   // the accumulator always holds >= 7 bits here (bits_peek before)
+ZI_FN uint32_t bits_bytepos(const Bits& b) { return b.used >> 3; }                                      // only meaningful when aligned
+
+// ---------------- canonical Huffman codes ----------------
+// count[len] = number of symbols with that code length, sym[] = symbols ordered by (length, symbol), fast[] = direct
+// lookup for codes of at most FB bits: symbol << 4 | length, 0 = longer code (or no code).
+constexpr int kLitFast = 9, kDistFast = 7, kMaxBits = 15;
+struct Tabs {
+  uint16_t lcount[16], lsym[288], lfast[1 << kLitFast];
+  uint16_t dcount[16], dsym[32], dfast[1 << kDistFast];
+  uint8_t lens[320];                  // code lengths of the block being set up (literal/length, then distance)
+};
+ZI_FN uint32_t rev_bits(uint32_t v, int n) { uint32_t r = 0; for (int i = 0; i < n; i++) { r = (r << 1) | (v & 1u); v >>= 1; } return r; }
+// returns: 0 complete, > 0 incomplete (bits of code space left), < 0 over-subscribed; *maxlen = longest code (0: no symbol)
+ZI_FN int huff_build(uint16_t* count, uint16_t* sym, uint16_t* fast, int fastbits, const uint8_t* lens, int n, int* maxlen) {
+  uint16_t offs[16];
+  for (int l = 0; l <= kMaxBits; l++) count[l] = 0;
+  for (int s = 0; s < n; s++) count[lens[s]]++;
+  int left = 1, mx = 0;
+  for (int l = 1; l <= kMaxBits; l++) { left <<= 1; left -= (int)count[l]; if (left < 0) return left; if (count[l]) mx = l; }
+  *maxlen = mx;
+  offs[1] = 0;
+  for (int l = 1; l < kMaxBits; l++) offs[l + 1] = (uint16_t)(offs[l] + count[l]);
+  for (int s = 0; s < n; s++) if (lens[s]) sym[offs[lens[s]]++] = (uint16_t)s;
+  for (int k = 0; k < (1 << fastbits); k++) fast[k] = 0;
+  uint32_t code = 0; int idx = 0;
+  for (int l = 1; l <= fastbits; l++) {
+    for (int c = 0; c < (int)count[l]; c++, code++, idx++) {
+      const uint16_t e = (uint16_t)((sym[idx] << 4) | l);
+      for (uint32_t k = rev_bits(code, l); k < (1u << fastbits); k += 1u << l) fast[k] = e;
+    }
+    code <<= 1;
+  }
+  return left;
+}
+// next symbol, or -1 when the bits match no code
+ZI_FN int huff_decode(Bits& b, const uint16_t* count, const uint16_t* sym, const uint16_t* fast, int fastbits) {
+  const uint32_t v = bits_peek(b, kMaxBits);
+  const uint32_t e = fast[v & ((1u << fastbits) - 1u)];
+  if (e) { bits_drop(b, e & 15u); return (int)(e >> 4); }
+  int code = 0, first = 0, index = 0;
+  for (int l = 1; l <= kMaxBits; l++) {
+    code |= (int)((v >> (l - 1)) & 1u);
+    const int c = (int)count[l];
+    if (code - c < first) { bits_drop(b, (uint32_t)l); return (int)sym[index + (code - first)]; }
+    index += c; first += c; first <<= 1; code <<= 1;
+  }
+  return -1;
+}
+
+// ---------------- stream / block structure ----------------
+enum { BLK_STORED = 0, BLK_CODED = 1, BLK_ERROR = -1 };
+enum { OP_LIT = 0, OP_MATCH = 1, OP_EOB = 2, OP_ERROR = -1 };
+struct Op { uint32_t len, dist; };     // OP_LIT: len = the byte
+
+// zlib header (RFC 1950; inflate.c:672-707 with the default 15 window bits and no dictionary)
+ZI_FN bool zlib_header(Bits& b) {
+  if (b.n < 2u) return false;
+  const uint32_t cmf = bits_get(b, 8), flg = bits_get(b, 8);
+  if (((cmf << 8) | flg) % 31u) return false;
+  if ((cmf & 15u) != 8u || (cmf >> 4) > 7u) return false;
+  if (flg & 0x20u) return false;                                   // preset dictionary: Z_NEED_DICT -> failure
+  return true;
+}
+
+ZI_FN void fixed_lengths(uint8_t* lens) {
+  for (int s = 0; s < 144; s++) lens[s] = 8;
+  for (int s = 144; s < 256; s++) lens[s] = 9;
+  for (int s = 256; s < 280; s++) lens[s] = 7;
+  for (int s = 280; s < 288; s++) lens[s] = 8;
+  for (int s = 0; s < 32; s++) lens[288 + s] = 5;      // 30 and 31 have codes but are invalid when decoded (next_op)
+}
+
+// reads one block header; *final = BFINAL.  BLK_STORED: *stored_len bytes follow at byte bits_bytepos(b) (the caller copies
+// them and calls bits_skip_bytes); BLK_CODED: the tables in `t` are ready for next_op().
+ZI_FN int block_begin(Bits& b, Tabs& t, int* final, uint32_t* stored_len) {
+  *final = (int)bits_get(b, 1);
+  const uint32_t type = bits_get(b, 2);
+  if (bits_overrun(b)) return BLK_ERROR;
+  if (type == 0u) {
+    bits_peek(b, 8); bits_align(b);
+    const uint32_t len = bits_get(b, 16), nlen = bits_get(b, 16);
+    if (bits_overrun(b) || len != (nlen ^ 0xffffu)) return BLK_ERROR;
+    if ((uint64_t)bits_bytepos(b) + len > b.n) return BLK_ERROR;
+    *stored_len = len;
+    return BLK_STORED;
+  }
+  if (type == 3u) return BLK_ERROR;
+  int nlen = 288, ndist = 32;
+  if (type == 1u) fixed_lengths(t.lens);
+  else {
+    nlen = (int)bits_get(b, 5) + 257; ndist = (int)bits_get(b, 5) + 1;
+    const int ncode = (int)bits_get(b, 4) + 4;
+    if (nlen > 286 || ndist > 30) return BLK_ERROR;
+    const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    uint8_t cl[19];
+    for (int i = 0; i < 19; i++) cl[i] = 0;
+    for (int i = 0; i < ncode; i++) cl[order[i]] = (uint8_t)bits_get(b, 3);
+    if (bits_overrun(b)) return BLK_ERROR;
+    int mx;
+    // the code-length code uses the distance arrays as scratch (they are rebuilt below)
+    const int left = huff_build(t.dcount, t.dsym, t.dfast, kDistFast, cl, 19, &mx);
+    if (left < 0 || (left > 0 && mx != 0)) return BLK_ERROR;   // must be complete (mx == 0: no code at all - every read below fails)
+    int have = 0;
+    while (have < nlen + ndist) {
+      const int s = mx ? huff_decode(b, t.dcount, t.dsym, t.dfast, kDistFast) : -1;
+      if (s < 0 || bits_overrun(b)) return BLK_ERROR;
+      if (s < 16) { t.lens[have++] = (uint8_t)s; continue; }
+      int rep, val = 0;
+      if (s == 16) { if (have == 0) return BLK_ERROR; val = t.lens[have - 1]; rep = 3 + (int)bits_get(b, 2); }
+      else if (s == 17) rep = 3 + (int)bits_get(b, 3);
+      else rep = 11 + (int)bits_get(b, 7);
+      if (have + rep > nlen + ndist) return BLK_ERROR;
+      while (rep--) t.lens[have++] = (uint8_t)val;
+    }
+    if (bits_overrun(b)) return BLK_ERROR;
+    if (t.lens[256] == 0) return BLK_ERROR;
+    // distance lengths to their fixed place behind the 288 literal/length slots
+    for (int s = ndist - 1; s >= 0; s--) t.lens[288 + s] = t.lens[nlen + s];
+  }
+  int mx;
+  int left = huff_build(t.lcount, t.lsym, t.lfast, kLitFast, t.lens, nlen, &mx);
+  if (left < 0 || (left > 0 && mx != 1)) return BLK_ERROR;
+  left = huff_build(t.dcount, t.dsym, t.dfast, kDistFast, t.lens + 288, ndist, &mx);
+  if (left < 0 || (left > 0 && mx > 1)) return BLK_ERROR;   // mx == 0: no distance code (fine until one is needed)
+  return BLK_CODED;
+}
+ZI_FN void bits_skip_bytes(Bits& b, uint32_t nbytes) {     // behind a stored block's header: the reader is byte-aligned
+  const uint32_t at = bits_bytepos(b) + nbytes;
+  b.pos = at; b.acc = 0; b.nacc = 0; b.used = 8u * at;
+}
+
+ZI_FN uint32_t len_base(int c) {      // c = symbol - 257, 0..28
+  return c < 8 ? 3u + (uint32_t)c : (c == 28 ? 258u : 3u + ((4u + ((uint32_t)c & 3u)) << ((uint32_t)(c >> 2) - 1u)));
+}
+ZI_FN uint32_t len_extra(int c) { return (c < 8 || c == 28) ? 0u : (uint32_t)(c >> 2) - 1u; }
+ZI_FN uint32_t dist_base(int c) { return c < 4 ? 1u + (uint32_t)c : 1u + ((2u + ((uint32_t)c & 1u)) << ((uint32_t)(c >> 1) - 1u)); }
+ZI_FN uint32_t dist_extra(int c) { return c < 4 ? 0u : (uint32_t)(c >> 1) - 1u; }
+
+// next literal / match / end-of-block of a coded block
+ZI_FN int next_op(Bits& b, const Tabs& t, Op& op) {
+  const int s = huff_decode(b, t.lcount, t.lsym, t.lfast, kLitFast);
+  if (s < 0 || bits_overrun(b)) return OP_ERROR;
+  if (s < 256) { op.len = (uint32_t)s; return OP_LIT; }
+  if (s == 256) return OP_EOB;
+  if (s > 285) return OP_ERROR;
+  const int lc = s - 257;
+  op.len = len_base(lc) + bits_get(b, len_extra(lc));
+  const int d = huff_decode(b, t.dcount, t.dsym, t.dfast, kDistFast);
+  if (d < 0 || d > 29) return OP_ERROR;
+  const uint32_t de = dist_extra(d);
+  op.dist = dist_base(d) + bits_get(b, de);
+  if (bits_overrun(b)) return OP_ERROR;
+  return OP_MATCH;
+}
+
+// Adler-32 of the plain bytes follows the last block, big-endian, on a byte boundary (RFC 1950)
+ZI_FN bool read_adler(Bits& b, uint32_t* value) {
+  bits_peek(b, 8); bits_align(b);
+  uint32_t v = 0;
+  for (int i = 0; i < 4; i++) v = (v << 8) | bits_get(b, 8);
+  *value = v;
+  return !bits_overrun(b);
+}
+
+}  // namespace zi

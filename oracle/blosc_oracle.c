@@ -662,6 +662,7 @@ static int orc_block_d(int flags, int versionlz_fmt, int typesize, int compresse
     else {
       if (versionlz_fmt == 0) nb = orc_blosclz_decompress(s, cb, out, neblock);
       else if (versionlz_fmt == 4) nb = orc_zstd_decompress(s, cb, out, neblock);   /* zstd_wrap_decompress, blosc.c:515-522 */
+      else if (versionlz_fmt == 3) nb = orc_zlib_decompress(s, cb, out, neblock);   /* zlib_wrap_decompress, blosc.c:484-495 */
       else nb = orc_lz4_decompress(s, cb, out, neblock);
       if (nb != neblock) return -2;
     }
@@ -672,11 +673,11 @@ static int orc_block_d(int flags, int versionlz_fmt, int typesize, int compresse
   return ntbytes;
 }
 
-/* initialize_decompress_func, blosc/blosc.c:525-574: BloscLZ, LZ4(+HC) and Zstd are restated here; Snappy and
- * Zlib answer -5 like a build configured without them.  All three known formats carry version 1. */
+/* initialize_decompress_func, blosc/blosc.c:525-574: BloscLZ, LZ4(+HC), Zlib and Zstd are restated here; Snappy
+ * answers -5 like a build configured without it.  All known formats carry version 1. */
 static int orc_pick_format(int flags, int versionlz) {
   int fmt = (flags & 0xe0) >> 5;
-  if (fmt == 0 || fmt == 1 || fmt == 4) return versionlz == 1 ? fmt : -9;
+  if (fmt == 0 || fmt == 1 || fmt == 3 || fmt == 4) return versionlz == 1 ? fmt : -9;
   return -5;
 }
 

@@ -49,6 +49,9 @@ int orc_blosclz_decompress(const uint8_t* src, int srclen, uint8_t* dst, int dst
 /* ---- Zstd frame decoder (oracle/zstd_oracle.c; zstd_wrap_decompress blosc/blosc.c:515-522): decoded size, 0 on error ---- */
 int orc_zstd_decompress(const void* src, int srcsize, void* dst, int dstcap);
 
+/* ---- zlib stream decoder (oracle/zlib_oracle.c; zlib_wrap_decompress blosc/blosc.c:484-495): decoded size, 0 on error ---- */
+int orc_zlib_decompress(const void* src, int srcsize, void* dst, int dstcap);
+
 /* ---- policy (blosc/blosc.c:929-1060) ---- */
 int orc_split_block(int codec, int typesize, int blocksize, int splitmode);
 int orc_compute_blocksize(int clevel, int typesize, int nbytes, int forced_blocksize, int codec,
@@ -57,7 +60,7 @@ int orc_compute_blocksize(int clevel, int typesize, int nbytes, int forced_block
 /* ---- chunk level (blosc/blosc.c:591-867, 1062-1279, 1435-1518, 1574-1703) ----
  * Same return conventions as blosc_compress_ctx / blosc_decompress / blosc_getitem with one
  * thread.  orc_compress knows BloscLZ and LZ4 (others: -5, as a stock build without them would);
- * orc_decompress / orc_getitem also read Zstd chunks. */
+ * orc_decompress / orc_getitem also read Zlib and Zstd chunks. */
 int orc_compress(int clevel, int doshuffle, size_t typesize, size_t nbytes, const void* src,
                  void* dest, size_t destsize, int codec, size_t forced_blocksize, int splitmode);
 int orc_decompress(const void* src, void* dest, size_t destsize);
