@@ -13,7 +13,8 @@ namespace bamd {
 enum : int32_t {
   FMT_BLOSCLZ = 0,  // header flag bits 5-7 (blosc/blosc.h:93-99)
   FMT_LZ4 = 1,
-  FMT_ZSTD = 4,     // decode only (k_zstd.hip)
+  FMT_ZLIB = 3,     // k_zlib.hip (decode), deflate_enc.h (encode)
+  FMT_ZSTD = 4,     // k_zstd.hip / k_zstd2.hip (decode), zstd_enc.h (encode)
 };
 
 enum : uint32_t {

@@ -22,6 +22,7 @@
 #include "k_encode.hip"
 #include "k_zstd.hip"
 #include "k_zstd2.hip"
+#include "k_zlib.hip"
 
 namespace bamd {
 
@@ -70,13 +71,13 @@ struct PinnedArena {
 struct ProfEntry { double ms = 0; int launches = 0; };
 
 // per-launch feedback words of the persistent kernels: [0,256) cycles per plane index, [256] tasks taken by the
-// stream kernel, [257] streams taken by the Zstd kernel, [258] blocks taken by k_decode_blocks - the host compares them
-// with what it queued
+// stream kernel, [257] streams taken by the Zstd kernel, [258] blocks taken by k_decode_blocks, [259] streams taken by the
+// Zlib kernel - the host compares them with what it queued
 constexpr size_t kCostWords = 264;
-static int check_done(const uint32_t* fb, size_t expect, size_t expect_zstd, const char* what, size_t expect_blocks = 0) {
-  if (fb[256] == expect && fb[257] == expect_zstd && fb[258] == expect_blocks) return 0;
-  fprintf(stderr, "blosc_amd: %s: the device took %u of %zu queued tasks (Zstd: %u of %zu, blocks: %u of %zu) - results discarded\n",
-          what, fb[256], expect, fb[257], expect_zstd, fb[258], expect_blocks);
+static int check_done(const uint32_t* fb, size_t expect, size_t expect_zstd, const char* what, size_t expect_blocks = 0, size_t expect_zlib = 0) {
+  if (fb[256] == expect && fb[257] == expect_zstd && fb[258] == expect_blocks && fb[259] == expect_zlib) return 0;
+  fprintf(stderr, "blosc_amd: %s: the device took %u of %zu queued tasks (Zstd: %u of %zu, blocks: %u of %zu, Zlib: %u of %zu) - results discarded\n",
+          what, fb[256], expect, fb[257], expect_zstd, fb[258], expect_blocks, fb[259], expect_zlib);
   return -1;
 }
 
@@ -486,7 +487,7 @@ static int classify_for_decompress(const Header& h, size_t srcsize, size_t dests
     return 1;
   }
   const int f = (h.flags & 0xe0) >> 5;                                         // blosc.c:525-574
-  if (f != FMT_BLOSCLZ && f != FMT_LZ4 && f != FMT_ZSTD) { *res = -5; return 0; }   // Zstd: decode only (k_zstd.hip)
+  if (f != FMT_BLOSCLZ && f != FMT_LZ4 && f != FMT_ZLIB && f != FMT_ZSTD) { *res = -5; return 0; }   // Snappy: not built, like a stock build without it
   if (h.versionlz != 1) { *res = -9; return 0; }
   *fmt = f;
   int32_t nblocks = h.nbytes / h.blocksize + ((h.nbytes % h.blocksize) ? 1 : 0);
@@ -559,6 +560,7 @@ struct DecodeLaunch {
   uint32_t* d_spans; uint8_t* d_pat;             // periodic spans of the fused unshuffle (k_decode.hip: SpanCtx)
   uint32_t* d_cost;                              // [256] cycles per plane index (scheduling feedback)
   uint32_t* d_zticket; bool any_zstd;            // Zstd frames: k_zstd_entropy + k_zstd_exec (two-phase), the rest through k_zstd_streams
+  bool any_zlib;                                 // zlib streams: k_zlib_streams (ticket word d_zticket[2])
   ZMeta* d_zmeta; ptrdiff_t zseq_delta;          // nullptr: everything through k_zstd_streams
   const int32_t* d_qlist; const int32_t* d_qoff;   // per-XCD stream queues
   size_t nblk, nstr; int nchunks;
@@ -694,6 +696,11 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
                          L.d_zticket, L.d_chunks, L.d_blocks, L.d_cost + 257, d_taken);
 #endif
     }
+    if (L.any_zlib) {
+      ProfScope ps(st, stream, "k_zlib_streams");
+      hipLaunchKernelGGL(k_zlib_streams, dim3(persistent_grid(L.nstr, ZLIB_WAVES_PER_CU)), dim3(64), 0, stream, L.d_streams, (int)L.nstr, L.d_status,
+                         L.d_zticket + 2, L.d_cost + 259);
+    }
     if (L.any_shuf) {
       ProfScope ps(st, stream, "k_unshuffle");
       hipLaunchKernelGGL(k_unshuffle, dim3((unsigned)L.nblk, (unsigned)L.tiles_shuf), dim3(FT_THREADS), 0, stream, L.d_chunks, L.d_blocks);
@@ -716,7 +723,7 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
 
 static void filter_tiles(ChunkDesc& c, bool& any_shuf, bool& any_bit, int& tiles_shuf, int& tiles_bit, bool may_fuse) {
   const int32_t T = c.typesize, N = c.blocksize / T;
-  if ((c.mode & CH_SHUFFLE) && (T == 8 || T == 4) && fuse_enabled() && may_fuse && c.fmt != FMT_ZSTD) { c.mode |= CH_FUSED_UNSHUF; return; }
+  if ((c.mode & CH_SHUFFLE) && (T == 8 || T == 4) && fuse_enabled() && may_fuse && c.fmt != FMT_ZSTD && c.fmt != FMT_ZLIB) { c.mode |= CH_FUSED_UNSHUF; return; }
   if (c.mode & CH_SHUFFLE) {
     any_shuf = true;
     int t = (N + shuffle_tile_elems(T) - 1) / shuffle_tile_elems(T); if (t < 1) t = 1;
@@ -757,6 +764,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
     filter_tiles(c, L.any_shuf, L.any_bit, L.tiles_shuf, L.tiles_bit, !st.single_queue);
     if (c.mode & (CH_SHUFFLE | CH_BITSHUFFLE)) filt_bytes = align_up(filt_bytes, 256) + (size_t)c.nbytes;
     if (c.fmt == FMT_ZSTD && !(c.mode & CH_MEMCPYED)) { L.any_zstd = true; zlit_bytes = align_up(zlit_bytes, 256) + (size_t)c.nbytes; }
+    if (c.fmt == FMT_ZLIB && !(c.mode & CH_MEMCPYED)) L.any_zlib = true;
     if (!device_ptrs) { io_src = align_up(io_src, 256) + (size_t)c.cbytes; io_dst = align_up(io_dst, 256) + (size_t)c.nbytes; }
   }
   const size_t nblk = blocks.size();
@@ -837,7 +845,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   L.d_cost = (uint32_t*)(D + o_cost);
   HIP_TRY(hipMemsetAsync(D + o_cost, 0, sizeof(uint32_t) * kCostWords, stream));
   L.d_zticket = (uint32_t*)(D + o_zticket);
-  if (L.any_zstd) HIP_TRY(hipMemsetAsync(D + o_zticket, 0, 64, stream));
+  if (L.any_zstd || L.any_zlib) HIP_TRY(hipMemsetAsync(D + o_zticket, 0, 64, stream));
   L.d_zmeta = L.any_zstd ? (ZMeta*)(D + o_zmeta) : nullptr; L.zseq_delta = (ptrdiff_t)o_zseq - (ptrdiff_t)o_zlit + 8;
   L.nblk = nblk; L.nstr = nstr; L.nchunks = n;
   L.d_bctl = (uint32_t*)(D + o_blist);
@@ -851,7 +859,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   HIP_TRY(hipMemcpyAsync(P + p_cost, D + o_cost, sizeof(uint32_t) * kCostWords, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   prof_collect(st);
-  if (nblk && check_done((const uint32_t*)(P + p_cost), nstr - nstr_lds, L.any_zstd ? nstr : 0, "decompress", blist[0].size() + blist[1].size())) return -1;
+  if (nblk && check_done((const uint32_t*)(P + p_cost), nstr - nstr_lds, L.any_zstd ? nstr : 0, "decompress", blist[0].size() + blist[1].size(), L.any_zlib ? nstr : 0)) return -1;
   if (nstr >= 4096) { memcpy(st.dec_cost, P + p_cost, sizeof st.dec_cost); st.dec_cost_valid = true; }
   const int32_t* stt = (const int32_t*)(P + p_status);
   for (int i = 0; i < n; i++) {
@@ -889,7 +897,7 @@ int engine_getitem(const void* src, int start, int nitems, void* dest, bool src_
     if (h.nbytes + kMaxOverhead != h.cbytes) return -1;
   } else {
     const int f = (h.flags & 0xe0) >> 5;
-    if (f != FMT_BLOSCLZ && f != FMT_LZ4 && f != FMT_ZSTD) return -5;
+    if (f != FMT_BLOSCLZ && f != FMT_LZ4 && f != FMT_ZLIB && f != FMT_ZSTD) return -5;
     if (h.versionlz != 1) return -9;
     fmt = f;
     if (nblocks >= (h.cbytes - 16) / 4) return -1;                               // blosc.c:1630-1632 (sic: >=)
@@ -967,15 +975,15 @@ int engine_getitem(const void* src, int start, int nitems, void* dest, bool src_
   L.d_spans = span_enabled() ? (uint32_t*)(D + o_spans) : nullptr; L.d_pat = D + o_pat;
   L.d_cost = (uint32_t*)(D + o_cost);   // a handful of blocks: the plane costs are not fed back, only the task count is checked
   HIP_TRY(hipMemsetAsync(D + o_cost, 0, sizeof(uint32_t) * kCostWords, stream));
-  L.any_zstd = fmt == FMT_ZSTD; L.d_zticket = (uint32_t*)(D + o_zticket);
-  if (L.any_zstd) HIP_TRY(hipMemsetAsync(D + o_zticket, 0, 64, stream));
+  L.any_zstd = fmt == FMT_ZSTD; L.any_zlib = fmt == FMT_ZLIB; L.d_zticket = (uint32_t*)(D + o_zticket);
+  if (L.any_zstd || L.any_zlib) HIP_TRY(hipMemsetAsync(D + o_zticket, 0, 64, stream));
   L.nblk = nblk; L.nstr = nstr; L.nchunks = 1; L.nstr_queued = nstr;    // a handful of blocks: always through k_decode_streams
   if (launch_decode(st, L, stream)) return -1;
   HIP_TRY(hipMemcpyAsync(P + p_status, D + o_status, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipMemcpyAsync(P + p_cost, D + o_cost, sizeof(uint32_t) * kCostWords, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   prof_collect(st);
-  if (check_done((const uint32_t*)(P + p_cost), nstr, L.any_zstd ? nstr : 0, "getitem")) return -1;
+  if (check_done((const uint32_t*)(P + p_cost), nstr, L.any_zstd ? nstr : 0, "getitem", 0, L.any_zlib ? nstr : 0)) return -1;
   const int32_t stt = *(const int32_t*)(P + p_status);
   if (stt < 0) return stt;                                                        // blosc.c:1689-1692: blosc_d's code is returned as is
   HIP_TRY(hipMemcpyAsync(dest, D + o_out + (size_t)(lo - (int64_t)j0 * bs), want, out_kind, stream));

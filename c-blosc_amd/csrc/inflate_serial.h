@@ -19,66 +19,95 @@
 
 #if defined(__HIPCC__)
 #define ZI_FN __device__ __forceinline__
+#define ZI_MFN __device__ __forceinline__
+#define ZI_COLD __device__ __attribute__((noinline))   // once per block: real calls keep the symbol loop small (and its registers free)
+#define ZI_NOUNROLL _Pragma("nounroll")
 #else
 #define ZI_FN static inline
+#define ZI_MFN inline
+#define ZI_COLD static inline
+#define ZI_NOUNROLL
 #endif
 
 namespace zi {
 
-// ---------------- bit reader: LSB first, never touches a byte outside [p, p + n) ----------------
-struct Bits { const uint8_t* p; uint32_t n; uint32_t pos; uint64_t acc; uint32_t nacc; uint32_t used; };   // used: bits consumed so far
-ZI_FN void bits_init(Bits& b, const uint8_t* p, uint32_t n) { b.p = p; b.n = n; b.pos = 0; b.acc = 0; b.nacc = 0; b.used = 0; }
-// at least 32 valid bits in the accumulator (zeros beyond the end of the input: the callers compare `used` with 8 n)
-ZI_FN void bits_fill(Bits& b) {
-  if (b.nacc >= 32u) return;
-  if (b.pos + 4u <= b.n) {
-    uint32_t v; __builtin_memcpy(&v, b.p + b.pos, 4);
-    b.acc |= (uint64_t)v << b.nacc; b.nacc += 32u; b.pos += 4u;
-  } else {
-    while (b.nacc < 32u) { const uint32_t v = b.pos < b.n ? b.p[b.pos] : 0u; b.pos++; b.acc |= (uint64_t)v << b.nacc; b.nacc += 8u; }
+// ---------------- bit reader: LSB first, never touches a byte outside the stream ----------------
+// `Src` supplies the bytes: fetch32(pos) = the four bytes at pos, little endian, zero beyond the end.  MemSrc reads memory
+// (CPU build); the GPU kernel supplies a 512-byte register window of the stream (k_zlib.hip: WinSrc).
+struct MemSrc {
+  const uint8_t* p; uint32_t n;
+  ZI_MFN uint32_t fetch32(uint32_t pos) const {
+    if (pos + 4u <= n) { uint32_t v; __builtin_memcpy(&v, p + pos, 4); return v; }
+    uint32_t v = 0;
+    for (uint32_t k = 0; k < 4u && pos + k < n; k++) v |= (uint32_t)p[pos + k] << (8u * k);
+    return v;
   }
+};
+template <class Src>
+struct BitsT { Src s; uint32_t n; uint32_t pos; uint64_t acc; uint32_t nacc; uint32_t used; };   // used: bits consumed so far
+typedef BitsT<MemSrc> Bits;
+template <class B> ZI_FN void bits_start(B& b, uint32_t n) { b.n = n; b.pos = 0; b.acc = 0; b.nacc = 0; b.used = 0; }
+ZI_FN void bits_init(Bits& b, const uint8_t* p, uint32_t n) { b.s.p = p; b.s.n = n; bits_start(b, n); }
+// at least 32 valid bits in the accumulator (zeros beyond the end of the input: the callers compare `used` with 8 n)
+template <class B> ZI_FN void bits_fill(B& b) {
+  if (b.nacc >= 32u) return;
+  b.acc |= (uint64_t)b.s.fetch32(b.pos) << b.nacc; b.nacc += 32u; b.pos += 4u;
 }
-ZI_FN uint32_t bits_peek(Bits& b, uint32_t k) { bits_fill(b); return (uint32_t)b.acc & ((1u << k) - 1u); }     // k <= 16
-ZI_FN void bits_drop(Bits& b, uint32_t k) { b.acc >>= k; b.nacc -= k; b.used += k; }
-ZI_FN uint32_t bits_get(Bits& b, uint32_t k) { const uint32_t v = bits_peek(b, k); bits_drop(b, k); return v; }
-ZI_FN bool bits_overrun(const Bits& b) { return b.used > 8u * b.n; }
-ZI_FN void bits_align(Bits& b) { const uint32_t k = (8u - (b.used & 7u)) & 7u; bits_drop(b, k); }   // the accumulator always holds >= 7 bits here (bits_peek before)
-ZI_FN uint32_t bits_bytepos(const Bits& b) { return b.used >> 3; }                                      // only meaningful when aligned
+template <class B> ZI_FN uint32_t bits_peek(B& b, uint32_t k) { bits_fill(b); return (uint32_t)b.acc & ((1u << k) - 1u); }     // k <= 16
+template <class B> ZI_FN void bits_drop(B& b, uint32_t k) { b.acc >>= k; b.nacc -= k; b.used += k; }
+template <class B> ZI_FN uint32_t bits_get(B& b, uint32_t k) { const uint32_t v = bits_peek(b, k); bits_drop(b, k); return v; }
+template <class B> ZI_FN bool bits_overrun(const B& b) { return b.used > 8u * b.n; }
+template <class B> ZI_FN void bits_align(B& b) { const uint32_t k = (8u - (b.used & 7u)) & 7u; bits_drop(b, k); }   // the accumulator holds >= 7 bits here (bits_peek before)
+template <class B> ZI_FN uint32_t bits_bytepos(const B& b) { return b.used >> 3; }                                      // only meaningful when aligned
 
 // ---------------- canonical Huffman codes ----------------
 // count[len] = number of symbols with that code length, sym[] = symbols ordered by (length, symbol), fast[] = direct
 // lookup for codes of at most FB bits: symbol << 4 | length, 0 = longer code (or no code).
+// On the GPU every lane of the wave runs this code with the same values (wave-uniform); the tables live in LDS, are written
+// by ONE lane (writer()) and read by all: volatile, so that no lane works with a value it has kept in a register across
+// another lane's store.
 constexpr int kLitFast = 9, kDistFast = 7, kMaxBits = 15;
+#if defined(__HIPCC__)
+#define ZI_TAB volatile
+ZI_FN bool writer() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u; }
+#else
+#define ZI_TAB
+ZI_FN bool writer() { return true; }
+#endif
+typedef ZI_TAB uint16_t tab16;
+typedef ZI_TAB uint8_t tab8;
 struct Tabs {
-  uint16_t lcount[16], lsym[288], lfast[1 << kLitFast];
-  uint16_t dcount[16], dsym[32], dfast[1 << kDistFast];
-  uint8_t lens[320];                  // code lengths of the block being set up (literal/length, then distance)
+  tab16 lcount[16], lsym[288], lfast[1 << kLitFast];
+  tab16 dcount[16], dsym[32], dfast[1 << kDistFast];
+  tab8 lens[320];                     // code lengths of the block being set up (literal/length, then distance)
 };
 ZI_FN uint32_t rev_bits(uint32_t v, int n) { uint32_t r = 0; for (int i = 0; i < n; i++) { r = (r << 1) | (v & 1u); v >>= 1; } return r; }
 // returns: 0 complete, > 0 incomplete (bits of code space left), < 0 over-subscribed; *maxlen = longest code (0: no symbol)
-ZI_FN int huff_build(uint16_t* count, uint16_t* sym, uint16_t* fast, int fastbits, const uint8_t* lens, int n, int* maxlen) {
-  uint16_t offs[16];
-  for (int l = 0; l <= kMaxBits; l++) count[l] = 0;
-  for (int s = 0; s < n; s++) count[lens[s]]++;
+ZI_COLD int huff_build(tab16* count, tab16* sym, tab16* fast, int fastbits, const tab8* lens, int n, int* maxlen) {
+  uint16_t cnt[16], offs[16];
+  ZI_NOUNROLL for (int l = 0; l <= kMaxBits; l++) cnt[l] = 0;
+  ZI_NOUNROLL for (int s = 0; s < n; s++) cnt[lens[s]]++;
   int left = 1, mx = 0;
-  for (int l = 1; l <= kMaxBits; l++) { left <<= 1; left -= (int)count[l]; if (left < 0) return left; if (count[l]) mx = l; }
+  ZI_NOUNROLL for (int l = 1; l <= kMaxBits; l++) { left <<= 1; left -= (int)cnt[l]; if (left < 0) return left; if (cnt[l]) mx = l; }
   *maxlen = mx;
+  const bool w = writer();
+  ZI_NOUNROLL for (int l = 0; l <= kMaxBits; l++) if (w) count[l] = cnt[l];
   offs[1] = 0;
-  for (int l = 1; l < kMaxBits; l++) offs[l + 1] = (uint16_t)(offs[l] + count[l]);
-  for (int s = 0; s < n; s++) if (lens[s]) sym[offs[lens[s]]++] = (uint16_t)s;
-  for (int k = 0; k < (1 << fastbits); k++) fast[k] = 0;
+  ZI_NOUNROLL for (int l = 1; l < kMaxBits; l++) offs[l + 1] = (uint16_t)(offs[l] + cnt[l]);
+  ZI_NOUNROLL for (int s = 0; s < n; s++) { const int l = lens[s]; if (l) { if (w) sym[offs[l]] = (uint16_t)s; offs[l]++; } }
+  ZI_NOUNROLL for (int k = 0; k < (1 << fastbits); k++) if (w) fast[k] = 0;
   uint32_t code = 0; int idx = 0;
-  for (int l = 1; l <= fastbits; l++) {
-    for (int c = 0; c < (int)count[l]; c++, code++, idx++) {
+  ZI_NOUNROLL for (int l = 1; l <= fastbits; l++) {
+    ZI_NOUNROLL for (int c = 0; c < (int)cnt[l]; c++, code++, idx++) {
       const uint16_t e = (uint16_t)((sym[idx] << 4) | l);
-      for (uint32_t k = rev_bits(code, l); k < (1u << fastbits); k += 1u << l) fast[k] = e;
+      ZI_NOUNROLL for (uint32_t k = rev_bits(code, l); k < (1u << fastbits); k += 1u << l) if (w) fast[k] = e;
     }
     code <<= 1;
   }
   return left;
 }
 // next symbol, or -1 when the bits match no code
-ZI_FN int huff_decode(Bits& b, const uint16_t* count, const uint16_t* sym, const uint16_t* fast, int fastbits) {
+template <class B> ZI_FN int huff_decode(B& b, const tab16* count, const tab16* sym, const tab16* fast, int fastbits) {
   const uint32_t v = bits_peek(b, kMaxBits);
   const uint32_t e = fast[v & ((1u << fastbits) - 1u)];
   if (e) { bits_drop(b, e & 15u); return (int)(e >> 4); }
@@ -98,7 +127,7 @@ enum { OP_LIT = 0, OP_MATCH = 1, OP_EOB = 2, OP_ERROR = -1 };
 struct Op { uint32_t len, dist; };     // OP_LIT: len = the byte
 
 // zlib header (RFC 1950; inflate.c:672-707 with the default 15 window bits and no dictionary)
-ZI_FN bool zlib_header(Bits& b) {
+template <class B> ZI_FN bool zlib_header(B& b) {
   if (b.n < 2u) return false;
   const uint32_t cmf = bits_get(b, 8), flg = bits_get(b, 8);
   if (((cmf << 8) | flg) % 31u) return false;
@@ -107,17 +136,18 @@ ZI_FN bool zlib_header(Bits& b) {
   return true;
 }
 
-ZI_FN void fixed_lengths(uint8_t* lens) {
-  for (int s = 0; s < 144; s++) lens[s] = 8;
-  for (int s = 144; s < 256; s++) lens[s] = 9;
-  for (int s = 256; s < 280; s++) lens[s] = 7;
-  for (int s = 280; s < 288; s++) lens[s] = 8;
-  for (int s = 0; s < 32; s++) lens[288 + s] = 5;      // 30 and 31 have codes but are invalid when decoded (next_op)
+ZI_COLD void fixed_lengths(tab8* lens) {
+  if (!writer()) return;
+  ZI_NOUNROLL for (int s = 0; s < 144; s++) lens[s] = 8;
+  ZI_NOUNROLL for (int s = 144; s < 256; s++) lens[s] = 9;
+  ZI_NOUNROLL for (int s = 256; s < 280; s++) lens[s] = 7;
+  ZI_NOUNROLL for (int s = 280; s < 288; s++) lens[s] = 8;
+  ZI_NOUNROLL for (int s = 0; s < 32; s++) lens[288 + s] = 5;      // 30 and 31 have codes but are invalid when decoded (next_op)
 }
 
 // reads one block header; *final = BFINAL.  BLK_STORED: *stored_len bytes follow at byte bits_bytepos(b) (the caller copies
 // them and calls bits_skip_bytes); BLK_CODED: the tables in `t` are ready for next_op().
-ZI_FN int block_begin(Bits& b, Tabs& t, int* final, uint32_t* stored_len) {
+template <class B> ZI_FN int block_begin(B& b, Tabs& t, int* final, uint32_t* stored_len) {
   *final = (int)bits_get(b, 1);
   const uint32_t type = bits_get(b, 2);
   if (bits_overrun(b)) return BLK_ERROR;
@@ -137,30 +167,32 @@ ZI_FN int block_begin(Bits& b, Tabs& t, int* final, uint32_t* stored_len) {
     const int ncode = (int)bits_get(b, 4) + 4;
     if (nlen > 286 || ndist > 30) return BLK_ERROR;
     const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-    uint8_t cl[19];
-    for (int i = 0; i < 19; i++) cl[i] = 0;
-    for (int i = 0; i < ncode; i++) cl[order[i]] = (uint8_t)bits_get(b, 3);
+    // the 19 lengths of the code-length code: scratch behind the distance lengths' slot (rewritten below)
+    tab8* cl = t.lens + 296;
+    const bool w = writer();
+    ZI_NOUNROLL for (int i = 0; i < 19; i++) if (w) cl[i] = 0;
+    ZI_NOUNROLL for (int i = 0; i < ncode; i++) { const uint32_t v = bits_get(b, 3); if (w) cl[order[i]] = (uint8_t)v; }
     if (bits_overrun(b)) return BLK_ERROR;
     int mx;
     // the code-length code uses the distance arrays as scratch (they are rebuilt below)
     const int left = huff_build(t.dcount, t.dsym, t.dfast, kDistFast, cl, 19, &mx);
     if (left < 0 || (left > 0 && mx != 0)) return BLK_ERROR;   // must be complete (mx == 0: no code at all - every read below fails)
     int have = 0;
-    while (have < nlen + ndist) {
+    ZI_NOUNROLL while (have < nlen + ndist) {
       const int s = mx ? huff_decode(b, t.dcount, t.dsym, t.dfast, kDistFast) : -1;
       if (s < 0 || bits_overrun(b)) return BLK_ERROR;
-      if (s < 16) { t.lens[have++] = (uint8_t)s; continue; }
+      if (s < 16) { if (w) t.lens[have] = (uint8_t)s; have++; continue; }
       int rep, val = 0;
       if (s == 16) { if (have == 0) return BLK_ERROR; val = t.lens[have - 1]; rep = 3 + (int)bits_get(b, 2); }
       else if (s == 17) rep = 3 + (int)bits_get(b, 3);
       else rep = 11 + (int)bits_get(b, 7);
       if (have + rep > nlen + ndist) return BLK_ERROR;
-      while (rep--) t.lens[have++] = (uint8_t)val;
+      ZI_NOUNROLL while (rep--) { if (w) t.lens[have] = (uint8_t)val; have++; }
     }
     if (bits_overrun(b)) return BLK_ERROR;
     if (t.lens[256] == 0) return BLK_ERROR;
     // distance lengths to their fixed place behind the 288 literal/length slots
-    for (int s = ndist - 1; s >= 0; s--) t.lens[288 + s] = t.lens[nlen + s];
+    ZI_NOUNROLL for (int s = ndist - 1; s >= 0; s--) { const uint8_t v = t.lens[nlen + s]; if (w) t.lens[288 + s] = v; }
   }
   int mx;
   int left = huff_build(t.lcount, t.lsym, t.lfast, kLitFast, t.lens, nlen, &mx);
@@ -169,7 +201,7 @@ ZI_FN int block_begin(Bits& b, Tabs& t, int* final, uint32_t* stored_len) {
   if (left < 0 || (left > 0 && mx > 1)) return BLK_ERROR;   // mx == 0: no distance code (fine until one is needed)
   return BLK_CODED;
 }
-ZI_FN void bits_skip_bytes(Bits& b, uint32_t nbytes) {     // behind a stored block's header: the reader is byte-aligned
+template <class B> ZI_FN void bits_skip_bytes(B& b, uint32_t nbytes) {     // behind a stored block's header: the reader is byte-aligned
   const uint32_t at = bits_bytepos(b) + nbytes;
   b.pos = at; b.acc = 0; b.nacc = 0; b.used = 8u * at;
 }
@@ -182,7 +214,7 @@ ZI_FN uint32_t dist_base(int c) { return c < 4 ? 1u + (uint32_t)c : 1u + ((2u + 
 ZI_FN uint32_t dist_extra(int c) { return c < 4 ? 0u : (uint32_t)(c >> 1) - 1u; }
 
 // next literal / match / end-of-block of a coded block
-ZI_FN int next_op(Bits& b, const Tabs& t, Op& op) {
+template <class B> ZI_FN int next_op(B& b, const Tabs& t, Op& op) {
   const int s = huff_decode(b, t.lcount, t.lsym, t.lfast, kLitFast);
   if (s < 0 || bits_overrun(b)) return OP_ERROR;
   if (s < 256) { op.len = (uint32_t)s; return OP_LIT; }
@@ -199,7 +231,7 @@ ZI_FN int next_op(Bits& b, const Tabs& t, Op& op) {
 }
 
 // Adler-32 of the plain bytes follows the last block, big-endian, on a byte boundary (RFC 1950)
-ZI_FN bool read_adler(Bits& b, uint32_t* value) {
+template <class B> ZI_FN bool read_adler(B& b, uint32_t* value) {
   bits_peek(b, 8); bits_align(b);
   uint32_t v = 0;
   for (int i = 0; i < 4; i++) v = (v << 8) | bits_get(b, 8);

@@ -721,8 +721,8 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
     raw_in_place = sp.enabled != 0u;
     if (!raw_in_place) wave_copy_disjoint(out, in, (uint32_t)want, lane);
     got = want;
-  } else if (sd->fmt == FMT_ZSTD) {
-    return;               // k_zstd_streams owns the frames of Zstd chunks
+  } else if (sd->fmt == FMT_ZSTD || sd->fmt == FMT_ZLIB) {
+    return;               // k_zstd_streams / k_zlib_streams own the streams of those chunks
   } else if (sd->fmt == FMT_LZ4) {
     got = lz4_decode_wave(in, csize, out, want, scr, lane, sp PROF_PASS);
   } else {

@@ -1,0 +1,136 @@
+// k_zlib.hip — zlib streams on the GPU, decode direction (codec row "Zlib" of SURVEY §8f-3): zlib_wrap_decompress
+// (blosc/blosc.c:484-495) -> uncompress -> inflate (internal-complibs/zlib-1.3.1/inflate.c:590-1270) for every split of a
+// Zlib chunk.  One wavefront per stream, persistent waves + ticket queue, in a kernel of its own (like Zstd's):
+//   * the bit stream is serial: every lane runs the plain-C++ primitives of inflate_serial.h with the SAME values
+//     (wave-uniform; tests/test_inflate_serial_cpu.py checks exactly that code on the CPU against the reference's own zlib).
+//     The stream bytes come out of the 512-byte register window of the LZ4 / BloscLZ decoder (one coalesced load per 256
+//     bytes, fetched one slide ahead), the code tables sit in LDS (2.3 KiB per wave), written by lane 0;
+//   * bytes move wave-parallel: literals are collected one per lane and leave 64 at a time, matches go through
+//     wave_match_copy (byte-exact overlap semantics), stored blocks through wave_copy_disjoint;
+//   * the Adler-32 of the output is computed by all lanes at the end (two weighted sums, RFC 1950) and compared with the
+//     stream's - a stream the reference would reject with Z_DATA_ERROR is rejected here.
+// Chunks of this codec are never "fused": k_unshuffle / k_bitunshuffle run afterwards as kernels of their own.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "dev_types.h"
+#include "wave_prims.h"
+#include "inflate_serial.h"
+
+namespace bamd {
+
+// byte source of the bit reader: the register window (wave_prims.h: Window); positions only move forward
+struct WinSrc {
+  Window w;
+  // Called from real (non-inlined) functions too, where the compiler takes every value for divergent: the position is made
+  // an SGPR value explicitly (v_readlane needs a scalar lane index).
+  __device__ __forceinline__ uint32_t fetch32(uint32_t pos_) {
+    const uint32_t pos = uni(pos_);
+    if (pos >= uni(w.in_size)) return 0u;
+    w.base = uni(w.base);
+    w.seek(pos);
+    const uint32_t r = uni(pos - w.base), i0 = r >> 2, i1 = (i0 + 1u) & 127u;     // r < 256 after the seek
+    const uint32_t a = i0 < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)w.lo, (int)i0) : (uint32_t)__builtin_amdgcn_readlane((int)w.hi, (int)(i0 - 64u));
+    const uint32_t b = i1 < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)w.lo, (int)i1) : (uint32_t)__builtin_amdgcn_readlane((int)w.hi, (int)(i1 - 64u));
+    return (uint32_t)((((uint64_t)b << 32) | a) >> ((r & 3u) * 8u));   // bytes beyond the end of the stream read as zero (Window::fetch)
+  }
+};
+typedef zi::BitsT<WinSrc> WBits;
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+  for (int m = 32; m >= 1; m >>= 1) v += (uint32_t)__shfl_xor((int)v, m, 64);
+  return v;
+}
+// Adler-32 of p[0..n): a = 1 + sum d_i, b = n + sum (n - i) d_i (mod 65521); every lane takes 16-byte pieces
+__device__ __forceinline__ uint32_t wave_adler32(const gu8* p, uint32_t n, int lane) {
+  uint64_t s1 = 0, s2 = 0;
+  uint32_t i = 16u * (uint32_t)lane;
+  for (; i + 16u <= n; i += 1024u) {
+    const uint4 v = g_ld16(p + i);
+    const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+    uint32_t t1 = 0, t2 = 0;             // t2 = sum k * d_(i+k), k = 0..15
+#pragma unroll
+    for (int k = 0; k < 16; k++) { const uint32_t d = (wds[k >> 2] >> (8 * (k & 3))) & 0xffu; t1 += d; t2 += (uint32_t)k * d; }
+    s1 += t1; s2 += (uint64_t)(n - i) * t1 - t2;
+  }
+  // the last n % 16 bytes: one byte per lane
+  const uint32_t tail0 = n & ~15u;
+  if (tail0 + (uint32_t)lane < n) { const uint32_t d = p[tail0 + (uint32_t)lane]; s1 += d; s2 += (uint64_t)(n - tail0 - (uint32_t)lane) * d; }
+  const uint32_t a = (1u + wave_sum_u32((uint32_t)(s1 % 65521u)) % 65521u) % 65521u;
+  const uint32_t b = (n % 65521u + wave_sum_u32((uint32_t)(s2 % 65521u)) % 65521u) % 65521u;
+  return (b << 16) | a;
+}
+
+// one stream -> out[0..cap); returns bytes produced, 0 on any error (zlib_wrap_decompress's contract)
+__device__ __forceinline__ int zlib_decode_wave(const uint8_t* in_, int n_, uint8_t* out_, int cap_, zi::Tabs& T, int lane) {
+  if (n_ <= 0) return 0;
+  const uint32_t n = (uint32_t)n_, cap = (uint32_t)cap_;
+  gu8* out = uni_ptr(as_global(out_));
+  const gu8* in = uni_ptr(as_global(in_));
+  WBits b;
+  b.s.w.init(in, n, lane);
+  zi::bits_start(b, n);
+  if (!zi::zlib_header(b)) return 0;
+  uint32_t op = 0;
+  uint32_t litreg = 0, nl = 0;            // pending literals: lane i holds the i-th
+  for (;;) {
+    int final = 0; uint32_t slen = 0;
+    const int kind = zi::block_begin(b, T, &final, &slen);
+    if (kind == zi::BLK_ERROR) return 0;
+    if (kind == zi::BLK_STORED) {
+      if ((uint64_t)op + slen > (uint64_t)cap) return 0;
+      wave_copy_disjoint(out + op, in + zi::bits_bytepos(b), slen, lane);
+      op += slen;
+      zi::bits_skip_bytes(b, slen);
+    } else {
+      for (;;) {
+        zi::Op o;
+        const int k = zi::next_op(b, T, o);
+        if (k == zi::OP_ERROR) return 0;
+        if (k == zi::OP_LIT) {
+          if (op + nl >= cap) return 0;
+          litreg = (uint32_t)lane == nl ? o.len : litreg;
+          if (++nl < 64u) continue;
+        }
+        if (nl) { if ((uint32_t)lane < nl) out[op + (uint32_t)lane] = (uint8_t)litreg; op += nl; nl = 0; }
+        if (k == zi::OP_EOB) break;
+        if (k == zi::OP_MATCH) {
+          if (o.dist > op || (uint64_t)op + o.len > (uint64_t)cap) return 0;
+          wave_match_copy(out, op, o.dist, o.len, lane);
+          op += o.len;
+        }
+      }
+    }
+    if (final) break;
+  }
+  uint32_t want = 0;
+  if (!zi::read_adler(b, &want)) return 0;
+  if (want != wave_adler32(out, op, lane)) return 0;
+  return (int)op;
+}
+
+// Persistent waves over ALL streams of the launch; only the non-raw streams of Zlib chunks are taken here
+// (k_decode_streams copies the raw ones and leaves these alone).
+constexpr int ZLIB_WAVES_PER_CU = 16;
+__global__ __launch_bounds__(64, 4) void k_zlib_streams(StreamDesc* __restrict__ streams, int nstreams, int32_t* __restrict__ status,
+                                                     uint32_t* __restrict__ ticket, uint32_t* __restrict__ done) {
+  __shared__ zi::Tabs tabs;
+  const int lane = threadIdx.x & 63;
+  uint32_t sid = take_ticket(ticket, lane);
+  uint32_t ndone = 0;
+  while (sid < (uint32_t)nstreams) {
+    StreamDesc* sd = streams + sid;
+    const int32_t csize = (int32_t)uni((uint32_t)sd->in_size), want = (int32_t)uni((uint32_t)sd->out_size);
+    if (uni((uint32_t)sd->fmt) == (uint32_t)FMT_ZLIB && csize >= 0 && csize != want) {
+      const int got = zlib_decode_wave(sd->in, csize, sd->out, want, tabs, lane);
+      if (lane == 0) {
+        sd->result = got;
+        if (got != want) atomicMin(&status[sd->chunk], (int32_t)ST_BADCODEC);   // blosc.c:780-782
+      }
+    }
+    ndone++;
+    sid = take_ticket(ticket, lane);
+  }
+  if (lane == 0 && ndone) atomicAdd(done, ndone);
+}
+
+}  // namespace bamd

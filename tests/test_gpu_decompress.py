@@ -17,10 +17,10 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 @pytest.mark.parametrize("fname", sorted(os.path.basename(f) for f in glob.glob(os.path.join(GOLDEN, "compat", "*.cdata"))))
 def test_compat_golden_vectors(pkg, fname):
     """compat/*.cdata (blosc 1.3.0 ... 1.18.0 writers): BloscLZ / LZ4 / LZ4HC decode to arange(1e6, int32);
-    Zstd too (k_zstd.hip); Snappy / Zlib give -5 (not built in), as stock does for Snappy (compat/filegen.c:97-103)."""
+    Zstd (k_zstd.hip) and Zlib (k_zlib.hip) too; Snappy gives -5 (not built in), as stock does (compat/filegen.c:97-103)."""
     chunk = np.fromfile(os.path.join(GOLDEN, "compat", fname), np.uint8)
     r, out = pkg.decompress(chunk, 4000000)
-    if any(k in fname for k in ("snappy", "zlib")):
+    if "snappy" in fname:
         assert r == -5
     else:
         assert r == 4000000
@@ -86,7 +86,8 @@ def test_error_returns_match_oracle(pkg, oracle, lib):
     c = good.copy(); c[0] = 3; cases.append(("version", c))
     c = good.copy(); c[1] = 2; cases.append(("versionlz", c))
     c = good.copy(); c[2] |= 0x08; cases.append(("reserved flag", c))
-    c = good.copy(); c[2] = (c[2] & 0x1f) | (3 << 5); cases.append(("zlib format", c))
+    c = good.copy(); c[2] = (c[2] & 0x1f) | (2 << 5); cases.append(("snappy format", c))
+    c = good.copy(); c[2] = (c[2] & 0x1f) | (3 << 5); cases.append(("zlib format over LZ4 streams", c))
     c = good.copy(); c[8:12] = 0; cases.append(("blocksize 0", c))
     c = good.copy(); c[12:16] = np.array([20], "<i4").view(np.uint8); cases.append(("cbytes too small", c))
     c = good.copy(); c[16:20] = np.array([10**9], "<i4").view(np.uint8); cases.append(("bstart oob", c))

@@ -15,8 +15,8 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 def test_compat_vectors(oracle, fname):
     chunk = np.fromfile(os.path.join(GOLDEN, "compat", fname), np.uint8)
     r, out = orc_decompress(oracle, chunk, 4000000)
-    if any(k in fname for k in ("snappy", "zlib")):
-        assert r == -5          # codecs outside this build's scope: same code a stock build without them gives
+    if "snappy" in fname:
+        assert r == -5          # codec outside this build's scope: same code a stock build without it gives
     else:
         assert r == 4000000 and np.array_equal(out.view("<i4"), np.arange(10**6, dtype="<i4"))
 
