@@ -8,6 +8,7 @@ scaled to the MI355X configurations of BASELINE.json / SURVEY.md §8d:
     --config 3   bitshuffle + LZ4    clevel 5, typesize 4, bench19   (3b: arange, 3c: small random ints)
     --config 4   byte-shuffle + Zstd clevel 3, typesize 8, bench19   (4b/4c/4d: the other float64 sets)
     --config 1g  byte-shuffle + BloscLZ clevel 5, typesize 8, bench19 (config #1's call, on the GPU)
+    --config z   byte-shuffle + Zlib clevel 5, typesize 8, bench19   (the remaining codec; zb: linspace)
 
 every one as 128 chunks x 64 MiB = 8 GiB per GPU (512 chunks = 32 GiB per GPU when N > 1: config #5).
 
@@ -39,8 +40,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (6.29 TB/s measured copy)
-COMPRESS_KERNELS = ["k_shuffle", "k_bitshuffle", "k_encode_streams", "k_zstd_encode", "k_chunk_scan", "k_chunk_compact"]
-DECOMPRESS_KERNELS = ["k_decode_plan", "k_classify_blocks", "k_decode_streams", "k_decode_blocks", "k_decode_blocks8", "k_zstd_entropy", "k_zstd_exec", "k_zstd_streams", "k_unshuffle",
+COMPRESS_KERNELS = ["k_shuffle", "k_bitshuffle", "k_encode_streams", "k_zstd_encode", "k_zlib_encode", "k_chunk_scan", "k_chunk_compact"]
+DECOMPRESS_KERNELS = ["k_decode_plan", "k_classify_blocks", "k_decode_streams", "k_decode_blocks", "k_decode_blocks8", "k_zstd_entropy", "k_zstd_exec", "k_zstd_streams", "k_zlib_streams", "k_unshuffle",
                       "k_bitunshuffle", "k_copy_chunks"]
 KERNELS = COMPRESS_KERNELS + DECOMPRESS_KERNELS
 REFSO = os.path.join(ROOT, "oracle", "_ref", "libblosc_ref.so")
@@ -59,6 +60,8 @@ CONFIGS = {
     "4c": dict(codec="zstd", shuffle=1, typesize=8, clevel=3, data="randwalk"),
     "4d": dict(codec="zstd", shuffle=1, typesize=8, clevel=3, data="random"),
     "1g": dict(codec="blosclz", shuffle=1, typesize=8, clevel=5, data="bench19"),
+    "z":  dict(codec="zlib", shuffle=1, typesize=8, clevel=5, data="bench19"),
+    "zb": dict(codec="zlib", shuffle=1, typesize=8, clevel=5, data="linspace"),
 }
 FILTER_NAME = {0: "no filter", 1: "byte-shuffle", 2: "bitshuffle"}
 

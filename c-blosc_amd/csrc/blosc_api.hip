@@ -27,7 +27,7 @@ static int g_splitmode = BLOSC_FORWARD_COMPAT_SPLIT;
 
 static const char* const kNames[6] = {BLOSC_BLOSCLZ_COMPNAME, BLOSC_LZ4_COMPNAME, BLOSC_LZ4HC_COMPNAME,
                                       BLOSC_SNAPPY_COMPNAME, BLOSC_ZLIB_COMPNAME, BLOSC_ZSTD_COMPNAME};
-static bool codec_built(int code) { return code == BLOSC_BLOSCLZ || code == BLOSC_LZ4 || code == BLOSC_LZ4HC || code == BLOSC_ZSTD; }
+static bool codec_built(int code) { return code == BLOSC_BLOSCLZ || code == BLOSC_LZ4 || code == BLOSC_LZ4HC || code == BLOSC_ZLIB || code == BLOSC_ZSTD; }
 
 extern "C" {
 
@@ -80,7 +80,7 @@ int blosc_set_compressor(const char* compname) {                        // blosc
   return code;
 }
 
-const char* blosc_list_compressors(void) { return "blosclz,lz4,lz4hc,zstd"; }
+const char* blosc_list_compressors(void) { return "blosclz,lz4,lz4hc,zlib,zstd"; }
 
 const char* blosc_get_version_string(void) { return BLOSC_VERSION_STRING; }
 
@@ -93,7 +93,8 @@ int blosc_get_complib_info(const char* compname, char** complib, char** version)
     clib = BLOSC_LZ4_LIB; libname = BLOSC_LZ4_LIBNAME; ver = "1.10.0";   // block format implemented, lz4.h:LZ4_VERSION_*
   }
   else if (strcmp(compname, BLOSC_ZSTD_COMPNAME) == 0) { clib = BLOSC_ZSTD_LIB; libname = BLOSC_ZSTD_LIBNAME; ver = "1.5.6"; }   // frame format written / read, zstd.h:ZSTD_VERSION_*
-  if (clib < 0) {   // Snappy / Zlib are not built in: same answer as a stock build without them
+  else if (strcmp(compname, BLOSC_ZLIB_COMPNAME) == 0) { clib = BLOSC_ZLIB_LIB; libname = BLOSC_ZLIB_LIBNAME; ver = "1.3.1"; }   // stream format written / read, zlib.h:ZLIB_VERSION
+  if (clib < 0) {   // Snappy is not built in: same answer as a stock build without it
     if (complib) *complib = NULL;
     if (version) *version = NULL;
     return -1;

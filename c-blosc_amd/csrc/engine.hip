@@ -259,7 +259,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
     if (typesize == 0) { results[i] = -10; continue; }
     if (typesize > (size_t)kMaxTypeSize) typesize = 1;
     const int codec = p.codec;
-    if (codec != kBloscLZ && codec != kLZ4 && codec != kLZ4HC && codec != kZstd) { results[i] = -5; continue; }  // blosc.c:1197-1207
+    if (codec != kBloscLZ && codec != kLZ4 && codec != kLZ4HC && codec != kZlib && codec != kZstd) { results[i] = -5; continue; }  // blosc.c:1197-1207 (Snappy: not built)
     const int32_t T = (int32_t)typesize, nb = (int32_t)nbytes;
     const int32_t bs = compute_blocksize(p.clevel, T, nb, p.forced_blocksize, codec, p.splitmode);
     int32_t nblocks = nb / bs;
@@ -335,7 +335,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   const size_t o_filt = cv.take(filt_bytes + 256);
   const size_t o_stage = cv.take(stage_bytes + 256);
   // Zstd: the predefined FSE tables and one sequence scratch per persistent wave
-  const bool zstd = p.codec == kZstd;
+  const bool zstd = p.codec == kZstd, zlibc = p.codec == kZlib;
   static const int enc_wpc = getenv("BLOSC_AMD_ENC_WPC") ? atoi(getenv("BLOSC_AMD_ENC_WPC")) : ENC_WAVES_PER_CU;
   const size_t zwaves = zstd ? (size_t)(st.cus > 0 ? st.cus : 256) * (size_t)enc_wpc : 0;
   const size_t o_ctabs = cv.take(sizeof(zenc::CTabs) + 64);
@@ -421,15 +421,16 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
     hipLaunchKernelGGL(k_bitshuffle, dim3((unsigned)nblk, (unsigned)tiles_bit), dim3(FT_THREADS), 0, stream, d_chunks, d_blocks, bitfast ? 1 : 0);
   }
   if (nstr) {
-    ProfScope ps(st, stream, zstd ? "k_zstd_encode" : "k_encode_streams");
+    ProfScope ps(st, stream, zstd ? "k_zstd_encode" : (zlibc ? "k_zlib_encode" : "k_encode_streams"));
     const int32_t* d_qoff = (const int32_t*)(D + o_queues); const int32_t* d_qlist = d_qoff + 9;
     uint32_t* d_ready = (uint32_t*)(D + o_ready);
     const size_t ntasks = queues.size() - 9;
 #ifdef BAMD_PROFILE_DECODE
     uint32_t* d_prof = nullptr;
     if (getenv("BLOSC_AMD_ENC_PROFILE")) { (void)hipMalloc((void**)&d_prof, nstr * 64); (void)hipMemsetAsync(d_prof, 0, nstr * 64, stream); }
-    if (zstd) hipLaunchKernelGGL(k_encode_streams_t<true>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)(D + o_seqbufs), (const zenc::CTabs*)(D + o_ctabs), 0, d_prof);
-    else hipLaunchKernelGGL(k_encode_streams_t<false>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)nullptr, (const zenc::CTabs*)nullptr, periodic_enabled() ? 1 : 0, d_prof);
+    if (zstd) hipLaunchKernelGGL(k_encode_streams_t<ENC_ZSTD>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)(D + o_seqbufs), (const zenc::CTabs*)(D + o_ctabs), 0, d_prof);
+    else if (zlibc) hipLaunchKernelGGL(k_encode_streams_t<ENC_ZLIB>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)nullptr, (const zenc::CTabs*)nullptr, 0, d_prof);
+    else hipLaunchKernelGGL(k_encode_streams_t<ENC_LZ>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)nullptr, (const zenc::CTabs*)nullptr, periodic_enabled() ? 1 : 0, d_prof);
     if (d_prof) {
       std::vector<uint32_t> h(nstr * 16);
       (void)hipStreamSynchronize(stream);
@@ -439,8 +440,9 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
       (void)hipFree(d_prof);
     }
 #else
-    if (zstd) hipLaunchKernelGGL(k_encode_streams_t<true>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)(D + o_seqbufs), (const zenc::CTabs*)(D + o_ctabs), 0);
-    else hipLaunchKernelGGL(k_encode_streams_t<false>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)nullptr, (const zenc::CTabs*)nullptr, periodic_enabled() ? 1 : 0);
+    if (zstd) hipLaunchKernelGGL(k_encode_streams_t<ENC_ZSTD>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)(D + o_seqbufs), (const zenc::CTabs*)(D + o_ctabs), 0);
+    else if (zlibc) hipLaunchKernelGGL(k_encode_streams_t<ENC_ZLIB>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)nullptr, (const zenc::CTabs*)nullptr, 0);
+    else hipLaunchKernelGGL(k_encode_streams_t<ENC_LZ>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)nullptr, (const zenc::CTabs*)nullptr, periodic_enabled() ? 1 : 0);
 #endif
   }
   {

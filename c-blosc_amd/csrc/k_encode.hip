@@ -23,6 +23,7 @@
 #include "dev_types.h"
 #include "wave_prims.h"
 #include "zstd_enc.h"
+#include "deflate_enc.h"
 
 namespace bamd {
 
@@ -162,7 +163,7 @@ __device__ __forceinline__ uint32_t emit_ext255(gu8* p, uint32_t v, int lane) {
   return n255 + 1u;
 }
 
-enum { EF_LZ4 = 0, EF_BLOSCLZ = 1, EF_ZSTD = 2 };
+enum { EF_LZ4 = 0, EF_BLOSCLZ = 1, EF_ZSTD = 2, EF_ZLIB = 3 };
 #ifndef BAMD_ZSTD_MINLEN
 #define BAMD_ZSTD_MINLEN 4     // shortest match the Zstd path takes (5 and 6: bench19 ratio and time in DESIGN.md 3.6)
 #endif
@@ -177,6 +178,58 @@ struct ZsSink {
   uint32_t nseq, seqcap;
 };
 __device__ __forceinline__ uint32_t zs_emit_seq(ZsSink& z, const gu8* lit, uint32_t ll, uint32_t off, uint32_t mlen, int lit_lane0, uint32_t ownbyte, int lane);
+
+// Where the findings go when the target is a zlib stream (deflate_enc.h): straight into the bit stream.  One lane packs one
+// symbol (a literal: 8 / 9 bits, a match piece: <= 31 bits); dfl_put_symbols places the symbols of all 64 lanes with a prefix
+// sum over their bit counts, ORs them into a 65-dword LDS strip behind the pending bits and stores the full dwords.
+struct DflSink {
+  gu8* out; uint32_t cap;         // the stream being written and its capacity
+  uint32_t pos;                   // bytes written so far
+  uint32_t acc, nb;               // pending bits (< 32), wave-uniform
+  volatile BAMD_LAS uint32_t* zb; // 65 dwords of this wave
+};
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)v, d, 64); if (lane >= d) v += t; }
+  return v;
+}
+__device__ __forceinline__ bool dfl_put_symbols(DflSink& z, uint32_t bits, uint32_t nbits, int lane) {
+  const uint32_t incl = wave_incl_scan_u32(nbits, lane);
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  z.zb[lane] = lane == 0 ? z.acc : 0u;
+  if (lane == 0) z.zb[64] = 0u;
+  if (nbits) {
+    const uint32_t start = z.nb + incl - nbits, w = start >> 5, sh = start & 31u;
+    __hip_atomic_fetch_or((BAMD_LAS uint32_t*)z.zb + w, bits << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (sh + nbits > 32u) __hip_atomic_fetch_or((BAMD_LAS uint32_t*)z.zb + w + 1u, bits >> (32u - sh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  }
+  const uint32_t fill = z.nb + total, ndw = fill >> 5;                  // <= 63 full dwords
+  if (z.pos + 4u * ndw + 16u > z.cap) return false;
+  const uint32_t mine = z.zb[lane], rest = z.zb[ndw];
+  if ((uint32_t)lane < ndw) g_st4(z.out + z.pos + 4u * (uint32_t)lane, mine);
+  z.acc = uni(rest); z.nb = fill & 31u; z.pos += 4u * ndw;
+  return true;
+}
+// `ll` literal bytes (from registers when the run lies inside this step, see emit_literals) and, when mlen != 0, one match
+__device__ __forceinline__ uint32_t dfl_emit_seq(DflSink& z, const gu8* lit, uint32_t ll, uint32_t dist, uint32_t mlen, int lit_lane0, uint32_t ownbyte, int lane) {
+  const bool in_regs = lit_lane0 >= 0 && ll <= 64u && (uint32_t)lit_lane0 + ll <= 64u;
+  const uint32_t np = mlen ? dfl::npieces(mlen) : 0u;
+  uint32_t ldone = 0, pdone = 0;
+  do {
+    // literals first, match pieces behind them in the same step when they fit
+    const uint32_t lcnt = ll - ldone < 64u ? ll - ldone : 64u;
+    uint32_t pcnt = 0;
+    if (ldone + lcnt == ll) { pcnt = np - pdone < 64u - lcnt ? np - pdone : 64u - lcnt; }
+    // the register gather runs in ALL lanes (a lane that sits out a ds_bpermute cannot be read by the others)
+    const uint32_t vreg = in_regs ? (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lit_lane0 + (uint32_t)lane) & 63u) << 2, (int)ownbyte) & 0xffu : 0u;
+    dfl::Sym s = {0u, 0u};
+    if ((uint32_t)lane < lcnt) s = dfl::literal(in_regs ? vreg : (uint32_t)lit[ldone + (uint32_t)lane]);
+    else if ((uint32_t)lane < lcnt + pcnt) s = dfl::match(dfl::piece_len(mlen, pdone + (uint32_t)lane - lcnt, np), dist);
+    if (!dfl_put_symbols(z, s.bits, s.nbits, lane)) return 0xffffffffu;
+    ldone += lcnt; pdone += pcnt;
+  } while (ldone < ll || pdone < np);
+  return 0u;
+}
 
 // ---- emitters --------------------------------------------------------------------------------
 // LZ4 sequence (lz4.c:1111-1226): token | litlen ext | literals | offset LE16 | matchlen ext.
@@ -362,14 +415,14 @@ struct EncWindow {
 // which sequences were emitted (the caller appends the literals behind it) or 0xffffffff when the sink is full.
 template <int FMT>
 __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8* __restrict__ dst, uint32_t cap,
-                                   int clevel, enc_entry_t* tab_generic, int lane EPROF_ARG, uint32_t start = 0, ZsSink* zs = nullptr) {
+                                   int clevel, enc_entry_t* tab_generic, int lane EPROF_ARG, uint32_t start = 0, ZsSink* zs = nullptr, DflSink* df = nullptr) {
   // the table lives in LDS; say so explicitly (a generic pointer in a non-inlined function would make
   // every probe a flat_load)
   EncTable tab;
   tab.init((void*)tab_generic);
   // stream-end rules.  LZ4: last match starts <= n-12, ends <= n-5 (lz4.c:245-246, :963-964).
   // BloscLZ: matches start < n-12 (blosclz.c:465), stream must end with >= 1 literal (blosclz.c:708-710).
-  if (FMT == EF_ZSTD) { if (n < start + 16u) return start; }
+  if (FMT == EF_ZSTD || FMT == EF_ZLIB) { if (n < start + 16u) return start; }
   else if (FMT == EF_LZ4 ? (n < 13u) : (n < 16u || cap < 66u)) return 0u;
   const uint32_t last_start = n - 12u;                       // inclusive bound on match starts
   const uint32_t mlimit = (FMT == EF_LZ4) ? n - 5u : n - 2u;  // matches end at or before this position
@@ -436,7 +489,7 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
       mine = enc_entry(mix, p);
       const uint32_t e = tab.get(h);
       const uint32_t d = (p - e) & 0xffffu;
-      if (d != 0u && d <= p && EncTable::tag_equal(e, mine)) { cand = p - d; tab_ok = true; }
+      if (d != 0u && d <= p && EncTable::tag_equal(e, mine) && (FMT != EF_ZLIB || d <= dfl::kMaxDist)) { cand = p - d; tab_ok = true; }
     } else {
       prev = 0x100u;
     }
@@ -495,6 +548,8 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
         if (op == 0xffffffffu) return 0u;
       } else if (FMT == EF_ZSTD) {
         if (zs_emit_seq(*zs, src + anchor, ll, dist, mlen, anchor >= ip ? (int)(anchor - ip) : -1, (uint32_t)own.a & 0xffu, lane) == 0xffffffffu) return 0xffffffffu;
+      } else if (FMT == EF_ZLIB) {
+        if (dfl_emit_seq(*df, src + anchor, ll, dist, mlen, anchor >= ip ? (int)(anchor - ip) : -1, (uint32_t)own.a & 0xffu, lane) == 0xffffffffu) return 0xffffffffu;
       } else {
         op = blz_emit_literals(dst, op, cap, src + anchor, ll, lane);
         if (op == 0xffffffffu) return 0u;
@@ -527,7 +582,7 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
     }
   }
   // closing literals
-  if (FMT == EF_ZSTD) return anchor;
+  if (FMT == EF_ZSTD || FMT == EF_ZLIB) return anchor;
   if (FMT == EF_LZ4) {
     op = lz4_emit_tail(dst, op, cap, src + anchor, n - anchor, lane);
     if (op == 0xffffffffu) return 0u;
@@ -707,6 +762,38 @@ __device__ uint32_t zstd_encode_wave(const gu8* __restrict__ src, uint32_t n, gu
 }
 
 // ---------------------------------------------------------------------------------------------
+// zlib streams (deflate_enc.h has the format).  One stream per blosc stream: header, ONE final block with the fixed
+// Huffman codes whose symbols the match finder above emits as it goes (dfl_emit_seq), end-of-block, Adler-32.
+// Returns the stream size, or 0 when it would not be smaller than the input (blosc then stores the split raw).
+// ---------------------------------------------------------------------------------------------
+constexpr int DFL_LDS_BYTES = 65 * 4 + 12;     // the 65-dword strip of dfl_put_symbols, rounded to 16 bytes
+__device__ uint32_t zlib_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8* __restrict__ dst, uint32_t cap, int clevel,
+                                     enc_entry_t* tab_generic, int lane EPROF_ARG) {
+  if (n < 16u || cap < 64u) return 0u;
+  DflSink z;
+  z.out = dst; z.cap = cap; z.pos = dfl::kHeader;
+  z.zb = (volatile BAMD_LAS uint32_t*)((BAMD_LAS uint8_t*)(void*)tab_generic + ENC_TAB_BYTES);
+  if (lane == 0) { uint8_t h[2]; dfl::write_header(h); dst[0] = h[0]; dst[1] = h[1]; }
+  const dfl::Sym bh = dfl::block_header();
+  z.acc = bh.bits; z.nb = bh.nbits;
+  const uint32_t covered = lz_encode_wave<EF_ZLIB>(src, n, dst, cap, clevel, tab_generic, lane EPROF_PASS, 0u, nullptr, &z);
+  if (covered == 0xffffffffu) return 0u;
+  // the literals behind the last match, then the end-of-block symbol.  A literal costs at least 8 bits: when what is left
+  // cannot fit below n any more (incompressible planes end here with everything still pending), skip the packing
+  if (z.pos + (n - covered) + 8u >= n) return 0u;
+  if (dfl_emit_seq(z, src + covered, n - covered, 0u, 0u, -1, 0u, lane) == 0xffffffffu) return 0u;
+  const dfl::Sym eob = dfl::end_of_block();
+  if (!dfl_put_symbols(z, lane == 0 ? eob.bits : 0u, lane == 0 ? eob.nbits : 0u, lane)) return 0u;
+  const uint32_t tailbytes = (z.nb + 7u) >> 3;                   // <= 4, zero padding up to the byte boundary
+  if ((uint32_t)lane < tailbytes) dst[z.pos + (uint32_t)lane] = (uint8_t)(z.acc >> (8u * (uint32_t)lane));
+  z.pos += tailbytes;
+  const uint32_t ad = wave_adler32(src, n, lane);
+  if (lane < 4) dst[z.pos + (uint32_t)lane] = (uint8_t)(ad >> (24u - 8u * (uint32_t)lane));
+  z.pos += dfl::kTrailer;
+  return z.pos < n ? z.pos : 0u;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Fused byte shuffle of one block by ONE wavefront (typesize 4 or 8): element-major source -> plane-major
 // scratch (blosc/shuffle-generic.h:27-58).  The mirror image of unshuffle_block_wave in k_decode.hip: per
 // step lane l loads the T*4 contiguous bytes of elements e+4l..e+4l+3 (coalesced 16-byte loads), transposes
@@ -878,6 +965,9 @@ __device__ __forceinline__ uint32_t emit_periodic_stream(const gu8* in, uint32_t
 }
 
 // one stream, not inlined into the queue loop (see decode_one_stream in k_decode.hip for why)
+// MODE: 0 = LZ4 / BloscLZ, 1 = Zstd, 2 = Zlib - a batch has ONE codec, so every kernel carries only its own code path
+enum { ENC_LZ = 0, ENC_ZSTD = 1, ENC_ZLIB = 2 };
+template <int MODE>
 __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, enc_entry_t* tab, const ChunkDesc* chunks, uint32_t* blk_ready, int lane,
                                                             const BlockDesc* blocks, uint32_t sid, uint32_t* plane_cost, uint64_t* seqbuf
 #ifdef BAMD_PROFILE_DECODE
@@ -901,9 +991,10 @@ __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, enc_
   const uint64_t cost_t0 = __builtin_amdgcn_s_memtime();
   uint32_t r;
   const int32_t hint = (int32_t)uni((uint32_t)sd->result);      // < 0: the shuffle task found this plane periodic (period -hint)
-  if (hint < 0) r = emit_periodic_stream(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, (uint32_t)-hint, uni((uint32_t)sd->fmt) == (uint32_t)FMT_LZ4, lane);
+  if (MODE == ENC_ZSTD) r = seqbuf ? zstd_encode_wave(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, (BAMD_GAS uint64_t*)seqbuf, lane EPROF_PASS) : 0u;
+  else if (MODE == ENC_ZLIB) r = zlib_encode_wave(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, lane EPROF_PASS);
+  else if (hint < 0) r = emit_periodic_stream(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, (uint32_t)-hint, uni((uint32_t)sd->fmt) == (uint32_t)FMT_LZ4, lane);
   else if (sd->fmt == FMT_LZ4) r = lz_encode_wave<EF_LZ4>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, lane EPROF_PASS);
-  else if (sd->fmt == FMT_ZSTD) r = seqbuf ? zstd_encode_wave(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, (BAMD_GAS uint64_t*)seqbuf, lane EPROF_PASS) : 0u;
   else r = lz_encode_wave<EF_BLOSCLZ>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, lane EPROF_PASS);
   if (lane == 0) sd->result = (int32_t)r;
   // cost feedback for the host's queue order (queue_order.h: build_encode_queues): cycles per plane index
@@ -922,7 +1013,7 @@ __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, enc_
 // host puts every block's shuffle task a few dozen entries ahead of its streams (queue_order.h:
 // build_encode_queues), so the bandwidth-bound transposes run underneath the latency/issue-bound match
 // finding of other waves instead of in a kernel of their own.
-template <bool ZSTD>
+template <int MODE>
 __global__ __launch_bounds__(64 * ENC_WAVES, BAMD_ENC_MINWAVES) void k_encode_streams_t(
     StreamDesc* __restrict__ streams, uint32_t* __restrict__ tickets /*[8]*/, const int32_t* __restrict__ qlist,
     const int32_t* __restrict__ qoff /*[9]*/, const ChunkDesc* __restrict__ chunks, const BlockDesc* __restrict__ blocks,
@@ -932,7 +1023,8 @@ __global__ __launch_bounds__(64 * ENC_WAVES, BAMD_ENC_MINWAVES) void k_encode_st
     , uint32_t* __restrict__ profbuf
 #endif
     ) {
-  __shared__ enc_entry_t tabs[ENC_WAVES][(ENC_TAB_BYTES + (ZSTD ? ZS_LDS_BYTES : 0)) / 4];
+  constexpr bool ZSTD = MODE == ENC_ZSTD;
+  __shared__ enc_entry_t tabs[ENC_WAVES][(ENC_TAB_BYTES + (ZSTD ? ZS_LDS_BYTES : (MODE == ENC_ZLIB ? DFL_LDS_BYTES : 0))) / 4];
   static_assert(ENC_WAVES == 1, "one stream per wave, one wave per workgroup");
   const int lane = threadIdx.x & 63;
   uint64_t* seqbuf = nullptr;
@@ -952,9 +1044,9 @@ __global__ __launch_bounds__(64 * ENC_WAVES, BAMD_ENC_MINWAVES) void k_encode_st
       shuffle_block_task(chunks, blocks, (uint32_t)(-(task + 1)), blk_ready, streams, detect_periodic, lane);
     } else {
 #ifdef BAMD_PROFILE_DECODE
-      encode_one_stream(streams + task, tabs[0], chunks, blk_ready, lane, blocks, (uint32_t)task, plane_cost, seqbuf, profbuf ? profbuf + (size_t)task * 16 : nullptr);
+      encode_one_stream<MODE>(streams + task, tabs[0], chunks, blk_ready, lane, blocks, (uint32_t)task, plane_cost, seqbuf, profbuf ? profbuf + (size_t)task * 16 : nullptr);
 #else
-      encode_one_stream(streams + task, tabs[0], chunks, blk_ready, lane, blocks, (uint32_t)task, plane_cost, seqbuf);
+      encode_one_stream<MODE>(streams + task, tabs[0], chunks, blk_ready, lane, blocks, (uint32_t)task, plane_cost, seqbuf);
 #endif
     }
     ndone++;

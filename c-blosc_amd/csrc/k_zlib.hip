@@ -36,30 +36,6 @@ struct WinSrc {
 };
 typedef zi::BitsT<WinSrc> WBits;
 
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-  for (int m = 32; m >= 1; m >>= 1) v += (uint32_t)__shfl_xor((int)v, m, 64);
-  return v;
-}
-// Adler-32 of p[0..n): a = 1 + sum d_i, b = n + sum (n - i) d_i (mod 65521); every lane takes 16-byte pieces
-__device__ __forceinline__ uint32_t wave_adler32(const gu8* p, uint32_t n, int lane) {
-  uint64_t s1 = 0, s2 = 0;
-  uint32_t i = 16u * (uint32_t)lane;
-  for (; i + 16u <= n; i += 1024u) {
-    const uint4 v = g_ld16(p + i);
-    const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
-    uint32_t t1 = 0, t2 = 0;             // t2 = sum k * d_(i+k), k = 0..15
-#pragma unroll
-    for (int k = 0; k < 16; k++) { const uint32_t d = (wds[k >> 2] >> (8 * (k & 3))) & 0xffu; t1 += d; t2 += (uint32_t)k * d; }
-    s1 += t1; s2 += (uint64_t)(n - i) * t1 - t2;
-  }
-  // the last n % 16 bytes: one byte per lane
-  const uint32_t tail0 = n & ~15u;
-  if (tail0 + (uint32_t)lane < n) { const uint32_t d = p[tail0 + (uint32_t)lane]; s1 += d; s2 += (uint64_t)(n - tail0 - (uint32_t)lane) * d; }
-  const uint32_t a = (1u + wave_sum_u32((uint32_t)(s1 % 65521u)) % 65521u) % 65521u;
-  const uint32_t b = (n % 65521u + wave_sum_u32((uint32_t)(s2 % 65521u)) % 65521u) % 65521u;
-  return (b << 16) | a;
-}
-
 // one stream -> out[0..cap); returns bytes produced, 0 on any error (zlib_wrap_decompress's contract)
 __device__ __forceinline__ int zlib_decode_wave(const uint8_t* in_, int n_, uint8_t* out_, int cap_, zi::Tabs& T, int lane) {
   if (n_ <= 0) return 0;

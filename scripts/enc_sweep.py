@@ -22,7 +22,7 @@ for dname in os.environ.get("DATA", "bench19,linspace,randwalk,random,zeros").sp
         for _ in range(2): bc.compress(8, CL, 1, codec.encode(), 0)
         lib.blosc_gpu_profile(0)
         cb = bc.results()
-        e = mod.profile_get("k_zstd_encode" if codec == "zstd" else "k_encode_streams"); s = mod.profile_get("k_shuffle")
+        e = mod.profile_get("k_zstd_encode" if codec == "zstd" else ("k_zlib_encode" if codec == "zlib" else "k_encode_streams")); s = mod.profile_get("k_shuffle")
         bd = mod.DeviceBatch([comp[i].data_ptr() for i in range(nchunks)], cb, [back[i].data_ptr() for i in range(nchunks)], [csz] * nchunks)
         bd.decompress()
         ok = bool((back == src).all())

@@ -1,0 +1,85 @@
+"""CPU: the format-writing half of the GPU Zlib encoder (c-blosc_amd/csrc/deflate_enc.h: zlib header, fixed Huffman code
+words, length / distance symbols with their extra bits, long matches cut into pieces) compiled with g++ behind a plain
+greedy matcher (tests/tools/deflate_enc_cpu.cpp).  Every stream must be read back bit-exactly by the oracle's inflate and -
+where oracle/_ref ships - by the reference's own `uncompress`; python's zlib (the same format, a third reader) too."""
+import ctypes as C
+import os
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+from helpers import DATASETS, ptr
+from test_oracle_zlib import _un, _zo, ref_uncompress
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def enc():
+    so = os.path.join(ROOT, "tests", "tools", "libdeflate_enc_cpu.so")
+    src = os.path.join(ROOT, "tests", "tools", "deflate_enc_cpu.cpp")
+    hdr = os.path.join(ROOT, "c-blosc_amd", "csrc", "deflate_enc.h")
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-o", so, src])
+    E = C.CDLL(so)
+    E.dfl_cpu_compress.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    return E
+
+
+def test_streams_decode_with_oracle_reference_and_python(enc, oracle, ref):
+    zo = _zo(oracle); ru = ref_uncompress(ref) if ref is not None else None
+    cases = 0
+    for dname in ["bench19", "linspace", "randwalk", "smallints", "zeros", "random"]:
+        for n in [1, 5, 100, 1000, 4096, 65536, 131072, 300001, 1 << 20]:
+            data = DATASETS[dname](n)
+            if dname != "random" and n >= 4096 and n % 8 == 0:
+                data = data.reshape(-1, 8).T.copy().reshape(-1)                          # byte planes, as inside a blosc block
+            for minmatch, maxdist in ((3, 32768), (4, 32768), (8, 1000)):
+                out = np.zeros(n + n // 4 + 64, np.uint8)
+                r = enc.dfl_cpu_compress(ptr(data), n, ptr(out), out.size, minmatch, maxdist)
+                assert r > 0
+                s = out[:r].copy()
+                got, back = _un(zo, s, n)
+                assert got == n and np.array_equal(back[:n], data), (dname, n, minmatch)
+                if ru is not None:
+                    got2, back2 = _un(ru, s, n)
+                    assert got2 == n and np.array_equal(back2[:n], data), (dname, n, minmatch)
+                assert zlib.decompress(s.tobytes()) == data.tobytes()
+                cases += 1
+    assert cases == 162
+
+
+def test_every_length_and_distance_symbol(enc, oracle, ref):
+    """matches of every length 3..258 (+ long ones cut into pieces: 259, 260, 261, 516, 517, 100000) at distances around
+    every distance-code boundary"""
+    import ctypes
+    zo = _zo(oracle)
+    rng = np.random.default_rng(2)
+    base = rng.integers(0, 256, 40000).astype(np.uint8)
+    dists = sorted({d for c in range(30) for d in ([1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577][c] + k for k in (-1, 0, 1)) if 1 <= d <= 32768} | {32768})
+    lens = list(range(3, 262)) + [516, 517, 518, 774, 100000]
+    # build plain data: random prefix, then for each (len, dist) a copy of `len` bytes from `dist` back, then 2 fresh bytes
+    for trial, dist in enumerate(dists):
+        parts = [base[:max(dist, 8)].copy()]
+        cur = parts[0].size
+        buf = bytearray(parts[0].tobytes())
+        for L in (lens if trial % 7 == 0 else lens[trial % 5::5]):
+            for _ in range(L):
+                buf.append(buf[-dist])
+            buf.append(int(rng.integers(0, 256))); buf.append(int(rng.integers(0, 256)))
+        data = np.frombuffer(bytes(buf), np.uint8).copy()
+        out = np.zeros(data.size + data.size // 4 + 64, np.uint8)
+        r = enc.dfl_cpu_compress(ptr(data), data.size, ptr(out), out.size, 3, 32768)
+        assert r > 0
+        s = out[:r].copy()
+        got, back = _un(zo, s, data.size)
+        assert got == data.size and np.array_equal(back[:got], data), dist
+        assert zlib.decompress(s.tobytes()) == data.tobytes()
+
+
+def test_too_small_destination(enc):
+    data = DATASETS["random"](5000)
+    out = np.zeros(8000, np.uint8)
+    assert enc.dfl_cpu_compress(ptr(data), 5000, ptr(out), 4000, 4, 32768) == 0        # does not fit: the caller stores the split raw

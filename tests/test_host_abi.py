@@ -26,19 +26,20 @@ def test_exports_every_declared_symbol(lib, pkg):
 
 def test_names_codes_versions(lib):
     assert lib.blosc_get_version_string() == b"1.21.7.dev"
-    assert lib.blosc_list_compressors() == b"blosclz,lz4,lz4hc,zstd"
-    for name, code in [(b"blosclz", 0), (b"lz4", 1), (b"lz4hc", 2), (b"zstd", 5)]:
+    assert lib.blosc_list_compressors() == b"blosclz,lz4,lz4hc,zlib,zstd"
+    for name, code in [(b"blosclz", 0), (b"lz4", 1), (b"lz4hc", 2), (b"zlib", 4), (b"zstd", 5)]:
         assert lib.blosc_compname_to_compcode(name) == code
         p = C.c_char_p()
         assert lib.blosc_compcode_to_compname(code, C.byref(p)) == code and p.value == name
-    for name in [b"snappy", b"zlib", b"nope"]:
+    for name in [b"snappy", b"nope"]:
         assert lib.blosc_compname_to_compcode(name) == -1
     p = C.c_char_p()
-    assert lib.blosc_compcode_to_compname(4, C.byref(p)) == -1 and p.value == b"zlib"   # name known, support absent
+    assert lib.blosc_compcode_to_compname(3, C.byref(p)) == -1 and p.value == b"snappy"   # name known, support absent
     a, b = C.c_char_p(), C.c_char_p()
     assert lib.blosc_get_complib_info(b"lz4", C.byref(a), C.byref(b)) == 1 and a.value == b"LZ4"
     assert lib.blosc_get_complib_info(b"zstd", C.byref(a), C.byref(b)) == 4 and a.value == b"Zstd"
-    assert lib.blosc_get_complib_info(b"zlib", C.byref(a), C.byref(b)) == -1
+    assert lib.blosc_get_complib_info(b"zlib", C.byref(a), C.byref(b)) == 3 and a.value == b"Zlib"
+    assert lib.blosc_get_complib_info(b"snappy", C.byref(a), C.byref(b)) == -1
 
 
 def test_globals(lib):
