@@ -24,7 +24,8 @@ for k in sorted(set(f) | set(w)):
     if "bamd::" not in k: continue
     name = k.split("bamd::")[-1]
     # kernels that bench.py reports under the name of their pipeline stage
-    if name.startswith("k_encode_streams_t<true>"): name = "k_zstd_encode"
+    if name.startswith("k_encode_streams_t<true>") or name.startswith("k_encode_streams_t<1>"): name = "k_zstd_encode"
+    elif name.startswith("k_encode_streams_t<2>"): name = "k_zlib_encode"
     elif name.startswith("k_encode_streams_t"): name = "k_encode_streams"
     elif name.startswith("k_bitfilter_fast<0>"): name = "k_bitshuffle"
     elif name.startswith("k_bitfilter_fast<1>"): name = "k_bitunshuffle"
