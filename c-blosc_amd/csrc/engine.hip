@@ -228,6 +228,11 @@ static bool span_enabled() { static const bool on = !(getenv("BLOSC_AMD_SPANS") 
 static bool blockdec_enabled() { static const bool on = getenv("BLOSC_AMD_BLOCKDEC") && atoi(getenv("BLOSC_AMD_BLOCKDEC")) != 0; return on; }
 // BLOSC_AMD_PERIODIC=0: every plane goes through the match finder (A/B switch for the periodic-plane shortcut of the fused shuffle)
 static bool periodic_enabled() { static const bool on = !(getenv("BLOSC_AMD_PERIODIC") && atoi(getenv("BLOSC_AMD_PERIODIC")) == 0); return on; }
+// BLOSC_AMD_ZSTD2: 2 (default) = two-phase path, 16 frames per wave, tables in a global scratch (k_zstd2.hip);
+// 1 = the same with the tables in LDS (one wave per CU); 0 = one wave per frame for everything (k_zstd_streams).
+// 8 GiB of reference-written frames, mode 0 / 2: bench19 107 / 50 ms, linspace 17.8 / 15.9, random walk 23.7 / 16.5
+// (profiles/r02f_zstd_decode_modes.txt)
+static int zstd2_mode() { static const int m = getenv("BLOSC_AMD_ZSTD2") ? atoi(getenv("BLOSC_AMD_ZSTD2")) : 2; return m; }
 static bool fuse_enabled() { static const bool on = !(getenv("BLOSC_AMD_FUSE") && atoi(getenv("BLOSC_AMD_FUSE")) == 0); return on; }
 
 int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* results, bool device_ptrs,
@@ -564,6 +569,7 @@ struct DecodeLaunch {
   uint32_t* d_zticket; bool any_zstd;            // Zstd frames: k_zstd_entropy + k_zstd_exec (two-phase), the rest through k_zstd_streams
   bool any_zlib;                                 // zlib streams: k_zlib_streams (ticket word d_zticket[2])
   ZMeta* d_zmeta; ptrdiff_t zseq_delta;          // nullptr: everything through k_zstd_streams
+  ZgLds* d_zgscr;                                // table scratch of the global two-phase variant (nullptr: not allocated)
   const int32_t* d_qlist; const int32_t* d_qoff;   // per-XCD stream queues
   size_t nblk, nstr; int nchunks;
   bool any_shuf, any_bit, any_copy; int tiles_shuf, tiles_bit;
@@ -660,16 +666,15 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
 #endif
       }
     }
-    // BLOSC_AMD_ZSTD2=1: single-block frames through k_zstd_entropy (16 frames per wave) + k_zstd_exec.  Off by default:
-    // faster on sequence-heavy frames (bench19: 112 vs 130 ms per 8 GiB) but its per-frame start-up (table descriptions
-    // and builds on single lanes, one wave per CU for LDS reasons) costs 40 ms per 65 536 frames, which loses on data
-    // with few sequences (linspace 54 vs 16 ms) - profiles/r02_e_zstd_decode.md
-    static const bool zstd2 = getenv("BLOSC_AMD_ZSTD2") && atoi(getenv("BLOSC_AMD_ZSTD2")) != 0;
+    // single-block frames through k_zstd_entropy (16 frames per wave) + k_zstd_exec (zstd2_mode above); every other frame
+    // shape is left to k_zstd_streams
+    const int zstd2 = zstd2_mode();
     const uint32_t* d_taken = nullptr;
     if (L.any_zstd && L.d_zmeta && zstd2) {
       {
         ProfScope ps(st, stream, "k_zstd_entropy");
-        hipLaunchKernelGGL(k_zstd_entropy, grid1(L.nstr, ZG_FRAMES), dim3(64), 0, stream, L.d_streams, (int)L.nstr, L.d_chunks, L.d_blocks, L.d_zmeta, L.zseq_delta);
+        if (zstd2 == 2 && L.d_zgscr) hipLaunchKernelGGL(k_zstd_entropy_t<true>, grid1(L.nstr, ZG_FRAMES), dim3(64), 0, stream, L.d_streams, (int)L.nstr, L.d_chunks, L.d_blocks, L.d_zmeta, L.zseq_delta, L.d_zgscr);
+        else hipLaunchKernelGGL(k_zstd_entropy_t<false>, grid1(L.nstr, ZG_FRAMES), dim3(64), 0, stream, L.d_streams, (int)L.nstr, L.d_chunks, L.d_blocks, L.d_zmeta, L.zseq_delta, (ZgLds*)nullptr);
       }
       {
         ProfScope ps(st, stream, "k_zstd_exec");
@@ -792,6 +797,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   const size_t o_zseq = cv.take(zlit_bytes + 512);      // sequence triples of the two-phase Zstd path, same layout as the literal scratch
   const size_t o_zmeta = cv.take(L.any_zstd ? sizeof(ZMeta) * (nstr ? nstr : 1) : 64);
   const size_t o_zticket = cv.take(64);
+  const size_t o_zgscr = cv.take((L.any_zstd && zstd2_mode() == 2) ? sizeof(ZgLds) * (nstr ? nstr : 1) : 64);
   const size_t o_far = cv.take(far_stride ? far_stride * far_wgs : 256);
   if (st.dev.ensure(cv.off)) return -1;
   uint8_t* D = st.dev.base;
@@ -849,6 +855,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   L.d_zticket = (uint32_t*)(D + o_zticket);
   if (L.any_zstd || L.any_zlib) HIP_TRY(hipMemsetAsync(D + o_zticket, 0, 64, stream));
   L.d_zmeta = L.any_zstd ? (ZMeta*)(D + o_zmeta) : nullptr; L.zseq_delta = (ptrdiff_t)o_zseq - (ptrdiff_t)o_zlit + 8;
+  L.d_zgscr = (L.any_zstd && zstd2_mode() == 2) ? (ZgLds*)(D + o_zgscr) : nullptr;
   L.nblk = nblk; L.nstr = nstr; L.nchunks = n;
   L.d_bctl = (uint32_t*)(D + o_blist);
   L.d_bcand[0] = (const int32_t*)(D + o_blist + 64); L.d_bcand[1] = L.d_bcand[0] + blist[0].size();

@@ -49,12 +49,16 @@ __device__ __forceinline__ uint64_t* zseq_ptr(const uint8_t* lit, ptrdiff_t zseq
   return (uint64_t*)(((uintptr_t)lit + (uintptr_t)zseq_delta) & ~(uintptr_t)7);
 }
 
-__global__ __launch_bounds__(64) void k_zstd_entropy(const StreamDesc* __restrict__ streams, int nstreams, const ChunkDesc* __restrict__ chunks,
-                                                     const BlockDesc* __restrict__ blocks, ZMeta* __restrict__ meta, ptrdiff_t zseq_delta) {
-  __shared__ ZgLds lds[ZG_FRAMES];
+// GLOBAL = false: the tables of the 16 frames in LDS (128 KiB: ONE wave per CU).  GLOBAL = true: the same structure per frame
+// in a global scratch (gscr[sid]): every table access becomes a trip to L2 / HBM, but nothing limits the number of waves
+// per CU any more - 65 536 frames are 4096 waves, all of them resident at once (BLOSC_AMD_ZSTD2=2).
+template <bool GLOBAL>
+__global__ __launch_bounds__(64) void k_zstd_entropy_t(const StreamDesc* __restrict__ streams, int nstreams, const ChunkDesc* __restrict__ chunks,
+                                                       const BlockDesc* __restrict__ blocks, ZMeta* __restrict__ meta, ptrdiff_t zseq_delta, ZgLds* __restrict__ gscr) {
+  __shared__ ZgLds lds[GLOBAL ? 1 : ZG_FRAMES];
   const int lane = threadIdx.x & 63, g = lane >> 2, sub = lane & 3;
   const int sid = (int)blockIdx.x * ZG_FRAMES + g;
-  ZgLds* L = &lds[g];
+  ZgLds* L = GLOBAL ? gscr + (sid < nstreams ? sid : 0) : &lds[GLOBAL ? 0 : g];
   // ---- lane 0 of the group: everything up to the literal streams ----
   uint32_t state = ZM_FALLBACK;
   bool take = false;

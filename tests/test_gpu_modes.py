@@ -39,11 +39,14 @@ def test_mode_combination(flip):
     assert p.returncode == 0 and "modes ok" in p.stdout, (flip, p.stdout[-2000:], p.stderr[-3000:])
 
 
-def test_zstd_two_phase_decoder():
-    """BLOSC_AMD_ZSTD2=1 (k_zstd_entropy + k_zstd_exec, off by default): the whole Zstd decode suite - reference-written
-    frames, corrupted frames with the oracle's verdict, getitem, mixed batches - in a process of its own."""
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_zstd_decoder_modes(mode):
+    """BLOSC_AMD_ZSTD2=0 (one wave per frame for everything: k_zstd_streams) and =1 (two-phase path with the tables in LDS);
+    the default, =2 (tables in a global scratch), is what tests/test_gpu_zstd.py runs in-process.  The whole Zstd decode
+    suite - reference-written frames, corrupted frames with the oracle's verdict, getitem, mixed batches - in a process of
+    its own per mode."""
     env = dict(os.environ)
-    env["BLOSC_AMD_ZSTD2"] = "1"
+    env["BLOSC_AMD_ZSTD2"] = mode
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_zstd.py"), "-m", "gpu", "-q", "-x", "--no-header",
                         "-p", "no:cacheprovider"], env=env, timeout=900, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert p.returncode == 0 and " passed" in p.stdout and "failed" not in p.stdout, (p.stdout[-3000:], p.stderr[-2000:])
