@@ -598,9 +598,13 @@ __device__ __forceinline__ Rows<T> unshuffle_load(const PlanePtrs<T>& pp, uint32
   return x;
 }
 #ifndef BAMD_DST_STREAM
-#define BAMD_DST_STREAM 0     // 1: final output of the fused unshuffle written through and dropped from L2 (g_st16_stream): measured 8.2 ms instead of 5.4 (bench19), off
+#define BAMD_DST_STREAM 0     // 2: final output of the fused unshuffle with non-temporal stores (see profiles/r02f_decode_nt_variants.txt)
 #endif
-__device__ __forceinline__ void st16_dst(gu8* p, uint4 v) { if (BAMD_DST_STREAM) g_st16_stream(p, v); else g_st16(p, v); }
+__device__ __forceinline__ void st16_dst(gu8* p, uint4 v) { if (BAMD_DST_STREAM == 2) g_st16_nt(p, v); else g_st16(p, v); }
+#ifndef BAMD_UNSH_LD_NT
+#define BAMD_UNSH_LD_NT 1     // the fused unshuffle reads the planes (scratch / raw splits: read once) with non-temporal loads: -2 % (same-session A/B)
+#endif
+__device__ __forceinline__ uint32_t ld4_plane(const gu8* p) { return BAMD_UNSH_LD_NT ? g_ld4_nt(p) : g_ld4(p); }
 template <int T>
 __device__ __forceinline__ void unshuffle_store(gu8* dst, uint32_t e, int lane, const Rows<T>& x) {
   gu8* o = dst + (size_t)(e + 4u * (uint32_t)lane) * T;
@@ -657,7 +661,7 @@ __device__ void unshuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize,
       if (reg) { a.r[j] = b.r[j] = c.r[j] = d.r[j] = pr[j]; }   // scalar branch: no load at all
       else {
         const gu8* p = in_span ? pat + (size_t)j * SPAN_PAT + (e & (SPAN_PAT - 1u)) : pl[j] + e;
-        a.r[j] = g_ld4(p + l4); b.r[j] = g_ld4(p + l4 + 256u); c.r[j] = g_ld4(p + l4 + 512u); d.r[j] = g_ld4(p + l4 + 768u);
+        a.r[j] = ld4_plane(p + l4); b.r[j] = ld4_plane(p + l4 + 256u); c.r[j] = ld4_plane(p + l4 + 512u); d.r[j] = ld4_plane(p + l4 + 768u);
       }
     }
     unshuffle_store<T>(dst, e, lane, a); unshuffle_store<T>(dst, e + 256u, lane, b);

@@ -707,6 +707,119 @@ __device__ __forceinline__ uint32_t zs_write_sequences(gu8* out, uint32_t room, 
   return ovf ? 0xffffffffu : pos;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same section, written without the scalar unit (BAMD_ZSTD_VSEQ, default).  The scalar version above costs ~60 SALU
+// instructions per sequence, and the 20 waves of a CU share ONE scalar unit: 262 M sequences per 8 GiB of bench19 were
+// ~30 of the kernel's 42 ms.  Here, per batch of 64 sequences:
+//   * every lane prepares its sequence (codes, table rows, extra bits) as before;
+//   * the three FSE state chains run on THREE LANES (0: literal lengths, 1: match lengths, 2: offsets), vector code: per
+//     step one dependent LDS read (the next state); the bits each transition emits go to an LDS array;
+//   * all 64 lanes then place their sequence's bits - state bits, then extra bits, <= 66 per sequence - with a prefix sum
+//     over the bit counts (in stream order: last sequence first), OR them into an LDS strip and store the full dwords.
+// Bit for bit the output of zenc::write_sequences (tests: every frame is read by ZSTD_decompress and by the oracle).
+// Scratch: 64 x 3 transition words + a 136-dword strip, taken from the START of this wave's hash table - the section is
+// written after the block's match finding; a later block of the same stream finds some stale entries there, which the
+// candidate check (tag, then bytes) rejects like any other stale entry.
+// ---------------------------------------------------------------------------------------------
+#ifndef BAMD_ZSTD_VSEQ
+#define BAMD_ZSTD_VSEQ 1
+#endif
+constexpr uint32_t ZV_STRIP = 136u;
+// OR the low n (<= 49) bits of v into the strip at bit position bitpos
+__device__ __forceinline__ void zv_or_bits(volatile BAMD_LAS uint32_t* strip, uint32_t bitpos, uint64_t v, uint32_t n) {
+  if (n == 0u) return;
+  const uint32_t w = bitpos >> 5, sh = bitpos & 31u;
+  const uint64_t lo = v << sh;
+  __hip_atomic_fetch_or((BAMD_LAS uint32_t*)strip + w, (uint32_t)lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  if (sh + n > 32u) __hip_atomic_fetch_or((BAMD_LAS uint32_t*)strip + w + 1u, (uint32_t)(lo >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  if (sh + n > 64u) __hip_atomic_fetch_or((BAMD_LAS uint32_t*)strip + w + 2u, (uint32_t)(v >> (64u - sh)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+__device__ __forceinline__ uint32_t zs_write_sequences_v(gu8* out, uint32_t room, const BAMD_GAS uint64_t* seqs, uint32_t nseq,
+                                                         const BAMD_LAS zenc::CTabs* T, volatile BAMD_LAS uint32_t* scr, int lane) {
+  if (room < 8u) return 0xffffffffu;
+  uint32_t pos = 0;
+  if (nseq == 0u) { if (lane == 0) out[0] = 0; return 1u; }
+  if (nseq < 128u) { if (lane == 0) out[0] = (uint8_t)nseq; pos = 1; }
+  else if (nseq < 0x7f00u) { if (lane == 0) { out[0] = (uint8_t)((nseq >> 8) + 128u); out[1] = (uint8_t)nseq; } pos = 2; }
+  else { if (lane == 0) { out[0] = 255u; out[1] = (uint8_t)(nseq - 0x7f00u); out[2] = (uint8_t)((nseq - 0x7f00u) >> 8); } pos = 3; }
+  if (lane == 0) out[pos] = 0;                               // three predefined tables
+  pos += 1;
+  const BAMD_LAS uint32_t* ll_dnb = (const BAMD_LAS uint32_t*)T->ll.dnb; const BAMD_LAS int32_t* ll_dfs = (const BAMD_LAS int32_t*)T->ll.dfs;
+  const BAMD_LAS uint32_t* ml_dnb = (const BAMD_LAS uint32_t*)T->ml.dnb; const BAMD_LAS int32_t* ml_dfs = (const BAMD_LAS int32_t*)T->ml.dfs;
+  const BAMD_LAS uint32_t* of_dnb = (const BAMD_LAS uint32_t*)T->of.dnb; const BAMD_LAS int32_t* of_dfs = (const BAMD_LAS int32_t*)T->of.dfs;
+  // this lane's chain (lanes 0 / 1 / 2): its state table
+  const BAMD_LAS uint16_t* my_st = lane == 0 ? (const BAMD_LAS uint16_t*)T->ll.st : (lane == 1 ? (const BAMD_LAS uint16_t*)T->ml.st : (const BAMD_LAS uint16_t*)T->of.st);
+  volatile BAMD_LAS uint32_t* trans = scr;                   // [64][3]: bits | count << 16 of every state transition
+  volatile BAMD_LAS uint32_t* strip = scr + 192;             // [ZV_STRIP]
+  uint32_t state = 0;                                        // lanes 0..2
+  uint32_t pend = 0, npend = 0;                              // bits not yet stored (< 32), wave-uniform
+  bool first = true, ovf = false;
+  for (uint32_t base = ((nseq - 1u) >> 6) << 6;; base -= 64u) {
+    const uint32_t cnt = nseq - base < 64u ? nseq - base : 64u;
+    const uint64_t q = (uint32_t)lane < cnt ? seqs[base + (uint32_t)lane] : zenc::pack_seq(0, 3, 4);
+    const zenc::Code l = zenc::ll_code(zenc::seq_ll(q)), m = zenc::ml_code(zenc::seq_ml(q)), o = zenc::of_code_value(zenc::seq_off(q));
+    const uint32_t dl_v = ll_dnb[l.code], dm_v = ml_dnb[m.code], do_v = of_dnb[o.code];
+    const uint32_t nbx = l.bits + m.bits + o.bits;
+    const uint32_t fpk_v = ((uint32_t)ll_dfs[l.code] & 0xffu) | (((uint32_t)ml_dfs[m.code] & 0xffu) << 8) | (((uint32_t)of_dfs[o.code] & 0xffu) << 16);
+    const uint64_t ext = (uint64_t)l.extra | ((uint64_t)m.extra << l.bits) | ((uint64_t)o.extra << (l.bits + m.bits));
+    // ---- the three chains, last sequence of the batch first ----
+    for (int k = (int)cnt - 1; k >= 0; k--) {
+      const uint32_t dl = (uint32_t)__builtin_amdgcn_readlane((int)dl_v, k), dm = (uint32_t)__builtin_amdgcn_readlane((int)dm_v, k);
+      const uint32_t dO = (uint32_t)__builtin_amdgcn_readlane((int)do_v, k), fpk = (uint32_t)__builtin_amdgcn_readlane((int)fpk_v, k);
+      if (lane < 3) {
+        const uint32_t d = lane == 0 ? dl : (lane == 1 ? dm : dO);
+        const int32_t f = (int32_t)(int8_t)((fpk >> (8u * (uint32_t)lane)) & 0xffu);
+        if (first) {
+          const uint32_t nb = (d + (1u << 15)) >> 16;
+          state = my_st[(int32_t)(((nb << 16) - d) >> nb) + f];
+          trans[3 * k + lane] = 0u;
+        } else {
+          const uint32_t nb = (state + d) >> 16;
+          trans[3 * k + lane] = (state & ((1u << nb) - 1u)) | (nb << 16);
+          state = my_st[(int32_t)(state >> nb) + f];
+        }
+      }
+      first = false;
+    }
+    // ---- placement: per sequence [offset-state bits | match-length-state bits | literal-length-state bits | extra bits] ----
+    uint32_t a_bits = 0, a_n = 0;
+    if ((uint32_t)lane < cnt) {
+      const uint32_t tl = trans[3 * lane], tm = trans[3 * lane + 1], to = trans[3 * lane + 2];
+      const uint32_t nO = to >> 16, nm = tm >> 16, nl = tl >> 16;
+      a_bits = (to & 0xffffu) | ((tm & 0xffffu) << nO) | ((tl & 0xffffu) << (nO + nm));
+      a_n = nO + nm + nl;
+    }
+    const uint32_t mylen = (uint32_t)lane < cnt ? a_n + nbx : 0u;
+    const uint32_t incl = wave_incl_scan_u32(mylen, lane);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    strip[lane] = lane == 0 ? pend : 0u; strip[lane + 64] = 0u;
+    if (lane < (int)ZV_STRIP - 128) strip[lane + 128] = 0u;
+    if (mylen) {
+      const uint32_t at = npend + (total - incl);            // stream order: the batch's last sequence first
+      zv_or_bits(strip, at, (uint64_t)a_bits, a_n);
+      zv_or_bits(strip, at + a_n, ext, nbx);
+    }
+    const uint32_t fill = npend + total, ndw = fill >> 5;     // <= 133 full dwords
+    if (pos + 4u * ndw + 8u > room) { ovf = true; break; }
+#pragma unroll
+    for (uint32_t i = 0; i < 3u; i++) { const uint32_t w = (uint32_t)lane + 64u * i; if (w < ndw) g_st4(out + pos + 4u * w, strip[w]); }
+    pend = uni(strip[ndw]); npend = fill & 31u; pos += 4u * ndw;
+    if (base == 0u) break;
+  }
+  if (ovf) return 0xffffffffu;
+  // final states (match length, offset, literal length), the mark bit, the pending bytes
+  const uint32_t sll = (uint32_t)__builtin_amdgcn_readlane((int)state, 0), sml = (uint32_t)__builtin_amdgcn_readlane((int)state, 1), sof = (uint32_t)__builtin_amdgcn_readlane((int)state, 2);
+  uint64_t acc = (uint64_t)pend; uint32_t nb = npend;
+  acc |= (uint64_t)(sml & 63u) << nb; nb += (uint32_t)zenc::kMLLog;
+  acc |= (uint64_t)(sof & 31u) << nb; nb += (uint32_t)zenc::kOFLog;
+  acc |= (uint64_t)(sll & 63u) << nb; nb += (uint32_t)zenc::kLLLog;
+  acc |= 1ull << nb; nb += 1u;
+  const uint32_t nbytes = (nb + 7u) >> 3;                    // <= 7
+  if (pos + nbytes > room) return 0xffffffffu;
+  if ((uint32_t)lane < nbytes) out[pos + (uint32_t)lane] = (uint8_t)(acc >> (8u * (uint32_t)lane));
+  return pos + nbytes;
+}
+
 // One stream -> one frame.  Returns the frame size, or 0 when it would not be smaller than the input (the split is
 // then stored raw by blosc's own rule, blosc.c:703-717).  `seqbuf`: zenc::kBlockMax / 4 entries of this wave.
 constexpr uint32_t ZS_SEQCAP = zenc::kBlockMax / 4u;
@@ -745,7 +858,8 @@ __device__ uint32_t zstd_encode_wave(const gu8* __restrict__ src, uint32_t n, gu
       zs_assign_offset_values(seqbuf, z.nseq, rep, lane);
       __builtin_amdgcn_s_waitcnt(0);
       PROF_LAP(4);                        // Zstd: slot 4 = tail literals + offset values, slot 5 = sequences section
-      const uint32_t ss = zs_write_sequences(z.lit + z.nlit, z.litcap - z.nlit, seqbuf, z.nseq, T, lane);
+      const uint32_t ss = BAMD_ZSTD_VSEQ ? zs_write_sequences_v(z.lit + z.nlit, z.litcap - z.nlit, seqbuf, z.nseq, T, (volatile BAMD_LAS uint32_t*)(BAMD_LAS uint8_t*)(void*)tab_generic, lane)
+                                         : zs_write_sequences(z.lit + z.nlit, z.litcap - z.nlit, seqbuf, z.nseq, T, lane);
       PROF_LAP(5);
       if (ss != 0xffffffffu) bsize = zenc::kLitHeader + z.nlit + ss;
     }

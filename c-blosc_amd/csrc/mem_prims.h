@@ -31,12 +31,14 @@ __device__ __forceinline__ void g_st16(gu8* p, uint4 v) {
   v4u32 t = {v.x, v.y, v.z, v.w};
   *(BAMD_GAS v4u32_una*)p = t;
 }
-// 16-byte store that does not stay in the XCD's L2 (sc0 sc1: written through and dropped, MI355X_MICROARCH.md "stores of
-// each flavour"): for final output nobody on the chip reads again, so that it does not push scratch lines out of L2
-__device__ __forceinline__ void g_st16_stream(gu8* p, uint4 v) {
+// non-temporal variants (compiler builtins: the nt bit; streaming data that nobody on the chip reads again soon is the first to
+// leave the caches).  Hand-written `asm volatile("global_store_dwordx4 ... nt")` stores are NOT an option: the compiler does
+// not count them in vmcnt and reuses their data registers while they are in flight (measured: wrong output).
+__device__ __forceinline__ void g_st16_nt(gu8* p, uint4 v) {
   v4u32 t = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(t) : "memory");
+  __builtin_nontemporal_store(t, (BAMD_GAS v4u32_una*)p);
 }
+__device__ __forceinline__ uint32_t g_ld4_nt(const gu8* p) { return __builtin_nontemporal_load((const BAMD_GAS u32una*)p); }
 __device__ __forceinline__ uint32_t g_ld4(const gu8* p) { return *(const BAMD_GAS u32una*)p; }
 __device__ __forceinline__ uint64_t g_ld8(const gu8* p) { return *(const BAMD_GAS u64una*)p; }
 __device__ __forceinline__ void g_st4(gu8* p, uint32_t v) { *(BAMD_GAS u32una*)p = v; }
