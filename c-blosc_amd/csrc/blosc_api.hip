@@ -258,7 +258,10 @@ int blosc_gpu_compress_batch(int clevel, int doshuffle, size_t typesize, const c
   if (!jobs) return -1;
   for (int i = 0; i < nchunks; i++) jobs[i] = Job{src[i], dest[i], nbytes[i], destsize[i]};
   CompressParams p{clevel, doshuffle, typesize, code, (int32_t)(blocksize ? blocksize : (size_t)g_force_blocksize), g_splitmode};
-  int r = engine_compress_batch(p, nchunks, jobs, cbytes_out, true, (hipStream_t)stream);
+  // host buffers (a file reader's chunks, c-blosc_amd/blpk.py) are staged like those of the stock entry points; a batch is all
+  // host or all device memory (the kind of chunk 0 decides)
+  const bool dev = engine_is_device_pointer(src[0]) && engine_is_device_pointer(dest[0]);
+  int r = engine_compress_batch(p, nchunks, jobs, cbytes_out, dev, (hipStream_t)stream);
   free(jobs);
   return r;
 }
@@ -269,7 +272,8 @@ int blosc_gpu_decompress_batch(int nchunks, const void* const* src, const size_t
   Job* jobs = (Job*)malloc(sizeof(Job) * (size_t)nchunks);
   if (!jobs) return -1;
   for (int i = 0; i < nchunks; i++) jobs[i] = Job{src[i], dest[i], srcsize ? srcsize[i] : 0, destsize[i]};
-  int r = engine_decompress_batch(nchunks, jobs, nbytes_out, true, (hipStream_t)stream);
+  const bool dev = engine_is_device_pointer(src[0]) && engine_is_device_pointer(dest[0]);
+  int r = engine_decompress_batch(nchunks, jobs, nbytes_out, dev, (hipStream_t)stream);
   free(jobs);
   return r;
 }

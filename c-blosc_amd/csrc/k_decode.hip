@@ -598,7 +598,7 @@ __device__ __forceinline__ Rows<T> unshuffle_load(const PlanePtrs<T>& pp, uint32
   return x;
 }
 #ifndef BAMD_DST_STREAM
-#define BAMD_DST_STREAM 0     // 2: final output of the fused unshuffle with non-temporal stores (see profiles/r02f_decode_nt_variants.txt)
+#define BAMD_DST_STREAM 2     // 2: final output of the fused unshuffle with non-temporal stores: bench19 -3.8 %, linspace -1.5 % (profiles/r02f_decode_nt_variants.txt); 0: plain
 #endif
 __device__ __forceinline__ void st16_dst(gu8* p, uint4 v) { if (BAMD_DST_STREAM == 2) g_st16_nt(p, v); else g_st16(p, v); }
 #ifndef BAMD_UNSH_LD_NT

@@ -913,6 +913,9 @@ __device__ uint32_t zlib_encode_wave(const gu8* __restrict__ src, uint32_t n, gu
 // step lane l loads the T*4 contiguous bytes of elements e+4l..e+4l+3 (coalesced 16-byte loads), transposes
 // bytes in registers and stores 4 bytes into every plane (each wave store writes 256 contiguous bytes).
 // ---------------------------------------------------------------------------------------------
+#ifndef BAMD_SHUF_LD_NT
+#define BAMD_SHUF_LD_NT 0     // 1: the fused shuffle reads the source (read once) with non-temporal loads
+#endif
 template <int T>
 struct ElemRows { uint4 a, b; };
 
@@ -920,8 +923,8 @@ template <int T>
 __device__ __forceinline__ ElemRows<T> shuffle_load(const gu8* src, uint32_t e, int lane) {
   ElemRows<T> x;
   const gu8* in = src + (size_t)(e + 4u * (uint32_t)lane) * T;
-  x.a = g_ld16(in);
-  if (T == 8) x.b = g_ld16(in + 16); else x.b = make_uint4(0, 0, 0, 0);
+  x.a = BAMD_SHUF_LD_NT ? g_ld16_nt(in) : g_ld16(in);
+  if (T == 8) x.b = BAMD_SHUF_LD_NT ? g_ld16_nt(in + 16) : g_ld16(in + 16); else x.b = make_uint4(0, 0, 0, 0);
   return x;
 }
 template <int T>

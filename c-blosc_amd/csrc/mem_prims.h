@@ -38,6 +38,10 @@ __device__ __forceinline__ void g_st16_nt(gu8* p, uint4 v) {
   v4u32 t = {v.x, v.y, v.z, v.w};
   __builtin_nontemporal_store(t, (BAMD_GAS v4u32_una*)p);
 }
+__device__ __forceinline__ uint4 g_ld16_nt(const gu8* p) {
+  v4u32 t = __builtin_nontemporal_load((const BAMD_GAS v4u32_una*)p);
+  return make_uint4(t.x, t.y, t.z, t.w);
+}
 __device__ __forceinline__ uint32_t g_ld4_nt(const gu8* p) { return __builtin_nontemporal_load((const BAMD_GAS u32una*)p); }
 __device__ __forceinline__ uint32_t g_ld4(const gu8* p) { return *(const BAMD_GAS u32una*)p; }
 __device__ __forceinline__ uint64_t g_ld8(const gu8* p) { return *(const BAMD_GAS u64una*)p; }

@@ -29,7 +29,9 @@ BLOSC_EXPORT int blosc_gpu_set_device(int device);
 /* Batched blosc_compress_ctx (blosc/blosc.h:245-248).  Chunk i: nbytes[i] bytes at src[i] ->
  * a chunk of at most destsize[i] bytes at dest[i]; cbytes_out[i] gets what blosc_compress_ctx
  * would return for it.  `compressor` NULL = the global compressor (blosc_set_compressor);
- * `blocksize` 0 = automatic.  Returns 0, or <0 if the device could not be used. */
+ * `blocksize` 0 = automatic.  Returns 0, or <0 if the device could not be used.
+ * The buffers of one batch are either all device (or managed) memory - the measured path - or all host memory
+ * (staged over PCIe like the stock entry points; c-blosc_amd/blpk.py feeds whole files this way). */
 BLOSC_EXPORT int blosc_gpu_compress_batch(int clevel, int doshuffle, size_t typesize, const char* compressor,
                                           size_t blocksize, int nchunks, const void* const* src,
                                           const size_t* nbytes, void* const* dest, const size_t* destsize,
