@@ -17,7 +17,8 @@ namespace bamd {
 // entry >= 0 is a stream index, an entry < 0 the shuffle task of block -(entry+1).  A block's shuffle
 // task is queued kEncLookahead blocks ahead of its streams: by the time a wave draws one of the streams
 // the transpose is normally finished, and it is always already owned by a running wave (no deadlock).
-constexpr size_t kEncLookahead = 32;
+constexpr size_t kEncLookaheadDefault = 32;
+inline size_t enc_lookahead() { static const size_t v = getenv("BLOSC_AMD_ENC_LOOKAHEAD") ? (size_t)atoi(getenv("BLOSC_AMD_ENC_LOOKAHEAD")) : kEncLookaheadDefault; return v ? v : 1; }
 // BLOSC_AMD_SCHED=0: plain block order (no cost feedback)
 inline bool sched_enabled() { static const bool on = !(getenv("BLOSC_AMD_SCHED") && atoi(getenv("BLOSC_AMD_SCHED")) == 0); return on; }
 
@@ -51,6 +52,7 @@ inline void build_encode_queues(const std::vector<BlockDesc>& blocks, const std:
       if (chunks[(size_t)blocks[B[i]].chunk].mode & CH_FUSED_SHUF) q[x].push_back(-(int32_t)B[i] - 1);
     };
     int maxT = 1;
+    const size_t kEncLookahead = enc_lookahead();
     for (size_t i = 0; i < B.size() && i < kEncLookahead; i++) push_shuffle(i);
     for (size_t i = 0; i < B.size(); i++) {
       if (i + kEncLookahead < B.size()) push_shuffle(i + kEncLookahead);

@@ -22,6 +22,7 @@ CASES = [  # name, codec, shuffle, typesize, clevel, dataset, GPU encodes it
     ("lz4-shuffle-T8-linspace", "lz4", 1, 8, 5, "linspace", True),
     ("lz4-shuffle-T8-randwalk", "lz4", 1, 8, 5, "randwalk", True),
     ("zstd-shuffle-T8", "zstd", 1, 8, 3, "bench19", True),
+    ("zlib-shuffle-T8", "zlib", 1, 8, 5, "bench19", True),
 ]
 
 
@@ -33,8 +34,8 @@ def test_batch_at_baseline_geometry(pkg, lib, oracle, ref, name, codec, shuffle,
     if ref is not None:
         r, stock = ref_compress(ref, data, T, clevel, shuffle, codec.encode(), nthreads=8)
     else:
-        if codec == "zstd":
-            pytest.skip("no Zstd writer without oracle/_ref")
+        if codec in ("zstd", "zlib"):
+            pytest.skip("no Zstd / Zlib writer without oracle/_ref")
         r, stock = orc_compress(oracle, data, T, clevel, shuffle, codec)
     assert r > 0
     d_data = torch.from_numpy(data).to(dev)
