@@ -469,6 +469,7 @@ def main():
     if not args.no_cpu_baseline and world == 1:      # the host-core baseline is a 1-GPU artefact (rank 0, N = 1)
         out["cpu_baseline"] = cpu_baseline(host_chunk, T, clevel, shuffle, cname, args.cpu_seconds)
     print(json.dumps(out))
+    lib.blosc_init(); lib.blosc_destroy()          # releases the arenas (and prints the BLOSC_AMD_HOSTTIME summary when that switch is on)
     dist.destroy_process_group()
 
 

@@ -12,6 +12,7 @@
 #include <vector>
 #include <algorithm>
 
+#include <chrono>
 #include "blosc_format.h"
 #include "dev_types.h"
 #include "queue_order.h"
@@ -172,6 +173,13 @@ static hipEvent_t prof_event(EngineState& st) {
   if (!st.ev_pool.empty()) { hipEvent_t e = st.ev_pool.back(); st.ev_pool.pop_back(); return e; }
   hipEvent_t e; (void)hipEventCreate(&e); return e;
 }
+// BLOSC_AMD_HOSTTIME=1: wall time of the host side of the batched calls per phase, printed when the library is released
+// (where do the ~0.4 ms per call outside the kernels go?)
+struct HostTime { double t[2][6] = {}; long calls[2] = {}; };
+static HostTime g_ht;
+static bool hosttime_on() { static const bool on = getenv("BLOSC_AMD_HOSTTIME") && atoi(getenv("BLOSC_AMD_HOSTTIME")) != 0; return on; }
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define HT_MARK(dir, i) do { if (hosttime_on()) { const double t_ = now_ms(); g_ht.t[dir][i] += t_ - ht_last; ht_last = t_; } } while (0)
 struct ProfScope {
   EngineState& st; hipStream_t s; const char* name; hipEvent_t a{}, b{}; bool on;
   ProfScope(EngineState& st_, hipStream_t s_, const char* n) : st(st_), s(s_), name(n), on(st_.prof) {
@@ -242,6 +250,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   if (n <= 0) return 0;
   if (ensure_device(st)) return -1;
 
+  double ht_last = hosttime_on() ? now_ms() : 0.0; if (hosttime_on()) g_ht.calls[0]++;
   std::vector<ChunkDesc> chunks((size_t)n);
   std::vector<BlockDesc> blocks;
   std::vector<StreamDesc> streams;
@@ -325,6 +334,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   }
 
   const size_t nblk = blocks.size(), nstr = streams.size();
+  HT_MARK(0, 0);     // per-chunk geometry + block / stream tables
   // ---- device workspace ----
   Carver cv;
   const size_t o_chunks = cv.take(sizeof(ChunkDesc) * (size_t)n);
@@ -385,6 +395,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
       }
     }
   }
+  HT_MARK(0, 1);     // queues, workspace, pointer patching
   // ---- upload tables ----
   Carver pc;
   const size_t p_chunks = pc.take(sizeof(ChunkDesc) * (size_t)n);
@@ -414,6 +425,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   int32_t* d_blkoff = (int32_t*)(D + o_blkoff);
   int32_t* d_results = (int32_t*)(D + o_results);
 
+  HT_MARK(0, 2);     // table copies to pinned memory + upload enqueues
   // ---- pipeline ----
   if (any_shuf && nblk) {
     ProfScope ps(st, stream, "k_shuffle");
@@ -461,7 +473,9 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(P + p_results, d_results, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipMemcpyAsync(P + p_cost, D + o_cost, sizeof(uint32_t) * kCostWords, hipMemcpyDeviceToHost, stream));
+  HT_MARK(0, 3);     // kernel launches
   HIP_TRY(hipStreamSynchronize(stream));
+  HT_MARK(0, 4);     // waiting for the device
   prof_collect(st);
   if (nstr && check_done((const uint32_t*)(P + p_cost), queues.size() - 9, 0, "compress")) return -1;
   if (nstr >= 4096) { memcpy(st.enc_cost, P + p_cost, sizeof st.enc_cost); st.enc_cost_valid = true; }   // small calls say little
@@ -748,8 +762,10 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   if (n <= 0) return 0;
   if (ensure_device(st)) return -1;
 
+  double ht_last = hosttime_on() ? now_ms() : 0.0; if (hosttime_on()) g_ht.calls[1]++;
   std::vector<Header> hdrs;
   if (fetch_headers(st, n, jobs, device_ptrs, stream, hdrs)) return -1;
+  HT_MARK(1, 0);     // header gather (kernel + copy + sync)
 
   std::vector<ChunkDesc> chunks((size_t)n);
   std::vector<BlockDesc> blocks;
@@ -863,10 +879,13 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   L.d_skind = (uint32_t*)(D + o_skind);
   L.nlist[0] = (uint32_t)blist[0].size(); L.nlist[1] = (uint32_t)blist[1].size();
   L.d_far = D + o_far; L.far_stride = far_stride; L.nstr_queued = nstr - nstr_lds;
+  HT_MARK(1, 2);     // tables, queues, uploads
   if (launch_decode(st, L, stream)) return -1;
   HIP_TRY(hipMemcpyAsync(P + p_status, D + o_status, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipMemcpyAsync(P + p_cost, D + o_cost, sizeof(uint32_t) * kCostWords, hipMemcpyDeviceToHost, stream));
+  HT_MARK(1, 3);     // kernel launches
   HIP_TRY(hipStreamSynchronize(stream));
+  HT_MARK(1, 4);     // waiting for the device
   prof_collect(st);
   if (nblk && check_done((const uint32_t*)(P + p_cost), nstr - nstr_lds, L.any_zstd ? nstr : 0, "decompress", blist[0].size() + blist[1].size(), L.any_zlib ? nstr : 0)) return -1;
   if (nstr >= 4096) { memcpy(st.dec_cost, P + p_cost, sizeof st.dec_cost); st.dec_cost_valid = true; }
@@ -1070,6 +1089,12 @@ int engine_set_device(int dev) {
 }
 
 void engine_release() {
+  if (hosttime_on()) {
+    const char* nm[2] = {"compress", "decompress"};
+    for (int d = 0; d < 2; d++) if (g_ht.calls[d])
+      fprintf(stderr, "blosc_amd host time per %s call (ms, %ld calls): phase0 %.3f  phase1 %.3f  phase2 %.3f  launches %.3f  wait %.3f\n", nm[d], g_ht.calls[d],
+              g_ht.t[d][0] / g_ht.calls[d], g_ht.t[d][1] / g_ht.calls[d], g_ht.t[d][2] / g_ht.calls[d], g_ht.t[d][3] / g_ht.calls[d], g_ht.t[d][4] / g_ht.calls[d]);
+  }
   EngineState& st = S();
   std::lock_guard<std::mutex> lock(st.mu);
   if (!st.device_ok || g_forked) return;
