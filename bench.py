@@ -86,7 +86,7 @@ def measured_traffic(kernel, config_name, nchunks, chunk_mib):
     read from inside a timed run, so a workload without a committed pass reports null."""
     if nchunks != 128 or chunk_mib != 64:
         return None
-    for rnd in ("r02f", "r02"):       # r02f: passes taken on the final code of round 2
+    for rnd in ("r02g", "r02f", "r02"):       # r02g / r02f: passes taken on the final code of round 2
         path = os.path.join(ROOT, "profiles", f"{rnd}_traffic_cfg{config_name}.json")
         if os.path.exists(path):
             with open(path) as fh:

@@ -26,6 +26,7 @@ STOCK_SYMBOLS = [
 ]
 GPU_SYMBOLS = [
     "blosc_gpu_set_device", "blosc_gpu_compress_batch", "blosc_gpu_decompress_batch", "blosc_gpu_getitem",
+    "blosc_gpu_compress_batch_host", "blosc_gpu_decompress_batch_host",
     "blosc_gpu_profile", "blosc_gpu_profile_reset", "blosc_gpu_profile_get",
 ]
 
@@ -72,6 +73,8 @@ def load():
                                            C.POINTER(vp), C.POINTER(sz), C.POINTER(i), vp]
     L.blosc_gpu_decompress_batch.argtypes = [i, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz),
                                              C.POINTER(i), vp]
+    L.blosc_gpu_compress_batch_host.argtypes = [i, i, sz, C.c_char_p, sz, i, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.POINTER(i)]
+    L.blosc_gpu_decompress_batch_host.argtypes = [i, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.POINTER(i)]
     L.blosc_gpu_getitem.argtypes = [vp, i, i, vp, vp]
     L.blosc_gpu_profile.argtypes = [i]
     L.blosc_gpu_profile.restype = None

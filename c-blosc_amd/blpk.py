@@ -3,7 +3,7 @@
 c-blosc compresses one buffer of at most 2 GiB per call; files are handled by callers such as Bloscpack (`README.md:173-177`
 of the reference points there), which cut the data into chunks, run `blosc_compress` on each and store the chunks behind a
 small header with an offset table.  This module is that caller for libblosc_amd: the chunks of a file go through
-`blosc_gpu_compress_batch` / `blosc_gpu_decompress_batch` several hundred at a time instead of one call per chunk, so a file
+`blosc_gpu_compress_batch_host` / `blosc_gpu_decompress_batch_host` several hundred at a time instead of one call per chunk, so a file
 is a handful of launches.
 
 File layout (Bloscpack format version 3, written from its published format description; **parity unpinned**: Bloscpack is
@@ -75,7 +75,7 @@ def _ptr_array(arrs):
 
 def pack(lib, data, fh, chunk_size=1 << 20, typesize=8, clevel=5, shuffle=1, cname=b"lz4", checksum=1, batch_bytes=1 << 30):
     """Compress `data` (numpy, any dtype) into the open binary file `fh`.  Chunks go to the GPU `batch_bytes` at a time
-    through blosc_gpu_compress_batch.  Returns (nchunks, bytes written)."""
+    through blosc_gpu_compress_batch_host.  Returns (nchunks, bytes written)."""
     a = np.ascontiguousarray(data).view(np.uint8).ravel()
     n = a.size
     if chunk_size <= 0 or chunk_size > (1 << 31) - 17:
@@ -95,7 +95,7 @@ def pack(lib, data, fh, chunk_size=1 << 20, typesize=8, clevel=5, shuffle=1, cna
         m = b1 - b0
         ssz = (C.c_size_t * m)(*[s.size for s in srcs]); dsz = (C.c_size_t * m)(*[d.size for d in dsts])
         res = (C.c_int * m)()
-        rc = lib.blosc_gpu_compress_batch(clevel, shuffle, typesize, cname, 0, m, _ptr_array(srcs), ssz, _ptr_array(dsts), dsz, res, None)
+        rc = lib.blosc_gpu_compress_batch_host(clevel, shuffle, typesize, cname, 0, m, _ptr_array(srcs), ssz, _ptr_array(dsts), dsz, res)
         if rc != 0 or any(r <= 0 for r in res):
             raise BlpkError(f"compression failed (rc {rc}, results {list(res)[:4]}...)")
         for k, (d, r) in enumerate(zip(dsts, res)):
@@ -109,7 +109,7 @@ def pack(lib, data, fh, chunk_size=1 << 20, typesize=8, clevel=5, shuffle=1, cna
 
 def unpack(lib, fh, batch_bytes=1 << 30, verify=True):
     """Read a bloscpack file from the open binary file `fh`; returns the plain bytes as a numpy uint8 array.  Chunks go to the
-    GPU `batch_bytes` at a time through blosc_gpu_decompress_batch."""
+    GPU `batch_bytes` at a time through blosc_gpu_decompress_batch_host."""
     blob = fh.read()
     h = unpack_header(blob)
     pos = HEADER_LENGTH
@@ -158,7 +158,7 @@ def unpack(lib, fh, batch_bytes=1 << 30, verify=True):
         dsts = [out[starts[k]:starts[k + 1]] for k in range(k0, k1)]
         ssz = (C.c_size_t * m)(*[s.size for s in srcs]); dsz = (C.c_size_t * m)(*[d.size for d in dsts])
         res = (C.c_int * m)()
-        rc = lib.blosc_gpu_decompress_batch(m, _ptr_array(srcs), ssz, _ptr_array(dsts), dsz, res, None)
+        rc = lib.blosc_gpu_decompress_batch_host(m, _ptr_array(srcs), ssz, _ptr_array(dsts), dsz, res)
         if rc != 0 or any(r != d.size for r, d in zip(res, dsts)):
             raise BlpkError(f"decompression failed (rc {rc}, results {list(res)[:4]}...)")
         k0 = k1

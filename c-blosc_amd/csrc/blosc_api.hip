@@ -248,9 +248,9 @@ int blosc_getitem(const void* src, int start, int nitems, void* dest) {
 // ---- device-resident batched extension (include/blosc_gpu.h) ---------------------------------------
 int blosc_gpu_set_device(int device) { return engine_set_device(device); }
 
-int blosc_gpu_compress_batch(int clevel, int doshuffle, size_t typesize, const char* compressor, size_t blocksize,
-                             int nchunks, const void* const* src, const size_t* nbytes, void* const* dest,
-                             const size_t* destsize, int* cbytes_out, void* stream) {
+static int compress_batch(int clevel, int doshuffle, size_t typesize, const char* compressor, size_t blocksize,
+                          int nchunks, const void* const* src, const size_t* nbytes, void* const* dest,
+                          const size_t* destsize, int* cbytes_out, void* stream, bool device_ptrs) {
   if (nchunks <= 0) return 0;
   const int code = compressor ? blosc_compname_to_compcode(compressor) : g_compressor;
   if (code < 0 || !codec_built(code)) { for (int i = 0; i < nchunks; i++) cbytes_out[i] = -5; return 0; }
@@ -258,24 +258,39 @@ int blosc_gpu_compress_batch(int clevel, int doshuffle, size_t typesize, const c
   if (!jobs) return -1;
   for (int i = 0; i < nchunks; i++) jobs[i] = Job{src[i], dest[i], nbytes[i], destsize[i]};
   CompressParams p{clevel, doshuffle, typesize, code, (int32_t)(blocksize ? blocksize : (size_t)g_force_blocksize), g_splitmode};
-  // host buffers (a file reader's chunks, c-blosc_amd/blpk.py) are staged like those of the stock entry points; a batch is all
-  // host or all device memory (the kind of chunk 0 decides)
-  const bool dev = engine_is_device_pointer(src[0]) && engine_is_device_pointer(dest[0]);
-  int r = engine_compress_batch(p, nchunks, jobs, cbytes_out, dev, (hipStream_t)stream);
+  int r = engine_compress_batch(p, nchunks, jobs, cbytes_out, device_ptrs, (hipStream_t)stream);
   free(jobs);
   return r;
 }
+int blosc_gpu_compress_batch(int clevel, int doshuffle, size_t typesize, const char* compressor, size_t blocksize,
+                             int nchunks, const void* const* src, const size_t* nbytes, void* const* dest,
+                             const size_t* destsize, int* cbytes_out, void* stream) {
+  return compress_batch(clevel, doshuffle, typesize, compressor, blocksize, nchunks, src, nbytes, dest, destsize, cbytes_out, stream, true);
+}
+// the same call on HOST buffers (staged over PCIe like the stock entry points): a file reader's chunks, c-blosc_amd/blpk.py
+int blosc_gpu_compress_batch_host(int clevel, int doshuffle, size_t typesize, const char* compressor, size_t blocksize,
+                                  int nchunks, const void* const* src, const size_t* nbytes, void* const* dest,
+                                  const size_t* destsize, int* cbytes_out) {
+  return compress_batch(clevel, doshuffle, typesize, compressor, blocksize, nchunks, src, nbytes, dest, destsize, cbytes_out, nullptr, false);
+}
 
-int blosc_gpu_decompress_batch(int nchunks, const void* const* src, const size_t* srcsize, void* const* dest,
-                               const size_t* destsize, int* nbytes_out, void* stream) {
+static int decompress_batch(int nchunks, const void* const* src, const size_t* srcsize, void* const* dest,
+                            const size_t* destsize, int* nbytes_out, void* stream, bool device_ptrs) {
   if (nchunks <= 0) return 0;
   Job* jobs = (Job*)malloc(sizeof(Job) * (size_t)nchunks);
   if (!jobs) return -1;
   for (int i = 0; i < nchunks; i++) jobs[i] = Job{src[i], dest[i], srcsize ? srcsize[i] : 0, destsize[i]};
-  const bool dev = engine_is_device_pointer(src[0]) && engine_is_device_pointer(dest[0]);
-  int r = engine_decompress_batch(nchunks, jobs, nbytes_out, dev, (hipStream_t)stream);
+  int r = engine_decompress_batch(nchunks, jobs, nbytes_out, device_ptrs, (hipStream_t)stream);
   free(jobs);
   return r;
+}
+int blosc_gpu_decompress_batch(int nchunks, const void* const* src, const size_t* srcsize, void* const* dest,
+                               const size_t* destsize, int* nbytes_out, void* stream) {
+  return decompress_batch(nchunks, src, srcsize, dest, destsize, nbytes_out, stream, true);
+}
+int blosc_gpu_decompress_batch_host(int nchunks, const void* const* src, const size_t* srcsize, void* const* dest,
+                                    const size_t* destsize, int* nbytes_out) {
+  return decompress_batch(nchunks, src, srcsize, dest, destsize, nbytes_out, nullptr, false);
 }
 
 int blosc_gpu_getitem(const void* src, int start, int nitems, void* dest, void* stream) {

@@ -29,9 +29,7 @@ BLOSC_EXPORT int blosc_gpu_set_device(int device);
 /* Batched blosc_compress_ctx (blosc/blosc.h:245-248).  Chunk i: nbytes[i] bytes at src[i] ->
  * a chunk of at most destsize[i] bytes at dest[i]; cbytes_out[i] gets what blosc_compress_ctx
  * would return for it.  `compressor` NULL = the global compressor (blosc_set_compressor);
- * `blocksize` 0 = automatic.  Returns 0, or <0 if the device could not be used.
- * The buffers of one batch are either all device (or managed) memory - the measured path - or all host memory
- * (staged over PCIe like the stock entry points; c-blosc_amd/blpk.py feeds whole files this way). */
+ * `blocksize` 0 = automatic.  Returns 0, or <0 if the device could not be used.  src / dest are DEVICE (or managed) memory. */
 BLOSC_EXPORT int blosc_gpu_compress_batch(int clevel, int doshuffle, size_t typesize, const char* compressor,
                                           size_t blocksize, int nchunks, const void* const* src,
                                           const size_t* nbytes, void* const* dest, const size_t* destsize,
@@ -43,6 +41,15 @@ BLOSC_EXPORT int blosc_gpu_compress_batch(int clevel, int doshuffle, size_t type
 BLOSC_EXPORT int blosc_gpu_decompress_batch(int nchunks, const void* const* src, const size_t* srcsize,
                                             void* const* dest, const size_t* destsize, int* nbytes_out,
                                             void* stream);
+
+/* The two batched calls on HOST buffers (staged over PCIe like the stock entry points, one staging pass per batch instead of
+ * one per chunk): what a file reader uses - c-blosc_amd/blpk.py feeds whole many-chunk files this way. */
+BLOSC_EXPORT int blosc_gpu_compress_batch_host(int clevel, int doshuffle, size_t typesize, const char* compressor,
+                                               size_t blocksize, int nchunks, const void* const* src,
+                                               const size_t* nbytes, void* const* dest, const size_t* destsize,
+                                               int* cbytes_out);
+BLOSC_EXPORT int blosc_gpu_decompress_batch_host(int nchunks, const void* const* src, const size_t* srcsize,
+                                                 void* const* dest, const size_t* destsize, int* nbytes_out);
 
 /* blosc_getitem (blosc/blosc.h:312) on a device-resident chunk into device memory. */
 BLOSC_EXPORT int blosc_gpu_getitem(const void* src, int start, int nitems, void* dest, void* stream);
