@@ -137,3 +137,40 @@ def test_corrupt_zlib_chunks_same_verdict_as_oracle_and_reference(pkg, oracle, r
             if ref is not None:
                 rr, _ = ref_decompress(ref, c, n)
                 assert (rr == n) == (rg == n), (trial, pos, rr, rg)
+
+
+@pytest.mark.parametrize("fixture", ["ref_zlib_chunks.npz", "ref_zstd_chunks.npz"])
+def test_corrupt_chunks_in_canary_padded_device_buffers(pkg, oracle, fixture):
+    """Random damage to reference-written Zlib / Zstd chunks, device-resident, output in canary-padded buffers: the verdict
+    equals the oracle's, accepted chunks carry the oracle's bytes, and nothing is written outside [dest, dest + nbytes) -
+    the literal scatter and the batched match execution of the two entropy-coded decoders included."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(41)
+    PAD = 4096
+    z = np.load(os.path.join(GOLDEN, fixture))
+    metas = [m.split(",") for m in z["meta"]]
+    for k in (0, 1, 2, 5, 9):
+        good = z[f"c{k}"]; n = int(metas[k][1])
+        nblocks_hdr = 16 + 4 * ((n + int(good[8:12].view("<i4")[0]) - 1) // int(good[8:12].view("<i4")[0]))
+        chunks, want = [], []
+        for trial in range(24):
+            c = good.copy()
+            cnt = int(rng.integers(1, 6))
+            pos = rng.integers(nblocks_hdr, c.size, cnt)
+            c[pos] = rng.integers(0, 256, cnt, dtype=np.uint8)
+            ro, oo = orc_decompress(oracle, c, n)
+            want.append((ro, oo.copy())); chunks.append(c)
+        d_src = [torch.from_numpy(c).to(dev) for c in chunks]
+        d_dst = [torch.full((n + 2 * PAD,), 0xA5, dtype=torch.uint8, device=dev) for _ in chunks]
+        b = pkg.DeviceBatch([t.data_ptr() for t in d_src], [c.size for c in chunks], [t.data_ptr() + PAD for t in d_dst], [n] * len(chunks))
+        assert b.decompress() == 0
+        for i, (rg, (ro, oo)) in enumerate(zip(b.results(), want)):
+            out = d_dst[i].cpu().numpy()
+            assert (out[:PAD] == 0xA5).all() and (out[PAD + n:] == 0xA5).all(), (fixture, k, i, "canary")
+            if ro == n:
+                assert rg == n and np.array_equal(out[PAD:PAD + n], oo), (fixture, k, i, rg)
+            else:
+                assert rg < 0, (fixture, k, i, rg, ro)
+        r, out = pkg.decompress(good, n)
+        assert r == n
