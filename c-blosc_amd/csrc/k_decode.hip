@@ -154,6 +154,120 @@ __device__ __forceinline__ bool span_long_match(gu8* out, uint32_t mpos, uint32_
   return true;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Dependent near matches of a step, resolved in LDS.  Bit-shuffled data decodes into streams whose matches reach back a few
+// dozen bytes (reference-written config #3 chunks: median distance 44): the source of sequence r of a step lies in the output
+// of sequences r-1, r-2 of the SAME step, so 9 in 10 matches took the in-order path - one store -> load round trip through
+// memory each (2300 cycles; 75 % of that kernel's time).  When a step has two or more such matches and all of them start at
+// most LZB_HIST bytes before the step's output, the step is assembled in an LDS buffer instead: the history bytes come in
+// with ONE load (in flight together with the loads of the independent matches), literals and independent matches are written
+// to the buffer as well as to memory, and the dependent matches become LDS copies in stream order - a match whose distance
+// is shorter than its length is the periodic extension of the bytes before it, so every lane reads only bytes that are
+// already final - whose values the lanes also store to memory.  No round trip between them.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t LZB_HIST = 1024u, LZB_STEP = 2048u, LZB_BYTES = LZB_HIST + LZB_STEP + 128u;   // LDS bytes per wave behind the 64 scratch dwords
+#ifndef BAMD_DEC_LDS_STEP
+#define BAMD_DEC_LDS_STEP 1
+#endif
+#ifndef BAMD_LZB_MIN_REST
+#define BAMD_LZB_MIN_REST 4     // dependent matches a step needs before the LDS form pays (2: BloscLZ byte-shuffled bench19 +8 %, see profiles/r02g_lds_step.txt)
+#endif
+constexpr int LZB_MIN_REST = BAMD_LZB_MIN_REST;
+typedef volatile __attribute__((address_space(3))) uint8_t lds_u8;
+template <int N>
+__device__ __forceinline__ uint32_t row_max16(uint32_t v) {     // maximum over the 16 lanes of a DPP row, valid in lane 15 of the row
+  uint32_t t;
+  t = row_shr<1>(v); v = t > v ? t : v; t = row_shr<2>(v); v = t > v ? t : v;
+  t = row_shr<4>(v); v = t > v ? t : v; t = row_shr<8>(v); v = t > v ? t : v;
+  return v;
+}
+
+// the LDS-assembled form of steps 3-5 of lz4_batch_step / blz_batch_step (a real call: the common step must not pay for its
+// registers).  fast_r / rest_r: this lane's sequence is an independent short match / a match that has to run in stream order.
+__device__ __attribute__((noinline)) void lz4_step_lds(gu8* out_, volatile uint32_t* scr_generic, uint32_t B, uint32_t c, uint32_t excl, uint32_t ll_r, uint32_t ml_r,
+                                                       uint32_t off_r, uint32_t mrel_r, uint32_t ext_r, bool fast_r, bool rest_r, uint32_t cnt_, uint32_t consumed_, uint32_t op_, uint32_t H_, int lane) {
+  volatile __attribute__((address_space(3))) uint32_t* scr = (volatile __attribute__((address_space(3))) uint32_t*)scr_generic;   // LDS
+  gu8* out = uni_ptr(out_);
+  const uint32_t cnt = uni(cnt_), consumed = uni(consumed_), op = uni(op_), H = uni(H_);
+  const bool use_lds = true;
+  lds_u8* lb = (lds_u8*)(scr + 64);
+  uint4 hv = make_uint4(0, 0, 0, 0);
+  const bool h16 = 16u * (uint32_t)lane + 16u <= H;
+  if (h16) hv = g_ld16(out + op - H + 16u * (uint32_t)lane);                           // history: one load, with the ones below
+  // ---- 3. literals: token info goes back to byte-lane space through a 64-dword LDS scratch, then one
+  //         scattered byte store covers the literals of every accepted sequence ----
+  // (volatile: lanes talk to each other through this scratch; without it the compiler forwards a lane's
+  //  own "= 0" store to its later load, which is legal for unsynchronised memory and wrong here)
+  // scratch word of a token: valid | length-extension flag << 25 | literal count << 16 | output offset (< 2^16: 16 x 542)
+  scr[lane] = 0u;
+  if ((uint32_t)lane < cnt) scr[c] = 0x80000000u | excl | (ll_r << 16) | (ext_r << 25);
+  const uint64_t mask = __ballot(scr[lane] >> 31);
+  {
+    const uint64_t below = mask & ((2ull << lane) - 1ull);     // accepted tokens at or before this byte lane
+    const uint32_t s = 63u - (uint32_t)__builtin_clzll(below | 1ull);
+    const uint32_t inf = scr[s];
+    const uint32_t k = (uint32_t)lane - s - 1u - ((inf >> 25) & 1u);
+    if ((uint32_t)lane < consumed && (uint32_t)lane > s + ((inf >> 25) & 1u) && k < ((inf >> 16) & 0x1ffu)) {
+      out[op + (inf & 0xffffu) + k] = (uint8_t)B;
+      if (use_lds) lb[H + (inf & 0xffffu) + k] = (uint8_t)B;
+    }
+  }
+  // ---- 4. short independent matches: 4 lanes per sequence, overlapping 4/8/16-byte pieces ----
+  {
+    const uint32_t r = (uint32_t)lane >> 2, q = (uint32_t)lane & 3u;
+    const uint32_t fA = bperm(r, fast_r ? (ml_r | 0x200u | (mrel_r << 10)) : 0u);
+    const uint32_t fB = bperm(r, off_r);
+    const uint32_t mlen = fA & 0x1ffu;
+    const bool go = (fA & 0x200u) != 0u;
+    gu8* d = out + op + (fA >> 10);
+    const gu8* sp = d - fB;
+    const bool w16 = go && mlen >= 16u && q < ((mlen + 15u) >> 4);
+    const bool w8 = go && mlen >= 8u && mlen < 16u && q < 2u;
+    const bool w4 = go && mlen < 8u && q < 2u;
+    const uint32_t np16 = (mlen + 15u) >> 4;
+    const uint32_t po16 = (q == np16 - 1u) ? mlen - 16u : 16u * q;
+    const uint32_t po8 = q ? mlen - 8u : 0u, po4 = q ? mlen - 4u : 0u;
+    uint4 v16 = make_uint4(0, 0, 0, 0); uint64_t v8 = 0; uint32_t v4 = 0;
+    if (w16) v16 = g_ld16(sp + po16);
+    if (w8) v8 = g_ld8(sp + po8);
+    if (w4) v4 = g_ld4(sp + po4);
+    if (w16) g_st16(d + po16, v16);
+    if (w8) *(BAMD_GAS u64una*)(d + po8) = v8;
+    if (w4) g_st4(d + po4, v4);
+    if (use_lds) {                                     // the same pieces into the step buffer (byte-unaligned LDS stores: fine on gfx950)
+      lds_u8* l = lb + H + (fA >> 10);
+      if (w16) { v4u32 t = {v16.x, v16.y, v16.z, v16.w}; *(volatile __attribute__((address_space(3))) v4u32_una*)(l + po16) = t; }
+      if (w8) *(volatile __attribute__((address_space(3))) u64una*)(l + po8) = v8;
+      if (w4) *(volatile __attribute__((address_space(3))) u32una*)(l + po4) = v4;
+    }
+  }
+  if (use_lds) {
+    if (h16) { v4u32 t = {hv.x, hv.y, hv.z, hv.w}; *(volatile __attribute__((address_space(3))) v4u32_una*)(lb + 16u * (uint32_t)lane) = t; }
+    const uint32_t hfull = H & ~15u;                   // H < 16-multiple only when op itself is small
+    if (hfull + (uint32_t)lane < H) lb[hfull + (uint32_t)lane] = out[op - H + hfull + (uint32_t)lane];
+  }
+  // ---- 5. everything else (long, or reading bytes this very step produces), in stream order ----
+  uint32_t rest = (uint32_t)__ballot(rest_r);
+  while (rest) {
+    const int sl = __builtin_ctz(rest);
+    rest &= rest - 1u;
+    const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)ml_r, sl);
+    const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)off_r, sl);
+    const uint32_t mr = (uint32_t)__builtin_amdgcn_readlane((int)mrel_r, sl);
+    {
+      // periodic extension of the o bytes before the match (o >= m: a plain copy); floor(k / o) by multiplication - exact for
+      // k < 512 because the quotient is only needed when o < m <= 273
+      const uint32_t M = o < m ? (1u << 20) / o + 1u : 0u;
+      for (uint32_t k = (uint32_t)lane; k < m; k += 64u) {
+        const uint32_t kk = o < m ? k - ((k * M) >> 20) * o : k;
+        const uint8_t v = lb[H + mr - o + kk];
+        lb[H + mr + k] = v;
+        out[op + mr + k] = v;
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ uint32_t lz4_batch_step(const Window& w, gu8* out, volatile uint32_t* scr_generic, uint32_t& ip, uint32_t& op,
                                                    uint32_t cap, uint32_t n, int lane, SpanCtx& sp PROF_ARG) {
   volatile __attribute__((address_space(3))) uint32_t* scr = (volatile __attribute__((address_space(3))) uint32_t*)scr_generic;   // LDS
@@ -206,6 +320,26 @@ __device__ __forceinline__ uint32_t lz4_batch_step(const Window& w, gu8* out, vo
   if (sp.hi && __ballot((uint32_t)lane < cnt && op + mrel_r - off_r < sp.hi)) span_materialize(out, lane, sp);
   const uint32_t consumed = (uint32_t)__builtin_amdgcn_readlane((int)nxt_r, (int)(cnt - 1u));
   const uint32_t acc = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(cnt - 1u));
+  // ---- two or more matches that are not independent of this step, all starting at most LZB_HIST bytes before its output:
+  //      the step is assembled in LDS (lz4_step_lds, see above) ----
+  if (BAMD_DEC_LDS_STEP && acc <= LZB_STEP && !sp.hi) {
+    const bool fast0 = (uint32_t)lane < cnt && ml_r <= 64u && off_r >= mrel_r + ml_r;
+    const bool rest_r = (uint32_t)lane < cnt && !fast0;
+    if (__builtin_popcountll(__ballot(rest_r)) >= LZB_MIN_REST) {
+      const uint32_t reach = rest_r ? (off_r > mrel_r ? off_r - mrel_r : 0u) : 0u;      // bytes before op the match needs
+      const uint32_t hneed = (uint32_t)__builtin_amdgcn_readlane((int)row_max16<0>(reach), 15);
+      if (hneed <= LZB_HIST) {
+        uint32_t H = (hneed + 15u) & ~15u;
+        if (H > op) H = op;                             // hneed <= op by the acceptance test: only the rounding is cut
+        lz4_step_lds(out, scr_generic, B, c, excl, ll_r, ml_r, off_r, mrel_r, ext_r, fast0, rest_r, cnt, consumed, op, H, lane);
+        PROF_ADD(0, 1); PROF_ADD(1, cnt);
+        ip += consumed;
+        op += acc;
+        PROF_LAP(11);
+        return cnt;
+      }
+    }
+  }
   // ---- 3. literals: token info goes back to byte-lane space through a 64-dword LDS scratch, then one
   //         scattered byte store covers the literals of every accepted sequence ----
   // (volatile: lanes talk to each other through this scratch; without it the compiler forwards a lane's
@@ -448,6 +582,24 @@ __device__ __forceinline__ uint32_t blz_batch_step(const Window& w, gu8* out, vo
   if (sp.hi && __ballot((uint32_t)lane < cnt && ml_r != 0u && op + excl - off_r < sp.hi)) span_materialize(out, lane, sp);
   const uint32_t consumed = (uint32_t)__builtin_amdgcn_readlane((int)nxt_r, (int)(cnt - 1u));
   const uint32_t acc = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(cnt - 1u));
+  // ---- two or more dependent matches close behind the output: the step is assembled in LDS (lz4_step_lds) ----
+  if (BAMD_DEC_LDS_STEP && acc <= LZB_STEP && !sp.hi) {
+    const bool match0 = (uint32_t)lane < cnt && ml_r != 0u;
+    const bool fast0 = match0 && ml_r >= 4u && ml_r <= 64u && off_r >= excl + ml_r;
+    const bool rest0 = match0 && !fast0;
+    if (__builtin_popcountll(__ballot(rest0)) >= LZB_MIN_REST) {
+      const uint32_t reach = rest0 ? (off_r > excl ? off_r - excl : 0u) : 0u;
+      const uint32_t hneed = (uint32_t)__builtin_amdgcn_readlane((int)row_max16<0>(reach), 15);
+      if (hneed <= LZB_HIST) {
+        uint32_t H = (hneed + 15u) & ~15u;
+        if (H > op) H = op;
+        lz4_step_lds(out, scr_generic, B, c, excl, ll_r, ml_r, off_r, excl, 0u, fast0, rest0, cnt, consumed, op, H, lane);
+        tp += consumed;
+        op += acc;
+        return cnt;
+      }
+    }
+  }
   // ---- literals of every accepted run in one scattered byte store ----
   scr[lane] = 0u;
   if ((uint32_t)lane < cnt) scr[c] = 0x80000000u | excl | (ll_r << 16);
@@ -787,7 +939,7 @@ __global__ __launch_bounds__(64 * DEC_WAVES, BAMD_DEC_MINWAVES) void k_decode_st
     , uint32_t* __restrict__ profbuf
 #endif
     ) {
-  __shared__ uint32_t scr[DEC_WAVES][64];   // per-wave scratch of the batched LZ4 step
+  __shared__ uint32_t scr[DEC_WAVES][64 + LZB_BYTES / 4];   // per-wave scratch of the batched LZ4 step + its LDS step buffer (lz4_batch_step)
   static_assert(DEC_WAVES == 1, "one stream per wave, one wave per workgroup");
   const int lane = threadIdx.x & 63;
   // HW_REG_XCC_ID[3:0]; queue 0 for everybody in the single-queue fallback (no in-kernel hand-offs there)

@@ -9,16 +9,17 @@ mod.LIB_PATH = os.path.join(ROOT, "c-blosc_amd", "libblosc_amd_prof.so")
 lib = mod.load()
 nchunks = int(os.environ.get("CHUNKS", "128")); csz = 64 << 20
 dname = os.environ.get("DATA", "bench19"); who = os.environ.get("WRITER", "stock")
+TS = int(os.environ.get("TYPESIZE", "8")); SHUF = int(os.environ.get("SHUFFLE", "1"))
 host = DATASETS[dname](csz)
 dev = torch.device("cuda:0")
 if who == "stock":
     R = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libblosc_ref.so"))
     R.blosc_compress_ctx.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int]
     tmp = np.empty(csz + 16, np.uint8)
-    r = R.blosc_compress_ctx(5, 1, 8, csz, host.ctypes.data, tmp.ctypes.data, csz + 16, b"lz4", 0, 1)
+    r = R.blosc_compress_ctx(5, SHUF, TS, csz, host.ctypes.data, tmp.ctypes.data, csz + 16, b"lz4", 0, 1)
     chunk = tmp[:r].copy()
 else:
-    r, chunk = mod.compress(host, 8, 5, 1, b"lz4")
+    r, chunk = mod.compress(host, TS, 5, SHUF, b"lz4")
 comp = torch.empty((nchunks, csz + 256), dtype=torch.uint8, device=dev)
 comp[:, :r].copy_(torch.from_numpy(chunk).to(dev).unsqueeze(0).expand(nchunks, r))
 back = torch.empty((nchunks, csz), dtype=torch.uint8, device=dev)
@@ -32,8 +33,8 @@ d = mod.profile_get("k_decode_streams")
 p = np.fromfile("/tmp/decprof.bin", np.uint32).reshape(-1, 16).astype(np.float64)
 print(f"{who} {dname}: kernel {d[0]/d[1]:.3f} ms (instrumented), streams {p.shape[0]}")
 names = {0: "batches", 1: "batch_seq", 2: "others", 3: "scalar_seq", 8: "cyc_parse", 9: "cyc_walk", 10: "cyc_lit+pieces", 11: "cyc_others", 12: "cyc_scalar", 13: "cyc_rest"}
-for plane in range(8):
-    q = p[plane::8].mean(axis=0)
+for plane in range(TS):
+    q = p[plane::TS].mean(axis=0)
     tot = q[8:14].sum()
     print(f" plane {plane}: " + "  ".join(f"{names[i]}={q[i]:.0f}" for i in names) + f"  | total cyc {tot:.0f}  cyc/seq {tot / max(q[1] + q[3], 1):.0f}")
 allm = p.mean(axis=0); print(" max stream total cycles:", p[:, 8:14].sum(axis=1).max(), " mean:", p[:, 8:14].sum(axis=1).mean())

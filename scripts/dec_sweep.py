@@ -12,7 +12,7 @@ host = DATASETS[dname](csz)
 R = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libblosc_ref.so"))
 R.blosc_compress_ctx.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int]
 tmp = np.empty(csz + 16, np.uint8)
-r = R.blosc_compress_ctx(int(os.environ.get("CLEVEL", "5")), 1, int(os.environ.get("TYPESIZE", "8")), csz, host.ctypes.data, tmp.ctypes.data, csz + 16, os.environ.get("CODEC", "lz4").encode(), 0, 1)
+r = R.blosc_compress_ctx(int(os.environ.get("CLEVEL", "5")), int(os.environ.get("SHUFFLE", "1")), int(os.environ.get("TYPESIZE", "8")), csz, host.ctypes.data, tmp.ctypes.data, csz + 16, os.environ.get("CODEC", "lz4").encode(), 0, 1)
 dev = torch.device("cuda:0")
 comp = torch.empty((nchunks, csz + 256), dtype=torch.uint8, device=dev)
 comp[:, :r].copy_(torch.from_numpy(tmp[:r].copy()).to(dev).unsqueeze(0).expand(nchunks, r))
@@ -24,7 +24,7 @@ for _ in range(3): bd.decompress()
 lib.blosc_gpu_profile(0)
 assert bd.results() == [csz] * nchunks
 ok = bool((back[0] == torch.from_numpy(host).to(dev)).all()) and bool((back[-1] == torch.from_numpy(host).to(dev)).all())
-names = ["k_decode_plan", "k_classify_blocks", "k_decode_streams", "k_decode_blocks", "k_decode_blocks8", "k_unshuffle", "k_zstd_entropy", "k_zstd_exec", "k_zstd_streams", "k_zlib_streams"]
+names = ["k_decode_plan", "k_classify_blocks", "k_decode_streams", "k_decode_blocks", "k_decode_blocks8", "k_unshuffle", "k_bitunshuffle", "k_zstd_entropy", "k_zstd_exec", "k_zstd_streams", "k_zlib_streams"]
 tot = 0.0; parts = []
 for k in names:
     ms, cnt = mod.profile_get(k)
