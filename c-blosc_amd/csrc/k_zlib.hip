@@ -56,12 +56,7 @@ __device__ __forceinline__ void zl_exec_matches(gu8* out, ZlPend& p, int lane) {
   const bool mine = (uint32_t)lane < p.nm;
   const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)p.mpos, 0);
   const bool indep = mine && p.mlen <= ZL_LANE_COPY_MAX && p.moff >= p.mlen && p.mpos - p.moff + p.mlen <= first;
-  if (indep) {
-    gu8* d = out + p.mpos; const gu8* s = d - p.moff;
-    uint32_t k = 0;
-    for (; k + 16u <= p.mlen; k += 16u) g_st16(d + k, g_ld16(s + k));
-    for (; k < p.mlen; k++) d[k] = s[k];
-  }
+  if (indep) { gu8* d = out + p.mpos; lane_copy_disjoint(d, d - p.moff, p.mlen); }
   uint32_t rest = (uint32_t)__ballot(mine && !indep);
   while (rest) {
     const int sl = __builtin_ctz(rest);

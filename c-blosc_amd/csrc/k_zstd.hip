@@ -87,19 +87,9 @@ __device__ __forceinline__ bool zstd_exec16(uint32_t ll_b, uint32_t ml_b, uint32
     wave_copy_disjoint(out + op + (uint32_t)__builtin_amdgcn_readlane((int)excl, sl), lit + lp + (uint32_t)__builtin_amdgcn_readlane((int)lexcl, sl),
                        (uint32_t)__builtin_amdgcn_readlane((int)ll, sl), lane);
   }
-  if (mine && ll && ll <= 256u) {                         // literals: disjoint buffers, every lane its own run
-    const gu8* s = lit + lp + lexcl; gu8* d = out + op + excl;
-    uint32_t k = 0;
-    for (; k + 16u <= ll; k += 16u) g_st16(d + k, g_ld16(s + k));
-    for (; k < ll; k++) d[k] = s[k];
-  }
+  if (mine && ll && ll <= 256u) lane_copy_disjoint(out + op + excl, lit + lp + lexcl, ll);   // literals: disjoint buffers, every lane its own run
   const bool indep = mine && ml <= 128u && off >= excl + tot;      // source ends at or before op: nothing of this group in it
-  if (indep) {
-    gu8* d = out + op + excl + ll; const gu8* s = d - off;          // off >= ml: source and destination do not overlap
-    uint32_t k = 0;
-    for (; k + 16u <= ml; k += 16u) g_st16(d + k, g_ld16(s + k));
-    for (; k < ml; k++) d[k] = s[k];
-  }
+  if (indep) { gu8* d = out + op + excl + ll; lane_copy_disjoint(d, d - off, ml); }   // source ends at or before op: disjoint from everything this group writes
   uint32_t rest = (uint32_t)__ballot(mine && !indep) & 0xffffu;
   while (rest) {
     const int sl = __builtin_ctz(rest);

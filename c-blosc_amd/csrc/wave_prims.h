@@ -137,6 +137,39 @@ __device__ __forceinline__ void wave_match_copy(gu8* out, uint32_t pos, uint32_t
   }
 }
 
+// ---- copy of n bytes between DISJOINT buffers by ONE lane (its own literal run / independent match; other lanes copy theirs at the
+// same time): 64 bytes per round with all loads ahead of the stores, and overlapping pieces instead of a byte tail - a
+// byte-at-a-time tail is up to 15 dependent memory round trips that every lane of the wave waits for ----
+__device__ __forceinline__ void lane_copy_disjoint(gu8* d, const gu8* s, uint32_t n) {
+  if (n >= 16u) {
+    uint32_t k = 0;
+    for (; k + 64u <= n; k += 64u) {
+      const uint4 a = ld16u(s + k), b = ld16u(s + k + 16), c = ld16u(s + k + 32), e = ld16u(s + k + 48);
+      st16u(d + k, a); st16u(d + k + 16, b); st16u(d + k + 32, c); st16u(d + k + 48, e);
+    }
+    // 0..63 bytes left: up to three whole pieces and one that ends exactly at n (it may overlap the one before)
+    const uint32_t r = n - k;
+    uint4 a = make_uint4(0, 0, 0, 0), b = a, c = a;
+    if (r >= 16u) a = ld16u(s + k);
+    if (r >= 32u) b = ld16u(s + k + 16);
+    if (r >= 48u) c = ld16u(s + k + 32);
+    const uint4 z = ld16u(s + n - 16u);
+    if (r >= 16u) st16u(d + k, a);
+    if (r >= 32u) st16u(d + k + 16, b);
+    if (r >= 48u) st16u(d + k + 32, c);
+    st16u(d + n - 16u, z);
+  } else if (n >= 8u) {
+    const uint64_t a = g_ld8(s), b = g_ld8(s + n - 8u);
+    *(BAMD_GAS u64una*)d = a; *(BAMD_GAS u64una*)(d + n - 8u) = b;
+  } else if (n >= 4u) {
+    const uint32_t a = g_ld4(s), b = g_ld4(s + n - 4u);
+    g_st4(d, a); g_st4(d + n - 4u, b);
+  } else if (n) {
+    const uint8_t a = s[0], b = s[n >> 1], c = s[n - 1u];
+    d[0] = a; d[n >> 1] = b; d[n - 1u] = c;
+  }
+}
+
 // ---- Adler-32 (RFC 1950) of a buffer, all lanes: used by the zlib decoder (k_zlib.hip) and encoder (k_encode.hip) ----
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
   for (int m = 32; m >= 1; m >>= 1) v += (uint32_t)__shfl_xor((int)v, m, 64);
