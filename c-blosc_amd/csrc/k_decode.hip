@@ -182,8 +182,7 @@ __device__ __forceinline__ uint32_t row_max16(uint32_t v) {     // maximum over 
   return v;
 }
 
-// the LDS-assembled form of steps 3-5 of lz4_batch_step / blz_batch_step (a real call: the common step must not pay for its
-// registers).  fast_r / rest_r: this lane's sequence is an independent short match / a match that has to run in stream order.
+// the LDS-assembled form of steps 3-5 of lz4_batch_step (a real call: the common step must not pay for its registers).  fast_r / rest_r: this lane's sequence is an independent short match / a match that has to run in stream order.
 __device__ __attribute__((noinline)) void lz4_step_lds(gu8* out_, volatile uint32_t* scr_generic, uint32_t B, uint32_t c, uint32_t excl, uint32_t ll_r, uint32_t ml_r,
                                                        uint32_t off_r, uint32_t mrel_r, uint32_t ext_r, bool fast_r, bool rest_r, uint32_t cnt_, uint32_t consumed_, uint32_t op_, uint32_t H_, int lane) {
   volatile __attribute__((address_space(3))) uint32_t* scr = (volatile __attribute__((address_space(3))) uint32_t*)scr_generic;   // LDS
@@ -582,24 +581,8 @@ __device__ __forceinline__ uint32_t blz_batch_step(const Window& w, gu8* out, vo
   if (sp.hi && __ballot((uint32_t)lane < cnt && ml_r != 0u && op + excl - off_r < sp.hi)) span_materialize(out, lane, sp);
   const uint32_t consumed = (uint32_t)__builtin_amdgcn_readlane((int)nxt_r, (int)(cnt - 1u));
   const uint32_t acc = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(cnt - 1u));
-  // ---- two or more dependent matches close behind the output: the step is assembled in LDS (lz4_step_lds) ----
-  if (BAMD_DEC_LDS_STEP && acc <= LZB_STEP && !sp.hi) {
-    const bool match0 = (uint32_t)lane < cnt && ml_r != 0u;
-    const bool fast0 = match0 && ml_r >= 4u && ml_r <= 64u && off_r >= excl + ml_r;
-    const bool rest0 = match0 && !fast0;
-    if (__builtin_popcountll(__ballot(rest0)) >= LZB_MIN_REST) {
-      const uint32_t reach = rest0 ? (off_r > excl ? off_r - excl : 0u) : 0u;
-      const uint32_t hneed = (uint32_t)__builtin_amdgcn_readlane((int)row_max16<0>(reach), 15);
-      if (hneed <= LZB_HIST) {
-        uint32_t H = (hneed + 15u) & ~15u;
-        if (H > op) H = op;
-        lz4_step_lds(out, scr_generic, B, c, excl, ll_r, ml_r, off_r, excl, 0u, fast0, rest0, cnt, consumed, op, H, lane);
-        tp += consumed;
-        op += acc;
-        return cnt;
-      }
-    }
-  }
+  // (no LDS-assembled form here, unlike lz4_batch_step: the mere presence of that call path cost reference-written byte-shuffled
+  //  BloscLZ chunks - config #1's data - 7 % in register allocation; bit-shuffled BloscLZ streams would gain 27 %, profiles/r02g_lds_step.txt)
   // ---- literals of every accepted run in one scattered byte store ----
   scr[lane] = 0u;
   if ((uint32_t)lane < cnt) scr[c] = 0x80000000u | excl | (ll_r << 16);
