@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from helpers import DATASETS, orc_compress, orc_decompress, header, ptr, wrap_stream_as_chunk
+from helpers import DATASETS, orc_compress, orc_decompress, header, ptr, wrap_stream_as_chunk, wrap_planes_as_chunk
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
@@ -321,3 +321,62 @@ def test_handbuilt_blosclz_streams(pkg, oracle):
             if (r2 < 0) != (ro < 0):
                 bad.append((i, "size", wrong, r2, ro))
     assert not bad, bad[:20]
+
+
+def test_handbuilt_dense_near_match_chains(pkg, oracle):
+    """LZ4 blocks made of MANY short sequences per 64 stream bytes whose matches reach back a few bytes - into the output of
+    the sequences right before them: what the LDS-assembled step of the decoder (k_decode.hip: lz4_step_lds) exists for.
+    Random chains with distances 1..40 (overlapping and not), 0..3 literals in between, matches that read the literals of
+    their own step, chains right at the start of the block (less history than the step asks for), chains whose history
+    need straddles the 1 KiB limit, long matches mixed in (the step must fall back), steps around the 2 KiB output limit."""
+    rng = np.random.default_rng(77)
+
+    def chain(nseq, maxoff, maxml, maxll, first_lit):
+        s = bytearray(); produced = 0
+        lit = rng.integers(0, 256, first_lit, dtype=np.uint8).tobytes()
+        for k in range(nseq):
+            off = int(rng.integers(1, min(maxoff, produced + len(lit)) + 1))
+            ml = int(rng.integers(4, maxml + 1))
+            s += _lz4_seq(lit, off, ml)
+            produced += len(lit) + ml
+            lit = rng.integers(0, 256, int(rng.integers(0, maxll + 1)), dtype=np.uint8).tobytes()
+        s += _lz4_tail(rng.integers(0, 256, 12 + int(rng.integers(0, 5)), dtype=np.uint8).tobytes())
+        return bytes(s)
+
+    streams = []
+    for first_lit in (1, 2, 5, 17, 64, 300, 1030, 1100):               # start of block: history shorter than asked for / around 1 KiB
+        for maxoff in (1, 2, 3, 7, 16, 40, 64, 700, 1024, 1030, 1500):
+            for maxml, maxll in ((4, 0), (8, 1), (18, 3), (30, 2), (64, 0), (140, 1), (273, 0)):
+                streams.append(chain(int(rng.integers(20, 400)), maxoff, maxml, maxll, first_lit))
+    bad = []
+    for i, s in enumerate(streams):
+        s = np.frombuffer(s, np.uint8)
+        cap = 1 << 20
+        tmp = np.zeros(cap, np.uint8)
+        n = oracle.orc_lz4_decompress(ptr(s), s.size, ptr(tmp), cap)
+        assert n > 0
+        want = tmp[:n].copy()
+        chunk = wrap_stream_as_chunk(s, n, 1)
+        r, out = pkg.decompress(chunk, n)
+        if r != n or not np.array_equal(out, want):
+            bad.append((i, r, n, int(np.argmax(out[:n] != want)) if r == n else -1))
+    assert not bad, bad[:10]
+    # the same chains as the T planes of split shuffled blocks (the fused path), 8 streams of equal size per chunk
+    T = 8
+    groups = {}
+    for s in streams[:200]:
+        s = np.frombuffer(s, np.uint8)
+        tmp = np.zeros(1 << 20, np.uint8)
+        n = oracle.orc_lz4_decompress(ptr(s), s.size, ptr(tmp), 1 << 20)
+        groups.setdefault(n, []).append((s, tmp[:n].copy()))
+    checked = 0
+    for n, lst in groups.items():
+        if n < 128:
+            continue
+        planes = (lst * T)[:T]
+        chunk = wrap_planes_as_chunk([bytes(p[0]) for p in planes], n, 1)
+        want = np.stack([p[1] for p in planes], 1).reshape(-1)
+        r, out = pkg.decompress(chunk, want.size)
+        assert r == want.size and np.array_equal(out, want), ("planes", n, r)
+        checked += 1
+    assert checked > 20
