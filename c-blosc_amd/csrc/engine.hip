@@ -235,6 +235,10 @@ static bool span_enabled() { static const bool on = !(getenv("BLOSC_AMD_SPANS") 
 // data set so far (profiles/r02_b_block_decoder.md); the whole GPU suite passes with it on (tests/test_gpu_modes.py).
 static bool blockdec_enabled() { static const bool on = getenv("BLOSC_AMD_BLOCKDEC") && atoi(getenv("BLOSC_AMD_BLOCKDEC")) != 0; return on; }
 // BLOSC_AMD_PERIODIC=0: every plane goes through the match finder (A/B switch for the periodic-plane shortcut of the fused shuffle)
+#ifndef BAMD_LZ4HC_DEFAULT
+#define BAMD_LZ4HC_DEFAULT 0   // "lz4hc" without BLOSC_AMD_LZ4HC in the environment: 1 = LZ4HC-grade search, 0 = plain LZ4 match finder
+#endif
+static bool lz4hc_search_enabled() { const char* e = getenv("BLOSC_AMD_LZ4HC"); return e ? atoi(e) != 0 : (BAMD_LZ4HC_DEFAULT != 0); }
 static bool periodic_enabled() { static const bool on = !(getenv("BLOSC_AMD_PERIODIC") && atoi(getenv("BLOSC_AMD_PERIODIC")) == 0); return on; }
 // BLOSC_AMD_ZSTD2: 2 (default) = two-phase path, 16 frames per wave, tables in a global scratch (k_zstd2.hip);
 // 1 = the same with the tables in LDS (one wave per CU); 0 = one wave per frame for everything (k_zstd_streams).
@@ -351,7 +355,11 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   const size_t o_stage = cv.take(stage_bytes + 256);
   // Zstd: the predefined FSE tables and one sequence scratch per persistent wave
   const bool zstd = p.codec == kZstd, zlibc = p.codec == kZlib;
-  static const int enc_wpc = getenv("BLOSC_AMD_ENC_WPC") ? atoi(getenv("BLOSC_AMD_ENC_WPC")) : ENC_WAVES_PER_CU;
+  // "lz4hc": the LZ4HC-grade search of k_encode.hip (lz4hc_encode_wave); BLOSC_AMD_LZ4HC=0 serves the name with the plain LZ4
+  // match finder at its highest effort instead (read per call, so that a test can compare the two in one process)
+  const bool hc = p.codec == kLZ4HC && lz4hc_search_enabled();
+  static const int enc_wpc_lz = getenv("BLOSC_AMD_ENC_WPC") ? atoi(getenv("BLOSC_AMD_ENC_WPC")) : ENC_WAVES_PER_CU;
+  const int enc_wpc = hc ? HC_WAVES_PER_CU : enc_wpc_lz;
   const size_t zwaves = zstd ? (size_t)(st.cus > 0 ? st.cus : 256) * (size_t)enc_wpc : 0;
   const size_t o_ctabs = cv.take(sizeof(zenc::CTabs) + 64);
   const size_t o_seqbufs = cv.take(zwaves * ZS_SEQCAP * sizeof(uint64_t) + 64);
@@ -438,7 +446,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
     hipLaunchKernelGGL(k_bitshuffle, dim3((unsigned)nblk, (unsigned)tiles_bit), dim3(FT_THREADS), 0, stream, d_chunks, d_blocks, bitfast ? 1 : 0);
   }
   if (nstr) {
-    ProfScope ps(st, stream, zstd ? "k_zstd_encode" : (zlibc ? "k_zlib_encode" : "k_encode_streams"));
+    ProfScope ps(st, stream, zstd ? "k_zstd_encode" : (zlibc ? "k_zlib_encode" : (hc ? "k_lz4hc_encode" : "k_encode_streams")));
     const int32_t* d_qoff = (const int32_t*)(D + o_queues); const int32_t* d_qlist = d_qoff + 9;
     uint32_t* d_ready = (uint32_t*)(D + o_ready);
     const size_t ntasks = queues.size() - 9;
@@ -447,6 +455,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
     if (getenv("BLOSC_AMD_ENC_PROFILE")) { (void)hipMalloc((void**)&d_prof, nstr * 64); (void)hipMemsetAsync(d_prof, 0, nstr * 64, stream); }
     if (zstd) hipLaunchKernelGGL(k_encode_streams_t<ENC_ZSTD>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)(D + o_seqbufs), (const zenc::CTabs*)(D + o_ctabs), 0, d_prof);
     else if (zlibc) hipLaunchKernelGGL(k_encode_streams_t<ENC_ZLIB>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)nullptr, (const zenc::CTabs*)nullptr, 0, d_prof);
+    else if (hc) hipLaunchKernelGGL(k_encode_streams_t<ENC_HC>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)nullptr, (const zenc::CTabs*)nullptr, periodic_enabled() ? 1 : 0, d_prof);
     else hipLaunchKernelGGL(k_encode_streams_t<ENC_LZ>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)nullptr, (const zenc::CTabs*)nullptr, periodic_enabled() ? 1 : 0, d_prof);
     if (d_prof) {
       std::vector<uint32_t> h(nstr * 16);
@@ -459,6 +468,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
 #else
     if (zstd) hipLaunchKernelGGL(k_encode_streams_t<ENC_ZSTD>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)(D + o_seqbufs), (const zenc::CTabs*)(D + o_ctabs), 0);
     else if (zlibc) hipLaunchKernelGGL(k_encode_streams_t<ENC_ZLIB>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)nullptr, (const zenc::CTabs*)nullptr, 0);
+    else if (hc) hipLaunchKernelGGL(k_encode_streams_t<ENC_HC>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)nullptr, (const zenc::CTabs*)nullptr, periodic_enabled() ? 1 : 0);
     else hipLaunchKernelGGL(k_encode_streams_t<ENC_LZ>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)nullptr, (const zenc::CTabs*)nullptr, periodic_enabled() ? 1 : 0);
 #endif
   }

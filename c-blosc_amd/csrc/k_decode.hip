@@ -888,7 +888,7 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
   // producers and this consumer share one L2: a store that has completed (vmcnt) is in that L2, and the
   // consumer only has to drop its own L1 lines.  No L2 write-back (`buffer_wbl2`) is needed - with 65 536
   // streams per launch an agent-scope release per stream flushed whole L2s and tripled the kernel time.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  BAMD_WAIT_STORES();
   uint32_t old = 0;
   if (lane == 0) old = __hip_atomic_fetch_add(&blk_done[gb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   old = (uint32_t)__builtin_amdgcn_readlane((int)old, 0);

@@ -602,6 +602,226 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
 }
 
 // ---------------------------------------------------------------------------------------------
+// LZ4HC-grade search ("lz4hc", blosc/blosc.c:422-433 -> LZ4_compress_HC, lz4hc.c): the same LZ4 block format and the same
+// step as above, with the two things the reference's chain search has over a single table probe, in the form a wave can
+// afford (tests/tools/enc_model2.c measures each on the CPU: SURVEY 8d planes, ratio against LZ4_compress_HC level 9):
+//   * several candidates per position: 4-way buckets (FIFO) instead of one entry - positions (4 x u16) and tags (4 x u8) of a
+//     bucket come with one 8-byte and one 4-byte LDS read, all candidates of a lane are fetched together;
+//   * candidates ranked by their TRUE length, not by their first 20 bytes: lanes whose candidates share a distance look
+//     at the same match, so one wave-wide comparison (wave_common_fwd) gives every one of them its exact length;
+//     at most HC_GROUPS such comparisons per step, what is left ranks with 20 bytes as before.
+// What enters the table, the (length - lane) choice and the re-selection behind a short match are those of
+// lz_encode_wave: the model says the reference's other ingredients (every position in the chain, deeper chains, an optimal parse of
+// the step) add nothing on this data once the ranking is exact.
+// ---------------------------------------------------------------------------------------------
+constexpr int HC_HASH_BITS = 11;
+constexpr int HC_SLOTS = 1 << HC_HASH_BITS;
+constexpr int HC_TAB_BYTES = HC_SLOTS * 12;            // 24 KiB per wave: 6 waves per CU
+constexpr int HC_WAVES_PER_CU = (160 * 1024) / HC_TAB_BYTES;
+constexpr int HC_GROUPS = 8;
+constexpr uint32_t HC_RANK_MAX = 1u << 20;             // lengths beyond this rank alike (keeps the selection key inside 32 bits)
+
+struct HcTable {
+  BAMD_LAS uint64_t* pos;     // bucket h: four positions mod 65536, newest in the low 16 bits
+  BAMD_LAS uint32_t* tag;     // bucket h: their four 8-bit tags, newest in the low byte
+  __device__ __forceinline__ void init(void* base) {
+    pos = (BAMD_LAS uint64_t*)base;
+    tag = (BAMD_LAS uint32_t*)((BAMD_LAS uint8_t*)base + 8 * HC_SLOTS);
+  }
+  __device__ __forceinline__ void clear(int lane) {
+    BAMD_LAS uint32_t* w = (BAMD_LAS uint32_t*)pos;
+    for (int k = lane; k < HC_TAB_BYTES / 4; k += 64) w[k] = 0u;
+  }
+  // Lanes of one call that share a bucket all shift the same old content; one of them lands.  Whatever a bucket
+  // holds is only ever a hint: every candidate is compared byte by byte before it is used.
+  __device__ __forceinline__ void put(uint32_t h, uint32_t p, uint32_t t8) {
+    const uint64_t pp = pos[h];
+    const uint32_t tt = tag[h];
+    pos[h] = (pp << 16) | (uint64_t)(p & 0xffffu);
+    tag[h] = (tt << 8) | (t8 & 0xffu);
+  }
+};
+__device__ __forceinline__ uint32_t hc_slot(uint32_t mix) { return mix >> (32 - HC_HASH_BITS); }
+__device__ __forceinline__ uint32_t hc_tag(uint32_t mix) { return (mix << HC_HASH_BITS) >> 24; }
+
+__device__ uint32_t lz4hc_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8* __restrict__ dst, uint32_t cap,
+                                      enc_entry_t* tab_generic, int lane) {
+  HcTable tab;
+  tab.init((void*)tab_generic);
+  if (n < 13u) return 0u;                                     // lz4.c:245-246, :963-964 as in lz_encode_wave
+  const uint32_t last_start = n - 12u;
+  const uint32_t mlimit = n - 5u;
+  const uint32_t minlen = 4u;
+  tab.clear(lane);
+  EncWindow win;
+  win.init(src, n, lane);
+  uint32_t ip = 0, anchor = 0, op = 0, nfail = 0;
+  bool ins_pending = false;
+  while (ip <= last_start) {
+    const uint32_t p = ip + (uint32_t)lane;
+    const bool live = p <= last_start;
+    // ---- own bytes out of the register window (as in lz_encode_wave) ----
+    win.seek(ip, lane);
+    const uint32_t lo = ip >= 4u ? ip - 4u : 0u;
+    const uint32_t rb = lo & ~3u;
+    const uint32_t D = (rb - win.wbase) >> 2;
+    const int gsel = (int)((D + (uint32_t)lane) << 2);
+    const uint32_t ra = (uint32_t)__builtin_amdgcn_ds_bpermute(gsel, (int)win.w0);
+    const uint32_t rc = (uint32_t)__builtin_amdgcn_ds_bpermute(gsel, (int)win.w1);
+    const uint32_t r = (D + (uint32_t)lane < 64u) ? ra : rc;
+    const uint32_t bo0 = ip - rb;
+    const uint32_t bo = bo0 + (uint32_t)lane;
+    const int ksel = (int)((bo >> 2) << 2);
+    const uint32_t x0 = (uint32_t)__builtin_amdgcn_ds_bpermute(ksel, (int)r);
+    const uint32_t x1 = (uint32_t)__builtin_amdgcn_ds_bpermute(ksel + 4, (int)r);
+    const uint32_t x2 = (uint32_t)__builtin_amdgcn_ds_bpermute(ksel + 8, (int)r);
+    const uint32_t x3 = (uint32_t)__builtin_amdgcn_ds_bpermute(ksel + 12, (int)r);
+    const uint32_t x4 = (uint32_t)__builtin_amdgcn_ds_bpermute(ksel + 16, (int)r);
+    const uint32_t x5 = (uint32_t)__builtin_amdgcn_ds_bpermute(ksel + 20, (int)r);
+    const uint32_t sh = bo & 3u;
+    const uint32_t o0 = __builtin_amdgcn_alignbyte(x1, x0, sh), o1 = __builtin_amdgcn_alignbyte(x2, x1, sh);
+    const uint32_t o2 = __builtin_amdgcn_alignbyte(x3, x2, sh), o3 = __builtin_amdgcn_alignbyte(x4, x3, sh);
+    const uint32_t o4 = __builtin_amdgcn_alignbyte(x5, x4, sh);
+    Bytes20 own;
+    own.a = ((uint64_t)o1 << 32) | o0; own.b = ((uint64_t)o3 << 32) | o2; own.c = o4;
+    const uint64_t r01 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)r, 1) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)r, 0);
+    const uint32_t before2 = bo0 >= 2u ? (uint32_t)(r01 >> (8u * (bo0 - 2u))) & 0xffffu : 0u;   // src[ip-2] | src[ip-1] << 8
+    uint32_t prev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane - 1u) & 63u) << 2, (int)(o0 & 0xffu));
+    if (lane == 0) prev = ip ? (bo0 >= 2u ? before2 >> 8 : (uint32_t)(r01 >> (8u * (bo0 - 1u))) & 0xffu) : 0x100u;
+    if (!live) prev = 0x100u;
+    if (ins_pending) {
+      const uint32_t m2 = enc_mix(before2 | (o0 << 16));
+      if (lane == 0) tab.put(hc_slot(m2), ip - 2u, hc_tag(m2));
+      ins_pending = false;
+    }
+    // ---- candidates: four bucket entries + distance 1, all fetched together, lengths up to RANK_CAP ----
+    const uint32_t room = live ? mlimit - p : 0u;                  // bytes a match starting at p may have
+    const uint32_t limit = room > RANK_CAP ? RANK_CAP : room;
+    const uint32_t mix = enc_mix(o0);
+    const uint32_t h = hc_slot(mix), mytag = hc_tag(mix);
+    uint32_t cw[5], lw[5];
+    uint32_t okm = 0;                                              // ways that hold a usable candidate
+    {
+      uint64_t pp = 0; uint32_t tt = 0;
+      if (live) { pp = tab.pos[h]; tt = tab.tag[h]; }
+      uint32_t dw[4];
+#pragma unroll
+      for (int w = 0; w < 4; w++) {
+        const uint32_t e = (uint32_t)(pp >> (16 * w)) & 0xffffu;
+        const uint32_t d = (p - e) & 0xffffu;
+        bool ok = live && d != 0u && d <= p && ((tt >> (8 * w)) & 0xffu) == mytag;
+#pragma unroll
+        for (int v = 0; v < w; v++) ok = ok && !(((okm >> v) & 1u) && dw[v] == d);   // the same position twice in a bucket
+        dw[w] = d;
+        cw[w] = ok ? p - d : 0u;
+        okm |= ok ? (1u << w) : 0u;
+      }
+    }
+    Bytes20 cb0 = load20(src, cw[0], n), cb1 = load20(src, cw[1], n), cb2 = load20(src, cw[2], n), cb3 = load20(src, cw[3], n);
+    {
+      uint32_t l0 = common20(own, cb0), l1 = common20(own, cb1), l2 = common20(own, cb2), l3 = common20(own, cb3);
+      l0 = l0 > limit ? limit : l0; l1 = l1 > limit ? limit : l1; l2 = l2 > limit ? limit : l2; l3 = l3 > limit ? limit : l3;
+      lw[0] = ((okm & 1u) && l0 >= minlen) ? l0 : 0u;
+      lw[1] = ((okm & 2u) && l1 >= minlen) ? l1 : 0u;
+      lw[2] = ((okm & 4u) && l2 >= minlen) ? l2 : 0u;
+      lw[3] = ((okm & 8u) && l3 >= minlen) ? l3 : 0u;
+    }
+    cw[4] = 0u; lw[4] = 0u;
+    if (prev < 0x100u) {                                           // distance 1: run of the previous byte
+      uint32_t rl = runlen20(own, prev);
+      if (rl > limit) rl = limit;
+      if (rl >= minlen) { lw[4] = rl; cw[4] = p - 1u; }
+    }
+    // ---- exact lengths for candidates that ran into RANK_CAP: one wave-wide comparison per distance ----
+    uint32_t um = 0;                                               // ways still ranked by their first RANK_CAP bytes only
+#pragma unroll
+    for (int w = 0; w < 5; w++) um |= (lw[w] == RANK_CAP && room > RANK_CAP) ? (1u << w) : 0u;
+    for (int g = 0; g < HC_GROUPS; g++) {
+      const uint64_t open = __ballot(um != 0u);
+      if (open == 0ull) break;
+      const int l0 = __builtin_ctzll(open);
+      const uint32_t um0 = (uint32_t)__builtin_amdgcn_readlane((int)um, l0);
+      const uint32_t w0 = (uint32_t)__builtin_ctz(um0);            // uniform
+      const uint32_t csel = w0 == 0u ? cw[0] : (w0 == 1u ? cw[1] : (w0 == 2u ? cw[2] : (w0 == 3u ? cw[3] : cw[4])));
+      const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)csel, l0);
+      const uint32_t p0 = ip + (uint32_t)l0;
+      const uint32_t d0 = p0 - c0;
+      // lane l0 has room > RANK_CAP, so there is at least one more byte to compare
+      const uint32_t L = RANK_CAP + wave_common_fwd(src, n, p0 + RANK_CAP, c0 + RANK_CAP, mlimit - (p0 + RANK_CAP), lane);
+      // lane l0 + j with the same distance sees the same match from j bytes further in: length L - j, as long as
+      // that is still what its own 20-byte comparison said (>= RANK_CAP)
+      const uint32_t j = (uint32_t)lane - (uint32_t)l0;
+      const bool inside = lane >= l0 && j + RANK_CAP <= L;
+#pragma unroll
+      for (int w = 0; w < 5; w++) {
+        if (((um >> w) & 1u) && inside && p - cw[w] == d0) { lw[w] = L - j; um &= ~(1u << w); }
+      }
+    }
+    // ---- this lane's best candidate ----
+    uint32_t len = 0, cand = 0;
+    bool exact = true;                                             // len is the whole match (no forward extension needed)
+#pragma unroll
+    for (int w = 0; w < 5; w++) {
+      if (lw[w] > len) { len = lw[w]; cand = cw[w]; exact = ((um >> w) & 1u) == 0u; }
+    }
+    if (len > HC_RANK_MAX) { len = HC_RANK_MAX; exact = false; }
+    // ---- select + emit (as in lz_encode_wave) ----
+    const uint32_t step_end = ip + 64u;
+    uint32_t lane_lo = 0;
+    bool any = false;
+    for (;;) {
+      const uint32_t key = (len && (uint32_t)lane >= lane_lo) ? (((len + 64u - (uint32_t)lane) << 6) | (63u - (uint32_t)lane)) : 0u;
+      const uint32_t best = wave_max_u32(key);
+      if (best == 0u) break;
+      any = true;
+      const int f = 63 - (int)(best & 63u);
+      if (live && (uint32_t)lane >= lane_lo && lane <= f) tab.put(h, p, mytag);
+      uint32_t pm = ip + (uint32_t)f;
+      uint32_t cm = (uint32_t)__builtin_amdgcn_readlane((int)cand, f);
+      const uint32_t len_f = (uint32_t)__builtin_amdgcn_readlane((int)len, f);
+      const bool exact_f = __builtin_amdgcn_readlane((int)(exact ? 1 : 0), f) != 0;
+      uint32_t maxb = pm - anchor;
+      if (cm < maxb) maxb = cm;
+      if (maxb > 64u) maxb = 64u;
+      uint32_t bx = 0, by = 1;
+      if ((uint32_t)lane < maxb) { bx = src[pm - 1u - (uint32_t)lane]; by = src[cm - 1u - (uint32_t)lane]; }
+      asm volatile("" ::: "memory");
+      uint32_t mlen = len_f;
+      if (!exact_f && pm + len_f < mlimit)
+        mlen += wave_common_fwd(src, n, pm + len_f, cm + len_f, mlimit - (pm + len_f), lane);
+      const uint64_t bm = __ballot(bx != by);          // lanes >= maxb always vote "differs"
+      const uint32_t back = bm ? (uint32_t)__builtin_ctzll(bm) : 64u;
+      pm -= back; cm -= back; mlen += back;
+      op = lz4_emit_seq(dst, op, cap, src + anchor, pm - anchor, pm - cm, mlen, anchor >= ip ? (int)(anchor - ip) : -1, (uint32_t)own.a & 0xffu, lane);
+      if (op == 0xffffffffu) return 0u;
+      anchor = pm + mlen;
+      if (anchor >= step_end) break;
+      lane_lo = anchor - ip;
+      if (live && (uint32_t)lane + 2u == lane_lo) tab.put(h, p, mytag);
+    }
+    if (!any) {
+      if (live) tab.put(h, p, mytag);
+      nfail++;
+      uint32_t adv = 1u + nfail / 16u;
+      if (adv > 16u) adv = 16u;
+      ip += 64u * adv;
+      continue;
+    }
+    nfail = 0;
+    if (anchor >= step_end) {
+      ip = anchor;
+      ins_pending = true;
+    } else {
+      if (live && (uint32_t)lane >= lane_lo) tab.put(h, p, mytag);
+      ip = step_end;
+    }
+  }
+  op = lz4_emit_tail(dst, op, cap, src + anchor, n - anchor, lane);
+  if (op == 0xffffffffu) return 0u;
+  return op < n ? op : 0u;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Zstd frames (zstd_enc.h has the format; this is its wave-parallel use).  One frame per stream, blocks of at most
 // 128 KiB; per block the match finder above fills a ZsSink, then the sequence section is coded: code numbers and extra
 // bits of 64 sequences at a time in the lanes, the three FSE state chains and the bit writer as a wave-uniform
@@ -1082,8 +1302,9 @@ __device__ __forceinline__ uint32_t emit_periodic_stream(const gu8* in, uint32_t
 }
 
 // one stream, not inlined into the queue loop (see decode_one_stream in k_decode.hip for why)
-// MODE: 0 = LZ4 / BloscLZ, 1 = Zstd, 2 = Zlib - a batch has ONE codec, so every kernel carries only its own code path
-enum { ENC_LZ = 0, ENC_ZSTD = 1, ENC_ZLIB = 2 };
+// MODE: 0 = LZ4 / BloscLZ, 1 = Zstd, 2 = Zlib, 3 = LZ4 with the LZ4HC-grade search - a batch has ONE codec, so every kernel
+// carries only its own code path
+enum { ENC_LZ = 0, ENC_ZSTD = 1, ENC_ZLIB = 2, ENC_HC = 3 };
 template <int MODE>
 __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, enc_entry_t* tab, const ChunkDesc* chunks, uint32_t* blk_ready, int lane,
                                                             const BlockDesc* blocks, uint32_t sid, uint32_t* plane_cost, uint64_t* seqbuf
@@ -1111,6 +1332,7 @@ __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, enc_
   if (MODE == ENC_ZSTD) r = seqbuf ? zstd_encode_wave(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, (BAMD_GAS uint64_t*)seqbuf, lane EPROF_PASS) : 0u;
   else if (MODE == ENC_ZLIB) r = zlib_encode_wave(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, lane EPROF_PASS);
   else if (hint < 0) r = emit_periodic_stream(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, (uint32_t)-hint, uni((uint32_t)sd->fmt) == (uint32_t)FMT_LZ4, lane);
+  else if (MODE == ENC_HC) r = lz4hc_encode_wave(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, tab, lane);
   else if (sd->fmt == FMT_LZ4) r = lz_encode_wave<EF_LZ4>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, lane EPROF_PASS);
   else r = lz_encode_wave<EF_BLOSCLZ>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, lane EPROF_PASS);
   if (lane == 0) sd->result = (int32_t)r;
@@ -1131,7 +1353,7 @@ __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, enc_
 // build_encode_queues), so the bandwidth-bound transposes run underneath the latency/issue-bound match
 // finding of other waves instead of in a kernel of their own.
 template <int MODE>
-__global__ __launch_bounds__(64 * ENC_WAVES, BAMD_ENC_MINWAVES) void k_encode_streams_t(
+__global__ __launch_bounds__(64 * ENC_WAVES, MODE == ENC_HC ? 2 : BAMD_ENC_MINWAVES) void k_encode_streams_t(
     StreamDesc* __restrict__ streams, uint32_t* __restrict__ tickets /*[8]*/, const int32_t* __restrict__ qlist,
     const int32_t* __restrict__ qoff /*[9]*/, const ChunkDesc* __restrict__ chunks, const BlockDesc* __restrict__ blocks,
     uint32_t* __restrict__ blk_ready, uint32_t* __restrict__ plane_cost, int single_queue,
@@ -1141,7 +1363,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES, BAMD_ENC_MINWAVES) void k_encode_st
 #endif
     ) {
   constexpr bool ZSTD = MODE == ENC_ZSTD;
-  __shared__ enc_entry_t tabs[ENC_WAVES][(ENC_TAB_BYTES + (ZSTD ? ZS_LDS_BYTES : (MODE == ENC_ZLIB ? DFL_LDS_BYTES : 0))) / 4];
+  __shared__ __attribute__((aligned(16))) enc_entry_t tabs[ENC_WAVES][(MODE == ENC_HC ? HC_TAB_BYTES : ENC_TAB_BYTES + (ZSTD ? ZS_LDS_BYTES : (MODE == ENC_ZLIB ? DFL_LDS_BYTES : 0))) / 4];
   static_assert(ENC_WAVES == 1, "one stream per wave, one wave per workgroup");
   const int lane = threadIdx.x & 63;
   uint64_t* seqbuf = nullptr;

@@ -47,6 +47,11 @@ __device__ __forceinline__ uint32_t g_ld4(const gu8* p) { return *(const BAMD_GA
 __device__ __forceinline__ uint64_t g_ld8(const gu8* p) { return *(const BAMD_GAS u64una*)p; }
 __device__ __forceinline__ void g_st4(gu8* p, uint32_t v) { *(BAMD_GAS u32una*)p = v; }
 
+// every vector memory operation of this wave has completed (stores have reached L2)
+#ifndef BAMD_WAIT_STORES        // (the wavefront emulator of tests/tools/wave_emu defines it away)
+#define BAMD_WAIT_STORES() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+
 __device__ __forceinline__ int32_t g_ld_i32le(const gu8* p) { return (int32_t)g_ld4(p); }   // device is little endian
 __device__ __forceinline__ void g_st_i32le(gu8* p, int32_t v) { g_st4(p, (uint32_t)v); }
 

@@ -1,0 +1,92 @@
+"""GPU: compressor name "lz4hc" (blosc/blosc.c:422-433 -> LZ4_compress_HC) served by the LZ4HC-grade search of
+c-blosc_amd/csrc/k_encode.hip (lz4hc_encode_wave): chunks are ordinary LZ4-format chunks that the oracle, the reference and
+our own decoder read back bit-exactly, headers are the reference's for that codec (format id LZ4, the HC block sizes),
+and the ratio is the reference's own LZ4HC ratio to within a few percent - not the plain LZ4 match finder's.
+BLOSC_AMD_LZ4HC=0 falls back to the plain match finder under the same name."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+from helpers import DATASETS, header, orc_decompress, ref_compress, ref_decompress
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def hc_on():
+    old = os.environ.get("BLOSC_AMD_LZ4HC")
+    os.environ["BLOSC_AMD_LZ4HC"] = "1"
+    yield
+    if old is None:
+        del os.environ["BLOSC_AMD_LZ4HC"]
+    else:
+        os.environ["BLOSC_AMD_LZ4HC"] = old
+
+
+def _roundtrip(pkg, oracle, ref, data, T, clevel, shuffle, blocksize=0):
+    r, chunk = pkg.compress(data, T, clevel, shuffle, b"lz4hc", blocksize)
+    assert 0 < r <= data.size + 16
+    h = header(chunk)
+    assert h["cbytes"] == r and h["nbytes"] == data.size and (h["flags"] >> 5) == 1      # LZ4 format id (blosc.h:96)
+    r2, out = orc_decompress(oracle, chunk, data.size)
+    assert r2 == data.size and np.array_equal(out, data)
+    if ref is not None:
+        r3, out3 = ref_decompress(ref, chunk, data.size)
+        assert r3 == data.size and np.array_equal(out3, data)
+    r4, out4 = pkg.decompress(chunk, data.size)
+    assert r4 == data.size and np.array_equal(out4, data)
+    return r, chunk
+
+
+def test_lz4hc_ratio_is_the_references(pkg, oracle, ref, hc_on):
+    rows = []
+    for dname, T, shuffle in [("bench19", 8, 1), ("bench19", 4, 1), ("linspace", 8, 1), ("smallints", 4, 1), ("randwalk", 8, 1)]:
+        data = DATASETS[dname](16 << 20)
+        r, chunk = _roundtrip(pkg, oracle, ref, data, T, 9, shuffle)
+        os.environ["BLOSC_AMD_LZ4HC"] = "0"
+        rp, _ = pkg.compress(data, T, 9, shuffle, b"lz4hc", 0)
+        os.environ["BLOSC_AMD_LZ4HC"] = "1"
+        rr = None
+        if ref is not None:
+            rr, stock = ref_compress(ref, data, T, 9, shuffle, b"lz4hc", nthreads=8)
+            assert header(stock)["blocksize"] == header(chunk)["blocksize"] and header(stock)["flags"] == header(chunk)["flags"]
+        rows.append((dname, T, data.size / r, data.size / rp, data.size / rr if rr else 0.0))
+        print(f"lz4hc {dname:9s} T={T}: search {data.size / r:8.2f}   plain match finder {data.size / rp:8.2f}   reference LZ4HC {data.size / rr if rr else 0:8.2f}")
+        assert r <= rp * 1.001                                # never worse than the plain match finder
+        if rr:
+            assert r <= rr * 1.08, (dname, r, rr)            # within 8 % of the reference's LZ4HC size on every set
+    assert rows[0][2] > rows[0][3] * 1.10                     # bench19: the search is worth > 10 %
+
+
+def test_lz4hc_chunks_are_valid_everywhere(pkg, oracle, ref, hc_on):
+    for dname in ["bench19", "linspace", "randwalk", "smallints", "zeros", "random", "arange"]:
+        for T, shuffle in [(8, 1), (4, 1), (4, 2), (1, 0), (3, 1), (16, 1)]:
+            for n in [129, 1000, 32768, 65536 + 17, 300001, (1 << 21) + 5]:
+                if n > 400000 and (T != 8 or dname in ("zeros", "random", "arange")):
+                    continue
+                for clevel in ((1, 9) if n <= 32768 else (9,)):
+                    _roundtrip(pkg, oracle, ref, DATASETS[dname](n), T, clevel, shuffle)
+    # forced block sizes: tiny streams, and one stream larger than the 64 KiB window
+    for bs in (128, 512, 4096, 1 << 20):
+        _roundtrip(pkg, oracle, ref, DATASETS["bench19"](300001), 1, 9, 0, blocksize=bs)
+        _roundtrip(pkg, oracle, ref, DATASETS["linspace"](300001), 8, 9, 1, blocksize=bs)
+
+
+def test_lz4hc_batch_time(pkg, hc_on):
+    """Not a bound, a number for the record: the BASELINE geometry (64 MiB chunks) through the HC kernel."""
+    import torch
+    dev = torch.device("cuda:0")
+    n, csz = 16, 64 << 20
+    data = torch.from_numpy(DATASETS["bench19"](csz)).to(dev)
+    src = data.unsqueeze(0).expand(n, csz).contiguous()
+    comp = torch.zeros((n, csz + 256), dtype=torch.uint8, device=dev)
+    b = pkg.DeviceBatch([src[i].data_ptr() for i in range(n)], [csz] * n, [comp[i].data_ptr() for i in range(n)], [csz + 16] * n)
+    for rep in range(3):
+        torch.cuda.synchronize(); t = time.time()
+        assert b.compress(8, 9, 1, b"lz4hc") == 0
+        torch.cuda.synchronize(); dt = time.time() - t
+    cb = b.results()
+    assert all(c > 0 for c in cb)
+    print(f"lz4hc encode, {n} x 64 MiB bench19: {dt * 1e3:.1f} ms = {n * csz / dt / 1e9:.1f} GB/s, ratio {csz / cb[0]:.2f}")

@@ -1,0 +1,138 @@
+"""CPU: the wave-parallel LZ encoders of c-blosc_amd/csrc/k_encode.hip - lz_encode_wave (LZ4, BloscLZ) and
+lz4hc_encode_wave (the LZ4HC-grade search) - the SAME source the GPU runs, executed lane by lane on the CPU by the
+wavefront emulator of tests/tools/wave_emu (every cross-lane instruction is a rendezvous of 64 coroutines).  What they
+write must be a valid stream: the oracle's LZ4 / BloscLZ decoders (pinned to the reference) and, where oracle/_ref
+ships, the reference's own decoders read every one of them back bit-exactly; a cross-lane instruction placed in
+divergent control flow aborts the run.  The GPU suite checks the same functions on the device; this file is what keeps
+them honest between GPU runs (and what a change to the match finder is tried against first)."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import DATASETS, ptr
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+LZ4, BLOSCLZ, LZ4HC = 0, 1, 2
+
+
+@pytest.fixture(scope="module")
+def emu():
+    if not os.path.exists(CLANG):
+        pytest.skip("the emulator needs the ROCm clang++ (ext_vector_type / address_space in host code)")
+    csrc = os.path.join(ROOT, "c-blosc_amd", "csrc")
+    tools = os.path.join(ROOT, "tests", "tools")
+    so = os.path.join(tools, "liblz_wave_cpu.so")
+    deps = [os.path.join(tools, "lz_wave_cpu.cpp"), os.path.join(tools, "wave_emu", "wave_emu.h")]
+    deps += [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h"))]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call([CLANG, "-std=c++17", "-O1", "-shared", "-fPIC", "-w", "-I", os.path.join(tools, "wave_emu"), "-I", csrc,
+                               "-x", "c++", deps[0], "-o", so])
+    E = C.CDLL(so)
+    E.emu_lz_encode.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_ulonglong)]
+    return E
+
+
+def _encode(emu, kind, data, cap=None, clevel=9):
+    data = np.ascontiguousarray(data)
+    cap = data.size if cap is None else cap
+    dst = np.full(max(cap, 1) + 64, 0xEE, np.uint8)
+    r = emu.emu_lz_encode(kind, ptr(data), data.size, ptr(dst), cap, clevel, None)
+    assert 0 <= r <= cap, (r, cap)
+    assert np.all(dst[max(cap, 1):] == 0xEE), "wrote beyond the capacity it was given"
+    return r, dst[:r].copy()
+
+
+def _decodes(oracle, ref, kind, stream, data):
+    n = data.size
+    back = np.zeros(n + 8, np.uint8)
+    if kind == BLOSCLZ:
+        assert oracle.orc_blosclz_decompress(ptr(stream), stream.size, ptr(back), n) == n
+    else:
+        assert oracle.orc_lz4_decompress(ptr(stream), stream.size, ptr(back), n) == n
+    assert np.array_equal(back[:n], data)
+    if ref is not None:
+        back2 = np.zeros(n + 8, np.uint8)
+        if kind == BLOSCLZ:
+            assert ref.blosclz_decompress(ptr(stream), stream.size, ptr(back2), n) == n
+        else:
+            assert ref.LZ4_decompress_safe(ptr(stream), ptr(back2), stream.size, n) == n
+        assert np.array_equal(back2[:n], data)
+
+
+def _plane(dname, n, T=8, j=0):
+    d = DATASETS[dname](n * T)
+    return np.ascontiguousarray(d.reshape(-1, T).T[j])
+
+
+@pytest.mark.parametrize("kind", [LZ4, BLOSCLZ, LZ4HC], ids=["lz4", "blosclz", "lz4hc"])
+def test_streams_decode_with_oracle_and_reference(emu, oracle, ref, kind):
+    oracle.orc_blosclz_decompress.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    rng = np.random.default_rng(5)
+    cases = 0
+    inputs = []
+    for dname in ["bench19", "linspace", "randwalk", "smallints", "arange"]:
+        for j in (0, 1, 3):
+            for n in (4096, 16384 + 64):
+                inputs.append(_plane(dname, n, 8, j))
+        inputs.append(DATASETS[dname](8192))                          # unshuffled
+    for n in [0, 1, 4, 12, 13, 14, 15, 16, 17, 19, 20, 21, 31, 32, 63, 64, 65, 66, 76, 77, 127, 128, 129, 130, 191, 255, 256, 257, 300, 1000, 1023, 1024, 1025]:
+        inputs.append(np.zeros(n, np.uint8))
+        inputs.append((np.arange(n) % 7).astype(np.uint8))
+        inputs.append(rng.integers(0, 4, n, dtype=np.uint8))
+        inputs.append(rng.integers(0, 256, n, dtype=np.uint8))
+    inputs.append(np.zeros(200000, np.uint8))                         # one long run
+    inputs.append(np.tile(rng.integers(0, 256, 300, dtype=np.uint8), 100))          # one long far-period match
+    inputs.append(np.concatenate([rng.integers(0, 256, 70000, dtype=np.uint8)] * 2))   # a match beyond 64 KiB: must not be used (LZ4) / far (BloscLZ)
+    inputs.append(np.concatenate([np.tile(rng.integers(0, 256, 40, dtype=np.uint8), 30), rng.integers(0, 256, 500, dtype=np.uint8)] * 8))
+    for data in inputs:
+        for clevel in ((9,) if kind == LZ4HC else (1, 5, 9)):
+            r, s = _encode(emu, kind, data, clevel=clevel)
+            if r == 0:
+                continue                                              # "store raw": the caller copies the plane
+            assert r < data.size
+            _decodes(oracle, ref, kind, s, data)
+            cases += 1
+    assert cases > (60 if kind == LZ4HC else 150)
+
+
+@pytest.mark.parametrize("kind", [LZ4, LZ4HC], ids=["lz4", "lz4hc"])
+def test_capacity_is_respected(emu, oracle, ref, kind):
+    """Whatever room the stream is given: either a complete valid stream inside it, or 0 (tests/test_maxout.c's rule one level down)."""
+    for data in (_plane("bench19", 8192, 8, 0), _plane("bench19", 8192, 8, 1), _plane("linspace", 8192, 8, 2), _plane("linspace", 8192, 8, 6)):
+        full, _ = _encode(emu, kind, data)
+        assert full > 0
+        for cap in [0, 1, 5, 12, 13, 20, full - 40, full - 9, full - 1, full, full + 1, full + 8, data.size]:
+            if cap < 0:
+                continue
+            r, s = _encode(emu, kind, data, cap=cap)
+            if r:
+                _decodes(oracle, ref, kind, s, data)
+            if cap >= full + 8:
+                assert r == full
+
+
+def test_lz4hc_search_finds_what_the_plain_one_misses(emu, oracle, ref):
+    """The point of the search: the ratio.  Against the reference's LZ4_compress_HC (level 9) where oracle/_ref ships, and
+    always against the plain LZ4 match finder on the same planes (tests/tools/enc_model2.c is the model behind the numbers)."""
+    tot = {"plain": 0, "hc": 0, "ref": 0, "n": 0}
+    for dname, T in (("bench19", 8), ("bench19", 4), ("linspace", 8)):
+        for j in range(0, T, 2):
+            data = _plane(dname, 32768, T, j)
+            a, _ = _encode(emu, LZ4, data)
+            h, s = _encode(emu, LZ4HC, data)
+            a = a or data.size; h = h or data.size
+            tot["plain"] += a; tot["hc"] += h; tot["n"] += data.size
+            if ref is not None:
+                ref.LZ4_compress_HC.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+                out = np.zeros(data.size + 64, np.uint8)
+                rr = ref.LZ4_compress_HC(ptr(data), ptr(out), data.size, data.size, 9)
+                tot["ref"] += rr if rr > 0 else data.size
+    print(f"planes of 32 KiB: plain {tot['n'] / tot['plain']:.2f}  lz4hc search {tot['n'] / tot['hc']:.2f}" + (f"  LZ4_compress_HC(9) {tot['n'] / tot['ref']:.2f}" if tot["ref"] else ""))
+    assert tot["hc"] <= tot["plain"] * 0.93
+    if tot["ref"]:
+        assert tot["hc"] <= tot["ref"] * 1.10
