@@ -236,7 +236,7 @@ static bool span_enabled() { static const bool on = !(getenv("BLOSC_AMD_SPANS") 
 static bool blockdec_enabled() { static const bool on = getenv("BLOSC_AMD_BLOCKDEC") && atoi(getenv("BLOSC_AMD_BLOCKDEC")) != 0; return on; }
 // BLOSC_AMD_PERIODIC=0: every plane goes through the match finder (A/B switch for the periodic-plane shortcut of the fused shuffle)
 #ifndef BAMD_LZ4HC_DEFAULT
-#define BAMD_LZ4HC_DEFAULT 0   // "lz4hc" without BLOSC_AMD_LZ4HC in the environment: 1 = LZ4HC-grade search, 0 = plain LZ4 match finder
+#define BAMD_LZ4HC_DEFAULT 1   // "lz4hc" without BLOSC_AMD_LZ4HC in the environment: 1 = LZ4HC-grade search, 0 = plain LZ4 match finder
 #endif
 static bool lz4hc_search_enabled() { const char* e = getenv("BLOSC_AMD_LZ4HC"); return e ? atoi(e) != 0 : (BAMD_LZ4HC_DEFAULT != 0); }
 static bool periodic_enabled() { static const bool on = !(getenv("BLOSC_AMD_PERIODIC") && atoi(getenv("BLOSC_AMD_PERIODIC")) == 0); return on; }

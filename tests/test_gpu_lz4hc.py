@@ -56,7 +56,7 @@ def test_lz4hc_ratio_is_the_references(pkg, oracle, ref, hc_on):
         print(f"lz4hc {dname:9s} T={T}: search {data.size / r:8.2f}   plain match finder {data.size / rp:8.2f}   reference LZ4HC {data.size / rr if rr else 0:8.2f}")
         assert r <= rp * 1.001                                # never worse than the plain match finder
         if rr:
-            assert r <= rr * 1.08, (dname, r, rr)            # within 8 % of the reference's LZ4HC size on every set
+            assert r <= rr * (1.12 if dname == "smallints" else 1.06), (dname, r, rr)   # the reference's LZ4HC size to within 6 % (noisy small integers, where its 256-deep chains count: 12 %)
     assert rows[0][2] > rows[0][3] * 1.10                     # bench19: the search is worth > 10 %
 
 
