@@ -179,36 +179,141 @@ ZE_FN void fse_encode(FseState& s, const CTab& t, uint32_t sym, BitWriter& bw) {
   s.v = t.st[(int32_t)(s.v >> nb) + t.dfs[sym]];
 }
 
-// Sequences_Section of one block (RFC 8878 section 3.1.1.3.2): count, compression-modes byte 0 (three predefined
-// tables), bitstream.  `seqs` hold Offset_Values already (assign_offset_values).  Returns the end of the section, or
-// nullptr when it does not fit.
-ZE_FN uint8_t* write_sequences(uint8_t* out, uint8_t* end, const uint64_t* seqs, uint32_t nseq, const CTabs& T) {
+// ---- per-block tables (RFC 8878 section 3.1.1.3.2.1: Symbol_Compression_Modes; section 4.1.1: FSE table description) ----
+// A table of a block is one of: the predefined distribution (mode 0), one symbol for every sequence (RLE_Mode 1: one byte
+// names it, the state needs no bits), or a distribution made for this block (FSE_Compressed_Mode 2: its description
+// travels in front of the bitstream).  The block-made tables here always have Accuracy_Log kCustomLog = 6 - the encoder
+// table stays 64 cells, like the predefined ones - and no "less than 1" probabilities, so cell k of the spread is simply
+// (k * step) & mask.
+enum : uint32_t { kModePredefined = 0u, kModeRLE = 1u, kModeFSE = 2u };
+constexpr int kCustomLog = 6;
+constexpr uint32_t kMaxNCountBytes = 48u;         // 4 + 53 symbols x <= 7 bits, rounded up generously
+
+// counts -> probabilities that sum to 1 << log, every present symbol >= 1.  Proportional shares rounded down (at least 1),
+// what is left over goes to the most frequent symbol; when the floor of 1 has handed out too much, the largest shares
+// give it back one by one.  false: fewer than two symbols present (RLE_Mode's case) or more symbols than cells.
+ZE_FN bool fse_normalize(const uint32_t* count, int nsym, uint32_t total, int log, int16_t* norm) {
+  const int size = 1 << log;
+  int present = 0, sum = 0, big = 0;
+  for (int s = 0; s < nsym; s++) {
+    int v = 0;
+    if (count[s]) { present++; v = (int)(((uint64_t)count[s] << log) / total); if (v < 1) v = 1; }
+    norm[s] = (int16_t)v; sum += v;
+    if (count[s] > count[big]) big = s;
+  }
+  if (present < 2 || present > size) return false;
+  if (sum <= size) { norm[big] = (int16_t)(norm[big] + size - sum); return true; }
+  for (int over = sum - size; over > 0; over--) {
+    int m = 0;
+    for (int s = 1; s < nsym; s++) if (norm[s] > norm[m]) m = s;
+    if (norm[m] < 2) return false;
+    norm[m]--;
+  }
+  return true;
+}
+// FSE table description (RFC 8878 section 4.1.1) of `norm` (no -1 entries), Accuracy_Log `log`; returns its length in bytes.
+// Fields are little-endian bit fields in a forward bitstream: 4 bits log - 5, then per symbol value = probability + 1 in
+// a field whose width depends on how many points are still to be given out; a probability of 0 is followed by 2-bit
+// repeat flags that count further zeros.
+ZE_FN uint32_t fse_write_ncount(uint8_t* out, const int16_t* norm, int nsym, int log) {
+  struct Bits {
+    uint8_t* out; uint64_t acc; uint32_t nb, pos;
+    ZE_FN void put(uint32_t v, uint32_t n) { acc |= (uint64_t)v << nb; nb += n; while (nb >= 8u) { out[pos++] = (uint8_t)acc; acc >>= 8; nb -= 8u; } }
+  } b = {out, 0, 0, 0};
+  b.put((uint32_t)(log - 5), 4u);
+  int remaining = 1 << log;                    // points still to be given out
+  int s = 0;
+  while (remaining > 0 && s < nsym) {
+    const uint32_t value = (uint32_t)(norm[s] + 1);
+    const uint32_t bits = (uint32_t)highbit((uint32_t)remaining + 1u) + 1u;       // enough for 0 .. remaining + 1
+    const uint32_t low = (1u << bits) - 1u - ((uint32_t)remaining + 1u);          // this many small values take one bit less
+    if (value < low) b.put(value, bits - 1u);
+    else if (value < (1u << (bits - 1u))) b.put(value, bits);
+    else b.put(value + low, bits);
+    remaining -= norm[s];
+    s++;
+    if (value == 1u) {                          // probability 0: how many more zeros follow, 2 bits at a time
+      int z = 0;
+      while (s + z < nsym && norm[s + z] == 0) z++;
+      s += z;
+      for (; z >= 3; z -= 3) b.put(3u, 2u);
+      b.put((uint32_t)z, 2u);
+    }
+  }
+  if (b.nb) out[b.pos++] = (uint8_t)b.acc;
+  return b.pos;
+}
+// bits the sequences' codes of one alphabet cost with table `norm` / log (for choosing a mode; 1/256 bit units)
+ZE_FN uint64_t fse_cost256(const uint32_t* count, int nsym, const int16_t* norm, int log) {
+  uint64_t c = 0;
+  for (int s = 0; s < nsym; s++) if (count[s]) {
+    const int n = norm[s] == -1 ? 1 : norm[s];
+    if (n <= 0) return ~0ull >> 1;               // a symbol the table cannot code
+    // -log2(n / size) in 1/256 bits: integer part from the high bit, fraction linearly between powers of two
+    const int hbit = highbit((uint32_t)n);
+    const uint32_t frac = ((uint32_t)n << 8 >> hbit) - 256u;                        // 0..255
+    const uint32_t bits256 = (uint32_t)((log - hbit) << 8) - frac;                   // log2(1 + x) ~ x
+    c += (uint64_t)count[s] * bits256;
+  }
+  return c;
+}
+
+struct SeqTables {              // what write_sequences needs to know about the three tables of a block
+  uint32_t mode[3];             // kMode*: literal lengths, offsets, match lengths (the order of the modes byte)
+  uint32_t log[3];
+  uint32_t rle[3];              // RLE_Mode: the symbol
+  const uint8_t* desc[3];       // FSE_Compressed_Mode: table description bytes
+  uint32_t desc_len[3];
+};
+ZE_FN void seq_tables_predefined(SeqTables& st) {
+  for (int k = 0; k < 3; k++) { st.mode[k] = kModePredefined; st.rle[k] = 0; st.desc[k] = nullptr; st.desc_len[k] = 0; }
+  st.log[0] = kLLLog; st.log[1] = kOFLog; st.log[2] = kMLLog;
+}
+
+// Sequences_Section of one block (RFC 8878 section 3.1.1.3.2): count, compression-modes byte, table descriptions in the order
+// literal lengths / offsets / match lengths, bitstream.  `seqs` hold Offset_Values already (assign_offset_values); T holds
+// the encoder tables that go with `st` (an RLE table is not consulted).  Returns the end of the section, or nullptr when it
+// does not fit.
+ZE_FN uint8_t* write_sequences(uint8_t* out, uint8_t* end, const uint64_t* seqs, uint32_t nseq, const CTabs& T, const SeqTables* stp = nullptr) {
+  SeqTables st0;
+  if (!stp) { seq_tables_predefined(st0); stp = &st0; }
+  const SeqTables& st = *stp;
   if (out + 4 > end) return nullptr;
   if (nseq == 0u) { *out++ = 0; return out; }
   if (nseq < 128u) *out++ = (uint8_t)nseq;
   else if (nseq < 0x7f00u) { *out++ = (uint8_t)((nseq >> 8) + 128u); *out++ = (uint8_t)nseq; }
   else { *out++ = 255u; *out++ = (uint8_t)(nseq - 0x7f00u); *out++ = (uint8_t)((nseq - 0x7f00u) >> 8); }
-  *out++ = 0;                                           // Symbol_Compression_Modes: predefined x 3
+  *out++ = (uint8_t)((st.mode[0] << 6) | (st.mode[1] << 4) | (st.mode[2] << 2));   // Symbol_Compression_Modes
+  for (int k = 0; k < 3; k++) {
+    if (st.mode[k] == kModeRLE) { if (out + 1 > end) return nullptr; *out++ = (uint8_t)st.rle[k]; }
+    else if (st.mode[k] == kModeFSE) { if (out + st.desc_len[k] > end) return nullptr; memcpy(out, st.desc[k], st.desc_len[k]); out += st.desc_len[k]; }
+  }
+  const bool fll = st.mode[0] != kModeRLE, fof = st.mode[1] != kModeRLE, fml = st.mode[2] != kModeRLE;
   BitWriter bw;
   bw.init(out, end);
   FseState sll, sml, sof;
+  sll.v = sml.v = sof.v = 0;
   {
     const uint64_t q = seqs[nseq - 1u];
     const Code l = ll_code(seq_ll(q)), m = ml_code(seq_ml(q)), o = of_code_value(seq_off(q));
-    fse_init(sml, T.ml, m.code); fse_init(sof, T.of, o.code); fse_init(sll, T.ll, l.code);
+    if (fml) fse_init(sml, T.ml, m.code);
+    if (fof) fse_init(sof, T.of, o.code);
+    if (fll) fse_init(sll, T.ll, l.code);
     bw.add(l.extra, l.bits); bw.add(m.extra, m.bits);
     if (o.bits > 24u) { bw.add(o.extra & 0xffffffu, 24u); bw.add(o.extra >> 24, o.bits - 24u); } else bw.add(o.extra, o.bits);
   }
   for (uint32_t n = nseq - 1u; n-- > 0u;) {
     const uint64_t q = seqs[n];
     const Code l = ll_code(seq_ll(q)), m = ml_code(seq_ml(q)), o = of_code_value(seq_off(q));
-    fse_encode(sof, T.of, o.code, bw); fse_encode(sml, T.ml, m.code, bw); fse_encode(sll, T.ll, l.code, bw);
+    if (fof) fse_encode(sof, T.of, o.code, bw);
+    if (fml) fse_encode(sml, T.ml, m.code, bw);
+    if (fll) fse_encode(sll, T.ll, l.code, bw);
     bw.add(l.extra, l.bits); bw.add(m.extra, m.bits);
     if (o.bits > 24u) { bw.add(o.extra & 0xffffffu, 24u); bw.add(o.extra >> 24, o.bits - 24u); } else bw.add(o.extra, o.bits);
   }
-  bw.add(sml.v & ((1u << kMLLog) - 1u), kMLLog);
-  bw.add(sof.v & ((1u << kOFLog) - 1u), kOFLog);
-  bw.add(sll.v & ((1u << kLLLog) - 1u), kLLLog);
+  if (fml) bw.add(sml.v & ((1u << st.log[2]) - 1u), st.log[2]);
+  if (fof) bw.add(sof.v & ((1u << st.log[1]) - 1u), st.log[1]);
+  if (fll) bw.add(sll.v & ((1u << st.log[0]) - 1u), st.log[0]);
   uint8_t* e = bw.close();
   return bw.overflow ? nullptr : e;
 }

@@ -37,8 +37,14 @@ static int put_ext(uint8_t* d, int op, int v) { for (; v >= 255; v -= 255) d[op+
 
 typedef struct { uint8_t* dst; int op, cap, nseq; } Out;
 
+/* optional capture of the sequences (literal length, match length, distance) for analyses outside the LZ4 format */
+static uint32_t* g_cap_buf = 0; static int g_cap_max = 0, g_cap_n = 0;
+void enc_model2_capture(uint32_t* buf, int max_triples) { g_cap_buf = buf; g_cap_max = max_triples; g_cap_n = 0; }
+int enc_model2_captured(void) { return g_cap_n; }
+
 static int emit_seq(Out* o, const uint8_t* src, int anchor, int pm, int dist, int mlen) {
   int ll = pm - anchor, mc = mlen - 4;
+  if (g_cap_buf && g_cap_n < g_cap_max) { g_cap_buf[3 * g_cap_n] = (uint32_t)ll; g_cap_buf[3 * g_cap_n + 1] = (uint32_t)mlen; g_cap_buf[3 * g_cap_n + 2] = (uint32_t)dist; g_cap_n++; }
   if (o->op + 1 + ll + ll / 255 + 1 + 2 + (mc + 240) / 255 + 1 > o->cap) return 0;
   int tok = o->op++;
   o->dst[tok] = (uint8_t)(((ll < 15 ? ll : 15) << 4) | (mc < 15 ? mc : 15));
