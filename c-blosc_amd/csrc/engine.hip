@@ -239,6 +239,10 @@ static bool blockdec_enabled() { static const bool on = getenv("BLOSC_AMD_BLOCKD
 #define BAMD_LZ4HC_DEFAULT 1   // "lz4hc" without BLOSC_AMD_LZ4HC in the environment: 1 = LZ4HC-grade search, 0 = plain LZ4 match finder
 #endif
 static bool lz4hc_search_enabled() { const char* e = getenv("BLOSC_AMD_LZ4HC"); return e ? atoi(e) != 0 : (BAMD_LZ4HC_DEFAULT != 0); }
+#ifndef BAMD_ZSTD_TABLES_DEFAULT
+#define BAMD_ZSTD_TABLES_DEFAULT 0
+#endif
+static bool zstd_tables_enabled() { const char* e = getenv("BLOSC_AMD_ZSTD_TABLES"); return e ? atoi(e) != 0 : (BAMD_ZSTD_TABLES_DEFAULT != 0); }
 static bool periodic_enabled() { static const bool on = !(getenv("BLOSC_AMD_PERIODIC") && atoi(getenv("BLOSC_AMD_PERIODIC")) == 0); return on; }
 // BLOSC_AMD_ZSTD2: 2 (default) = two-phase path, 16 frames per wave, tables in a global scratch (k_zstd2.hip);
 // 1 = the same with the tables in LDS (one wave per CU); 0 = one wave per frame for everything (k_zstd_streams).
@@ -358,6 +362,9 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   // "lz4hc": the LZ4HC-grade search of k_encode.hip (lz4hc_encode_wave); BLOSC_AMD_LZ4HC=0 serves the name with the plain LZ4
   // match finder at its highest effort instead (read per call, so that a test can compare the two in one process)
   const bool hc = p.codec == kLZ4HC && lz4hc_search_enabled();
+  // Zstd: sequence tables made per block (k_encode.hip: zt_make_tables) instead of the predefined ones; opt-in (BLOSC_AMD_ZSTD_TABLES=1)
+  // until it has been timed on the device, read per call
+  const bool ztab = zstd && zstd_tables_enabled();
   static const int enc_wpc_lz = getenv("BLOSC_AMD_ENC_WPC") ? atoi(getenv("BLOSC_AMD_ENC_WPC")) : ENC_WAVES_PER_CU;
   const int enc_wpc = hc ? HC_WAVES_PER_CU : enc_wpc_lz;
   const size_t zwaves = zstd ? (size_t)(st.cus > 0 ? st.cus : 256) * (size_t)enc_wpc : 0;
@@ -453,7 +460,8 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
 #ifdef BAMD_PROFILE_DECODE
     uint32_t* d_prof = nullptr;
     if (getenv("BLOSC_AMD_ENC_PROFILE")) { (void)hipMalloc((void**)&d_prof, nstr * 64); (void)hipMemsetAsync(d_prof, 0, nstr * 64, stream); }
-    if (zstd) hipLaunchKernelGGL(k_encode_streams_t<ENC_ZSTD>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)(D + o_seqbufs), (const zenc::CTabs*)(D + o_ctabs), 0, d_prof);
+    if (zstd && ztab) hipLaunchKernelGGL(k_encode_streams_t<ENC_ZSTD_T>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)(D + o_seqbufs), (const zenc::CTabs*)(D + o_ctabs), 0, d_prof);
+    else if (zstd) hipLaunchKernelGGL(k_encode_streams_t<ENC_ZSTD>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)(D + o_seqbufs), (const zenc::CTabs*)(D + o_ctabs), 0, d_prof);
     else if (zlibc) hipLaunchKernelGGL(k_encode_streams_t<ENC_ZLIB>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)nullptr, (const zenc::CTabs*)nullptr, 0, d_prof);
     else if (hc) hipLaunchKernelGGL(k_encode_streams_t<ENC_HC>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)nullptr, (const zenc::CTabs*)nullptr, periodic_enabled() ? 1 : 0, d_prof);
     else hipLaunchKernelGGL(k_encode_streams_t<ENC_LZ>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)nullptr, (const zenc::CTabs*)nullptr, periodic_enabled() ? 1 : 0, d_prof);
@@ -466,7 +474,8 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
       (void)hipFree(d_prof);
     }
 #else
-    if (zstd) hipLaunchKernelGGL(k_encode_streams_t<ENC_ZSTD>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)(D + o_seqbufs), (const zenc::CTabs*)(D + o_ctabs), 0);
+    if (zstd && ztab) hipLaunchKernelGGL(k_encode_streams_t<ENC_ZSTD_T>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)(D + o_seqbufs), (const zenc::CTabs*)(D + o_ctabs), 0);
+    else if (zstd) hipLaunchKernelGGL(k_encode_streams_t<ENC_ZSTD>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)(D + o_seqbufs), (const zenc::CTabs*)(D + o_ctabs), 0);
     else if (zlibc) hipLaunchKernelGGL(k_encode_streams_t<ENC_ZLIB>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)nullptr, (const zenc::CTabs*)nullptr, 0);
     else if (hc) hipLaunchKernelGGL(k_encode_streams_t<ENC_HC>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)nullptr, (const zenc::CTabs*)nullptr, periodic_enabled() ? 1 : 0);
     else hipLaunchKernelGGL(k_encode_streams_t<ENC_LZ>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)nullptr, (const zenc::CTabs*)nullptr, periodic_enabled() ? 1 : 0);

@@ -17,6 +17,12 @@
 
 namespace bamd {
 
+// Where lanes hand data to each other through LDS between two instructions, relying on the wavefront's lock step: nothing on
+// the device; the wavefront emulator of tests/tools/wave_emu (lanes are coroutines there) makes it a rendezvous.
+#ifndef BAMD_LDS_SYNC
+#define BAMD_LDS_SYNC() ((void)0)
+#endif
+
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 // a pointer every lane agrees on, moved into SGPRs: accesses off it become `global_* v, voffset32, s[base]`
 // instead of 64-bit VALU address arithmetic (function arguments and loaded pointers arrive in VGPRs)

@@ -1,0 +1,62 @@
+"""GPU: Zstd frames with sequence tables made per block (BLOSC_AMD_ZSTD_TABLES=1, k_encode.hip: zt_make_tables)
+instead of the predefined ones.  Same contract as every encoder here: stock c-blosc (ZSTD_decompress), the oracle and our own
+decoder read every chunk back bit-exactly; and the point of it - the ratio - is checked against the predefined-table frames.
+The CPU suite runs the same device source through the wavefront emulator (tests/test_wave_emu_encoders.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import DATASETS, header, orc_decompress, ref_compress, ref_decompress
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def tables_on():
+    old = os.environ.get("BLOSC_AMD_ZSTD_TABLES")
+    os.environ["BLOSC_AMD_ZSTD_TABLES"] = "1"
+    yield
+    if old is None:
+        del os.environ["BLOSC_AMD_ZSTD_TABLES"]
+    else:
+        os.environ["BLOSC_AMD_ZSTD_TABLES"] = old
+
+
+def _roundtrip(pkg, oracle, ref, data, T, clevel, shuffle, blocksize=0):
+    r, chunk = pkg.compress(data, T, clevel, shuffle, b"zstd", blocksize)
+    assert 0 < r <= data.size + 16
+    assert header(chunk)["cbytes"] == r
+    r2, out = orc_decompress(oracle, chunk, data.size)
+    assert r2 == data.size and np.array_equal(out, data)
+    if ref is not None:
+        r3, out3 = ref_decompress(ref, chunk, data.size)
+        assert r3 == data.size and np.array_equal(out3, data)
+    r4, out4 = pkg.decompress(chunk, data.size)
+    assert r4 == data.size and np.array_equal(out4, data)
+    return r
+
+
+def test_frames_with_block_tables_are_valid_everywhere(pkg, oracle, ref, tables_on):
+    for dname in ["bench19", "linspace", "randwalk", "smallints", "zeros", "random", "arange"]:
+        for T, shuffle in [(8, 1), (4, 1), (4, 2), (1, 0), (3, 1)]:
+            for n in [129, 1000, 32768, 65536 + 17, 300001, (1 << 21) + 5]:
+                if n > 400000 and (T != 8 or dname in ("zeros", "random", "arange")):
+                    continue
+                for clevel in ((1, 3, 9) if n <= 32768 else (3,)):
+                    _roundtrip(pkg, oracle, ref, DATASETS[dname](n), T, clevel, shuffle)
+    for bs in (128, 512, 4096, 1 << 20):            # tiny blocks (RLE tables, nothing to code) and frames of several Zstd blocks
+        _roundtrip(pkg, oracle, ref, DATASETS["bench19"](300001), 1, 3, 0, blocksize=bs)
+        _roundtrip(pkg, oracle, ref, DATASETS["linspace"](300001 * 8), 8, 3, 1, blocksize=bs * 8)
+
+
+def test_block_tables_ratio(pkg, oracle, ref, tables_on):
+    for dname, T, want in [("bench19", 8, 0.85), ("linspace", 8, 0.85), ("randwalk", 8, 1.005), ("smallints", 4, 1.005)]:
+        data = DATASETS[dname](16 << 20)
+        r = _roundtrip(pkg, oracle, ref, data, T, 3, 1)
+        os.environ["BLOSC_AMD_ZSTD_TABLES"] = "0"
+        rp, _ = pkg.compress(data, T, 3, 1, b"zstd", 0)
+        os.environ["BLOSC_AMD_ZSTD_TABLES"] = "1"
+        rr = ref_compress(ref, data, T, 3, 1, b"zstd", nthreads=8)[0] if ref is not None else 0
+        print(f"zstd clevel 3 {dname:9s} T={T}: per-block tables {data.size / r:8.2f}   predefined tables {data.size / rp:8.2f}   reference {data.size / rr if rr else 0:8.2f}")
+        assert r <= rp * want, (dname, r, rp)

@@ -1,6 +1,7 @@
-"""CPU: the wave-parallel LZ encoders of c-blosc_amd/csrc/k_encode.hip - lz_encode_wave (LZ4, BloscLZ) and
-lz4hc_encode_wave (the LZ4HC-grade search) - the SAME source the GPU runs, executed lane by lane on the CPU by the
-wavefront emulator of tests/tools/wave_emu (every cross-lane instruction is a rendezvous of 64 coroutines).  What they
+"""CPU: the wave-parallel encoders of c-blosc_amd/csrc/k_encode.hip - lz_encode_wave (LZ4, BloscLZ), lz4hc_encode_wave
+(the LZ4HC-grade search), zstd_encode_wave (predefined and per-block sequence tables) and zlib_encode_wave - the SAME
+source the GPU runs, executed lane by lane on the CPU by the wavefront emulator of tests/tools/wave_emu (every
+cross-lane instruction is a rendezvous of 64 coroutines; BAMD_LDS_SYNC marks where lanes talk through LDS).  What they
 write must be a valid stream: the oracle's LZ4 / BloscLZ decoders (pinned to the reference) and, where oracle/_ref
 ships, the reference's own decoders read every one of them back bit-exactly; a cross-lane instruction placed in
 divergent control flow aborts the run.  The GPU suite checks the same functions on the device; this file is what keeps
@@ -17,7 +18,7 @@ from helpers import DATASETS, ptr
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-LZ4, BLOSCLZ, LZ4HC = 0, 1, 2
+LZ4, BLOSCLZ, LZ4HC, ZSTD, ZLIB, ZSTD_TABLES = 0, 1, 2, 3, 4, 5
 
 
 @pytest.fixture(scope="module")
@@ -136,3 +137,79 @@ def test_lz4hc_search_finds_what_the_plain_one_misses(emu, oracle, ref):
     assert tot["hc"] <= tot["plain"] * 0.93
     if tot["ref"]:
         assert tot["hc"] <= tot["ref"] * 1.10
+
+
+def _zstd_reads(oracle, ref, stream, data):
+    n = data.size
+    oracle.orc_zstd_decompress.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    back = np.zeros(n + 8, np.uint8)
+    assert oracle.orc_zstd_decompress(ptr(stream), stream.size, ptr(back), n) == n and np.array_equal(back[:n], data)
+    if ref is not None:
+        ref.ZSTD_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        ref.ZSTD_decompress.restype = C.c_size_t
+        back2 = np.zeros(n + 8, np.uint8)
+        assert ref.ZSTD_decompress(ptr(back2), n, ptr(stream), stream.size) == n and np.array_equal(back2[:n], data)
+
+
+def _entropy_inputs():
+    rng = np.random.default_rng(9)
+    inputs = []
+    for dname in ["bench19", "linspace", "randwalk", "smallints", "arange"]:
+        for j in (0, 1, 5):
+            inputs.append(_plane(dname, 16384, 8, j))
+    inputs.append(_plane("bench19", 131072 + 4096, 8, 1))             # two blocks in one frame: the second one starts on a table the first one's scratch has overwritten
+    for n in [0, 1, 16, 31, 32, 33, 63, 64, 65, 100, 255, 256, 1000, 4097]:
+        inputs.append(np.zeros(n, np.uint8))                           # one sequence: every alphabet RLE
+        inputs.append((np.arange(n) % 5).astype(np.uint8))
+        inputs.append(rng.integers(0, 3, n, dtype=np.uint8))
+        inputs.append(rng.integers(0, 256, n, dtype=np.uint8))
+    inputs.append(np.concatenate([np.tile(rng.integers(0, 256, int(k), dtype=np.uint8), 40) for k in rng.integers(3, 200, 60)]))   # many match-length / offset codes
+    inputs.append(np.concatenate([rng.integers(0, 256, int(k), dtype=np.uint8) if i % 2 else np.zeros(int(k), np.uint8) for i, k in enumerate(rng.integers(1, 90, 400))]))  # many literal-length codes
+    return inputs
+
+
+@pytest.mark.parametrize("kind", [ZSTD, ZSTD_TABLES], ids=["predefined", "per-block-tables"])
+def test_zstd_frames_decode_with_oracle_and_reference(emu, oracle, ref, kind):
+    cases = 0
+    for data in _entropy_inputs():
+        for clevel in (1, 3, 9):
+            r, s = _encode(emu, kind, data, clevel=clevel)
+            if r:
+                assert r < data.size
+                _zstd_reads(oracle, ref, s, data)
+                cases += 1
+    assert cases > 60
+    # capacity: a complete frame inside what it was given, or 0
+    data = _plane("bench19", 16384, 8, 1)
+    full, _ = _encode(emu, kind, data, clevel=3)
+    assert full > 0
+    for cap in [0, 20, 63, 64, 100, full - 30, full - 1, full, full + 1, full + 40, data.size]:
+        r, s = _encode(emu, kind, data, cap=max(cap, 0), clevel=3)
+        if r:
+            _zstd_reads(oracle, ref, s, data)
+
+
+def test_zstd_tables_made_for_the_block_pay(emu, oracle, ref):
+    """Sizes with per-block tables against the predefined ones on the SURVEY 8d planes (16 KiB: what a 64 MiB chunk's blocks
+    look like at clevel 3): never larger by more than a header's worth, and on bench19 / linspace at least 20 % smaller."""
+    for dname, want in (("bench19", 0.83), ("linspace", 0.83), ("randwalk", 1.001), ("smallints", 1.001)):
+        a = b = 0
+        for j in range(8):
+            data = _plane(dname, 16384, 8, j)
+            ra, _ = _encode(emu, ZSTD, data, clevel=3)
+            rb, s = _encode(emu, ZSTD_TABLES, data, clevel=3)
+            a += ra or data.size; b += rb or data.size
+        print(f"{dname}: predefined tables {8 * 16384 / a:.2f}, per-block tables {8 * 16384 / b:.2f}")
+        assert b <= a * want, (dname, a, b)
+
+
+def test_zlib_streams_decode(emu, oracle, ref):
+    import zlib
+    cases = 0
+    for data in _entropy_inputs():
+        for clevel in (1, 5, 9):
+            r, s = _encode(emu, ZLIB, data, clevel=clevel)
+            if r:
+                assert zlib.decompress(s.tobytes()) == data.tobytes()
+                cases += 1
+    assert cases > 60

@@ -13,27 +13,37 @@
 #include "k_encode.hip"
 
 namespace {
-struct Job { int kind; const uint8_t* src; int n; uint8_t* dst; int cap; int clevel; uint32_t* tab; uint32_t result; };
+struct Job { int kind; const uint8_t* src; int n; uint8_t* dst; int cap; int clevel; uint32_t* tab; uint32_t result; uint64_t* seqbuf; };
 
 void lane_body(int lane, void* arg) {
   Job* j = (Job*)arg;
   using namespace bamd;
   uint32_t r;
-  if (j->kind == 2) r = lz4hc_encode_wave((const gu8*)j->src, (uint32_t)j->n, (gu8*)j->dst, (uint32_t)j->cap, j->tab, lane);
+  if (j->kind == 5) r = zstd_encode_wave<true>((const gu8*)j->src, (uint32_t)j->n, (gu8*)j->dst, (uint32_t)j->cap, j->clevel, j->tab, (BAMD_GAS uint64_t*)j->seqbuf, lane);
+  else if (j->kind == 3) r = zstd_encode_wave((const gu8*)j->src, (uint32_t)j->n, (gu8*)j->dst, (uint32_t)j->cap, j->clevel, j->tab, (BAMD_GAS uint64_t*)j->seqbuf, lane);
+  else if (j->kind == 4) r = zlib_encode_wave((const gu8*)j->src, (uint32_t)j->n, (gu8*)j->dst, (uint32_t)j->cap, j->clevel, j->tab, lane);
+  else if (j->kind == 2) r = lz4hc_encode_wave((const gu8*)j->src, (uint32_t)j->n, (gu8*)j->dst, (uint32_t)j->cap, j->tab, lane);
   else if (j->kind == 1) r = lz_encode_wave<EF_BLOSCLZ>((const gu8*)j->src, (uint32_t)j->n, (gu8*)j->dst, (uint32_t)j->cap, j->clevel, j->tab, lane);
   else r = lz_encode_wave<EF_LZ4>((const gu8*)j->src, (uint32_t)j->n, (gu8*)j->dst, (uint32_t)j->cap, j->clevel, j->tab, lane);
   if (lane == 0) j->result = r;
 }
 }  // namespace
 
-// kind: 0 = LZ4, 1 = BloscLZ, 2 = LZ4 with the LZ4HC-grade search.  Returns the stream size (0 = "store raw").
+// kind: 0 = LZ4, 1 = BloscLZ, 2 = LZ4 with the LZ4HC-grade search, 3 = Zstd frame, 4 = zlib stream, 5 = Zstd frame with per-block sequence tables.  Returns the stream
+// size (0 = "store raw").
 extern "C" int emu_lz_encode(int kind, const uint8_t* src, int n, uint8_t* dst, int cap, int clevel, unsigned long long* rendezvous) {
-  Job j = {kind, src, n, dst, cap, clevel, nullptr, 0};
+  Job j = {kind, src, n, dst, cap, clevel, nullptr, 0, nullptr};
   // the wave's LDS: big enough for either table, 16-byte aligned, poisoned (the kernels clear what they use)
   j.tab = (uint32_t*)aligned_alloc(64, 64 * 1024);
   memset(j.tab, 0xA5, 64 * 1024);
+  if (kind == 3 || kind == 5) {      // what k_encode_streams_t<ENC_ZSTD> sets up once per persistent wave: the predefined tables behind the hash table, the sequence scratch
+    static bamd::zenc::CTabs predefined;
+    bamd::zenc::build_predefined(predefined);
+    memcpy((uint8_t*)j.tab + bamd::ENC_TAB_BYTES, &predefined, sizeof predefined);
+    j.seqbuf = (uint64_t*)malloc(sizeof(uint64_t) * bamd::ZS_SEQCAP);
+  }
   wave_emu::run(lane_body, &j);
   if (rendezvous) *rendezvous = wave_emu::last_rendezvous();
-  free(j.tab);
+  free(j.tab); free(j.seqbuf);
   return (int)j.result;
 }
