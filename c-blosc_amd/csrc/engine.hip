@@ -243,6 +243,7 @@ static bool lz4hc_search_enabled() { const char* e = getenv("BLOSC_AMD_LZ4HC"); 
 #define BAMD_ZSTD_TABLES_DEFAULT 0
 #endif
 static bool zstd_tables_enabled() { const char* e = getenv("BLOSC_AMD_ZSTD_TABLES"); return e ? atoi(e) != 0 : (BAMD_ZSTD_TABLES_DEFAULT != 0); }
+static bool env_flag(const char* name) { const char* e = getenv(name); return e && atoi(e) != 0; }
 static bool periodic_enabled() { static const bool on = !(getenv("BLOSC_AMD_PERIODIC") && atoi(getenv("BLOSC_AMD_PERIODIC")) == 0); return on; }
 // BLOSC_AMD_ZSTD2: 2 (default) = two-phase path, 16 frames per wave, tables in a global scratch (k_zstd2.hip);
 // 1 = the same with the tables in LDS (one wave per CU); 0 = one wave per frame for everything (k_zstd_streams).
@@ -365,8 +366,10 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   // Zstd: sequence tables made per block (k_encode.hip: zt_make_tables) instead of the predefined ones; opt-in (BLOSC_AMD_ZSTD_TABLES=1)
   // until it has been timed on the device, read per call
   const bool ztab = zstd && zstd_tables_enabled();
+  // the LZ4HC-grade search in front of the Zstd writer (with per-block tables) / the zlib writer: BLOSC_AMD_ZSTD_SEARCH=1, BLOSC_AMD_ZLIB_SEARCH=1
+  const bool zsearch = (zstd && env_flag("BLOSC_AMD_ZSTD_SEARCH")) || (zlibc && env_flag("BLOSC_AMD_ZLIB_SEARCH"));
   static const int enc_wpc_lz = getenv("BLOSC_AMD_ENC_WPC") ? atoi(getenv("BLOSC_AMD_ENC_WPC")) : ENC_WAVES_PER_CU;
-  const int enc_wpc = hc ? HC_WAVES_PER_CU : enc_wpc_lz;
+  const int enc_wpc = zsearch ? (160 * 1024) / (HC_TAB_BYTES + ZS_LDS_BYTES) : (hc ? HC_WAVES_PER_CU : enc_wpc_lz);   // what fits into a CU's LDS
   const size_t zwaves = zstd ? (size_t)(st.cus > 0 ? st.cus : 256) * (size_t)enc_wpc : 0;
   const size_t o_ctabs = cv.take(sizeof(zenc::CTabs) + 64);
   const size_t o_seqbufs = cv.take(zwaves * ZS_SEQCAP * sizeof(uint64_t) + 64);
@@ -457,14 +460,26 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
     const int32_t* d_qoff = (const int32_t*)(D + o_queues); const int32_t* d_qlist = d_qoff + 9;
     uint32_t* d_ready = (uint32_t*)(D + o_ready);
     const size_t ntasks = queues.size() - 9;
+    uint64_t* d_seqbufs = zstd ? (uint64_t*)(D + o_seqbufs) : nullptr;
+    const zenc::CTabs* d_ctabs = zstd ? (const zenc::CTabs*)(D + o_ctabs) : nullptr;
+    const int detect = (!zstd && !zlibc && periodic_enabled()) ? 1 : 0;
+    const dim3 grid(persistent_grid(ntasks, enc_wpc)), block(64 * ENC_WAVES);
 #ifdef BAMD_PROFILE_DECODE
     uint32_t* d_prof = nullptr;
     if (getenv("BLOSC_AMD_ENC_PROFILE")) { (void)hipMalloc((void**)&d_prof, nstr * 64); (void)hipMemsetAsync(d_prof, 0, nstr * 64, stream); }
-    if (zstd && ztab) hipLaunchKernelGGL(k_encode_streams_t<ENC_ZSTD_T>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)(D + o_seqbufs), (const zenc::CTabs*)(D + o_ctabs), 0, d_prof);
-    else if (zstd) hipLaunchKernelGGL(k_encode_streams_t<ENC_ZSTD>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)(D + o_seqbufs), (const zenc::CTabs*)(D + o_ctabs), 0, d_prof);
-    else if (zlibc) hipLaunchKernelGGL(k_encode_streams_t<ENC_ZLIB>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)nullptr, (const zenc::CTabs*)nullptr, 0, d_prof);
-    else if (hc) hipLaunchKernelGGL(k_encode_streams_t<ENC_HC>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)nullptr, (const zenc::CTabs*)nullptr, periodic_enabled() ? 1 : 0, d_prof);
-    else hipLaunchKernelGGL(k_encode_streams_t<ENC_LZ>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)nullptr, (const zenc::CTabs*)nullptr, periodic_enabled() ? 1 : 0, d_prof);
+#define BAMD_ENC_LAUNCH(MODE) hipLaunchKernelGGL(k_encode_streams_t<MODE>, grid, block, 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, d_seqbufs, d_ctabs, detect, d_prof)
+#else
+#define BAMD_ENC_LAUNCH(MODE) hipLaunchKernelGGL(k_encode_streams_t<MODE>, grid, block, 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, d_seqbufs, d_ctabs, detect)
+#endif
+    if (zstd && zsearch) BAMD_ENC_LAUNCH(ENC_ZSTD_HC);
+    else if (zstd && ztab) BAMD_ENC_LAUNCH(ENC_ZSTD_T);
+    else if (zstd) BAMD_ENC_LAUNCH(ENC_ZSTD);
+    else if (zlibc && zsearch) BAMD_ENC_LAUNCH(ENC_ZLIB_HC);
+    else if (zlibc) BAMD_ENC_LAUNCH(ENC_ZLIB);
+    else if (hc) BAMD_ENC_LAUNCH(ENC_HC);
+    else BAMD_ENC_LAUNCH(ENC_LZ);
+#undef BAMD_ENC_LAUNCH
+#ifdef BAMD_PROFILE_DECODE
     if (d_prof) {
       std::vector<uint32_t> h(nstr * 16);
       (void)hipStreamSynchronize(stream);
@@ -473,12 +488,6 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
       if (f) { fwrite(h.data(), 4, h.size(), f); fclose(f); }
       (void)hipFree(d_prof);
     }
-#else
-    if (zstd && ztab) hipLaunchKernelGGL(k_encode_streams_t<ENC_ZSTD_T>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)(D + o_seqbufs), (const zenc::CTabs*)(D + o_ctabs), 0);
-    else if (zstd) hipLaunchKernelGGL(k_encode_streams_t<ENC_ZSTD>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)(D + o_seqbufs), (const zenc::CTabs*)(D + o_ctabs), 0);
-    else if (zlibc) hipLaunchKernelGGL(k_encode_streams_t<ENC_ZLIB>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)nullptr, (const zenc::CTabs*)nullptr, 0);
-    else if (hc) hipLaunchKernelGGL(k_encode_streams_t<ENC_HC>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)nullptr, (const zenc::CTabs*)nullptr, periodic_enabled() ? 1 : 0);
-    else hipLaunchKernelGGL(k_encode_streams_t<ENC_LZ>, dim3(persistent_grid(ntasks, enc_wpc)), dim3(64 * ENC_WAVES), 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, (uint64_t*)nullptr, (const zenc::CTabs*)nullptr, periodic_enabled() ? 1 : 0);
 #endif
   }
   {

@@ -646,18 +646,22 @@ struct HcTable {
 __device__ __forceinline__ uint32_t hc_slot(uint32_t mix) { return mix >> (32 - HC_HASH_BITS); }
 __device__ __forceinline__ uint32_t hc_tag(uint32_t mix) { return (mix << HC_HASH_BITS) >> 24; }
 
-__device__ uint32_t lz4hc_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8* __restrict__ dst, uint32_t cap,
-                                      enc_entry_t* tab_generic, int lane) {
+// FMT: EF_LZ4 (the "lz4hc" compressor), or EF_ZSTD / EF_ZLIB: the same search in front of the Zstd / zlib writers (their sinks, the
+// part [start, n) of the stream and the return value as in lz_encode_wave)
+template <int FMT>
+__device__ uint32_t hc_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8* __restrict__ dst, uint32_t cap,
+                                   enc_entry_t* tab_generic, int lane, uint32_t start = 0, ZsSink* zs = nullptr, DflSink* df = nullptr) {
   HcTable tab;
   tab.init((void*)tab_generic);
-  if (n < 13u) return 0u;                                     // lz4.c:245-246, :963-964 as in lz_encode_wave
+  if (FMT == EF_LZ4) { if (n < 13u) return 0u; }              // lz4.c:245-246, :963-964 as in lz_encode_wave
+  else if (n < start + 16u) return start;
   const uint32_t last_start = n - 12u;
-  const uint32_t mlimit = n - 5u;
+  const uint32_t mlimit = (FMT == EF_LZ4) ? n - 5u : n - 2u;
   const uint32_t minlen = 4u;
-  tab.clear(lane);
+  if (start == 0u) tab.clear(lane);
   EncWindow win;
   win.init(src, n, lane);
-  uint32_t ip = 0, anchor = 0, op = 0, nfail = 0;
+  uint32_t ip = start, anchor = start, op = 0, nfail = 0;
   bool ins_pending = false;
   while (ip <= last_start) {
     const uint32_t p = ip + (uint32_t)lane;
@@ -711,7 +715,7 @@ __device__ uint32_t lz4hc_encode_wave(const gu8* __restrict__ src, uint32_t n, g
       for (int w = 0; w < 4; w++) {
         const uint32_t e = (uint32_t)(pp >> (16 * w)) & 0xffffu;
         const uint32_t d = (p - e) & 0xffffu;
-        bool ok = live && d != 0u && d <= p && ((tt >> (8 * w)) & 0xffu) == mytag;
+        bool ok = live && d != 0u && d <= p && ((tt >> (8 * w)) & 0xffu) == mytag && (FMT != EF_ZLIB || d <= dfl::kMaxDist);
 #pragma unroll
         for (int v = 0; v < w; v++) ok = ok && !(((okm >> v) & 1u) && dw[v] == d);   // the same position twice in a bucket
         dw[w] = d;
@@ -794,8 +798,14 @@ __device__ uint32_t lz4hc_encode_wave(const gu8* __restrict__ src, uint32_t n, g
       const uint64_t bm = __ballot(bx != by);          // lanes >= maxb always vote "differs"
       const uint32_t back = bm ? (uint32_t)__builtin_ctzll(bm) : 64u;
       pm -= back; cm -= back; mlen += back;
-      op = lz4_emit_seq(dst, op, cap, src + anchor, pm - anchor, pm - cm, mlen, anchor >= ip ? (int)(anchor - ip) : -1, (uint32_t)own.a & 0xffu, lane);
-      if (op == 0xffffffffu) return 0u;
+      if (FMT == EF_LZ4) {
+        op = lz4_emit_seq(dst, op, cap, src + anchor, pm - anchor, pm - cm, mlen, anchor >= ip ? (int)(anchor - ip) : -1, (uint32_t)own.a & 0xffu, lane);
+        if (op == 0xffffffffu) return 0u;
+      } else if (FMT == EF_ZSTD) {
+        if (zs_emit_seq(*zs, src + anchor, pm - anchor, pm - cm, mlen, anchor >= ip ? (int)(anchor - ip) : -1, (uint32_t)own.a & 0xffu, lane) == 0xffffffffu) return 0xffffffffu;
+      } else {
+        if (dfl_emit_seq(*df, src + anchor, pm - anchor, pm - cm, mlen, anchor >= ip ? (int)(anchor - ip) : -1, (uint32_t)own.a & 0xffu, lane) == 0xffffffffu) return 0xffffffffu;
+      }
       anchor = pm + mlen;
       if (anchor >= step_end) break;
       lane_lo = anchor - ip;
@@ -818,9 +828,13 @@ __device__ uint32_t lz4hc_encode_wave(const gu8* __restrict__ src, uint32_t n, g
       ip = step_end;
     }
   }
+  if (FMT != EF_LZ4) return anchor;
   op = lz4_emit_tail(dst, op, cap, src + anchor, n - anchor, lane);
   if (op == 0xffffffffu) return 0u;
   return op < n ? op : 0u;
+}
+__device__ uint32_t lz4hc_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8* __restrict__ dst, uint32_t cap, enc_entry_t* tab_generic, int lane) {
+  return hc_encode_wave<EF_LZ4>(src, n, dst, cap, tab_generic, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1231,7 +1245,7 @@ __device__ __forceinline__ uint32_t zs_write_sequences_v(gu8* out, uint32_t room
 // then stored raw by blosc's own rule, blosc.c:703-717).  `seqbuf`: zenc::kBlockMax / 4 entries of this wave.
 constexpr uint32_t ZS_SEQCAP = zenc::kBlockMax / 4u;
 constexpr int ZS_LDS_BYTES = (int)((sizeof(zenc::CTabs) + 15) / 16 * 16);
-template <bool TABLES = false>
+template <bool TABLES = false, bool HC = false>      // HC: the LZ4HC-grade search (hc_encode_wave) as the match finder, its 24 KiB table in front of the FSE tables
 __device__ uint32_t zstd_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8* __restrict__ dst, uint32_t cap, int clevel,
                                      enc_entry_t* tab_generic, BAMD_GAS uint64_t* seqbuf, int lane EPROF_ARG) {
   if (n < 32u || cap < 64u) return 0u;
@@ -1253,7 +1267,8 @@ __device__ uint32_t zstd_encode_wave(const gu8* __restrict__ src, uint32_t n, gu
     z.lit = bh + zenc::kBlockHeader + zenc::kLitHeader; z.nlit = 0;
     z.litcap = cap - (op + zenc::kBlockHeader + zenc::kLitHeader);
     z.seq = seqbuf; z.nseq = 0; z.seqcap = ZS_SEQCAP;
-    const uint32_t covered = lz_encode_wave<EF_ZSTD>(src, s1, dst, cap, clevel, tab_generic, lane EPROF_PASS, s0, &z);
+    const uint32_t covered = HC ? hc_encode_wave<EF_ZSTD>(src, s1, dst, cap, tab_generic, lane, s0, &z)
+                                : lz_encode_wave<EF_ZSTD>(src, s1, dst, cap, clevel, tab_generic, lane EPROF_PASS, s0, &z);
     uint32_t bsize = 0xffffffffu;
     const zenc::RepState rep_before = rep;
     if (covered != 0xffffffffu && z.nlit + (s1 - covered) <= z.litcap) {
@@ -1261,7 +1276,7 @@ __device__ uint32_t zstd_encode_wave(const gu8* __restrict__ src, uint32_t n, gu
       z.nlit += s1 - covered;
       if (lane == 0) { uint8_t h[4]; zenc::write_raw_literals_header(h, z.nlit); bh[3] = h[0]; bh[4] = h[1]; bh[5] = h[2]; }
       // the FSE tables sit behind this wave's hash table in LDS (k_encode_streams_t<true> puts them there once)
-      const BAMD_LAS zenc::CTabs* T = (const BAMD_LAS zenc::CTabs*)((BAMD_LAS uint8_t*)(void*)tab_generic + ENC_TAB_BYTES);
+      const BAMD_LAS zenc::CTabs* T = (const BAMD_LAS zenc::CTabs*)((BAMD_LAS uint8_t*)(void*)tab_generic + (HC ? HC_TAB_BYTES : ENC_TAB_BYTES));
       __builtin_amdgcn_s_waitcnt(0);      // this wave's sequence triples are in memory before other lanes load them
       zs_assign_offset_values(seqbuf, z.nseq, rep, lane);
       __builtin_amdgcn_s_waitcnt(0);
@@ -1297,16 +1312,18 @@ __device__ uint32_t zstd_encode_wave(const gu8* __restrict__ src, uint32_t n, gu
 // Returns the stream size, or 0 when it would not be smaller than the input (blosc then stores the split raw).
 // ---------------------------------------------------------------------------------------------
 constexpr int DFL_LDS_BYTES = 65 * 4 + 12;     // the 65-dword strip of dfl_put_symbols, rounded to 16 bytes
+template <bool HC = false>
 __device__ uint32_t zlib_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8* __restrict__ dst, uint32_t cap, int clevel,
                                      enc_entry_t* tab_generic, int lane EPROF_ARG) {
   if (n < 16u || cap < 64u) return 0u;
   DflSink z;
   z.out = dst; z.cap = cap; z.pos = dfl::kHeader;
-  z.zb = (volatile BAMD_LAS uint32_t*)((BAMD_LAS uint8_t*)(void*)tab_generic + ENC_TAB_BYTES);
+  z.zb = (volatile BAMD_LAS uint32_t*)((BAMD_LAS uint8_t*)(void*)tab_generic + (HC ? HC_TAB_BYTES : ENC_TAB_BYTES));
   if (lane == 0) { uint8_t h[2]; dfl::write_header(h); dst[0] = h[0]; dst[1] = h[1]; }
   const dfl::Sym bh = dfl::block_header();
   z.acc = bh.bits; z.nb = bh.nbits;
-  const uint32_t covered = lz_encode_wave<EF_ZLIB>(src, n, dst, cap, clevel, tab_generic, lane EPROF_PASS, 0u, nullptr, &z);
+  const uint32_t covered = HC ? hc_encode_wave<EF_ZLIB>(src, n, dst, cap, tab_generic, lane, 0u, nullptr, &z)
+                              : lz_encode_wave<EF_ZLIB>(src, n, dst, cap, clevel, tab_generic, lane EPROF_PASS, 0u, nullptr, &z);
   if (covered == 0xffffffffu) return 0u;
   // the literals behind the last match, then the end-of-block symbol.  A literal costs at least 8 bits: when what is left
   // cannot fit below n any more (incompressible planes end here with everything still pending), skip the packing
@@ -1500,7 +1517,9 @@ __device__ __forceinline__ uint32_t emit_periodic_stream(const gu8* in, uint32_t
 // one stream, not inlined into the queue loop (see decode_one_stream in k_decode.hip for why)
 // MODE: 0 = LZ4 / BloscLZ, 1 = Zstd, 2 = Zlib, 3 = LZ4 with the LZ4HC-grade search, 4 = Zstd with per-block sequence tables -
 // a batch has ONE codec, so every kernel carries only its own code path
-enum { ENC_LZ = 0, ENC_ZSTD = 1, ENC_ZLIB = 2, ENC_HC = 3, ENC_ZSTD_T = 4 };
+// 5 = Zstd with per-block tables behind the LZ4HC-grade search, 6 = zlib behind the LZ4HC-grade search
+enum { ENC_LZ = 0, ENC_ZSTD = 1, ENC_ZLIB = 2, ENC_HC = 3, ENC_ZSTD_T = 4, ENC_ZSTD_HC = 5, ENC_ZLIB_HC = 6 };
+constexpr bool enc_mode_hc(int mode) { return mode == ENC_HC || mode == ENC_ZSTD_HC || mode == ENC_ZLIB_HC; }
 template <int MODE>
 __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, enc_entry_t* tab, const ChunkDesc* chunks, uint32_t* blk_ready, int lane,
                                                             const BlockDesc* blocks, uint32_t sid, uint32_t* plane_cost, uint64_t* seqbuf
@@ -1526,6 +1545,8 @@ __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, enc_
   uint32_t r;
   const int32_t hint = (int32_t)uni((uint32_t)sd->result);      // < 0: the shuffle task found this plane periodic (period -hint)
   if (MODE == ENC_ZSTD) r = seqbuf ? zstd_encode_wave(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, (BAMD_GAS uint64_t*)seqbuf, lane EPROF_PASS) : 0u;
+  else if (MODE == ENC_ZSTD_HC) r = seqbuf ? zstd_encode_wave<true, true>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, (BAMD_GAS uint64_t*)seqbuf, lane EPROF_PASS) : 0u;
+  else if (MODE == ENC_ZLIB_HC) r = zlib_encode_wave<true>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, lane EPROF_PASS);
   else if (MODE == ENC_ZSTD_T) r = seqbuf ? zstd_encode_wave<true>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, (BAMD_GAS uint64_t*)seqbuf, lane EPROF_PASS) : 0u;
   else if (MODE == ENC_ZLIB) r = zlib_encode_wave(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, lane EPROF_PASS);
   else if (hint < 0) r = emit_periodic_stream(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, (uint32_t)-hint, uni((uint32_t)sd->fmt) == (uint32_t)FMT_LZ4, lane);
@@ -1550,7 +1571,7 @@ __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, enc_
 // build_encode_queues), so the bandwidth-bound transposes run underneath the latency/issue-bound match
 // finding of other waves instead of in a kernel of their own.
 template <int MODE>
-__global__ __launch_bounds__(64 * ENC_WAVES, MODE == ENC_HC ? 2 : BAMD_ENC_MINWAVES) void k_encode_streams_t(
+__global__ __launch_bounds__(64 * ENC_WAVES, enc_mode_hc(MODE) ? 2 : BAMD_ENC_MINWAVES) void k_encode_streams_t(
     StreamDesc* __restrict__ streams, uint32_t* __restrict__ tickets /*[8]*/, const int32_t* __restrict__ qlist,
     const int32_t* __restrict__ qoff /*[9]*/, const ChunkDesc* __restrict__ chunks, const BlockDesc* __restrict__ blocks,
     uint32_t* __restrict__ blk_ready, uint32_t* __restrict__ plane_cost, int single_queue,
@@ -1559,14 +1580,15 @@ __global__ __launch_bounds__(64 * ENC_WAVES, MODE == ENC_HC ? 2 : BAMD_ENC_MINWA
     , uint32_t* __restrict__ profbuf
 #endif
     ) {
-  constexpr bool ZSTD = MODE == ENC_ZSTD || MODE == ENC_ZSTD_T;
-  __shared__ __attribute__((aligned(16))) enc_entry_t tabs[ENC_WAVES][(MODE == ENC_HC ? HC_TAB_BYTES : ENC_TAB_BYTES + (ZSTD ? ZS_LDS_BYTES : (MODE == ENC_ZLIB ? DFL_LDS_BYTES : 0))) / 4];
+  constexpr bool ZSTD = MODE == ENC_ZSTD || MODE == ENC_ZSTD_T || MODE == ENC_ZSTD_HC;
+  constexpr int TABBYTES = enc_mode_hc(MODE) ? HC_TAB_BYTES : ENC_TAB_BYTES;      // the match finder's table; the writers' LDS sits behind it
+  __shared__ __attribute__((aligned(16))) enc_entry_t tabs[ENC_WAVES][(TABBYTES + (ZSTD ? ZS_LDS_BYTES : ((MODE == ENC_ZLIB || MODE == ENC_ZLIB_HC) ? DFL_LDS_BYTES : 0))) / 4];
   static_assert(ENC_WAVES == 1, "one stream per wave, one wave per workgroup");
   const int lane = threadIdx.x & 63;
   uint64_t* seqbuf = nullptr;
   if (ZSTD) {       // the predefined FSE tables of the sequence coder, once per persistent wave
     const uint32_t* g = (const uint32_t*)ctabs;
-    for (uint32_t k = (uint32_t)lane; k < sizeof(zenc::CTabs) / 4u; k += 64u) tabs[0][ENC_TAB_BYTES / 4 + k] = g[k];
+    for (uint32_t k = (uint32_t)lane; k < sizeof(zenc::CTabs) / 4u; k += 64u) tabs[0][TABBYTES / 4 + k] = g[k];
     seqbuf = seqbufs + (size_t)blockIdx.x * ZS_SEQCAP;
   }
   // HW_REG_XCC_ID[3:0]; queue 0 for everybody in the single-queue fallback (no in-kernel hand-offs there)

@@ -60,3 +60,35 @@ def test_block_tables_ratio(pkg, oracle, ref, tables_on):
         rr = ref_compress(ref, data, T, 3, 1, b"zstd", nthreads=8)[0] if ref is not None else 0
         print(f"zstd clevel 3 {dname:9s} T={T}: per-block tables {data.size / r:8.2f}   predefined tables {data.size / rp:8.2f}   reference {data.size / rr if rr else 0:8.2f}")
         assert r <= rp * want, (dname, r, rp)
+
+
+@pytest.mark.parametrize("codec,switch", [(b"zstd", "BLOSC_AMD_ZSTD_SEARCH"), (b"zlib", "BLOSC_AMD_ZLIB_SEARCH")], ids=["zstd", "zlib"])
+def test_lz4hc_search_in_front_of_the_entropy_writers(pkg, oracle, ref, codec, switch):
+    """BLOSC_AMD_ZSTD_SEARCH=1 / BLOSC_AMD_ZLIB_SEARCH=1: the LZ4HC-grade search of DESIGN.md 3.9 feeds the Zstd writer (with per-block
+    tables) / the zlib writer.  Chunks must be read by everybody; the ratio is printed next to the plain path's and the reference's."""
+    old = os.environ.get(switch)
+    try:
+        for dname, T in [("bench19", 8), ("linspace", 8), ("smallints", 4), ("randwalk", 8), ("zeros", 8)]:
+            for n in (1000, 65536 + 17, 300001, 4 << 20):
+                data = DATASETS[dname](n)
+                os.environ[switch] = "1"
+                r, chunk = pkg.compress(data, T, 5, 1, codec, 0)
+                os.environ[switch] = "0"
+                rp, _ = pkg.compress(data, T, 5, 1, codec, 0)
+                assert 0 < r <= data.size + 16 and header(chunk)["cbytes"] == r
+                r2, out = orc_decompress(oracle, chunk, data.size)
+                assert r2 == data.size and np.array_equal(out, data)
+                if ref is not None:
+                    r3, out3 = ref_decompress(ref, chunk, data.size)
+                    assert r3 == data.size and np.array_equal(out3, data)
+                r4, out4 = pkg.decompress(chunk, data.size)
+                assert r4 == data.size and np.array_equal(out4, data)
+                if n == 4 << 20:
+                    rr = ref_compress(ref, data, T, 5, 1, codec, nthreads=8)[0] if ref is not None else 0
+                    print(f"{codec.decode()} clevel 5 {dname:9s}: with the search {data.size / r:8.2f}   plain {data.size / rp:8.2f}   reference {data.size / rr if rr else 0:8.2f}")
+                    assert r <= rp * 1.02
+    finally:
+        if old is None:
+            os.environ.pop(switch, None)
+        else:
+            os.environ[switch] = old

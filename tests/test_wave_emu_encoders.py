@@ -18,7 +18,7 @@ from helpers import DATASETS, ptr
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-LZ4, BLOSCLZ, LZ4HC, ZSTD, ZLIB, ZSTD_TABLES = 0, 1, 2, 3, 4, 5
+LZ4, BLOSCLZ, LZ4HC, ZSTD, ZLIB, ZSTD_TABLES, ZSTD_SEARCH, ZLIB_SEARCH = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 @pytest.fixture(scope="module")
@@ -168,17 +168,17 @@ def _entropy_inputs():
     return inputs
 
 
-@pytest.mark.parametrize("kind", [ZSTD, ZSTD_TABLES], ids=["predefined", "per-block-tables"])
+@pytest.mark.parametrize("kind", [ZSTD, ZSTD_TABLES, ZSTD_SEARCH], ids=["predefined", "per-block-tables", "tables+lz4hc-search"])
 def test_zstd_frames_decode_with_oracle_and_reference(emu, oracle, ref, kind):
     cases = 0
     for data in _entropy_inputs():
-        for clevel in (1, 3, 9):
+        for clevel in ((1, 3, 9) if kind != ZSTD_SEARCH else (3,)):
             r, s = _encode(emu, kind, data, clevel=clevel)
             if r:
                 assert r < data.size
                 _zstd_reads(oracle, ref, s, data)
                 cases += 1
-    assert cases > 60
+    assert cases > (60 if kind != ZSTD_SEARCH else 20)
     # capacity: a complete frame inside what it was given, or 0
     data = _plane("bench19", 16384, 8, 1)
     full, _ = _encode(emu, kind, data, clevel=3)
@@ -203,13 +203,14 @@ def test_zstd_tables_made_for_the_block_pay(emu, oracle, ref):
         assert b <= a * want, (dname, a, b)
 
 
-def test_zlib_streams_decode(emu, oracle, ref):
+@pytest.mark.parametrize("kind", [ZLIB, ZLIB_SEARCH], ids=["plain", "lz4hc-search"])
+def test_zlib_streams_decode(emu, oracle, ref, kind):
     import zlib
     cases = 0
     for data in _entropy_inputs():
-        for clevel in (1, 5, 9):
-            r, s = _encode(emu, ZLIB, data, clevel=clevel)
+        for clevel in ((1, 5, 9) if kind == ZLIB else (5,)):
+            r, s = _encode(emu, kind, data, clevel=clevel)
             if r:
                 assert zlib.decompress(s.tobytes()) == data.tobytes()
                 cases += 1
-    assert cases > 60
+    assert cases > (60 if kind == ZLIB else 20)
