@@ -40,7 +40,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (6.29 TB/s measured copy)
-COMPRESS_KERNELS = ["k_shuffle", "k_bitshuffle", "k_encode_streams", "k_zstd_encode", "k_zlib_encode", "k_chunk_scan", "k_chunk_compact"]
+COMPRESS_KERNELS = ["k_shuffle", "k_bitshuffle", "k_encode_streams", "k_lz4hc_encode", "k_zstd_encode", "k_zlib_encode", "k_chunk_scan", "k_chunk_compact"]
 DECOMPRESS_KERNELS = ["k_decode_plan", "k_classify_blocks", "k_decode_streams", "k_decode_blocks", "k_decode_blocks8", "k_zstd_entropy", "k_zstd_exec", "k_zstd_streams", "k_zlib_streams", "k_unshuffle",
                       "k_bitunshuffle", "k_copy_chunks"]
 KERNELS = COMPRESS_KERNELS + DECOMPRESS_KERNELS
@@ -62,6 +62,11 @@ CONFIGS = {
     "1g": dict(codec="blosclz", shuffle=1, typesize=8, clevel=5, data="bench19"),
     "z":  dict(codec="zlib", shuffle=1, typesize=8, clevel=5, data="bench19"),
     "zb": dict(codec="zlib", shuffle=1, typesize=8, clevel=5, data="linspace"),
+    # the encoder options of DESIGN.md 3.6 / 3.9 (an "env" entry is put into the environment before the library is used)
+    "h":  dict(codec="lz4hc", shuffle=1, typesize=8, clevel=9, data="bench19"),
+    "4t": dict(codec="zstd", shuffle=1, typesize=8, clevel=3, data="bench19", env={"BLOSC_AMD_ZSTD_TABLES": "1"}),
+    "4s": dict(codec="zstd", shuffle=1, typesize=8, clevel=3, data="bench19", env={"BLOSC_AMD_ZSTD_SEARCH": "1"}),
+    "zs": dict(codec="zlib", shuffle=1, typesize=8, clevel=5, data="bench19", env={"BLOSC_AMD_ZLIB_SEARCH": "1"}),
 }
 FILTER_NAME = {0: "no filter", 1: "byte-shuffle", 2: "bitshuffle"}
 
@@ -253,6 +258,7 @@ def main():
     ap.add_argument("--no-stock", action="store_true", help="skip the decompression of reference-written chunks")
     args = ap.parse_args()
     cfg = dict(CONFIGS[args.config])
+    os.environ.update(cfg.pop("env", {}))
     for k in ("typesize", "clevel", "shuffle", "codec", "data"):
         if getattr(args, k) is not None:
             cfg[k] = getattr(args, k)
