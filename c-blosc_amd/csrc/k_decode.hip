@@ -137,6 +137,7 @@ __device__ __forceinline__ bool span_long_match(gu8* out, uint32_t mpos, uint32_
   const uint32_t lo = (mpos + 1023u) & ~1023u, hi = (mpos + ml) & ~1023u;
   if (hi < lo + 8192u) return false;
   if (lo > mpos) wave_match_copy(out, mpos, off, lo - mpos, lane);
+  BAMD_MEM_SYNC();
   const uint32_t base = mpos - off, pm = off - 1u;         // plane[q] = out[base + ((q - base) & pm)] for q >= base
   uint32_t v[8];
 #pragma unroll
@@ -148,6 +149,7 @@ __device__ __forceinline__ bool span_long_match(gu8* out, uint32_t mpos, uint32_
   }
 #pragma unroll
   for (int k = 0; k < 8; k++) g_st4(sp.pat + 4u * ((uint32_t)lane + 64u * (uint32_t)k), v[k]);
+  BAMD_MEM_SYNC();
   // behind the span: < 1 KiB, contiguous in the table just written (hi is a multiple of 1024, so no wrap)
   wave_copy_disjoint(out + hi, sp.pat + (hi & (SPAN_PAT - 1u)), mpos + ml - hi, lane);
   sp.lo = lo; sp.hi = hi; sp.off = off;
@@ -199,7 +201,9 @@ __device__ __attribute__((noinline)) void lz4_step_lds(gu8* out_, volatile uint3
   //  own "= 0" store to its later load, which is legal for unsynchronised memory and wrong here)
   // scratch word of a token: valid | length-extension flag << 25 | literal count << 16 | output offset (< 2^16: 16 x 542)
   scr[lane] = 0u;
+  BAMD_LDS_SYNC();
   if ((uint32_t)lane < cnt) scr[c] = 0x80000000u | excl | (ll_r << 16) | (ext_r << 25);
+  BAMD_LDS_SYNC();
   const uint64_t mask = __ballot(scr[lane] >> 31);
   {
     const uint64_t below = mask & ((2ull << lane) - 1ull);     // accepted tokens at or before this byte lane
@@ -345,7 +349,9 @@ __device__ __forceinline__ uint32_t lz4_batch_step(const Window& w, gu8* out, vo
   //  own "= 0" store to its later load, which is legal for unsynchronised memory and wrong here)
   // scratch word of a token: valid | length-extension flag << 25 | literal count << 16 | output offset (< 2^16: 16 x 542)
   scr[lane] = 0u;
+  BAMD_LDS_SYNC();
   if ((uint32_t)lane < cnt) scr[c] = 0x80000000u | excl | (ll_r << 16) | (ext_r << 25);
+  BAMD_LDS_SYNC();
   const uint64_t mask = __ballot(scr[lane] >> 31);
   {
     const uint64_t below = mask & ((2ull << lane) - 1ull);     // accepted tokens at or before this byte lane
@@ -585,7 +591,9 @@ __device__ __forceinline__ uint32_t blz_batch_step(const Window& w, gu8* out, vo
   //  BloscLZ chunks - config #1's data - 7 % in register allocation; bit-shuffled BloscLZ streams would gain 27 %, profiles/r02g_lds_step.txt)
   // ---- literals of every accepted run in one scattered byte store ----
   scr[lane] = 0u;
+  BAMD_LDS_SYNC();
   if ((uint32_t)lane < cnt) scr[c] = 0x80000000u | excl | (ll_r << 16);
+  BAMD_LDS_SYNC();
   const uint64_t mask = __ballot(scr[lane] >> 31);
   {
     const uint64_t below = mask & ((2ull << lane) - 1ull);

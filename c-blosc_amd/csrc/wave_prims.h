@@ -22,6 +22,11 @@ namespace bamd {
 #ifndef BAMD_LDS_SYNC
 #define BAMD_LDS_SYNC() ((void)0)
 #endif
+// The same for global memory: a load that has to see what OTHER lanes of this wave stored in an earlier instruction (the
+// memory-ordering contract below).  Nothing on the device.
+#ifndef BAMD_MEM_SYNC
+#define BAMD_MEM_SYNC() ((void)0)
+#endif
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 // a pointer every lane agrees on, moved into SGPRs: accesses off it become `global_* v, voffset32, s[base]`
@@ -72,6 +77,7 @@ __device__ __forceinline__ void wave_copy_disjoint(gu8* dst, const gu8* src, uin
 __device__ __forceinline__ void wave_match_copy(gu8* out, uint32_t pos, uint32_t off, uint32_t len, int lane) {
   uint32_t done = 0;
   uint32_t off_e = off;  // effective distance: a multiple of `off` not exceeding the periodic history
+  BAMD_MEM_SYNC();
   if (off < 64 && off < len) {
     // Short period: the match replicates the `off` bytes before pos.  Fetch them once, spread them
     // over the lanes (lane i holds pattern byte i mod off) and store G = off * floor(64/off) bytes
@@ -89,6 +95,7 @@ __device__ __forceinline__ void wave_match_copy(gu8* out, uint32_t pos, uint32_t
       done += chunk;
     }
     if (done >= len) return;
+    BAMD_MEM_SYNC();
     if ((off & (off - 1u)) == 0u && off <= 16u) {
       // period divides 16: every 16-byte group of the run is the same value -> no more loads at all
       const uint4 v = ld16u(out + pos + done - 16u);
@@ -100,6 +107,7 @@ __device__ __forceinline__ void wave_match_copy(gu8* out, uint32_t pos, uint32_t
     // only if the copied prefix really is periodic up to `done`, which it is.  Restart from G.
   }
   while (done < len) {
+    BAMD_MEM_SYNC();
     uint32_t rem = len - done;
     while (off_e < 4096u && 2u * off_e <= off + done) off_e *= 2u;  // history grew: lengthen the stride
     if (off_e == 1024u && (off & (off - 1u)) == 0u && rem >= 2048u) {

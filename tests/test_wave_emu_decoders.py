@@ -1,0 +1,207 @@
+"""CPU: the LZ4 and BloscLZ stream decoders of c-blosc_amd/csrc/k_decode.hip (lz4_decode_wave with its batched step and the
+LDS-assembled step, blosclz_decode_wave) - the SAME source the GPU runs - executed lane by lane by the wavefront emulator of
+tests/tools/wave_emu.  The decoders rely on the wavefront's lock step where one lane loads what another lane stored an
+instruction earlier; those places are marked BAMD_MEM_SYNC / BAMD_LDS_SYNC in the source (nothing on the device, a rendezvous
+here).  Yardstick: the oracle's decoders (pinned to the reference) - same bytes, same verdict on damaged streams, and never a
+byte written outside the room the stream was given."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import DATASETS, ptr
+from test_gpu_decompress import _blz_lits, _blz_match, _lz4_seq, _lz4_tail
+from test_wave_emu_encoders import emu  # noqa: F401  (fixture: builds tests/tools/liblz_wave_cpu.so)
+
+LZ4, BLOSCLZ = 0, 1
+
+
+def _decode(emu, kind, stream, cap):
+    emu.emu_lz_decode.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    s = np.concatenate([np.ascontiguousarray(stream, dtype=np.uint8), np.zeros(256, np.uint8)])     # the engine pads its buffers as well
+    out = np.full(cap + 512, 0xEE, np.uint8)
+    r = emu.emu_lz_decode(kind, ptr(s), int(np.asarray(stream).size), ptr(out), cap)
+    assert np.all(out[cap:] == 0xEE), "wrote outside the room it was given"
+    return r, out[:cap]
+
+
+def _oracle_decode(oracle, kind, stream, cap):
+    oracle.orc_blosclz_decompress.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    s = np.ascontiguousarray(stream, dtype=np.uint8)
+    out = np.zeros(cap + 8, np.uint8)
+    f = oracle.orc_blosclz_decompress if kind == BLOSCLZ else oracle.orc_lz4_decompress
+    return f(ptr(s), s.size, ptr(out), cap), out[:cap]
+
+
+def _same_as_oracle(emu, oracle, kind, stream, cap):
+    ro, want = _oracle_decode(oracle, kind, stream, cap)
+    r, got = _decode(emu, kind, stream, cap)
+    ok_o, ok_d = ro == cap and cap > 0, r == cap and cap > 0
+    if cap == 0:
+        return
+    assert ok_o == ok_d, (kind, np.asarray(stream).size, cap, ro, r)
+    if ok_o:
+        assert np.array_equal(got, want), (kind, np.asarray(stream).size, cap)
+
+
+def _compress(oracle, kind, data, clevel=5):
+    data = np.ascontiguousarray(data)
+    dst = np.zeros(data.size + 1024, np.uint8)
+    if kind == LZ4:
+        r = oracle.orc_lz4_compress(ptr(data), data.size, ptr(dst), data.size - 1, 1)
+    else:
+        r = oracle.orc_blosclz_compress(clevel, ptr(data), data.size, ptr(dst), data.size - 1, 1)
+    return dst[:r].copy() if r > 0 else None
+
+
+def _inputs(oracle):
+    rng = np.random.default_rng(21)
+    out = []
+    for dname, T in (("bench19", 8), ("linspace", 8), ("randwalk", 8), ("smallints", 4), ("arange", 4)):
+        d = DATASETS[dname](T * 16384)
+        sh = np.ascontiguousarray(d.reshape(-1, T).T)
+        for j in (0, 1, T - 1):
+            out.append(sh[j].copy())
+        bs = np.zeros(d.size, np.uint8)                               # bit-shuffled: streams full of near matches (the LDS step's case)
+        oracle.orc_bitshuffle(T, d.size, ptr(d), ptr(bs))
+        out.append(bs[:32768].copy()); out.append(bs[d.size // 2:d.size // 2 + 20000].copy())
+    out.append(np.zeros(100000, np.uint8))
+    out.append(np.tile(rng.integers(0, 256, 1024, dtype=np.uint8), 40))             # period 1024: the row-replicating copy
+    out.append(np.tile(rng.integers(0, 256, 48, dtype=np.uint8), 900))
+    out.append(rng.integers(0, 3, 30000, dtype=np.uint8))
+    for n in (13, 16, 17, 40, 64, 65, 100, 257, 1000):
+        out.append((np.arange(n) % 3).astype(np.uint8))
+    return out
+
+
+@pytest.mark.parametrize("kind", [LZ4, BLOSCLZ], ids=["lz4", "blosclz"])
+def test_reference_written_streams(emu, oracle, kind):
+    n = 0
+    for data in _inputs(oracle):
+        s = _compress(oracle, kind, data)
+        if s is None:
+            continue
+        r, got = _decode(emu, kind, s, data.size)
+        assert r == data.size and np.array_equal(got, data), (kind, data.size, r)
+        n += 1
+    assert n > 25
+
+
+def test_handbuilt_lz4_streams(emu, oracle):
+    """The adversarial streams of tests/test_gpu_decompress.py (a thinner grid): overlapping matches at small offsets and at the
+    copy-path boundaries, matches that read their own sequence's literals, long literal runs, long runs."""
+    rng = np.random.default_rng(11)
+    streams = []
+    for off in list(range(1, 20)) + [31, 32, 33, 63, 64, 65, 127, 128, 255, 256, 1023, 1024, 1025, 2048, 4099]:
+        for mlen in [4, 7, 16, 19, 63, 64, 65, 255, 300, 1024, 1025, 2049, 5000, 70000]:
+            s = bytearray()
+            pre = rng.integers(0, 256, max(off, 16) + 3, dtype=np.uint8).tobytes()
+            s += _lz4_seq(pre, off, mlen)
+            s += _lz4_seq(rng.integers(0, 256, 5, dtype=np.uint8).tobytes(), 3, 9)
+            s += _lz4_seq(b"", 1, 40)
+            s += _lz4_tail(rng.integers(0, 256, 12, dtype=np.uint8).tobytes())
+            streams.append(bytes(s))
+    for ll in [0, 1, 14, 15, 16, 63, 64, 65, 255, 270, 300, 511, 512, 513, 1024, 5000, 70000]:
+        s = bytearray()
+        s += _lz4_seq(rng.integers(0, 256, ll + 4, dtype=np.uint8).tobytes(), 4, 20)
+        s += _lz4_seq(rng.integers(0, 256, ll, dtype=np.uint8).tobytes(), 7, 4)
+        s += _lz4_tail(rng.integers(0, 256, ll + 13, dtype=np.uint8).tobytes())
+        streams.append(bytes(s))
+    for s in streams:
+        s = np.frombuffer(s, np.uint8)
+        tmp = np.zeros(1 << 20, np.uint8)
+        n = oracle.orc_lz4_decompress(ptr(s), s.size, ptr(tmp), 1 << 20)
+        assert n > 0
+        for cap in (n, n - 1, n + 1):
+            _same_as_oracle(emu, oracle, LZ4, s, cap)
+
+
+def test_dense_near_match_chains(emu, oracle):
+    """Many short sequences per 64 stream bytes whose matches reach into the output of the sequences right before them: the
+    LDS-assembled step (lz4_step_lds)."""
+    rng = np.random.default_rng(77)
+
+    def chain(nseq, maxoff, maxml, maxll, first_lit):
+        s = bytearray(); produced = 0
+        lit = rng.integers(0, 256, first_lit, dtype=np.uint8).tobytes()
+        for k in range(nseq):
+            off = int(rng.integers(1, min(maxoff, produced + len(lit)) + 1))
+            ml = int(rng.integers(4, maxml + 1))
+            s += _lz4_seq(lit, off, ml)
+            produced += len(lit) + ml
+            lit = rng.integers(0, 256, int(rng.integers(0, maxll + 1)), dtype=np.uint8).tobytes()
+        s += _lz4_tail(rng.integers(0, 256, 12 + int(rng.integers(0, 5)), dtype=np.uint8).tobytes())
+        return bytes(s)
+
+    k = 0
+    for first_lit in (1, 5, 64, 1030):
+        for maxoff in (1, 3, 16, 40, 700, 1024, 1500):
+            for maxml, maxll in ((4, 0), (18, 3), (64, 0), (273, 0)):
+                s = np.frombuffer(chain(int(rng.integers(20, 200)), maxoff, maxml, maxll, first_lit), np.uint8)
+                tmp = np.zeros(1 << 20, np.uint8)
+                n = oracle.orc_lz4_decompress(ptr(s), s.size, ptr(tmp), 1 << 20)
+                assert n > 0
+                _same_as_oracle(emu, oracle, LZ4, s, n)
+                k += 1
+    assert k == 112
+
+
+def test_handbuilt_blosclz_streams(emu, oracle):
+    rng = np.random.default_rng(12)
+    oracle.orc_blosclz_decompress.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    streams = []
+    for dist in list(range(1, 9)) + [32, 63, 64, 256, 1024, 8191, 8192, 8193, 20000]:          # (the 73 KiB distances stay with the GPU suite: minutes of 32-byte literal runs here)
+        for mlen in ([3, 4, 9, 10, 64, 65, 263, 264, 519, 1025, 5000] if dist < 1024 else [3, 264, 5000]):
+            s = bytearray()
+            s += _blz_lits(rng.integers(0, 256, max(dist, 4) + int(rng.integers(0, 5)), dtype=np.uint8).tobytes())
+            s += _blz_match(dist, mlen)
+            s += _blz_lits(rng.integers(0, 256, int(rng.integers(1, 33)), dtype=np.uint8).tobytes())
+            s += _blz_match(3, 9)
+            s += _blz_match(1, 40)
+            s += _blz_lits(rng.integers(0, 256, 7, dtype=np.uint8).tobytes())
+            streams.append(bytes(s))
+    for trial in range(25):
+        s = bytearray(_blz_lits(rng.integers(0, 256, 40, dtype=np.uint8).tobytes()))
+        produced = 40
+        for _ in range(int(rng.integers(20, 300))):
+            if rng.random() < 0.35:
+                k = int(rng.integers(1, 6)); s += _blz_lits(rng.integers(0, 256, k, dtype=np.uint8).tobytes()); produced += k
+            else:
+                d = int(rng.integers(1, min(produced, 300) + 1)); m = int(rng.choice([3, 4, 5, 6, 7, 8, 9, 12, 20, 70]))
+                s += _blz_match(d, m); produced += m
+        s += _blz_lits(rng.integers(0, 256, 9, dtype=np.uint8).tobytes())
+        streams.append(bytes(s))
+    for s in streams:
+        s = np.frombuffer(s, np.uint8)
+        tmp = np.zeros(1 << 20, np.uint8)
+        n = oracle.orc_blosclz_decompress(ptr(s), s.size, ptr(tmp), 1 << 20)
+        assert n > 0
+        for cap in (n, n - 1):
+            _same_as_oracle(emu, oracle, BLOSCLZ, s, cap)
+
+
+@pytest.mark.parametrize("kind", [LZ4, BLOSCLZ], ids=["lz4", "blosclz"])
+def test_damaged_streams_get_the_oracles_verdict(emu, oracle, kind):
+    """Bit flips, truncations and junk: accepted or rejected exactly like the oracle's (= the reference's) decoder, same bytes when
+    accepted, nothing written outside the output room (the fuzz rows of SURVEY 8f-1, here without a GPU)."""
+    rng = np.random.default_rng(5)
+    tried = 0
+    for data in _inputs(oracle)[:14]:
+        s = _compress(oracle, kind, data[:6000])
+        if s is None or s.size < 20:
+            continue
+        n = min(data.size, 6000)
+        for trial in range(12):
+            t = s.copy()
+            mode = trial % 4
+            if mode == 0:
+                t[int(rng.integers(0, t.size))] ^= 1 << int(rng.integers(0, 8))
+            elif mode == 1:
+                t = t[:int(rng.integers(1, t.size))]
+            elif mode == 2:
+                pos = int(rng.integers(0, t.size)); t[pos:pos + 4] = rng.integers(0, 256, min(4, t.size - pos), dtype=np.uint8)
+            else:
+                t = np.concatenate([t, rng.integers(0, 256, int(rng.integers(1, 9)), dtype=np.uint8)])
+            _same_as_oracle(emu, oracle, kind, t, n)
+            tried += 1
+    assert tried > 100

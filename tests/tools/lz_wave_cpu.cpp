@@ -31,6 +31,29 @@ void lane_body(int lane, void* arg) {
 }
 }  // namespace
 
+// ---- the decoders of k_decode.hip (lz4_decode_wave, blosclz_decode_wave): one stream, no periodic-span bookkeeping ----
+namespace {
+struct DJob { int kind; const uint8_t* src; int n; uint8_t* dst; int cap; uint32_t* scr; int result; };
+void dec_body(int lane, void* arg) {
+  DJob* j = (DJob*)arg;
+  using namespace bamd;
+  SpanCtx sp = {0u, 0u, 0u, 0u, nullptr};
+  int r;
+  if (j->kind == 1) r = blosclz_decode_wave((const gu8*)j->src, j->n, (gu8*)j->dst, j->cap, (volatile uint32_t*)j->scr, lane, sp);
+  else r = lz4_decode_wave((const gu8*)j->src, j->n, (gu8*)j->dst, j->cap, (volatile uint32_t*)j->scr, lane, sp);
+  if (lane == 0) j->result = r;
+}
+}  // namespace
+// kind: 0 = LZ4 block, 1 = BloscLZ stream.  Returns what the device function returns (bytes produced, or its error code).
+extern "C" int emu_lz_decode(int kind, const uint8_t* src, int n, uint8_t* dst, int cap) {
+  DJob j = {kind, src, n, dst, cap, nullptr, 0};
+  j.scr = (uint32_t*)aligned_alloc(64, 64 * 4 + bamd::LZB_BYTES + 256);      // the wave's LDS: 64 scratch dwords + the step buffer
+  memset(j.scr, 0xA5, 64 * 4 + bamd::LZB_BYTES + 256);
+  wave_emu::run(dec_body, &j);
+  free(j.scr);
+  return j.result;
+}
+
 // kind: 0 = LZ4, 1 = BloscLZ, 2 = LZ4 with the LZ4HC-grade search, 3 = Zstd frame, 4 = zlib stream, 5 = Zstd frame with per-block sequence tables,
 // 6 = 5 behind the LZ4HC-grade search, 7 = zlib stream behind the LZ4HC-grade search.  Returns the stream
 // size (0 = "store raw").

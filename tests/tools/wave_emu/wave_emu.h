@@ -175,6 +175,7 @@ uint64_t last_rendezvous();
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))
 #define BAMD_WAIT_STORES() ((void)0)
 #define BAMD_LDS_SYNC() (wave_emu::sync(WAVE_EMU_HERE))
+#define BAMD_MEM_SYNC() (wave_emu::sync(WAVE_EMU_HERE))
 #define __syncthreads() (wave_emu::fail("__syncthreads: only single-wave code runs here", WAVE_EMU_HERE))
 #ifndef __HIP_MEMORY_SCOPE_WAVEFRONT
 #define __HIP_MEMORY_SCOPE_SINGLETHREAD 1
