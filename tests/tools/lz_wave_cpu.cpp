@@ -31,6 +31,42 @@ void lane_body(int lane, void* arg) {
 }
 }  // namespace
 
+// ---- the fused byte (un)shuffle of one block by one wave (k_encode.hip: shuffle_block_wave_T / shuffle_block_wave_detect with its
+// periodic-plane detection and emit_periodic_stream; k_decode.hip: unshuffle_block_wave) ----
+namespace {
+struct SJob { int T, mode; const uint8_t* src; uint8_t* dst; uint32_t bsize; uint32_t period[8]; uint32_t per; };
+void shuf_body(int lane, void* arg) {
+  SJob* j = (SJob*)arg;
+  using namespace bamd;
+  if (j->mode == 2) { unshuffle_block_wave(j->src, j->dst, j->bsize, j->T, lane, nullptr, nullptr, nullptr); return; }
+  uint32_t period[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t per = 0;
+  if (j->T == 8) { if (j->mode) per = shuffle_block_wave_detect<8>((const gu8*)j->src, (gu8*)j->dst, j->bsize, lane, period); else shuffle_block_wave_T<8>((const gu8*)j->src, (gu8*)j->dst, j->bsize, lane); }
+  else { if (j->mode) per = shuffle_block_wave_detect<4>((const gu8*)j->src, (gu8*)j->dst, j->bsize, lane, period); else shuffle_block_wave_T<4>((const gu8*)j->src, (gu8*)j->dst, j->bsize, lane); }
+  if (lane == 0) { j->per = per; for (int k = 0; k < 8; k++) j->period[k] = period[k]; }
+}
+struct PJob { const uint8_t* in; uint32_t n; uint8_t* out; uint32_t cap, p; int lz4; uint32_t result; };
+void per_body(int lane, void* arg) {
+  PJob* j = (PJob*)arg;
+  const uint32_t r = bamd::emit_periodic_stream((const bamd::gu8*)j->in, j->n, (bamd::gu8*)j->out, j->cap, j->p, j->lz4 != 0, lane);
+  if (lane == 0) j->result = r;
+}
+}  // namespace
+// mode 0: shuffle, 1: shuffle with periodic-plane detection (period_out[k] != 0: plane k repeats with that period and only its first
+// 256 bytes were written), 2: unshuffle.  typesize 4 or 8; bsize a multiple of 256 * typesize for modes 0 / 1.  Returns the plane mask.
+extern "C" unsigned emu_shuffle_block(int T, int mode, const uint8_t* src, uint8_t* dst, unsigned bsize, unsigned* period_out) {
+  SJob j = {T, mode, src, dst, bsize, {0, 0, 0, 0, 0, 0, 0, 0}, 0};
+  wave_emu::run(shuf_body, &j);
+  if (period_out) for (int k = 0; k < 8; k++) period_out[k] = j.period[k];
+  return j.per;
+}
+// the whole stream of a plane of n bytes with period p whose first 256 bytes are `in256`
+extern "C" unsigned emu_periodic_stream(const uint8_t* in256, unsigned n, uint8_t* out, unsigned cap, unsigned p, int lz4) {
+  PJob j = {in256, n, out, cap, p, lz4, 0};
+  wave_emu::run(per_body, &j);
+  return j.result;
+}
+
 // ---- the decoders of k_decode.hip (lz4_decode_wave, blosclz_decode_wave): one stream, no periodic-span bookkeeping ----
 namespace {
 struct DJob { int kind; const uint8_t* src; int n; uint8_t* dst; int cap; uint32_t* scr; int result; };
