@@ -1099,6 +1099,7 @@ __device__ __forceinline__ void zt_make_table(uint32_t c, uint32_t total, int a,
 // histogram + the three tables of one block; `pre`: the predefined tables, `scr`: the wave's scratch
 __device__ __forceinline__ void zt_make_tables(const BAMD_GAS uint64_t* seqs, uint32_t nseq, volatile BAMD_LAS uint32_t* scr, ZsTabs& zt, int lane) {
   volatile BAMD_LAS uint32_t* hist = scr + ZT_HIST;
+  BAMD_LDS_SYNC();                                     // the scratch overlays the match finder's table: every lane is done with that
   hist[lane] = 0u; hist[lane + 64] = 0u; hist[lane + 128] = 0u;
   BAMD_LDS_SYNC();
   for (uint32_t base = 0; base < nseq; base += 64u) {
@@ -1296,6 +1297,7 @@ __device__ uint32_t zstd_encode_wave(const gu8* __restrict__ src, uint32_t n, gu
     }
     if (bsize >= seg) {                   // no gain: Raw_Block
       if (op + zenc::kBlockHeader + seg >= cap) return 0u;
+      BAMD_MEM_SYNC();                    // the copy overwrites what other lanes have just written of the compressed form
       wave_copy_disjoint(bh + zenc::kBlockHeader, src + s0, seg, lane);
       bsize = seg;
       rep = rep_before;                   // a raw block leaves the decoder's repeat offsets alone

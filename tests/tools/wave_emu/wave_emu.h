@@ -21,6 +21,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <ucontext.h>
+#include <signal.h>
+#include <unistd.h>
 
 #define __device__
 #define __host__
@@ -202,6 +204,16 @@ thread_local dim3 g_block_idx(0, 0, 0), g_thread_base(0, 0, 0);
 static thread_local uint64_t g_last_rendezvous = 0;
 uint64_t last_rendezvous() { return g_last_rendezvous; }
 
+// a fault inside emulated device code: say which lane it was and where that lane last met the others
+static void on_fault(int sig) {
+  Wave* w = g_wave;
+  char buf[512];
+  const char* where = "?";
+  if (w) { const int l = w->cur; const uint64_t k = w->opno[l]; where = w->site[k & 1u][l] ? w->site[k & 1u][l] : "?"; }
+  const int n = snprintf(buf, sizeof buf, "wave_emu: signal %d in lane %d, last rendezvous at %s\n", sig, w ? w->cur : -1, where);
+  if (n > 0) { ssize_t r = write(2, buf, (size_t)n); (void)r; }
+  _exit(134);
+}
 static void trampoline(unsigned lo, unsigned hi) {
   Wave* w = (Wave*)(((uint64_t)hi << 32) | lo);
   const int l = w->cur;
@@ -211,6 +223,8 @@ static void trampoline(unsigned lo, unsigned hi) {
 }
 
 void run(void (*body)(int lane, void* arg), void* arg) {
+  static bool handlers = false;
+  if (!handlers) { handlers = true; signal(SIGFPE, on_fault); signal(SIGSEGV, on_fault); signal(SIGBUS, on_fault); }
   Wave* w = (Wave*)calloc(1, sizeof(Wave));
   Wave* outer = g_wave;
   g_wave = w;
