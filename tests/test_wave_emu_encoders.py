@@ -158,6 +158,7 @@ def _entropy_inputs():
         for j in (0, 1, 5):
             inputs.append(_plane(dname, 16384, 8, j))
     inputs.append(_plane("bench19", 131072 + 4096, 8, 1))             # two blocks in one frame: the second one starts on a table the first one's scratch has overwritten
+    inputs.append(np.concatenate([_plane("bench19", 131072, 8, 1), rng.integers(0, 256, 1069, dtype=np.uint8)]))   # ... and a second block without a single sequence (stored raw)
     for n in [0, 1, 16, 31, 32, 33, 63, 64, 65, 100, 255, 256, 1000, 4097]:
         inputs.append(np.zeros(n, np.uint8))                           # one sequence: every alphabet RLE
         inputs.append((np.arange(n) % 5).astype(np.uint8))
