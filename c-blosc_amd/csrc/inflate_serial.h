@@ -16,6 +16,9 @@
 // g++ and is compared with the real zlib of the reference on valid and corrupted streams (tests/test_inflate_serial_cpu.py).
 #pragma once
 #include <stdint.h>
+#ifndef BAMD_LDS_SYNC          // wave_prims.h: where lanes hand data to each other through LDS (a rendezvous for the wavefront emulator only)
+#define BAMD_LDS_SYNC() ((void)0)
+#endif
 
 #if defined(__HIPCC__)
 #define ZI_FN __device__ __forceinline__
@@ -67,7 +70,7 @@ template <class B> ZI_FN uint32_t bits_bytepos(const B& b) { return b.used >> 3;
 // by ONE lane (writer()) and read by all: volatile, so that no lane works with a value it has kept in a register across
 // another lane's store.
 constexpr int kLitFast = 9, kDistFast = 7, kMaxBits = 15;
-#if defined(__HIPCC__)
+#if defined(__HIPCC__) || defined(BAMD_WAVE_EMU)      // (the wavefront emulator of tests/tools/wave_emu runs the device form on the host)
 #define ZI_TAB volatile
 ZI_FN bool writer() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u; }
 #else
@@ -87,10 +90,11 @@ ZI_FN uint32_t rev_bits(uint32_t v, int n) { uint32_t r = 0; for (int i = 0; i <
 // returns: 0 complete, > 0 incomplete (bits of code space left), < 0 over-subscribed; *maxlen = longest code (0: no symbol)
 ZI_COLD int huff_build(tab16* count, tab16* sym, tab16* fast, int fastbits, const tab8* lens, int n, int* maxlen, tab16* cnt, tab16* offs) {
   const bool w = writer();
+  BAMD_LDS_SYNC();          // the counters are shared by the three tables of a block: every lane is done with the previous build
   ZI_NOUNROLL for (int l = 0; l <= kMaxBits; l++) if (w) cnt[l] = 0;
   ZI_NOUNROLL for (int s = 0; s < n; s++) { const int l = lens[s]; const uint16_t c = cnt[l]; if (w) cnt[l] = (uint16_t)(c + 1); }
   int left = 1, mx = 0;
-  ZI_NOUNROLL for (int l = 1; l <= kMaxBits; l++) { const int c = cnt[l]; left <<= 1; left -= c; if (left < 0) return left; if (c) mx = l; }
+  ZI_NOUNROLL for (int l = 1; l <= kMaxBits; l++) { const int c = cnt[l]; left <<= 1; left -= c; if (left < 0) { BAMD_LDS_SYNC(); return left; } if (c) mx = l; }
   *maxlen = mx;
   ZI_NOUNROLL for (int l = 0; l <= kMaxBits; l++) { const uint16_t c = cnt[l]; if (w) count[l] = c; }
   if (w) offs[1] = 0;
@@ -106,6 +110,7 @@ ZI_COLD int huff_build(tab16* count, tab16* sym, tab16* fast, int fastbits, cons
     }
     code <<= 1;
   }
+  BAMD_LDS_SYNC();
   return left;
 }
 // next symbol, or -1 when the bits match no code

@@ -121,6 +121,7 @@ __device__ __forceinline__ int zlib_decode_wave(const uint8_t* in_, int n_, uint
   zl_flush_literals(out, p, lane); zl_exec_matches(out, p, lane);
   uint32_t want = 0;
   if (!zi::read_adler(b, &want)) return 0;
+  BAMD_MEM_SYNC();                        // the checksum reads what all lanes have stored
   if (want != wave_adler32(out, op, lane)) return 0;
   return (int)op;
 }

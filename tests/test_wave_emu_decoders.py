@@ -205,3 +205,79 @@ def test_damaged_streams_get_the_oracles_verdict(emu, oracle, kind):
             _same_as_oracle(emu, oracle, kind, t, n)
             tried += 1
     assert tried > 100
+
+
+# ---- the entropy-coded formats: zlib_decode_wave (k_zlib.hip + inflate_serial.h) and the one-wave Zstd frame decoder (k_zstd.hip) ----
+ZSTD, ZLIB = 3, 4
+
+
+def _entropy_decode(emu, kind, stream, cap):
+    emu.emu_entropy_decode.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    s = np.concatenate([np.ascontiguousarray(stream, dtype=np.uint8), np.zeros(256, np.uint8)])
+    out = np.full(cap + 512, 0xEE, np.uint8)
+    r = emu.emu_entropy_decode(kind, ptr(s), int(np.asarray(stream).size), ptr(out), cap)
+    assert np.all(out[cap:] == 0xEE), "wrote outside the room it was given"
+    return r, out[:cap]
+
+
+def test_zlib_streams_written_by_zlib(emu, oracle):
+    """Streams of zlib itself (python's): every level, fixed / Huffman-only / RLE strategies, small windows, several blocks,
+    stored blocks - and damaged copies of them, which must get the oracle's verdict."""
+    from test_oracle_zlib import _un, _zo, stock_streams
+    zo = _zo(oracle)
+    rng = np.random.default_rng(8)
+    n_ok = n_bad = 0
+    for s, data in stock_streams(sizes=(1, 17, 255, 4096, 20000)):
+        r, got = _entropy_decode(emu, ZLIB, s, data.size)
+        assert r == data.size and np.array_equal(got, data), (data.size, s.size, r)
+        n_ok += 1
+        if s.size > 12 and n_ok % 3 == 0:
+            for mode in range(3):
+                t = s.copy()
+                if mode == 0: t[int(rng.integers(2, t.size))] ^= 1 << int(rng.integers(0, 8))
+                elif mode == 1: t = t[:int(rng.integers(3, t.size))]
+                else: t[-1] ^= 0x10                                           # the Adler-32
+                ro, want = _un(zo, t, data.size)
+                r, got = _entropy_decode(emu, ZLIB, t, data.size)
+                assert (ro == data.size) == (r == data.size), (mode, ro, r)
+                if ro == data.size:
+                    assert np.array_equal(got, want[:data.size])
+                n_bad += 1
+    assert n_ok > 100 and n_bad > 60
+
+
+def test_zstd_frames(emu, oracle, ref):
+    """Frames of the reference's ZSTD_compress (levels 1 / 3 / 5 / 19: raw, RLE and Huffman literals, predefined / RLE / FSE / repeat
+    sequence tables) where oracle/_ref ships, and frames written by this repo's own encoder (all its modes) run on the same emulator."""
+    oracle.orc_zstd_decompress.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    rng = np.random.default_rng(14)
+    inputs = [x for x in _inputs(oracle) if x.size <= 40000][:22]
+    inputs.append(np.concatenate([DATASETS["bench19"](131072 * 8).reshape(-1, 8).T[1], rng.integers(0, 256, 3000, dtype=np.uint8)]))   # several blocks
+    n = 0
+    for data in inputs:
+        streams = []
+        if ref is not None:
+            ref.ZSTD_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+            ref.ZSTD_compress.restype = C.c_size_t
+            for level in (1, 3, 5, 19):
+                dst = np.zeros(data.size + 1024, np.uint8)
+                r = ref.ZSTD_compress(ptr(dst), dst.size, ptr(data), data.size, level)
+                streams.append(dst[:r].copy())
+        from test_wave_emu_encoders import _encode
+        for kind in (3, 5, 6):
+            r, s = _encode(emu, kind, data, clevel=3)
+            if r:
+                streams.append(s)
+        for s in streams:
+            r, got = _entropy_decode(emu, ZSTD, s, data.size)
+            assert r == data.size and np.array_equal(got, data), (data.size, s.size, r)
+            n += 1
+            if n % 4 == 0 and s.size > 16:                                     # damaged: the oracle's verdict
+                t = s.copy(); t[int(rng.integers(5, t.size))] ^= 1 << int(rng.integers(0, 8))
+                want = np.zeros(data.size + 8, np.uint8)
+                ro = oracle.orc_zstd_decompress(ptr(t), t.size, ptr(want), data.size)
+                r, got = _entropy_decode(emu, ZSTD, t, data.size)
+                assert (ro == data.size) == (r == data.size), (ro, r)
+                if ro == data.size:
+                    assert np.array_equal(got, want[:data.size])
+    assert n > 60

@@ -11,6 +11,9 @@
 #include "k_decode.hip"
 #include "k_decode_blocks.hip"
 #include "k_encode.hip"
+#include "k_zstd.hip"
+#include "k_zstd2.hip"
+#include "k_zlib.hip"
 
 namespace {
 struct Job { int kind; const uint8_t* src; int n; uint8_t* dst; int cap; int clevel; uint32_t* tab; uint32_t result; uint64_t* seqbuf; };
@@ -64,6 +67,29 @@ extern "C" unsigned emu_shuffle_block(int T, int mode, const uint8_t* src, uint8
 extern "C" unsigned emu_periodic_stream(const uint8_t* in256, unsigned n, uint8_t* out, unsigned cap, unsigned p, int lz4) {
   PJob j = {in256, n, out, cap, p, lz4, 0};
   wave_emu::run(per_body, &j);
+  return j.result;
+}
+
+// ---- the entropy-coded formats' decoders: zlib_decode_wave (k_zlib.hip) and the one-wave-per-frame Zstd decoder (k_zstd.hip) ----
+namespace {
+struct EJob { int kind; const uint8_t* src; int n; uint8_t* dst; int cap; void* lds; uint8_t* lit; int result; };
+void ent_body(int lane, void* arg) {
+  EJob* j = (EJob*)arg;
+  int r;
+  if (j->kind == 4) r = bamd::zlib_decode_wave(j->src, j->n, j->dst, j->cap, *(zi::Tabs*)j->lds, lane);
+  else r = bamd::zstd_decode_wave(j->src, j->n, j->dst, j->cap, j->lit, (bamd::ZstdLds*)j->lds, lane);
+  if (lane == 0) j->result = r;
+}
+}  // namespace
+// kind: 3 = Zstd frame, 4 = zlib stream.  Returns bytes produced (0 = rejected).
+extern "C" int emu_entropy_decode(int kind, const uint8_t* src, int n, uint8_t* dst, int cap) {
+  EJob j = {kind, src, n, dst, cap, nullptr, nullptr, 0};
+  const size_t lds = kind == 4 ? sizeof(zi::Tabs) : sizeof(bamd::ZstdLds);
+  j.lds = aligned_alloc(64, (lds + 63) / 64 * 64);
+  memset(j.lds, 0xA5, lds);
+  j.lit = (uint8_t*)malloc(128 * 1024 + 64);                    // the Zstd decoder's literals scratch (one block)
+  wave_emu::run(ent_body, &j);
+  free(j.lds); free(j.lit);
   return j.result;
 }
 

@@ -16,6 +16,7 @@
 // Compile device sources with the ROCm clang++ for the host (ext_vector_type, address_space attributes):
 //   /opt/rocm/lib/llvm/bin/clang++ -std=c++17 -O1 -I tests/tools/wave_emu -x c++ ...
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -24,6 +25,7 @@
 #include <signal.h>
 #include <unistd.h>
 
+#define BAMD_WAVE_EMU 1
 #define __device__
 #define __host__
 #define __global__
