@@ -28,7 +28,7 @@ def _decode(emu, kind, stream, cap):
 def _oracle_decode(oracle, kind, stream, cap):
     oracle.orc_blosclz_decompress.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     s = np.ascontiguousarray(stream, dtype=np.uint8)
-    out = np.zeros(cap + 8, np.uint8)
+    out = np.full(cap + 8, 0xEE, np.uint8)            # the same fill as _decode: an LZ4 match with offset 0 "copies" what the buffer held (lz4.c:2356)
     f = oracle.orc_blosclz_decompress if kind == BLOSCLZ else oracle.orc_lz4_decompress
     return f(ptr(s), s.size, ptr(out), cap), out[:cap]
 
