@@ -1573,7 +1573,8 @@ __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, enc_
 // build_encode_queues), so the bandwidth-bound transposes run underneath the latency/issue-bound match
 // finding of other waves instead of in a kernel of their own.
 template <int MODE>
-__global__ __launch_bounds__(64 * ENC_WAVES, enc_mode_hc(MODE) ? 2 : BAMD_ENC_MINWAVES) void k_encode_streams_t(
+// (waves per SIMD the register allocator plans for: the 24 KiB table of the HC modes leaves room for 1.5, the Zstd modes' LDS for 5)
+__global__ __launch_bounds__(64 * ENC_WAVES, enc_mode_hc(MODE) ? 2 : (MODE == ENC_ZSTD_T ? 5 : BAMD_ENC_MINWAVES)) void k_encode_streams_t(
     StreamDesc* __restrict__ streams, uint32_t* __restrict__ tickets /*[8]*/, const int32_t* __restrict__ qlist,
     const int32_t* __restrict__ qoff /*[9]*/, const ChunkDesc* __restrict__ chunks, const BlockDesc* __restrict__ blocks,
     uint32_t* __restrict__ blk_ready, uint32_t* __restrict__ plane_cost, int single_queue,
