@@ -1,0 +1,176 @@
+// enc_shuffle.h — the byte shuffle as work of the encode kernel's own waves (included by k_encode.hip inside namespace bamd):
+// shuffle_block_wave_T, the periodic-plane detection, shuffle_block_task, emit_periodic_stream.  DESIGN.md 3.3.
+// ---------------------------------------------------------------------------------------------
+// Fused byte shuffle of one block by ONE wavefront (typesize 4 or 8): element-major source -> plane-major
+// scratch (blosc/shuffle-generic.h:27-58).  The mirror image of unshuffle_block_wave in k_decode.hip: per
+// step lane l loads the T*4 contiguous bytes of elements e+4l..e+4l+3 (coalesced 16-byte loads), transposes
+// bytes in registers and stores 4 bytes into every plane (each wave store writes 256 contiguous bytes).
+// ---------------------------------------------------------------------------------------------
+#ifndef BAMD_SHUF_LD_NT
+#define BAMD_SHUF_LD_NT 0     // 1: the fused shuffle reads the source (read once) with non-temporal loads
+#endif
+template <int T>
+struct ElemRows { uint4 a, b; };
+
+template <int T>
+__device__ __forceinline__ ElemRows<T> shuffle_load(const gu8* src, uint32_t e, int lane) {
+  ElemRows<T> x;
+  const gu8* in = src + (size_t)(e + 4u * (uint32_t)lane) * T;
+  x.a = BAMD_SHUF_LD_NT ? g_ld16_nt(in) : g_ld16(in);
+  if (T == 8) x.b = BAMD_SHUF_LD_NT ? g_ld16_nt(in + 16) : g_ld16(in + 16); else x.b = make_uint4(0, 0, 0, 0);
+  return x;
+}
+template <int T>
+__device__ __forceinline__ void shuffle_store(gu8* dst, uint32_t N, uint32_t e, int lane, const ElemRows<T>& x) {
+  gu8* o = dst + e + 4u * (uint32_t)lane;
+  uint32_t r0, r1, r2, r3;
+  if (T == 8) {
+    // a = (lo0, hi0, lo1, hi1), b = (lo2, hi2, lo3, hi3): low / high dword of elements 0..3
+    transpose4x4(x.a.x, x.a.z, x.b.x, x.b.z, r0, r1, r2, r3);
+    g_st4(o, r0); g_st4(o + (size_t)N, r1); g_st4(o + 2 * (size_t)N, r2); g_st4(o + 3 * (size_t)N, r3);
+    transpose4x4(x.a.y, x.a.w, x.b.y, x.b.w, r0, r1, r2, r3);
+    g_st4(o + 4 * (size_t)N, r0); g_st4(o + 5 * (size_t)N, r1); g_st4(o + 6 * (size_t)N, r2); g_st4(o + 7 * (size_t)N, r3);
+  } else {
+    transpose4x4(x.a.x, x.a.y, x.a.z, x.a.w, r0, r1, r2, r3);
+    g_st4(o, r0); g_st4(o + (size_t)N, r1); g_st4(o + 2 * (size_t)N, r2); g_st4(o + 3 * (size_t)N, r3);
+  }
+}
+template <int T>
+__device__ void shuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize, int lane) {
+  const uint32_t N = bsize / T;
+  uint32_t e = 0;
+  for (; e + 1024u <= N; e += 1024u) {   // 4 steps per iteration: all loads are issued before the first store
+    const ElemRows<T> a = shuffle_load<T>(src, e, lane), b = shuffle_load<T>(src, e + 256u, lane);
+    const ElemRows<T> c = shuffle_load<T>(src, e + 512u, lane), d = shuffle_load<T>(src, e + 768u, lane);
+    shuffle_store<T>(dst, N, e, lane, a); shuffle_store<T>(dst, N, e + 256u, lane, b);
+    shuffle_store<T>(dst, N, e + 512u, lane, c); shuffle_store<T>(dst, N, e + 768u, lane, d);
+  }
+  for (; e + 256u <= N; e += 256u) shuffle_store<T>(dst, N, e, lane, shuffle_load<T>(src, e, lane));
+  // tail: fewer than 256 elements, then the bytes that do not form a whole element (copied as they are)
+  for (uint32_t k = e * T + (uint32_t)lane; k < N * T; k += 64u) { const uint32_t el = k / T, j = k - el * T; dst[(size_t)j * N + el] = src[k]; }
+  for (uint32_t k = N * T + (uint32_t)lane; k < bsize; k += 64u) dst[k] = src[k];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Periodic planes.  A byte plane whose every 256-byte row equals its first row - a constant byte, a counter's low
+// byte, the zero top bytes of small integers: the planes shuffling exists to produce - needs no match finder and no
+// trip through the scratch: its stream is "first period as literals + one match over the rest".  The shuffle wave
+// notices them for free (it holds each row in a register): as long as a plane's rows keep repeating, nothing is
+// stored; the first row that differs back-fills the rows skipped so far (copies of row 0) and the plane is an
+// ordinary one from there on.  A plane that stays periodic to the end gets its first row stored (the literals' source)
+// and its period p (smallest power of two, 1..256) left in its stream's `result` as -p; encode_one_stream turns that
+// into the stream (emit_periodic_stream).  The mirror image of the decoder's periodic spans (k_decode.hip).
+// Only whole-row blocks (N % 256 == 0, N >= 1024) whose planes are streams of their own (split blocks).
+// ---------------------------------------------------------------------------------------------
+template <int T>
+__device__ __forceinline__ void shuffle_rows(const ElemRows<T>& x, uint32_t (&r)[8]) {
+  if (T == 8) {
+    transpose4x4(x.a.x, x.a.z, x.b.x, x.b.z, r[0], r[1], r[2], r[3]);
+    transpose4x4(x.a.y, x.a.w, x.b.y, x.b.w, r[4], r[5], r[6], r[7]);
+  } else {
+    transpose4x4(x.a.x, x.a.y, x.a.z, x.a.w, r[0], r[1], r[2], r[3]);
+    r[4] = r[5] = r[6] = r[7] = 0;
+  }
+}
+// smallest power-of-two period (bytes) of a 256-byte row held one dword per lane; 256 when there is none below
+__device__ __forceinline__ uint32_t row_period(uint32_t w, int lane) {
+  uint32_t p = 256u;
+  for (uint32_t sh = 32u; sh >= 1u; sh >>= 1) {
+    const uint32_t other = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((((uint32_t)lane + sh) & 63u) << 2), (int)w);
+    if (__ballot(other != w) != 0ull) return p;
+    p = 4u * sh;
+  }
+  const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);       // all lanes hold the same dword here
+  if ((w0 >> 16) != (w0 & 0xffffu)) return 4u;
+  return ((w0 >> 8) & 0xffu) == (w0 & 0xffu) ? 1u : 2u;
+}
+// returns the mask of planes that stayed periodic; their period goes to period[k]
+template <int T>
+__device__ uint32_t shuffle_block_wave_detect(const gu8* src, gu8* dst, uint32_t bsize, int lane, uint32_t (&period)[8]) {
+  const uint32_t N = bsize / T;
+  uint32_t row0[8], r[8];
+  uint32_t per = (1u << T) - 1u;                       // wave-uniform: planes whose rows all equalled row 0 so far
+  shuffle_rows<T>(shuffle_load<T>(src, 0u, lane), row0);
+  auto step = [&](const ElemRows<T>& x, uint32_t e) {
+    if (per == 0u) { shuffle_store<T>(dst, N, e, lane, x); return; }
+    shuffle_rows<T>(x, r);
+    gu8* o = dst + e + 4u * (uint32_t)lane;
+#pragma unroll
+    for (int k = 0; k < T; k++) {
+      if (per & (1u << k)) {
+        if (__ballot(r[k] != row0[k]) == 0ull) continue;
+        per &= ~(1u << k);
+        for (uint32_t t = 0; t < e; t += 256u) g_st4(dst + (size_t)k * N + t + 4u * (uint32_t)lane, row0[k]);
+      }
+      g_st4(o + (size_t)k * N, r[k]);
+    }
+  };
+  uint32_t e = 256u;
+  for (; e + 1024u <= N; e += 1024u) {
+    const ElemRows<T> a = shuffle_load<T>(src, e, lane), b = shuffle_load<T>(src, e + 256u, lane);
+    const ElemRows<T> c = shuffle_load<T>(src, e + 512u, lane), d = shuffle_load<T>(src, e + 768u, lane);
+    step(a, e); step(b, e + 256u); step(c, e + 512u); step(d, e + 768u);
+  }
+  for (; e + 256u <= N; e += 256u) step(shuffle_load<T>(src, e, lane), e);
+#pragma unroll
+  for (int k = 0; k < T; k++) {
+    period[k] = 0u;
+    if (per & (1u << k)) {
+      g_st4(dst + (size_t)k * N + 4u * (uint32_t)lane, row0[k]);
+      period[k] = row_period(row0[k], lane);
+    }
+  }
+  return per;
+}
+
+// queue task "shuffle block gb": afterwards the block's flag tells the encoders of its streams to go ahead.
+// Producer and consumers run on the same XCD (per-XCD queues), so the hand-off goes through that XCD's L2:
+// drain the stores, then a relaxed agent-scope flag store - no L2 write-back needed.
+template <int T>
+__device__ __forceinline__ void shuffle_block_detect_T(const gu8* src, gu8* dst, uint32_t bsize, StreamDesc* planes, int lane) {
+  uint32_t period[8];
+  const uint32_t per = shuffle_block_wave_detect<T>(src, dst, bsize, lane, period);
+#pragma unroll
+  for (int k = 0; k < T; k++)
+    if ((per & (1u << k)) && lane == 0) planes[k].result = -(int32_t)period[k];
+}
+__device__ __attribute__((noinline)) void shuffle_block_task(const ChunkDesc* chunks, const BlockDesc* blocks, uint32_t gb,
+                                                             uint32_t* blk_ready, StreamDesc* streams, int detect, int lane) {
+  const BlockDesc* b = blocks + gb;
+  const ChunkDesc* c = chunks + uni((uint32_t)b->chunk);
+  const uint32_t blk = uni((uint32_t)b->blk), bsize = uni((uint32_t)b->bsize), bs = uni((uint32_t)c->blocksize);
+  const gu8* src = uni_ptr(as_global(c->src)) + (size_t)blk * bs;
+  gu8* dst = uni_ptr(as_global(c->filt)) + (size_t)blk * bs;
+  const uint32_t T = uni((uint32_t)c->typesize), N = bsize / T;
+  // periodic planes (see above): whole rows only, planes that are streams of their own, LZ4 / BloscLZ streams
+  const bool det = detect && uni((uint32_t)b->nstreams) == T && N * T == bsize && (N & 255u) == 0u && N >= 1024u &&
+                   (uni((uint32_t)c->fmt) == (uint32_t)FMT_LZ4 || uni((uint32_t)c->fmt) == (uint32_t)FMT_BLOSCLZ);
+  StreamDesc* planes = streams + uni((uint32_t)b->first_stream);
+  if (T == 8u) { if (det) shuffle_block_detect_T<8>(src, dst, bsize, planes, lane); else shuffle_block_wave_T<8>(src, dst, bsize, lane); }
+  else { if (det) shuffle_block_detect_T<4>(src, dst, bsize, planes, lane); else shuffle_block_wave_T<4>(src, dst, bsize, lane); }
+  __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): every store of this wave has reached L2
+  if (lane == 0) __hip_atomic_store(&blk_ready[gb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The stream of a plane of n bytes (n % 256 == 0, n >= 1024) that repeats with period p <= 256; `in` holds its first 256
+// bytes.  LZ4: p literals, one match at distance p up to n - 5, the last five bytes as literals (lz4.c:245-246 end
+// rules).  BloscLZ: the same with the match ending at n - 2 (the encoder's own limit above) and the marker bit of
+// blosclz.c:607.  Always smaller than n, so the "store raw" fallback - which would need the plane in memory - cannot hit.
+__device__ __forceinline__ uint32_t emit_periodic_stream(const gu8* in, uint32_t n, gu8* out, uint32_t cap, uint32_t p, bool lz4, int lane) {
+  uint32_t op;
+  if (lz4) {
+    op = lz4_emit_seq(out, 0u, cap, in, p, p, n - 5u - p, -1, 0u, lane);
+    if (op == 0xffffffffu) return 0u;
+    op = lz4_emit_tail(out, op, cap, in + 251u, 5u, lane);
+    return op == 0xffffffffu ? 0u : op;
+  }
+  op = blz_emit_literals(out, 0u, cap, in, p, lane);
+  if (op == 0xffffffffu) return 0u;
+  op = blz_emit_match(out, op, cap, p, n - 2u - p, lane);
+  if (op == 0xffffffffu) return 0u;
+  op = blz_emit_literals(out, op, cap, in + 254u, 2u, lane);
+  if (op == 0xffffffffu) return 0u;
+  if (lane == 0) out[0] |= 0x20u;
+  return op;
+}
+
