@@ -26,6 +26,7 @@ namespace zenc {
 
 constexpr uint32_t kMagic = 0xFD2FB528u;
 constexpr uint32_t kBlockMax = 128u * 1024u;     // Block_Maximum_Size
+constexpr uint32_t kLitHeaderRaw = 3u;            // the raw literals header this writer always uses (write_raw_literals_header)
 constexpr int kLLLog = 6, kMLLog = 6, kOFLog = 5;
 constexpr int kLLSyms = 36, kMLSyms = 53, kOFSyms = 29;
 
@@ -316,6 +317,132 @@ ZE_FN uint8_t* write_sequences(uint8_t* out, uint8_t* end, const uint64_t* seqs,
   if (fll) bw.add(sll.v & ((1u << st.log[0]) - 1u), st.log[0]);
   uint8_t* e = bw.close();
   return bw.overflow ? nullptr : e;
+}
+
+// ---- Huffman-coded literals (RFC 8878 sections 3.1.1.3.1 and 4.2) ----
+// A prefix code over the literal bytes, code lengths 1..kHufMaxBits, given as `nbits[256]` (0 = byte does not occur) and
+// COMPLETE (the Kraft sum is exactly 1): the format has no way to say otherwise - it transmits weights
+// w = maxbits + 1 - nbits for all bytes but the last present one, whose weight is whatever completes a power of two.
+// Codes are canonical in the format's own order: within a length by byte value, and longer codes BELOW shorter ones
+// (the decoder's table starts with the longest codes).
+constexpr int kHufMaxBits = 11;
+struct HufCode { uint16_t code[256]; uint8_t nbits[256]; int maxbits; int last; };     // last = highest byte value present
+// false: not a complete code of at least two symbols within the length limit
+ZE_FN bool huf_assign_codes(HufCode& h) {
+  uint32_t count[kHufMaxBits + 2] = {0};
+  int maxbits = 0, present = 0; h.last = -1;
+  for (int s = 0; s < 256; s++) if (h.nbits[s]) { if (h.nbits[s] > kHufMaxBits) return false; count[h.nbits[s]]++; if (h.nbits[s] > maxbits) maxbits = h.nbits[s]; present++; h.last = s; }
+  if (present < 2) return false;
+  uint32_t kraft = 0;
+  for (int b = 1; b <= maxbits; b++) kraft += count[b] << (maxbits - b);
+  if (kraft != (1u << maxbits)) return false;
+  // first table index of every length: the longest codes come first
+  uint32_t start[kHufMaxBits + 2]; uint32_t at = 0;
+  for (int b = maxbits; b >= 1; b--) { start[b] = at; at += count[b] << (maxbits - b); }
+  for (int s = 0; s < 256; s++) {
+    const int b = h.nbits[s];
+    if (!b) { h.code[s] = 0; continue; }
+    h.code[s] = (uint16_t)(start[b] >> (maxbits - b));
+    start[b] += 1u << (maxbits - b);
+  }
+  h.maxbits = maxbits;
+  return true;
+}
+// Huffman_Tree_Description: weights of bytes 0 .. last-1, direct (4 bits each, up to 128 of them) or FSE-compressed (two
+// interleaved states).  Returns its size, 0 when neither form can carry these weights (the caller stores the literals raw).
+ZE_FN uint32_t huf_write_tree(uint8_t* out, uint32_t room, const HufCode& h) {
+  const int nw = h.last;                                     // the last present byte's weight is implied
+  uint8_t w[256];
+  for (int s = 0; s < nw; s++) w[s] = h.nbits[s] ? (uint8_t)(h.maxbits + 1 - h.nbits[s]) : 0;
+  // ---- FSE-compressed: alphabet 0..11, Accuracy_Log <= 6 ----
+  uint32_t cnt[12] = {0};
+  for (int s = 0; s < nw; s++) cnt[w[s]]++;
+  int16_t norm[16]; int maxsym = 0;
+  for (int v = 0; v < 12; v++) if (cnt[v]) maxsym = v;
+  uint32_t fse_len = 0;
+  uint8_t tmp[160];
+  if (nw >= 2 && fse_normalize(cnt, maxsym + 1, (uint32_t)nw, 6, norm)) {
+    CTab t;
+    build_ctab(t, norm, maxsym + 1, 6);
+    const uint32_t hl = fse_write_ncount(tmp, norm, maxsym + 1, 6);
+    BitWriter bw; bw.init(tmp + hl, tmp + sizeof tmp);
+    // weight k is decoded from state 1 when k is even, from state 2 when odd; the two last weights only initialise
+    // the states (with the state that needs the most bits next: the decoder must run dry right behind them)
+    FseState s1, s2; s1.v = s2.v = 0;
+    bool i1 = false, i2 = false;
+    for (int k = nw - 1; k >= 0; k--) {
+      FseState& st = (k & 1) ? s2 : s1; bool& inited = (k & 1) ? i2 : i1;
+      if (!inited) { fse_init(st, t, w[k]); inited = true; } else fse_encode(st, t, w[k], bw);
+    }
+    bw.add(s2.v & 63u, 6u); bw.add(s1.v & 63u, 6u);
+    uint8_t* e = bw.close();
+    if (!bw.overflow && (uint32_t)(e - tmp) < 128u) fse_len = (uint32_t)(e - tmp);
+  }
+  const uint32_t direct_len = nw <= 128 ? (uint32_t)((nw + 1) / 2) : 0u;
+  if (fse_len && (!direct_len || fse_len < direct_len)) {
+    if (1u + fse_len > room) return 0u;
+    out[0] = (uint8_t)fse_len; memcpy(out + 1, tmp, fse_len);
+    return 1u + fse_len;
+  }
+  if (!direct_len || 1u + direct_len > room) return 0u;
+  out[0] = (uint8_t)(127 + nw);
+  for (int k = 0; k < nw; k += 2) out[1 + k / 2] = (uint8_t)((w[k] << 4) | (k + 1 < nw ? w[k + 1] : 0));
+  return 1u + direct_len;
+}
+// one Huffman stream: the decoder reads it backwards from the final mark bit and meets the FIRST byte's code first
+ZE_FN uint8_t* huf_write_stream(uint8_t* out, uint8_t* end, const uint8_t* lit, uint32_t n, const HufCode& h) {
+  BitWriter bw; bw.init(out, end);
+  for (uint32_t k = n; k-- > 0u;) bw.add(h.code[lit[k]], h.nbits[lit[k]]);
+  uint8_t* e = bw.close();
+  return bw.overflow ? nullptr : e;
+}
+// Literals_Section with Literals_Block_Type 2 (Compressed): header (3 / 4 / 5 bytes by size), tree, and ONE stream (up to 1023
+// literal bytes, if it fits the 10-bit sizes) or FOUR with their jump table.  Returns the end of the section, nullptr when it
+// does not fit or is not smaller than the raw form (3 + n bytes).
+ZE_FN uint8_t* write_huffman_literals(uint8_t* out, uint8_t* end, const uint8_t* lit, uint32_t n, const HufCode& h) {
+  if (n < 8u || out + 5 + 6 > end) return nullptr;
+  const bool single = n < 256u;                                  // short runs: one stream, no jump table
+  const uint32_t hdr = (single || n < 1024u) ? 3u : (n < 16384u ? 4u : 5u);
+  uint8_t* p = out + hdr;
+  const uint32_t tl = huf_write_tree(p, (uint32_t)(end - p), h);
+  if (!tl) return nullptr;
+  p += tl;
+  uint32_t csize;
+  if (single) {
+    uint8_t* e = huf_write_stream(p, end, lit, n, h);
+    if (!e) return nullptr;
+    csize = (uint32_t)(e - (out + hdr));
+    p = e;
+  } else {
+    if (p + 6 > end) return nullptr;
+    uint8_t* jump = p; p += 6;
+    const uint32_t q = (n + 3u) / 4u;
+    for (int k = 0; k < 4; k++) {
+      const uint32_t from = q * (uint32_t)k, len = k < 3 ? q : n - 3u * q;
+      uint8_t* e = huf_write_stream(p, end, lit + from, len, h);
+      if (!e) return nullptr;
+      const uint32_t sz = (uint32_t)(e - p);
+      if (k < 3) { if (sz > 0xffffu) return nullptr; jump[2 * k] = (uint8_t)sz; jump[2 * k + 1] = (uint8_t)(sz >> 8); }
+      p = e;
+    }
+    csize = (uint32_t)(p - (out + hdr));
+  }
+  if (csize + hdr >= n + kLitHeaderRaw) return nullptr;
+  // header: type 2 | Size_Format << 2 | regenerated size | compressed size (10 / 10, 14 / 14 or 18 / 18 bits)
+  if (hdr == 3u) {
+    if (csize >= 1024u) return nullptr;
+    const uint32_t v = 2u | ((single ? 0u : 1u) << 2) | (n << 4) | (csize << 14);
+    out[0] = (uint8_t)v; out[1] = (uint8_t)(v >> 8); out[2] = (uint8_t)(v >> 16);
+  } else if (hdr == 4u) {
+    if (csize >= 16384u) return nullptr;
+    const uint32_t v = 2u | (2u << 2) | (n << 4) | (csize << 18);
+    out[0] = (uint8_t)v; out[1] = (uint8_t)(v >> 8); out[2] = (uint8_t)(v >> 16); out[3] = (uint8_t)(v >> 24);
+  } else {
+    if (n >= (1u << 18) || csize >= (1u << 18)) return nullptr;
+    const uint64_t v = 2u | (3u << 2) | ((uint64_t)n << 4) | ((uint64_t)csize << 22);
+    for (int k = 0; k < 5; k++) out[k] = (uint8_t)(v >> (8 * k));
+  }
+  return p;
 }
 
 // frame header: magic, FHD 0xA0 (single segment, 4-byte content size), content size

@@ -1,6 +1,7 @@
 """CPU: the format-writing half of the GPU Zstd encoder (c-blosc_amd/csrc/zstd_enc.h: frame / block / raw-literals
 headers, sequence codes, predefined FSE tables as the encoder sees them, per-block tables - normalised counts, their
-FSE table description, RLE mode -, repeat-offset codes, the backward bitstream) compiled with g++ behind a plain greedy matcher (tests/tools/zstd_enc_cpu.cpp).  Every frame must be read back
+FSE table description, RLE mode -, Huffman-coded literals (complete length-limited codes, tree description direct or with
+FSE-compressed weights on two interleaved states, one or four streams), repeat-offset codes, the backward bitstream) compiled with g++ behind a plain greedy matcher (tests/tools/zstd_enc_cpu.cpp).  Every frame must be read back
 bit-exactly by the oracle's decoder and - where oracle/_ref ships - by the reference's own ZSTD_decompress."""
 import ctypes as C
 import os
@@ -40,7 +41,7 @@ def test_frames_decode_with_oracle_and_reference(enc, oracle, ref):
             data = DATASETS[dname](n)
             if dname != "random" and n >= 4096 and n % 8 == 0:
                 data = data.reshape(-1, 8).T.copy().reshape(-1)                          # byte planes, as inside a blosc block
-            for minmatch, tables in ((3, 0), (4, 0), (8, 0), (3, 1), (4, 1), (8, 1)):
+            for minmatch, tables in ((3, 0), (4, 0), (8, 0), (3, 1), (4, 1), (8, 1), (4, 2), (4, 3), (8, 3)):
                 out = np.zeros(n + n // 8 + 64, np.uint8)
                 r = enc.zenc_cpu_compress2(ptr(data), n, ptr(out), out.size, minmatch, tables, None, 0)
                 assert r > 0
@@ -52,8 +53,8 @@ def test_frames_decode_with_oracle_and_reference(enc, oracle, ref):
                     d = ref.ZSTD_decompress(ptr(back2), n, ptr(out), r)
                     assert not ref.ZSTD_isError(d) and d == n and np.array_equal(back2[:n], data), (dname, n, minmatch)
                 cases += 1
-    assert cases == 360
-    assert sizes[1] < sizes[0]                       # per-block tables are only taken where they pay
+    assert cases == 540
+    assert sizes[1] < sizes[0] and sizes[3] < sizes[1]                       # per-block tables are only taken where they pay
 
 
 def test_too_small_destination(enc):
@@ -107,3 +108,33 @@ def test_table_descriptions_cover_the_corner_cases(enc, ref):
             assert d == data.size and np.array_equal(back, data), (trial, kind, tables, d)
             tried += 1
     assert tried == 600
+
+
+def test_huffman_literals_on_odd_byte_distributions(enc, ref):
+    """Literal alphabets of 2 .. 256 bytes, flat and extremely skewed (the 11-bit limit and its repair), values above 128 (weights
+    must travel FSE-compressed), short and long runs (one stream / four streams, all three header sizes)."""
+    if ref is None:
+        pytest.skip("needs the reference's ZSTD_decompress (oracle/_ref)")
+    ref.ZSTD_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    ref.ZSTD_decompress.restype = C.c_size_t
+    rng = np.random.default_rng(1)
+    smaller = 0
+    for trial in range(240):
+        n = int(rng.choice([40, 255, 256, 1000, 1023, 1024, 5000, 16383, 16384, 70000, 131072]))
+        k = int(rng.choice([2, 3, 5, 16, 100, 129, 200, 256]))
+        pr = np.random.default_rng(trial).dirichlet(np.ones(k) * rng.choice([0.02, 0.5, 5]))
+        data = rng.choice(k, n, p=pr).astype(np.uint8)
+        if trial % 3 == 0:
+            data = (data.astype(np.int32) * int(rng.integers(1, 256 // k + 1))).astype(np.uint8)
+        sizes = []
+        for tables in (1, 3):
+            out = np.zeros(n + 1024, np.uint8)
+            r = enc.zenc_cpu_compress2(ptr(data), n, ptr(out), out.size, 4, tables, None, 0)
+            assert r > 0
+            back = np.zeros(n, np.uint8)
+            d = ref.ZSTD_decompress(ptr(back), n, ptr(out), r)
+            assert d == n and np.array_equal(back, data), (trial, n, k, tables)
+            sizes.append(r)
+        assert sizes[1] <= sizes[0]
+        smaller += sizes[1] < sizes[0]
+    assert smaller > 150

@@ -2,8 +2,9 @@
 // greedy hash matcher stands in for the wave-parallel match finder, the frame is written with exactly the functions
 // the device uses.  tests/test_zstd_enc_cpu.py feeds the frames to the reference's ZSTD_decompress (oracle/_ref) and to
 // the oracle's decoder.   Build: g++ -O2 -shared -fPIC -o tests/tools/libzstd_enc_cpu.so tests/tools/zstd_enc_cpu.cpp
-//   tables: 0 = the predefined FSE tables for every block; 1 = per block and per alphabet the cheapest of predefined /
-//   RLE_Mode / a distribution made for the block (FSE_Compressed_Mode, Accuracy_Log 6)
+//   tables: bit 0 = per block and per alphabet the cheapest of predefined / RLE_Mode / a distribution made for the block
+//   (FSE_Compressed_Mode, Accuracy_Log 6) instead of the predefined FSE tables; bit 1 = Huffman-coded literals where that is
+//   smaller than the raw form (code lengths: a plain Huffman tree, cut to 11 bits and repaired to a complete code)
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -30,6 +31,42 @@ void choose_table(const uint32_t* count, int nsym, uint32_t nseq, const int16_t*
   if (cost_new >= cost_pre) return;
   build_ctab(tab, norm, last + 1, kCustomLog);
   st.mode[k] = kModeFSE; st.log[k] = kCustomLog; st.desc[k] = desc; st.desc_len[k] = len;
+}
+// ---- code lengths for Huffman-coded literals: classic tree, then the length limit ----
+bool huf_lengths(const uint32_t* cnt, uint8_t* nbits) {
+  int sym[256], n = 0;
+  for (int s = 0; s < 256; s++) { nbits[s] = 0; if (cnt[s]) sym[n++] = s; }
+  if (n < 2) return false;
+  // nodes 0..n-1 leaves, n.. internal; repeatedly join the two lightest live roots
+  uint64_t wgt[512]; int parent[512]; bool live[512];
+  for (int i = 0; i < n; i++) { wgt[i] = cnt[sym[i]]; parent[i] = -1; live[i] = true; }
+  int nodes = n;
+  for (int m = 0; m < n - 1; m++) {
+    int a = -1, b = -1;
+    for (int i = 0; i < nodes; i++) if (live[i]) { if (a < 0 || wgt[i] < wgt[a]) { b = a; a = i; } else if (b < 0 || wgt[i] < wgt[b]) b = i; }
+    wgt[nodes] = wgt[a] + wgt[b]; parent[nodes] = -1; live[nodes] = true; live[a] = live[b] = false; parent[a] = parent[b] = nodes; nodes++;
+  }
+  const int L = kHufMaxBits;
+  int len[256];
+  for (int i = 0; i < n; i++) { int d = 0; for (int j = i; parent[j] >= 0; j = parent[j]) d++; len[i] = d > L ? L : d; }
+  // the cut may have over-subscribed the code space: lengthen the cheapest codes until it fits, then hand back what is left
+  long kraft = 0;
+  for (int i = 0; i < n; i++) kraft += 1L << (L - len[i]);
+  while (kraft > (1L << L)) {
+    int best = -1;
+    for (int i = 0; i < n; i++) if (len[i] < L && (best < 0 || len[i] > len[best] || (len[i] == len[best] && wgt[i] < wgt[best]))) best = i;
+    if (best < 0) return false;
+    kraft -= 1L << (L - len[best] - 1); len[best]++;
+  }
+  long slack = (1L << L) - kraft;
+  while (slack > 0) {
+    int best = -1;
+    for (int i = 0; i < n; i++) if (len[i] > 1 && (1L << (L - len[i])) <= slack && (best < 0 || len[i] < len[best] || (len[i] == len[best] && wgt[i] > wgt[best]))) best = i;
+    if (best < 0) return false;
+    slack -= 1L << (L - len[best]); len[best]--;
+  }
+  for (int i = 0; i < n; i++) nbits[sym[i]] = (uint8_t)len[i];
+  return true;
 }
 const int16_t kLLNorm[kLLSyms] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
 const int16_t kMLNorm[kMLSyms] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
@@ -81,19 +118,30 @@ extern "C" int zenc_cpu_compress2(const uint8_t* src, int n, uint8_t* dst, int c
     }
     memcpy(lit + nlit, src + anchor, s1 - anchor); nlit += s1 - anchor;
     write_raw_literals_header(bh + kBlockHeader, nlit);
+    uint8_t* lit_end = lit + nlit;                 // where the sequences section starts
+    if ((tables & 2) && nlit >= 32) {
+      uint32_t cnt[256] = {0};
+      for (uint32_t k = 0; k < nlit; k++) cnt[lit[k]]++;
+      HufCode h;
+      if (huf_lengths(cnt, h.nbits) && huf_assign_codes(h)) {
+        std::vector<uint8_t> raw(lit, lit + nlit), tmp(nlit + 64);
+        uint8_t* e = write_huffman_literals(tmp.data(), tmp.data() + nlit + 2, raw.data(), nlit, h);
+        if (e) { memcpy(bh + kBlockHeader, tmp.data(), (size_t)(e - tmp.data())); lit_end = bh + kBlockHeader + (e - tmp.data()); }
+      }
+    }
     const RepState rep_before = rep;
     assign_offset_values(seqs.data(), (uint32_t)seqs.size(), rep);
     CTabs T = P;
     SeqTables st; seq_tables_predefined(st);
     uint8_t desc[3][kMaxNCountBytes];
-    if (tables && !seqs.empty()) {
+    if ((tables & 1) && !seqs.empty()) {
       uint32_t cl[kLLSyms] = {0}, cm[kMLSyms] = {0}, co[32] = {0};
       for (uint64_t q : seqs) { cl[ll_code(seq_ll(q)).code]++; cm[ml_code(seq_ml(q)).code]++; co[of_code_value(seq_off(q)).code]++; }
       choose_table(cl, kLLSyms, (uint32_t)seqs.size(), kLLNorm, kLLLog, P.ll, T.ll, st, 0, desc[0]);
       choose_table(co, kOFSyms, (uint32_t)seqs.size(), kOFNorm, kOFLog, P.of, T.of, st, 1, desc[1]);
       choose_table(cm, kMLSyms, (uint32_t)seqs.size(), kMLNorm, kMLLog, P.ml, T.ml, st, 2, desc[2]);
     }
-    uint8_t* e = write_sequences(lit + nlit, end, seqs.data(), (uint32_t)seqs.size(), T, &st);
+    uint8_t* e = write_sequences(lit_end, end, seqs.data(), (uint32_t)seqs.size(), T, &st);
     uint32_t bsize = e ? (uint32_t)(e - (bh + kBlockHeader)) : 0xffffffffu;
     if (!e || bsize >= s1 - s0) {              // not worth it: Raw_Block
       if (op + kBlockHeader + (s1 - s0) > (uint32_t)cap) return 0;
