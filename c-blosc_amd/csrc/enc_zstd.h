@@ -166,6 +166,8 @@ __device__ __forceinline__ uint32_t zt_bits256(uint32_t n, uint32_t log) {
 }
 // One alphabet.  `c`: this lane's symbol count (0 for lanes beyond the alphabet).  Fills zt.* for index a and, in FSE mode, the
 // encoder table `ct` and the description at desc[0 .. 12).  Returns nothing; all decisions are wave-uniform.
+// FORCE: no predefined alternative (the weights of a Huffman tree description): FSE mode whenever the counts can be normalised
+template <bool FORCE = false>
 __device__ __forceinline__ void zt_make_table(uint32_t c, uint32_t total, int a, uint32_t predef_log, ZsTabs& zt, BAMD_LAS zenc::CTab* ct,
                                               volatile BAMD_LAS uint32_t* desc, int lane) {
   zt.mode[a] = zenc::kModePredefined; zt.log[a] = predef_log; zt.rle[a] = 0u; zt.desc_len[a] = 0u;
@@ -190,9 +192,12 @@ __device__ __forceinline__ void zt_make_table(uint32_t c, uint32_t total, int a,
   const uint32_t incl = wave_incl_scan_u32(v, lane);
   const uint32_t excl = incl - v;                                    // cells handed out before this symbol
   // ---- cost with this table against the predefined one ----
-  const int32_t pn = (int32_t)kZtPredef[a][lane];
-  const uint32_t cost_pre = wave_sum_u32(c ? c * zt_bits256(pn < 0 ? 1u : (uint32_t)pn, predef_log) : 0u);
-  uint32_t cost_new = wave_sum_u32(c ? c * zt_bits256(v, 6u) : 0u);
+  uint32_t cost_pre = 0xffffffffu, cost_new = 0u;
+  if (!FORCE) {
+    const int32_t pn = (int32_t)kZtPredef[a][lane];
+    cost_pre = wave_sum_u32(c ? c * zt_bits256(pn < 0 ? 1u : (uint32_t)pn, predef_log) : 0u);
+    cost_new = wave_sum_u32(c ? c * zt_bits256(v, 6u) : 0u);
+  }
   // ---- the description: 4 bits log - 5, then per symbol up to `last` a field whose width follows from the points still left ----
   uint64_t field = 0; uint32_t width = 0;
   if (lane <= last) {
@@ -220,7 +225,7 @@ __device__ __forceinline__ void zt_make_table(uint32_t c, uint32_t total, int a,
   const uint32_t dbits = (uint32_t)__builtin_amdgcn_readlane((int)wincl, 63);
   const uint32_t dlen = (dbits + 7u) >> 3;
   cost_new += dlen << 11;
-  if (cost_new >= cost_pre) return;                                  // the predefined table is cheaper (short blocks)
+  if (!FORCE && cost_new >= cost_pre) return;                        // the predefined table is cheaper (short blocks)
   if (lane < 12) desc[lane] = 0u;
   BAMD_LDS_SYNC();
   zv_or_bits(desc, wincl - width, field, width);
@@ -279,6 +284,235 @@ __device__ __forceinline__ void zt_make_tables(const BAMD_GAS uint64_t* seqs, ui
   zt_make_table(lane < 32 ? hist[64 + lane] : 0u, nseq, 1, (uint32_t)zenc::kOFLog, zt, &C->of, scr + ZT_DESC + 12, lane);
   zt_make_table(lane < zenc::kMLSyms ? hist[128 + lane] : 0u, nseq, 2, (uint32_t)zenc::kMLLog, zt, &C->ml, scr + ZT_DESC + 24, lane);
 }
+// ---------------------------------------------------------------------------------------------
+// Huffman-coded literals (zstd_enc.h: "Huffman-coded literals"; flag bit 0 of the tables kernels).  Noisy planes keep most of
+// their bytes as literals, and those are what the reference's ratio on such data comes from (small integers: 2.0 -> 2.35).
+// Per block, after the match finder and before the sequence tables (same scratch): byte histogram (LDS atomics); code lengths with
+// one lane per four byte values - ceil(log2(total / count)) cut to 11 bits, then the code space is brought to exactly full:
+// over-subscription is paid by the longest codes below 11 bits, slack goes to where it saves the most bits (count << length),
+// one wave-wide maximum per move (tests/test_zstd_enc_cpu.py's true Huffman tree is within 3 % of this); canonical codes in the
+// format's order by one prefix sum per length; tree description direct (up to 128 weights) or FSE-compressed (weights' table by
+// zt_make_table<FORCE>, the two interleaved states walked by lane 0); then one or four streams, 64 literals per step placed with a
+// prefix sum over their code lengths.  The section is assembled in the sequence scratch behind the block's triples and copied
+// in front of the sequences section if it is smaller than the raw form.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t ZH_CNT = 0u, ZH_CODE = 256u, ZH_STRIP = 512u, ZH_CTAB = 544u, ZH_DESC = 688u, ZH_W = 704u, ZH_H12 = 768u, ZH_END = 784u;   // dwords
+static_assert(ZH_CTAB + (sizeof(zenc::CTab) + 3) / 4 <= ZH_DESC && ZH_END * 4u <= (uint32_t)ENC_TAB_BYTES, "scratch layout");
+struct ZhOut { gu8* p; uint32_t pos, cap, acc, nb; };            // forward bit writer, wave-uniform state
+// the codes of up to 64 symbols, lane order = stream order (lane 0 lands in the lowest bits); <= 11 bits each
+__device__ __forceinline__ bool zh_put(ZhOut& o, volatile BAMD_LAS uint32_t* strip, uint32_t bits, uint32_t nbits, int lane) {
+  const uint32_t incl = wave_incl_scan_u32(nbits, lane);
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  if (lane < 24) strip[lane] = lane == 0 ? o.acc : 0u;
+  BAMD_LDS_SYNC();
+  if (nbits) zv_or_bits(strip, o.nb + incl - nbits, (uint64_t)bits, nbits);
+  const uint32_t fill = o.nb + total, ndw = fill >> 5;            // <= 22 full dwords
+  if (o.pos + 4u * ndw + 8u > o.cap) return false;
+  BAMD_LDS_SYNC();
+  if ((uint32_t)lane < ndw) g_st4(o.p + o.pos + 4u * (uint32_t)lane, strip[lane]);
+  o.acc = uni(strip[ndw]); o.nb = fill & 31u; o.pos += 4u * ndw;
+  return true;
+}
+// one stream: literals lit[0..len) coded last byte first, the mark bit, zero padding to the byte
+__device__ __forceinline__ bool zh_stream(ZhOut& o, volatile BAMD_LAS uint32_t* scr, const gu8* lit, uint32_t len, int lane) {
+  o.acc = 0u; o.nb = 0u;
+  for (uint32_t base = 0; base < len; base += 64u) {
+    uint32_t e = 0;
+    if (base + (uint32_t)lane < len) e = scr[ZH_CODE + (uint32_t)lit[len - 1u - base - (uint32_t)lane]];
+    if (!zh_put(o, scr + ZH_STRIP, e & 0xfffu, e >> 12, lane)) return false;
+  }
+  if (!zh_put(o, scr + ZH_STRIP, lane == 0 ? 1u : 0u, lane == 0 ? 1u : 0u, lane)) return false;
+  const uint32_t tail = (o.nb + 7u) >> 3;
+  if (o.pos + tail > o.cap) return false;
+  if ((uint32_t)lane < tail) o.p[o.pos + (uint32_t)lane] = (uint8_t)(o.acc >> (8u * (uint32_t)lane));
+  o.pos += tail;
+  return true;
+}
+// the whole Literals_Section of lit[0..n) into stage[0..cap); returns its size, 0 = keep the raw form
+__device__ __forceinline__ uint32_t zh_literals(const gu8* lit, uint32_t n, gu8* stage, uint32_t cap, volatile BAMD_LAS uint32_t* scr, int lane) {
+  if (n < 64u || n >= (1u << 18) || cap < 256u) return 0u;
+  volatile BAMD_LAS uint32_t* cnt = scr + ZH_CNT;
+  BAMD_LDS_SYNC();                                                  // the scratch overlays the match finder's table
+#pragma unroll
+  for (int j = 0; j < 4; j++) cnt[64 * j + lane] = 0u;
+  BAMD_LDS_SYNC();
+  for (uint32_t i = 4u * (uint32_t)lane; i < n; i += 256u) {
+    if (i + 4u <= n) {
+      const uint32_t w = g_ld4(lit + i);
+#pragma unroll
+      for (int b = 0; b < 4; b++) __hip_atomic_fetch_add((BAMD_LAS uint32_t*)cnt + ((w >> (8 * b)) & 0xffu), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    } else {
+      for (uint32_t k = i; k < n; k++) __hip_atomic_fetch_add((BAMD_LAS uint32_t*)cnt + (uint32_t)lit[k], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+  }
+  BAMD_LDS_SYNC();
+  // ---- code lengths: this lane's byte values are 4 lane .. 4 lane + 3 ----
+  uint32_t c[4], l[4];
+  uint32_t kraft = 0, npresent = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    c[j] = cnt[4 * lane + j]; l[j] = 0u;
+    if (c[j]) {
+      uint32_t b = 1u;
+      while (b < 11u && (c[j] << b) < n) b++;
+      l[j] = b; kraft += 1u << (11u - b); npresent++;
+    }
+  }
+  npresent = wave_sum_u32(npresent);
+  if (npresent < 2u) return 0u;
+  kraft = wave_sum_u32(kraft);
+  while (kraft > 2048u) {                                           // over-subscribed: the longest code below 11 bits (the rarest of them) gets one more bit
+    uint32_t key = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (l[j] && l[j] < 11u) { const uint32_t k2 = (l[j] << 20) | (0xfffffu - (c[j] < 0xfffffu ? c[j] : 0xfffffu)); key = k2 > key ? k2 : key; }
+    const uint32_t best = wave_max_u32(key);
+    if (best == 0u) return 0u;
+    const uint64_t who = __ballot(key == best);
+    if (lane == __builtin_ctzll(who)) {
+      bool done = false;
+#pragma unroll
+      for (int j = 0; j < 4; j++) if (!done && l[j] && l[j] < 11u && ((l[j] << 20) | (0xfffffu - (c[j] < 0xfffffu ? c[j] : 0xfffffu))) == best) { l[j]++; done = true; }
+    }
+    kraft -= 1u << (11u - (best >> 20) - 1u);
+  }
+  uint32_t slack = 2048u - kraft;
+  while (slack) {                                                   // room left: one bit less where that saves the most (count << length) and still fits
+    uint32_t key = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (l[j] > 1u && (1u << (11u - l[j])) <= slack) { const uint32_t k2 = c[j] << l[j]; key = k2 > key ? k2 : key; }
+    const uint32_t best = wave_max_u32(key);
+    if (best == 0u) return 0u;                                      // cannot be completed (never seen): raw literals
+    const uint64_t who = __ballot(key == best);
+    const int wl = __builtin_ctzll(who);
+    uint32_t step = 0;
+    if (lane == wl) {
+      bool done = false;
+#pragma unroll
+      for (int j = 0; j < 4; j++) if (!done && l[j] > 1u && (1u << (11u - l[j])) <= slack && (c[j] << l[j]) == best) { step = 1u << (11u - l[j]); l[j]--; done = true; }
+    }
+    slack -= (uint32_t)__builtin_amdgcn_readlane((int)step, wl);
+  }
+  // ---- canonical codes: longer codes first, within a length by byte value ----
+  uint32_t lmax = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) lmax = l[j] > lmax ? l[j] : lmax;
+  const uint32_t maxbits = wave_max_u32(lmax);
+  uint32_t code[4] = {0, 0, 0, 0};
+  uint32_t at = 0;                                                  // first table index of the current length
+  for (uint32_t b = maxbits; b >= 1u; b--) {
+    uint32_t mine = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) mine += l[j] == b ? 1u : 0u;
+    const uint32_t incl = wave_incl_scan_u32(mine, lane);
+    const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    uint32_t r = incl - mine;
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (l[j] == b) { code[j] = (at >> (maxbits - b)) + r; r++; }
+    at += tot << (maxbits - b);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) scr[ZH_CODE + 4u * (uint32_t)lane + (uint32_t)j] = code[j] | (l[j] << 12);
+  // ---- tree description: weights of byte values 0 .. last - 1 ----
+  const uint64_t anyl = __ballot((l[0] | l[1] | l[2] | l[3]) != 0u);
+  const int hl = 63 - __builtin_clzll(anyl);
+  const uint32_t lj = l[3] ? 3u : (l[2] ? 2u : (l[1] ? 1u : 0u));
+  const uint32_t last = 4u * (uint32_t)hl + (uint32_t)__builtin_amdgcn_readlane((int)lj, hl);
+  const uint32_t nw = last;
+  const uint32_t hdr = n < 1024u ? 3u : (n < 16384u ? 4u : 5u);
+  const bool single = n < 256u;
+  uint32_t wv[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) wv[j] = l[j] ? maxbits + 1u - l[j] : 0u;
+  volatile BAMD_LAS uint32_t* h12 = scr + ZH_H12;
+  if (lane < 16) h12[lane] = 0u;
+  scr[ZH_W + (uint32_t)lane] = wv[0] | (wv[1] << 8) | (wv[2] << 16) | (wv[3] << 24);       // weights as bytes, in byte-value order
+  BAMD_LDS_SYNC();
+#pragma unroll
+  for (int j = 0; j < 4; j++) if (4u * (uint32_t)lane + (uint32_t)j < nw) __hip_atomic_fetch_add((BAMD_LAS uint32_t*)h12 + wv[j], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  BAMD_LDS_SYNC();
+  gu8* tree = stage + hdr;
+  uint32_t tree_len = 0;
+  {
+    ZsTabs zt;
+    BAMD_LAS zenc::CTab* ct = (BAMD_LAS zenc::CTab*)((BAMD_LAS uint32_t*)scr + ZH_CTAB);
+    zt_make_table<true>(lane < 12 ? h12[lane] : 0u, nw, 0, 6u, zt, ct, scr + ZH_DESC, lane);
+    if (zt.mode[0] == zenc::kModeFSE) {
+      // description bytes, then the two interleaved state chains (lane 0: a serial walk over <= 255 weights)
+      const uint32_t dl = zt.desc_len[0];
+      const uint32_t dwv = scr[ZH_DESC + ((uint32_t)lane >> 2)];
+      if ((uint32_t)lane < dl) tree[1u + (uint32_t)lane] = (uint8_t)(dwv >> (8u * ((uint32_t)lane & 3u)));
+      uint32_t total_len = 0;
+      if (lane == 0) {
+        const BAMD_LAS uint32_t* dnb = (const BAMD_LAS uint32_t*)ct->dnb; const BAMD_LAS int32_t* dfs = (const BAMD_LAS int32_t*)ct->dfs;
+        const BAMD_LAS uint16_t* stt = (const BAMD_LAS uint16_t*)ct->st;
+        const volatile BAMD_LAS uint8_t* wb = (const volatile BAMD_LAS uint8_t*)(scr + ZH_W);
+        uint64_t acc = 0; uint32_t nb = 0, pos = 1u + dl;
+        uint32_t s1 = 0, s2 = 0; bool i1 = false, i2 = false;
+        for (int k = (int)nw - 1; k >= 0; k--) {
+          const uint32_t sym = wb[k];
+          const uint32_t d = dnb[sym]; const int32_t f = dfs[sym];
+          uint32_t& st = (k & 1) ? s2 : s1; bool& inited = (k & 1) ? i2 : i1;
+          if (!inited) { const uint32_t nbb = (d + (1u << 15)) >> 16; st = stt[(int32_t)(((nbb << 16) - d) >> nbb) + f]; inited = true; }
+          else {
+            const uint32_t nbb = (st + d) >> 16;
+            acc |= (uint64_t)(st & ((1u << nbb) - 1u)) << nb; nb += nbb;
+            st = stt[(int32_t)(st >> nbb) + f];
+            while (nb >= 8u) { if (pos < 140u) tree[pos] = (uint8_t)acc; pos++; acc >>= 8; nb -= 8u; }
+          }
+        }
+        acc |= (uint64_t)(s2 & 63u) << nb; nb += 6u;
+        acc |= (uint64_t)(s1 & 63u) << nb; nb += 6u;
+        acc |= 1ull << nb; nb += 1u;
+        while (nb > 0u) { if (pos < 140u) tree[pos] = (uint8_t)acc; pos++; acc >>= 8; nb = nb > 8u ? nb - 8u : 0u; }
+        total_len = pos - 1u;
+      }
+      total_len = (uint32_t)__builtin_amdgcn_readlane((int)total_len, 0);
+      if (total_len < 128u && (nw > 128u || total_len < (nw + 1u) / 2u)) { if (lane == 0) tree[0] = (uint8_t)total_len; tree_len = 1u + total_len; }
+    }
+  }
+  if (tree_len == 0u) {                                             // direct: 4 bits per weight
+    if (nw > 128u) return 0u;
+    BAMD_MEM_SYNC();
+    const uint32_t nbytes = (nw + 1u) / 2u;
+    const volatile BAMD_LAS uint8_t* wb = (const volatile BAMD_LAS uint8_t*)(scr + ZH_W);
+    if ((uint32_t)lane < nbytes) {
+      const uint32_t a = wb[2 * lane], b2 = 2u * (uint32_t)lane + 1u < nw ? (uint32_t)wb[2 * lane + 1] : 0u;
+      tree[1u + (uint32_t)lane] = (uint8_t)((a << 4) | b2);
+    }
+    if (lane == 0) tree[0] = (uint8_t)(127u + nw);
+    tree_len = 1u + nbytes;
+  }
+  // ---- the streams ----
+  ZhOut o = {stage, hdr + tree_len, cap, 0u, 0u};
+  if (single) { if (!zh_stream(o, scr, lit, n, lane)) return 0u; }
+  else {
+    const uint32_t jump = o.pos; o.pos += 6u;
+    const uint32_t q = (n + 3u) / 4u;
+#pragma unroll 1
+    for (uint32_t k = 0; k < 4u; k++) {
+      const uint32_t from = q * k, len = k < 3u ? q : n - 3u * q, p0 = o.pos;
+      if (!zh_stream(o, scr, lit + from, len, lane)) return 0u;
+      const uint32_t sz = o.pos - p0;
+      if (k < 3u) { if (sz > 0xffffu) return 0u; if (lane == 0) { stage[jump + 2u * k] = (uint8_t)sz; stage[jump + 2u * k + 1u] = (uint8_t)(sz >> 8); } }
+    }
+  }
+  const uint32_t csize = o.pos - hdr;
+  if (o.pos >= n + zenc::kLitHeaderRaw) return 0u;
+  if (hdr == 3u) {
+    if (csize >= 1024u) return 0u;
+    const uint32_t v = 2u | ((single ? 0u : 1u) << 2) | (n << 4) | (csize << 14);
+    if (lane < 3) stage[lane] = (uint8_t)(v >> (8 * lane));
+  } else if (hdr == 4u) {
+    if (csize >= 16384u) return 0u;
+    const uint32_t v = 2u | (2u << 2) | (n << 4) | (csize << 18);
+    if (lane < 4) stage[lane] = (uint8_t)(v >> (8 * lane));
+  } else {
+    const uint64_t v = 2u | (3u << 2) | ((uint64_t)n << 4) | ((uint64_t)csize << 22);
+    if (lane < 5) stage[lane] = (uint8_t)(v >> (8 * lane));
+  }
+  return o.pos;
+}
+
 template <bool TABLES>
 __device__ __forceinline__ uint32_t zs_write_sequences_v(gu8* out, uint32_t room, const BAMD_GAS uint64_t* seqs, uint32_t nseq,
                                                          const BAMD_LAS zenc::CTabs* T, volatile BAMD_LAS uint32_t* scr, int lane, const ZsTabs* ztp = nullptr) {
@@ -409,7 +643,9 @@ __device__ __forceinline__ uint32_t zs_write_sequences_v(gu8* out, uint32_t room
 // then stored raw by blosc's own rule, blosc.c:703-717).  `seqbuf`: zenc::kBlockMax / 4 entries of this wave.
 constexpr uint32_t ZS_SEQCAP = zenc::kBlockMax / 4u;
 constexpr int ZS_LDS_BYTES = (int)((sizeof(zenc::CTabs) + 15) / 16 * 16);
-template <bool TABLES = false, bool HC = false>      // HC: the LZ4HC-grade search (hc_encode_wave) as the match finder, its 24 KiB table in front of the FSE tables
+// HC: the LZ4HC-grade search (hc_encode_wave) as the match finder, its 24 KiB table in front of the FSE tables; HUF (with TABLES):
+// Huffman-coded literals where they are smaller than the raw form
+template <bool TABLES = false, bool HC = false, bool HUF = false>
 __device__ uint32_t zstd_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8* __restrict__ dst, uint32_t cap, int clevel,
                                      enc_entry_t* tab_generic, BAMD_GAS uint64_t* seqbuf, int lane EPROF_ARG) {
   if (n < 32u || cap < 64u) return 0u;
@@ -446,17 +682,31 @@ __device__ uint32_t zstd_encode_wave(const gu8* __restrict__ src, uint32_t n, gu
       __builtin_amdgcn_s_waitcnt(0);
       PROF_LAP(4);                        // Zstd: slot 4 = tail literals + offset values, slot 5 = sequences section
       uint32_t ss;
+      uint32_t lit_bytes = zenc::kLitHeader + z.nlit;              // size of the literals section (raw form so far)
       if (TABLES) {
-        // per-block tables (zt_make_tables): worth their description from a few dozen sequences on
         volatile BAMD_LAS uint32_t* scr = (volatile BAMD_LAS uint32_t*)(BAMD_LAS uint8_t*)(void*)tab_generic;
+        gu8* seq_out = z.lit + z.nlit;
+        if (HUF) {
+          // the section is put together behind the block's triples in the sequence scratch, then moved in front of the sequences
+          gu8* stage = (gu8*)(seqbuf + z.nseq);
+          const uint32_t hs = zh_literals(z.lit, z.nlit, stage, (ZS_SEQCAP - z.nseq) * 8u, scr, lane);
+          if (hs) {
+            BAMD_MEM_SYNC();
+            wave_copy_disjoint(bh + zenc::kBlockHeader, stage, hs, lane);
+            seq_out = bh + zenc::kBlockHeader + hs; lit_bytes = hs;
+          }
+        }
+        // per-block tables (zt_make_tables): worth their description from a few dozen sequences on
         ZsTabs zt;
         zt_make_tables(seqbuf, z.nseq, scr, zt, lane);
-        ss = zs_write_sequences_v<true>(z.lit + z.nlit, z.litcap - z.nlit, seqbuf, z.nseq, T, scr, lane, &zt);
-      } else
+        ss = zs_write_sequences_v<true>(seq_out, cap - (uint32_t)(seq_out - dst), seqbuf, z.nseq, T, scr, lane, &zt);
+        if (ss != 0xffffffffu) bsize = lit_bytes + ss;
+      } else {
       ss = BAMD_ZSTD_VSEQ ? zs_write_sequences_v<false>(z.lit + z.nlit, z.litcap - z.nlit, seqbuf, z.nseq, T, (volatile BAMD_LAS uint32_t*)(BAMD_LAS uint8_t*)(void*)tab_generic, lane)
                                          : zs_write_sequences(z.lit + z.nlit, z.litcap - z.nlit, seqbuf, z.nseq, T, lane);
-      PROF_LAP(5);
       if (ss != 0xffffffffu) bsize = zenc::kLitHeader + z.nlit + ss;
+      }
+      PROF_LAP(5);
     }
     if (bsize >= seg) {                   // no gain: Raw_Block
       if (op + zenc::kBlockHeader + seg >= cap) return 0u;

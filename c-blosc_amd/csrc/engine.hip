@@ -368,6 +368,8 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   const bool ztab = zstd && zstd_tables_enabled();
   // the LZ4HC-grade search in front of the Zstd writer (with per-block tables) / the zlib writer: BLOSC_AMD_ZSTD_SEARCH=1, BLOSC_AMD_ZLIB_SEARCH=1
   const bool zsearch = (zstd && env_flag("BLOSC_AMD_ZSTD_SEARCH")) || (zlibc && env_flag("BLOSC_AMD_ZLIB_SEARCH"));
+  // Huffman-coded literals (with the per-block tables, or tables + search): BLOSC_AMD_ZSTD_HUFFMAN=1 on top of either switch
+  const bool zhuf = zstd && (ztab || zsearch) && env_flag("BLOSC_AMD_ZSTD_HUFFMAN");
   static const int enc_wpc_lz = getenv("BLOSC_AMD_ENC_WPC") ? atoi(getenv("BLOSC_AMD_ENC_WPC")) : ENC_WAVES_PER_CU;
   const int enc_wpc = zsearch ? (160 * 1024) / (HC_TAB_BYTES + ZS_LDS_BYTES) : (hc ? HC_WAVES_PER_CU : enc_wpc_lz);   // what fits into a CU's LDS
   const size_t zwaves = zstd ? (size_t)(st.cus > 0 ? st.cus : 256) * (size_t)enc_wpc : 0;
@@ -471,8 +473,8 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
 #else
 #define BAMD_ENC_LAUNCH(MODE) hipLaunchKernelGGL(k_encode_streams_t<MODE>, grid, block, 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, d_seqbufs, d_ctabs, detect)
 #endif
-    if (zstd && zsearch) BAMD_ENC_LAUNCH(ENC_ZSTD_HC);
-    else if (zstd && ztab) BAMD_ENC_LAUNCH(ENC_ZSTD_T);
+    if (zstd && zsearch) { if (zhuf) BAMD_ENC_LAUNCH(ENC_ZSTD_HCH); else BAMD_ENC_LAUNCH(ENC_ZSTD_HC); }
+    else if (zstd && ztab) { if (zhuf) BAMD_ENC_LAUNCH(ENC_ZSTD_TH); else BAMD_ENC_LAUNCH(ENC_ZSTD_T); }
     else if (zstd) BAMD_ENC_LAUNCH(ENC_ZSTD);
     else if (zlibc && zsearch) BAMD_ENC_LAUNCH(ENC_ZLIB_HC);
     else if (zlibc) BAMD_ENC_LAUNCH(ENC_ZLIB);

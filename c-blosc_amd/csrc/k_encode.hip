@@ -55,8 +55,10 @@ namespace bamd {
 // MODE: 0 = LZ4 / BloscLZ, 1 = Zstd, 2 = Zlib, 3 = LZ4 with the LZ4HC-grade search, 4 = Zstd with per-block sequence tables -
 // a batch has ONE codec, so every kernel carries only its own code path
 // 5 = Zstd with per-block tables behind the LZ4HC-grade search, 6 = zlib behind the LZ4HC-grade search
-enum { ENC_LZ = 0, ENC_ZSTD = 1, ENC_ZLIB = 2, ENC_HC = 3, ENC_ZSTD_T = 4, ENC_ZSTD_HC = 5, ENC_ZLIB_HC = 6 };
-constexpr bool enc_mode_hc(int mode) { return mode == ENC_HC || mode == ENC_ZSTD_HC || mode == ENC_ZLIB_HC; }
+// 7 / 8 = 4 / 5 with Huffman-coded literals
+enum { ENC_LZ = 0, ENC_ZSTD = 1, ENC_ZLIB = 2, ENC_HC = 3, ENC_ZSTD_T = 4, ENC_ZSTD_HC = 5, ENC_ZLIB_HC = 6, ENC_ZSTD_TH = 7, ENC_ZSTD_HCH = 8 };
+constexpr bool enc_mode_hc(int mode) { return mode == ENC_HC || mode == ENC_ZSTD_HC || mode == ENC_ZLIB_HC || mode == ENC_ZSTD_HCH; }
+constexpr bool enc_mode_zstd(int mode) { return mode == ENC_ZSTD || mode == ENC_ZSTD_T || mode == ENC_ZSTD_HC || mode == ENC_ZSTD_TH || mode == ENC_ZSTD_HCH; }
 template <int MODE>
 __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, enc_entry_t* tab, const ChunkDesc* chunks, uint32_t* blk_ready, int lane,
                                                             const BlockDesc* blocks, uint32_t sid, uint32_t* plane_cost, uint64_t* seqbuf
@@ -82,6 +84,8 @@ __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, enc_
   uint32_t r;
   const int32_t hint = (int32_t)uni((uint32_t)sd->result);      // < 0: the shuffle task found this plane periodic (period -hint)
   if (MODE == ENC_ZSTD) r = seqbuf ? zstd_encode_wave(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, (BAMD_GAS uint64_t*)seqbuf, lane EPROF_PASS) : 0u;
+  else if (MODE == ENC_ZSTD_HCH) r = seqbuf ? zstd_encode_wave<true, true, true>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, (BAMD_GAS uint64_t*)seqbuf, lane EPROF_PASS) : 0u;
+  else if (MODE == ENC_ZSTD_TH) r = seqbuf ? zstd_encode_wave<true, false, true>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, (BAMD_GAS uint64_t*)seqbuf, lane EPROF_PASS) : 0u;
   else if (MODE == ENC_ZSTD_HC) r = seqbuf ? zstd_encode_wave<true, true>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, (BAMD_GAS uint64_t*)seqbuf, lane EPROF_PASS) : 0u;
   else if (MODE == ENC_ZLIB_HC) r = zlib_encode_wave<true>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, lane EPROF_PASS);
   else if (MODE == ENC_ZSTD_T) r = seqbuf ? zstd_encode_wave<true>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, (BAMD_GAS uint64_t*)seqbuf, lane EPROF_PASS) : 0u;
@@ -109,7 +113,7 @@ __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, enc_
 // finding of other waves instead of in a kernel of their own.
 template <int MODE>
 // (waves per SIMD the register allocator plans for: the 24 KiB table of the HC modes leaves room for 1.5, the Zstd modes' LDS for 5)
-__global__ __launch_bounds__(64 * ENC_WAVES, enc_mode_hc(MODE) ? 2 : (MODE == ENC_ZSTD_T ? 5 : BAMD_ENC_MINWAVES)) void k_encode_streams_t(
+__global__ __launch_bounds__(64 * ENC_WAVES, enc_mode_hc(MODE) ? 2 : ((MODE == ENC_ZSTD_T || MODE == ENC_ZSTD_TH) ? 5 : BAMD_ENC_MINWAVES)) void k_encode_streams_t(
     StreamDesc* __restrict__ streams, uint32_t* __restrict__ tickets /*[8]*/, const int32_t* __restrict__ qlist,
     const int32_t* __restrict__ qoff /*[9]*/, const ChunkDesc* __restrict__ chunks, const BlockDesc* __restrict__ blocks,
     uint32_t* __restrict__ blk_ready, uint32_t* __restrict__ plane_cost, int single_queue,
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES, enc_mode_hc(MODE) ? 2 : (MODE == EN
     , uint32_t* __restrict__ profbuf
 #endif
     ) {
-  constexpr bool ZSTD = MODE == ENC_ZSTD || MODE == ENC_ZSTD_T || MODE == ENC_ZSTD_HC;
+  constexpr bool ZSTD = enc_mode_zstd(MODE);
   constexpr int TABBYTES = enc_mode_hc(MODE) ? HC_TAB_BYTES : ENC_TAB_BYTES;      // the match finder's table; the writers' LDS sits behind it
   __shared__ __attribute__((aligned(16))) enc_entry_t tabs[ENC_WAVES][(TABBYTES + (ZSTD ? ZS_LDS_BYTES : ((MODE == ENC_ZLIB || MODE == ENC_ZLIB_HC) ? DFL_LDS_BYTES : 0))) / 4];
   static_assert(ENC_WAVES == 1, "one stream per wave, one wave per workgroup");
