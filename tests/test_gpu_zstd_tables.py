@@ -92,3 +92,31 @@ def test_lz4hc_search_in_front_of_the_entropy_writers(pkg, oracle, ref, codec, s
             os.environ.pop(switch, None)
         else:
             os.environ[switch] = old
+
+
+def test_huffman_literals(pkg, oracle, ref):
+    """BLOSC_AMD_ZSTD_HUFFMAN=1 on top of the per-block tables (and of the search): literal-heavy data must come out smaller and be read by
+    everybody (the reference's ZSTD_decompress checks the Huffman tree description and the four streams)."""
+    keys = ("BLOSC_AMD_ZSTD_TABLES", "BLOSC_AMD_ZSTD_SEARCH", "BLOSC_AMD_ZSTD_HUFFMAN")
+    old = {k: os.environ.get(k) for k in keys}
+    try:
+        for base in ("BLOSC_AMD_ZSTD_TABLES", "BLOSC_AMD_ZSTD_SEARCH"):
+            for k in keys:
+                os.environ.pop(k, None)
+            os.environ[base] = "1"
+            for dname, T, want in [("smallints", 4, 0.92), ("randwalk", 8, 1.002), ("bench19", 8, 1.002), ("random", 1, 1.002)]:
+                for n in (1000, 300001, 4 << 20):
+                    data = DATASETS[dname](n)
+                    os.environ["BLOSC_AMD_ZSTD_HUFFMAN"] = "0"
+                    rp, _ = pkg.compress(data, T, 3, 1, b"zstd", 0)
+                    os.environ["BLOSC_AMD_ZSTD_HUFFMAN"] = "1"
+                    r = _roundtrip(pkg, oracle, ref, data, T, 3, 1)
+                    if n == 4 << 20:
+                        print(f"zstd clevel 3 {dname:9s} ({base[-6:].lower()}): Huffman literals {data.size / r:8.2f}   raw literals {data.size / rp:8.2f}")
+                        assert r <= rp * want, (dname, base, r, rp)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
