@@ -227,7 +227,7 @@ def test_zlib_streams_written_by_zlib(emu, oracle):
     zo = _zo(oracle)
     rng = np.random.default_rng(8)
     n_ok = n_bad = 0
-    for s, data in stock_streams(sizes=(1, 17, 255, 4096, 20000)):
+    for s, data in stock_streams(sizes=(1, 17, 255, 3000)):
         r, got = _entropy_decode(emu, ZLIB, s, data.size)
         assert r == data.size and np.array_equal(got, data), (data.size, s.size, r)
         n_ok += 1
@@ -251,7 +251,7 @@ def test_zstd_frames(emu, oracle, ref):
     sequence tables) where oracle/_ref ships, and frames written by this repo's own encoder (all its modes) run on the same emulator."""
     oracle.orc_zstd_decompress.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     rng = np.random.default_rng(14)
-    inputs = [x for x in _inputs(oracle) if x.size <= 40000][:22]
+    inputs = [x for x in _inputs(oracle) if x.size <= 40000][:14]
     inputs.append(np.concatenate([DATASETS["bench19"](131072 * 8).reshape(-1, 8).T[1], rng.integers(0, 256, 3000, dtype=np.uint8)]))   # several blocks
     n = 0
     for data in inputs:
@@ -264,7 +264,7 @@ def test_zstd_frames(emu, oracle, ref):
                 r = ref.ZSTD_compress(ptr(dst), dst.size, ptr(data), data.size, level)
                 streams.append(dst[:r].copy())
         from test_wave_emu_encoders import _encode
-        for kind in (3, 5, 6):
+        for kind in (3, 5, 6, 8, 9):                                         # predefined tables, per-block tables, + search, + Huffman literals
             r, s = _encode(emu, kind, data, clevel=3)
             if r:
                 streams.append(s)
@@ -280,4 +280,4 @@ def test_zstd_frames(emu, oracle, ref):
                 assert (ro == data.size) == (r == data.size), (ro, r)
                 if ro == data.size:
                     assert np.array_equal(got, want[:data.size])
-    assert n > 60
+    assert n > 40

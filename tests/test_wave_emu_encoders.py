@@ -155,9 +155,9 @@ def _entropy_inputs():
     rng = np.random.default_rng(9)
     inputs = []
     for dname in ["bench19", "linspace", "randwalk", "smallints", "arange"]:
-        for j in (0, 1, 5):
-            inputs.append(_plane(dname, 16384, 8, j))
-    inputs.append(_plane("bench19", 131072 + 4096, 8, 1))             # two blocks in one frame: the second one starts on a table the first one's scratch has overwritten
+        for j in (1, 5):
+            inputs.append(_plane(dname, 8192, 8, j))
+    inputs.append(np.concatenate([_plane("bench19", 131072, 8, 1)[:131072 - 3000], _plane("linspace", 8192, 8, 1)]))   # two blocks in one frame: the second one starts on a table the first one's scratch has overwritten
     inputs.append(np.concatenate([_plane("bench19", 131072, 8, 1), rng.integers(0, 256, 1069, dtype=np.uint8)]))   # ... and a second block without a single sequence (stored raw)
     for n in [0, 1, 16, 31, 32, 33, 63, 64, 65, 100, 255, 256, 1000, 4097]:
         inputs.append(np.zeros(n, np.uint8))                           # one sequence: every alphabet RLE
@@ -175,13 +175,13 @@ def test_zstd_frames_decode_with_oracle_and_reference(emu, oracle, ref, kind):
     cases = 0
     inputs = _entropy_inputs()
     for data in (inputs if kind in (ZSTD, ZSTD_TABLES) else inputs[::2]):
-        for clevel in ((1, 3, 9) if kind in (ZSTD, ZSTD_TABLES) else (3,)):
+        for clevel in ((1, 9) if kind in (ZSTD, ZSTD_TABLES) else (3,)):
             r, s = _encode(emu, kind, data, clevel=clevel)
             if r:
                 assert r < data.size
                 _zstd_reads(oracle, ref, s, data)
                 cases += 1
-    assert cases > (60 if kind in (ZSTD, ZSTD_TABLES) else 10)
+    assert cases > (30 if kind in (ZSTD, ZSTD_TABLES) else 8)
     # capacity: a complete frame inside what it was given, or 0
     data = _plane("bench19", 16384, 8, 1)
     full, _ = _encode(emu, kind, data, clevel=3)
@@ -216,7 +216,7 @@ def test_zlib_streams_decode(emu, oracle, ref, kind):
             if r:
                 assert zlib.decompress(s.tobytes()) == data.tobytes()
                 cases += 1
-    assert cases > (60 if kind == ZLIB else 20)
+    assert cases > (40 if kind == ZLIB else 12)
 
 
 def test_zstd_huffman_literals(emu, oracle, ref):
@@ -226,8 +226,8 @@ def test_zstd_huffman_literals(emu, oracle, ref):
     be smaller than with raw literals."""
     rng = np.random.default_rng(3)
     smaller = tried = 0
-    for trial in range(30):
-        n = int(rng.choice([255, 256, 300, 1000, 1023, 1024, 5000, 16383, 16384, 40000]))
+    for trial in range(24):
+        n = int(rng.choice([255, 256, 300, 1000, 1023, 1024, 5000, 16383, 16384, 20000]))
         k = int(rng.choice([2, 3, 5, 16, 100, 129, 200, 256]))
         pr = np.random.default_rng(trial).dirichlet(np.ones(k) * rng.choice([0.02, 0.5, 5]))
         data = rng.choice(k, n, p=pr).astype(np.uint8)
