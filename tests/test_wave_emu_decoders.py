@@ -281,3 +281,63 @@ def test_zstd_frames(emu, oracle, ref):
                 if ro == data.size:
                     assert np.array_equal(got, want[:data.size])
     assert n > 40
+
+
+# ---- whole split blocks through decode_one_stream: per-stream decode, periodic spans, raw-in-place planes, the fused unshuffle ----
+def _block_streams(chunk, T):
+    """the T compressed splits of block 0 of a one-block chunk (blosc/blosc.c:635-719 layout: bstarts, then int32 csize + bytes per split)"""
+    c = np.asarray(chunk, np.uint8)
+    pos = int(c[16:20].view("<i4")[0])
+    out = []
+    for _ in range(T):
+        cs = int(c[pos:pos + 4].view("<i4")[0]); pos += 4
+        out.append(c[pos:pos + cs].copy()); pos += cs
+    return out
+
+
+@pytest.mark.parametrize("codec,fmt", [("lz4", 1), ("blosclz", 0)])
+@pytest.mark.parametrize("T", [4, 8])
+def test_fused_block_decode(emu, oracle, codec, fmt, T):
+    """One block = typesize split streams, decoded stream by stream (in shuffled order: any wave may be the one that completes the block)
+    by decode_one_stream itself; constant and short-period planes leave only their edges in the scratch (periodic spans, pattern
+    table / register row), incompressible planes are read where they lie in the chunk, and the last stream's wave unshuffles."""
+    from helpers import header, orc_compress
+    emu.emu_decode_block.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_uint, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
+    rng = np.random.default_rng(30 + T)
+    ne = 65536                                                     # bytes per plane: long enough for spans (>= 16 KiB matches)
+    bsize = ne * T
+    seen = {"span": 0, "small": 0, "raw": 0, "plain": 0}
+    for trial in range(6):
+        planes = []
+        for j in range(T):
+            kind = (trial + j) % 6
+            if kind == 0: planes.append(np.zeros(ne, np.uint8))                                              # constant: period 1
+            elif kind == 1: planes.append(np.resize(rng.integers(0, 256, int(rng.choice([2, 4, 64, 256])), dtype=np.uint8), ne))
+            elif kind == 2: planes.append(np.resize(rng.integers(0, 256, int(rng.choice([512, 1024, 2048])), dtype=np.uint8), ne))   # pattern-table span
+            elif kind == 3: planes.append(rng.integers(0, 256, ne, dtype=np.uint8))                          # incompressible: stored raw
+            elif kind == 4: planes.append(rng.integers(0, 4, ne, dtype=np.uint8))                            # ordinary
+            else:                                                                                            # a span that a later match reaches back into
+                a = np.resize(rng.integers(0, 256, 128, dtype=np.uint8), ne).copy(); a[ne - 3000:] = a[5000:8000]; a[ne - 100:] = rng.integers(0, 256, 100, dtype=np.uint8)
+                planes.append(a)
+        data = np.ascontiguousarray(np.stack(planes, 1)).reshape(-1)
+        r, chunk = orc_compress(oracle, data, T, 5, 1, codec, blocksize=bsize)
+        assert r > 0 and header(chunk)["blocksize"] == bsize and header(chunk)["nbytes"] == bsize
+        streams = _block_streams(chunk, T)
+        padded = [np.concatenate([s, np.zeros(256, np.uint8)]) for s in streams]
+        ptrs = (C.c_void_p * T)(*[p.ctypes.data for p in padded])
+        cs = (C.c_int * T)(*[int(s.size) for s in streams])
+        order = (C.c_int * T)(*[int(x) for x in rng.permutation(T)])
+        dst = np.full(bsize + 256, 0xEE, np.uint8)
+        spans = (C.c_uint * 16)()
+        st = emu.emu_decode_block(T, fmt, ptrs, cs, bsize, ptr(dst), order, spans)
+        assert st == 0
+        assert np.array_equal(dst[:bsize], data), (trial, int(np.argmax(dst[:bsize] != data)))
+        assert np.all(dst[bsize:] == 0xEE)
+        for j in range(T):
+            w, hi = spans[2 * j], spans[2 * j + 1]
+            if w & 2: seen["raw"] += 1
+            elif hi and (w & 1): seen["small"] += 1
+            elif hi: seen["span"] += 1
+            else: seen["plain"] += 1
+    assert seen["raw"] and seen["small"] and seen["plain"], seen
+    print(codec, T, seen)

@@ -72,6 +72,44 @@ extern "C" unsigned emu_periodic_stream(const uint8_t* in256, unsigned n, uint8_
   return j.result;
 }
 
+// ---- one whole split block through decode_one_stream (k_decode.hip): every stream decoded by its own (emulated) wave, one after the
+// other, with the periodic-span bookkeeping of fused chunks; the wave that completes the block's last stream runs the fused unshuffle ----
+namespace {
+struct BJob { bamd::StreamDesc* sd; int32_t* status; uint32_t* scr; bamd::ChunkDesc* chunks; bamd::BlockDesc* blocks; uint32_t* blk_done; uint32_t sid; uint32_t* spans; uint8_t* pat; };
+void blk_body(int lane, void* arg) {
+  BJob* j = (BJob*)arg;
+  bamd::decode_one_stream(j->sd + j->sid, j->status, (volatile uint32_t*)j->scr, j->chunks, j->blocks, j->blk_done, lane, j->sid, j->spans, j->pat, nullptr);
+}
+}  // namespace
+// streams[k] / csize[k]: the T compressed splits of one block of `bsize` bytes (typesize T = 4 or 8, byte-shuffled), fmt = FMT_LZ4 /
+// FMT_BLOSCLZ; dst receives the unshuffled block.  order[k]: the sequence in which the streams are decoded (any permutation).  Returns the
+// chunk status word (0 = fine).  spans_out (2 T words) shows which planes took the periodic-span / raw-in-place shortcuts.
+extern "C" int emu_decode_block(int T, int fmt, const uint8_t* const* streams, const int* csize, unsigned bsize, uint8_t* dst, const int* order, unsigned* spans_out) {
+  using namespace bamd;
+  const uint32_t ne = bsize / (uint32_t)T;
+  uint8_t* filt = (uint8_t*)malloc(bsize + 4096);
+  memset(filt, 0xCD, bsize + 4096);
+  ChunkDesc c; memset(&c, 0, sizeof c);
+  c.src = nullptr; c.dst = dst; c.filt = filt; c.nbytes = (int32_t)bsize; c.blocksize = (int32_t)bsize; c.typesize = T; c.nblocks = 1;
+  c.nsplits = T; c.fmt = fmt; c.mode = CH_SHUFFLE | CH_FUSED_UNSHUF; c.first_block = 0; c.first_stream = 0;
+  BlockDesc b; memset(&b, 0, sizeof b);
+  b.chunk = 0; b.blk = 0; b.first_stream = 0; b.nstreams = T; b.bsize = (int32_t)bsize;
+  StreamDesc sd[8];
+  for (int k = 0; k < T; k++) { sd[k].in = streams[k]; sd[k].out = filt + (size_t)k * ne; sd[k].in_size = csize[k]; sd[k].out_size = (int32_t)ne; sd[k].chunk = 0; sd[k].fmt = fmt; sd[k].aux = 0; sd[k].result = 0; }
+  int32_t status = 0; uint32_t blk_done = 0;
+  uint32_t spans[16]; memset(spans, 0, sizeof spans);
+  uint8_t* pat = (uint8_t*)malloc((size_t)T * SPAN_PAT + 64);
+  uint32_t* scr = (uint32_t*)aligned_alloc(64, 64 * 4 + LZB_BYTES + 256);
+  for (int k = 0; k < T; k++) {
+    memset(scr, 0xA5, 64 * 4 + LZB_BYTES + 256);
+    BJob j = {sd, &status, scr, &c, &b, &blk_done, (uint32_t)order[k], spans, pat};
+    wave_emu::run(blk_body, &j);
+  }
+  if (spans_out) memcpy(spans_out, spans, sizeof(uint32_t) * 2 * (size_t)T);
+  free(filt); free(pat); free(scr);
+  return status;
+}
+
 // ---- the entropy-coded formats' decoders: zlib_decode_wave (k_zlib.hip) and the one-wave-per-frame Zstd decoder (k_zstd.hip) ----
 namespace {
 struct EJob { int kind; const uint8_t* src; int n; uint8_t* dst; int cap; void* lds; uint8_t* lit; int result; };
