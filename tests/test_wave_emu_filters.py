@@ -85,3 +85,43 @@ def test_periodic_planes_are_found_and_written_as_one_match(emu, oracle, T):
                 back = np.zeros(N + 8, np.uint8)
                 f = oracle.orc_lz4_decompress if lz4 else oracle.orc_blosclz_decompress
                 assert f(ptr(out), r, ptr(back), N) == N and np.array_equal(back[:N], planes[j]), (trial, j, lz4)
+
+
+@pytest.mark.parametrize("fmt,mode", [(1, 0), (0, 0), (1, 3)], ids=["lz4", "blosclz", "lz4hc"])
+@pytest.mark.parametrize("T", [4, 8])
+def test_block_through_the_kernels_task_functions(emu, oracle, T, fmt, mode):
+    """shuffle_block_task (periodic planes noted in their stream descriptors) followed by encode_one_stream for every plane - the two
+    task kinds of the persistent encode kernel, as it calls them: every plane's stream must decode to that plane (constant and
+    short-period planes through emit_periodic_stream, the others through the match finder), incompressible planes report 0."""
+    emu.emu_encode_block.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint, C.c_void_p, C.c_uint, C.POINTER(C.c_int)]
+    oracle.orc_blosclz_decompress.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    rng = np.random.default_rng(50 + T + fmt)
+    ne = 8192
+    for trial in range(4):
+        planes = []
+        for j in range(T):
+            kind = (trial + j) % 5
+            if kind == 0: planes.append(np.zeros(ne, np.uint8))
+            elif kind == 1: planes.append(np.resize(rng.integers(0, 256, int(rng.choice([2, 16, 128, 256])), dtype=np.uint8), ne))
+            elif kind == 2: planes.append(rng.integers(0, 256, ne, dtype=np.uint8))
+            elif kind == 3: planes.append(rng.integers(0, 3, ne, dtype=np.uint8))
+            else: planes.append(np.resize(rng.integers(0, 256, 700, dtype=np.uint8), ne))
+        data = np.ascontiguousarray(np.stack(planes, 1)).reshape(-1)
+        slot = ne + 64
+        out = np.full(T * slot + 64, 0xEE, np.uint8)
+        res = (C.c_int * 8)()
+        emu.emu_encode_block(T, fmt, mode, 9 if mode == 3 else 5, ptr(data), ne * T, ptr(out), slot, res)
+        assert np.all(out[T * slot:] == 0xEE)
+        for j in range(T):
+            r = res[j]
+            kind = (trial + j) % 5
+            if kind == 2:
+                assert r == 0
+                continue
+            assert 0 < r < ne, (trial, j, r)
+            if kind in (0, 1):
+                assert r < 340                                              # the periodic shortcut: a few literals and one match
+            s = out[j * slot:j * slot + r].copy()
+            back = np.zeros(ne + 8, np.uint8)
+            f = oracle.orc_lz4_decompress if fmt == 1 else oracle.orc_blosclz_decompress
+            assert f(ptr(s), r, ptr(back), ne) == ne and np.array_equal(back[:ne], planes[j]), (trial, j)

@@ -110,6 +110,41 @@ extern "C" int emu_decode_block(int T, int fmt, const uint8_t* const* streams, c
   return status;
 }
 
+// ---- the encode side of the same: shuffle_block_task (with the periodic-plane detection) then encode_one_stream<MODE> for every plane
+// of one block, as the persistent encode kernel does it task by task ----
+namespace {
+struct CJob { int mode; bamd::StreamDesc* sd; uint32_t* tab; bamd::ChunkDesc* chunks; bamd::BlockDesc* blocks; uint32_t* blk_ready; uint32_t sid; uint64_t* seqbuf; int shuffle_task; };
+void enc_blk_body(int lane, void* arg) {
+  CJob* j = (CJob*)arg;
+  using namespace bamd;
+  if (j->shuffle_task) { shuffle_block_task(j->chunks, j->blocks, 0u, j->blk_ready, j->sd, 1, lane); return; }
+  if (j->mode == ENC_HC) encode_one_stream<ENC_HC>(j->sd + j->sid, j->tab, j->chunks, j->blk_ready, lane, j->blocks, j->sid, nullptr, j->seqbuf);
+  else encode_one_stream<ENC_LZ>(j->sd + j->sid, j->tab, j->chunks, j->blk_ready, lane, j->blocks, j->sid, nullptr, j->seqbuf);
+}
+}  // namespace
+// src: one block of bsize bytes (typesize T = 4 or 8); fmt FMT_LZ4 / FMT_BLOSCLZ; mode 0 = plain match finder, 3 = LZ4HC-grade search.
+// out: T slots of `slot` bytes each; result[k]: the stream size of plane k (0 = store raw), as the kernel leaves it in StreamDesc::result.
+extern "C" void emu_encode_block(int T, int fmt, int mode, int clevel, const uint8_t* src, unsigned bsize, uint8_t* out, unsigned slot, int* result) {
+  using namespace bamd;
+  const uint32_t ne = bsize / (uint32_t)T;
+  uint8_t* filt = (uint8_t*)malloc(bsize + 4096);
+  memset(filt, 0xCD, bsize + 4096);
+  ChunkDesc c; memset(&c, 0, sizeof c);
+  c.src = src; c.dst = nullptr; c.filt = filt; c.nbytes = (int32_t)bsize; c.blocksize = (int32_t)bsize; c.typesize = T; c.nblocks = 1;
+  c.nsplits = T; c.fmt = fmt; c.mode = CH_SHUFFLE | CH_FUSED_SHUF; c.clevel = clevel;
+  BlockDesc b; memset(&b, 0, sizeof b);
+  b.nstreams = T; b.bsize = (int32_t)bsize;
+  StreamDesc sd[8];
+  for (int k = 0; k < T; k++) { sd[k].in = filt + (size_t)k * ne; sd[k].out = out + (size_t)k * slot; sd[k].in_size = (int32_t)ne; sd[k].out_size = (int32_t)slot; sd[k].chunk = 0; sd[k].fmt = fmt; sd[k].aux = clevel; sd[k].result = 0; }
+  uint32_t blk_ready = 0;
+  uint32_t* tab = (uint32_t*)aligned_alloc(64, 64 * 1024);
+  CJob j = {mode, sd, tab, &c, &b, &blk_ready, 0u, nullptr, 1};
+  wave_emu::run(enc_blk_body, &j);                                 // the block's shuffle task
+  j.shuffle_task = 0;
+  for (int k = 0; k < T; k++) { memset(tab, 0xA5, 64 * 1024); j.sid = (uint32_t)k; wave_emu::run(enc_blk_body, &j); result[k] = sd[k].result; }
+  free(filt); free(tab);
+}
+
 // ---- the entropy-coded formats' decoders: zlib_decode_wave (k_zlib.hip) and the one-wave-per-frame Zstd decoder (k_zstd.hip) ----
 namespace {
 struct EJob { int kind; const uint8_t* src; int n; uint8_t* dst; int cap; void* lds; uint8_t* lit; int result; };
