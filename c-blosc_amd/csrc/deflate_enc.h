@@ -70,6 +70,69 @@ DF_FN Sym match(uint32_t len, uint32_t dist) {
   return s;
 }
 
+// ---- dynamic Huffman blocks (RFC 1951 3.2.7): codes made for the block, their lengths in front of it ----
+// The symbol numbers and extra bits of match(), separately: a length symbol 257..285, a distance symbol 0..29.
+constexpr int kLitLenSyms = 286, kDistSyms = 30, kCodeLenSyms = 19, kMaxCodeBits = 15, kMaxCodeLenBits = 7;
+struct MatchSyms { uint32_t lsym, lextra, lbits, dsym, dextra, dbits; };
+DF_FN MatchSyms match_symbols(uint32_t len, uint32_t dist) {
+  MatchSyms m;
+  const uint32_t l = len - 3u;
+  m.lextra = 0; m.lbits = 0;
+  if (len == 258u) m.lsym = 285u;
+  else if (l < 8u) m.lsym = 257u + l;
+  else { const uint32_t h = hb(l); m.lbits = h - 2u; m.lsym = 257u + 4u * (h - 1u) + ((l >> m.lbits) & 3u); m.lextra = l & ((1u << m.lbits) - 1u); }
+  const uint32_t d = dist - 1u;
+  m.dextra = 0; m.dbits = 0;
+  if (d < 4u) m.dsym = d;
+  else { const uint32_t h = hb(d); m.dbits = h - 1u; m.dsym = 2u * h + ((d >> m.dbits) & 1u); m.dextra = d & ((1u << m.dbits) - 1u); }
+  return m;
+}
+// canonical codes from code lengths (RFC 1951 3.2.2: shorter codes first, within a length by symbol), kept bit-reversed - the way
+// they enter the LSB-first stream
+DF_FN void assign_codes(const uint8_t* len, int n, uint16_t* code) {
+  uint32_t count[kMaxCodeBits + 1] = {0}, next[kMaxCodeBits + 2];
+  for (int s = 0; s < n; s++) count[len[s]]++;
+  count[0] = 0;
+  uint32_t c = 0;
+  for (int b = 1; b <= kMaxCodeBits; b++) { c = (c + count[b - 1]) << 1; next[b] = c; }
+  for (int s = 0; s < n; s++) code[s] = len[s] ? (uint16_t)rev(next[len[s]]++, len[s]) : 0;
+}
+struct DynCodes {
+  uint8_t llen[kLitLenSyms], dlen[kDistSyms];
+  uint16_t lcode[kLitLenSyms], dcode[kDistSyms];
+};
+DF_FN Sym dyn_literal(const DynCodes& c, uint32_t byte) { Sym s = {c.lcode[byte], c.llen[byte]}; return s; }
+DF_FN Sym dyn_end_of_block(const DynCodes& c) { Sym s = {c.lcode[256], c.llen[256]}; return s; }
+// one match piece: <= 15 + 5 + 15 + 13 = 48 bits, in two parts (length symbol + extra, distance symbol + extra)
+DF_FN void dyn_match(const DynCodes& c, uint32_t len, uint32_t dist, Sym& lpart, Sym& dpart) {
+  const MatchSyms m = match_symbols(len, dist);
+  lpart.bits = c.lcode[m.lsym] | (m.lextra << c.llen[m.lsym]); lpart.nbits = c.llen[m.lsym] + m.lbits;
+  dpart.bits = c.dcode[m.dsym] | (m.dextra << c.dlen[m.dsym]); dpart.nbits = c.dlen[m.dsym] + m.dbits;
+}
+// The code lengths of both alphabets as the block header carries them: run-length symbols 16 (repeat the previous length 3-6
+// times), 17 (3-10 zeros), 18 (11-138 zeros) over llen[0..nlit) followed by dlen[0..ndist).  Fills sym[] / extra[] (extra bits'
+// value; their width follows from the symbol), returns the count.
+DF_FN int code_length_symbols(const uint8_t* lens, int n, uint8_t* sym, uint8_t* extra) {
+  int k = 0;
+  for (int i = 0; i < n;) {
+    const uint8_t v = lens[i];
+    int r = 1;
+    while (i + r < n && lens[i + r] == v) r++;
+    i += r;
+    if (v == 0) {
+      while (r >= 11) { const int t = r < 138 ? r : 138; sym[k] = 18; extra[k++] = (uint8_t)(t - 11); r -= t; }
+      if (r >= 3) { sym[k] = 17; extra[k++] = (uint8_t)(r - 3); r = 0; }
+      while (r-- > 0) { sym[k] = 0; extra[k++] = 0; }
+    } else {
+      sym[k] = v; extra[k++] = 0; r--;
+      while (r >= 3) { const int t = r < 6 ? r : 6; sym[k] = 16; extra[k++] = (uint8_t)(t - 3); r -= t; }
+      while (r-- > 0) { sym[k] = v; extra[k++] = 0; }
+    }
+  }
+  return k;
+}
+constexpr uint8_t kCodeLenOrder[kCodeLenSyms] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
 // a match of `mlen` >= 3 bytes as pieces of at most 258: all but the last two are 258 long, the last is never shorter than 3
 DF_FN uint32_t npieces(uint32_t mlen) { return (mlen + kMaxLen - 1u) / kMaxLen; }
 DF_FN uint32_t piece_len(uint32_t mlen, uint32_t k, uint32_t np) {

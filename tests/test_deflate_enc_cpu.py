@@ -25,6 +25,7 @@ def enc():
         subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-o", so, src])
     E = C.CDLL(so)
     E.dfl_cpu_compress.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    E.dfl_cpu_compress2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
     return E
 
 
@@ -83,3 +84,43 @@ def test_too_small_destination(enc):
     data = DATASETS["random"](5000)
     out = np.zeros(8000, np.uint8)
     assert enc.dfl_cpu_compress(ptr(data), 5000, ptr(out), 4000, 4, 32768) == 0        # does not fit: the caller stores the split raw
+
+
+def test_dynamic_huffman_blocks(enc, oracle, ref):
+    """One final block with codes made for the stream (RFC 1951 3.2.7): canonical codes from length-limited complete code lengths,
+    the header's run-length symbols 16 / 17 / 18 under a code-length code of their own, lone and absent distance codes, inputs of
+    1 byte to 1 MiB and alphabets of 1 .. 256 byte values.  Read by the oracle, python's zlib and - where it ships - the reference."""
+    zo = _zo(oracle); ru = ref_uncompress(ref) if ref is not None else None
+    rng = np.random.default_rng(2)
+    inputs = []
+    for dname in ["bench19", "linspace", "randwalk", "smallints", "zeros", "random"]:
+        for n in [1, 5, 100, 4096, 65536, 300001]:
+            d = DATASETS[dname](n)
+            if dname != "random" and n >= 4096 and n % 8 == 0:
+                d = d.reshape(-1, 8).T.copy().reshape(-1)
+            inputs.append(d)
+    for trial in range(120):
+        n = int(rng.choice([1, 2, 9, 40, 300, 5000, 70000])); k = int(rng.choice([1, 2, 3, 16, 100, 256]))
+        p = rng.choice(k, n, p=np.random.default_rng(trial).dirichlet(np.ones(k) * rng.choice([0.02, 0.5, 5]))).astype(np.uint8)
+        if trial % 4 == 0:
+            p = np.resize(p[:max(1, n // int(rng.integers(2, 50)))], n)
+        inputs.append(p)
+    fixed = dyn = 0
+    for data in inputs:
+        n = data.size
+        for minmatch in (3, 4):
+            sizes = []
+            for dynamic in (0, 1):
+                out = np.zeros(n + n // 4 + 1024, np.uint8)
+                r = enc.dfl_cpu_compress2(ptr(data), n, ptr(out), out.size, minmatch, 32768, dynamic)
+                assert r > 0
+                s = out[:r].copy()
+                got, back = _un(zo, s, n)
+                assert got == n and np.array_equal(back[:n], data), (n, minmatch, dynamic)
+                assert zlib.decompress(s.tobytes()) == data.tobytes()
+                if ru is not None:
+                    got, back = _un(ru, s, n)
+                    assert got == n and np.array_equal(back[:n], data)
+                sizes.append(r)
+            fixed += sizes[0]; dyn += sizes[1]
+    assert dyn < fixed * 0.9
