@@ -284,6 +284,61 @@ __device__ __forceinline__ void zt_make_tables(const BAMD_GAS uint64_t* seqs, ui
   zt_make_table(lane < 32 ? hist[64 + lane] : 0u, nseq, 1, (uint32_t)zenc::kOFLog, zt, &C->of, scr + ZT_DESC + 12, lane);
   zt_make_table(lane < zenc::kMLSyms ? hist[128 + lane] : 0u, nseq, 2, (uint32_t)zenc::kMLLog, zt, &C->ml, scr + ZT_DESC + 24, lane);
 }
+// Code lengths of a complete prefix code, at most LIMIT bits, for an alphabet of 64 * PER symbols (this lane: symbols PER * lane ..
+// PER * lane + PER - 1, counts c[], `total` their sum): ceil(log2(total / count)) cut to LIMIT, then the code space is brought to exactly
+// full - over-subscription is paid by the longest codes below LIMIT (the rarest of them first), slack goes to where it saves the most
+// bits (count << length) and still fits - one wave-wide maximum per move.  Returns the number of symbols present; 0: the space could
+// not be filled (never seen; the caller falls back); 1: a lone symbol, length 1 (an incomplete code: what Deflate wants there).
+template <int PER, int LIMIT>
+__device__ __forceinline__ uint32_t wave_code_lengths(const uint32_t (&c)[PER], uint32_t total, uint32_t (&l)[PER], int lane) {
+  constexpr uint32_t FULL = 1u << LIMIT;
+  uint32_t kraft = 0, npresent = 0;
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    l[j] = 0u;
+    if (c[j]) {
+      uint32_t b = 1u;
+      while (b < (uint32_t)LIMIT && ((uint64_t)c[j] << b) < (uint64_t)total) b++;
+      l[j] = b; kraft += FULL >> b; npresent++;
+    }
+  }
+  npresent = wave_sum_u32(npresent);
+  if (npresent < 2u) return npresent;                               // (the lone symbol already has length 1)
+  kraft = wave_sum_u32(kraft);
+  while (kraft > FULL) {
+    uint32_t key = 0;
+#pragma unroll
+    for (int j = 0; j < PER; j++) if (l[j] && l[j] < (uint32_t)LIMIT) { const uint32_t k2 = (l[j] << 20) | (0xfffffu - (c[j] < 0xfffffu ? c[j] : 0xfffffu)); key = k2 > key ? k2 : key; }
+    const uint32_t best = wave_max_u32(key);
+    if (best == 0u) return 0u;
+    const uint64_t who = __ballot(key == best);
+    if (lane == __builtin_ctzll(who)) {
+      bool done = false;
+#pragma unroll
+      for (int j = 0; j < PER; j++) if (!done && l[j] && l[j] < (uint32_t)LIMIT && ((l[j] << 20) | (0xfffffu - (c[j] < 0xfffffu ? c[j] : 0xfffffu))) == best) { l[j]++; done = true; }
+    }
+    kraft -= FULL >> ((best >> 20) + 1u);
+  }
+  uint32_t slack = FULL - kraft;
+  while (slack) {
+    uint32_t key = 0;
+#pragma unroll
+    for (int j = 0; j < PER; j++) if (l[j] > 1u && (FULL >> l[j]) <= slack) { const uint32_t k2 = (c[j] < 0xffffu ? c[j] : 0xffffu) << l[j]; key = k2 > key ? k2 : key; }
+    const uint32_t best = wave_max_u32(key);
+    if (best == 0u) return 0u;
+    const uint64_t who = __ballot(key == best);
+    const int wl = __builtin_ctzll(who);
+    uint32_t step = 0;
+    if (lane == wl) {
+      bool done = false;
+#pragma unroll
+      for (int j = 0; j < PER; j++) if (!done && l[j] > 1u && (FULL >> l[j]) <= slack && ((c[j] < 0xffffu ? c[j] : 0xffffu) << l[j]) == best) { step = FULL >> l[j]; l[j]--; done = true; }
+    }
+    slack -= (uint32_t)__builtin_amdgcn_readlane((int)step, wl);
+  }
+  return npresent;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Huffman-coded literals (zstd_enc.h: "Huffman-coded literals"; flag bit 0 of the tables kernels).  Noisy planes keep most of
 // their bytes as literals, and those are what the reference's ratio on such data comes from (small integers: 2.0 -> 2.35).
@@ -348,50 +403,9 @@ __device__ __forceinline__ uint32_t zh_literals(const gu8* lit, uint32_t n, gu8*
   BAMD_LDS_SYNC();
   // ---- code lengths: this lane's byte values are 4 lane .. 4 lane + 3 ----
   uint32_t c[4], l[4];
-  uint32_t kraft = 0, npresent = 0;
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    c[j] = cnt[4 * lane + j]; l[j] = 0u;
-    if (c[j]) {
-      uint32_t b = 1u;
-      while (b < 11u && (c[j] << b) < n) b++;
-      l[j] = b; kraft += 1u << (11u - b); npresent++;
-    }
-  }
-  npresent = wave_sum_u32(npresent);
-  if (npresent < 2u) return 0u;
-  kraft = wave_sum_u32(kraft);
-  while (kraft > 2048u) {                                           // over-subscribed: the longest code below 11 bits (the rarest of them) gets one more bit
-    uint32_t key = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) if (l[j] && l[j] < 11u) { const uint32_t k2 = (l[j] << 20) | (0xfffffu - (c[j] < 0xfffffu ? c[j] : 0xfffffu)); key = k2 > key ? k2 : key; }
-    const uint32_t best = wave_max_u32(key);
-    if (best == 0u) return 0u;
-    const uint64_t who = __ballot(key == best);
-    if (lane == __builtin_ctzll(who)) {
-      bool done = false;
-#pragma unroll
-      for (int j = 0; j < 4; j++) if (!done && l[j] && l[j] < 11u && ((l[j] << 20) | (0xfffffu - (c[j] < 0xfffffu ? c[j] : 0xfffffu))) == best) { l[j]++; done = true; }
-    }
-    kraft -= 1u << (11u - (best >> 20) - 1u);
-  }
-  uint32_t slack = 2048u - kraft;
-  while (slack) {                                                   // room left: one bit less where that saves the most (count << length) and still fits
-    uint32_t key = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) if (l[j] > 1u && (1u << (11u - l[j])) <= slack) { const uint32_t k2 = c[j] << l[j]; key = k2 > key ? k2 : key; }
-    const uint32_t best = wave_max_u32(key);
-    if (best == 0u) return 0u;                                      // cannot be completed (never seen): raw literals
-    const uint64_t who = __ballot(key == best);
-    const int wl = __builtin_ctzll(who);
-    uint32_t step = 0;
-    if (lane == wl) {
-      bool done = false;
-#pragma unroll
-      for (int j = 0; j < 4; j++) if (!done && l[j] > 1u && (1u << (11u - l[j])) <= slack && (c[j] << l[j]) == best) { step = 1u << (11u - l[j]); l[j]--; done = true; }
-    }
-    slack -= (uint32_t)__builtin_amdgcn_readlane((int)step, wl);
-  }
+  for (int j = 0; j < 4; j++) c[j] = cnt[4 * lane + j];
+  if (wave_code_lengths<4, 11>(c, n, l, lane) < 2u) return 0u;
   // ---- canonical codes: longer codes first, within a length by byte value ----
   uint32_t lmax = 0;
 #pragma unroll
