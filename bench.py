@@ -67,6 +67,7 @@ CONFIGS = {
     "4t": dict(codec="zstd", shuffle=1, typesize=8, clevel=3, data="bench19", env={"BLOSC_AMD_ZSTD_TABLES": "1"}),
     "4s": dict(codec="zstd", shuffle=1, typesize=8, clevel=3, data="bench19", env={"BLOSC_AMD_ZSTD_SEARCH": "1"}),
     "zs": dict(codec="zlib", shuffle=1, typesize=8, clevel=5, data="bench19", env={"BLOSC_AMD_ZLIB_SEARCH": "1"}),
+    "zd": dict(codec="zlib", shuffle=1, typesize=8, clevel=5, data="bench19", env={"BLOSC_AMD_ZLIB_DYNAMIC": "1", "BLOSC_AMD_ZLIB_SEARCH": "1"}),
     "4h": dict(codec="zstd", shuffle=1, typesize=4, clevel=3, data="smallints", env={"BLOSC_AMD_ZSTD_TABLES": "1", "BLOSC_AMD_ZSTD_HUFFMAN": "1"}),
     "4r": dict(codec="zstd", shuffle=1, typesize=4, clevel=3, data="smallints"),       # 4h's baseline: raw literals, predefined tables
 }

@@ -123,7 +123,8 @@ __device__ __forceinline__ uint32_t emit_ext255(gu8* p, uint32_t v, int lane) {
   return n255 + 1u;
 }
 
-enum { EF_LZ4 = 0, EF_BLOSCLZ = 1, EF_ZSTD = 2, EF_ZLIB = 3 };
+// EF_ZLIB2: Deflate's limits (distance <= 32 KiB) with the Zstd path's sink - the tokens are kept for a second pass (dynamic Huffman codes, enc_zlib.h)
+enum { EF_LZ4 = 0, EF_BLOSCLZ = 1, EF_ZSTD = 2, EF_ZLIB = 3, EF_ZLIB2 = 4 };
 #ifndef BAMD_ZSTD_MINLEN
 #define BAMD_ZSTD_MINLEN 4     // shortest match the Zstd path takes (5 and 6: bench19 ratio and time in DESIGN.md 3.6)
 #endif
@@ -384,7 +385,7 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
   tab.init((void*)tab_generic);
   // stream-end rules.  LZ4: last match starts <= n-12, ends <= n-5 (lz4.c:245-246, :963-964).
   // BloscLZ: matches start < n-12 (blosclz.c:465), stream must end with >= 1 literal (blosclz.c:708-710).
-  if (FMT == EF_ZSTD || FMT == EF_ZLIB) { if (n < start + 16u) return start; }
+  if (FMT == EF_ZSTD || FMT == EF_ZLIB || FMT == EF_ZLIB2) { if (n < start + 16u) return start; }
   else if (FMT == EF_LZ4 ? (n < 13u) : (n < 16u || cap < 66u)) return 0u;
   const uint32_t last_start = n - 12u;                       // inclusive bound on match starts
   const uint32_t mlimit = (FMT == EF_LZ4) ? n - 5u : n - 2u;  // matches end at or before this position
@@ -451,7 +452,7 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
       mine = enc_entry(mix, p);
       const uint32_t e = tab.get(h);
       const uint32_t d = (p - e) & 0xffffu;
-      if (d != 0u && d <= p && EncTable::tag_equal(e, mine) && (FMT != EF_ZLIB || d <= dfl::kMaxDist)) { cand = p - d; tab_ok = true; }
+      if (d != 0u && d <= p && EncTable::tag_equal(e, mine) && ((FMT != EF_ZLIB && FMT != EF_ZLIB2) || d <= dfl::kMaxDist)) { cand = p - d; tab_ok = true; }
     } else {
       prev = 0x100u;
     }
@@ -508,7 +509,7 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
       if (FMT == EF_LZ4) {
         op = lz4_emit_seq(dst, op, cap, src + anchor, ll, dist, mlen, anchor >= ip ? (int)(anchor - ip) : -1, (uint32_t)own.a & 0xffu, lane);
         if (op == 0xffffffffu) return 0u;
-      } else if (FMT == EF_ZSTD) {
+      } else if (FMT == EF_ZSTD || FMT == EF_ZLIB2) {
         if (zs_emit_seq(*zs, src + anchor, ll, dist, mlen, anchor >= ip ? (int)(anchor - ip) : -1, (uint32_t)own.a & 0xffu, lane) == 0xffffffffu) return 0xffffffffu;
       } else if (FMT == EF_ZLIB) {
         if (dfl_emit_seq(*df, src + anchor, ll, dist, mlen, anchor >= ip ? (int)(anchor - ip) : -1, (uint32_t)own.a & 0xffu, lane) == 0xffffffffu) return 0xffffffffu;
@@ -544,7 +545,7 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
     }
   }
   // closing literals
-  if (FMT == EF_ZSTD || FMT == EF_ZLIB) return anchor;
+  if (FMT == EF_ZSTD || FMT == EF_ZLIB || FMT == EF_ZLIB2) return anchor;
   if (FMT == EF_LZ4) {
     op = lz4_emit_tail(dst, op, cap, src + anchor, n - anchor, lane);
     if (op == 0xffffffffu) return 0u;
@@ -675,7 +676,7 @@ __device__ uint32_t hc_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
       for (int w = 0; w < 4; w++) {
         const uint32_t e = (uint32_t)(pp >> (16 * w)) & 0xffffu;
         const uint32_t d = (p - e) & 0xffffu;
-        bool ok = live && d != 0u && d <= p && ((tt >> (8 * w)) & 0xffu) == mytag && (FMT != EF_ZLIB || d <= dfl::kMaxDist);
+        bool ok = live && d != 0u && d <= p && ((tt >> (8 * w)) & 0xffu) == mytag && ((FMT != EF_ZLIB && FMT != EF_ZLIB2) || d <= dfl::kMaxDist);
 #pragma unroll
         for (int v = 0; v < w; v++) ok = ok && !(((okm >> v) & 1u) && dw[v] == d);   // the same position twice in a bucket
         dw[w] = d;
@@ -761,7 +762,7 @@ __device__ uint32_t hc_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
       if (FMT == EF_LZ4) {
         op = lz4_emit_seq(dst, op, cap, src + anchor, pm - anchor, pm - cm, mlen, anchor >= ip ? (int)(anchor - ip) : -1, (uint32_t)own.a & 0xffu, lane);
         if (op == 0xffffffffu) return 0u;
-      } else if (FMT == EF_ZSTD) {
+      } else if (FMT == EF_ZSTD || FMT == EF_ZLIB2) {
         if (zs_emit_seq(*zs, src + anchor, pm - anchor, pm - cm, mlen, anchor >= ip ? (int)(anchor - ip) : -1, (uint32_t)own.a & 0xffu, lane) == 0xffffffffu) return 0xffffffffu;
       } else {
         if (dfl_emit_seq(*df, src + anchor, pm - anchor, pm - cm, mlen, anchor >= ip ? (int)(anchor - ip) : -1, (uint32_t)own.a & 0xffu, lane) == 0xffffffffu) return 0xffffffffu;

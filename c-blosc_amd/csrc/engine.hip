@@ -372,7 +372,8 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   const bool zhuf = zstd && (ztab || zsearch) && env_flag("BLOSC_AMD_ZSTD_HUFFMAN");
   static const int enc_wpc_lz = getenv("BLOSC_AMD_ENC_WPC") ? atoi(getenv("BLOSC_AMD_ENC_WPC")) : ENC_WAVES_PER_CU;
   const int enc_wpc = zsearch ? (160 * 1024) / (HC_TAB_BYTES + ZS_LDS_BYTES) : (hc ? HC_WAVES_PER_CU : enc_wpc_lz);   // what fits into a CU's LDS
-  const size_t zwaves = zstd ? (size_t)(st.cus > 0 ? st.cus : 256) * (size_t)enc_wpc : 0;
+  const bool zdyn = zlibc && env_flag("BLOSC_AMD_ZLIB_DYNAMIC");      // zlib with dynamic Huffman codes: two passes, the tokens in the sequence scratch
+  const size_t zwaves = (zstd || zdyn) ? (size_t)(st.cus > 0 ? st.cus : 256) * (size_t)enc_wpc : 0;
   const size_t o_ctabs = cv.take(sizeof(zenc::CTabs) + 64);
   const size_t o_seqbufs = cv.take(zwaves * ZS_SEQCAP * sizeof(uint64_t) + 64);
   if (st.dev.ensure(cv.off)) return -1;
@@ -462,7 +463,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
     const int32_t* d_qoff = (const int32_t*)(D + o_queues); const int32_t* d_qlist = d_qoff + 9;
     uint32_t* d_ready = (uint32_t*)(D + o_ready);
     const size_t ntasks = queues.size() - 9;
-    uint64_t* d_seqbufs = zstd ? (uint64_t*)(D + o_seqbufs) : nullptr;
+    uint64_t* d_seqbufs = (zstd || zdyn) ? (uint64_t*)(D + o_seqbufs) : nullptr;
     const zenc::CTabs* d_ctabs = zstd ? (const zenc::CTabs*)(D + o_ctabs) : nullptr;
     const int detect = (!zstd && !zlibc && periodic_enabled()) ? 1 : 0;
     const dim3 grid(persistent_grid(ntasks, enc_wpc)), block(64 * ENC_WAVES);
@@ -476,6 +477,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
     if (zstd && zsearch) { if (zhuf) BAMD_ENC_LAUNCH(ENC_ZSTD_HCH); else BAMD_ENC_LAUNCH(ENC_ZSTD_HC); }
     else if (zstd && ztab) { if (zhuf) BAMD_ENC_LAUNCH(ENC_ZSTD_TH); else BAMD_ENC_LAUNCH(ENC_ZSTD_T); }
     else if (zstd) BAMD_ENC_LAUNCH(ENC_ZSTD);
+    else if (zlibc && zdyn) { if (zsearch) BAMD_ENC_LAUNCH(ENC_ZLIB_DYN_HC); else BAMD_ENC_LAUNCH(ENC_ZLIB_DYN); }
     else if (zlibc && zsearch) BAMD_ENC_LAUNCH(ENC_ZLIB_HC);
     else if (zlibc) BAMD_ENC_LAUNCH(ENC_ZLIB);
     else if (hc) BAMD_ENC_LAUNCH(ENC_HC);

@@ -56,8 +56,11 @@ namespace bamd {
 // a batch has ONE codec, so every kernel carries only its own code path
 // 5 = Zstd with per-block tables behind the LZ4HC-grade search, 6 = zlib behind the LZ4HC-grade search
 // 7 / 8 = 4 / 5 with Huffman-coded literals
-enum { ENC_LZ = 0, ENC_ZSTD = 1, ENC_ZLIB = 2, ENC_HC = 3, ENC_ZSTD_T = 4, ENC_ZSTD_HC = 5, ENC_ZLIB_HC = 6, ENC_ZSTD_TH = 7, ENC_ZSTD_HCH = 8 };
-constexpr bool enc_mode_hc(int mode) { return mode == ENC_HC || mode == ENC_ZSTD_HC || mode == ENC_ZLIB_HC || mode == ENC_ZSTD_HCH; }
+// 9 / 10 = zlib with dynamic Huffman codes (two passes), plain match finder / LZ4HC-grade search
+enum { ENC_LZ = 0, ENC_ZSTD = 1, ENC_ZLIB = 2, ENC_HC = 3, ENC_ZSTD_T = 4, ENC_ZSTD_HC = 5, ENC_ZLIB_HC = 6, ENC_ZSTD_TH = 7, ENC_ZSTD_HCH = 8,
+       ENC_ZLIB_DYN = 9, ENC_ZLIB_DYN_HC = 10 };
+constexpr bool enc_mode_hc(int mode) { return mode == ENC_HC || mode == ENC_ZSTD_HC || mode == ENC_ZLIB_HC || mode == ENC_ZSTD_HCH || mode == ENC_ZLIB_DYN_HC; }
+constexpr bool enc_mode_zlib(int mode) { return mode == ENC_ZLIB || mode == ENC_ZLIB_HC || mode == ENC_ZLIB_DYN || mode == ENC_ZLIB_DYN_HC; }
 constexpr bool enc_mode_zstd(int mode) { return mode == ENC_ZSTD || mode == ENC_ZSTD_T || mode == ENC_ZSTD_HC || mode == ENC_ZSTD_TH || mode == ENC_ZSTD_HCH; }
 template <int MODE>
 __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, enc_entry_t* tab, const ChunkDesc* chunks, uint32_t* blk_ready, int lane,
@@ -87,6 +90,8 @@ __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, enc_
   else if (MODE == ENC_ZSTD_HCH) r = seqbuf ? zstd_encode_wave<true, true, true>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, (BAMD_GAS uint64_t*)seqbuf, lane EPROF_PASS) : 0u;
   else if (MODE == ENC_ZSTD_TH) r = seqbuf ? zstd_encode_wave<true, false, true>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, (BAMD_GAS uint64_t*)seqbuf, lane EPROF_PASS) : 0u;
   else if (MODE == ENC_ZSTD_HC) r = seqbuf ? zstd_encode_wave<true, true>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, (BAMD_GAS uint64_t*)seqbuf, lane EPROF_PASS) : 0u;
+  else if (MODE == ENC_ZLIB_DYN) r = seqbuf ? zlib_dyn_encode_wave<false>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, (BAMD_GAS uint64_t*)seqbuf, lane EPROF_PASS) : 0u;
+  else if (MODE == ENC_ZLIB_DYN_HC) r = seqbuf ? zlib_dyn_encode_wave<true>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, (BAMD_GAS uint64_t*)seqbuf, lane EPROF_PASS) : 0u;
   else if (MODE == ENC_ZLIB_HC) r = zlib_encode_wave<true>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, lane EPROF_PASS);
   else if (MODE == ENC_ZSTD_T) r = seqbuf ? zstd_encode_wave<true>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, (BAMD_GAS uint64_t*)seqbuf, lane EPROF_PASS) : 0u;
   else if (MODE == ENC_ZLIB) r = zlib_encode_wave(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, lane EPROF_PASS);
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES, enc_mode_hc(MODE) ? 2 : ((MODE == E
     ) {
   constexpr bool ZSTD = enc_mode_zstd(MODE);
   constexpr int TABBYTES = enc_mode_hc(MODE) ? HC_TAB_BYTES : ENC_TAB_BYTES;      // the match finder's table; the writers' LDS sits behind it
-  __shared__ __attribute__((aligned(16))) enc_entry_t tabs[ENC_WAVES][(TABBYTES + (ZSTD ? ZS_LDS_BYTES : ((MODE == ENC_ZLIB || MODE == ENC_ZLIB_HC) ? DFL_LDS_BYTES : 0))) / 4];
+  __shared__ __attribute__((aligned(16))) enc_entry_t tabs[ENC_WAVES][(TABBYTES + (ZSTD ? ZS_LDS_BYTES : (enc_mode_zlib(MODE) ? DFL_LDS_BYTES : 0))) / 4];
   static_assert(ENC_WAVES == 1, "one stream per wave, one wave per workgroup");
   const int lane = threadIdx.x & 63;
   uint64_t* seqbuf = nullptr;
@@ -133,6 +138,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES, enc_mode_hc(MODE) ? 2 : ((MODE == E
     for (uint32_t k = (uint32_t)lane; k < sizeof(zenc::CTabs) / 4u; k += 64u) tabs[0][TABBYTES / 4 + k] = g[k];
     seqbuf = seqbufs + (size_t)blockIdx.x * ZS_SEQCAP;
   }
+  if (MODE == ENC_ZLIB_DYN || MODE == ENC_ZLIB_DYN_HC) seqbuf = seqbufs + (size_t)blockIdx.x * ZS_SEQCAP;      // the tokens of the first pass
   // HW_REG_XCC_ID[3:0]; queue 0 for everybody in the single-queue fallback (no in-kernel hand-offs there)
   const uint32_t xcc = single_queue ? 0u : (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);
   const uint32_t qbase = (uint32_t)qoff[xcc], qlen = (uint32_t)qoff[xcc + 1] - qbase;

@@ -120,3 +120,38 @@ def test_huffman_literals(pkg, oracle, ref):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def test_zlib_dynamic_huffman_codes(pkg, oracle, ref):
+    """BLOSC_AMD_ZLIB_DYNAMIC=1 (alone and with BLOSC_AMD_ZLIB_SEARCH=1): one final block with Huffman codes made for the stream
+    (DESIGN.md 3.8).  Stock zlib (the reference's uncompress), the oracle and our own decoder read every chunk."""
+    keys = ("BLOSC_AMD_ZLIB_DYNAMIC", "BLOSC_AMD_ZLIB_SEARCH")
+    old = {k: os.environ.get(k) for k in keys}
+    try:
+        for search in ("0", "1"):
+            for dname, T in [("bench19", 8), ("linspace", 8), ("smallints", 4), ("randwalk", 8), ("zeros", 8), ("random", 1)]:
+                for n in (129, 1000, 65536 + 17, 300001, 4 << 20):
+                    data = DATASETS[dname](n)
+                    os.environ["BLOSC_AMD_ZLIB_SEARCH"] = search
+                    os.environ["BLOSC_AMD_ZLIB_DYNAMIC"] = "0"
+                    rp, _ = pkg.compress(data, T, 5, 1, b"zlib", 0)
+                    os.environ["BLOSC_AMD_ZLIB_DYNAMIC"] = "1"
+                    r, chunk = pkg.compress(data, T, 5, 1, b"zlib", 0)
+                    assert 0 < r <= data.size + 16 and header(chunk)["cbytes"] == r
+                    r2, out = orc_decompress(oracle, chunk, data.size)
+                    assert r2 == data.size and np.array_equal(out, data)
+                    if ref is not None:
+                        r3, out3 = ref_decompress(ref, chunk, data.size)
+                        assert r3 == data.size and np.array_equal(out3, data)
+                    r4, out4 = pkg.decompress(chunk, data.size)
+                    assert r4 == data.size and np.array_equal(out4, data)
+                    if n == 4 << 20:
+                        rr = ref_compress(ref, data, T, 5, 1, b"zlib", nthreads=8)[0] if ref is not None else 0
+                        print(f"zlib clevel 5 {dname:9s} search={search}: dynamic codes {data.size / r:8.2f}   fixed codes {data.size / rp:8.2f}   reference {data.size / rr if rr else 0:8.2f}")
+                        assert r <= rp * 1.002
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v

@@ -18,7 +18,7 @@ from helpers import DATASETS, ptr
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-LZ4, BLOSCLZ, LZ4HC, ZSTD, ZLIB, ZSTD_TABLES, ZSTD_SEARCH, ZLIB_SEARCH, ZSTD_HUF, ZSTD_SEARCH_HUF = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+LZ4, BLOSCLZ, LZ4HC, ZSTD, ZLIB, ZSTD_TABLES, ZSTD_SEARCH, ZLIB_SEARCH, ZSTD_HUF, ZSTD_SEARCH_HUF, ZLIB_DYN, ZLIB_DYN_SEARCH = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 
 
 @pytest.fixture(scope="module")
@@ -206,7 +206,7 @@ def test_zstd_tables_made_for_the_block_pay(emu, oracle, ref):
         assert b <= a * want, (dname, a, b)
 
 
-@pytest.mark.parametrize("kind", [ZLIB, ZLIB_SEARCH], ids=["plain", "lz4hc-search"])
+@pytest.mark.parametrize("kind", [ZLIB, ZLIB_SEARCH, ZLIB_DYN, ZLIB_DYN_SEARCH], ids=["plain", "lz4hc-search", "dynamic-codes", "dynamic-codes+search"])
 def test_zlib_streams_decode(emu, oracle, ref, kind):
     import zlib
     cases = 0
@@ -249,3 +249,27 @@ def test_zstd_huffman_literals(emu, oracle, ref):
         _zstd_reads(oracle, ref, s, block)
         print(f"{dname}: raw literals {block.size / ra:.2f}, Huffman literals {block.size / rb:.2f}")
         assert rb <= ra * want
+
+
+def test_zlib_dynamic_codes_pay(emu):
+    """Streams with codes of their own against the fixed codes, on unsplit shuffled blocks (what blosc hands to zlib): never larger,
+    and clearly smaller where the symbols are unevenly used; python's zlib reads them."""
+    import zlib
+    for dname, T, want in (("linspace", 8, 0.93), ("smallints", 4, 0.90), ("randwalk", 8, 0.99), ("bench19", 8, 1.0)):
+        d = DATASETS[dname](65536)
+        block = np.ascontiguousarray(d.reshape(-1, T).T).reshape(-1)
+        ra, _ = _encode(emu, ZLIB, block, clevel=5)
+        rb, s = _encode(emu, ZLIB_DYN, block, clevel=5)
+        assert zlib.decompress(s.tobytes()) == block.tobytes()
+        print(f"{dname}: fixed codes {block.size / (ra or block.size):.2f}, dynamic codes {block.size / rb:.2f}")
+        assert rb <= (ra or block.size) * want, (dname, ra, rb)
+    # odd symbol statistics: one literal value, no match at all, one distance only, every length symbol
+    rng = np.random.default_rng(6)
+    odd = [np.zeros(5000, np.uint8), rng.integers(0, 256, 3000, dtype=np.uint8), np.tile(rng.integers(0, 256, 700, dtype=np.uint8), 30),
+           np.concatenate([np.tile(rng.integers(0, 256, int(k), dtype=np.uint8), 3) for k in range(3, 300)]),
+           rng.choice(3, 20000, p=[0.98, 0.01, 0.01]).astype(np.uint8), np.arange(70000, dtype=np.uint32).view(np.uint8)[:70000]]
+    for data in odd:
+        for kind in (ZLIB_DYN, ZLIB_DYN_SEARCH):
+            r, s = _encode(emu, kind, data, clevel=5)
+            if r:
+                assert zlib.decompress(s.tobytes()) == data.tobytes()

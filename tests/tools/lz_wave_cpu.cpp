@@ -22,7 +22,9 @@ void lane_body(int lane, void* arg) {
   Job* j = (Job*)arg;
   using namespace bamd;
   uint32_t r;
-  if (j->kind == 8) r = zstd_encode_wave<true, false, true>((const gu8*)j->src, (uint32_t)j->n, (gu8*)j->dst, (uint32_t)j->cap, j->clevel, j->tab, (BAMD_GAS uint64_t*)j->seqbuf, lane);
+  if (j->kind == 10) r = zlib_dyn_encode_wave<false>((const gu8*)j->src, (uint32_t)j->n, (gu8*)j->dst, (uint32_t)j->cap, j->clevel, j->tab, (BAMD_GAS uint64_t*)j->seqbuf, lane);
+  else if (j->kind == 11) r = zlib_dyn_encode_wave<true>((const gu8*)j->src, (uint32_t)j->n, (gu8*)j->dst, (uint32_t)j->cap, j->clevel, j->tab, (BAMD_GAS uint64_t*)j->seqbuf, lane);
+  else if (j->kind == 8) r = zstd_encode_wave<true, false, true>((const gu8*)j->src, (uint32_t)j->n, (gu8*)j->dst, (uint32_t)j->cap, j->clevel, j->tab, (BAMD_GAS uint64_t*)j->seqbuf, lane);
   else if (j->kind == 9) r = zstd_encode_wave<true, true, true>((const gu8*)j->src, (uint32_t)j->n, (gu8*)j->dst, (uint32_t)j->cap, j->clevel, j->tab, (BAMD_GAS uint64_t*)j->seqbuf, lane);
   else if (j->kind == 6) r = zstd_encode_wave<true, true>((const gu8*)j->src, (uint32_t)j->n, (gu8*)j->dst, (uint32_t)j->cap, j->clevel, j->tab, (BAMD_GAS uint64_t*)j->seqbuf, lane);
   else if (j->kind == 7) r = zlib_encode_wave<true>((const gu8*)j->src, (uint32_t)j->n, (gu8*)j->dst, (uint32_t)j->cap, j->clevel, j->tab, lane);
@@ -192,13 +194,15 @@ extern "C" int emu_lz_decode(int kind, const uint8_t* src, int n, uint8_t* dst, 
 }
 
 // kind: 0 = LZ4, 1 = BloscLZ, 2 = LZ4 with the LZ4HC-grade search, 3 = Zstd frame, 4 = zlib stream, 5 = Zstd frame with per-block sequence tables,
-// 6 = 5 behind the LZ4HC-grade search, 7 = zlib stream behind the LZ4HC-grade search, 8 / 9 = 5 / 6 with Huffman-coded literals.  Returns the stream
+// 6 = 5 behind the LZ4HC-grade search, 7 = zlib stream behind the LZ4HC-grade search, 8 / 9 = 5 / 6 with Huffman-coded literals,
+// 10 / 11 = zlib stream with dynamic Huffman codes (plain match finder / LZ4HC-grade search).  Returns the stream
 // size (0 = "store raw").
 extern "C" int emu_lz_encode(int kind, const uint8_t* src, int n, uint8_t* dst, int cap, int clevel, unsigned long long* rendezvous) {
   Job j = {kind, src, n, dst, cap, clevel, nullptr, 0, nullptr};
   // the wave's LDS: big enough for either table, 16-byte aligned, poisoned (the kernels clear what they use)
   j.tab = (uint32_t*)aligned_alloc(64, 64 * 1024);
   memset(j.tab, 0xA5, 64 * 1024);
+  if (kind == 10 || kind == 11) j.seqbuf = (uint64_t*)malloc(sizeof(uint64_t) * bamd::ZS_SEQCAP);
   if (kind == 3 || kind == 5 || kind == 6 || kind == 8 || kind == 9) {      // what k_encode_streams_t<ENC_ZSTD> sets up once per persistent wave: the predefined tables behind the hash table, the sequence scratch
     static bamd::zenc::CTabs predefined;
     bamd::zenc::build_predefined(predefined);
