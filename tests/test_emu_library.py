@@ -1,0 +1,130 @@
+"""CPU: the WHOLE library - host engine (tables, queues, staging, return codes) and every kernel - built for the host on top of the
+wavefront emulator and its HIP runtime stand-in (tests/tools/blosc_emu_lib.cpp: the same engine.hip / blosc_api.hip / k_*.hip sources,
+kernel launches run workgroup by workgroup as groups of fibers).  Test infrastructure, never shipped: the product has no CPU path.
+Chunk-level round trips through the stock C ABI for every codec and for every encoder option behind a switch - the options built after
+the round's GPU time was spent get their host wiring (kernel selection, scratch allocation) exercised here before their first device
+run.  Yardsticks: the oracle and, where oracle/_ref ships, the reference itself."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import DATASETS, header, orc_compress, orc_decompress, ptr, ref_compress, ref_decompress
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+@pytest.fixture(scope="module")
+def emulib():
+    if not os.path.exists(CLANG):
+        pytest.skip("needs the ROCm clang++")
+    csrc = os.path.join(ROOT, "c-blosc_amd", "csrc")
+    tools = os.path.join(ROOT, "tests", "tools")
+    so = os.path.join(tools, "libblosc_amd_emu.so")
+    deps = [os.path.join(tools, "blosc_emu_lib.cpp"), os.path.join(tools, "wave_emu", "wave_emu.h"), os.path.join(tools, "wave_emu", "hip_emu_runtime.h")]
+    deps += [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h"))]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call([CLANG, "-std=c++17", "-O1", "-shared", "-fPIC", "-w", "-I", os.path.join(tools, "wave_emu"), "-I", csrc,
+                               "-I", os.path.join(ROOT, "include"), "-x", "c++", deps[0], "-o", so, "-lpthread"])
+    L = C.CDLL(so)
+    sz, i, vp = C.c_size_t, C.c_int, C.c_void_p
+    L.blosc_compress_ctx.argtypes = [i, i, sz, sz, vp, vp, sz, C.c_char_p, sz, i]
+    L.blosc_decompress_ctx.argtypes = [vp, vp, sz, i]
+    L.blosc_getitem.argtypes = [vp, i, i, vp]
+    return L
+
+
+def _compress(L, data, T, clevel, shuffle, cname, blocksize=0):
+    data = np.ascontiguousarray(data)
+    out = np.full(data.size + 16 + 64, 0xEE, np.uint8)
+    r = L.blosc_compress_ctx(clevel, shuffle, T, data.size, ptr(data), ptr(out), data.size + 16, cname, blocksize, 1)
+    assert np.all(out[data.size + 16:] == 0xEE)
+    return r, out[:max(r, 0)].copy()
+
+
+def _decompress(L, chunk, n):
+    chunk = np.ascontiguousarray(chunk)
+    out = np.full(n + 64, 0xEE, np.uint8)
+    r = L.blosc_decompress_ctx(ptr(chunk), ptr(out), n, 1)
+    assert np.all(out[n:] == 0xEE)
+    return r, out[:n]
+
+
+def _everybody_reads(L, oracle, ref, chunk, data):
+    r, out = orc_decompress(oracle, chunk, data.size)
+    assert r == data.size and np.array_equal(out, data), "the oracle cannot read it"
+    if ref is not None:
+        r, out = ref_decompress(ref, chunk, data.size)
+        assert r == data.size and np.array_equal(out, data), "stock c-blosc cannot read it"
+    r, out = _decompress(L, chunk, data.size)
+    assert r == data.size and np.array_equal(out, data), "our own decoder cannot read it"
+
+
+@pytest.mark.parametrize("cname", [b"lz4", b"blosclz", b"lz4hc", b"zlib", b"zstd"])
+def test_round_trips_through_the_c_abi(emulib, oracle, ref, cname):
+    for dname, T, shuffle, n in [("bench19", 8, 1, 70000), ("linspace", 8, 1, 40001), ("smallints", 4, 2, 30000), ("randwalk", 8, 1, 20000),
+                                 ("zeros", 4, 1, 50000), ("random", 1, 0, 3000), ("bench19", 3, 1, 10000), ("arange", 4, 1, 129)]:
+        data = DATASETS[dname](n)
+        r, chunk = _compress(emulib, data, T, 5, shuffle, cname)
+        assert 0 < r <= n + 16 and header(chunk)["cbytes"] == r and header(chunk)["nbytes"] == n
+        _everybody_reads(emulib, oracle, ref, chunk, data)
+    # chunks written by the reference / the oracle come back bit-exactly, whole and in items
+    data = DATASETS["bench19"](60000)
+    if ref is not None:
+        r, stock = ref_compress(ref, data, 8, 5, 1, cname)
+    elif cname in (b"lz4", b"blosclz"):
+        r, stock = orc_compress(oracle, data, 8, 5, 1, cname.decode())
+    else:
+        return
+    r2, out = _decompress(emulib, stock, data.size)
+    assert r2 == data.size and np.array_equal(out, data)
+    item = np.zeros(8 * 100, np.uint8)
+    assert emulib.blosc_getitem(ptr(stock), 1000, 100, ptr(item)) == 800 and np.array_equal(item, data[8000:8800])
+
+
+SWITCHES = [
+    (b"zstd", {"BLOSC_AMD_ZSTD_TABLES": "1"}),
+    (b"zstd", {"BLOSC_AMD_ZSTD_TABLES": "1", "BLOSC_AMD_ZSTD_HUFFMAN": "1"}),
+    (b"zstd", {"BLOSC_AMD_ZSTD_SEARCH": "1"}),
+    (b"zstd", {"BLOSC_AMD_ZSTD_SEARCH": "1", "BLOSC_AMD_ZSTD_HUFFMAN": "1"}),
+    (b"zlib", {"BLOSC_AMD_ZLIB_SEARCH": "1"}),
+    (b"zlib", {"BLOSC_AMD_ZLIB_DYNAMIC": "1"}),
+    (b"zlib", {"BLOSC_AMD_ZLIB_DYNAMIC": "1", "BLOSC_AMD_ZLIB_SEARCH": "1"}),
+    (b"lz4hc", {"BLOSC_AMD_LZ4HC": "0"}),
+]
+
+
+@pytest.mark.parametrize("cname,env", SWITCHES, ids=["+".join(k[10:].lower() + "=" + v for k, v in e.items()) for _, e in SWITCHES])
+def test_encoder_options_behind_switches(emulib, oracle, ref, cname, env):
+    """Every switch selects its kernel (and the scratch that kernel needs) in the host engine, chunks stay readable by everybody, and the
+    option does what it is for: not larger than the plain path, and smaller where it should be."""
+    keys = ("BLOSC_AMD_ZSTD_TABLES", "BLOSC_AMD_ZSTD_HUFFMAN", "BLOSC_AMD_ZSTD_SEARCH", "BLOSC_AMD_ZLIB_SEARCH", "BLOSC_AMD_ZLIB_DYNAMIC", "BLOSC_AMD_LZ4HC")
+    old = {k: os.environ.get(k) for k in keys}
+    try:
+        tot_plain = tot_opt = 0
+        for dname, T, n in [("bench19", 8, 262144), ("linspace", 8, 65536), ("smallints", 4, 65536), ("randwalk", 8, 32768), ("zeros", 8, 20000)]:
+            data = DATASETS[dname](n)
+            for k in keys:
+                os.environ.pop(k, None)
+            if cname == b"lz4hc":
+                os.environ["BLOSC_AMD_LZ4HC"] = "1"
+            rp, _ = _compress(emulib, data, T, 5, 1, cname)
+            os.environ.update(env)
+            r, chunk = _compress(emulib, data, T, 5, 1, cname)
+            assert r > 0 and rp > 0
+            _everybody_reads(emulib, oracle, ref, chunk, data)
+            tot_plain += rp; tot_opt += r
+        print(f"{cname.decode()} {env}: {tot_plain} -> {tot_opt} bytes")
+        if cname == b"lz4hc":
+            assert tot_opt >= tot_plain                   # the switch turns the search OFF
+        else:
+            assert tot_opt < tot_plain
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v

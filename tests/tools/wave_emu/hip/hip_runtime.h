@@ -2,3 +2,6 @@
 // (tests/tools/wave_emu/wave_emu.h).  Test infrastructure only.
 #pragma once
 #include "../wave_emu.h"
+#ifdef WAVE_EMU_RUNTIME
+#include "../hip_emu_runtime.h"
+#endif

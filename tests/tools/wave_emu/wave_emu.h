@@ -42,27 +42,36 @@ struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c 
 namespace wave_emu {
 
 constexpr int LANES = 64;
+constexpr int MAXT = 1024;               // fibers of one workgroup (16 wavefronts)
 constexpr size_t STACK_BYTES = 256 * 1024;
 
+// One workgroup: `nthreads` fibers, wavefront w = fibers 64 w .. 64 w + 63.  Cross-lane operations meet inside a wavefront,
+// __syncthreads() across the workgroup.  (A single wavefront is the workgroup of 64.)
 struct Wave {
   ucontext_t sched;
-  ucontext_t ctx[LANES];
-  char* stack[LANES];
-  bool done[LANES];
-  int cur;
-  // rendezvous state, double buffered by the parity of the lane's operation counter
-  uint64_t val[2][LANES];
-  uint64_t stamp[2][LANES];
-  const char* site[2][LANES];
-  uint64_t opno[LANES];
+  ucontext_t ctx[MAXT];
+  char* stack[MAXT];
+  bool done[MAXT];
+  int cur;                                // fiber running now
+  int nthreads;
+  // rendezvous state, double buffered by the parity of the fiber's operation counter
+  uint64_t val[2][MAXT];
+  uint64_t stamp[2][MAXT];
+  const char* site[2][MAXT];
+  uint64_t opno[MAXT];
   void (*body)(int lane, void* arg);
   void* arg;
   uint64_t rendezvous;     // statistics
+  // __syncthreads
+  uint64_t bar_gen; int bar_arrived;
+  uint64_t spins;          // consecutive s_sleep yields without progress (a wait nobody will ever satisfy)
 };
 extern thread_local Wave* g_wave;
-extern thread_local dim3 g_block_idx, g_thread_base;
+extern thread_local dim3 g_block_idx, g_thread_base, g_block_dim, g_grid_dim;
 
-inline int lane() { return g_wave->cur; }
+inline int lane() { return g_wave->cur & (LANES - 1); }
+inline int wave_base() { return g_wave->cur & ~(LANES - 1); }
+inline int fiber() { return g_wave->cur; }
 
 [[noreturn]] inline void fail(const char* what, const char* where) {
   fprintf(stderr, "wave_emu: %s at %s (lane %d)\n", what, where ? where : "?", g_wave ? g_wave->cur : -1);
@@ -78,6 +87,7 @@ inline void yield_lane() {
 inline uint64_t deposit(uint64_t v, const char* where) {
   Wave* w = g_wave;
   const int l = w->cur;
+  w->spins = 0;
   const uint64_t k = ++w->opno[l];
   const int b = (int)(k & 1u);
   w->val[b][l] = v; w->stamp[b][l] = k; w->site[b][l] = where;
@@ -88,7 +98,7 @@ inline uint64_t deposit(uint64_t v, const char* where) {
 inline uint64_t fetch(uint64_t k, int from, const char* where) {
   Wave* w = g_wave;
   const int b = (int)(k & 1u);
-  from &= LANES - 1;
+  from = wave_base() + (from & (LANES - 1));
   if (w->stamp[b][from] == k && w->site[b][from] == where) return w->val[b][from];
   if (w->done[from]) return 0;                        // a lane that left before this operation: hardware returns the register's last content; 0 here
   if (w->stamp[b][from] != k || w->site[b][from] != where) fail("cross-lane operation in divergent control flow (source lane is elsewhere)", where);
@@ -97,7 +107,7 @@ inline uint64_t fetch(uint64_t k, int from, const char* where) {
 inline void check_all(uint64_t k, const char* where) {
   Wave* w = g_wave;
   const int b = (int)(k & 1u);
-  for (int l = 0; l < LANES; l++) if ((w->stamp[b][l] != k || w->site[b][l] != where) && !w->done[l]) fail("wave-wide operation in divergent control flow", where);
+  for (int l = wave_base(); l < wave_base() + LANES; l++) if ((w->stamp[b][l] != k || w->site[b][l] != where) && !w->done[l]) fail("wave-wide operation in divergent control flow", where);
 }
 
 inline uint32_t xlane(uint32_t v, int from, const char* where) { const uint64_t k = deposit(v, where); return (uint32_t)fetch(k, from, where); }
@@ -105,7 +115,7 @@ inline uint32_t readfirst(uint32_t v, const char* where) {
   const uint64_t k = deposit(v, where);
   Wave* w = g_wave;
   check_all(k, where);
-  for (int l = 0; l < LANES; l++) if (w->stamp[k & 1u][l] == k) return (uint32_t)w->val[k & 1u][l];
+  for (int l = wave_base(); l < wave_base() + LANES; l++) if (w->stamp[k & 1u][l] == k) return (uint32_t)w->val[k & 1u][l];
   return v;
 }
 inline uint64_t ballot(bool p, const char* where) {
@@ -113,7 +123,7 @@ inline uint64_t ballot(bool p, const char* where) {
   Wave* w = g_wave;
   check_all(k, where);
   uint64_t m = 0;
-  for (int l = 0; l < LANES; l++) if (w->stamp[k & 1u][l] == k && w->val[k & 1u][l]) m |= 1ull << l;
+  for (int l = 0; l < LANES; l++) if (w->stamp[k & 1u][wave_base() + l] == k && w->val[k & 1u][wave_base() + l]) m |= 1ull << l;
   return m;
 }
 inline uint32_t dpp(uint32_t old, uint32_t src, int ctrl, bool bound_ctrl, const char* where) {
@@ -133,6 +143,23 @@ inline uint32_t dpp(uint32_t old, uint32_t src, int ctrl, bool bound_ctrl, const
 }
 // explicit lock-step point for code that communicates through memory between cross-lane instructions
 inline void sync(const char* where = "sync") { const uint64_t k = deposit(0, where); check_all(k, where); }
+// __syncthreads(): every fiber of the workgroup that has not returned
+inline void syncthreads(const char* where) {
+  Wave* w = g_wave;
+  w->spins = 0;
+  int live = 0;
+  for (int t = 0; t < w->nthreads; t++) live += w->done[t] ? 0 : 1;
+  const uint64_t gen = w->bar_gen;
+  if (++w->bar_arrived >= live) { w->bar_arrived = 0; w->bar_gen++; return; }
+  while (w->bar_gen == gen) yield_lane();
+  (void)where;
+}
+// s_sleep inside a wait loop: let the others run; a wait that nothing in this (sequentially emulated) launch can satisfy is reported
+inline void sleep_yield(const char* where) {
+  Wave* w = g_wave;
+  if (++w->spins > 2000000ull) fail("waiting for something no running workgroup will ever produce", where);
+  yield_lane();
+}
 
 inline uint32_t perm(uint32_t a, uint32_t b, uint32_t sel) {     // v_perm_b32 D = perm({a, b}, sel): bytes 0-3 from b, 4-7 from a
   const uint64_t ab = ((uint64_t)a << 32) | b;
@@ -150,6 +177,7 @@ inline uint32_t perm(uint32_t a, uint32_t b, uint32_t sel) {     // v_perm_b32 D
 }
 
 void run(void (*body)(int lane, void* arg), void* arg);      // one wavefront: 64 lanes through `body`
+void run_group(int nthreads, void (*body)(int thread, void* arg), void* arg);   // one workgroup of `nthreads` (a multiple of 64 or less) fibers
 uint64_t last_rendezvous();
 
 }  // namespace wave_emu
@@ -171,16 +199,16 @@ uint64_t last_rendezvous();
 #define __builtin_amdgcn_mbcnt_lo(mask, add) ((uint32_t)(add) + (uint32_t)__builtin_popcount((uint32_t)(mask) & (wave_emu::lane() >= 32 ? 0xffffffffu : ((1u << wave_emu::lane()) - 1u))))
 #define __builtin_amdgcn_mbcnt_hi(mask, add) ((uint32_t)(add) + (uint32_t)__builtin_popcount((uint32_t)(mask) & (wave_emu::lane() < 32 ? 0u : ((1u << (wave_emu::lane() - 32)) - 1u))))
 #define __builtin_amdgcn_s_memtime() ((uint64_t)0)
-#define __builtin_amdgcn_s_sleep(n) (wave_emu::yield_lane())
+#define __builtin_amdgcn_s_sleep(n) (wave_emu::sleep_yield(WAVE_EMU_HERE))
 #define __builtin_amdgcn_s_waitcnt(n) ((void)0)
-#define __builtin_amdgcn_s_getreg(r) (0u)
+#define __builtin_amdgcn_s_getreg(r) (wave_emu::g_block_idx.x & 7u)     /* HW_REG_XCC_ID: workgroups are dealt round-robin to 8 XCDs */
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_nontemporal_load(p) (*(p))
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))
 #define BAMD_WAIT_STORES() ((void)0)
 #define BAMD_LDS_SYNC() (wave_emu::sync(WAVE_EMU_HERE))
 #define BAMD_MEM_SYNC() (wave_emu::sync(WAVE_EMU_HERE))
-#define __syncthreads() (wave_emu::fail("__syncthreads: only single-wave code runs here", WAVE_EMU_HERE))
+#define __syncthreads() (wave_emu::syncthreads(WAVE_EMU_HERE))
 #ifndef __HIP_MEMORY_SCOPE_WAVEFRONT
 #define __HIP_MEMORY_SCOPE_SINGLETHREAD 1
 #define __HIP_MEMORY_SCOPE_WAVEFRONT 2
@@ -196,13 +224,14 @@ template <typename T, typename V> static inline T atomicMin(T* p, V v) { T o = *
 
 #define threadIdx (wave_emu::thread_idx())
 #define blockIdx (wave_emu::g_block_idx)
-namespace wave_emu { inline dim3 thread_idx() { return dim3((unsigned)lane() + g_thread_base.x, 0, 0); } }
-static const dim3 blockDim(64, 1, 1), gridDim(1, 1, 1);
+namespace wave_emu { inline dim3 thread_idx() { return dim3((unsigned)fiber() + g_thread_base.x, 0, 0); } }
+#define blockDim (wave_emu::g_block_dim)
+#define gridDim (wave_emu::g_grid_dim)
 
 #ifdef WAVE_EMU_IMPLEMENTATION
 namespace wave_emu {
 thread_local Wave* g_wave = nullptr;
-thread_local dim3 g_block_idx(0, 0, 0), g_thread_base(0, 0, 0);
+thread_local dim3 g_block_idx(0, 0, 0), g_thread_base(0, 0, 0), g_block_dim(64, 1, 1), g_grid_dim(1, 1, 1);
 static thread_local uint64_t g_last_rendezvous = 0;
 uint64_t last_rendezvous() { return g_last_rendezvous; }
 
@@ -212,7 +241,7 @@ static void on_fault(int sig) {
   char buf[512];
   const char* where = "?";
   if (w) { const int l = w->cur; const uint64_t k = w->opno[l]; where = w->site[k & 1u][l] ? w->site[k & 1u][l] : "?"; }
-  const int n = snprintf(buf, sizeof buf, "wave_emu: signal %d in lane %d, last rendezvous at %s\n", sig, w ? w->cur : -1, where);
+  const int n = snprintf(buf, sizeof buf, "wave_emu: signal %d in fiber %d, last rendezvous at %s\n", sig, w ? w->cur : -1, where);
   if (n > 0) { ssize_t r = write(2, buf, (size_t)n); (void)r; }
   _exit(134);
 }
@@ -221,18 +250,28 @@ static void trampoline(unsigned lo, unsigned hi) {
   const int l = w->cur;
   w->body(l, w->arg);
   w->done[l] = true;
+  // a fiber that leaves while others wait at a barrier may be the one they were waiting for
+  int live = 0;
+  for (int t = 0; t < w->nthreads; t++) live += w->done[t] ? 0 : 1;
+  if (live > 0 && w->bar_arrived >= live) { w->bar_arrived = 0; w->bar_gen++; }
   swapcontext(&w->ctx[l], &w->sched);
 }
 
-void run(void (*body)(int lane, void* arg), void* arg) {
+static thread_local char* g_stack_pool[MAXT];
+
+void run_group(int nthreads, void (*body)(int thread, void* arg), void* arg) {
   static bool handlers = false;
   if (!handlers) { handlers = true; signal(SIGFPE, on_fault); signal(SIGSEGV, on_fault); signal(SIGBUS, on_fault); }
+  if (nthreads < 1 || nthreads > MAXT) { fprintf(stderr, "wave_emu: workgroup of %d threads\n", nthreads); abort(); }
   Wave* w = (Wave*)calloc(1, sizeof(Wave));
   Wave* outer = g_wave;
   g_wave = w;
-  w->body = body; w->arg = arg;
-  for (int l = 0; l < LANES; l++) {
-    w->stack[l] = (char*)malloc(STACK_BYTES);
+  w->body = body; w->arg = arg; w->nthreads = nthreads;
+  const int padded = (nthreads + LANES - 1) / LANES * LANES;
+  for (int l = nthreads; l < padded; l++) w->done[l] = true;        // the idle lanes of a partly filled last wavefront
+  for (int l = 0; l < nthreads; l++) {
+    if (!g_stack_pool[l]) g_stack_pool[l] = (char*)malloc(STACK_BYTES);
+    w->stack[l] = g_stack_pool[l];
     getcontext(&w->ctx[l]);
     w->ctx[l].uc_stack.ss_sp = w->stack[l];
     w->ctx[l].uc_stack.ss_size = STACK_BYTES;
@@ -241,7 +280,7 @@ void run(void (*body)(int lane, void* arg), void* arg) {
   }
   for (;;) {
     bool any = false;
-    for (int l = 0; l < LANES; l++) {
+    for (int l = 0; l < nthreads; l++) {
       if (w->done[l]) continue;
       any = true;
       w->cur = l;
@@ -250,9 +289,9 @@ void run(void (*body)(int lane, void* arg), void* arg) {
     if (!any) break;
   }
   g_last_rendezvous = w->rendezvous;
-  for (int l = 0; l < LANES; l++) free(w->stack[l]);
   free(w);
   g_wave = outer;
 }
+void run(void (*body)(int lane, void* arg), void* arg) { run_group(LANES, body, arg); }
 }  // namespace wave_emu
 #endif
