@@ -128,3 +128,36 @@ def test_encoder_options_behind_switches(emulib, oracle, ref, cname, env):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+@pytest.mark.parametrize("cname", ["lz4", "blosclz"])
+def test_damaged_chunks_get_the_references_verdict(emulib, oracle, cname):
+    """Headers, block offsets, split sizes and stream bytes of reference-written chunks flipped, cut and overwritten: the return code class
+    (negative / the size) and, when accepted, the bytes of blosc_decompress in the oracle (= the reference) - through the
+    host engine's own validation and the kernels' status words, not only through the stream decoders."""
+    rng = np.random.default_rng(17)
+    tried = rejected = 0
+    for dname, T, shuffle, n in [("bench19", 8, 1, 20000), ("smallints", 4, 1, 9000), ("randwalk", 8, 0, 5000), ("linspace", 4, 2, 12000)]:
+        data = DATASETS[dname](n)
+        r, chunk = orc_compress(oracle, data, T, 5, shuffle, cname, blocksize=int(rng.choice([0, 2048, 4096])))
+        assert r > 0
+        for trial in range(40):
+            t = chunk.copy()
+            mode = trial % 5
+            if mode == 0: t[int(rng.integers(0, 16))] ^= 1 << int(rng.integers(0, 8))                      # header
+            elif mode == 1: t[int(rng.integers(16, min(t.size, 80)))] ^= 1 << int(rng.integers(0, 8))      # bstarts / first split size
+            elif mode == 2: t[int(rng.integers(16, t.size))] = int(rng.integers(0, 256))                  # anywhere
+            elif mode == 3: t[int(rng.integers(16, t.size)):] = 0                                           # the tail wiped (the buffer keeps its size: blosc_decompress trusts cbytes)
+            else:
+                pos = int(rng.integers(16, t.size)); t[pos:pos + 6] = rng.integers(0, 256, min(6, t.size - pos), dtype=np.uint8)
+            if int(t[12:16].view("<i4")[0]) > t.size:
+                continue                      # cbytes now claims more than the buffer holds: blosc_decompress has no source size, reading it all is the caller's problem
+            ro, want = orc_decompress(oracle, t, n)
+            r, got = _decompress(emulib, t, n)
+            assert (ro < 0) == (r < 0) or (ro == r), (dname, cname, trial, mode, ro, r)
+            if ro == n and r == n and mode != 0:
+                # accepted by both: same bytes, unless the damage made an LZ4 offset 0 (content unspecified, lz4.c:2356)
+                if not np.array_equal(got, want):
+                    assert cname == "lz4", (dname, trial, mode)
+            tried += 1; rejected += ro < 0
+    assert tried > 100 and rejected > 20
