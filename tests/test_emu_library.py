@@ -161,3 +161,26 @@ def test_damaged_chunks_get_the_references_verdict(emulib, oracle, cname):
                     assert cname == "lz4", (dname, trial, mode)
             tried += 1; rejected += ro < 0
     assert tried > 100 and rejected > 20
+
+
+def test_sampled_parameter_grid(emulib, oracle, ref):
+    """A random sample of tests/test_gpu_compress.py's grid (typesize x size x data x shuffle x clevel x codec, leftovers and
+    typesizes that are not split included), sized for the emulator: headers as the reference writes them, chunks read by everybody."""
+    rng = np.random.default_rng(99)
+    for k in range(70):
+        cname = [b"lz4hc", b"lz4", b"blosclz", b"zstd", b"zlib"][k % 5]
+        T = int(rng.choice([1, 2, 3, 4, 7, 8, 16, 17, 32]))
+        n = int(rng.choice([128, 129, 1000, 4096, 32768, 65536 + 17, 100001]))
+        dname = str(rng.choice(["bench19", "randwalk", "zeros", "smallints"]))
+        shuffle = int(rng.choice([0, 1, 2])); clevel = int(rng.choice([1, 5, 9]))
+        if n > 40000 and cname in (b"zstd", b"zlib") and dname == "randwalk":
+            n = 32768                                     # (literal-heavy entropy coding is the slowest thing to emulate)
+        data = DATASETS[dname](n)
+        r, chunk = _compress(emulib, data, T, clevel, shuffle, cname)
+        assert 0 < r <= n + 16, (cname, T, n, dname, shuffle, clevel, r)
+        if ref is not None:
+            rr, stock = ref_compress(ref, data, T, clevel, shuffle, cname)
+            a, b = chunk[:12].copy(), stock[:12].copy()
+            a[2] &= 0xFD; b[2] &= 0xFD                     # MEMCPYED depends on how well each encoder did
+            assert np.array_equal(a, b), (cname, T, n, clevel, header(chunk), header(stock))
+        _everybody_reads(emulib, oracle, ref, chunk, data)
