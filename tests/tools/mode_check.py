@@ -1,6 +1,7 @@
 """Round trips under whatever BLOSC_AMD_* switches the environment carries (tests/test_gpu_modes.py runs this
 script once per combination: the switches are read once per process).  No torch: host buffers through the stock
-ABI.  Prints 'modes ok <n>' or raises."""
+ABI.  Prints 'modes ok <n>' or raises.  BLOSC_MODE_CHECK_SHRINK=k divides the input sizes by k (the emulated library of
+tests/tools/blosc_emu_lib.cpp runs the same combinations on the CPU, tests/test_emu_library.py)."""
 import ctypes as C
 import importlib.util
 import os
@@ -21,11 +22,13 @@ O.orc_compress.argtypes = [i, i, sz, sz, vp, vp, sz, i, sz, i]
 O.orc_decompress.argtypes = [vp, vp, sz]
 O.orc_lz4_compress.argtypes = [vp, i, vp, i, i]
 
+SHRINK = int(os.environ.get("BLOSC_MODE_CHECK_SHRINK", "1"))
 n_ok = 0
 for codec in ("lz4", "blosclz"):
     for dname, T, shuffle, n in [("bench19", 8, 1, (8 << 20) + 40), ("bench19", 4, 1, 3 << 20), ("linspace", 8, 1, 4 << 20),
                                  ("randwalk", 8, 1, 2 << 20), ("bench19", 4, 2, 2 << 20), ("zeros", 8, 1, 4 << 20),
                                  ("bench19", 2, 1, 1 << 20), ("smallints", 4, 0, 1 << 20)]:
+        n = max(n // SHRINK, 8192) + (n % 64)
         data = DATASETS[dname](n)
         ro, och = orc_compress(O, data, T, 5, shuffle, codec)
         r, out = pkg.decompress(och, n)
