@@ -209,3 +209,39 @@ def test_fallback_switches(emulib, flip):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "mode_check.py")], env=env, timeout=900,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert p.returncode == 0 and "modes ok" in p.stdout, (flip, p.stdout[-2000:], p.stderr[-3000:])
+
+
+# ---- the reference's OWN test programs (tests/ref_suite/_bin, built unmodified from /root/reference/tests where that exists) linked at
+#      run time against the emulated library: what tests/test_gpu_ref_suite.py does on the device, here for the programs that are quick
+#      enough at emulator speed ----
+@pytest.fixture(scope="module")
+def ref_programs(emulib, tmp_path_factory):
+    bindir = os.path.join(ROOT, "tests", "ref_suite", "_bin")
+    if not os.path.exists(os.path.join(bindir, "test_api")):
+        pytest.skip("tests/ref_suite/_bin is missing (built where /root/reference exists)")
+    libdir = tmp_path_factory.mktemp("libblosc_emu")
+    os.symlink(os.path.join(ROOT, "tests", "tools", "libblosc_amd_emu.so"), os.path.join(libdir, "libblosc.so.1"))   # the stock SONAME
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = f"{libdir}:" + env.get("LD_LIBRARY_PATH", "")
+    return bindir, env
+
+
+@pytest.mark.parametrize("prog", ["test_api", "test_maxout", "test_nthreads"])
+def test_reference_minunit_programs(ref_programs, prog):
+    bindir, env = ref_programs
+    p = subprocess.run([os.path.join(bindir, prog)], env=env, timeout=600, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, errors="replace")
+    assert p.returncode == 0 and "ALL TESTS PASSED" in p.stdout, (p.stdout[-1500:], p.stderr[-1500:])
+
+
+def test_reference_bitshuffle_leftovers_and_compat_vectors(ref_programs):
+    bindir, env = ref_programs
+    p = subprocess.run([os.path.join(bindir, "test_bitshuffle_leftovers")], env=env, timeout=600, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 0 and p.stdout.count("Successful roundtrip!") == 2, (p.stdout[-1500:], p.stderr[-1500:])
+    compat = os.path.join(ROOT, "tests", "golden", "compat")
+    names = sorted(f for f in os.listdir(compat) if f.endswith(".cdata"))
+    picked = [next(f for f in names if key in f) for key in ("blosclz", "lz4hc", "zlib", "zstd") if any(key in f for f in names)]
+    assert len(picked) >= 3
+    for f in picked:                                      # compat/filegen.c in decompress mode: 4 MB of arange(10^6, int32) per vector
+        p = subprocess.run([os.path.join(bindir, "filegen"), "decompress", os.path.join(compat, f)], env=env, timeout=900,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert p.returncode == 0 and "Decompression successful!" in p.stdout, (f, p.stdout[-500:], p.stderr[-1500:])
