@@ -91,7 +91,8 @@ __device__ __forceinline__ void zd_assign_codes(const uint32_t (&l)[PER], volati
 template <bool HC = false>
 __device__ uint32_t zlib_dyn_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8* __restrict__ dst, uint32_t cap, int clevel,
                                          enc_entry_t* tab_generic, BAMD_GAS uint64_t* seqbuf, int lane EPROF_ARG) {
-  if (n < 16u || cap < 64u || n >= (1u << 18)) return 0u;
+  if (n < 16u || cap < 64u) return 0u;
+  if (n > (1u << 18)) return zlib_encode_wave<HC, 1>(src, n, dst, cap, clevel, tab_generic, lane EPROF_PASS);   // the triples hold 18-bit lengths (blosc's zlib blocks are <= 256 KiB unless forced)
   // ---- pass 1: the tokens ----
   ZsSink zs;
   zs.lit = (gu8*)seqbuf + ZD_LITOFF; zs.nlit = 0; zs.litcap = ZD_LITCAP;

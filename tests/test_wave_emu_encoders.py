@@ -263,6 +263,11 @@ def test_zlib_dynamic_codes_pay(emu):
         assert zlib.decompress(s.tobytes()) == block.tobytes()
         print(f"{dname}: fixed codes {block.size / (ra or block.size):.2f}, dynamic codes {block.size / rb:.2f}")
         assert rb <= (ra or block.size) * want, (dname, ra, rb)
+    # exactly 256 KiB: blosc's zlib block size at clevel 5 for typesize 4 (the triples' 18-bit fields must hold it)
+    d = DATASETS["smallints"](262144)
+    block = np.ascontiguousarray(d.reshape(-1, 4).T).reshape(-1)
+    rb, s = _encode(emu, ZLIB_DYN, block, clevel=5)
+    assert 0 < rb < block.size * 0.6 and zlib.decompress(s.tobytes()) == block.tobytes()
     # odd symbol statistics: one literal value, no match at all, one distance only, every length symbol
     rng = np.random.default_rng(6)
     odd = [np.zeros(5000, np.uint8), rng.integers(0, 256, 3000, dtype=np.uint8), np.tile(rng.integers(0, 256, 700, dtype=np.uint8), 30),
