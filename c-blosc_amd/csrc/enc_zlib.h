@@ -49,7 +49,7 @@ __device__ uint32_t zlib_encode_wave(const gu8* __restrict__ src, uint32_t n, gu
 constexpr uint32_t ZD_LCNT = 0u, ZD_DCNT = 320u, ZD_LTAB = 384u, ZD_DTAB = 704u, ZD_LENS = 768u, ZD_CS = 848u, ZD_CCNT = 1008u, ZD_CTAB = 1040u,
                    ZD_STRIP = 1072u, ZD_END = ZD_STRIP + ZV_STRIP;                                  // dword offsets in the wave's scratch
 static_assert(ZD_END * 4u <= (uint32_t)ENC_TAB_BYTES, "scratch layout");
-constexpr uint32_t ZD_SEQCAP = 12288u, ZD_LITOFF = ZD_SEQCAP * 8u, ZD_LITCAP = ZS_SEQCAP * 8u - ZD_LITOFF;   // the sequence scratch: triples, then literals
+constexpr uint32_t ZD_SEQCAP = 32768u, ZD_LITOFF = ZD_SEQCAP * 8u, ZD_LITCAP = 256u * 1024u, ZD_SCRATCH_U64 = (ZD_LITOFF + ZD_LITCAP) / 8u;   // this mode's scratch per wave: 256 KiB of triples, then 256 KiB of literals
 
 struct ZdSink { gu8* out; uint32_t cap, pos, acc, nb; volatile BAMD_LAS uint32_t* strip; };
 // one field of up to 48 bits per lane, lane order = stream order

@@ -375,7 +375,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   const bool zdyn = zlibc && env_flag("BLOSC_AMD_ZLIB_DYNAMIC");      // zlib with dynamic Huffman codes: two passes, the tokens in the sequence scratch
   const size_t zwaves = (zstd || zdyn) ? (size_t)(st.cus > 0 ? st.cus : 256) * (size_t)enc_wpc : 0;
   const size_t o_ctabs = cv.take(sizeof(zenc::CTabs) + 64);
-  const size_t o_seqbufs = cv.take(zwaves * ZS_SEQCAP * sizeof(uint64_t) + 64);
+  const size_t o_seqbufs = cv.take(zwaves * (zdyn ? (size_t)ZD_SCRATCH_U64 : (size_t)ZS_SEQCAP) * sizeof(uint64_t) + 64);
   if (st.dev.ensure(cv.off)) return -1;
   uint8_t* D = st.dev.base;
   uint8_t *io_s = nullptr, *io_d = nullptr;

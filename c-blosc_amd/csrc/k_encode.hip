@@ -138,7 +138,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES, enc_mode_hc(MODE) ? 2 : ((MODE == E
     for (uint32_t k = (uint32_t)lane; k < sizeof(zenc::CTabs) / 4u; k += 64u) tabs[0][TABBYTES / 4 + k] = g[k];
     seqbuf = seqbufs + (size_t)blockIdx.x * ZS_SEQCAP;
   }
-  if (MODE == ENC_ZLIB_DYN || MODE == ENC_ZLIB_DYN_HC) seqbuf = seqbufs + (size_t)blockIdx.x * ZS_SEQCAP;      // the tokens of the first pass
+  if (MODE == ENC_ZLIB_DYN || MODE == ENC_ZLIB_DYN_HC) seqbuf = seqbufs + (size_t)blockIdx.x * ZD_SCRATCH_U64;   // the tokens of the first pass
   // HW_REG_XCC_ID[3:0]; queue 0 for everybody in the single-queue fallback (no in-kernel hand-offs there)
   const uint32_t xcc = single_queue ? 0u : (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);
   const uint32_t qbase = (uint32_t)qoff[xcc], qlen = (uint32_t)qoff[xcc + 1] - qbase;

@@ -202,7 +202,7 @@ extern "C" int emu_lz_encode(int kind, const uint8_t* src, int n, uint8_t* dst, 
   // the wave's LDS: big enough for either table, 16-byte aligned, poisoned (the kernels clear what they use)
   j.tab = (uint32_t*)aligned_alloc(64, 64 * 1024);
   memset(j.tab, 0xA5, 64 * 1024);
-  if (kind == 10 || kind == 11) j.seqbuf = (uint64_t*)malloc(sizeof(uint64_t) * bamd::ZS_SEQCAP);
+  if (kind == 10 || kind == 11) j.seqbuf = (uint64_t*)malloc(sizeof(uint64_t) * bamd::ZD_SCRATCH_U64);
   if (kind == 3 || kind == 5 || kind == 6 || kind == 8 || kind == 9) {      // what k_encode_streams_t<ENC_ZSTD> sets up once per persistent wave: the predefined tables behind the hash table, the sequence scratch
     static bamd::zenc::CTabs predefined;
     bamd::zenc::build_predefined(predefined);
