@@ -18,6 +18,7 @@ from helpers import DATASETS, ptr
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+FULL = os.environ.get("BLOSC_EMU_FULL") == "1"          # the default run is sized for a CPU suite of a few minutes; BLOSC_EMU_FULL=1 takes everything
 LZ4, BLOSCLZ, LZ4HC, ZSTD, ZLIB, ZSTD_TABLES, ZSTD_SEARCH, ZLIB_SEARCH, ZSTD_HUF, ZSTD_SEARCH_HUF, ZLIB_DYN, ZLIB_DYN_SEARCH = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 
 
@@ -90,15 +91,15 @@ def test_streams_decode_with_oracle_and_reference(emu, oracle, ref, kind):
     inputs.append(np.tile(rng.integers(0, 256, 300, dtype=np.uint8), 100))          # one long far-period match
     inputs.append(np.concatenate([rng.integers(0, 256, 70000, dtype=np.uint8)] * 2))   # a match beyond 64 KiB: must not be used (LZ4) / far (BloscLZ)
     inputs.append(np.concatenate([np.tile(rng.integers(0, 256, 40, dtype=np.uint8), 30), rng.integers(0, 256, 500, dtype=np.uint8)] * 8))
-    for data in inputs:
-        for clevel in ((9,) if kind == LZ4HC else (1, 5, 9)):
+    for data in (inputs if FULL else inputs[::2]):
+        for clevel in ((9,) if kind == LZ4HC else ((1, 5, 9) if FULL else (1, 9))):
             r, s = _encode(emu, kind, data, clevel=clevel)
             if r == 0:
                 continue                                              # "store raw": the caller copies the plane
             assert r < data.size
             _decodes(oracle, ref, kind, s, data)
             cases += 1
-    assert cases > (60 if kind == LZ4HC else 150)
+    assert cases > (60 if FULL else 25)
 
 
 @pytest.mark.parametrize("kind", [LZ4, LZ4HC], ids=["lz4", "lz4hc"])
@@ -174,14 +175,14 @@ def _entropy_inputs():
 def test_zstd_frames_decode_with_oracle_and_reference(emu, oracle, ref, kind):
     cases = 0
     inputs = _entropy_inputs()
-    for data in (inputs if kind == ZSTD_TABLES else inputs[::2]):
+    for data in (inputs if (kind == ZSTD_TABLES and FULL) else inputs[::2]):
         for clevel in ((1, 9) if kind == ZSTD else (3,)):
             r, s = _encode(emu, kind, data, clevel=clevel)
             if r:
                 assert r < data.size
                 _zstd_reads(oracle, ref, s, data)
                 cases += 1
-    assert cases > (20 if kind in (ZSTD, ZSTD_TABLES) else 8)
+    assert cases > 8
     # capacity: a complete frame inside what it was given, or 0
     data = _plane("bench19", 16384, 8, 1)
     full, _ = _encode(emu, kind, data, clevel=3)
@@ -210,13 +211,13 @@ def test_zstd_tables_made_for_the_block_pay(emu, oracle, ref):
 def test_zlib_streams_decode(emu, oracle, ref, kind):
     import zlib
     cases = 0
-    for data in _entropy_inputs():
-        for clevel in ((1, 5, 9) if kind == ZLIB else (5,)):
+    for data in (_entropy_inputs() if FULL else _entropy_inputs()[::2]):
+        for clevel in ((1, 5, 9) if (kind == ZLIB and FULL) else (5,)):
             r, s = _encode(emu, kind, data, clevel=clevel)
             if r:
                 assert zlib.decompress(s.tobytes()) == data.tobytes()
                 cases += 1
-    assert cases > (40 if kind == ZLIB else 12)
+    assert cases > 12
 
 
 def test_zstd_huffman_literals(emu, oracle, ref):
@@ -226,7 +227,7 @@ def test_zstd_huffman_literals(emu, oracle, ref):
     be smaller than with raw literals."""
     rng = np.random.default_rng(3)
     smaller = tried = 0
-    for trial in range(24):
+    for trial in range(16):
         n = int(rng.choice([255, 256, 300, 1000, 1023, 1024, 5000, 16383, 16384, 20000]))
         k = int(rng.choice([2, 3, 5, 16, 100, 129, 200, 256]))
         pr = np.random.default_rng(trial).dirichlet(np.ones(k) * rng.choice([0.02, 0.5, 5]))
@@ -240,7 +241,7 @@ def test_zstd_huffman_literals(emu, oracle, ref):
             tried += 1
             assert rb <= (ra or data.size)
             smaller += rb < (ra or data.size)
-    assert tried > 10 and smaller > 8
+    assert tried > 6 and smaller > 5
     for dname, T, want in (("smallints", 4, 0.90), ("randwalk", 8, 1.001)):
         d = DATASETS[dname](131072)
         block = np.ascontiguousarray(d.reshape(-1, T).T).reshape(-1)           # an unsplit shuffled block, as blosc hands it to Zstd
