@@ -366,6 +366,7 @@ __device__ __attribute__((noinline)) int zstd_decode_wave(const uint8_t* in, int
   if (has_checksum) {              // low 32 bits of XXH64 of the content (lane 0, serial: blosc itself never writes such frames)
     if (ip + 4 > n) return 0;
     uint32_t good = 0;
+    BAMD_MEM_SYNC();                  // lane 0 reads what all lanes have stored
     if (lane == 0) {
       const uint32_t want = (uint32_t)in[ip] | ((uint32_t)in[ip + 1] << 8) | ((uint32_t)in[ip + 2] << 16) | ((uint32_t)in[ip + 3] << 24);
       __builtin_amdgcn_s_waitcnt(0);
