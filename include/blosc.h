@@ -7,10 +7,9 @@
  * maintainer links an existing caller against this library instead of stock libblosc.
  *
  * Differences a caller can observe (all documented in DESIGN.md):
- *  - codecs: BloscLZ, LZ4 (and "lz4hc" as a higher-effort LZ4 encoder; its chunks carry the
- *    shared LZ4 format id, blosc.h:96) are implemented on the GPU; Zstd chunks are READ (decompress,
- *    getitem) but not written.  Snappy/Zlib - and "zstd" as a compressor - return -5 exactly like a
- *    stock build configured without them (blosc/blosc.c:525-574, :687-695).
+ *  - codecs: BloscLZ, LZ4, "lz4hc" (a higher-effort LZ4 encoder; its chunks carry the shared LZ4
+ *    format id, blosc.h:96), Zlib and Zstd are implemented on the GPU in both directions.  Snappy
+ *    returns -5 exactly like a stock build configured without it (blosc/blosc.c:525-574, :687-695).
  *  - compressed bytes differ from stock (different match finder, block-order layout) but are
  *    valid chunks: stock blosc_decompress() reads them, and this library reads stock chunks.
  *  - src/dest may be host pointers (stock behaviour; data crosses PCIe) or HIP device / managed

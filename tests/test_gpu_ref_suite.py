@@ -11,6 +11,7 @@ import glob
 import os
 import shutil
 import subprocess
+import tempfile
 
 import numpy as np
 import pytest
@@ -38,7 +39,8 @@ def env(tmp_path_factory):
 
 
 def run(env, args, timeout=600, cwd=None):
-    p = subprocess.run([os.path.join(BIN, args[0])] + list(args[1:]), env=env, cwd=cwd, timeout=timeout,
+    # never the repo root: some of the reference's programs (test_bitshuffle_leftovers.c:24,65) write files into their cwd
+    p = subprocess.run([os.path.join(BIN, args[0])] + list(args[1:]), env=env, cwd=cwd or tempfile.gettempdir(), timeout=timeout,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, errors="replace")
     return p.returncode, p.stdout, p.stderr
 
@@ -49,10 +51,10 @@ def test_minunit_program(env, prog):
     assert rc == 0 and "ALL TESTS PASSED" in out, (rc, out[-2000:], err[-2000:])
 
 
-def test_bitshuffle_leftovers(env):
+def test_bitshuffle_leftovers(env, tmp_path):
     """tests/test_bitshuffle_leftovers.c: 641091-byte buffers (not a multiple of 8 elements) through bitshuffle with
     both codecs; the program prints one 'Successful roundtrip!' per case and returns 0."""
-    rc, out, err = run(env, ["test_bitshuffle_leftovers"])
+    rc, out, err = run(env, ["test_bitshuffle_leftovers"], cwd=tmp_path)      # the program writes two .cdata files into its cwd
     assert rc == 0 and out.count("Successful roundtrip!") == 2 and "error" not in out.lower(), (rc, out[-2000:], err[-2000:])
 
 
