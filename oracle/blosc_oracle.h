@@ -48,6 +48,7 @@ int orc_blosclz_decompress(const uint8_t* src, int srclen, uint8_t* dst, int dst
 
 /* ---- Zstd frame decoder (oracle/zstd_oracle.c; zstd_wrap_decompress blosc/blosc.c:515-522): decoded size, 0 on error ---- */
 int orc_zstd_decompress(const void* src, int srcsize, void* dst, int dstcap);
+void orc_zstd_set_huf_lenient(int on);   /* test switch, see zstd_oracle.c */
 
 /* ---- zlib stream decoder (oracle/zlib_oracle.c; zlib_wrap_decompress blosc/blosc.c:484-495): decoded size, 0 on error ---- */
 int orc_zlib_decompress(const void* src, int srcsize, void* dst, int dstcap);
