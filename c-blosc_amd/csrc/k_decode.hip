@@ -402,6 +402,13 @@ __device__ __forceinline__ uint32_t lz4_batch_step(const Window& w, gu8* out, vo
   return cnt;
 }
 
+}  // namespace bamd
+#ifndef BAMD_DEC_BULK
+#define BAMD_DEC_BULK 1       // the pipelined steady-state loop of dec_bulk.h in front of the round-2 step
+#endif
+#include "dec_bulk.h"
+namespace bamd {
+
 // ---------------------------------------------------------------------------------------------
 // LZ4 block decode, one wave.  Returns bytes produced (== cap on success) or a negative number.
 // Acceptance rules are those of the reference's safe loop (lz4.c:2215-2435):
@@ -438,7 +445,17 @@ __device__ int lz4_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* out,
   Window w;
   w.init(in, n, lane);
   uint32_t ip = 0, op = 0;
+  uint32_t bulk_wait = 0, bulk_pen = 1;     // steps to leave to the code below after the bulk loop could not take a single one
   for (;;) {
+    if (BAMD_DEC_BULK) {
+      if (bulk_wait == 0u) {
+        const uint64_t r = lz4_bulk(in, n, out, cap, scr, ip, op, sp.hi, lane PROF_PASS);
+        const uint32_t ip_b = uni((uint32_t)r), op_b = uni((uint32_t)(r >> 32));
+        if (ip_b == ip) { bulk_wait = bulk_pen; bulk_pen = bulk_pen < 32u ? 2u * bulk_pen : 64u; }
+        else bulk_pen = 1u;
+        ip = ip_b; op = op_b;
+      } else bulk_wait--;
+    }
     w.seek(ip);
     uint32_t hdr = w.peek32(ip);
     if (ip + 72u <= n) {

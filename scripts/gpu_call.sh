@@ -37,11 +37,15 @@ for stage in "$@"; do
                   echo -n "WPC=$wpc SCHED=$sched  "; BLOSC_AMD_DEC_WPC=$wpc BLOSC_AMD_SCHED=$sched timeout 120 python scripts/dec_sweep.py 2>&1 | tail -1
                 done; done | tee gpurun_out/${TAG}_dec_sweep.txt ;;
     decphase)   timeout 120 python scripts/dec_phase.py 2>&1 | tee gpurun_out/${TAG}_dec_phase.txt | tail -30 ;;
-    dec)        # decode-only timing, library under test vs gpurun_tune_base.so when present
-                for d in ${DATA:-bench19 linspace walk}; do for lib in c-blosc_amd/libblosc_amd.so gpurun_tune_base.so; do
-                  [ -f $lib ] && { echo -n "$lib "; DATA=$d BLOSC_AMD_LIB=$PWD/$lib timeout 150 python scripts/dec_sweep.py 2>&1 | tail -1; }
-                done; done | tee -a gpurun_out/${TAG}_dec_ab.txt ;;
-    enc)        for d in ${DATA:-bench19 linspace walk}; do for lib in c-blosc_amd/libblosc_amd.so gpurun_tune_base.so; do
+    dec)        # decode-only timing of reference-written chunks: the library under test and every gpurun_tune_*.so next to it (same-session A/B)
+                for spec in ${DECSETS:-bench19:1:8 linspace:1:8 randwalk:1:8 bench19:2:4}; do
+                  IFS=: read d sh ts <<< "$spec"
+                  for lib in c-blosc_amd/libblosc_amd.so gpurun_tune_*.so; do
+                    [ -f $lib ] && { echo -n "$lib shuffle=$sh T=$ts "; DATA=$d SHUFFLE=$sh TYPESIZE=$ts BLOSC_AMD_LIB=$PWD/$lib timeout 150 python scripts/dec_sweep.py 2>&1 | tail -1; }
+                  done
+                done | tee -a gpurun_out/${TAG}_dec_ab.txt ;;
+    dectests)   timeout 900 python -m pytest tests/test_gpu_decompress.py tests/test_gpu_spans.py tests/test_gpu_baseline_geometry.py tests/test_gpu_getitem_batch.py -m gpu -x -q --no-header -p no:cacheprovider 2>&1 | tee gpurun_out/${TAG}_pytest_dec.log | tail -8 ;;
+    enc)        for d in ${DATA:-bench19 linspace randwalk}; do for lib in c-blosc_amd/libblosc_amd.so gpurun_tune_*.so; do
                   [ -f $lib ] && { echo -n "$lib "; DATA=$d BLOSC_AMD_LIB=$PWD/$lib timeout 150 python scripts/enc_sweep.py 2>&1 | tail -1; }
                 done; done | tee -a gpurun_out/${TAG}_enc_ab.txt ;;
     encopts)    # device timing of the encoder options built at the end of round 2 (formerly scripts/r03_call_a.sh)

@@ -342,3 +342,35 @@ def test_fused_block_decode(emu, oracle, codec, fmt, T):
             else: seen["plain"] += 1
     assert seen["raw"] and seen["small"] and seen["plain"], seen
     print(codec, T, seen)
+
+
+def test_bulk_loop_takes_reference_streams(emu, oracle, ref):
+    """dec_bulk.h: the pipelined steady-state loop must actually run (and be right) on what the benchmark decodes: byte planes of
+    bench19 as the reference's own LZ4 writes them (offsets of a few KiB, 13 sequences per 64 stream bytes), a ragged tail, a
+    stream that changes between plain steps and long matches, and output rooms too small for the stream."""
+    emu.emu_bulk_steps.restype = C.c_ulonglong
+    n = 32768
+    planes = DATASETS["bench19"](8 * n).reshape(-1, 8).T.copy()
+    before = emu.emu_bulk_steps()
+    seqs = 0
+    for j in (1, 2, 5):
+        for cut in (n, n - 1237):
+            data = planes[j][:cut].copy()
+            stream = _compress(oracle, LZ4, data)
+            if stream is None:
+                continue
+            r, got = _decode(emu, LZ4, stream, data.size)
+            assert r == data.size and np.array_equal(got, data), (j, cut)
+            for cap in (data.size - 1, data.size // 2, 40, 15):          # too small a room: the oracle's verdict, no byte outside
+                _same_as_oracle(emu, oracle, LZ4, stream, cap)
+            seqs += 1
+    steps = emu.emu_bulk_steps() - before
+    assert seqs >= 4 and steps >= 50 * seqs, (seqs, steps)
+    # damaged copies of one stream: verdict and bytes of the oracle
+    rng = np.random.default_rng(5)
+    stream = _compress(oracle, LZ4, planes[1])
+    for trial in range(60 if FULL else 25):
+        s = stream.copy()
+        for pos in rng.integers(0, s.size, 1 + trial % 3):
+            s[pos] ^= 1 << int(rng.integers(0, 8))
+        _same_as_oracle(emu, oracle, LZ4, s, n)

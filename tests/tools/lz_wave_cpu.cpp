@@ -193,6 +193,9 @@ extern "C" int emu_lz_decode(int kind, const uint8_t* src, int n, uint8_t* dst, 
   return j.result;
 }
 
+// steps taken by the pipelined steady-state loop of dec_bulk.h so far (the tests check that reference-written streams go through it)
+extern "C" unsigned long long emu_bulk_steps() { return bamd::g_emu_bulk_steps; }
+
 // kind: 0 = LZ4, 1 = BloscLZ, 2 = LZ4 with the LZ4HC-grade search, 3 = Zstd frame, 4 = zlib stream, 5 = Zstd frame with per-block sequence tables,
 // 6 = 5 behind the LZ4HC-grade search, 7 = zlib stream behind the LZ4HC-grade search, 8 / 9 = 5 / 6 with Huffman-coded literals,
 // 10 / 11 = zlib stream with dynamic Huffman codes (plain match finder / LZ4HC-grade search).  Returns the stream
