@@ -135,6 +135,34 @@ def _capture_stdout(fn):
         return tf.read().decode(errors="replace").strip()
 
 
+def _shuffle_accel_of_reference():
+    """what BLOSC_PRINT_SHUFFLE_ACCEL=1 makes the reference print on its first shuffle (shuffle.c:258-273), from a process of its own"""
+    import subprocess
+    code = ("import ctypes as C, numpy as np\n"
+            f"R = C.CDLL({REFSO!r})\n"
+            "R.blosc_compress_ctx.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int]\n"
+            "a = np.arange(1 << 16, dtype=np.uint8); d = np.empty(a.size + 16, np.uint8)\n"
+            "R.blosc_compress_ctx(5, 1, 8, a.size, a.ctypes.data, d.ctypes.data, d.size, b'lz4', 0, 1)\n"
+            "C.CDLL(None).fflush(None)\n")
+    try:
+        env = dict(os.environ, BLOSC_PRINT_SHUFFLE_ACCEL="1")
+        r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=120)
+        return r.stdout.decode(errors="replace").strip()
+    except Exception as e:      # the baseline is context, never a reason to lose the line
+        return f"(not captured: {e})"
+
+
+def _mem_available():
+    try:
+        with open("/proc/meminfo") as fh:
+            for ln in fh:
+                if ln.startswith("MemAvailable"):
+                    return int(ln.split()[1]) * 1024
+    except OSError:
+        pass
+    return 64 << 30
+
+
 def cpu_baseline(chunk_host, typesize, clevel, shuffle, cname, budget_s=20.0):
     """SURVEY §8d / BASELINE.md §4: nthreads = 1, a sweep up to nproc (cap 256, blosc.h:51) and — because one
     64 MiB chunk has only 64-128 blocks for the pool to share — `P` independent blosc_compress_ctx /
@@ -157,7 +185,9 @@ def cpu_baseline(chunk_host, typesize, clevel, shuffle, cname, budget_s=20.0):
         return {"value": n / (tc + td) / 1e9, "unit": "GB/s", "cores": 1, "kind": "port",
                 "compress_GBps": n / tc / 1e9, "decompress_GBps": n / td / 1e9, "ratio": n / r, **info,
                 "sample": f"one pass of one {n >> 20} MiB chunk through the scalar oracle port"}
-    os.environ["BLOSC_PRINT_SHUFFLE_ACCEL"] = "1"
+    # shuffle.c:258-273 prints the chosen implementation once, from the pthread_once that the FIRST call into the library
+    # triggers - and this process has already used the reference (stock chunks).  Ask a fresh process.
+    info["shuffle_accel"] = _shuffle_accel_of_reference()
     R = C.CDLL(REFSO)
     sz, i, vp = C.c_size_t, C.c_int, C.c_void_p
     R.blosc_compress_ctx.argtypes = [i, i, sz, sz, vp, vp, sz, C.c_char_p, sz, i]
@@ -173,8 +203,6 @@ def cpu_baseline(chunk_host, typesize, clevel, shuffle, cname, budget_s=20.0):
         r = R.blosc_decompress_ctx(dests[k % 4].ctypes.data, back.ctypes.data, n, nth)
         assert r == n
 
-    info["shuffle_accel"] = _capture_stdout(lambda: one_c(0, 1))
-    os.environ.pop("BLOSC_PRINT_SHUFFLE_ACCEL", None)
     for k in range(4):
         one_c(k, 1)
     one_d(0, 1)
@@ -204,7 +232,8 @@ def cpu_baseline(chunk_host, typesize, clevel, shuffle, cname, budget_s=20.0):
                      "roundtrip_GBps": n / (mc + md) / 1e9, "compress_best_GBps": n / bc_ / 1e9, "decompress_best_GBps": n / bd_ / 1e9,
                      "passes": [kc, kd]})
     # chunk-parallel arm: P threads, one chunk each, nthreads = 1 inside (ctypes releases the GIL)
-    P = min(ncores, 64)
+    # every hardware thread gets a chunk (cap: blosc's own 256, blosc.h:51, and a third of the free memory)
+    P = max(1, min(ncores, 256, int(_mem_available() // (3 * (n + 16))) or 1))
     pd = [np.empty(n + 16, np.uint8) for _ in range(P)]
     pb = [np.empty(n, np.uint8) for _ in range(P)]
     reps = 4
@@ -242,93 +271,36 @@ def cpu_baseline(chunk_host, typesize, clevel, shuffle, cname, budget_s=20.0):
                       f"from its own sources; mean over >= 3 passes per arm, about {budget_s:.0f} s in total"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="2", choices=sorted(CONFIGS))
-    ap.add_argument("--chunks", type=int, default=0, help="chunks per GPU (default 128; 512 when N > 1 = config #5's share)")
-    ap.add_argument("--chunk-mib", type=int, default=64)
-    ap.add_argument("--typesize", type=int, default=None)
-    ap.add_argument("--clevel", type=int, default=None)
-    ap.add_argument("--shuffle", type=int, default=None)
-    ap.add_argument("--codec", default=None)
-    ap.add_argument("--data", default=None)
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-verify", action="store_true")
-    ap.add_argument("--no-stock", action="store_true", help="skip the decompression of reference-written chunks")
-    args = ap.parse_args()
-    cfg = dict(CONFIGS[args.config])
-    os.environ.update(cfg.pop("env", {}))
-    for k in ("typesize", "clevel", "shuffle", "codec", "data"):
-        if getattr(args, k) is not None:
-            cfg[k] = getattr(args, k)
-    overridden = any(getattr(args, k) is not None for k in ("typesize", "clevel", "shuffle", "codec", "data"))
+class Rig:
+    """everything one process sets up once: torch / RCCL, the library, the rank's share of the chunk list"""
+    pass
 
-    import torch
-    import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    dev = torch.device(f"cuda:{local}")
-    # RCCL communicator also at N = 1 (size 1): the code path is the same for every N (SURVEY §8e).
-    # RCCL prints a version banner through C stdio when the communicator comes up; stdout is for the one JSON line, so
-    # fd 1 points at stderr until the first collective is through and C stdio is flushed.
-    libc = C.CDLL(None)
-    sys.stdout.flush()
-    saved_fd1 = os.dup(1)
-    os.dup2(2, 1)
-    try:
-        if world > 1:
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            rdv = tempfile.NamedTemporaryFile(prefix="bamd_rdv_", delete=False)
-            rdv.close()
-            os.unlink(rdv.name)
-            dist.init_process_group("nccl", init_method=f"file://{rdv.name}", rank=0, world_size=1, device_id=dev)
-        dist.barrier()
-        torch.cuda.synchronize()
-        libc.fflush(None)
-    finally:
-        os.dup2(saved_fd1, 1)
-        os.close(saved_fd1)
-    mod = load_pkg()
-    lib = mod.load()
-    mspec = importlib.util.spec_from_file_location("c_blosc_amd_multigpu", os.path.join(ROOT, "c-blosc_amd", "multigpu.py"))
-    multigpu = importlib.util.module_from_spec(mspec)
-    mspec.loader.exec_module(multigpu)
-    assert lib.blosc_gpu_set_device(local) == 0
+
+def measure(rig, name, cfg, steps, warmup, args, cold=False, mixed=None):
+    """One workload through the timed protocol of the contract: `warmup` untimed steps, then exactly `steps` steps between
+    barrier + synchronize pairs, MAX over ranks.  Returns the fields of the JSON line that belong to this workload."""
+    torch, dist, mod, lib, multigpu, dev = rig.torch, rig.dist, rig.mod, rig.lib, rig.multigpu, rig.dev
+    world, rank = rig.world, rig.rank
     cname = cfg["codec"].encode()
     T, clevel, shuffle = cfg["typesize"], cfg["clevel"], cfg["shuffle"]
     gpu_can_encode = lib.blosc_compname_to_compcode(cname) >= 0
-
-    per_gpu = args.chunks or (128 if world == 1 else 512)
-    nchunks_total = per_gpu * world
-    lo, hi = multigpu.chunk_range(nchunks_total, world, rank)
-    nchunks, csz = hi - lo, args.chunk_mib << 20
-    total = nchunks * csz
-    host_chunk = make_chunk(cfg["data"], csz)
-    d_chunk = torch.from_numpy(host_chunk).to(dev)
-    # distinct buffers per chunk (identical content, like bench.c's "i from 0 per chunk"): real HBM traffic
-    src = torch.empty((nchunks, csz), dtype=torch.uint8, device=dev)
-    src.copy_(d_chunk.unsqueeze(0).expand(nchunks, csz))
-    cstride = csz + 256
-    comp = torch.empty((nchunks, cstride), dtype=torch.uint8, device=dev)
-    back = torch.empty((nchunks, csz), dtype=torch.uint8, device=dev)
+    nchunks, csz, total = rig.nchunks, rig.csz, rig.nchunks * rig.csz
+    src, comp, back = rig.src, rig.comp, rig.back
+    datasets = mixed or [cfg["data"]]
+    hosts = [make_chunk(d, csz) for d in datasets]
+    for k, h in enumerate(hosts):                 # chunk i holds dataset i mod len(datasets): distinct buffers, real HBM traffic
+        d_chunk = torch.from_numpy(h).to(dev)
+        src[k::len(hosts)].copy_(d_chunk.unsqueeze(0).expand(len(range(k, nchunks, len(hosts))), csz))
+    host_chunk = hosts[0]
     stream = torch.cuda.current_stream().cuda_stream
-
     bc = mod.DeviceBatch([src[i].data_ptr() for i in range(nchunks)], [csz] * nchunks,
                          [comp[i].data_ptr() for i in range(nchunks)], [csz + 16] * nchunks)
     bd = mod.DeviceBatch([comp[i].data_ptr() for i in range(nchunks)], [csz + 16] * nchunks,
                          [back[i].data_ptr() for i in range(nchunks)], [csz] * nchunks)
 
-    # the reference's own chunk of this data (drop-in direction; the only source of chunks for a codec the GPU
-    # cannot encode yet)
+    # the reference's own chunk of this data (drop-in direction; the only source of chunks for a codec the GPU cannot encode)
     ref_chunk = None
-    if os.path.exists(REFSO) and not (args.no_stock and gpu_can_encode):
+    if os.path.exists(REFSO) and not mixed and not (args.no_stock and gpu_can_encode):
         R = C.CDLL(REFSO)
         R.blosc_compress_ctx.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int]
         tmp = np.empty(csz + 16, np.uint8)
@@ -354,8 +326,13 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    first_ms = None
+    for w in range(warmup):
+        if w == 0:
+            sync_all(); tf = time.perf_counter()
         step()
+        if w == 0:
+            torch.cuda.synchronize(); first_ms = (time.perf_counter() - tf) * 1e3
     cbytes = [ref_chunk.size] * nchunks if decode_only else bc.results()
     assert all(c > 0 for c in cbytes), cbytes[:4]
     assert bd.results() == [csz] * nchunks, bd.results()[:4]
@@ -364,7 +341,7 @@ def main():
     lib.blosc_gpu_profile_reset()
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     sync_all()
     elapsed = time.perf_counter() - t0
@@ -376,10 +353,10 @@ def main():
     # ---- consolidation: every rank learns the global cbytes table (RCCL all_gather, 4 bytes per chunk) ----
     torch.cuda.synchronize()
     tg = time.perf_counter()
-    table, offsets = multigpu.gather_cbytes(cbytes, nchunks_total, device=dev)
+    table, offsets = multigpu.gather_cbytes(cbytes, rig.nchunks_total, device=dev)
     torch.cuda.synchronize()
     consolidation_ms = (time.perf_counter() - tg) * 1e3
-    assert len(table) == nchunks_total and table[lo:hi] == list(cbytes)
+    assert len(table) == rig.nchunks_total and table[rig.lo:rig.hi] == list(cbytes)
     sum_cb_global = float(sum(table))
 
     prof = {}
@@ -422,7 +399,7 @@ def main():
         assert bd.decompress(stream) == 0     # warm
         lib.blosc_gpu_profile(1); lib.blosc_gpu_profile_reset()
         torch.cuda.synchronize(); ts = time.perf_counter()
-        reps = max(2, args.steps)
+        reps = max(2, steps)
         for _ in range(reps):
             assert bd.decompress(stream) == 0
         torch.cuda.synchronize(); te = time.perf_counter()
@@ -432,12 +409,12 @@ def main():
         kms = {k: mod.profile_get(k)[0] / max(mod.profile_get(k)[1], 1) for k in DECOMPRESS_KERNELS if mod.profile_get(k)[1]}
         tk = sum(kms.values()) / 1e3
         wall = (te - ts) / reps
+        kdom = max(kms, key=kms.get)
         stock = {"GBps_wall": total / wall / 1e9, "GBps_kernels": total / tk / 1e9, "ratio": csz / ref_chunk.size,
-                 "roofline_frac": (total + nchunks * ref_chunk.size) / tk / 1e9 / HBM_PEAK_GBPS, "kernels_ms": kms}
-
-    if rank != 0:
-        dist.destroy_process_group()
-        return
+                 "roofline_frac": (total + nchunks * ref_chunk.size) / tk / 1e9 / HBM_PEAK_GBPS, "kernels_ms": kms,
+                 "roofline": {"bound": "hbm", "kernel": kdom, "avg_launch_ms": kms[kdom], "algorithmic_bytes_per_launch": float(total + nchunks * ref_chunk.size),
+                              "achieved": (total + nchunks * ref_chunk.size) / (kms[kdom] / 1e3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                              "frac": (total + nchunks * ref_chunk.size) / (kms[kdom] / 1e3) / 1e9 / HBM_PEAK_GBPS}}
 
     # ---- roofline of the dominant kernel ----
     dom = max(prof, key=lambda k: prof[k]["ms_avg"])
@@ -446,24 +423,20 @@ def main():
     alg_bytes = 2.0 * total if filt_only else total + sum_cb
     ach = alg_bytes / (prof[dom]["ms_avg"] / 1e3) / 1e9
     roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": ach / HBM_PEAK_GBPS, "traffic": None if overridden else measured_traffic(dom, args.config, nchunks, args.chunk_mib),
+            "frac": ach / HBM_PEAK_GBPS, "traffic": None if (rig.overridden or mixed) else measured_traffic(dom, name, nchunks, args.chunk_mib),
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": prof[dom]["ms_avg"]}
     what = "decompress pass of reference-written chunks (the GPU does not encode this codec)" if decode_only else "compress pass + decompress pass"
-    out = {
-        "metric": "compress+decompress GB/s (uncompressed) at 1/2/4/8 GPUs vs HBM roofline; ratio",
-        "value": world * args.steps * total / elapsed / 1e9,
-        "unit": "GB/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u8", "data": "synthetic",
-        "config": {"workload": f"config #{args.config}: {FILTER_NAME[shuffle]} + {cfg['codec']} clevel={clevel} typesize={T}, "
-                               f"{nchunks} x {args.chunk_mib} MiB {cfg['data']} chunks per GPU ({total / 2**30:.0f} GiB), "
+    res = {
+        "value": world * steps * total / elapsed / 1e9, "unit": "GB/s", "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3,
+        "first_call_ms": first_ms,             # the first step of this workload in this process: cold queues (no cost feedback yet), arenas still growing
+        "config": {"workload": f"config #{name}: {FILTER_NAME[shuffle]} + {cfg['codec']} clevel={clevel} typesize={T}, "
+                               f"{nchunks} x {args.chunk_mib} MiB {'+'.join(datasets)} chunks per GPU ({total / 2**30:.0f} GiB), "
                                f"step = {what}, device-resident",
-                   "name": args.config, "codec": cfg["codec"], "shuffle": shuffle, "typesize": T, "clevel": clevel,
-                   "chunks_per_gpu": nchunks, "chunks_total": nchunks_total, "chunk_bytes": csz, "dataset": cfg["data"],
+                   "name": name, "codec": cfg["codec"], "shuffle": shuffle, "typesize": T, "clevel": clevel,
+                   "chunks_per_gpu": nchunks, "chunks_total": rig.nchunks_total, "chunk_bytes": csz, "dataset": "+".join(datasets),
                    "direction": "decompress" if decode_only else "compress+decompress"},
-        "ratio": nchunks_total * csz / sum_cb_global,
+        "ratio": rig.nchunks_total * csz / sum_cb_global,
         "decompress": {"GBps_kernels": total / t_d / 1e9, "roofline_frac_path": (total + sum_cb) / t_d / 1e9 / HBM_PEAK_GBPS},
         "decompress_stock_chunks": stock,
         "multi_gpu": {"partition": "contiguous chunk ranges, no data-path collective", "consolidation": "all_gather of the cbytes table, backend nccl (RCCL)",
@@ -474,11 +447,119 @@ def main():
         "verified": verified,
     }
     if not decode_only:
-        out["compress"] = {"GBps_kernels": total / t_c / 1e9, "roofline_frac_path": (total + sum_cb) / t_c / 1e9 / HBM_PEAK_GBPS}
+        res["compress"] = {"GBps_kernels": total / t_c / 1e9, "roofline_frac_path": (total + sum_cb) / t_c / 1e9 / HBM_PEAK_GBPS}
+    res["_host_chunk"] = host_chunk
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="2", choices=sorted(CONFIGS))
+    ap.add_argument("--chunks", type=int, default=0, help="chunks per GPU (default 128; 512 when N > 1 = config #5's share)")
+    ap.add_argument("--chunk-mib", type=int, default=64)
+    ap.add_argument("--typesize", type=int, default=None)
+    ap.add_argument("--clevel", type=int, default=None)
+    ap.add_argument("--shuffle", type=int, default=None)
+    ap.add_argument("--codec", default=None)
+    ap.add_argument("--data", default=None)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-stock", action="store_true", help="skip the decompression of reference-written chunks")
+    ap.add_argument("--no-extra", action="store_true", help="default config only: skip the short legs for configs #3 / #4 and the mixed batch")
+    args = ap.parse_args()
+    cfg = dict(CONFIGS[args.config])
+    os.environ.update(cfg.pop("env", {}))
+    for k in ("typesize", "clevel", "shuffle", "codec", "data"):
+        if getattr(args, k) is not None:
+            cfg[k] = getattr(args, k)
+    overridden = any(getattr(args, k) is not None for k in ("typesize", "clevel", "shuffle", "codec", "data"))
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+    # RCCL communicator also at N = 1 (size 1): the code path is the same for every N (SURVEY §8e).
+    # RCCL prints a version banner through C stdio when the communicator comes up; stdout is for the one JSON line, so
+    # fd 1 points at stderr until the first collective is through and C stdio is flushed.
+    libc = C.CDLL(None)
+    sys.stdout.flush()
+    saved_fd1 = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        if world > 1:
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            rdv = tempfile.NamedTemporaryFile(prefix="bamd_rdv_", delete=False)
+            rdv.close()
+            os.unlink(rdv.name)
+            dist.init_process_group("nccl", init_method=f"file://{rdv.name}", rank=0, world_size=1, device_id=dev)
+        dist.barrier()
+        torch.cuda.synchronize()
+        libc.fflush(None)
+    finally:
+        os.dup2(saved_fd1, 1)
+        os.close(saved_fd1)
+    rig = Rig()
+    rig.torch, rig.dist, rig.dev, rig.world, rig.rank, rig.overridden = torch, dist, dev, world, rank, overridden
+    rig.mod = load_pkg()
+    rig.lib = rig.mod.load()
+    mspec = importlib.util.spec_from_file_location("c_blosc_amd_multigpu", os.path.join(ROOT, "c-blosc_amd", "multigpu.py"))
+    rig.multigpu = importlib.util.module_from_spec(mspec)
+    mspec.loader.exec_module(rig.multigpu)
+    assert rig.lib.blosc_gpu_set_device(local) == 0
+
+    per_gpu = args.chunks or (128 if world == 1 else 512)
+    rig.nchunks_total = per_gpu * world
+    rig.lo, rig.hi = rig.multigpu.chunk_range(rig.nchunks_total, world, rank)
+    rig.nchunks, rig.csz = rig.hi - rig.lo, args.chunk_mib << 20
+    rig.src = torch.empty((rig.nchunks, rig.csz), dtype=torch.uint8, device=dev)
+    rig.comp = torch.empty((rig.nchunks, rig.csz + 256), dtype=torch.uint8, device=dev)
+    rig.back = torch.empty((rig.nchunks, rig.csz), dtype=torch.uint8, device=dev)
+
+    res = measure(rig, args.config, cfg, args.steps, args.warmup, args)
+    host_chunk = res.pop("_host_chunk")
+    # ---- the other BASELINE.json configurations and a batch of mixed data, as short legs of the default run:
+    #      each with its own roofline object (dominant kernel, algorithmic bytes, average launch) and its ratio next to stock's ----
+    extra = None
+    mixed = None
+    if args.config == "2" and not overridden and not args.no_extra and world == 1:
+        extra = {}
+        for name in ("3", "4"):
+            r = measure(rig, name, dict(CONFIGS[name]), min(args.steps, 5), 1, args)
+            r.pop("_host_chunk")
+            keep = ("value", "unit", "steps", "ms_per_step", "first_call_ms", "ratio", "roofline", "kernels", "decompress_stock_chunks", "verified", "compress", "decompress")
+            extra[name] = {k: r[k] for k in keep if k in r}
+            extra[name]["workload"] = r["config"]["workload"]
+        m = measure(rig, "2", cfg, min(args.steps, 5), 1, args, mixed=["bench19", "linspace", "randwalk", "random"])
+        m.pop("_host_chunk")
+        mixed = {k: m[k] for k in ("value", "unit", "steps", "ms_per_step", "first_call_ms", "ratio", "kernels", "verified")}
+        mixed["workload"] = m["config"]["workload"]
+    if rank != 0:
+        dist.destroy_process_group()
+        return
+    out = {
+        "metric": "compress+decompress GB/s (uncompressed) at 1/2/4/8 GPUs vs HBM roofline; ratio",
+        "value": res.pop("value"), "unit": res.pop("unit"),
+        "n_gpus": world, "steps": res.pop("steps"), "warmup": res.pop("warmup"),
+        "ms_per_step": res.pop("ms_per_step"),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+    }
+    out.update(res)
+    if extra is not None:
+        out["extra_configs"] = extra
+        out["mixed_batch"] = mixed
     if not args.no_cpu_baseline and world == 1:      # the host-core baseline is a 1-GPU artefact (rank 0, N = 1)
-        out["cpu_baseline"] = cpu_baseline(host_chunk, T, clevel, shuffle, cname, args.cpu_seconds)
+        out["cpu_baseline"] = cpu_baseline(host_chunk, cfg["typesize"], cfg["clevel"], cfg["shuffle"], cfg["codec"].encode(), args.cpu_seconds)
     print(json.dumps(out))
-    lib.blosc_init(); lib.blosc_destroy()          # releases the arenas (and prints the BLOSC_AMD_HOSTTIME summary when that switch is on)
+    rig.lib.blosc_init(); rig.lib.blosc_destroy()          # releases the arenas (and prints the BLOSC_AMD_HOSTTIME summary when that switch is on)
     dist.destroy_process_group()
 
 

@@ -263,31 +263,32 @@ __device__ __forceinline__ bool bulk_half(BulkState& st, const BulkStep& cur, Bu
   return took;
 }
 
-// Runs steps from (ip, op) while they are plain; returns ip | op << 32 behind the last step it took (unchanged: none taken).
-// A real call: the caller (decode_one_stream with everything inlined) sits at its register limit, and a reload of a spilled
-// register inside this loop is a vector memory operation that every exact vmcnt below would have to wait behind.
-// LDS: scr[0..64) for the literal scatter as in lz4_batch_step; the input ring lives in the first 512 bytes of the step buffer
-// behind it (lz4_step_lds is never active at the same time: a step that wants it ends this loop).
-__device__ __attribute__((noinline)) uint64_t lz4_bulk(const gu8* in_, uint32_t n_, gu8* out_, uint32_t cap_, volatile uint32_t* scr_generic,
-                                                       uint32_t ip_, uint32_t op_, uint32_t span_hi_, int lane PROF_ARG) {
+// Runs steps from (ip, op) while they are plain; returns the number of steps taken, ip / op behind the last one.
+// The caller's register window (wave_prims.h: Window, sought to ip: ip - w.base < 256) IS the ring's first two blocks on the way
+// in, and is re-made from the ring on the way out: entering and leaving cost LDS traffic, no memory round trip.  (The first
+// version filled the ring with two loads of its own and let the caller re-seek afterwards; with a real call around it that was
+// three serialised round trips per visit - 40 000 cycles - and streams that alternate between a plain step and a long match got
+// slower than without the loop: profiles/r03b_dec_phase_bulk_v1.txt.)
+// LDS: scr[0..64) for the literal scatter as in lz4_batch_step; the ring lives in the first 512 bytes of the step buffer behind it
+// (lz4_step_lds is never active at the same time: a step that wants it ends this loop).
+__device__ __forceinline__ uint32_t lz4_bulk(Window& w, uint32_t n_, gu8* out_, uint32_t cap_, volatile uint32_t* scr_generic,
+                                            uint32_t& ip_, uint32_t& op_, uint32_t span_hi_, int lane PROF_ARG) {
   volatile __attribute__((address_space(3))) uint32_t* scr = (volatile __attribute__((address_space(3))) uint32_t*)scr_generic;
   lds_vu32* ring32 = (lds_vu32*)(scr + 64);
   const lds_vu8* ring = (const lds_vu8*)(scr + 64);
-  // everything that steers the loop lives in SGPRs (arguments of a real call count as divergent)
-  const gu8* in = uni_ptr(in_);
+  // everything that steers the loop lives in SGPRs
+  const gu8* in = uni_ptr(w.in);
   gu8* out = uni_ptr(out_);
   const uint32_t n = uni(n_), cap = uni(cap_), span_hi = uni(span_hi_);
   BulkState st;
   st.ip = uni(ip_); st.op = uni(op_);
-  if (st.ip + 72u > n || cap < 16u) return (uint64_t)st.ip | ((uint64_t)st.op << 32);
-  // ---- fill the ring: blocks 0 and 1 from wb = ip ----
-  st.wb = st.ip;
-  {
-    const uint32_t b0 = bulk_block_load(in, n, st.wb, 0u, lane), b1 = bulk_block_load(in, n, st.wb, 1u, lane);
-    bulk_block_store(ring32, 0u, b0, lane); bulk_block_store(ring32, 1u, b1, lane);
-  }
+  if (st.ip + 72u > n || cap < 16u) return 0u;
+  const uint32_t ip0 = st.ip;
+  // ---- the ring takes over the window: blocks 0 and 1 at wb = w.base ----
+  st.wb = uni(w.base);
+  bulk_block_store(ring32, 0u, w.lo, lane); bulk_block_store(ring32, 1u, w.hi, lane);
   st.hi_blk = 1u; st.pend = false; st.wpend_blk = 0u;
-  uint32_t wa = 0u, wb_ = 0u;            // the two block registers: an iteration loads one and stores the other (no copies, see bulk_iter)
+  uint32_t wa = 0u, wb_ = 0u;            // the two block registers: a half loads one and stores the other (no copies, see bulk_half)
   BAMD_LDS_SYNC();
   // Two step records used alternately.  The loop is entered with an EMPTY current step, so that each record's loads are
   // issued at exactly one place in the code (a first step parsed and loaded in front of the loop gave the piece registers two
@@ -297,16 +298,33 @@ __device__ __attribute__((noinline)) uint64_t lz4_bulk(const gu8* in_, uint32_t 
   b.v16 = make_uint4(0u, 0u, 0u, 0u); b.v8 = 0u; b.v4 = 0u;
   a = b;
   st.ip1 = st.ip; st.op1 = st.op;
+  uint32_t steps = 0, nrest = 0;
   bool go;
   do {
     const bool t1 = bulk_half(st, b, a, wb_, wa, in, n, out, cap, span_hi, scr, ring32, ring, lane PROF_PASS);      // stores b, parses a
     const bool t2 = bulk_half(st, a, b, wa, wb_, in, n, out, cap, span_hi, scr, ring32, ring, lane PROF_PASS);      // stores a, parses b
+    steps += (t1 ? 1u : 0u) + (t2 ? 1u : 0u);
+    nrest += (a.restmask ? 1u : 0u) + (b.restmask ? 1u : 0u);
     go = t1 && t2;
   } while (go);
   // b is empty here: if a was not taken, the same step was offered to b and refused for the same reason
   if (b.cnt) bulk_execute(b, out, scr, st.op, lane);
+  // ---- hand the window back: the ring's blocks j, j + 1 around the position reached ----
+  if (st.pend) { bulk_block_store(ring32, st.wpend_blk, wa, lane); }       // the block the last half loaded
+  BAMD_LDS_SYNC();
+  {
+    const uint32_t j = (st.ip1 - st.wb) >> 8;                               // hi_blk - 1 or hi_blk (bulk_half keeps ip + 131 covered)
+    w.base = st.wb + 256u * j;
+    w.lo = ring32[64u * (j & 1u) + (uint32_t)lane];
+    if (j < st.hi_blk) w.hi = ring32[64u * ((j + 1u) & 1u) + (uint32_t)lane];
+    else w.hi = w.fetch(w.base + 256u);
+  }
+  ip_ = st.ip1; op_ = st.op1;
+  (void)ip0;
   PROF_LAP(10);
-  return (uint64_t)st.ip1 | ((uint64_t)st.op1 << 32);
+  // bit 31: most steps had matches to run in stream order (long ones, or chains through the step's own output) - those wait for
+  // everything in flight, the pipeline buys nothing there and the caller should stay with the round-2 step for a while
+  return steps | ((2u * nrest > steps) ? 0x80000000u : 0u);
 }
 
 }  // namespace bamd

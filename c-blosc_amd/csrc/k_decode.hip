@@ -127,17 +127,38 @@ __device__ __forceinline__ uint32_t hop(uint32_t table, uint32_t x) {
 struct SpanCtx { uint32_t enabled, lo, hi, off; gu8* pat; };
 constexpr uint32_t SPAN_PAT = 2048u;
 
-__device__ __forceinline__ void span_materialize(gu8* out, int lane, SpanCtx& sp) {
+__device__ __attribute__((noinline)) void span_materialize(gu8* out_, int lane, SpanCtx& sp) {
+  gu8* out = uni_ptr(out_);
   if (sp.hi) wave_match_copy(out, sp.lo, sp.off, sp.hi - sp.lo, lane);   // out[lo - off, lo) was written by the head copy
   sp.lo = 0; sp.hi = 0; sp.enabled = 0;
 }
 // returns true when the match was handled here (head, pattern table and tail written, middle skipped)
-__device__ __forceinline__ bool span_long_match(gu8* out, uint32_t mpos, uint32_t off, uint32_t ml, int lane, SpanCtx& sp) {
-  if (!sp.enabled || sp.hi || ml < 16384u || off > SPAN_PAT || (off & (off - 1u))) return false;
+//
+// Round 3: periods ABOVE the pattern table's 2 KiB (any power of two up to 64 KiB).  Byte planes of slowly varying data repeat
+// with the period of the generator (bench19's second byte: 32 KiB; a third of the plane is content, the rest ONE match - which
+// round 2 wrote to the scratch, 95 KiB, only to read it back twice).  Such a span needs no table: the plane itself holds the
+// period, in the `off` bytes in front of the skipped range.  With ob = the 4-aligned position at or behind mpos - off,
+//     plane[q] = plane[ob + ((q - ob) & (off - 1))]     for q in [lo, hi)
+// (every step back by `off` stays inside the match), and a dword at a 4-aligned q never straddles the wrap.
+// The unshuffle computes that address per lane (SPAN_SELF); ob and off travel in the first 8 bytes of the stream's table slot.
+__device__ __attribute__((noinline)) bool span_long_match(gu8* out_, uint32_t mpos_, uint32_t off_, uint32_t ml_, int lane, SpanCtx& sp) {
+  // (a real call, made a few times per stream at most: arguments are wave-uniform, say so)
+  gu8* out = uni_ptr(out_);
+  const uint32_t mpos = uni(mpos_), off = uni(off_), ml = uni(ml_);
+  if (!sp.enabled || sp.hi || ml < 16384u || off > 65536u || (off & (off - 1u))) return false;
   const uint32_t lo = (mpos + 1023u) & ~1023u, hi = (mpos + ml) & ~1023u;
   if (hi < lo + 8192u) return false;
   if (lo > mpos) wave_match_copy(out, mpos, off, lo - mpos, lane);
   BAMD_MEM_SYNC();
+  if (off > SPAN_PAT) {
+    const uint32_t ob = (mpos - off + 3u) & ~3u, om = off - 1u;
+    if (lane == 0) { g_st4(sp.pat, ob); g_st4(sp.pat + 4, off); }
+    // behind the span: < 1 KiB, byte by byte through the same mapping (the sources lie in front of lo: written, not overwritten here)
+    const uint32_t tail = mpos + ml - hi;
+    for (uint32_t i = (uint32_t)lane; i < tail; i += 64u) out[hi + i] = out[ob + ((hi + i - ob) & om)];     // (once per plane: no need to batch the loads)
+    sp.lo = lo; sp.hi = hi; sp.off = off;
+    return true;
+  }
   const uint32_t base = mpos - off, pm = off - 1u;         // plane[q] = out[base + ((q - base) & pm)] for q >= base
   uint32_t v[8];
 #pragma unroll
@@ -445,17 +466,8 @@ __device__ int lz4_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* out,
   Window w;
   w.init(in, n, lane);
   uint32_t ip = 0, op = 0;
-  uint32_t bulk_wait = 0, bulk_pen = 1;     // steps to leave to the code below after the bulk loop could not take a single one
+  uint32_t bulk_wait = 0, bulk_pen = 4;     // steps to leave to the round-2 code after a visit of the bulk loop that took (almost) nothing
   for (;;) {
-    if (BAMD_DEC_BULK) {
-      if (bulk_wait == 0u) {
-        const uint64_t r = lz4_bulk(in, n, out, cap, scr, ip, op, sp.hi, lane PROF_PASS);
-        const uint32_t ip_b = uni((uint32_t)r), op_b = uni((uint32_t)(r >> 32));
-        if (ip_b == ip) { bulk_wait = bulk_pen; bulk_pen = bulk_pen < 32u ? 2u * bulk_pen : 64u; }
-        else bulk_pen = 1u;
-        ip = ip_b; op = op_b;
-      } else bulk_wait--;
-    }
     w.seek(ip);
     uint32_t hdr = w.peek32(ip);
     if (ip + 72u <= n) {
@@ -465,6 +477,17 @@ __device__ int lz4_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* out,
       uint32_t ll1 = tk >> 4, tpos = ip + 1u;
       if (ll1 == 15u) { const uint32_t e = (hdr >> 8) & 0xffu; try_batch = e != 255u && 17u + e + 3u <= 64u; ll1 = 15u + e; tpos++; }
       if (try_batch && (tk & 15u) == 15u) try_batch = (w.peek32(tpos + ll1 + 2u) & 0xffu) != 255u;
+      if (BAMD_DEC_BULK && try_batch) {
+        if (bulk_wait == 0u) {
+          const uint32_t rb = lz4_bulk(w, n, out, cap, scr, ip, op, sp.hi, lane PROF_PASS);
+          const uint32_t steps = rb & 0x7fffffffu;
+          // a visit that took nothing (typically: the stream's steps want the LDS-assembled form) or hardly anything, or whose
+          // steps were mostly in-order copies: leave the next steps to the code below, four times as many after every such visit
+          if (steps <= 1u || (rb >> 31)) { bulk_wait = bulk_pen; bulk_pen = bulk_pen < 64u ? 4u * bulk_pen : 256u; }
+          else if (steps >= 4u) bulk_pen = 4u;
+          if (steps) continue;
+        } else bulk_wait--;
+      }
       if (try_batch && lz4_batch_step(w, out, scr, ip, op, cap, n, lane, sp PROF_PASS)) continue;
     }
     PROF_ADD(3, 1);
@@ -789,21 +812,27 @@ __device__ __forceinline__ void unshuffle_store(gu8* dst, uint32_t e, int lane, 
 // Flag bit 1, `raw`: the split was stored raw (blosc/blosc.c:773-776) and has NOT been copied to the scratch: the plane is
 // read where it lies in the chunk (raw[j], any byte alignment).  Noisy float64 data stores 3 of 4 planes raw: the copy
 // was a read and a write of the plane for nothing.
-constexpr uint32_t SPAN_SMALL = 1u, SPAN_RAW = 2u;
+// Flag bit 2, `self`: a period above the table's 2 KiB (span_long_match): the skipped positions are read from the plane's own bytes
+// in front of the span, at ob + ((q - ob) & (off - 1)) per lane; ob and off are the first two words of the stream's table slot.
+constexpr uint32_t SPAN_SMALL = 1u, SPAN_RAW = 2u, SPAN_SELF = 4u;
 template <int T>
 __device__ void unshuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize, int lane, const uint32_t* spans, const gu8* pat, const StreamDesc* sds) {
   const uint32_t N = bsize / T;
-  uint32_t lo[T], hi[T], pr[T];
+  uint32_t lo[T], hi[T], pr[T], ob[T];                   // ob: a self span's base | log2(period) << 24
   const gu8* pl[T];                                      // where plane j lies: the scratch, or the chunk itself (raw)
-  uint32_t small = 0;                                    // wave-uniform plane mask
+  uint32_t small = 0, self = 0;                          // wave-uniform plane masks
 #pragma unroll
   for (int j = 0; j < T; j++) {
     const uint32_t w = spans ? uni(spans[2 * j]) : 0u;
     lo[j] = w & ~1023u; hi[j] = spans ? uni(spans[2 * j + 1]) : 0u;
-    pr[j] = 0u;
+    pr[j] = 0u; ob[j] = 0u;
     pl[j] = src + (size_t)j * N;
     if (w & SPAN_RAW) { pl[j] = uni_ptr(as_global(sds[j].in)); hi[j] = 0u; }
     else if ((w & SPAN_SMALL) && hi[j] > lo[j]) { small |= 1u << j; pr[j] = g_ld4(pat + (size_t)j * SPAN_PAT + 4u * (uint32_t)lane); }
+    else if ((w & SPAN_SELF) && hi[j] > lo[j]) {
+      self |= 1u << j;
+      ob[j] = uni(g_ld4(pat + (size_t)j * SPAN_PAT)) | ((31u - (uint32_t)__builtin_clz(uni(g_ld4(pat + (size_t)j * SPAN_PAT + 4)))) << 24);
+    }
   }
   // the register rows are in before the loop: otherwise the compiler, which cannot tell whether they are still in flight,
   // waits for vmcnt(0) at the top of EVERY iteration - i.e. for the previous iteration's stores
@@ -819,7 +848,12 @@ __device__ void unshuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize,
       const bool in_span = e >= lo[j] && e < hi[j];            // wave-uniform
       const bool reg = in_span && ((small >> j) & 1u);
       if (reg) { a.r[j] = b.r[j] = c.r[j] = d.r[j] = pr[j]; }   // scalar branch: no load at all
-      else {
+      else if (in_span && ((self >> j) & 1u)) {                 // the plane's own period in front of the span, address per lane
+        const uint32_t o = ob[j] & 0xffffffu, m = (1u << (ob[j] >> 24)) - 1u;
+        const uint32_t q = e + l4 - o;
+        a.r[j] = ld4_plane(pl[j] + o + (q & m)); b.r[j] = ld4_plane(pl[j] + o + ((q + 256u) & m));
+        c.r[j] = ld4_plane(pl[j] + o + ((q + 512u) & m)); d.r[j] = ld4_plane(pl[j] + o + ((q + 768u) & m));
+      } else {
         const gu8* p = in_span ? pat + (size_t)j * SPAN_PAT + (e & (SPAN_PAT - 1u)) : pl[j] + e;
         a.r[j] = ld4_plane(p + l4); b.r[j] = ld4_plane(p + l4 + 256u); c.r[j] = ld4_plane(p + l4 + 512u); d.r[j] = ld4_plane(p + l4 + 768u);
       }
@@ -906,7 +940,7 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
   // ---- fused unshuffle: the wave that completes a block's LAST stream transposes the block ----
   if (!(mode & CH_FUSED_UNSHUF) || got != want) return;
   if (spans && lane == 0) {
-    spans[2 * (size_t)sid] = raw_in_place ? SPAN_RAW : (sp.lo | ((sp.hi && sp.off <= 256u) ? SPAN_SMALL : 0u));
+    spans[2 * (size_t)sid] = raw_in_place ? SPAN_RAW : (sp.lo | ((sp.hi && sp.off <= 256u) ? SPAN_SMALL : 0u) | ((sp.hi && sp.off > SPAN_PAT) ? SPAN_SELF : 0u));
     spans[2 * (size_t)sid + 1] = sp.hi;
   }
   // All streams of one block are handed out from the SAME per-XCD queue (see k_decode_streams), so the

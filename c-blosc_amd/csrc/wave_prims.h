@@ -106,6 +106,17 @@ __device__ __forceinline__ void wave_match_copy(gu8* out, uint32_t pos, uint32_t
     // `done` may not be a multiple of G when head was cut; any multiple of `off` <= off+done is valid
     // only if the copied prefix really is periodic up to `done`, which it is.  Restart from G.
   }
+  if (done == 0u && off >= 64u && off <= 1024u && (off & (off - 1u)) == 0u && len >= 2048u) {
+    // The period divides 1024: every 1 KiB row of the match is the same, and lane l's 16 bytes of it lie at
+    // pos - off + (16 l mod off) - in front of the match, so ONE load serves all rows (round 3: byte planes of a few significant
+    // bits decode into dozens of 4 KiB runs of period 128, each of which took five dependent round trips to get going)
+    const uint4 row = ld16u(out + pos - off + ((16u * (uint32_t)lane) & (off - 1u)));
+    while (len - done >= 1024u) { st16u(out + pos + done + 16 * lane, row); done += 1024u; }
+    const uint32_t n16 = (len - done) >> 4;
+    if ((uint32_t)lane < n16) st16u(out + pos + done + 16 * lane, row);
+    done += n16 << 4;
+    // (fewer than 16 bytes are left to the loop below)
+  }
   while (done < len) {
     BAMD_MEM_SYNC();
     uint32_t rem = len - done;

@@ -44,6 +44,8 @@ for stage in "$@"; do
                     [ -f $lib ] && { echo -n "$lib shuffle=$sh T=$ts "; DATA=$d SHUFFLE=$sh TYPESIZE=$ts BLOSC_AMD_LIB=$PWD/$lib timeout 150 python scripts/dec_sweep.py 2>&1 | tail -1; }
                   done
                 done | tee -a gpurun_out/${TAG}_dec_ab.txt ;;
+    decab)      # the same in ONE process, the builds taking turns on the same buffers (scripts/dec_ab.py): process-to-process differences cancel
+                DECSETS="${DECSETS:-bench19:1:8 linspace:1:8 randwalk:1:8 bench19:2:4}" timeout 600 python scripts/dec_ab.py c-blosc_amd/libblosc_amd.so gpurun_tune_*.so 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/${TAG}_dec_ab1.txt ;;
     dectests)   timeout 900 python -m pytest tests/test_gpu_decompress.py tests/test_gpu_spans.py tests/test_gpu_baseline_geometry.py tests/test_gpu_getitem_batch.py -m gpu -x -q --no-header -p no:cacheprovider 2>&1 | tee gpurun_out/${TAG}_pytest_dec.log | tail -8 ;;
     enc)        for d in ${DATA:-bench19 linspace randwalk}; do for lib in c-blosc_amd/libblosc_amd.so gpurun_tune_*.so; do
                   [ -f $lib ] && { echo -n "$lib "; DATA=$d BLOSC_AMD_LIB=$PWD/$lib timeout 150 python scripts/enc_sweep.py 2>&1 | tail -1; }

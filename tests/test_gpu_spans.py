@@ -51,7 +51,7 @@ FOLLOW = {
 }
 
 
-@pytest.mark.parametrize("period", [1, 2, 4, 8, 64, 256, 1024, 2048, 3, 100, 4096])
+@pytest.mark.parametrize("period", [1, 2, 4, 8, 64, 256, 1024, 2048, 3, 100, 4096, 8192, 32768, 12288])
 @pytest.mark.parametrize("follow", list(FOLLOW))
 def test_span_streams(pkg, oracle, period, follow):
     rng = np.random.default_rng(period * 131 + len(follow))

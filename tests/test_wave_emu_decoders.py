@@ -307,12 +307,21 @@ def test_fused_block_decode(emu, oracle, codec, fmt, T):
     rng = np.random.default_rng(30 + T)
     ne = 65536                                                     # bytes per plane: long enough for spans (>= 16 KiB matches)
     bsize = ne * T
-    seen = {"span": 0, "small": 0, "raw": 0, "plain": 0}
-    for trial in range(6 if FULL else 3):
+    seen = {"span": 0, "small": 0, "raw": 0, "plain": 0, "self": 0}
+    for trial in range(8 if FULL else 4):
         planes = []
         for j in range(T):
-            kind = (trial + j) % 6
-            if kind == 0: planes.append(np.zeros(ne, np.uint8))                                              # constant: period 1
+            kind = (trial + j) % 8
+            if kind == 6:                                                                                    # period above the pattern table: SPAN_SELF, odd start
+                per = int(rng.choice([4096, 8192, 16384])); lead = int(rng.integers(0, 9))
+                a = np.concatenate([rng.integers(0, 256, lead, dtype=np.uint8), np.resize(rng.integers(0, 256, per, dtype=np.uint8), ne)])[:ne].copy()
+                if j % 2 == 0: a[ne - 700:] = a[per + 100:per + 800]                                       # ... and a match reaching back into the span
+                planes.append(a)
+            elif kind == 7:                                                                                  # runs of period 128 with breaks (the one-load row fill of wave_match_copy)
+                a = np.resize(rng.integers(0, 8, 128, dtype=np.uint8), ne).copy()
+                for k in range(3000, ne - 200, 4100): a[k:k + 5] = rng.integers(8, 16, 5, dtype=np.uint8); a[k + 5:] = np.resize(np.roll(a[k - 123:k + 5], int(rng.integers(0, 128))), ne - k - 5)
+                planes.append(a)
+            elif kind == 0: planes.append(np.zeros(ne, np.uint8))                                              # constant: period 1
             elif kind == 1: planes.append(np.resize(rng.integers(0, 256, int(rng.choice([2, 4, 64, 256])), dtype=np.uint8), ne))
             elif kind == 2: planes.append(np.resize(rng.integers(0, 256, int(rng.choice([512, 1024, 2048])), dtype=np.uint8), ne))   # pattern-table span
             elif kind == 3: planes.append(rng.integers(0, 256, ne, dtype=np.uint8))                          # incompressible: stored raw
@@ -337,10 +346,11 @@ def test_fused_block_decode(emu, oracle, codec, fmt, T):
         for j in range(T):
             w, hi = spans[2 * j], spans[2 * j + 1]
             if w & 2: seen["raw"] += 1
+            elif hi and (w & 4): seen["self"] += 1
             elif hi and (w & 1): seen["small"] += 1
             elif hi: seen["span"] += 1
             else: seen["plain"] += 1
-    assert seen["raw"] and seen["small"] and seen["plain"], seen
+    assert seen["raw"] and seen["small"] and seen["plain"] and (seen["self"] or codec != "lz4"), seen      # (BloscLZ's encoder cuts those planes into shorter matches)
     print(codec, T, seen)
 
 
