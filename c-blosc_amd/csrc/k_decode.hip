@@ -127,9 +127,13 @@ __device__ __forceinline__ uint32_t hop(uint32_t table, uint32_t x) {
 struct SpanCtx { uint32_t enabled, lo, hi, off; gu8* pat; };
 constexpr uint32_t SPAN_PAT = 2048u;
 
-__device__ __attribute__((noinline)) void span_materialize(gu8* out_, int lane, SpanCtx& sp) {
-  gu8* out = uni_ptr(out_);
-  if (sp.hi) wave_match_copy(out, sp.lo, sp.off, sp.hi - sp.lo, lane);   // out[lo - off, lo) was written by the head copy
+// (real calls, made a few times per stream at most, with plain arguments: the helpers' registers must not count against the hot
+//  loops of the caller, and a SpanCtx handed over by reference would live in memory - its `hi` is tested in every step)
+__device__ __attribute__((noinline)) void span_fill_call(gu8* out_, uint32_t lo_, uint32_t off_, uint32_t n_, int lane) {
+  wave_match_copy(uni_ptr(out_), uni(lo_), uni(off_), uni(n_), lane);      // out[lo - off, lo) was written by the head copy
+}
+__device__ __forceinline__ void span_materialize(gu8* out, int lane, SpanCtx& sp) {
+  if (sp.hi) span_fill_call(out, sp.lo, sp.off, sp.hi - sp.lo, lane);
   sp.lo = 0; sp.hi = 0; sp.enabled = 0;
 }
 // returns true when the match was handled here (head, pattern table and tail written, middle skipped)
@@ -141,13 +145,12 @@ __device__ __attribute__((noinline)) void span_materialize(gu8* out_, int lane, 
 //     plane[q] = plane[ob + ((q - ob) & (off - 1))]     for q in [lo, hi)
 // (every step back by `off` stays inside the match), and a dword at a 4-aligned q never straddles the wrap.
 // The unshuffle computes that address per lane (SPAN_SELF); ob and off travel in the first 8 bytes of the stream's table slot.
-__device__ __attribute__((noinline)) bool span_long_match(gu8* out_, uint32_t mpos_, uint32_t off_, uint32_t ml_, int lane, SpanCtx& sp) {
-  // (a real call, made a few times per stream at most: arguments are wave-uniform, say so)
+__device__ __attribute__((noinline)) void span_long_match_call(gu8* out_, uint32_t mpos_, uint32_t off_, uint32_t ml_, int lane, gu8* pat_) {
   gu8* out = uni_ptr(out_);
   const uint32_t mpos = uni(mpos_), off = uni(off_), ml = uni(ml_);
-  if (!sp.enabled || sp.hi || ml < 16384u || off > 65536u || (off & (off - 1u))) return false;
+  struct { gu8* pat; uint32_t lo, hi, off; } sp;         // (locals with the old names)
+  sp.pat = uni_ptr(pat_);
   const uint32_t lo = (mpos + 1023u) & ~1023u, hi = (mpos + ml) & ~1023u;
-  if (hi < lo + 8192u) return false;
   if (lo > mpos) wave_match_copy(out, mpos, off, lo - mpos, lane);
   BAMD_MEM_SYNC();
   if (off > SPAN_PAT) {
@@ -156,8 +159,7 @@ __device__ __attribute__((noinline)) bool span_long_match(gu8* out_, uint32_t mp
     // behind the span: < 1 KiB, byte by byte through the same mapping (the sources lie in front of lo: written, not overwritten here)
     const uint32_t tail = mpos + ml - hi;
     for (uint32_t i = (uint32_t)lane; i < tail; i += 64u) out[hi + i] = out[ob + ((hi + i - ob) & om)];     // (once per plane: no need to batch the loads)
-    sp.lo = lo; sp.hi = hi; sp.off = off;
-    return true;
+    return;
   }
   const uint32_t base = mpos - off, pm = off - 1u;         // plane[q] = out[base + ((q - base) & pm)] for q >= base
   uint32_t v[8];
@@ -173,6 +175,15 @@ __device__ __attribute__((noinline)) bool span_long_match(gu8* out_, uint32_t mp
   BAMD_MEM_SYNC();
   // behind the span: < 1 KiB, contiguous in the table just written (hi is a multiple of 1024, so no wrap)
   wave_copy_disjoint(out + hi, sp.pat + (hi & (SPAN_PAT - 1u)), mpos + ml - hi, lane);
+}
+__device__ __forceinline__ bool span_long_match(gu8* out, uint32_t mpos, uint32_t off, uint32_t ml, int lane, SpanCtx& sp) {
+#ifndef BAMD_SELFSPAN
+#define BAMD_SELFSPAN 1
+#endif
+  if (!sp.enabled || sp.hi || ml < 16384u || off > (BAMD_SELFSPAN ? 65536u : SPAN_PAT) || (off & (off - 1u))) return false;
+  const uint32_t lo = (mpos + 1023u) & ~1023u, hi = (mpos + ml) & ~1023u;
+  if (hi < lo + 8192u) return false;
+  span_long_match_call(out, mpos, off, ml, lane, sp.pat);
   sp.lo = lo; sp.hi = hi; sp.off = off;
   return true;
 }
@@ -459,7 +470,9 @@ __device__ __forceinline__ void lz4_ext_run(Window& w, uint32_t& ip, uint32_t& v
   }
 }
 
-__device__ int lz4_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* out, int32_t cap_, volatile uint32_t* scr, int lane, SpanCtx& sp PROF_ARG) {
+// allow_bulk: the pipelined loop of dec_bulk.h may be tried (decode_one_stream: not for bit-shuffled chunks, whose streams are chains of
+// near matches - the LDS-assembled step's case - so that every visit would be a wasted parse)
+__device__ int lz4_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* out, int32_t cap_, volatile uint32_t* scr, int lane, SpanCtx& sp PROF_ARG, bool allow_bulk = true) {
   if (cap_ == 0) return (n_ == 1 && in[0] == 0) ? 0 : -1;
   if (n_ <= 0) return -1;
   const uint32_t n = (uint32_t)n_, cap = (uint32_t)cap_;
@@ -477,7 +490,7 @@ __device__ int lz4_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* out,
       uint32_t ll1 = tk >> 4, tpos = ip + 1u;
       if (ll1 == 15u) { const uint32_t e = (hdr >> 8) & 0xffu; try_batch = e != 255u && 17u + e + 3u <= 64u; ll1 = 15u + e; tpos++; }
       if (try_batch && (tk & 15u) == 15u) try_batch = (w.peek32(tpos + ll1 + 2u) & 0xffu) != 255u;
-      if (BAMD_DEC_BULK && try_batch) {
+      if (BAMD_DEC_BULK && allow_bulk && try_batch) {
         if (bulk_wait == 0u) {
           const uint32_t rb = lz4_bulk(w, n, out, cap, scr, ip, op, sp.hi, lane PROF_PASS);
           const uint32_t steps = rb & 0x7fffffffu;
@@ -838,28 +851,79 @@ __device__ void unshuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize,
   // waits for vmcnt(0) at the top of EVERY iteration - i.e. for the previous iteration's stores
   __builtin_amdgcn_s_waitcnt(0);
   uint32_t e = 0;
-  // 4 steps (1024 elements) per iteration: all loads are issued before the first store.  Span bounds are
-  // multiples of 1024, so one decision per plane and iteration picks the plane, the pattern table or the register.
-  for (; e + 1024u <= N; e += 1024u) {
-    Rows<T> a, b, c, d;
+  // One decision per plane and group picks the plane, the pattern table, the plane's own period or the register.
+  // Round 3: a software pipeline over TWO register sets.  The loop used to issue a group's loads, wait, store, and only then
+  // issue the next group's loads - which then sat behind 8 stores in the one in-order memory counter, so that "these loads
+  // have arrived" included "those stores have been acknowledged by a write queue under full load": two round trips per 8 KiB of
+  // output, and the wave that unshuffles a block needs 128 of these groups.  The profile (profiles/r03d_dec_phase_*: streams
+  // account for half of the kernel's wave time) says the other half was spent here.  Now group g + 1 is loaded BEFORE group g
+  // is stored; every group issues exactly 4 T loads (planes served from a register read a dummy dword) and the sets alternate
+  // without copies, so that the one wait per group is an exact vmcnt(4 T) that leaves the younger loads in flight (the rules
+  // dec_bulk.h spells out).
+  // A group is 4 steps (1024 elements) for typesize 4 and 2 steps (512) for typesize 8: 16 registers either way, two sets = 32
+  // (with 1024-element groups for typesize 8 the two sets, 64 registers, left too little room: plane pointers went to the stack,
+  // and every reload of one is a memory operation with a vmcnt(0) behind it).  Span bounds are multiples of 1024: a group never
+  // straddles one.
+  constexpr int S = T == 8 ? 2 : 4;                      // steps per group
+  constexpr uint32_t GE = 256u * S;                      // elements per group
+  struct Grp { Rows<T> r[S]; uint32_t regmask; };
+  auto load_group = [&](Grp& g, uint32_t e0) {
     const uint32_t l4 = 4u * (uint32_t)lane;
+    g.regmask = 0u;
 #pragma unroll
     for (int j = 0; j < T; j++) {
-      const bool in_span = e >= lo[j] && e < hi[j];            // wave-uniform
-      const bool reg = in_span && ((small >> j) & 1u);
-      if (reg) { a.r[j] = b.r[j] = c.r[j] = d.r[j] = pr[j]; }   // scalar branch: no load at all
-      else if (in_span && ((self >> j) & 1u)) {                 // the plane's own period in front of the span, address per lane
-        const uint32_t o = ob[j] & 0xffffffu, m = (1u << (ob[j] >> 24)) - 1u;
-        const uint32_t q = e + l4 - o;
-        a.r[j] = ld4_plane(pl[j] + o + (q & m)); b.r[j] = ld4_plane(pl[j] + o + ((q + 256u) & m));
-        c.r[j] = ld4_plane(pl[j] + o + ((q + 512u) & m)); d.r[j] = ld4_plane(pl[j] + o + ((q + 768u) & m));
-      } else {
-        const gu8* p = in_span ? pat + (size_t)j * SPAN_PAT + (e & (SPAN_PAT - 1u)) : pl[j] + e;
-        a.r[j] = ld4_plane(p + l4); b.r[j] = ld4_plane(p + l4 + 256u); c.r[j] = ld4_plane(p + l4 + 512u); d.r[j] = ld4_plane(p + l4 + 768u);
-      }
+      const bool in_span = e0 >= lo[j] && e0 < hi[j];           // wave-uniform
+      const gu8* base = pl[j] + e0;
+      uint32_t o[S];
+#pragma unroll
+      for (int k = 0; k < S; k++) o[k] = l4 + 256u * (uint32_t)k;
+      if (in_span && ((small >> j) & 1u)) {                     // value comes from pr[j]; the load is a dummy
+        g.regmask |= 1u << j; base = pl[j];
+#pragma unroll
+        for (int k = 0; k < S; k++) o[k] = l4;
+      } else if (in_span && ((self >> j) & 1u)) {               // the plane's own period in front of the span, address per lane
+        const uint32_t ofs = ob[j] & 0xffffffu, m = (1u << (ob[j] >> 24)) - 1u, q = e0 + l4 - ofs;
+        base = pl[j] + ofs;
+#pragma unroll
+        for (int k = 0; k < S; k++) o[k] = (q + 256u * (uint32_t)k) & m;
+      } else if (in_span) base = pat + (size_t)j * SPAN_PAT + (e0 & (SPAN_PAT - 1u));
+      // (the base goes through readfirstlane so that the loads take the "scalar base + 32-bit lane offset" form)
+      base = uni_ptr(base);
+#pragma unroll
+      for (int k = 0; k < S; k++) g.r[k].r[j] = ld4_plane(base + o[k]);
     }
-    unshuffle_store<T>(dst, e, lane, a); unshuffle_store<T>(dst, e + 256u, lane, b);
-    unshuffle_store<T>(dst, e + 512u, lane, c); unshuffle_store<T>(dst, e + 768u, lane, d);
+  };
+  auto store_group = [&](const Grp& g, uint32_t e0) {
+#ifndef BAMD_WAVE_EMU
+    // ONE wait for the whole group, here, where the only younger operations are the next group's S T loads (dec_bulk.h: bulk_execute)
+#pragma unroll
+    for (int k = 0; k < S; k++)
+#pragma unroll
+      for (int j = 0; j < T; j += 4) asm volatile("; group ready" ::"v"(g.r[k].r[j]), "v"(g.r[k].r[j + 1]), "v"(g.r[k].r[j + 2]), "v"(g.r[k].r[j + 3]));
+#endif
+#pragma unroll
+    for (int k = 0; k < S; k++) {
+      Rows<T> x = g.r[k];
+#pragma unroll
+      for (int j = 0; j < T; j++) if ((g.regmask >> j) & 1u) x.r[j] = pr[j];
+      unshuffle_store<T>(dst, e0 + 256u * (uint32_t)k, lane, x);
+    }
+  };
+  const uint32_t ngroups = (N >> 10) * (1024u / GE);
+  if (ngroups) {
+    Grp ga, gb;
+    load_group(ga, 0u);
+    uint32_t g = 0;
+    // two groups per trip; the group loaded ahead is clamped to the last one (loaded twice at the end instead of a branch)
+    for (; g + 2u <= ngroups; g += 2u) {
+      load_group(gb, (g + 1u) * GE);
+      store_group(ga, g * GE);
+      load_group(ga, (g + 2u < ngroups ? g + 2u : ngroups - 1u) * GE);
+      store_group(gb, (g + 1u) * GE);
+    }
+    if (g < ngroups) store_group(ga, g * GE);               // odd count: the last group is in ga
+    e = (N >> 10) << 10;
+    __builtin_amdgcn_s_waitcnt(0);
   }
   // behind the last multiple of 1024 nothing is skipped
   for (; e + 256u <= N; e += 256u) {
@@ -922,7 +986,7 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
   } else if (sd->fmt == FMT_ZSTD || sd->fmt == FMT_ZLIB) {
     return;               // k_zstd_streams / k_zlib_streams own the streams of those chunks
   } else if (sd->fmt == FMT_LZ4) {
-    got = lz4_decode_wave(in, csize, out, want, scr, lane, sp PROF_PASS);
+    got = lz4_decode_wave(in, csize, out, want, scr, lane, sp PROF_PASS, (mode & CH_BITSHUFFLE) == 0u);
   } else {
     got = blosclz_decode_wave(in, csize, out, want, scr, lane, sp);
   }
@@ -961,7 +1025,7 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
 }
 
 #ifndef BAMD_DEC_MINWAVES
-#define BAMD_DEC_MINWAVES 6   // waves per SIMD (80 VGPRs).  Same-session A/B on MI355X with both batched decoders in:
+#define BAMD_DEC_MINWAVES 5   // waves per SIMD (96 VGPRs).  Round 2: 6 = 5 < 7 < 8 (spills cost more than occupancy gives).  Round 3, with the pipelined loops of dec_bulk.h and the fused unshuffle (both keep two register sets in flight): 5 beats 6 by 4-6 % on every data set (profiles/r03h_dec_ab_rowfill_off.txt)
 #endif                       // 6 = 5 (5.90 / 5.95 ms) < 7 (6.33) < 8 (7.0): spills cost more than occupancy gives
 constexpr int DEC_WAVES_PER_CU = 4 * BAMD_DEC_MINWAVES;
 // Persistent launch: the grid is sized to what the chip can hold (engine.hip) and every wave pulls stream

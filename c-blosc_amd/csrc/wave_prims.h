@@ -106,7 +106,10 @@ __device__ __forceinline__ void wave_match_copy(gu8* out, uint32_t pos, uint32_t
     // `done` may not be a multiple of G when head was cut; any multiple of `off` <= off+done is valid
     // only if the copied prefix really is periodic up to `done`, which it is.  Restart from G.
   }
-  if (done == 0u && off >= 64u && off <= 1024u && (off & (off - 1u)) == 0u && len >= 2048u) {
+#ifndef BAMD_ROWFILL
+#define BAMD_ROWFILL 0     // measured (profiles/r03g_dec_ab_bisect_rowfill_selfspan.txt): 7 % SLOWER kernels on bench19 and linspace with it, although the streams that use it get shorter
+#endif
+  if (BAMD_ROWFILL && done == 0u && off >= 64u && off <= 1024u && (off & (off - 1u)) == 0u && len >= 2048u) {
     // The period divides 1024: every 1 KiB row of the match is the same, and lane l's 16 bytes of it lie at
     // pos - off + (16 l mod off) - in front of the match, so ONE load serves all rows (round 3: byte planes of a few significant
     // bits decode into dozens of 4 KiB runs of period 128, each of which took five dependent round trips to get going)

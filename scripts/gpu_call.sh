@@ -46,6 +46,21 @@ for stage in "$@"; do
                 done | tee -a gpurun_out/${TAG}_dec_ab.txt ;;
     decab)      # the same in ONE process, the builds taking turns on the same buffers (scripts/dec_ab.py): process-to-process differences cancel
                 DECSETS="${DECSETS:-bench19:1:8 linspace:1:8 randwalk:1:8 bench19:2:4}" timeout 600 python scripts/dec_ab.py c-blosc_amd/libblosc_amd.so gpurun_tune_*.so 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/${TAG}_dec_ab1.txt ;;
+    decwpc)     # waves per CU of the decode kernel (grid size only) on the library under test, reference-written bench19 chunks
+                for wpc in 24 20 16 12 8; do echo -n "WPC=$wpc  "; BLOSC_AMD_DEC_WPC=$wpc timeout 120 python scripts/dec_sweep.py 2>&1 | tail -1; done | tee gpurun_out/${TAG}_dec_wpc.txt ;;
+    dectraffic) # FETCH_SIZE / WRITE_SIZE of the decode kernels (one counter per pass, --kernel-trace only), reference-written bench19 chunks
+                for PMC in FETCH_SIZE WRITE_SIZE; do
+                  timeout 300 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d gpurun_out/${TAG}_pmc_$PMC -o pmc -- python scripts/dec_sweep.py > gpurun_out/${TAG}_pmc_$PMC.log 2>&1
+                  f=$(find gpurun_out/${TAG}_pmc_$PMC -name "*counter_collection.csv" | head -1)
+                  [ -n "$f" ] && python - "$f" $PMC <<'PY'
+import csv, sys, collections
+acc = collections.defaultdict(list)
+for row in csv.DictReader(open(sys.argv[1])):
+    if row['Counter_Name'] == sys.argv[2]: acc[row['Kernel_Name'].split('(')[0][-40:]].append(float(row['Counter_Value']))
+for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1]))[:6]: print(f"{sys.argv[2]} {k}: launches {len(v)} mean {sum(v)/len(v)/1e6:.1f} M units  max {max(v)/1e6:.1f}")
+PY
+                  rm -rf gpurun_out/${TAG}_pmc_$PMC
+                done | tee gpurun_out/${TAG}_dec_traffic.txt ;;
     dectests)   timeout 900 python -m pytest tests/test_gpu_decompress.py tests/test_gpu_spans.py tests/test_gpu_baseline_geometry.py tests/test_gpu_getitem_batch.py -m gpu -x -q --no-header -p no:cacheprovider 2>&1 | tee gpurun_out/${TAG}_pytest_dec.log | tail -8 ;;
     enc)        for d in ${DATA:-bench19 linspace randwalk}; do for lib in c-blosc_amd/libblosc_amd.so gpurun_tune_*.so; do
                   [ -f $lib ] && { echo -n "$lib "; DATA=$d BLOSC_AMD_LIB=$PWD/$lib timeout 150 python scripts/enc_sweep.py 2>&1 | tail -1; }
