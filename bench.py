@@ -64,9 +64,12 @@ CONFIGS = {
     "zb": dict(codec="zlib", shuffle=1, typesize=8, clevel=5, data="linspace"),
     # the encoder options of DESIGN.md 3.6 / 3.9 (an "env" entry is put into the environment before the library is used)
     "h":  dict(codec="lz4hc", shuffle=1, typesize=8, clevel=9, data="bench19"),
+    "4p": dict(codec="zstd", shuffle=1, typesize=8, clevel=3, data="bench19", env={"BLOSC_AMD_ZSTD_TABLES": "0"}),    # predefined tables (the round-2 default)
     "4t": dict(codec="zstd", shuffle=1, typesize=8, clevel=3, data="bench19", env={"BLOSC_AMD_ZSTD_TABLES": "1"}),
+    "zf": dict(codec="zlib", shuffle=1, typesize=8, clevel=5, data="bench19", env={"BLOSC_AMD_ZLIB_DYNAMIC": "0", "BLOSC_AMD_ZLIB_SEARCH": "0"}),   # fixed codes, plain match finder (the round-2 default)
+    "zy": dict(codec="zlib", shuffle=1, typesize=8, clevel=5, data="bench19", env={"BLOSC_AMD_ZLIB_DYNAMIC": "1", "BLOSC_AMD_ZLIB_SEARCH": "0"}),   # dynamic codes only
     "4s": dict(codec="zstd", shuffle=1, typesize=8, clevel=3, data="bench19", env={"BLOSC_AMD_ZSTD_SEARCH": "1"}),
-    "zs": dict(codec="zlib", shuffle=1, typesize=8, clevel=5, data="bench19", env={"BLOSC_AMD_ZLIB_SEARCH": "1"}),
+    "zs": dict(codec="zlib", shuffle=1, typesize=8, clevel=5, data="bench19", env={"BLOSC_AMD_ZLIB_SEARCH": "1", "BLOSC_AMD_ZLIB_DYNAMIC": "0"}),
     "zd": dict(codec="zlib", shuffle=1, typesize=8, clevel=5, data="bench19", env={"BLOSC_AMD_ZLIB_DYNAMIC": "1", "BLOSC_AMD_ZLIB_SEARCH": "1"}),
     "4h": dict(codec="zstd", shuffle=1, typesize=4, clevel=3, data="smallints", env={"BLOSC_AMD_ZSTD_TABLES": "1", "BLOSC_AMD_ZSTD_HUFFMAN": "1"}),
     "4r": dict(codec="zstd", shuffle=1, typesize=4, clevel=3, data="smallints"),       # 4h's baseline: raw literals, predefined tables

@@ -240,10 +240,11 @@ static bool blockdec_enabled() { static const bool on = getenv("BLOSC_AMD_BLOCKD
 #endif
 static bool lz4hc_search_enabled() { const char* e = getenv("BLOSC_AMD_LZ4HC"); return e ? atoi(e) != 0 : (BAMD_LZ4HC_DEFAULT != 0); }
 #ifndef BAMD_ZSTD_TABLES_DEFAULT
-#define BAMD_ZSTD_TABLES_DEFAULT 0
+#define BAMD_ZSTD_TABLES_DEFAULT 1   // measured on MI355X (profiles/r03a_encopts_bench_cfg4t.json): bench19 ratio 18.3 -> 23.8 for +5.6 % encode time
 #endif
 static bool zstd_tables_enabled() { const char* e = getenv("BLOSC_AMD_ZSTD_TABLES"); return e ? atoi(e) != 0 : (BAMD_ZSTD_TABLES_DEFAULT != 0); }
 static bool env_flag(const char* name) { const char* e = getenv(name); return e && atoi(e) != 0; }
+static bool env_flag_or(const char* name, bool dflt) { const char* e = getenv(name); return e ? atoi(e) != 0 : dflt; }
 static bool periodic_enabled() { static const bool on = !(getenv("BLOSC_AMD_PERIODIC") && atoi(getenv("BLOSC_AMD_PERIODIC")) == 0); return on; }
 // BLOSC_AMD_ZSTD2: 2 (default) = two-phase path, 16 frames per wave, tables in a global scratch (k_zstd2.hip);
 // 1 = the same with the tables in LDS (one wave per CU); 0 = one wave per frame for everything (k_zstd_streams).
@@ -367,12 +368,16 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   // until it has been timed on the device, read per call
   const bool ztab = zstd && zstd_tables_enabled();
   // the LZ4HC-grade search in front of the Zstd writer (with per-block tables) / the zlib writer: BLOSC_AMD_ZSTD_SEARCH=1, BLOSC_AMD_ZLIB_SEARCH=1
-  const bool zsearch = (zstd && env_flag("BLOSC_AMD_ZSTD_SEARCH")) || (zlibc && env_flag("BLOSC_AMD_ZLIB_SEARCH"));
+  // Defaults after the device timings of round 3 (profiles/r03a_encopts_bench_*.json, 8 GiB bench19): Zstd - the search costs 2.6 x the
+  // encode time (35.8 -> 94.9 ms) for ratio 23.8 -> 35.1, so it serves the upper clevels (the reference maps clevel >= 6 to its
+  // lazy / optimal strategies, blosc.c:502-504 + clevels.h) and stays off at the default clevel; zlib - whoever names zlib wants its
+  // ratio: search + dynamic codes give 73.4 (reference 47.4, fixed codes without search 40.5) at 57 ms per 8 GiB, still 150 GB/s.
+  const bool zsearch = (zstd && env_flag_or("BLOSC_AMD_ZSTD_SEARCH", p.clevel >= 6)) || (zlibc && env_flag_or("BLOSC_AMD_ZLIB_SEARCH", true));
   // Huffman-coded literals (with the per-block tables, or tables + search): BLOSC_AMD_ZSTD_HUFFMAN=1 on top of either switch
   const bool zhuf = zstd && (ztab || zsearch) && env_flag("BLOSC_AMD_ZSTD_HUFFMAN");
   static const int enc_wpc_lz = getenv("BLOSC_AMD_ENC_WPC") ? atoi(getenv("BLOSC_AMD_ENC_WPC")) : ENC_WAVES_PER_CU;
   const int enc_wpc = zsearch ? (160 * 1024) / (HC_TAB_BYTES + ZS_LDS_BYTES) : (hc ? HC_WAVES_PER_CU : enc_wpc_lz);   // what fits into a CU's LDS
-  const bool zdyn = zlibc && env_flag("BLOSC_AMD_ZLIB_DYNAMIC");      // zlib with dynamic Huffman codes: two passes, the tokens in the sequence scratch
+  const bool zdyn = zlibc && env_flag_or("BLOSC_AMD_ZLIB_DYNAMIC", true);      // zlib with dynamic Huffman codes: two passes, the tokens in the sequence scratch
   const size_t zwaves = (zstd || zdyn) ? (size_t)(st.cus > 0 ? st.cus : 256) * (size_t)enc_wpc : 0;
   const size_t o_ctabs = cv.take(sizeof(zenc::CTabs) + 64);
   const size_t o_seqbufs = cv.take(zwaves * (zdyn ? (size_t)ZD_SCRATCH_U64 : (size_t)ZS_SEQCAP) * sizeof(uint64_t) + 64);

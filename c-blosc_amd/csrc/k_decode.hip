@@ -847,83 +847,36 @@ __device__ void unshuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize,
       ob[j] = uni(g_ld4(pat + (size_t)j * SPAN_PAT)) | ((31u - (uint32_t)__builtin_clz(uni(g_ld4(pat + (size_t)j * SPAN_PAT + 4)))) << 24);
     }
   }
+  // (Round 3 tried this loop as a software pipeline - two register sets, the next group's loads issued before the current group's
+  //  stores, one exact vmcnt per group, the recipe of dec_bulk.h: 10 % SLOWER kernels on every data set,
+  //  profiles/r03i_dec_ab_pipelined_unshuffle_rejected.txt.  Unlike the decoder's steps, consecutive groups here have no data
+  //  dependence, so the plain form already keeps 4 KiB of loads in flight per wave and the memory system, not the wave, is the limit.)
   // the register rows are in before the loop: otherwise the compiler, which cannot tell whether they are still in flight,
   // waits for vmcnt(0) at the top of EVERY iteration - i.e. for the previous iteration's stores
   __builtin_amdgcn_s_waitcnt(0);
   uint32_t e = 0;
-  // One decision per plane and group picks the plane, the pattern table, the plane's own period or the register.
-  // Round 3: a software pipeline over TWO register sets.  The loop used to issue a group's loads, wait, store, and only then
-  // issue the next group's loads - which then sat behind 8 stores in the one in-order memory counter, so that "these loads
-  // have arrived" included "those stores have been acknowledged by a write queue under full load": two round trips per 8 KiB of
-  // output, and the wave that unshuffles a block needs 128 of these groups.  The profile (profiles/r03d_dec_phase_*: streams
-  // account for half of the kernel's wave time) says the other half was spent here.  Now group g + 1 is loaded BEFORE group g
-  // is stored; every group issues exactly 4 T loads (planes served from a register read a dummy dword) and the sets alternate
-  // without copies, so that the one wait per group is an exact vmcnt(4 T) that leaves the younger loads in flight (the rules
-  // dec_bulk.h spells out).
-  // A group is 4 steps (1024 elements) for typesize 4 and 2 steps (512) for typesize 8: 16 registers either way, two sets = 32
-  // (with 1024-element groups for typesize 8 the two sets, 64 registers, left too little room: plane pointers went to the stack,
-  // and every reload of one is a memory operation with a vmcnt(0) behind it).  Span bounds are multiples of 1024: a group never
-  // straddles one.
-  constexpr int S = T == 8 ? 2 : 4;                      // steps per group
-  constexpr uint32_t GE = 256u * S;                      // elements per group
-  struct Grp { Rows<T> r[S]; uint32_t regmask; };
-  auto load_group = [&](Grp& g, uint32_t e0) {
+  // 4 steps (1024 elements) per iteration: all loads are issued before the first store.  Span bounds are
+  // multiples of 1024, so one decision per plane and iteration picks the plane, the pattern table or the register.
+  for (; e + 1024u <= N; e += 1024u) {
+    Rows<T> a, b, c, d;
     const uint32_t l4 = 4u * (uint32_t)lane;
-    g.regmask = 0u;
 #pragma unroll
     for (int j = 0; j < T; j++) {
-      const bool in_span = e0 >= lo[j] && e0 < hi[j];           // wave-uniform
-      const gu8* base = pl[j] + e0;
-      uint32_t o[S];
-#pragma unroll
-      for (int k = 0; k < S; k++) o[k] = l4 + 256u * (uint32_t)k;
-      if (in_span && ((small >> j) & 1u)) {                     // value comes from pr[j]; the load is a dummy
-        g.regmask |= 1u << j; base = pl[j];
-#pragma unroll
-        for (int k = 0; k < S; k++) o[k] = l4;
-      } else if (in_span && ((self >> j) & 1u)) {               // the plane's own period in front of the span, address per lane
-        const uint32_t ofs = ob[j] & 0xffffffu, m = (1u << (ob[j] >> 24)) - 1u, q = e0 + l4 - ofs;
-        base = pl[j] + ofs;
-#pragma unroll
-        for (int k = 0; k < S; k++) o[k] = (q + 256u * (uint32_t)k) & m;
-      } else if (in_span) base = pat + (size_t)j * SPAN_PAT + (e0 & (SPAN_PAT - 1u));
-      // (the base goes through readfirstlane so that the loads take the "scalar base + 32-bit lane offset" form)
-      base = uni_ptr(base);
-#pragma unroll
-      for (int k = 0; k < S; k++) g.r[k].r[j] = ld4_plane(base + o[k]);
+      const bool in_span = e >= lo[j] && e < hi[j];            // wave-uniform
+      const bool reg = in_span && ((small >> j) & 1u);
+      if (reg) { a.r[j] = b.r[j] = c.r[j] = d.r[j] = pr[j]; }   // scalar branch: no load at all
+      else if (in_span && ((self >> j) & 1u)) {                 // the plane's own period in front of the span, address per lane
+        const uint32_t o = ob[j] & 0xffffffu, m = (1u << (ob[j] >> 24)) - 1u;
+        const uint32_t q = e + l4 - o;
+        a.r[j] = ld4_plane(pl[j] + o + (q & m)); b.r[j] = ld4_plane(pl[j] + o + ((q + 256u) & m));
+        c.r[j] = ld4_plane(pl[j] + o + ((q + 512u) & m)); d.r[j] = ld4_plane(pl[j] + o + ((q + 768u) & m));
+      } else {
+        const gu8* p = in_span ? pat + (size_t)j * SPAN_PAT + (e & (SPAN_PAT - 1u)) : pl[j] + e;
+        a.r[j] = ld4_plane(p + l4); b.r[j] = ld4_plane(p + l4 + 256u); c.r[j] = ld4_plane(p + l4 + 512u); d.r[j] = ld4_plane(p + l4 + 768u);
+      }
     }
-  };
-  auto store_group = [&](const Grp& g, uint32_t e0) {
-#ifndef BAMD_WAVE_EMU
-    // ONE wait for the whole group, here, where the only younger operations are the next group's S T loads (dec_bulk.h: bulk_execute)
-#pragma unroll
-    for (int k = 0; k < S; k++)
-#pragma unroll
-      for (int j = 0; j < T; j += 4) asm volatile("; group ready" ::"v"(g.r[k].r[j]), "v"(g.r[k].r[j + 1]), "v"(g.r[k].r[j + 2]), "v"(g.r[k].r[j + 3]));
-#endif
-#pragma unroll
-    for (int k = 0; k < S; k++) {
-      Rows<T> x = g.r[k];
-#pragma unroll
-      for (int j = 0; j < T; j++) if ((g.regmask >> j) & 1u) x.r[j] = pr[j];
-      unshuffle_store<T>(dst, e0 + 256u * (uint32_t)k, lane, x);
-    }
-  };
-  const uint32_t ngroups = (N >> 10) * (1024u / GE);
-  if (ngroups) {
-    Grp ga, gb;
-    load_group(ga, 0u);
-    uint32_t g = 0;
-    // two groups per trip; the group loaded ahead is clamped to the last one (loaded twice at the end instead of a branch)
-    for (; g + 2u <= ngroups; g += 2u) {
-      load_group(gb, (g + 1u) * GE);
-      store_group(ga, g * GE);
-      load_group(ga, (g + 2u < ngroups ? g + 2u : ngroups - 1u) * GE);
-      store_group(gb, (g + 1u) * GE);
-    }
-    if (g < ngroups) store_group(ga, g * GE);               // odd count: the last group is in ga
-    e = (N >> 10) << 10;
-    __builtin_amdgcn_s_waitcnt(0);
+    unshuffle_store<T>(dst, e, lane, a); unshuffle_store<T>(dst, e + 256u, lane, b);
+    unshuffle_store<T>(dst, e + 512u, lane, c); unshuffle_store<T>(dst, e + 768u, lane, d);
   }
   // behind the last multiple of 1024 nothing is skipped
   for (; e + 256u <= N; e += 256u) {

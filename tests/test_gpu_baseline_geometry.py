@@ -23,12 +23,22 @@ CASES = [  # name, codec, shuffle, typesize, clevel, dataset, GPU encodes it
     ("lz4-shuffle-T8-randwalk", "lz4", 1, 8, 5, "randwalk", True),
     ("zstd-shuffle-T8", "zstd", 1, 8, 3, "bench19", True),
     ("zlib-shuffle-T8", "zlib", 1, 8, 5, "bench19", True),
+    # the encoder options that are not the default at these settings: the LZ4HC-grade search in front of the Zstd
+    # writer (the default from clevel 6 on), Huffman-coded literals, and the round-2 forms of both writers
+    ("zstd-cl7-search", "zstd", 1, 8, 7, "bench19", True),
+    ("zstd-huffman-smallints", "zstd", 1, 4, 3, "smallints", True, {"BLOSC_AMD_ZSTD_HUFFMAN": "1"}),
+    ("zstd-predefined-tables", "zstd", 1, 8, 3, "bench19", True, {"BLOSC_AMD_ZSTD_TABLES": "0"}),
+    ("zlib-fixed-codes", "zlib", 1, 8, 5, "bench19", True, {"BLOSC_AMD_ZLIB_DYNAMIC": "0", "BLOSC_AMD_ZLIB_SEARCH": "0"}),
+    ("zlib-search-only", "zlib", 1, 8, 5, "linspace", True, {"BLOSC_AMD_ZLIB_DYNAMIC": "0", "BLOSC_AMD_ZLIB_SEARCH": "1"}),
 ]
+CASES = [c if len(c) == 8 else c + ({},) for c in CASES]
 
 
-@pytest.mark.parametrize("name,codec,shuffle,T,clevel,dname,gpu_enc", CASES, ids=[c[0] for c in CASES])
-def test_batch_at_baseline_geometry(pkg, lib, oracle, ref, name, codec, shuffle, T, clevel, dname, gpu_enc):
+@pytest.mark.parametrize("name,codec,shuffle,T,clevel,dname,gpu_enc,env", CASES, ids=[c[0] for c in CASES])
+def test_batch_at_baseline_geometry(pkg, lib, oracle, ref, monkeypatch, name, codec, shuffle, T, clevel, dname, gpu_enc, env):
     import torch
+    for k, v in env.items():          # the encoder switches are read per call (engine.hip)
+        monkeypatch.setenv(k, v)
     dev = torch.device("cuda:0")
     data = DATASETS[dname](CSZ)
     if ref is not None:
