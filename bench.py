@@ -279,7 +279,7 @@ class Rig:
     pass
 
 
-def measure(rig, name, cfg, steps, warmup, args, cold=False, mixed=None):
+def measure(rig, name, cfg, steps, warmup, args, mixed=None, payload=False):
     """One workload through the timed protocol of the contract: `warmup` untimed steps, then exactly `steps` steps between
     barrier + synchronize pairs, MAX over ranks.  Returns the fields of the JSON line that belong to this workload."""
     torch, dist, mod, lib, multigpu, dev = rig.torch, rig.dist, rig.mod, rig.lib, rig.multigpu, rig.dev
@@ -361,6 +361,17 @@ def measure(rig, name, cfg, steps, warmup, args, cold=False, mixed=None):
     consolidation_ms = (time.perf_counter() - tg) * 1e3
     assert len(table) == rig.nchunks_total and table[rig.lo:rig.hi] == list(cbytes)
     sum_cb_global = float(sum(table))
+    # ---- and the payloads: this rank's chunks packed back to back, then the all-gather-v onto rank 0, timed apart ----
+    payload_ms = None
+    if payload:
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        packed = multigpu.pack_local([comp[i] for i in range(nchunks)], list(cbytes))
+        container, _ = multigpu.gather_payload(packed, table, rig.nchunks_total, dst=0)
+        torch.cuda.synchronize()
+        payload_ms = (time.perf_counter() - tp) * 1e3
+        assert container is None or container.numel() == int(sum_cb_global)
+        del packed, container
 
     prof = {}
     for k in KERNELS:
@@ -444,6 +455,8 @@ def measure(rig, name, cfg, steps, warmup, args, cold=False, mixed=None):
         "decompress_stock_chunks": stock,
         "multi_gpu": {"partition": "contiguous chunk ranges, no data-path collective", "consolidation": "all_gather of the cbytes table, backend nccl (RCCL)",
                       "consolidation_ms": consolidation_ms, "world": world,
+                      "payload_consolidation": "pack + all-gather-v of the compressed chunks onto rank 0 (grouped send/recv, counts from the table)",
+                      "payload_consolidation_ms": payload_ms, "payload_bytes": sum_cb_global,
                       "note": None if world > 1 else "communicator of size 1: no N > 1 line exists until the driver has a multi-GPU node"},
         "kernels": prof,
         "roofline": roof,
@@ -526,7 +539,7 @@ def main():
     rig.comp = torch.empty((rig.nchunks, rig.csz + 256), dtype=torch.uint8, device=dev)
     rig.back = torch.empty((rig.nchunks, rig.csz), dtype=torch.uint8, device=dev)
 
-    res = measure(rig, args.config, cfg, args.steps, args.warmup, args)
+    res = measure(rig, args.config, cfg, args.steps, args.warmup, args, payload=True)
     host_chunk = res.pop("_host_chunk")
     # ---- the other BASELINE.json configurations and a batch of mixed data, as short legs of the default run:
     #      each with its own roofline object (dominant kernel, algorithmic bytes, average launch) and its ratio next to stock's ----

@@ -50,6 +50,15 @@ def test_partition_batch_and_rccl_gather(pkg, oracle):
         bd = pkg.DeviceBatch([comp[i].data_ptr() for i in range(hi - lo)], table[lo:hi], [back[i].data_ptr() for i in range(hi - lo)], [csz] * (hi - lo))
         assert bd.decompress() == 0 and bd.results() == [csz] * (hi - lo)
         assert torch.equal(back, src)
+        # payload consolidation over the same communicator: pack, all-gather-v, scatter back
+        packed = multigpu.pack_local([comp[i] for i in range(hi - lo)], cb)
+        container, offs = multigpu.gather_payload(packed, table, nchunks)
+        assert offs == offsets and container.numel() == sum(cb)
+        for i in (0, 11, nchunks - 1):
+            assert torch.equal(container[offs[i]:offs[i] + cb[i]], comp[i][:cb[i]])
+        owner, _ = multigpu.gather_payload(packed, table, nchunks, dst=0)
+        mine, loff = multigpu.scatter_payload(owner, table, nchunks, src=0)
+        assert torch.equal(mine, packed) and loff == offsets
         # byte counters / elapsed time are reduced the way bench.py does it
         t = torch.tensor([float(sum(cb))], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
