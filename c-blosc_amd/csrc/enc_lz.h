@@ -291,6 +291,9 @@ __device__ __forceinline__ uint32_t blz_emit_match(gu8* dst, uint32_t op, uint32
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t RANK_CAP = 20u;   // bytes of a candidate that are compared for ranking (16 instead: more extensions, lower ratio, no faster)
 
+#ifndef BAMD_ENC_BACK8
+#define BAMD_ENC_BACK8 0      // backward extension from registers (lz_encode_wave, round 3): bit-identical output, but no gain on the device (profiles/r03l_enc_ab_back8_no_gain.txt: the "extension" phase is not waiting for its own loads) - off
+#endif
 struct Bytes20 { uint64_t a, b; uint32_t c; };
 
 // 20 bytes at src[pos..], zero beyond n (only the last step of a stream takes the slow branch)
@@ -459,8 +462,16 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
     PROF_LAP(8); PROF_ADD(0, 1);
     // ---- round 2: candidate bytes, exact lengths up to RANK_CAP ----
     uint32_t len = 0;
+    // Round 3: the 8 bytes IN FRONT of the candidate travel with its 20 bytes (one more 8-byte load in the same round trip).  The
+    // backward extension of a match - tried for 4 in 10 sequences on bench19, longer than 4 bytes for 1 in 25 - needed a round
+    // trip of its own per sequence (2200 cycles, the largest single item of the encoder's phase profile,
+    // profiles/r03k_enc_phase_before.txt); with these bytes and the window registers it is decided in registers unless it
+    // runs past 8 bytes.  cbk: little endian, its top byte is src[cand - 1]; has_back: cbk belongs to `cand`.
+    uint64_t cbk = 0;
+    bool has_back = false;
     if (tab_ok) {
       const Bytes20 cb = load20(src, cand, n);
+      if (BAMD_ENC_BACK8 && cand >= 8u) { cbk = g_ld8(src + cand - 8u); has_back = true; }
       len = common20(own, cb);
       if (len > limit) len = limit;
       if (len < minlen) len = 0;
@@ -469,7 +480,7 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
     if (live && prev < 0x100u) {                    // distance 1: run of the previous byte
       uint32_t rl = runlen20(own, prev);
       if (rl > limit) rl = limit;
-      if (rl >= minlen && rl > len) { len = rl; cand = p - 1u; }
+      if (rl >= minlen && rl > len) { len = rl; cand = p - 1u; has_back = false; }
     }
     // ---- select + emit.  The winner maximises (len - lane), ties to the lower lane.  When its match
     // ends inside this step's 64 positions, the lanes behind it still hold valid candidates: pick
@@ -492,16 +503,40 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
       uint32_t maxb = pm - anchor;
       if (cm < maxb) maxb = cm;
       if (maxb > 64u) maxb = 64u;
-      // backward bytes are requested first and looked at last, so that they travel together with the
+      // ---- backward extension from registers where that settles it: own bytes out of the window dwords `r` (q = offset of pm in
+      //      r's byte space, everything wave-uniform), the candidate's out of cbk ----
+      uint32_t back = 0;
+      bool back_known = maxb == 0u;
+      if (BAMD_ENC_BACK8 && !back_known && (uint32_t)__builtin_amdgcn_readlane((int)(has_back ? 1u : 0u), f)) {
+        const uint32_t q = bo0 + (uint32_t)f;                       // >= 4 (or ip + f at the stream's start)
+        uint32_t nb = maxb < 8u ? maxb : 8u;
+        if (q < nb) nb = q;
+        const uint32_t q8 = q >= 8u ? q - 8u : 0u;                  // first of the (up to) 8 own bytes in r's byte space
+        const uint32_t i0 = q8 >> 2;
+        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)r, (int)i0), d1 = (uint32_t)__builtin_amdgcn_readlane((int)r, (int)(i0 + 1u));
+        const uint32_t d2 = (uint32_t)__builtin_amdgcn_readlane((int)r, (int)(i0 + 2u));
+        const uint32_t shb = (q8 & 3u) * 8u;
+        uint64_t own8 = shb ? ((((uint64_t)d1 << 32) | d0) >> shb) | ((uint64_t)d2 << (64u - shb)) : (((uint64_t)d1 << 32) | d0);   // bytes q8 .. q8 + 7
+        if (q < 8u) own8 <<= 8u * (8u - q);                         // fewer than 8 bytes in front of pm: line the last one up with the top byte
+        const uint64_t c8 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cbk >> 32), f) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cbk, f);
+        const uint64_t x = own8 ^ c8;
+        const uint32_t eq = x ? (uint32_t)__builtin_clzll(x) >> 3 : 8u;   // equal bytes counted from src[pm - 1] / src[cm - 1] downwards
+        if (eq < nb) { back = eq; back_known = true; }
+        else if (nb == maxb) { back = nb; back_known = true; }            // ran to the allowed limit
+        // else: equal as far as the registers reach - the memory path below finds the end
+      }
+      // otherwise backward bytes are requested first and looked at last, so that they travel together with the
       // forward rows (one memory round trip for both directions)
       uint32_t bx = 0, by = 1;
-      if ((uint32_t)lane < maxb) { bx = src[pm - 1u - (uint32_t)lane]; by = src[cm - 1u - (uint32_t)lane]; }
+      if (!back_known && (uint32_t)lane < maxb) { bx = src[pm - 1u - (uint32_t)lane]; by = src[cm - 1u - (uint32_t)lane]; }
       asm volatile("" ::: "memory");
       uint32_t mlen = len_f;
       if (len_f == RANK_CAP && pm + RANK_CAP < mlimit)
         mlen += wave_common_fwd(src, n, pm + RANK_CAP, cm + RANK_CAP, mlimit - (pm + RANK_CAP), lane);
-      const uint64_t bm = __ballot(bx != by);          // lanes >= maxb always vote "differs"
-      const uint32_t back = bm ? (uint32_t)__builtin_ctzll(bm) : 64u;
+      if (!back_known) {
+        const uint64_t bm = __ballot(bx != by);          // lanes >= maxb always vote "differs"
+        back = bm ? (uint32_t)__builtin_ctzll(bm) : 64u;
+      }
       PROF_LAP(10); PROF_ADD(2, len_f == RANK_CAP); PROF_ADD(3, anchor < ip && pm > anchor); PROF_ADD(6, 1); PROF_ADD(7, back > 0); if (FMT != EF_ZSTD) { PROF_ADD(4, back > 4); PROF_ADD(5, maxb > 0); }
       pm -= back; cm -= back; mlen += back;
       const uint32_t ll = pm - anchor;

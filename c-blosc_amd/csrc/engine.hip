@@ -822,7 +822,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
     results[i] = c.nbytes;
     if (c.mode & CH_MEMCPYED) L.any_copy = true;
     filter_tiles(c, L.any_shuf, L.any_bit, L.tiles_shuf, L.tiles_bit, !st.single_queue);
-    if (c.mode & (CH_SHUFFLE | CH_BITSHUFFLE)) filt_bytes = align_up(filt_bytes, 256) + (size_t)c.nbytes;
+    if (c.mode & (CH_SHUFFLE | CH_BITSHUFFLE)) filt_bytes = align_up(filt_bytes, 256) + (size_t)c.nblocks * filt_block_stride(c);
     if (c.fmt == FMT_ZSTD && !(c.mode & CH_MEMCPYED)) { L.any_zstd = true; zlit_bytes = align_up(zlit_bytes, 256) + (size_t)c.nbytes; }
     if (c.fmt == FMT_ZLIB && !(c.mode & CH_MEMCPYED)) L.any_zlib = true;
     if (!device_ptrs) { io_src = align_up(io_src, 256) + (size_t)c.cbytes; io_dst = align_up(io_dst, 256) + (size_t)c.nbytes; }
@@ -870,7 +870,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
         c.src = io_s + is; c.dst = io_d + id;
         is += (size_t)c.cbytes; id += (size_t)c.nbytes;
       }
-      if (c.mode & (CH_SHUFFLE | CH_BITSHUFFLE)) { fo = align_up(fo, 256); c.filt = D + o_filt + fo; fo += (size_t)c.nbytes; }
+      if (c.mode & (CH_SHUFFLE | CH_BITSHUFFLE)) { fo = align_up(fo, 256); c.filt = D + o_filt + fo; fo += (size_t)c.nblocks * filt_block_stride(c); }
       if (c.fmt == FMT_ZSTD && !(c.mode & CH_MEMCPYED)) { zo = align_up(zo, 256); c.stage = D + o_zlit + zo; zo += (size_t)c.nbytes; }
     }
   }
@@ -1003,7 +1003,7 @@ int engine_getitem(const void* src, int start, int nitems, void* dest, bool src_
   const size_t o_spans = cv.take(8 * nstr);
   const size_t o_pat = cv.take(span_enabled() ? (size_t)2048 * nstr : 256);
   const size_t o_out = cv.take(span + 256);
-  const size_t o_filt = cv.take(span + 256);
+  const size_t o_filt = cv.take(span + (size_t)nblk * (size_t)FILT_PLANE_PAD * (size_t)(c.typesize > 0 ? c.typesize : 1) + 256);   // room for the padded plane layout of a fused chunk
   const size_t o_zlit = cv.take((fmt == FMT_ZSTD ? span : 0) + 256);
   const size_t o_zticket = cv.take(64);
   if (st.dev.ensure(cv.off)) return -1;
@@ -1011,10 +1011,10 @@ int engine_getitem(const void* src, int start, int nitems, void* dest, bool src_
   c.src = dsrc;
   // kernels address block j at base + j*blocksize: bias the bases so that block j0 lands at offset 0
   c.dst = D + o_out - (size_t)j0 * bs;
-  c.filt = (c.mode & (CH_SHUFFLE | CH_BITSHUFFLE)) ? D + o_filt - (size_t)j0 * bs : nullptr;
   c.stage = (fmt == FMT_ZSTD) ? D + o_zlit - (size_t)j0 * bs : nullptr;
   DecodeLaunch L{};
   filter_tiles(c, L.any_shuf, L.any_bit, L.tiles_shuf, L.tiles_bit, !st.single_queue);   // may set CH_FUSED_UNSHUF: before the upload
+  c.filt = (c.mode & (CH_SHUFFLE | CH_BITSHUFFLE)) ? D + o_filt - (size_t)j0 * filt_block_stride(c) : nullptr;   // (the block stride depends on the mode just chosen)
   Carver pc;
   const size_t p_chunks = pc.take(sizeof(ChunkDesc));
   const size_t p_blocks = pc.take(sizeof(BlockDesc) * nblk);

@@ -33,13 +33,15 @@ __global__ void k_decode_plan(const ChunkDesc* __restrict__ chunks, const BlockD
   const ChunkDesc& c = chunks[b.chunk];
   const int32_t bsize = b.bsize;
   const int32_t neblock = bsize / b.nstreams;
-  uint8_t* out = ((c.mode & (CH_SHUFFLE | CH_BITSHUFFLE)) ? c.filt : c.dst) + (size_t)b.blk * c.blocksize;
+  const bool to_filt = (c.mode & (CH_SHUFFLE | CH_BITSHUFFLE)) != 0;
+  uint8_t* out = to_filt ? c.filt + (size_t)b.blk * filt_block_stride(c) : c.dst + (size_t)b.blk * c.blocksize;
+  const uint32_t pstride = to_filt ? filt_plane_stride(c, (uint32_t)bsize, b.nstreams) : (uint32_t)neblock;
   int32_t off = ld_i32(c.src + 16 + 4 * (size_t)b.blk);
   bool bad = false;
   for (int j = 0; j < b.nstreams; j++) {
     StreamDesc s;
     s.chunk = b.chunk; s.fmt = c.fmt; s.aux = g; s.result = 0;
-    s.out = out + (size_t)j * neblock; s.out_size = neblock;
+    s.out = out + (size_t)j * pstride; s.out_size = neblock;
     s.in = nullptr; s.in_size = -1;  // -1: nothing to decode (chain broken)
     if (!bad) {
       if (off < 0 || off > c.cbytes - 4) bad = true;
@@ -829,7 +831,7 @@ __device__ __forceinline__ void unshuffle_store(gu8* dst, uint32_t e, int lane, 
 // in front of the span, at ob + ((q - ob) & (off - 1)) per lane; ob and off are the first two words of the stream's table slot.
 constexpr uint32_t SPAN_SMALL = 1u, SPAN_RAW = 2u, SPAN_SELF = 4u;
 template <int T>
-__device__ void unshuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize, int lane, const uint32_t* spans, const gu8* pat, const StreamDesc* sds) {
+__device__ void unshuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize, int lane, const uint32_t* spans, const gu8* pat, const StreamDesc* sds, uint32_t pstride) {
   const uint32_t N = bsize / T;
   uint32_t lo[T], hi[T], pr[T], ob[T];                   // ob: a self span's base | log2(period) << 24
   const gu8* pl[T];                                      // where plane j lies: the scratch, or the chunk itself (raw)
@@ -839,7 +841,7 @@ __device__ void unshuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize,
     const uint32_t w = spans ? uni(spans[2 * j]) : 0u;
     lo[j] = w & ~1023u; hi[j] = spans ? uni(spans[2 * j + 1]) : 0u;
     pr[j] = 0u; ob[j] = 0u;
-    pl[j] = src + (size_t)j * N;
+    pl[j] = src + (size_t)j * pstride;
     if (w & SPAN_RAW) { pl[j] = uni_ptr(as_global(sds[j].in)); hi[j] = 0u; }
     else if ((w & SPAN_SMALL) && hi[j] > lo[j]) { small |= 1u << j; pr[j] = g_ld4(pat + (size_t)j * SPAN_PAT + 4u * (uint32_t)lane); }
     else if ((w & SPAN_SELF) && hi[j] > lo[j]) {
@@ -893,15 +895,16 @@ __device__ void unshuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize,
 }
 
 __device__ __attribute__((noinline)) void unshuffle_block_wave(const uint8_t* src, uint8_t* dst, uint32_t bsize_, int typesize_, int lane,
-                                                               const uint32_t* spans_, const uint8_t* pat, const StreamDesc* sds_) {
+                                                               const uint32_t* spans_, const uint8_t* pat, const StreamDesc* sds_, uint32_t pstride_ = 0) {
   // arguments of a real (non-inlined) call count as divergent for the compiler: without the readfirstlanes below the loop
   // bounds, the span decisions and the plane pointers all lived in VGPRs (64-bit pointer pairs spilled inside the loop)
   const uint32_t bsize = uni(bsize_); const int typesize = (int)uni((uint32_t)typesize_);
   const uint64_t sv = (uint64_t)spans_, dv = (uint64_t)sds_;
   const uint32_t* spans = (const uint32_t*)(((uint64_t)uni((uint32_t)(sv >> 32)) << 32) | uni((uint32_t)sv));
   const StreamDesc* sds = (const StreamDesc*)(((uint64_t)uni((uint32_t)(dv >> 32)) << 32) | uni((uint32_t)dv));
-  if (typesize == 8) unshuffle_block_wave_T<8>(uni_ptr(as_global(src)), uni_ptr(as_global(dst)), bsize, lane, spans, uni_ptr(as_global(pat)), sds);
-  else unshuffle_block_wave_T<4>(uni_ptr(as_global(src)), uni_ptr(as_global(dst)), bsize, lane, spans, uni_ptr(as_global(pat)), sds);
+  const uint32_t pstride = uni(pstride_) ? uni(pstride_) : bsize / (uint32_t)typesize;      // 0: the plain plane-major image
+  if (typesize == 8) unshuffle_block_wave_T<8>(uni_ptr(as_global(src)), uni_ptr(as_global(dst)), bsize, lane, spans, uni_ptr(as_global(pat)), sds, pstride);
+  else unshuffle_block_wave_T<4>(uni_ptr(as_global(src)), uni_ptr(as_global(dst)), bsize, lane, spans, uni_ptr(as_global(pat)), sds, pstride);
 }
 
 // One stream, start to finish.  Deliberately NOT inlined into the queue loop below: with the decoders
@@ -973,8 +976,16 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
   const size_t boff = (size_t)uni((uint32_t)b->blk) * (size_t)uni((uint32_t)c->blocksize);
   const bool split = spans && nstreams == uni((uint32_t)c->typesize);
   const uint32_t fs = uni((uint32_t)b->first_stream);
-  unshuffle_block_wave(c->filt + boff, c->dst + boff, uni((uint32_t)b->bsize), (int)uni((uint32_t)c->typesize), lane,
-                       split ? spans + 2 * (size_t)fs : nullptr, pat + (size_t)fs * SPAN_PAT, sd - (sid - fs));
+#ifdef BAMD_PROFILE_DECODE
+  const uint64_t ut0 = __builtin_amdgcn_s_memtime();
+#endif
+  unshuffle_block_wave(c->filt + (size_t)uni((uint32_t)b->blk) * filt_block_stride(*c), c->dst + boff, uni((uint32_t)b->bsize), (int)uni((uint32_t)c->typesize), lane,
+                       split ? spans + 2 * (size_t)fs : nullptr, pat + (size_t)fs * SPAN_PAT, sd - (sid - fs),
+                       filt_plane_stride(*c, uni((uint32_t)b->bsize), (int)nstreams));
+#ifdef BAMD_PROFILE_DECODE
+  __builtin_amdgcn_s_waitcnt(0);
+  if (lane == 0 && profslot) { profslot[6] = (uint32_t)(__builtin_amdgcn_s_memtime() - ut0); profslot[7] = 1u; }      // cycles of the block's fused unshuffle, charged to the stream that arrived last
+#endif
 }
 
 #ifndef BAMD_DEC_MINWAVES

@@ -38,6 +38,8 @@ for plane in range(TS):
     tot = q[8:14].sum()
     print(f" plane {plane}: " + "  ".join(f"{names[i]}={q[i]:.0f}" for i in names) + f"  | total cyc {tot:.0f}  cyc/seq {tot / max(q[1] + q[3], 1):.0f}")
 allm = p.mean(axis=0); print(" max stream total cycles:", p[:, 8:14].sum(axis=1).max(), " mean:", p[:, 8:14].sum(axis=1).mean())
+un = p[p[:, 7] > 0][:, 6]
+if un.size: print(f" fused unshuffle: {un.size} blocks, mean {un.mean():.0f} cycles per block (max {un.max():.0f}); per stream {un.sum() / p.shape[0]:.0f} - streams' own mean {p[:, 8:14].sum(axis=1).mean():.0f}")
 
 
 # concurrency per XCD (s_memtime counters are per XCD): mean number of streams in flight

@@ -65,6 +65,8 @@ PY
     enc)        for d in ${DATA:-bench19 linspace randwalk}; do for lib in c-blosc_amd/libblosc_amd.so gpurun_tune_*.so; do
                   [ -f $lib ] && { echo -n "$lib "; DATA=$d BLOSC_AMD_LIB=$PWD/$lib timeout 150 python scripts/enc_sweep.py 2>&1 | tail -1; }
                 done; done | tee -a gpurun_out/${TAG}_enc_ab.txt ;;
+    encab)      ENCSETS="${ENCSETS:-bench19:1:8 linspace:1:8 randwalk:1:8 bench19:2:4}" timeout 600 python scripts/enc_ab.py c-blosc_amd/libblosc_amd.so gpurun_tune_*.so 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/${TAG}_enc_ab1.txt ;;
+    encphase)   timeout 200 python scripts/enc_phase.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${TAG}_enc_phase.txt | tail -14 ;;
     encopts)    # device timing of the encoder options built at the end of round 2 (formerly scripts/r03_call_a.sh)
                 timeout 300 python -m pytest tests/test_gpu_zstd_tables.py tests/test_gpu_lz4hc.py -m gpu -q --no-header -p no:cacheprovider 2>&1 | tee gpurun_out/${TAG}_pytest_encopts.log | tail -5
                 for cfg in 2 4 4t 4s z zs zd h 4r 4h; do bench_cfg $cfg; done; summarise ;;

@@ -89,15 +89,15 @@ void blk_body(int lane, void* arg) {
 extern "C" int emu_decode_block(int T, int fmt, const uint8_t* const* streams, const int* csize, unsigned bsize, uint8_t* dst, const int* order, unsigned* spans_out) {
   using namespace bamd;
   const uint32_t ne = bsize / (uint32_t)T;
-  uint8_t* filt = (uint8_t*)malloc(bsize + 4096);
-  memset(filt, 0xCD, bsize + 4096);
+  uint8_t* filt = (uint8_t*)malloc(bsize + 4096 + 8 * FILT_PLANE_PAD);          // the padded plane layout of fused chunks (dev_types.h)
+  memset(filt, 0xCD, bsize + 4096 + 8 * FILT_PLANE_PAD);
   ChunkDesc c; memset(&c, 0, sizeof c);
   c.src = nullptr; c.dst = dst; c.filt = filt; c.nbytes = (int32_t)bsize; c.blocksize = (int32_t)bsize; c.typesize = T; c.nblocks = 1;
   c.nsplits = T; c.fmt = fmt; c.mode = CH_SHUFFLE | CH_FUSED_UNSHUF; c.first_block = 0; c.first_stream = 0;
   BlockDesc b; memset(&b, 0, sizeof b);
   b.chunk = 0; b.blk = 0; b.first_stream = 0; b.nstreams = T; b.bsize = (int32_t)bsize;
   StreamDesc sd[8];
-  for (int k = 0; k < T; k++) { sd[k].in = streams[k]; sd[k].out = filt + (size_t)k * ne; sd[k].in_size = csize[k]; sd[k].out_size = (int32_t)ne; sd[k].chunk = 0; sd[k].fmt = fmt; sd[k].aux = 0; sd[k].result = 0; }
+  for (int k = 0; k < T; k++) { sd[k].in = streams[k]; sd[k].out = filt + (size_t)k * filt_plane_stride(c, bsize, T); sd[k].in_size = csize[k]; sd[k].out_size = (int32_t)ne; sd[k].chunk = 0; sd[k].fmt = fmt; sd[k].aux = 0; sd[k].result = 0; }
   int32_t status = 0; uint32_t blk_done = 0;
   uint32_t spans[16]; memset(spans, 0, sizeof spans);
   uint8_t* pat = (uint8_t*)malloc((size_t)T * SPAN_PAT + 64);
