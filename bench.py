@@ -92,12 +92,12 @@ def make_chunk(kind, nbytes):
 
 def measured_traffic(kernel, config_name, nchunks, chunk_mib):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of THIS workload
-    (profiles/r02f_traffic_cfg<config>.json, else r02_..., made by scripts/profile_config.sh + scripts/make_traffic_json.py:
+    (profiles/r03_traffic_cfg<config>.json, else r02g_ / r02f_ / r02_..., made by scripts/profile_config.sh + scripts/make_traffic_json.py:
     FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 corrections applied).  PMC counters cannot be
     read from inside a timed run, so a workload without a committed pass reports null."""
     if nchunks != 128 or chunk_mib != 64:
         return None
-    for rnd in ("r02g", "r02f", "r02"):       # r02g / r02f: passes taken on the final code of round 2
+    for rnd in ("r03", "r02g", "r02f", "r02"):       # r03: passes taken on the final code of round 3 (scripts/gpu_call.sh profile)
         path = os.path.join(ROOT, "profiles", f"{rnd}_traffic_cfg{config_name}.json")
         if os.path.exists(path):
             with open(path) as fh:

@@ -21,6 +21,9 @@
 #include "wave_prims.h"
 #include "zstd_serial.h"
 
+#ifndef BAMD_ZSTD_LDS_FSE
+#define BAMD_ZSTD_LDS_FSE 0      // the three sequence tables of a frame compact in LDS (40 KiB per wave: 4 waves per CU).  Measured (8 GiB of reference-written frames, k_zstd_entropy): bench19 27.1 ms with, 28.8 without; linspace 14.5 with, 6.1 without - the lookups are not what the kernel waits for, the occupancy is what it needs.  Off.
+#endif
 namespace bamd {
 
 enum : uint32_t { ZM_FALLBACK = 0, ZM_READY = 1, ZM_ERROR = 2 };
@@ -55,7 +58,15 @@ __device__ __forceinline__ uint64_t* zseq_ptr(const uint8_t* lit, ptrdiff_t zseq
 template <bool GLOBAL>
 __global__ __launch_bounds__(64) void k_zstd_entropy_t(const StreamDesc* __restrict__ streams, int nstreams, const ChunkDesc* __restrict__ chunks,
                                                        const BlockDesc* __restrict__ blocks, ZMeta* __restrict__ meta, ptrdiff_t zseq_delta, ZgLds* __restrict__ gscr) {
-  __shared__ ZgLds lds[GLOBAL ? 1 : ZG_FRAMES];
+  __shared__ uint64_t lds_raw[GLOBAL ? 1 : (sizeof(ZgLds) * ZG_FRAMES + 7) / 8];
+  ZgLds* lds = (ZgLds*)lds_raw;
+  // Round 3 (GLOBAL only): the three SEQUENCE tables of every frame of the wave, compact, in LDS.  With all tables in the global
+  // scratch every FSE step was three dependent 4-byte reads out of an 8.4 KiB per-frame structure: 31 GB fetched to decode 0.3 GB
+  // (profiles/r02g_traffic_cfg4.json), ~7 us per sequence.  A cell is kept as symbol | x << 6 (x = the cell's "next state"
+  // counter, < 1024): 16 bits, from which nbBits = al - floor(log2 x) and baseline = (x << nbBits) - 2^al follow - so the
+  // largest tables the format allows (LL 512 + OF 256 + ML 512 cells) take 2.5 KiB per frame, 40 KiB per wave, 4 waves per CU.
+  // The Huffman table (4 KiB, used once per literal) and the build scratch stay global.
+  __shared__ uint16_t lfse[(GLOBAL && BAMD_ZSTD_LDS_FSE) ? ZG_FRAMES : 1][(GLOBAL && BAMD_ZSTD_LDS_FSE) ? 1280 : 4];
   const int lane = threadIdx.x & 63, g = lane >> 2, sub = lane & 3;
   const int sid = (int)blockIdx.x * ZG_FRAMES + g;
   ZgLds* L = GLOBAL ? gscr + (sid < nstreams ? sid : 0) : &lds[GLOBAL ? 0 : g];
@@ -186,8 +197,17 @@ __global__ __launch_bounds__(64) void k_zstd_entropy_t(const StreamDesc* __restr
       zd::Fse ft = {L->t.fse[sub], 0};
       built = zd::fse_build(ft, L->norm[sub], ns, al, L->next[sub]) ? 1u : 0u;
     }
+    if (GLOBAL && BAMD_ZSTD_LDS_FSE && take && gs == ZM_READY && gn > 0 && sub < 3 && kd >= 0 && built) {      // the lane that built a table packs it into LDS (RLE: one cell)
+      const int size = 1 << al, o = sub == 0 ? 0 : (sub == 1 ? 512 : 768);                    // LL | OF | ML
+      for (int i = 0; i < size; i++) {
+        const uint32_t e = L->t.fse[sub][i];
+        lfse[g][o + i] = (uint16_t)((e & 63u) | ((((e >> 16) + (uint32_t)size) >> ((e >> 8) & 0xffu)) << 6));
+      }
+    }
   }
   const uint32_t b1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src0 + 4, (int)built), b2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src0 + 8, (int)built);
+  // (lane 0 of a group reads below what lanes 1 and 2 packed into LDS above: lock step on the device; on the wavefront emulator the
+  //  two cross-lane reads of `built` just above are the rendezvous - lane 0 cannot get past them before lanes 1 and 2 arrive there)
   // ---- lane 0: the FSE sequence stream ----
   if (take && sub == 0) {
     if (state == ZM_READY && nseq > 0) {
@@ -197,6 +217,75 @@ __global__ __launch_bounds__(64) void k_zstd_entropy_t(const StreamDesc* __restr
       zd::SeqState st;
       st.rep[0] = 1u; st.rep[1] = 4u; st.rep[2] = 8u;
       if (fine) fine = size - p >= 1 && zd::seq_begin(st, tb, b + p, size - p);
+      if (GLOBAL) {
+        // zd::seq_next with the tables in LDS (same order of reads, same checks - zstd_serial.h is the specification and what the
+        // CPU tests pin to the reference); symbol codes above the format's limits cannot occur: a 6-bit symbol of a table whose
+        // description was accepted is at most 35 / 31 / 52 by fse_read_ncount's max_sym.
+        // Everything the loop carries is a plain local: SeqState's repeat offsets are an array indexed by a decoded value, which put
+        // the WHOLE state - bit reader included - on the stack (every field access a scratch load or store, every refill a flat load
+        // with a vmcnt(0) + lgkmcnt(0) behind it: the ISA of round 2's loop).  The bit stream is read through a global pointer, four
+        // bytes per refill, the NEXT refill's word already on its way.
+        const uint16_t* tl = &lfse[BAMD_ZSTD_LDS_FSE ? g : 0][0]; const uint16_t* to = &lfse[BAMD_ZSTD_LDS_FSE ? g : 0][BAMD_ZSTD_LDS_FSE ? 512 : 0]; const uint16_t* tm = &lfse[BAMD_ZSTD_LDS_FSE ? g : 0][BAMD_ZSTD_LDS_FSE ? 768 : 0];
+        const uint32_t* gl = L->t.fse[0]; const uint32_t* go = L->t.fse[1]; const uint32_t* gm = L->t.fse[2];      // (BAMD_ZSTD_LDS_FSE = 0: the tables where round 2 had them)
+        const int al_l = t_al[0], al_o = t_al[1], al_m = t_al[2];
+        const gu8* bp = as_global(st.b.p);
+        int bytepos = st.b.bytepos, nacc = st.b.nacc, off = st.b.off;
+        uint64_t acc = st.b.acc;
+        uint32_t sl = st.sl, so = st.so, sm = st.sm, r0 = 1u, r1 = 4u, r2 = 8u;
+        uint32_t nxt = bytepos >= 4 ? g_ld4(bp + bytepos - 4) : 0u;          // the word the next refill will take
+        auto rd = [&](int nb_) -> uint32_t {                                   // zd::back_read on the locals
+          if (nb_ == 0) return 0u;
+          if (nacc < nb_ && bytepos >= 4) {
+            bytepos -= 4; acc = (acc << 32) | nxt; nacc += 32;
+            if (bytepos >= 4) nxt = g_ld4(bp + bytepos - 4);
+          }
+          while (nacc < nb_ && bytepos > 0) { bytepos--; acc = (acc << 8) | bp[bytepos]; nacc += 8; }
+          if (nacc < nb_) { acc <<= (nb_ - nacc); nacc = nb_; }
+          const uint32_t v = (uint32_t)(acc >> (nacc - nb_)) & (nb_ >= 32 ? 0xffffffffu : ((1u << nb_) - 1u));
+          nacc -= nb_;
+          acc &= (nacc ? ((1ull << nacc) - 1ull) : 0ull);
+          off -= nb_;
+          return v;
+        };
+        for (int i = 0; fine && i < nseq; i++) {
+          uint32_t cl, co, cm;
+          if (BAMD_ZSTD_LDS_FSE) { cl = tl[sl]; co = to[so]; cm = tm[sm]; }
+          else {                                                                // the same compact form out of the 32-bit cells
+            const uint32_t el = gl[sl], eo = go[so], em = gm[sm];
+            cl = (el & 63u) | ((((el >> 16) + (1u << al_l)) >> ((el >> 8) & 0xffu)) << 6);
+            co = (eo & 63u) | ((((eo >> 16) + (1u << al_o)) >> ((eo >> 8) & 0xffu)) << 6);
+            cm = (em & 63u) | ((((em >> 16) + (1u << al_m)) >> ((em >> 8) & 0xffu)) << 6);
+          }
+          const int lc = (int)(cl & 63u), oc = (int)(co & 63u), mc = (int)(cm & 63u);
+          if (oc > 31 || mc > 52 || lc > 35) { fine = false; break; }
+          const uint32_t ov = (1u << oc) + rd(oc);
+          const uint32_t q_ml = zd::ml_base(mc) + rd(zd::ml_bits(mc));
+          const uint32_t q_ll = zd::ll_base(lc) + rd(zd::ll_bits(lc));
+          if (i + 1 != nseq) {
+            const uint32_t xl = cl >> 6, xm = cm >> 6, xo = co >> 6;
+            const int nl = al_l - zd::hb32(xl), nm = al_m - zd::hb32(xm), no = al_o - zd::hb32(xo);
+            sl = ((xl << nl) - (1u << al_l)) + rd(nl);
+            sm = ((xm << nm) - (1u << al_m)) + rd(nm);
+            so = ((xo << no) - (1u << al_o)) + rd(no);
+          }
+          if (off < 0) { fine = false; break; }
+          uint32_t q_off;
+          if (ov > 3) { q_off = ov - 3u; r2 = r1; r1 = r0; r0 = q_off; }
+          else {
+            uint32_t idx = ov - 1u;
+            if (q_ll == 0) idx++;
+            if (idx == 0) q_off = r0;
+            else {
+              q_off = idx == 1u ? r1 : (idx == 2u ? r2 : r0 - 1u);
+              if (q_off == 0) { fine = false; break; }
+              if (idx > 1) r2 = r1;
+              r1 = r0; r0 = q_off;
+            }
+          }
+          sq[i] = zpack(q_ll, q_ml, q_off);
+        }
+        st.b.off = off;
+      } else
       for (int i = 0; fine && i < nseq; i++) {
         zd::Seq q;
         if (!zd::seq_next(st, tb, i + 1 == nseq, q)) { fine = false; break; }

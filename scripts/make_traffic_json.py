@@ -24,9 +24,10 @@ for k in sorted(set(f) | set(w)):
     if "bamd::" not in k: continue
     name = k.split("bamd::")[-1]
     # kernels that bench.py reports under the name of their pipeline stage
-    if name.startswith("k_encode_streams_t<true>") or name.startswith("k_encode_streams_t<1>"): name = "k_zstd_encode"
-    elif name.startswith("k_encode_streams_t<2>"): name = "k_zlib_encode"
-    elif name.startswith("k_encode_streams_t"): name = "k_encode_streams"
+    if name.startswith("k_encode_streams_t<"):          # k_encode.hip: ENC_LZ 0, ENC_ZSTD 1, ENC_ZLIB 2, ENC_HC 3, ENC_ZSTD_T 4, ENC_ZSTD_HC 5, ENC_ZLIB_HC 6, ENC_ZSTD_TH 7, ENC_ZSTD_HCH 8, ENC_ZLIB_DYN 9, ENC_ZLIB_DYN_HC 10
+        mode = name[len("k_encode_streams_t<"):].split(">")[0]
+        name = {"true": "k_zstd_encode", "1": "k_zstd_encode", "4": "k_zstd_encode", "5": "k_zstd_encode", "7": "k_zstd_encode", "8": "k_zstd_encode",
+                "2": "k_zlib_encode", "6": "k_zlib_encode", "9": "k_zlib_encode", "10": "k_zlib_encode", "3": "k_lz4hc_encode"}.get(mode, "k_encode_streams")
     elif name.startswith("k_bitfilter_fast<0>"): name = "k_bitshuffle"
     elif name.startswith("k_bitfilter_fast<1>"): name = "k_bitunshuffle"
     elif name.startswith("k_decode_blocks<8, 8>"): name = "k_decode_blocks8"

@@ -6,13 +6,13 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 CFG=${CFG:-2}; TAG=${TAG:-r02}_cfg${CFG}
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_trace -o trace -- python bench.py --config $CFG --no-cpu-baseline > gpurun_out/${TAG}_bench_under_trace.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_trace -o trace -- python bench.py --config $CFG --no-cpu-baseline --no-extra > gpurun_out/${TAG}_bench_under_trace.log 2>&1
 grep '^{' gpurun_out/${TAG}_bench_under_trace.log | tail -1 > gpurun_out/${TAG}_bench_under_trace.json
 f=$(find gpurun_out/${TAG}_trace -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" gpurun_out/${TAG}_kernel_stats.csv && head -14 "$f" | cut -c1-160
 rm -rf gpurun_out/${TAG}_trace
 for PMC in FETCH_SIZE WRITE_SIZE; do
-  timeout 400 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d gpurun_out/${TAG}_pmc_$PMC -o pmc -- python bench.py --config $CFG --steps 1 --warmup 1 --no-cpu-baseline --no-verify --no-stock > gpurun_out/${TAG}_pmc_$PMC.log 2>&1
+  timeout 400 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d gpurun_out/${TAG}_pmc_$PMC -o pmc -- python bench.py --config $CFG --steps 1 --warmup 1 --no-cpu-baseline --no-verify --no-stock --no-extra > gpurun_out/${TAG}_pmc_$PMC.log 2>&1
   f=$(find gpurun_out/${TAG}_pmc_$PMC -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python - "$f" $PMC gpurun_out/${TAG}_pmc_$PMC.csv <<'PY'
 import csv, sys, collections
