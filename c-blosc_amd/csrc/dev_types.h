@@ -66,7 +66,7 @@ BAMD_HD inline size_t filt_block_stride(const ChunkDesc& c) {
 }
 // plane stride inside one block: split blocks of fused chunks are padded, everything else is the plain plane-major image
 BAMD_HD inline uint32_t filt_plane_stride(const ChunkDesc& c, uint32_t bsize, int nstreams) {
-  const uint32_t N = bsize / (uint32_t)(nstreams > 0 ? nstreams : 1);
+  const uint32_t N = bsize / (uint32_t)(c.typesize > 0 ? c.typesize : 1);      // bytes per plane (an unsplit block is ONE stream, but still typesize planes)
   return N + (((c.mode & CH_FUSED_UNSHUF) && nstreams == c.typesize && nstreams > 1) ? FILT_PLANE_PAD : 0u);
 }
 

@@ -35,7 +35,7 @@ __global__ void k_decode_plan(const ChunkDesc* __restrict__ chunks, const BlockD
   const int32_t neblock = bsize / b.nstreams;
   const bool to_filt = (c.mode & (CH_SHUFFLE | CH_BITSHUFFLE)) != 0;
   uint8_t* out = to_filt ? c.filt + (size_t)b.blk * filt_block_stride(c) : c.dst + (size_t)b.blk * c.blocksize;
-  const uint32_t pstride = to_filt ? filt_plane_stride(c, (uint32_t)bsize, b.nstreams) : (uint32_t)neblock;
+  const uint32_t pstride = (to_filt && b.nstreams > 1) ? filt_plane_stride(c, (uint32_t)bsize, b.nstreams) : (uint32_t)neblock;   // split blocks: one stream per plane
   int32_t off = ld_i32(c.src + 16 + 4 * (size_t)b.blk);
   bool bad = false;
   for (int j = 0; j < b.nstreams; j++) {

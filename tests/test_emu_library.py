@@ -87,6 +87,22 @@ def test_round_trips_through_the_c_abi(emulib, oracle, ref, cname):
     assert emulib.blosc_getitem(ptr(stock), 1000, 100, ptr(item)) == 800 and np.array_equal(item, data[8000:8800])
 
 
+def test_split_blocks_followed_by_an_unsplit_leftover_block(emulib, oracle, ref):
+    """A chunk whose last block is shorter than the block size: the full blocks are split into typesize streams (and unshuffled by the
+    decode kernel from one plane per stream), the leftover block is ONE stream holding all planes back to back - both layouts in one
+    chunk, through our own writer and the reference's.  (Round 3: a scratch-layout change had the unshuffle of the leftover block
+    read its planes one block apart; only the container test on the device noticed.)"""
+    for T, forced, bsize, n in ((4, 16384, 65536, 65536 * 2 + 5001), (8, 8192, 65536, 65536 + 12345)):      # (a splittable block is typesize x the forced size, blosc.c:1037-1048)
+        data = DATASETS["smallints" if T == 4 else "bench19"](n)
+        r, chunk = _compress(emulib, data, T, 5, 1, b"lz4", blocksize=forced)
+        assert r > 0 and header(chunk)["blocksize"] == bsize
+        _everybody_reads(emulib, oracle, ref, chunk, data)
+        ro, stock = orc_compress(oracle, data, T, 5, 1, "lz4", blocksize=forced)
+        assert header(stock)["blocksize"] == bsize
+        r2, out = _decompress(emulib, stock, n)
+        assert r2 == n and np.array_equal(out, data)
+
+
 SWITCHES = [
     (b"zstd", {"BLOSC_AMD_ZSTD_TABLES": "1"}),
     (b"zstd", {"BLOSC_AMD_ZSTD_TABLES": "1", "BLOSC_AMD_ZSTD_HUFFMAN": "1"}),
