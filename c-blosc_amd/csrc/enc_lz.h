@@ -1,6 +1,16 @@
 // enc_lz.h — the wave-parallel LZ match finders of the encode kernels (included by k_encode.hip inside namespace bamd):
 // lz_encode_wave (LZ4 / BloscLZ streams, and the front end of the Zstd / zlib writers through their sinks) and hc_encode_wave
 // (the LZ4HC-grade search), with the table, window and emit helpers they share.  DESIGN.md 3.3.
+// build switches of the round-3 changes (defaults are what bench.py measures; the others are kept for same-session A/B runs, scripts/enc_ab.py)
+#ifndef BAMD_ENC_WINSETTLE
+#define BAMD_ENC_WINSETTLE 1   // EncWindow: the prefetched dword is corrected behind the step's candidate wait (0: at once, as before round 3)
+#endif
+#ifndef BAMD_ENC_EXT1K
+#define BAMD_ENC_EXT1K 3      // wave_common_fwd: short first trips before the 2 KiB rows (1: 1 KiB, 2: 512 bytes, 3: 256 bytes then 1 KiB - 5 % / 11 % / 19 % of the kernel on bench19)
+#endif
+#ifndef BAMD_ENC_EMIT1
+#define BAMD_ENC_EMIT1 1      // lz4_emit_seq: a sequence with < 15 literals (in registers) and a match below 274 bytes leaves as ONE byte-store instruction
+#endif
 constexpr int ENC_WAVES = 1;       // one stream per workgroup: a slot frees up as soon as ITS stream is done
 // Table entry = position mod 65536 | 16 further hash bits as a tag << 16.  The tag lets a lane reject a
 // stale or colliding entry WITHOUT touching memory: untagged, nearly every lane of every step fetched 20
@@ -74,6 +84,52 @@ __device__ __forceinline__ uint32_t common16(const uint4& x, const uint4& y) {
 __device__ __forceinline__ uint32_t wave_common_fwd(const gu8* src, uint32_t n, uint32_t a, uint32_t b,
                                                     uint32_t maxlen, int lane) {
   uint32_t done = 0;
+#if BAMD_ENC_EXT1K == 3
+  if (maxlen && a + 256u <= n) {     // variant: 256 bytes
+    const uint32_t x = g_ld4(src + a + 4 * lane) ^ g_ld4(src + b + 4 * lane);
+    const uint32_t q = 4u * (uint32_t)lane;
+    uint32_t e0 = x ? (uint32_t)(__builtin_ctz(x) >> 3) : 4u;
+    const uint32_t r0 = q < maxlen ? maxlen - q : 0u;
+    if (e0 > r0) e0 = r0;
+    const uint64_t s0 = __ballot(e0 < 4u);
+    if (s0) { const int f = __builtin_ctzll(s0); return 4u * (uint32_t)f + (uint32_t)__builtin_amdgcn_readlane((int)e0, f); }
+    done = 256u;
+    if (done < maxlen && a + done + 1024u <= n) {      // second trip: 1 KiB
+      const uint4 x0 = g_ld16(src + a + done + 16 * lane), y0 = g_ld16(src + b + done + 16 * lane);
+      const uint32_t q1 = done + 16u * (uint32_t)lane;
+      uint32_t e1 = common16(x0, y0);
+      const uint32_t r1 = q1 < maxlen ? maxlen - q1 : 0u;
+      if (e1 > r1) e1 = r1;
+      const uint64_t s1 = __ballot(e1 < 16u);
+      if (s1) { const int f = __builtin_ctzll(s1); return done + 16u * (uint32_t)f + (uint32_t)__builtin_amdgcn_readlane((int)e1, f); }
+      done += 1024u;
+    }
+  }
+#elif BAMD_ENC_EXT1K == 2
+  if (maxlen && a + 512u <= n) {     // variant: 512 bytes
+    const uint64_t x = g_ld8(src + a + 8 * lane) ^ g_ld8(src + b + 8 * lane);
+    const uint32_t q = 8u * (uint32_t)lane;
+    uint32_t e0 = x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8u;
+    const uint32_t r0 = q < maxlen ? maxlen - q : 0u;
+    if (e0 > r0) e0 = r0;
+    const uint64_t s0 = __ballot(e0 < 8u);
+    if (s0) { const int f = __builtin_ctzll(s0); return 8u * (uint32_t)f + (uint32_t)__builtin_amdgcn_readlane((int)e0, f); }
+    done = 512u;
+  }
+#elif BAMD_ENC_EXT1K
+  // First trip: ONE 1 KiB row of each side.  Nearly every extension ends inside it (bench19's noisy planes: 385 of 386 per stream end
+  // within 256 bytes) - the 2 KiB-per-side trips below fetched 4 KiB for them.
+  if (maxlen && a + 1024u <= n) {
+    const uint4 x0 = g_ld16(src + a + 16 * lane), y0 = g_ld16(src + b + 16 * lane);
+    const uint32_t q = 16u * (uint32_t)lane;
+    uint32_t e0 = common16(x0, y0);
+    const uint32_t r0 = q < maxlen ? maxlen - q : 0u;
+    if (e0 > r0) e0 = r0;
+    const uint64_t s0 = __ballot(e0 < 16u);
+    if (s0) { const int f = __builtin_ctzll(s0); return 16u * (uint32_t)f + (uint32_t)__builtin_amdgcn_readlane((int)e0, f); }
+    done = 1024u;
+  }
+#endif
   while (done < maxlen && a + done + 2048u <= n) {
     const gu8* pa = src + a + done + 16 * lane;
     const gu8* pb = src + b + done + 16 * lane;
@@ -115,11 +171,15 @@ __device__ __forceinline__ uint32_t wave_common_fwd(const gu8* src, uint32_t n, 
   return maxlen;
 }
 
+#ifndef BAMD_ENC_NOSTORE
+#define BAMD_ENC_NOSTORE 0    // experiment only (wrong output): the LZ4 emitter computes everything and stores nothing - what the stores cost
+#endif
+#define ENC_ST1(ptr, val) do { if (!BAMD_ENC_NOSTORE) *(ptr) = (val); } while (0)
 // write `v` as LZ4's 255-run length extension starting at p; returns bytes written
 __device__ __forceinline__ uint32_t emit_ext255(gu8* p, uint32_t v, int lane) {
   const uint32_t n255 = v / 255u, rem = v - n255 * 255u;
-  for (uint32_t k = (uint32_t)lane; k < n255; k += 64u) p[k] = 255u;
-  if (lane == 0) p[n255] = (uint8_t)rem;
+  for (uint32_t k = (uint32_t)lane; k < n255; k += 64u) ENC_ST1(p + k, (uint8_t)255u);
+  if (lane == 0) ENC_ST1(p + n255, (uint8_t)rem);
   return n255 + 1u;
 }
 
@@ -203,9 +263,9 @@ __device__ __forceinline__ uint32_t dfl_emit_seq(DflSink& z, const gu8* lit, uin
 __device__ __forceinline__ void emit_literals(gu8* dst, const gu8* lit, uint32_t ll, int lit_lane0, uint32_t ownbyte, int lane) {
   if (lit_lane0 >= 0 && ll <= 64u && (uint32_t)lit_lane0 + ll <= 64u) {
     const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lit_lane0 + (uint32_t)lane) & 63u) << 2, (int)ownbyte);
-    if ((uint32_t)lane < ll) dst[lane] = (uint8_t)v;
+    if ((uint32_t)lane < ll) ENC_ST1(dst + lane, (uint8_t)v);
   } else {
-    wave_copy_disjoint(dst, lit, ll, lane);
+    if (!BAMD_ENC_NOSTORE) wave_copy_disjoint(dst, lit, ll, lane);
   }
 }
 
@@ -213,13 +273,27 @@ __device__ __forceinline__ uint32_t lz4_emit_seq(gu8* dst, uint32_t op, uint32_t
                                                  uint32_t ll, uint32_t off, uint32_t mlen, int lit_lane0, uint32_t ownbyte, int lane) {
   if (op + 1u + ll + (2u + 1u + 5u) + ll / 255u > cap) return 0xffffffffu;
   const uint32_t mcode = mlen - 4u;
+  if (BAMD_ENC_EMIT1 && ll < 15u && mcode < 15u + 255u && (ll == 0u || (lit_lane0 >= 0 && (uint32_t)lit_lane0 + ll <= 64u))) {
+    // the common shape (bench19's noisy planes: 1150 of 1163 sequences): token, <= 14 literals out of this step's registers, offset, at most one
+    // length byte - lane j holds byte j of the sequence, one store.  Same bytes and the same two budget checks as the general path below.
+    if (op + 1u + ll + 2u + (1u + 5u) + (mcode + 240u) / 255u > cap) return 0xffffffffu;
+    const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lit_lane0 + (uint32_t)lane - 1u) & 63u) << 2, (int)ownbyte);
+    uint32_t b = v;
+    b = lane == 0 ? ((ll << 4) | (mcode < 15u ? mcode : 15u)) : b;
+    b = (uint32_t)lane == ll + 1u ? off : b;
+    b = (uint32_t)lane == ll + 2u ? off >> 8 : b;
+    b = (uint32_t)lane == ll + 3u ? mcode - 15u : b;
+    const uint32_t total = ll + 3u + (mcode >= 15u ? 1u : 0u);
+    if ((uint32_t)lane < total) ENC_ST1(dst + op + lane, (uint8_t)b);
+    return op + total;
+  }
   const uint32_t tok = ((ll < 15u ? ll : 15u) << 4) | (mcode < 15u ? mcode : 15u);
-  if (lane == 0) dst[op] = (uint8_t)tok;
+  if (lane == 0) ENC_ST1(dst + op, (uint8_t)tok);
   op += 1u;
   if (ll >= 15u) op += emit_ext255(dst + op, ll - 15u, lane);
   emit_literals(dst + op, lit, ll, lit_lane0, ownbyte, lane);
   op += ll;
-  if (lane < 2) dst[op + lane] = (uint8_t)(off >> (8 * lane));
+  if (lane < 2) ENC_ST1(dst + op + lane, (uint8_t)(off >> (8 * lane)));
   op += 2u;
   if (op + (1u + 5u) + (mcode + 240u) / 255u > cap) return 0xffffffffu;
   if (mcode >= 15u) op += emit_ext255(dst + op, mcode - 15u, lane);
@@ -289,17 +363,24 @@ __device__ __forceinline__ uint32_t blz_emit_match(gu8* dst, uint32_t op, uint32
 //            findable
 //   round 3  backward + forward extension loads are issued together; then the sequence is emitted.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t RANK_CAP = 20u;   // bytes of a candidate that are compared for ranking (16 instead: more extensions, lower ratio, no faster)
-
-#ifndef BAMD_ENC_BACK8
-#define BAMD_ENC_BACK8 0      // backward extension from registers (lz_encode_wave, round 3): bit-identical output, but no gain on the device (profiles/r03l_enc_ab_back8_no_gain.txt: the "extension" phase is not waiting for its own loads) - off
+#ifndef BAMD_ENC_RANK_CAP
+#define BAMD_ENC_RANK_CAP 20
 #endif
+constexpr uint32_t RANK_CAP = BAMD_ENC_RANK_CAP;   // bytes of a candidate that are compared for ranking (16 instead: more extensions, lower ratio, no faster)
+
+#ifndef BAMD_ENC_BACKN
+#define BAMD_ENC_BACKN 0      // backward extension from registers (lz_encode_wave, round 3): bit-identical output, both forms measured and off.
+                              // 8: the 8 bytes in front of a candidate come with one more load per lane and step - no gain (profiles/r03l_enc_ab_back8_no_gain.txt).
+                              // 4: the candidate's 24 bytes [cand - 4, cand + 20) come as 8 + 16 instead of 16 + 4, no extra instruction - 3 % SLOWER
+                              // (profiles/r03x_enc_ab_back4_ext512.txt): the kernel is not waiting for these round trips, it pays for bytes and instructions
+#endif
+#define BAMD_ENC_BACK8 (BAMD_ENC_BACKN != 0)
 struct Bytes20 { uint64_t a, b; uint32_t c; };
 
 // 20 bytes at src[pos..], zero beyond n (only the last step of a stream takes the slow branch)
 __device__ __forceinline__ Bytes20 load20(const gu8* src, uint32_t pos, uint32_t n) {
   Bytes20 r;
-  if (pos + 20u <= n) { r.a = g_ld8(src + pos); r.b = g_ld8(src + pos + 8u); r.c = g_ld4(src + pos + 16u); }
+  if (pos + 20u <= n) { r.a = g_ld8(src + pos); r.b = g_ld8(src + pos + 8u); r.c = RANK_CAP > 16u ? g_ld4(src + pos + 16u) : 0u; }
   else {
     r.a = 0; r.b = 0; r.c = 0;
     for (uint32_t k = 0; k < 20u && pos + k < n; k++) {
@@ -347,32 +428,55 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // own 20 bytes per lane with ds_bpermutes from here instead of a memory round trip.
 // ---------------------------------------------------------------------------------------------
 struct EncWindow {
-  uint32_t w0, w1, w2;
+  uint32_t w0, w1, w2;     // while `pending`, w2 is RAW: the dword as loaded, not yet corrected for the end of the stream.  settle() corrects it,
+                           // and the step calls settle() right behind its wait for the candidate bytes - where every older load has landed anyway.
+                           // Correcting it inside seek() made the wave wait for the load it had just issued (the shift is the load's first use): a
+                           // full memory round trip every 256 bytes instead of a prefetch; correcting it at the next rotation still waited for
+                           // the stores of the step before (the one in-order counter).
+  bool pending;            // uniform
   uint32_t wbase;          // uniform, multiple of 256
   const gu8* src;
   uint32_t n;
 
   // dword at stream offset base + 4*lane; bytes at or beyond n read as zero.  Branch-free: a dword that
   // would cross the end is read at n-4 instead and shifted down (n >= 13 here).
-  __device__ __forceinline__ uint32_t fetch(uint32_t base, int lane) const {
+  __device__ __forceinline__ uint32_t fetch_raw(uint32_t base, int lane) const {
+    const uint32_t off = base + 4u * (uint32_t)lane;
+    const uint32_t a = off < n - 4u ? off : n - 4u;
+    return g_ld4(src + a);
+  }
+  __device__ __forceinline__ uint32_t fix(uint32_t v, uint32_t base, int lane) const {
     const uint32_t off = base + 4u * (uint32_t)lane;
     const uint32_t a = off < n - 4u ? off : n - 4u;
     const uint32_t sh = off - a;                       // 0 in the body of the stream
-    const uint32_t v = g_ld4(src + a);
     return sh < 4u ? v >> (8u * sh) : 0u;
+  }
+  __device__ __forceinline__ uint32_t fetch(uint32_t base, int lane) const { return fix(fetch_raw(base, lane), base, lane); }
+  __device__ __forceinline__ void settle(int lane) {
+    // a select, not a branch: w2 must be the result of an ALU instruction on EVERY path through the step, or the next rotation waits for
+    // "a load that may still be in flight" - with vmcnt(0), i.e. for the emitter's stores
+    const uint32_t fixed = fix(w2, wbase + 512u, lane);
+    w2 = pending ? fixed : w2;
+    pending = false;
+#ifndef BAMD_WAVE_EMU
+    asm volatile("; window settled" : "+v"(w2));       // keeps the correction HERE (the compiler sank it to the end of the step, behind the emitter's stores)
+#endif
   }
   __device__ __forceinline__ void init(const gu8* s, uint32_t n_, int lane) {
     src = s; n = n_; wbase = 0;
-    w0 = fetch(0u, lane); w1 = fetch(256u, lane); w2 = fetch(512u, lane);
+    w0 = fetch(0u, lane); w1 = fetch(256u, lane); w2 = fetch(512u, lane); pending = false;
   }
   // make [lo, lo + 256 + 92) resident in w0/w1, lo = max(ip - 4, 0); ip only moves forward
   __device__ __forceinline__ void seek(uint32_t ip, int lane) {
     const uint32_t lo = ip >= 4u ? ip - 4u : 0u;
     const uint32_t d = lo - wbase;
     if (d < 256u) return;
-    if (d < 512u) { w0 = w1; w1 = w2; wbase += 256u; w2 = fetch(wbase + 512u, lane); }
-    else if (d < 768u) { w0 = w2; wbase += 512u; w1 = fetch(wbase + 256u, lane); w2 = fetch(wbase + 512u, lane); }
-    else { wbase = lo & ~255u; w0 = fetch(wbase, lane); w1 = fetch(wbase + 256u, lane); w2 = fetch(wbase + 512u, lane); }
+    // w2 is settled here: every step calls settle() after its seek(), init() leaves it settled
+    if (d < 512u) { w0 = w1; w1 = w2; wbase += 256u; }
+    else if (d < 768u) { w0 = w2; wbase += 512u; w1 = fetch(wbase + 256u, lane); }
+    else { wbase = lo & ~255u; w0 = fetch(wbase, lane); w1 = fetch(wbase + 256u, lane); }
+    if (BAMD_ENC_WINSETTLE) { w2 = fetch_raw(wbase + 512u, lane); pending = true; }
+    else w2 = fetch(wbase + 512u, lane);
   }
 };
 
@@ -435,11 +539,11 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
     const uint32_t o2 = __builtin_amdgcn_alignbyte(x3, x2, sh), o3 = __builtin_amdgcn_alignbyte(x4, x3, sh);
     const uint32_t o4 = __builtin_amdgcn_alignbyte(x5, x4, sh);
     Bytes20 own;
-    own.a = ((uint64_t)o1 << 32) | o0; own.b = ((uint64_t)o3 << 32) | o2; own.c = o4;
+    own.a = ((uint64_t)o1 << 32) | o0; own.b = ((uint64_t)o3 << 32) | o2; own.c = RANK_CAP > 16u ? o4 : 0u;
     // the two bytes before ip (uniform): r's lanes 0/1 hold them
     const uint64_t r01 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)r, 1) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)r, 0);
     const uint32_t before2 = bo0 >= 2u ? (uint32_t)(r01 >> (8u * (bo0 - 2u))) & 0xffffu : 0u;   // src[ip-2] | src[ip-1] << 8
-    uint32_t prev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane - 1u) & 63u) << 2, (int)(o0 & 0xffu));
+    uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(o0 & 0xffu), 0x138, 0xf, 0xf, false);   // wave_shr:1 - the byte of the lane below, without the LDS pipe
     if (lane == 0) prev = ip ? (bo0 >= 2u ? before2 >> 8 : (uint32_t)(r01 >> (8u * (bo0 - 1u))) & 0xffu) : 0x100u;
     if (ins_pending) {
       const uint32_t m2 = enc_mix(before2 | (o0 << 16));
@@ -470,8 +574,16 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
     uint64_t cbk = 0;
     bool has_back = false;
     if (tab_ok) {
-      const Bytes20 cb = load20(src, cand, n);
-      if (BAMD_ENC_BACK8 && cand >= 8u) { cbk = g_ld8(src + cand - 8u); has_back = true; }
+      Bytes20 cb;
+      if (BAMD_ENC_BACKN == 4 && cand >= 4u && cand + 20u <= n) {
+        const uint64_t lo = g_ld8(src + cand - 4u);
+        const uint4 hi = g_ld16(src + cand + 4u);
+        cbk = lo << 32; has_back = true;
+        cb.a = (lo >> 32) | ((uint64_t)hi.x << 32); cb.b = (uint64_t)hi.y | ((uint64_t)hi.z << 32); cb.c = hi.w;
+      } else {
+        cb = load20(src, cand, n);
+        if (BAMD_ENC_BACKN == 8 && cand >= 8u) { cbk = g_ld8(src + cand - 8u); has_back = true; }
+      }
       len = common20(own, cb);
       if (len > limit) len = limit;
       if (len < minlen) len = 0;
@@ -482,6 +594,7 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
       if (rl > limit) rl = limit;
       if (rl >= minlen && rl > len) { len = rl; cand = p - 1u; has_back = false; }
     }
+    win.settle(lane);                               // behind the wait for the candidates: free
     // ---- select + emit.  The winner maximises (len - lane), ties to the lower lane.  When its match
     // ends inside this step's 64 positions, the lanes behind it still hold valid candidates: pick
     // again among them instead of paying a new probe + candidate round trip for a short advance. ----
@@ -509,7 +622,8 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
       bool back_known = maxb == 0u;
       if (BAMD_ENC_BACK8 && !back_known && (uint32_t)__builtin_amdgcn_readlane((int)(has_back ? 1u : 0u), f)) {
         const uint32_t q = bo0 + (uint32_t)f;                       // >= 4 (or ip + f at the stream's start)
-        uint32_t nb = maxb < 8u ? maxb : 8u;
+        constexpr uint32_t NB = BAMD_ENC_BACKN == 4 ? 4u : 8u;      // bytes of cbk that are real
+        uint32_t nb = maxb < NB ? maxb : NB;
         if (q < nb) nb = q;
         const uint32_t q8 = q >= 8u ? q - 8u : 0u;                  // first of the (up to) 8 own bytes in r's byte space
         const uint32_t i0 = q8 >> 2;
@@ -519,22 +633,30 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
         uint64_t own8 = shb ? ((((uint64_t)d1 << 32) | d0) >> shb) | ((uint64_t)d2 << (64u - shb)) : (((uint64_t)d1 << 32) | d0);   // bytes q8 .. q8 + 7
         if (q < 8u) own8 <<= 8u * (8u - q);                         // fewer than 8 bytes in front of pm: line the last one up with the top byte
         const uint64_t c8 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cbk >> 32), f) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cbk, f);
-        const uint64_t x = own8 ^ c8;
-        const uint32_t eq = x ? (uint32_t)__builtin_clzll(x) >> 3 : 8u;   // equal bytes counted from src[pm - 1] / src[cm - 1] downwards
+        const uint64_t x = NB == 4u ? (own8 ^ c8) | 0x00000000ffffffffull : own8 ^ c8;
+        const uint32_t eq = x ? (uint32_t)__builtin_clzll(x) >> 3 : 8u;   // equal bytes counted from src[pm - 1] / src[cm - 1] downwards (<= NB)
         if (eq < nb) { back = eq; back_known = true; }
         else if (nb == maxb) { back = nb; back_known = true; }            // ran to the allowed limit
         // else: equal as far as the registers reach - the memory path below finds the end
       }
       // otherwise backward bytes are requested first and looked at last, so that they travel together with the
       // forward rows (one memory round trip for both directions)
+      // Every lane loads (lanes >= maxb a harmless byte): a load under a per-lane condition is compared where it is issued - the
+      // compiler then waits for it at once (the ISA had "load, load, s_waitcnt vmcnt(0)" here) and the forward rows became a second trip.
       uint32_t bx = 0, by = 1;
-      if (!back_known && (uint32_t)lane < maxb) { bx = src[pm - 1u - (uint32_t)lane]; by = src[cm - 1u - (uint32_t)lane]; }
+      if (!back_known) {                                 // uniform
+        const bool bl = (uint32_t)lane < maxb;
+        bx = src[bl ? pm - 1u - (uint32_t)lane : pm]; by = src[bl ? cm - 1u - (uint32_t)lane : cm];
+      }
       asm volatile("" ::: "memory");
       uint32_t mlen = len_f;
       if (len_f == RANK_CAP && pm + RANK_CAP < mlimit)
         mlen += wave_common_fwd(src, n, pm + RANK_CAP, cm + RANK_CAP, mlimit - (pm + RANK_CAP), lane);
+#ifndef BAMD_WAVE_EMU
+      asm volatile("; back bytes looked at here" : "+v"(bx), "+v"(by) :: "memory");   // or the comparison is hoisted to the loads, wait included
+#endif
       if (!back_known) {
-        const uint64_t bm = __ballot(bx != by);          // lanes >= maxb always vote "differs"
+        const uint64_t bm = __ballot((uint32_t)lane >= maxb || bx != by);
         back = bm ? (uint32_t)__builtin_ctzll(bm) : 64u;
       }
       PROF_LAP(10); PROF_ADD(2, len_f == RANK_CAP); PROF_ADD(3, anchor < ip && pm > anchor); PROF_ADD(6, 1); PROF_ADD(7, back > 0); if (FMT != EF_ZSTD) { PROF_ADD(4, back > 4); PROF_ADD(5, maxb > 0); }
@@ -688,7 +810,7 @@ __device__ uint32_t hc_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
     own.a = ((uint64_t)o1 << 32) | o0; own.b = ((uint64_t)o3 << 32) | o2; own.c = o4;
     const uint64_t r01 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)r, 1) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)r, 0);
     const uint32_t before2 = bo0 >= 2u ? (uint32_t)(r01 >> (8u * (bo0 - 2u))) & 0xffffu : 0u;   // src[ip-2] | src[ip-1] << 8
-    uint32_t prev = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lane - 1u) & 63u) << 2, (int)(o0 & 0xffu));
+    uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(o0 & 0xffu), 0x138, 0xf, 0xf, false);   // wave_shr:1 - the byte of the lane below, without the LDS pipe
     if (lane == 0) prev = ip ? (bo0 >= 2u ? before2 >> 8 : (uint32_t)(r01 >> (8u * (bo0 - 1u))) & 0xffu) : 0x100u;
     if (!live) prev = 0x100u;
     if (ins_pending) {
@@ -728,6 +850,7 @@ __device__ uint32_t hc_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
       lw[2] = ((okm & 4u) && l2 >= minlen) ? l2 : 0u;
       lw[3] = ((okm & 8u) && l3 >= minlen) ? l3 : 0u;
     }
+    win.settle(lane);
     cw[4] = 0u; lw[4] = 0u;
     if (prev < 0x100u) {                                           // distance 1: run of the previous byte
       uint32_t rl = runlen20(own, prev);
@@ -786,12 +909,18 @@ __device__ uint32_t hc_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
       if (cm < maxb) maxb = cm;
       if (maxb > 64u) maxb = 64u;
       uint32_t bx = 0, by = 1;
-      if ((uint32_t)lane < maxb) { bx = src[pm - 1u - (uint32_t)lane]; by = src[cm - 1u - (uint32_t)lane]; }
+      if (maxb) {                                        // uniform; every lane loads (see lz_encode_wave)
+        const bool bl = (uint32_t)lane < maxb;
+        bx = src[bl ? pm - 1u - (uint32_t)lane : pm]; by = src[bl ? cm - 1u - (uint32_t)lane : cm];
+      }
       asm volatile("" ::: "memory");
       uint32_t mlen = len_f;
       if (!exact_f && pm + len_f < mlimit)
         mlen += wave_common_fwd(src, n, pm + len_f, cm + len_f, mlimit - (pm + len_f), lane);
-      const uint64_t bm = __ballot(bx != by);          // lanes >= maxb always vote "differs"
+#ifndef BAMD_WAVE_EMU
+      asm volatile("; back bytes looked at here" : "+v"(bx), "+v"(by) :: "memory");
+#endif
+      const uint64_t bm = __ballot((uint32_t)lane >= maxb || bx != by);
       const uint32_t back = bm ? (uint32_t)__builtin_ctzll(bm) : 64u;
       pm -= back; cm -= back; mlen += back;
       if (FMT == EF_LZ4) {

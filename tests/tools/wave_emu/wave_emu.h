@@ -139,6 +139,10 @@ inline uint32_t dpp(uint32_t old, uint32_t src, int ctrl, bool bound_ctrl, const
     if ((l & 15) + n <= 15) return (uint32_t)fetch(k, l + n, where);
     return bound_ctrl ? 0u : old;
   }
+  if (ctrl == 0x138) {                                // wave_shr:1 (GFX9): lane l <- lane l-1 across the whole wave
+    if (l >= 1) return (uint32_t)fetch(k, l - 1, where);
+    return bound_ctrl ? 0u : old;
+  }
   fail("DPP control not modelled", where);
 }
 // explicit lock-step point for code that communicates through memory between cross-lane instructions
