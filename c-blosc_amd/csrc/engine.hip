@@ -51,6 +51,7 @@ struct DeviceArena {   // one grow-only device allocation carved up per call
     size_t want = align_up(bytes + bytes / 8, 1 << 20);
     HIP_TRY(hipMalloc((void**)&base, want));
     cap = want;
+    if (getenv("BLOSC_AMD_DEBUG")) fprintf(stderr, "[blosc_amd] device arena %p, %zu MiB\n", (void*)base, want >> 20);
     return 0;
   }
   void release() { if (base) (void)hipFree(base); base = nullptr; cap = 0; }

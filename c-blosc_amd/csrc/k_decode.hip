@@ -34,6 +34,9 @@ __global__ void k_decode_plan(const ChunkDesc* __restrict__ chunks, const BlockD
   const int32_t bsize = b.bsize;
   const int32_t neblock = bsize / b.nstreams;
   const bool to_filt = (c.mode & (CH_SHUFFLE | CH_BITSHUFFLE)) != 0;
+  // (Round 3 tried the scratch of block g at slot g % S of ONE arena - 768 ... 1536 slots, without any synchronisation, i.e. the most a ring of
+  //  block slots could ever give: no change, profiles/r03zd_dec_ab_block_slot_ring_no_gain.txt.  Address reuse does not bring the round trip
+  //  into the Infinity Cache while a block's scratch lives as long as its slowest stream.)
   uint8_t* out = to_filt ? c.filt + (size_t)b.blk * filt_block_stride(c) : c.dst + (size_t)b.blk * c.blocksize;
   const uint32_t pstride = (to_filt && b.nstreams > 1) ? filt_plane_stride(c, (uint32_t)bsize, b.nstreams) : (uint32_t)neblock;   // split blocks: one stream per plane
   int32_t off = ld_i32(c.src + 16 + 4 * (size_t)b.blk);

@@ -80,7 +80,10 @@ inline void build_encode_queues(const std::vector<BlockDesc>& blocks, const std:
 // With cost feedback the expensive planes of block i + kDecLead are queued together with the cheap planes of
 // block i: blocks still complete in order (the unshuffles stay spread over the whole kernel), but the
 // streams drawn last - the kernel's tail - are cheap ones.
-constexpr size_t kDecLead = 256;
+#ifndef BAMD_DEC_LEAD
+#define BAMD_DEC_LEAD 256
+#endif
+constexpr size_t kDecLead = BAMD_DEC_LEAD;
 inline void build_xcd_queues(const std::vector<BlockDesc>& blocks, size_t nstr, const uint32_t* cost, bool cost_valid,
                              std::vector<int32_t>& out, int nq = 8) {
   std::vector<int32_t> q[8];

@@ -38,7 +38,7 @@ for spec in os.environ.get("DECSETS", "bench19:1:8").split():
     res = [[] for _ in mods]
     for m, b in zip(mods, batches):
         back.zero_(); b.decompress(); b.decompress()
-        assert b.results() == [csz] * nchunks and bool((back[0] == want).all()) and bool((back[-1] == want).all()), m.LIB_PATH
+        assert os.environ.get("NOCHECK") or (b.results() == [csz] * nchunks and bool((back[0] == want).all()) and bool((back[-1] == want).all())), m.LIB_PATH
     for _ in range(rounds):
         for k, (m, b) in enumerate(zip(mods, batches)):
             L = m.load()
