@@ -82,6 +82,7 @@ struct BlockDesc {
 };
 enum : int32_t {
   BLK_LDS = 1,          // decompress: the block is decoded by k_decode_blocks (one workgroup, LDS-resident planes), not by k_decode_streams
+  BLK_Z = 2,            // decompress: a block of a Zstd / zlib chunk: every stream of it belongs to k_zstd_* / k_zlib_streams, k_decode_streams' queues leave it out
 };
 
 struct StreamDesc {

@@ -1,7 +1,7 @@
 // enc_shuffle.h — the byte shuffle as work of the encode kernel's own waves (included by k_encode.hip inside namespace bamd):
 // shuffle_block_wave_T, the periodic-plane detection, shuffle_block_task, emit_periodic_stream.  DESIGN.md 3.3.
 // ---------------------------------------------------------------------------------------------
-// Fused byte shuffle of one block by ONE wavefront (typesize 4 or 8): element-major source -> plane-major
+// Fused byte shuffle of one block by ONE wavefront (typesize 2, 4, 8 or 16): element-major source -> plane-major
 // scratch (blosc/shuffle-generic.h:27-58).  The mirror image of unshuffle_block_wave in k_decode.hip: per
 // step lane l loads the T*4 contiguous bytes of elements e+4l..e+4l+3 (coalesced 16-byte loads), transposes
 // bytes in registers and stores 4 bytes into every plane (each wave store writes 256 contiguous bytes).
@@ -35,10 +35,69 @@ __device__ __forceinline__ void shuffle_store(gu8* dst, uint32_t N, uint32_t e, 
     g_st4(o, r0); g_st4(o + (size_t)N, r1); g_st4(o + 2 * (size_t)N, r2); g_st4(o + 3 * (size_t)N, r3);
   }
 }
+// Typesize 2 and 16 (round 3; blosc/shuffle-generic.h:27-58 is the same loop for every typesize): the same step - lane l owns
+// elements e + 4l .. e + 4l + 3 and ends up with 4 bytes of every plane - with 8 bytes (T = 2) or 64 bytes (T = 16) per lane.
+struct ElemRows2 { uint32_t lo, hi; };                   // (e0b0 e0b1 e1b0 e1b1), (e2b0 e2b1 e3b0 e3b1)
+struct ElemRows16 { uint4 v[4]; };                       // element k of the lane: bytes 0-3, 4-7, 8-11, 12-15
+__device__ __forceinline__ ElemRows2 shuffle_load2(const gu8* src, uint32_t e, int lane) {
+  const uint64_t w = g_ld8(src + (size_t)(e + 4u * (uint32_t)lane) * 2u);
+  ElemRows2 x; x.lo = (uint32_t)w; x.hi = (uint32_t)(w >> 32);
+  return x;
+}
+__device__ __forceinline__ void shuffle_rows2(const ElemRows2& x, uint32_t (&r)[16]) {
+  r[0] = __builtin_amdgcn_perm(x.hi, x.lo, 0x06040200u);       // byte 0 of elements 0..3
+  r[1] = __builtin_amdgcn_perm(x.hi, x.lo, 0x07050301u);       // byte 1
+}
+__device__ __forceinline__ ElemRows16 shuffle_load16(const gu8* src, uint32_t e, int lane) {
+  const gu8* in = src + (size_t)(e + 4u * (uint32_t)lane) * 16u;
+  ElemRows16 x;
+#pragma unroll
+  for (int k = 0; k < 4; k++) x.v[k] = g_ld16(in + 16 * k);
+  return x;
+}
+__device__ __forceinline__ void shuffle_rows16(const ElemRows16& x, uint32_t (&r)[16]) {
+  transpose4x4(x.v[0].x, x.v[1].x, x.v[2].x, x.v[3].x, r[0], r[1], r[2], r[3]);
+  transpose4x4(x.v[0].y, x.v[1].y, x.v[2].y, x.v[3].y, r[4], r[5], r[6], r[7]);
+  transpose4x4(x.v[0].z, x.v[1].z, x.v[2].z, x.v[3].z, r[8], r[9], r[10], r[11]);
+  transpose4x4(x.v[0].w, x.v[1].w, x.v[2].w, x.v[3].w, r[12], r[13], r[14], r[15]);
+}
+template <int T>
+__device__ __forceinline__ void shuffle_store_rows(gu8* dst, uint32_t N, uint32_t e, int lane, const uint32_t (&r)[16]) {
+  gu8* o = dst + e + 4u * (uint32_t)lane;
+#pragma unroll
+  for (int k = 0; k < T; k++) g_st4(o + (size_t)k * N, r[k]);
+}
+// whole-row part of a block (N / 256 steps); the tails are the caller's
+__device__ __forceinline__ uint32_t shuffle_block_rows2(const gu8* src, gu8* dst, uint32_t N, int lane) {
+  uint32_t e = 0, r[16];
+  for (; e + 1024u <= N; e += 1024u) {   // 4 steps per iteration: all loads are issued before the first store
+    const ElemRows2 a = shuffle_load2(src, e, lane), b = shuffle_load2(src, e + 256u, lane);
+    const ElemRows2 c = shuffle_load2(src, e + 512u, lane), d = shuffle_load2(src, e + 768u, lane);
+    shuffle_rows2(a, r); shuffle_store_rows<2>(dst, N, e, lane, r);
+    shuffle_rows2(b, r); shuffle_store_rows<2>(dst, N, e + 256u, lane, r);
+    shuffle_rows2(c, r); shuffle_store_rows<2>(dst, N, e + 512u, lane, r);
+    shuffle_rows2(d, r); shuffle_store_rows<2>(dst, N, e + 768u, lane, r);
+  }
+  for (; e + 256u <= N; e += 256u) { shuffle_rows2(shuffle_load2(src, e, lane), r); shuffle_store_rows<2>(dst, N, e, lane, r); }
+  return e;
+}
+__device__ __forceinline__ uint32_t shuffle_block_rows16(const gu8* src, gu8* dst, uint32_t N, int lane) {
+  uint32_t e = 0, r[16];
+  for (; e + 512u <= N; e += 512u) {     // 2 steps per iteration (8 KiB of loads in flight per wave, as for typesize 8)
+    const ElemRows16 a = shuffle_load16(src, e, lane), b = shuffle_load16(src, e + 256u, lane);
+    shuffle_rows16(a, r); shuffle_store_rows<16>(dst, N, e, lane, r);
+    shuffle_rows16(b, r); shuffle_store_rows<16>(dst, N, e + 256u, lane, r);
+  }
+  for (; e + 256u <= N; e += 256u) { shuffle_rows16(shuffle_load16(src, e, lane), r); shuffle_store_rows<16>(dst, N, e, lane, r); }
+  return e;
+}
 template <int T>
 __device__ void shuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize, int lane) {
   const uint32_t N = bsize / T;
   uint32_t e = 0;
+  if constexpr (T == 2) e = shuffle_block_rows2(src, dst, N, lane);
+  else if constexpr (T == 16) e = shuffle_block_rows16(src, dst, N, lane);
+  else {
   for (; e + 1024u <= N; e += 1024u) {   // 4 steps per iteration: all loads are issued before the first store
     const ElemRows<T> a = shuffle_load<T>(src, e, lane), b = shuffle_load<T>(src, e + 256u, lane);
     const ElemRows<T> c = shuffle_load<T>(src, e + 512u, lane), d = shuffle_load<T>(src, e + 768u, lane);
@@ -46,6 +105,7 @@ __device__ void shuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize, i
     shuffle_store<T>(dst, N, e + 512u, lane, c); shuffle_store<T>(dst, N, e + 768u, lane, d);
   }
   for (; e + 256u <= N; e += 256u) shuffle_store<T>(dst, N, e, lane, shuffle_load<T>(src, e, lane));
+  }
   // tail: fewer than 256 elements, then the bytes that do not form a whole element (copied as they are)
   for (uint32_t k = e * T + (uint32_t)lane; k < N * T; k += 64u) { const uint32_t el = k / T, j = k - el * T; dst[(size_t)j * N + el] = src[k]; }
   for (uint32_t k = N * T + (uint32_t)lane; k < bsize; k += 64u) dst[k] = src[k];
@@ -123,16 +183,71 @@ __device__ uint32_t shuffle_block_wave_detect(const gu8* src, gu8* dst, uint32_t
   return per;
 }
 
+// The same for typesize 2 and 16 (rows through shuffle_rows2 / shuffle_rows16).  Typesize 16 keeps one step in flight
+// (64 bytes per lane: 4 KiB per wave; the row registers of 16 planes and their first rows take the rest of the budget).
+template <int T>
+__device__ uint32_t shuffle_block_wave_detect_x(const gu8* src, gu8* dst, uint32_t bsize, int lane, uint32_t (&period)[16]) {
+  static_assert(T == 2 || T == 16, "typesize 4 / 8 use shuffle_block_wave_detect");
+  const uint32_t N = bsize / T;
+  uint32_t row0[16], r[16];
+  uint32_t per = (1u << T) - 1u;                       // wave-uniform: planes whose rows all equalled row 0 so far
+  if constexpr (T == 2) shuffle_rows2(shuffle_load2(src, 0u, lane), row0); else shuffle_rows16(shuffle_load16(src, 0u, lane), row0);
+  auto step = [&](uint32_t e) {                        // r: the rows of step e
+    if (per == 0u) { shuffle_store_rows<T>(dst, N, e, lane, r); return; }
+    gu8* o = dst + e + 4u * (uint32_t)lane;
+#pragma unroll
+    for (int k = 0; k < T; k++) {
+      if (per & (1u << k)) {
+        if (__ballot(r[k] != row0[k]) == 0ull) continue;
+        per &= ~(1u << k);
+        for (uint32_t t = 0; t < e; t += 256u) g_st4(dst + (size_t)k * N + t + 4u * (uint32_t)lane, row0[k]);
+      }
+      g_st4(o + (size_t)k * N, r[k]);
+    }
+  };
+  uint32_t e = 256u;
+  if constexpr (T == 2) {
+    for (; e + 1024u <= N; e += 1024u) {
+      const ElemRows2 a = shuffle_load2(src, e, lane), b = shuffle_load2(src, e + 256u, lane);
+      const ElemRows2 c = shuffle_load2(src, e + 512u, lane), d = shuffle_load2(src, e + 768u, lane);
+      shuffle_rows2(a, r); step(e); shuffle_rows2(b, r); step(e + 256u); shuffle_rows2(c, r); step(e + 512u); shuffle_rows2(d, r); step(e + 768u);
+    }
+    for (; e + 256u <= N; e += 256u) { shuffle_rows2(shuffle_load2(src, e, lane), r); step(e); }
+  } else {
+    for (; e + 256u <= N; e += 256u) { shuffle_rows16(shuffle_load16(src, e, lane), r); step(e); }
+  }
+#pragma unroll
+  for (int k = 0; k < T; k++) {
+    period[k] = 0u;
+    if (per & (1u << k)) {
+      g_st4(dst + (size_t)k * N + 4u * (uint32_t)lane, row0[k]);
+      period[k] = row_period(row0[k], lane);
+    }
+  }
+  return per;
+}
+
 // queue task "shuffle block gb": afterwards the block's flag tells the encoders of its streams to go ahead.
 // Producer and consumers run on the same XCD (per-XCD queues), so the hand-off goes through that XCD's L2:
 // drain the stores, then a relaxed agent-scope flag store - no L2 write-back needed.
 template <int T>
 __device__ __forceinline__ void shuffle_block_detect_T(const gu8* src, gu8* dst, uint32_t bsize, StreamDesc* planes, int lane) {
-  uint32_t period[8];
-  const uint32_t per = shuffle_block_wave_detect<T>(src, dst, bsize, lane, period);
+  uint32_t period[(T == 4 || T == 8) ? 8 : 16];
+  uint32_t per;
+  if constexpr (T == 4 || T == 8) per = shuffle_block_wave_detect<T>(src, dst, bsize, lane, period);
+  else per = shuffle_block_wave_detect_x<T>(src, dst, bsize, lane, period);
 #pragma unroll
   for (int k = 0; k < T; k++)
     if ((per & (1u << k)) && lane == 0) planes[k].result = -(int32_t)period[k];
+}
+__device__ __attribute__((noinline)) void shuffle_block_task_x(const gu8* src_, gu8* dst_, uint32_t bsize_, uint32_t T_, bool det_, StreamDesc* planes_, int lane) {
+  // (arguments of a real call count as divergent: back to scalars first, as in unshuffle_block_wave of k_decode.hip)
+  const gu8* src = uni_ptr(src_); gu8* dst = uni_ptr(dst_);
+  const uint32_t bsize = uni(bsize_), T = uni(T_); const bool det = uni((uint32_t)det_) != 0u;
+  const uint64_t pv = (uint64_t)planes_;
+  StreamDesc* planes = (StreamDesc*)(((uint64_t)uni((uint32_t)(pv >> 32)) << 32) | uni((uint32_t)pv));
+  if (T == 16u) { if (det) shuffle_block_detect_T<16>(src, dst, bsize, planes, lane); else shuffle_block_wave_T<16>(src, dst, bsize, lane); }
+  else { if (det) shuffle_block_detect_T<2>(src, dst, bsize, planes, lane); else shuffle_block_wave_T<2>(src, dst, bsize, lane); }
 }
 __device__ __attribute__((noinline)) void shuffle_block_task(const ChunkDesc* chunks, const BlockDesc* blocks, uint32_t gb,
                                                              uint32_t* blk_ready, StreamDesc* streams, int detect, int lane) {
@@ -147,7 +262,8 @@ __device__ __attribute__((noinline)) void shuffle_block_task(const ChunkDesc* ch
                    (uni((uint32_t)c->fmt) == (uint32_t)FMT_LZ4 || uni((uint32_t)c->fmt) == (uint32_t)FMT_BLOSCLZ);
   StreamDesc* planes = streams + uni((uint32_t)b->first_stream);
   if (T == 8u) { if (det) shuffle_block_detect_T<8>(src, dst, bsize, planes, lane); else shuffle_block_wave_T<8>(src, dst, bsize, lane); }
-  else { if (det) shuffle_block_detect_T<4>(src, dst, bsize, planes, lane); else shuffle_block_wave_T<4>(src, dst, bsize, lane); }
+  else if (T == 4u) { if (det) shuffle_block_detect_T<4>(src, dst, bsize, planes, lane); else shuffle_block_wave_T<4>(src, dst, bsize, lane); }
+  else shuffle_block_task_x(src, dst, bsize, T, det, planes, lane);       // typesize 2 / 16: out of line, so that the registers of the 16-plane form do not count here
   __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): every store of this wave has reached L2
   if (lane == 0) __hip_atomic_store(&blk_ready[gb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

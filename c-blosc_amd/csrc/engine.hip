@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <map>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -90,8 +91,7 @@ struct EngineState {
   DeviceArena dev;      // descriptors + scratch
   DeviceArena io;       // staging for host-pointer calls
   PinnedArena pin;
-  // profiling
-  bool prof = false;
+  // profiling (switched on for all contexts at once: g_prof)
   std::map<std::string, ProfEntry> prof_acc;
   struct Pending { std::string name; hipEvent_t a, b; };
   std::vector<Pending> prof_pending;
@@ -106,8 +106,42 @@ struct EngineState {
   // or BLOSC_AMD_SINGLE_QUEUE=1) - one queue, shuffle / unshuffle in kernels of their own.
   bool single_queue = false;
   int cus = 0;          // compute units of the selected device (persistent grids)
+  hipStream_t own = nullptr;   // host-buffer calls that name no stream run here (non-blocking: see the contexts below)
 };
-static EngineState& S() { static EngineState s; return s; }
+
+// Contexts (round 3).  blosc_compress_ctx / blosc_decompress_ctx / blosc_getitem are re-entrant in the reference: every call builds
+// a context of its own and callers on different threads run side by side (blosc/blosc.c:1288-1305, :1560-1572, :1618-1690).
+// A call here needs a workspace - arenas, pinned tables, an event pool, the cost feedback of its last batch - and there are
+// ctx_count() of them (BLOSC_AMD_CONTEXTS, default 4, at most 8).  A caller takes the first one that is free, so a single-threaded
+// program only ever touches context 0 and never pays for the others; with every context busy a caller queues on one of them in
+// turn.  A host-buffer call that names no stream runs on its context's own non-blocking stream: the staging copies of one caller
+// overlap the kernels of another instead of lining up on the null stream (the PCIe-bound stock ABI is where that pays).
+// Device-pointer calls keep the caller's stream and its ordering.  The selected device is process-wide (g_device); a context
+// notices a change the next time it is used.
+constexpr int kMaxCtx = 8;
+static EngineState g_ctx[kMaxCtx];
+static std::atomic<int> g_device{-1};      // -1: whatever device is current when the library is first used
+static std::atomic<bool> g_prof{false};
+static std::atomic<unsigned> g_ctx_turn{0};
+static int ctx_count() {
+#ifdef BAMD_WAVE_EMU
+  return 1;                                // the wavefront emulator (tests/tools) runs one launch at a time
+#else
+  static const int n = [] { const char* e = getenv("BLOSC_AMD_CONTEXTS"); int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > kMaxCtx ? kMaxCtx : v); }();
+  return n;
+#endif
+}
+struct CtxGuard {                          // owns one context for the duration of a call
+  EngineState* st = nullptr;
+  CtxGuard() {
+    const int n = ctx_count();
+    for (int i = 0; i < n && !st; i++) if (g_ctx[i].mu.try_lock()) st = &g_ctx[i];
+    if (!st) { st = &g_ctx[g_ctx_turn.fetch_add(1u) % (unsigned)n]; st->mu.lock(); }
+  }
+  ~CtxGuard() { st->mu.unlock(); }
+  CtxGuard(const CtxGuard&) = delete;
+  CtxGuard& operator=(const CtxGuard&) = delete;
+};
 
 // Where do 64 consecutive workgroups land?  Expected on an SPX-mode MI355X: XCC ids 0..7, eight workgroups each.
 __global__ void k_probe_xcc(uint32_t* hist) {
@@ -132,23 +166,30 @@ static void probe_topology(EngineState& st) {
 
 // fork(): the reference re-creates its thread pool in the child (blosc/blosc.c:2210-2221 blosc_atfork_child).  A HIP
 // context does not survive fork(), so there is nothing to re-create here: the child is marked and every compute call
-// in it fails loudly (-1) instead of touching the parent's device state.  prepare/parent keep the engine mutex
-// consistent across the fork (a forking thread never inherits it locked by somebody else).
+// in it fails loudly (-1) instead of touching the parent's device state.  prepare/parent keep the context mutexes
+// consistent across the fork (a forking thread never inherits one locked by somebody else).
 static bool g_forked = false;
-static void atfork_prepare() { S().mu.lock(); }
-static void atfork_parent() { S().mu.unlock(); }
-static void atfork_child() { S().mu.unlock(); g_forked = true; }
+static void atfork_prepare() { for (int i = 0; i < kMaxCtx; i++) g_ctx[i].mu.lock(); }
+static void atfork_parent() { for (int i = kMaxCtx - 1; i >= 0; i--) g_ctx[i].mu.unlock(); }
+static void atfork_child() { for (int i = kMaxCtx - 1; i >= 0; i--) g_ctx[i].mu.unlock(); g_forked = true; }
 
 static int ensure_device(EngineState& st) {
   if (g_forked) {
     fprintf(stderr, "blosc_amd: this process was forked after the library had initialised its HIP device; a device context does not survive fork() - call exec() or use the library only in the parent\n");
     return -1;
   }
-  static bool atfork_set = false;
-  if (!atfork_set) { atfork_set = true; (void)pthread_atfork(atfork_prepare, atfork_parent, atfork_child); }
-  // the HIP current device is per host thread: every entry point (they all come through here, under the
-  // engine lock) re-selects the engine's device for the calling thread
-  if (st.device_ok) { HIP_TRY(hipSetDevice(st.device)); return 0; }
+  static std::once_flag atfork_once;
+  std::call_once(atfork_once, [] { (void)pthread_atfork(atfork_prepare, atfork_parent, atfork_child); });
+  // the HIP current device is per host thread: every entry point (they all come through here, holding a
+  // context) re-selects the engine's device for the calling thread
+  const int want_dev = g_device.load();
+  if (st.device_ok && (want_dev < 0 || want_dev == st.device)) { HIP_TRY(hipSetDevice(st.device)); return 0; }
+  if (st.device_ok) {                      // the process moved to another device (engine_set_device through another context)
+    st.dev.release(); st.io.release();     // arenas belong to the device they were allocated on
+    if (st.own) { (void)hipStreamDestroy(st.own); st.own = nullptr; }
+    st.device_ok = false;
+  }
+  st.device = want_dev;
   int cnt = 0;
   hipError_t e = hipGetDeviceCount(&cnt);
   if (e != hipSuccess || cnt <= 0) {
@@ -160,7 +201,7 @@ static int ensure_device(EngineState& st) {
     return -1;
   }
   if (st.device >= 0) HIP_TRY(hipSetDevice(st.device));
-  else HIP_TRY(hipGetDevice(&st.device));
+  else { HIP_TRY(hipGetDevice(&st.device)); int none = -1; (void)g_device.compare_exchange_strong(none, st.device); }
   probe_topology(st);
   hipDeviceProp_t pr;
   st.cus = (hipGetDeviceProperties(&pr, st.device) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
@@ -183,7 +224,7 @@ static double now_ms() { return std::chrono::duration<double, std::milli>(std::c
 #define HT_MARK(dir, i) do { if (hosttime_on()) { const double t_ = now_ms(); g_ht.t[dir][i] += t_ - ht_last; ht_last = t_; } } while (0)
 struct ProfScope {
   EngineState& st; hipStream_t s; const char* name; hipEvent_t a{}, b{}; bool on;
-  ProfScope(EngineState& st_, hipStream_t s_, const char* n) : st(st_), s(s_), name(n), on(st_.prof) {
+  ProfScope(EngineState& st_, hipStream_t s_, const char* n) : st(st_), s(s_), name(n), on(g_prof.load(std::memory_order_relaxed)) {
     if (on) { a = prof_event(st); b = prof_event(st); (void)hipEventRecord(a, s); }
   }
   ~ProfScope() { if (on) { (void)hipEventRecord(b, s); st.prof_pending.push_back({name, a, b}); } }
@@ -213,8 +254,8 @@ struct Carver {
 };
 
 // grid of a persistent one-wave-per-workgroup kernel: as many waves as the device keeps resident
-static unsigned persistent_grid(size_t nitems, int waves_per_cu) {
-  const int cus = S().cus > 0 ? S().cus : 256;
+static unsigned persistent_grid(const EngineState& st, size_t nitems, int waves_per_cu) {
+  const int cus = st.cus > 0 ? st.cus : 256;
   size_t g = (size_t)cus * (size_t)waves_per_cu;
   if (nitems < g) g = nitems;
   // workgroups are dealt round-robin to the 8 XCDs and every XCD serves only its own queue: never fewer than 8
@@ -252,14 +293,28 @@ static bool periodic_enabled() { static const bool on = !(getenv("BLOSC_AMD_PERI
 // 8 GiB of reference-written frames, mode 0 / 2: bench19 107 / 50 ms, linspace 17.8 / 15.9, random walk 23.7 / 16.5
 // (profiles/r02f_zstd_decode_modes.txt)
 static int zstd2_mode() { static const int m = getenv("BLOSC_AMD_ZSTD2") ? atoi(getenv("BLOSC_AMD_ZSTD2")) : 2; return m; }
+// typesizes whose byte (un)shuffle runs inside the codec kernels (enc_shuffle.h, k_decode.hip: unshuffle_block_wave); BLOSC_AMD_FUSE_T=0
+// restricts it to 4 and 8 (the state before round 3's typesize 2 / 16 paths: A/B switch)
+static bool fused_typesize(int T) {
+  static const bool wide = !(getenv("BLOSC_AMD_FUSE_T") && atoi(getenv("BLOSC_AMD_FUSE_T")) == 0);
+  return T == 8 || T == 4 || (wide && (T == 2 || T == 16));
+}
 static bool fuse_enabled() { static const bool on = !(getenv("BLOSC_AMD_FUSE") && atoi(getenv("BLOSC_AMD_FUSE")) == 0); return on; }
+
+// the stream a call runs on: the caller's, or - host buffers and no stream named - the context's own
+static int call_stream(EngineState& st, bool host_buffers, hipStream_t* stream) {
+  if (!host_buffers || *stream != (hipStream_t)0 || ctx_count() == 1) return 0;
+  if (!st.own) HIP_TRY(hipStreamCreateWithFlags(&st.own, hipStreamNonBlocking));
+  *stream = st.own;
+  return 0;
+}
 
 int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* results, bool device_ptrs,
                           hipStream_t stream) {
-  EngineState& st = S();
-  std::lock_guard<std::mutex> lock(st.mu);
   if (n <= 0) return 0;
-  if (ensure_device(st)) return -1;
+  CtxGuard ctx;
+  EngineState& st = *ctx.st;
+  if (ensure_device(st) || call_stream(st, !device_ptrs, &stream)) return -1;
 
   double ht_last = hosttime_on() ? now_ms() : 0.0; if (hosttime_on()) g_ht.calls[0]++;
   std::vector<ChunkDesc> chunks((size_t)n);
@@ -307,7 +362,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
     c.mode = 0;
     c.first_block = (int32_t)blocks.size(); c.first_stream = (int32_t)streams.size();
     if (memcpyed) c.mode |= CH_MEMCPYED;
-    else if (p.doshuffle == 1 && T > 1) { c.mode |= CH_SHUFFLE; if ((T == 8 || T == 4) && fuse_enabled() && !st.single_queue) c.mode |= CH_FUSED_SHUF; }
+    else if (p.doshuffle == 1 && T > 1) { c.mode |= CH_SHUFFLE; if (fused_typesize(T) && fuse_enabled() && !st.single_queue) c.mode |= CH_FUSED_SHUF; }
     else if (p.doshuffle == 2) c.mode |= CH_BITSHUFFLE;
     live[(size_t)i] = 1;
     results[i] = 0;
@@ -472,7 +527,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
     uint64_t* d_seqbufs = (zstd || zdyn) ? (uint64_t*)(D + o_seqbufs) : nullptr;
     const zenc::CTabs* d_ctabs = zstd ? (const zenc::CTabs*)(D + o_ctabs) : nullptr;
     const int detect = (!zstd && !zlibc && periodic_enabled()) ? 1 : 0;
-    const dim3 grid(persistent_grid(ntasks, enc_wpc)), block(64 * ENC_WAVES);
+    const dim3 grid(persistent_grid(st, ntasks, enc_wpc)), block(64 * ENC_WAVES);
 #ifdef BAMD_PROFILE_DECODE
     uint32_t* d_prof = nullptr;
     if (getenv("BLOSC_AMD_ENC_PROFILE")) { (void)hipMalloc((void**)&d_prof, nstr * 64); (void)hipMemsetAsync(d_prof, 0, nstr * 64, stream); }
@@ -606,7 +661,7 @@ static void add_decode_chunk(const Header& h, int fmt, int chunk_index, int32_t 
     b.chunk = chunk_index; b.blk = j; b.first_stream = (int32_t)nstreams;
     const bool last = (j == c.nblocks - 1) && c.leftover > 0;
     b.nstreams = (split && !last) ? T : 1;
-    b.bsize = last ? c.leftover : bs; b.flags = 0;
+    b.bsize = last ? c.leftover : bs; b.flags = (fmt == FMT_ZSTD || fmt == FMT_ZLIB) ? BLK_Z : 0;   // BLK_Z: not in k_decode_streams' queues
     nstreams += (size_t)b.nstreams;
     blocks.push_back(b);
   }
@@ -661,7 +716,7 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
       // Occupancy knob: unused dynamic LDS caps how many decoder waves share a CU (and its L2 slice).
       static const int dec_lds = getenv("BLOSC_AMD_DEC_LDS") ? atoi(getenv("BLOSC_AMD_DEC_LDS")) : 0;
       static const int dec_wpc = getenv("BLOSC_AMD_DEC_WPC") ? atoi(getenv("BLOSC_AMD_DEC_WPC")) : DEC_WAVES_PER_CU;
-      const dim3 dgrid(persistent_grid(L.nstr_queued ? L.nstr_queued : 1, dec_wpc));
+      const dim3 dgrid(persistent_grid(st, L.nstr_queued ? L.nstr_queued : 1, dec_wpc));
 #ifdef BAMD_PROFILE_DECODE
       uint32_t* d_prof = nullptr;
       if (getenv("BLOSC_AMD_DEC_PROFILE")) { (void)hipMalloc((void**)&d_prof, L.nstr * 64); (void)hipMemsetAsync(d_prof, 0, L.nstr * 64, stream); }
@@ -730,7 +785,7 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
       }
       {
         ProfScope ps(st, stream, "k_zstd_exec");
-        hipLaunchKernelGGL(k_zstd_exec, dim3(persistent_grid(L.nstr, ZEXEC_WAVES_PER_CU)), dim3(64), 0, stream, L.d_streams, (int)L.nstr, L.d_status, L.d_zticket + 1,
+        hipLaunchKernelGGL(k_zstd_exec, dim3(persistent_grid(st, L.nstr, ZEXEC_WAVES_PER_CU)), dim3(64), 0, stream, L.d_streams, (int)L.nstr, L.d_status, L.d_zticket + 1,
                            L.d_chunks, L.d_blocks, L.d_zmeta, L.zseq_delta);
       }
       d_taken = (const uint32_t*)L.d_zmeta;
@@ -740,7 +795,7 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
 #ifdef BAMD_PROFILE_DECODE
       uint32_t* d_zprof = nullptr;
       if (getenv("BLOSC_AMD_ZSTD_PROFILE")) { (void)hipMalloc((void**)&d_zprof, L.nstr * 64); (void)hipMemsetAsync(d_zprof, 0, L.nstr * 64, stream); }
-      hipLaunchKernelGGL(k_zstd_streams, dim3(persistent_grid(L.nstr, ZSTD_WAVES_PER_CU)), dim3(64), 0, stream, L.d_streams, (int)L.nstr, L.d_status,
+      hipLaunchKernelGGL(k_zstd_streams, dim3(persistent_grid(st, L.nstr, ZSTD_WAVES_PER_CU)), dim3(64), 0, stream, L.d_streams, (int)L.nstr, L.d_status,
                          L.d_zticket, L.d_chunks, L.d_blocks, L.d_cost + 257, d_taken, d_zprof);
       if (d_zprof) {
         std::vector<uint32_t> h(L.nstr * 16);
@@ -751,14 +806,14 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
         (void)hipFree(d_zprof);
       }
 #else
-      hipLaunchKernelGGL(k_zstd_streams, dim3(persistent_grid(L.nstr, ZSTD_WAVES_PER_CU)), dim3(64), 0, stream, L.d_streams, (int)L.nstr, L.d_status,
+      hipLaunchKernelGGL(k_zstd_streams, dim3(persistent_grid(st, L.nstr, ZSTD_WAVES_PER_CU)), dim3(64), 0, stream, L.d_streams, (int)L.nstr, L.d_status,
                          L.d_zticket, L.d_chunks, L.d_blocks, L.d_cost + 257, d_taken);
 #endif
     }
     if (L.any_zlib) {
       ProfScope ps(st, stream, "k_zlib_streams");
-      hipLaunchKernelGGL(k_zlib_streams, dim3(persistent_grid(L.nstr, ZLIB_WAVES_PER_CU)), dim3(64), 0, stream, L.d_streams, (int)L.nstr, L.d_status,
-                         L.d_zticket + 2, L.d_cost + 259);
+      hipLaunchKernelGGL(k_zlib_streams, dim3(persistent_grid(st, L.nstr, ZLIB_WAVES_PER_CU)), dim3(64), 0, stream, L.d_streams, (int)L.nstr, L.d_status,
+                         L.d_zticket + 2, L.d_cost + 259, L.d_chunks, L.d_blocks);
     }
     if (L.any_shuf) {
       ProfScope ps(st, stream, "k_unshuffle");
@@ -782,7 +837,11 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
 
 static void filter_tiles(ChunkDesc& c, bool& any_shuf, bool& any_bit, int& tiles_shuf, int& tiles_bit, bool may_fuse) {
   const int32_t T = c.typesize, N = c.blocksize / T;
-  if ((c.mode & CH_SHUFFLE) && (T == 8 || T == 4) && fuse_enabled() && may_fuse && c.fmt != FMT_ZSTD && c.fmt != FMT_ZLIB) { c.mode |= CH_FUSED_UNSHUF; return; }
+  // (Zstd / zlib chunks: only unsplit ones - the wave that decodes a block's one stream unshuffles it, k_decode.hip: fused_unshuffle_own_block;
+  //  BLOSC_AMD_FUSE_Z=0 keeps k_unshuffle for them: A/B switch)
+  static const bool fuse_z = !(getenv("BLOSC_AMD_FUSE_Z") && atoi(getenv("BLOSC_AMD_FUSE_Z")) == 0);
+  const bool zfmt = c.fmt == FMT_ZSTD || c.fmt == FMT_ZLIB;
+  if ((c.mode & CH_SHUFFLE) && fused_typesize(T) && fuse_enabled() && may_fuse && (!zfmt || (fuse_z && c.nsplits == 1))) { c.mode |= CH_FUSED_UNSHUF; return; }
   if (c.mode & CH_SHUFFLE) {
     any_shuf = true;
     int t = (N + shuffle_tile_elems(T) - 1) / shuffle_tile_elems(T); if (t < 1) t = 1;
@@ -795,10 +854,10 @@ static void filter_tiles(ChunkDesc& c, bool& any_shuf, bool& any_bit, int& tiles
 }
 
 int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_ptrs, hipStream_t stream) {
-  EngineState& st = S();
-  std::lock_guard<std::mutex> lock(st.mu);
   if (n <= 0) return 0;
-  if (ensure_device(st)) return -1;
+  CtxGuard ctx;
+  EngineState& st = *ctx.st;
+  if (ensure_device(st) || call_stream(st, !device_ptrs, &stream)) return -1;
 
   double ht_last = hosttime_on() ? now_ms() : 0.0; if (hosttime_on()) g_ht.calls[1]++;
   std::vector<Header> hdrs;
@@ -808,7 +867,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   std::vector<ChunkDesc> chunks((size_t)n);
   std::vector<BlockDesc> blocks;
   std::vector<uint8_t> live((size_t)n, 0);
-  size_t nstr = 0, filt_bytes = 0, zlit_bytes = 0, io_src = 0, io_dst = 0;
+  size_t nstr = 0, nstr_z = 0, filt_bytes = 0, zlit_bytes = 0, io_src = 0, io_dst = 0;      // nstr_z: streams of Zstd / zlib chunks (their own kernels')
   DecodeLaunch L{};
   for (int i = 0; i < n; i++) {
     ChunkDesc& c = chunks[(size_t)i];
@@ -826,6 +885,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
     if (c.mode & (CH_SHUFFLE | CH_BITSHUFFLE)) filt_bytes = align_up(filt_bytes, 256) + (size_t)c.nblocks * filt_block_stride(c);
     if (c.fmt == FMT_ZSTD && !(c.mode & CH_MEMCPYED)) { L.any_zstd = true; zlit_bytes = align_up(zlit_bytes, 256) + (size_t)c.nbytes; }
     if (c.fmt == FMT_ZLIB && !(c.mode & CH_MEMCPYED)) L.any_zlib = true;
+    if (c.fmt == FMT_ZSTD || c.fmt == FMT_ZLIB) nstr_z += nstr - (size_t)c.first_stream;     // (memcpyed chunks have no streams)
     if (!device_ptrs) { io_src = align_up(io_src, 256) + (size_t)c.cbytes; io_dst = align_up(io_dst, 256) + (size_t)c.nbytes; }
   }
   const size_t nblk = blocks.size();
@@ -916,7 +976,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   L.d_blists[0] = (int32_t*)(D + o_blist + 64) + nbl; L.d_blists[1] = L.d_blists[0] + 2 * blist[0].size();
   L.d_skind = (uint32_t*)(D + o_skind);
   L.nlist[0] = (uint32_t)blist[0].size(); L.nlist[1] = (uint32_t)blist[1].size();
-  L.d_far = D + o_far; L.far_stride = far_stride; L.nstr_queued = nstr - nstr_lds;
+  L.d_far = D + o_far; L.far_stride = far_stride; L.nstr_queued = nstr - nstr_lds - nstr_z;
   HT_MARK(1, 2);     // tables, queues, uploads
   if (launch_decode(st, L, stream)) return -1;
   HIP_TRY(hipMemcpyAsync(P + p_status, D + o_status, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, stream));
@@ -925,7 +985,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   HIP_TRY(hipStreamSynchronize(stream));
   HT_MARK(1, 4);     // waiting for the device
   prof_collect(st);
-  if (nblk && check_done((const uint32_t*)(P + p_cost), nstr - nstr_lds, L.any_zstd ? nstr : 0, "decompress", blist[0].size() + blist[1].size(), L.any_zlib ? nstr : 0)) return -1;
+  if (nblk && check_done((const uint32_t*)(P + p_cost), nstr - nstr_lds - nstr_z, L.any_zstd ? nstr : 0, "decompress", blist[0].size() + blist[1].size(), L.any_zlib ? nstr : 0)) return -1;
   if (nstr >= 4096) { memcpy(st.dec_cost, P + p_cost, sizeof st.dec_cost); st.dec_cost_valid = true; }
   const int32_t* stt = (const int32_t*)(P + p_status);
   for (int i = 0; i < n; i++) {
@@ -946,9 +1006,9 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
 // getitem (blosc/blosc.c:1574-1703): decode only the blocks overlapping [start, start+nitems)
 // ---------------------------------------------------------------------------------------------
 int engine_getitem(const void* src, int start, int nitems, void* dest, bool src_dev, bool dst_dev, hipStream_t stream) {
-  EngineState& st = S();
-  std::lock_guard<std::mutex> lock(st.mu);
-  if (ensure_device(st)) return -1;
+  CtxGuard ctx;
+  EngineState& st = *ctx.st;
+  if (ensure_device(st) || call_stream(st, !src_dev && !dst_dev, &stream)) return -1;
   Job job{src, nullptr, 0, 0};
   std::vector<Header> hdrs;
   if (fetch_headers(st, 1, &job, src_dev, stream, hdrs)) return -1;
@@ -1043,13 +1103,13 @@ int engine_getitem(const void* src, int start, int nitems, void* dest, bool src_
   HIP_TRY(hipMemsetAsync(D + o_cost, 0, sizeof(uint32_t) * kCostWords, stream));
   L.any_zstd = fmt == FMT_ZSTD; L.any_zlib = fmt == FMT_ZLIB; L.d_zticket = (uint32_t*)(D + o_zticket);
   if (L.any_zstd || L.any_zlib) HIP_TRY(hipMemsetAsync(D + o_zticket, 0, 64, stream));
-  L.nblk = nblk; L.nstr = nstr; L.nchunks = 1; L.nstr_queued = nstr;    // a handful of blocks: always through k_decode_streams
+  L.nblk = nblk; L.nstr = nstr; L.nchunks = 1; L.nstr_queued = (L.any_zstd || L.any_zlib) ? 0 : nstr;    // a handful of blocks: always through k_decode_streams (Zstd / zlib: their own kernels)
   if (launch_decode(st, L, stream)) return -1;
   HIP_TRY(hipMemcpyAsync(P + p_status, D + o_status, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipMemcpyAsync(P + p_cost, D + o_cost, sizeof(uint32_t) * kCostWords, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   prof_collect(st);
-  if (check_done((const uint32_t*)(P + p_cost), nstr, L.any_zstd ? nstr : 0, "getitem", 0, L.any_zlib ? nstr : 0)) return -1;
+  if (check_done((const uint32_t*)(P + p_cost), L.nstr_queued, L.any_zstd ? nstr : 0, "getitem", 0, L.any_zlib ? nstr : 0)) return -1;
   const int32_t stt = *(const int32_t*)(P + p_status);
   if (stt < 0) return stt;                                                        // blosc.c:1689-1692: blosc_d's code is returned as is
   HIP_TRY(hipMemcpyAsync(dest, D + o_out + (size_t)(lo - (int64_t)j0 * bs), want, out_kind, stream));
@@ -1063,8 +1123,8 @@ int engine_getitem(const void* src, int start, int nitems, void* dest, bool src_
 // kind: 0 shuffle, 1 unshuffle, 2 bitshuffle, 3 bitunshuffle
 // ---------------------------------------------------------------------------------------------
 int engine_filter(int kind, size_t typesize, size_t blocksize, const void* src, void* dst) {
-  EngineState& st = S();
-  std::lock_guard<std::mutex> lock(st.mu);
+  CtxGuard ctx;
+  EngineState& st = *ctx.st;
   if (ensure_device(st)) return -1;
   if (blocksize == 0) return 0;
   if (typesize == 0 || typesize > 255 || blocksize > (size_t)kMaxBlockSize) return -1;
@@ -1114,16 +1174,13 @@ int engine_filter(int kind, size_t typesize, size_t blocksize, const void* src, 
 // misc
 // ---------------------------------------------------------------------------------------------
 int engine_set_device(int dev) {
-  EngineState& st = S();
-  std::lock_guard<std::mutex> lock(st.mu);
   int cnt = 0;
   if (hipGetDeviceCount(&cnt) != hipSuccess || dev < 0 || dev >= cnt) return -1;
-  if (st.device_ok && st.device == dev) { HIP_TRY(hipSetDevice(dev)); return 0; }
-  if (st.device_ok) { st.dev.release(); st.io.release(); }   // arenas belong to the device they were allocated on
-  // not "ok" yet: ensure_device() probes the topology of THIS device (per-XCD queues are only valid where the
-  // probe says so) and resets everything cached about the previous one
-  st.device = dev; st.device_ok = false;
-  return ensure_device(st);
+  g_device.store(dev);
+  // ensure_device() probes the topology of THIS device (per-XCD queues are only valid where the probe says so) and resets
+  // everything a context cached about the previous one; the other contexts do the same the next time they are used
+  CtxGuard ctx;
+  return ensure_device(*ctx.st);
 }
 
 void engine_release() {
@@ -1133,10 +1190,14 @@ void engine_release() {
       fprintf(stderr, "blosc_amd host time per %s call (ms, %ld calls): phase0 %.3f  phase1 %.3f  phase2 %.3f  launches %.3f  wait %.3f\n", nm[d], g_ht.calls[d],
               g_ht.t[d][0] / g_ht.calls[d], g_ht.t[d][1] / g_ht.calls[d], g_ht.t[d][2] / g_ht.calls[d], g_ht.t[d][3] / g_ht.calls[d], g_ht.t[d][4] / g_ht.calls[d]);
   }
-  EngineState& st = S();
-  std::lock_guard<std::mutex> lock(st.mu);
-  if (!st.device_ok || g_forked) return;
-  st.dev.release(); st.io.release(); st.pin.release();
+  if (g_forked) return;
+  for (int i = 0; i < kMaxCtx; i++) {
+    EngineState& st = g_ctx[i];
+    std::lock_guard<std::mutex> lock(st.mu);
+    if (!st.device_ok) continue;
+    st.dev.release(); st.io.release(); st.pin.release();
+    if (st.own) { (void)hipStreamDestroy(st.own); st.own = nullptr; }
+  }
 }
 
 bool engine_is_device_pointer(const void* p) {
@@ -1147,16 +1208,21 @@ bool engine_is_device_pointer(const void* p) {
   return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
 }
 
-void engine_prof_enable(int on) { EngineState& st = S(); std::lock_guard<std::mutex> lock(st.mu); st.prof = on != 0; }
-void engine_prof_reset() { EngineState& st = S(); std::lock_guard<std::mutex> lock(st.mu); st.prof_acc.clear(); }
-int engine_prof_get(const char* kernel, double* total_ms, int* launches) {
-  EngineState& st = S();
-  std::lock_guard<std::mutex> lock(st.mu);
-  auto it = st.prof_acc.find(kernel);
-  if (it == st.prof_acc.end()) { if (total_ms) *total_ms = 0; if (launches) *launches = 0; return -1; }
-  if (total_ms) *total_ms = it->second.ms;
-  if (launches) *launches = it->second.launches;
-  return 0;
+void engine_prof_enable(int on) { g_prof.store(on != 0); }
+void engine_prof_reset() {
+  for (int i = 0; i < kMaxCtx; i++) { std::lock_guard<std::mutex> lock(g_ctx[i].mu); g_ctx[i].prof_acc.clear(); }
+}
+int engine_prof_get(const char* kernel, double* total_ms, int* launches) {      // summed over the contexts
+  double ms = 0; int n = 0; bool found = false;
+  for (int i = 0; i < kMaxCtx; i++) {
+    std::lock_guard<std::mutex> lock(g_ctx[i].mu);
+    auto it = g_ctx[i].prof_acc.find(kernel);
+    if (it == g_ctx[i].prof_acc.end()) continue;
+    ms += it->second.ms; n += it->second.launches; found = true;
+  }
+  if (total_ms) *total_ms = ms;
+  if (launches) *launches = n;
+  return found ? 0 : -1;
 }
 
 }  // namespace bamd

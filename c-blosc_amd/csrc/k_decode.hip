@@ -767,7 +767,7 @@ __device__ int blosclz_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* 
 // decode kernel: persistent waves + ticket queue, block = 64 * DEC_WAVES
 // ---------------------------------------------------------------------------------------------
 // ---------------------------------------------------------------------------------------------
-// Fused byte-unshuffle of one block by ONE wavefront (typesize 4 or 8), used by the decode kernel when the
+// Fused byte-unshuffle of one block by ONE wavefront (typesize 2, 4, 8 or 16), used by the decode kernel when the
 // last stream of a block has been decoded.  Plane-major scratch -> element-major destination
 // (blosc/shuffle-generic.h:61-81).  Per step each lane loads 16 bytes of every plane (coalesced 1 KiB
 // rows), transposes bytes in registers (v_perm_b32) and stores 16-byte pieces of its own contiguous
@@ -809,6 +809,11 @@ __device__ __forceinline__ uint32_t ld4_plane(const gu8* p) { return BAMD_UNSH_L
 template <int T>
 __device__ __forceinline__ void unshuffle_store(gu8* dst, uint32_t e, int lane, const Rows<T>& x) {
   gu8* o = dst + (size_t)(e + 4u * (uint32_t)lane) * T;
+  if constexpr (T == 2) {                            // elements 0..3 (2 bytes each): one 8-byte store per lane
+    const uint32_t lo = __builtin_amdgcn_perm(x.r[1], x.r[0], 0x05010400u), hi = __builtin_amdgcn_perm(x.r[1], x.r[0], 0x07030602u);
+    const uint64_t v = (uint64_t)lo | ((uint64_t)hi << 32);
+    if (BAMD_DST_STREAM == 2) g_st8_nt(o, v); else g_st8(o, v);
+  } else {
   uint32_t t0, t1, t2, t3;
   transpose4x4(x.r[0], x.r[1], x.r[2], x.r[3], t0, t1, t2, t3);
   if (T == 8) {
@@ -818,6 +823,7 @@ __device__ __forceinline__ void unshuffle_store(gu8* dst, uint32_t e, int lane, 
     st16_dst(o + 16, make_uint4(t2, u2, t3, u3));    // elements 2, 3
   } else {
     st16_dst(o, make_uint4(t0, t1, t2, t3));         // elements 0..3 (4 bytes each)
+  }
   }
 }
 
@@ -897,6 +903,86 @@ __device__ void unshuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize,
   for (uint32_t k = N * T + (uint32_t)lane; k < bsize; k += 64u) dst[k] = src[k];
 }
 
+// Typesize 16 (round 3).  The same steps - lane l owns elements e + 4l .. e + 4l + 3, 4 bytes of every plane in, 64 contiguous
+// bytes out - but sixteen planes' worth of span bounds, flags and plane pointers do not fit the scalar registers next to the
+// loop: they live in a LANE TABLE (lane j holds plane j's words) and a step reads what it needs with v_readlane.  Two steps
+// (8 KiB of loads) in flight per wave, as many bytes as typesize 8 keeps in flight with four.  Planes whose period divides 256
+// read their dword from the first row of the pattern table in every iteration (the same 256 bytes: cache-resident) instead
+// of holding it in a register per plane.
+__device__ __forceinline__ void unshuffle_store16(gu8* dst, uint32_t e, int lane, const uint32_t (&x)[16]) {
+  gu8* o = dst + (size_t)(e + 4u * (uint32_t)lane) * 16u;
+  uint32_t t[4][4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) transpose4x4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3], t[q][0], t[q][1], t[q][2], t[q][3]);
+#pragma unroll
+  for (int k = 0; k < 4; k++) st16_dst(o + 16 * k, make_uint4(t[0][k], t[1][k], t[2][k], t[3][k]));      // element k
+}
+__device__ __attribute__((noinline)) void unshuffle_block_wave_16(const gu8* src_, gu8* dst_, uint32_t bsize_, int lane, const uint32_t* spans_,
+                                                                  const gu8* pat_, const StreamDesc* sds_, uint32_t pstride_) {
+  const gu8* src = uni_ptr(src_); gu8* dst = uni_ptr(dst_); const gu8* pat = uni_ptr(pat_);
+  const uint32_t bsize = uni(bsize_), pstride = uni(pstride_);
+  const uint64_t sv = (uint64_t)spans_, dv = (uint64_t)sds_;
+  const uint32_t* spans = (const uint32_t*)(((uint64_t)uni((uint32_t)(sv >> 32)) << 32) | uni((uint32_t)sv));
+  const StreamDesc* sds = (const StreamDesc*)(((uint64_t)uni((uint32_t)(dv >> 32)) << 32) | uni((uint32_t)dv));
+  const uint32_t N = bsize / 16u;
+  // the lane table: plane j = lane & 15
+  uint32_t t_lo = 0u, t_hi = 0u, t_kind = 0u, t_ob = 0u, t_om = 0u;       // kind 1: period divides 256, 2: self span, 0: pattern table (or no span)
+  uint64_t t_pl;
+  {
+    const uint32_t j = (uint32_t)lane & 15u;
+    t_pl = (uint64_t)(src + (size_t)j * pstride);
+    if (spans) {
+      const uint32_t w = spans[2u * j];
+      t_lo = w & ~1023u; t_hi = spans[2u * j + 1u];
+      if (w & SPAN_RAW) { t_pl = (uint64_t)as_global(sds[j].in); t_hi = 0u; }
+      else if (t_hi > t_lo) {
+        if (w & SPAN_SMALL) t_kind = 1u;
+        else if (w & SPAN_SELF) { t_kind = 2u; t_ob = g_ld4(pat + (size_t)j * SPAN_PAT); t_om = g_ld4(pat + (size_t)j * SPAN_PAT + 4) - 1u; }
+      } else t_hi = 0u;
+    }
+  }
+  const uint32_t t_pl_lo = (uint32_t)t_pl, t_pl_hi = (uint32_t)(t_pl >> 32);
+  const uint32_t l4 = 4u * (uint32_t)lane;
+  auto plane = [&](int j) -> const gu8* {
+    return (const gu8*)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)t_pl_hi, j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)t_pl_lo, j));
+  };
+  uint32_t e = 0;
+  for (; e + 512u <= N; e += 512u) {
+    uint32_t a[16], b[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)t_lo, j), hi = (uint32_t)__builtin_amdgcn_readlane((int)t_hi, j);
+      const gu8* pl = plane(j);
+      if (!(e >= lo && e < hi)) { a[j] = ld4_plane(pl + e + l4); b[j] = ld4_plane(pl + e + l4 + 256u); continue; }      // wave-uniform
+      const uint32_t kind = (uint32_t)__builtin_amdgcn_readlane((int)t_kind, j);
+      const gu8* pj = pat + (size_t)j * SPAN_PAT;
+      if (kind == 1u) { a[j] = b[j] = g_ld4(pj + l4); }
+      else if (kind == 2u) {
+        const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)t_ob, j), m = (uint32_t)__builtin_amdgcn_readlane((int)t_om, j);
+        const uint32_t q = e + l4 - o;
+        a[j] = ld4_plane(pl + o + (q & m)); b[j] = ld4_plane(pl + o + ((q + 256u) & m));
+      } else {
+        const gu8* p = pj + (e & (SPAN_PAT - 1u));
+        a[j] = ld4_plane(p + l4); b[j] = ld4_plane(p + l4 + 256u);
+      }
+    }
+    unshuffle_store16(dst, e, lane, a); unshuffle_store16(dst, e + 256u, lane, b);
+  }
+  // behind the last multiple of 1024 (span bounds are multiples of 1024) nothing is skipped
+  for (; e + 256u <= N; e += 256u) {
+    uint32_t a[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) a[j] = g_ld4(plane(j) + e + l4);
+    unshuffle_store16(dst, e, lane, a);
+  }
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    const gu8* pl = plane(j);
+    for (uint32_t el = e + (uint32_t)lane; el < N; el += 64u) dst[(size_t)el * 16u + j] = pl[el];
+  }
+  for (uint32_t k = N * 16u + (uint32_t)lane; k < bsize; k += 64u) dst[k] = src[k];
+}
+
 __device__ __attribute__((noinline)) void unshuffle_block_wave(const uint8_t* src, uint8_t* dst, uint32_t bsize_, int typesize_, int lane,
                                                                const uint32_t* spans_, const uint8_t* pat, const StreamDesc* sds_, uint32_t pstride_ = 0) {
   // arguments of a real (non-inlined) call count as divergent for the compiler: without the readfirstlanes below the loop
@@ -907,7 +993,73 @@ __device__ __attribute__((noinline)) void unshuffle_block_wave(const uint8_t* sr
   const StreamDesc* sds = (const StreamDesc*)(((uint64_t)uni((uint32_t)(dv >> 32)) << 32) | uni((uint32_t)dv));
   const uint32_t pstride = uni(pstride_) ? uni(pstride_) : bsize / (uint32_t)typesize;      // 0: the plain plane-major image
   if (typesize == 8) unshuffle_block_wave_T<8>(uni_ptr(as_global(src)), uni_ptr(as_global(dst)), bsize, lane, spans, uni_ptr(as_global(pat)), sds, pstride);
-  else unshuffle_block_wave_T<4>(uni_ptr(as_global(src)), uni_ptr(as_global(dst)), bsize, lane, spans, uni_ptr(as_global(pat)), sds, pstride);
+  else if (typesize == 4) unshuffle_block_wave_T<4>(uni_ptr(as_global(src)), uni_ptr(as_global(dst)), bsize, lane, spans, uni_ptr(as_global(pat)), sds, pstride);
+  else if (typesize == 2) unshuffle_block_wave_T<2>(uni_ptr(as_global(src)), uni_ptr(as_global(dst)), bsize, lane, spans, uni_ptr(as_global(pat)), sds, pstride);
+  else unshuffle_block_wave_16(as_global(src), as_global(dst), bsize, lane, spans, as_global(pat), sds, pstride);      // typesize 16, out of line: its registers must not count against the loops above
+}
+
+// ---------------------------------------------------------------------------------------------
+// The fused unshuffle of the entropy-coded formats (round 3).  A Zstd or zlib chunk is normally not split (blosc/blosc.c:929-959:
+// only BloscLZ / LZ4 split in the default mode): a block is ONE stream that decodes into the plane-major scratch.  The wave that
+// has decoded it (k_zstd_exec, k_zstd_streams, k_zlib_streams) transposes it into the destination right away - its own stores,
+// no hand-off between waves, the bandwidth-bound transposes run underneath the latency-bound decoding of the other waves instead
+// of in a kernel of their own behind them (k_unshuffle: 3.4 ms per 8 GiB).  No spans, and fewer steps in flight than
+// unshuffle_block_wave: k_zstd_exec runs 8 waves per SIMD on 64 registers.
+// ---------------------------------------------------------------------------------------------
+template <int T, int STEPS>
+__device__ __forceinline__ void unshuffle_plain_T(const gu8* src, gu8* dst, uint32_t bsize, int lane) {
+  const uint32_t N = bsize / T;
+  uint32_t e = 0;
+  for (; e + 256u * STEPS <= N; e += 256u * STEPS) {
+    Rows<T> x[STEPS];
+#pragma unroll
+    for (int s = 0; s < STEPS; s++)
+#pragma unroll
+      for (int j = 0; j < T; j++) x[s].r[j] = ld4_plane(src + (size_t)j * N + e + 256u * s + 4u * (uint32_t)lane);
+#pragma unroll
+    for (int s = 0; s < STEPS; s++) unshuffle_store<T>(dst, e + 256u * s, lane, x[s]);
+  }
+  for (; e + 256u <= N; e += 256u) {
+    Rows<T> x;
+#pragma unroll
+    for (int j = 0; j < T; j++) x.r[j] = g_ld4(src + (size_t)j * N + e + 4u * (uint32_t)lane);
+    unshuffle_store<T>(dst, e, lane, x);
+  }
+#pragma unroll
+  for (int j = 0; j < T; j++)
+    for (uint32_t el = e + (uint32_t)lane; el < N; el += 64u) dst[(size_t)el * T + j] = src[(size_t)j * N + el];
+  for (uint32_t k = N * T + (uint32_t)lane; k < bsize; k += 64u) dst[k] = src[k];
+}
+__device__ __forceinline__ void unshuffle_plain_16(const gu8* src, gu8* dst, uint32_t bsize, int lane) {
+  const uint32_t N = bsize / 16u;
+  uint32_t e = 0;
+  for (; e + 256u <= N; e += 256u) {
+    uint32_t a[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) a[j] = ld4_plane(src + (size_t)j * N + e + 4u * (uint32_t)lane);
+    unshuffle_store16(dst, e, lane, a);
+  }
+#pragma unroll
+  for (int j = 0; j < 16; j++)
+    for (uint32_t el = e + (uint32_t)lane; el < N; el += 64u) dst[(size_t)el * 16u + j] = src[(size_t)j * N + el];
+  for (uint32_t k = N * 16u + (uint32_t)lane; k < bsize; k += 64u) dst[k] = src[k];
+}
+__device__ __attribute__((noinline)) void unshuffle_block_plain(const uint8_t* src_, uint8_t* dst_, uint32_t bsize_, int typesize_, int lane) {
+  const gu8* src = uni_ptr(as_global(src_)); gu8* dst = uni_ptr(as_global(dst_));
+  const uint32_t bsize = uni(bsize_); const int typesize = (int)uni((uint32_t)typesize_);
+  if (typesize == 8) unshuffle_plain_T<8, 2>(src, dst, bsize, lane);
+  else if (typesize == 4) unshuffle_plain_T<4, 4>(src, dst, bsize, lane);
+  else if (typesize == 2) unshuffle_plain_T<2, 4>(src, dst, bsize, lane);
+  else unshuffle_plain_16(src, dst, bsize, lane);
+}
+// Called by the wave that has just written the whole of stream `sd` (the only stream of its block) into the scratch.
+__device__ __forceinline__ void fused_unshuffle_own_block(const ChunkDesc* c, const BlockDesc* b, int lane) {
+  if (!(uni(c->mode) & CH_FUSED_UNSHUF) || uni((uint32_t)b->nstreams) != 1u) return;
+  BAMD_WAIT_STORES();     // this wave's own stores are what it reads back: no other wave, no other cache involved
+  BAMD_MEM_SYNC();
+  const uint32_t blk = uni((uint32_t)b->blk);
+  unshuffle_block_plain(c->filt + (size_t)blk * filt_block_stride(*c), c->dst + (size_t)blk * (size_t)uni((uint32_t)c->blocksize),
+                        uni((uint32_t)b->bsize), (int)uni((uint32_t)c->typesize), lane);
 }
 
 // One stream, start to finish.  Deliberately NOT inlined into the queue loop below: with the decoders
@@ -937,13 +1089,13 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
   const uint64_t cost_t0 = __builtin_amdgcn_s_memtime();
   int got;
   bool raw_in_place = false;
-  if (csize == want) {    // split stored raw (blosc/blosc.c:773-776)
+  if (sd->fmt == FMT_ZSTD || sd->fmt == FMT_ZLIB) {
+    return;               // k_zstd_* / k_zlib_streams own every stream of those chunks, the ones stored raw included (round 3)
+  } else if (csize == want) {    // split stored raw (blosc/blosc.c:773-776)
     // fused split blocks: the unshuffle reads the plane where it lies in the chunk (SPAN_RAW), no copy to the scratch
     raw_in_place = sp.enabled != 0u;
     if (!raw_in_place) wave_copy_disjoint(out, in, (uint32_t)want, lane);
     got = want;
-  } else if (sd->fmt == FMT_ZSTD || sd->fmt == FMT_ZLIB) {
-    return;               // k_zstd_streams / k_zlib_streams own the streams of those chunks
   } else if (sd->fmt == FMT_LZ4) {
     got = lz4_decode_wave(in, csize, out, want, scr, lane, sp PROF_PASS, (mode & CH_BITSHUFFLE) == 0u);
   } else {

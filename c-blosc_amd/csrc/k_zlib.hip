@@ -126,11 +126,12 @@ __device__ __forceinline__ int zlib_decode_wave(const uint8_t* in_, int n_, uint
   return (int)op;
 }
 
-// Persistent waves over ALL streams of the launch; only the non-raw streams of Zlib chunks are taken here
-// (k_decode_streams copies the raw ones and leaves these alone).
+// Persistent waves over ALL streams of the launch; the streams of Zlib chunks are taken here, splits stored raw included
+// (k_decode_streams leaves them alone); an unsplit block is unshuffled by the wave that decoded it (fused_unshuffle_own_block).
 constexpr int ZLIB_WAVES_PER_CU = 16;
 __global__ __launch_bounds__(64, 4) void k_zlib_streams(StreamDesc* __restrict__ streams, int nstreams, int32_t* __restrict__ status,
-                                                     uint32_t* __restrict__ ticket, uint32_t* __restrict__ done) {
+                                                     uint32_t* __restrict__ ticket, uint32_t* __restrict__ done,
+                                                     const ChunkDesc* __restrict__ chunks, const BlockDesc* __restrict__ blocks) {
   __shared__ zi::Tabs tabs;
   const int lane = threadIdx.x & 63;
   uint32_t sid = take_ticket(ticket, lane);
@@ -138,12 +139,17 @@ __global__ __launch_bounds__(64, 4) void k_zlib_streams(StreamDesc* __restrict__
   while (sid < (uint32_t)nstreams) {
     StreamDesc* sd = streams + sid;
     const int32_t csize = (int32_t)uni((uint32_t)sd->in_size), want = (int32_t)uni((uint32_t)sd->out_size);
-    if (uni((uint32_t)sd->fmt) == (uint32_t)FMT_ZLIB && csize >= 0 && csize != want) {
-      const int got = zlib_decode_wave(sd->in, csize, sd->out, want, tabs, lane);
+    if (uni((uint32_t)sd->fmt) == (uint32_t)FMT_ZLIB && csize >= 0) {
+      int got;
+      if (csize == want) {    // split stored raw (blosc/blosc.c:773-776)
+        wave_copy_disjoint(uni_ptr(as_global(sd->out)), uni_ptr(as_global(sd->in)), (uint32_t)want, lane);
+        got = want;
+      } else got = zlib_decode_wave(sd->in, csize, sd->out, want, tabs, lane);
       if (lane == 0) {
         sd->result = got;
         if (got != want) atomicMin(&status[sd->chunk], (int32_t)ST_BADCODEC);   // blosc.c:780-782
       }
+      if (got == want) fused_unshuffle_own_block(chunks + uni((uint32_t)sd->chunk), blocks + uni((uint32_t)sd->aux), lane);
     }
     ndone++;
     sid = take_ticket(ticket, lane);

@@ -380,8 +380,8 @@ __device__ __attribute__((noinline)) int zstd_decode_wave(const uint8_t* in, int
   return (int)op;
 }
 
-// Persistent waves over ALL streams of the launch; only the non-raw streams of Zstd chunks are taken here
-// (k_decode_streams copies the raw ones and leaves these alone).
+// Persistent waves over ALL streams of the launch; the streams of Zstd chunks are taken here, splits stored raw included
+// (k_decode_streams leaves them alone); an unsplit block is unshuffled by the wave that decoded it (fused_unshuffle_own_block).
 constexpr int ZSTD_WAVES_PER_CU = 12;
 __global__ __launch_bounds__(64, 3) void k_zstd_streams(StreamDesc* __restrict__ streams, int nstreams, int32_t* __restrict__ status,
                                                      uint32_t* __restrict__ ticket, const ChunkDesc* __restrict__ chunks,
@@ -393,33 +393,56 @@ __global__ __launch_bounds__(64, 3) void k_zstd_streams(StreamDesc* __restrict__
                                                      ) {
   __shared__ ZstdLds lds;
   const int lane = threadIdx.x & 63;
-  uint32_t sid = take_ticket(ticket, lane);
+  // Tickets.  Without the two-phase path every Zstd stream is this kernel's: one stream per ticket.  With it (taken != nullptr)
+  // this kernel only sees what phase A left alone - frames of several blocks, raw / RLE blocks, splits stored raw: usually nothing -
+  // so a ticket is a run of 64 consecutive streams, every lane looks at one of them and the wave walks the few that are its own.
+  // (One ticket per stream made the empty case 65 536 atomics on one word: 0.8 ms per call for nothing)
+  const uint32_t run = taken ? 64u : 1u;
   uint32_t ndone = 0;
-  while (sid < (uint32_t)nstreams) {
-    StreamDesc* sd = streams + sid;
-    const int32_t csize = (int32_t)uni((uint32_t)sd->in_size), want = (int32_t)uni((uint32_t)sd->out_size);
-    const bool mine = !taken || uni(taken[8 * (size_t)sid]) == 0u;     // 0 = ZM_FALLBACK: the two-phase path left this frame alone
-    if (mine && uni((uint32_t)sd->fmt) == (uint32_t)FMT_ZSTD && csize >= 0 && csize != want) {
+  for (;;) {
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(ticket, run);
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);
+    if (base >= (uint32_t)nstreams) break;
+    const uint32_t cnt = (uint32_t)nstreams - base < run ? (uint32_t)nstreams - base : run;
+    ndone += cnt;
+    uint64_t todo = 1ull;
+    if (taken) {
+      const uint32_t s_l = base + (uint32_t)lane;
+      const bool m = (uint32_t)lane < cnt && taken[8 * (size_t)s_l] == 0u && streams[s_l].fmt == FMT_ZSTD && streams[s_l].in_size >= 0;   // 0 = ZM_FALLBACK
+      todo = __ballot(m);
+    }
+    while (todo) {
+      const uint32_t sid = base + (uint32_t)__builtin_ctzll(todo);
+      todo &= todo - 1ull;
+      StreamDesc* sd = streams + sid;
+      const int32_t csize = (int32_t)uni((uint32_t)sd->in_size), want = (int32_t)uni((uint32_t)sd->out_size);
+      if (uni((uint32_t)sd->fmt) != (uint32_t)FMT_ZSTD || csize < 0) continue;
       const ChunkDesc* c = chunks + uni((uint32_t)sd->chunk);
       const BlockDesc* b = blocks + uni((uint32_t)sd->aux);
-      // literal scratch: this stream's slice of the chunk's `stage` area (same offset as its output)
-      const size_t boff = (size_t)uni((uint32_t)b->blk) * (size_t)uni((uint32_t)c->blocksize) +
-                          (size_t)(sid - uni((uint32_t)b->first_stream)) * (size_t)want;
+      int got;
+      if (csize == want) {    // split stored raw (blosc/blosc.c:773-776)
+        wave_copy_disjoint(uni_ptr(as_global(sd->out)), uni_ptr(as_global(sd->in)), (uint32_t)want, lane);
+        got = want;
+      } else {
+        // literal scratch: this stream's slice of the chunk's `stage` area (same offset as its output)
+        const size_t boff = (size_t)uni((uint32_t)b->blk) * (size_t)uni((uint32_t)c->blocksize) +
+                            (size_t)(sid - uni((uint32_t)b->first_stream)) * (size_t)want;
 #ifdef BAMD_PROFILE_DECODE
-      ZProf zp; for (int i_ = 0; i_ < 16; i_++) zp.c[i_] = 0; zp.t = __builtin_amdgcn_s_memtime();
+        ZProf zp; for (int i_ = 0; i_ < 16; i_++) zp.c[i_] = 0; zp.t = __builtin_amdgcn_s_memtime();
 #endif
-      const int got = zstd_decode_wave(sd->in, csize, sd->out, want, c->stage + boff, &lds, lane ZP_PASS);
+        got = zstd_decode_wave(sd->in, csize, sd->out, want, c->stage + boff, &lds, lane ZP_PASS);
 #ifdef BAMD_PROFILE_DECODE
-      ZP_LAP(5);
-      if (profbuf && lane == 0) for (int i_ = 0; i_ < 16; i_++) profbuf[(size_t)sid * 16 + i_] = zp.c[i_];
+        ZP_LAP(5);
+        if (profbuf && lane == 0) for (int i_ = 0; i_ < 16; i_++) profbuf[(size_t)sid * 16 + i_] = zp.c[i_];
 #endif
+      }
       if (lane == 0) {
         sd->result = got;
         if (got != want) atomicMin(&status[sd->chunk], (int32_t)ST_BADCODEC);   // blosc.c:780-782
       }
+      if (got == want) fused_unshuffle_own_block(c, b, lane);
     }
-    ndone++;
-    sid = take_ticket(ticket, lane);
   }
   if (lane == 0 && ndone) atomicAdd(done, ndone);
 }

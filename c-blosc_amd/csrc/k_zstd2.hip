@@ -346,6 +346,7 @@ __global__ __launch_bounds__(64, 8) void k_zstd_exec(StreamDesc* __restrict__ st
         sd->result = ok ? (int32_t)op : 0;
         if (!ok || op != want) atomicMin(&status[sd->chunk], (int32_t)ST_BADCODEC);   // blosc.c:780-782
       }
+      if (ok && op == want) fused_unshuffle_own_block(c, bk, lane);
     }
     sid = take_ticket(ticket, lane);
   }

@@ -88,7 +88,7 @@ inline void build_xcd_queues(const std::vector<BlockDesc>& blocks, size_t nstr, 
                              std::vector<int32_t>& out, int nq = 8) {
   std::vector<int32_t> q[8];
   std::vector<uint32_t> mine[8];
-  for (size_t g = 0; g < blocks.size(); g++) if (blocks[g].nstreams > 0 && !(blocks[g].flags & BLK_LDS)) mine[g % (size_t)nq].push_back((uint32_t)g);
+  for (size_t g = 0; g < blocks.size(); g++) if (blocks[g].nstreams > 0 && !(blocks[g].flags & (BLK_LDS | BLK_Z))) mine[g % (size_t)nq].push_back((uint32_t)g);
   std::vector<int> order; int nheavy = 0, lastT = -1;
   auto prep = [&](const BlockDesc& b) {
     if (b.nstreams != lastT) { plane_order(cost, cost_valid && sched_enabled(), b.nstreams, order, &nheavy); lastT = b.nstreams; }

@@ -103,6 +103,38 @@ def test_split_blocks_followed_by_an_unsplit_leftover_block(emulib, oracle, ref)
         assert r2 == n and np.array_equal(out, data)
 
 
+@pytest.mark.parametrize("T", [2, 16])
+def test_typesize_2_and_16_take_the_fused_paths(emulib, oracle, ref, T):
+    """Round 3: the byte (un)shuffle of typesize 2 and 16 runs inside the encode / decode kernels like that of 4 and 8 (enc_shuffle.h:
+    shuffle_block_task_x, k_decode.hip: unshuffle_block_wave_T<2> / unshuffle_block_wave_16 with the lane table): split blocks with
+    constant, periodic, noisy and incompressible planes + an unsplit leftover block, written here and by the reference."""
+    rng = np.random.default_rng(70 + T)
+    ne = 16384                                                    # bytes per plane of a full block: spans need >= 16 KiB matches
+    nfull = 2
+    planes = []
+    for j in range(T):
+        kind = j % 5
+        if kind == 0: planes.append(np.zeros(ne * nfull + 777, np.uint8))
+        elif kind == 1: planes.append(rng.integers(0, 256, ne * nfull + 777, dtype=np.uint8))
+        elif kind == 2: planes.append(np.resize(rng.integers(0, 256, 64, dtype=np.uint8), ne * nfull + 777))
+        elif kind == 3: planes.append(rng.integers(0, 3, ne * nfull + 777, dtype=np.uint8))
+        else: planes.append(np.resize(rng.integers(0, 256, 4096, dtype=np.uint8), ne * nfull + 777))
+    data = np.ascontiguousarray(np.stack(planes, 1)).reshape(-1)
+    data = np.concatenate([data, rng.integers(0, 256, T - 1, dtype=np.uint8)])          # bytes that do not form a whole element
+    for cname in (b"lz4", b"blosclz"):
+        r, chunk = _compress(emulib, data, T, 5, 1, cname, blocksize=ne)               # (a splittable block is typesize x the forced size)
+        ro, stock = orc_compress(oracle, data, T, 5, 1, cname.decode(), blocksize=ne)
+        bs = header(stock)["blocksize"]
+        assert ro > 0 and bs >= ne * T and bs < data.size and not header(stock)["flags"] & 0x10            # (blosc.c:1037-1048 widens small split blocks to 64 KiB); split
+        assert r > 0 and header(chunk)["blocksize"] == bs and header(chunk)["typesize"] == T and header(chunk)["flags"] == header(stock)["flags"]
+        assert r < data.size * 0.75
+        _everybody_reads(emulib, oracle, ref, chunk, data)
+        r2, out = _decompress(emulib, stock, data.size)
+        assert r2 == data.size and np.array_equal(out, data)
+        item = np.zeros(T * 300, np.uint8)
+        assert emulib.blosc_getitem(ptr(stock), ne + 100, 300, ptr(item)) == T * 300 and np.array_equal(item, data[T * (ne + 100):T * (ne + 400)])
+
+
 SWITCHES = [
     (b"zstd", {"BLOSC_AMD_ZSTD_TABLES": "1"}),
     (b"zstd", {"BLOSC_AMD_ZSTD_TABLES": "1", "BLOSC_AMD_ZSTD_HUFFMAN": "1"}),
@@ -244,15 +276,16 @@ def ref_programs(emulib, tmp_path_factory):
 
 
 @pytest.mark.parametrize("prog", ["test_api", "test_maxout", "test_nthreads"])
-def test_reference_minunit_programs(ref_programs, prog):
+def test_reference_minunit_programs(ref_programs, prog, tmp_path):
     bindir, env = ref_programs
-    p = subprocess.run([os.path.join(bindir, prog)], env=env, timeout=600, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, errors="replace")
+    p = subprocess.run([os.path.join(bindir, prog)], env=env, cwd=tmp_path, timeout=600, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, errors="replace")
     assert p.returncode == 0 and "ALL TESTS PASSED" in p.stdout, (p.stdout[-1500:], p.stderr[-1500:])
 
 
-def test_reference_bitshuffle_leftovers_and_compat_vectors(ref_programs):
+def test_reference_bitshuffle_leftovers_and_compat_vectors(ref_programs, tmp_path):
     bindir, env = ref_programs
-    p = subprocess.run([os.path.join(bindir, "test_bitshuffle_leftovers")], env=env, timeout=600, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    # (never the repo root: test_bitshuffle_leftovers.c:24,65 writes two .cdata files into its cwd)
+    p = subprocess.run([os.path.join(bindir, "test_bitshuffle_leftovers")], env=env, cwd=tmp_path, timeout=600, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert p.returncode == 0 and p.stdout.count("Successful roundtrip!") == 2, (p.stdout[-1500:], p.stderr[-1500:])
     compat = os.path.join(ROOT, "tests", "golden", "compat")
     names = sorted(f for f in os.listdir(compat) if f.endswith(".cdata"))

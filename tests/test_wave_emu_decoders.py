@@ -297,7 +297,7 @@ def _block_streams(chunk, T):
 
 
 @pytest.mark.parametrize("codec,fmt", [("lz4", 1), ("blosclz", 0)])
-@pytest.mark.parametrize("T", [4, 8])
+@pytest.mark.parametrize("T", [2, 4, 8, 16])
 def test_fused_block_decode(emu, oracle, codec, fmt, T):
     """One block = typesize split streams, decoded stream by stream (in shuffled order: any wave may be the one that completes the block)
     by decode_one_stream itself; constant and short-period planes leave only their edges in the scratch (periodic spans, pattern
@@ -308,7 +308,7 @@ def test_fused_block_decode(emu, oracle, codec, fmt, T):
     ne = 65536                                                     # bytes per plane: long enough for spans (>= 16 KiB matches)
     bsize = ne * T
     seen = {"span": 0, "small": 0, "raw": 0, "plain": 0, "self": 0}
-    for trial in range(8 if FULL else 4):
+    for trial in range(8 if (FULL or T == 2) else (2 if T == 16 else 4)):      # (typesize 2 needs all eight to see every kind of plane)
         planes = []
         for j in range(T):
             kind = (trial + j) % 8
@@ -338,7 +338,7 @@ def test_fused_block_decode(emu, oracle, codec, fmt, T):
         cs = (C.c_int * T)(*[int(s.size) for s in streams])
         order = (C.c_int * T)(*[int(x) for x in rng.permutation(T)])
         dst = np.full(bsize + 256, 0xEE, np.uint8)
-        spans = (C.c_uint * 16)()
+        spans = (C.c_uint * 32)()
         st = emu.emu_decode_block(T, fmt, ptrs, cs, bsize, ptr(dst), order, spans)
         assert st == 0
         assert np.array_equal(dst[:bsize], data), (trial, int(np.argmax(dst[:bsize] != data)))

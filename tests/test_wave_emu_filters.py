@@ -19,7 +19,7 @@ def _api(emu):
     return emu
 
 
-@pytest.mark.parametrize("T", [4, 8])
+@pytest.mark.parametrize("T", [2, 4, 8, 16])
 def test_shuffle_and_unshuffle_equal_the_oracles(emu, oracle, T):
     e = _api(emu)
     rng = np.random.default_rng(T)
@@ -42,7 +42,7 @@ def test_shuffle_and_unshuffle_equal_the_oracles(emu, oracle, T):
         assert np.array_equal(back[:bsize], data) and np.all(back[bsize:] == 0xEE), (T, bsize)
 
 
-@pytest.mark.parametrize("T", [4, 8])
+@pytest.mark.parametrize("T", [2, 4, 8, 16])
 def test_periodic_planes_are_found_and_written_as_one_match(emu, oracle, T):
     """A plane whose 256-byte rows are all equal is not written by the shuffle (only its first row is) and not searched by the
     match finder: its stream is `period` literals + one match.  Planes of every period that divides 256, mixed with planes that
@@ -68,7 +68,7 @@ def test_periodic_planes_are_found_and_written_as_one_match(emu, oracle, T):
         # true period of a periodic plane may be smaller than the one it was built with
         data = np.ascontiguousarray(np.stack(planes, 1)).reshape(-1)          # element-major block
         got = np.zeros(N * T, np.uint8)
-        per = (C.c_uint * 8)()
+        per = (C.c_uint * 16)()
         mask = e.emu_shuffle_block(T, 1, ptr(data), ptr(got), N * T, per)
         for j in range(T):
             plane = got[j * N:(j + 1) * N]
@@ -88,7 +88,7 @@ def test_periodic_planes_are_found_and_written_as_one_match(emu, oracle, T):
 
 
 @pytest.mark.parametrize("fmt,mode", [(1, 0), (0, 0), (1, 3)], ids=["lz4", "blosclz", "lz4hc"])
-@pytest.mark.parametrize("T", [4, 8])
+@pytest.mark.parametrize("T", [2, 4, 8, 16])
 def test_block_through_the_kernels_task_functions(emu, oracle, T, fmt, mode):
     """shuffle_block_task (periodic planes noted in their stream descriptors) followed by encode_one_stream for every plane - the two
     task kinds of the persistent encode kernel, as it calls them: every plane's stream must decode to that plane (constant and
@@ -109,7 +109,7 @@ def test_block_through_the_kernels_task_functions(emu, oracle, T, fmt, mode):
         data = np.ascontiguousarray(np.stack(planes, 1)).reshape(-1)
         slot = ne + 64
         out = np.full(T * slot + 64, 0xEE, np.uint8)
-        res = (C.c_int * 8)()
+        res = (C.c_int * 16)()
         emu.emu_encode_block(T, fmt, mode, 9 if mode == 3 else 5, ptr(data), ne * T, ptr(out), slot, res)
         assert np.all(out[T * slot:] == 0xEE)
         for j in range(T):

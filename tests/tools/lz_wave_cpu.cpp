@@ -41,16 +41,21 @@ void lane_body(int lane, void* arg) {
 // ---- the fused byte (un)shuffle of one block by one wave (k_encode.hip: shuffle_block_wave_T / shuffle_block_wave_detect with its
 // periodic-plane detection and emit_periodic_stream; k_decode.hip: unshuffle_block_wave) ----
 namespace {
-struct SJob { int T, mode; const uint8_t* src; uint8_t* dst; uint32_t bsize; uint32_t period[8]; uint32_t per; };
+struct SJob { int T, mode; const uint8_t* src; uint8_t* dst; uint32_t bsize; uint32_t period[16]; uint32_t per; };
 void shuf_body(int lane, void* arg) {
   SJob* j = (SJob*)arg;
   using namespace bamd;
   if (j->mode == 2) { unshuffle_block_wave(j->src, j->dst, j->bsize, j->T, lane, nullptr, nullptr, nullptr); return; }
-  uint32_t period[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t period[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   uint32_t per = 0;
-  if (j->T == 8) { if (j->mode) per = shuffle_block_wave_detect<8>((const gu8*)j->src, (gu8*)j->dst, j->bsize, lane, period); else shuffle_block_wave_T<8>((const gu8*)j->src, (gu8*)j->dst, j->bsize, lane); }
-  else { if (j->mode) per = shuffle_block_wave_detect<4>((const gu8*)j->src, (gu8*)j->dst, j->bsize, lane, period); else shuffle_block_wave_T<4>((const gu8*)j->src, (gu8*)j->dst, j->bsize, lane); }
-  if (lane == 0) { j->per = per; for (int k = 0; k < 8; k++) j->period[k] = period[k]; }
+  if (j->T == 8 || j->T == 4) {
+    uint32_t p8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (j->T == 8) { if (j->mode) per = shuffle_block_wave_detect<8>((const gu8*)j->src, (gu8*)j->dst, j->bsize, lane, p8); else shuffle_block_wave_T<8>((const gu8*)j->src, (gu8*)j->dst, j->bsize, lane); }
+    else { if (j->mode) per = shuffle_block_wave_detect<4>((const gu8*)j->src, (gu8*)j->dst, j->bsize, lane, p8); else shuffle_block_wave_T<4>((const gu8*)j->src, (gu8*)j->dst, j->bsize, lane); }
+    for (int k = 0; k < 8; k++) period[k] = p8[k];
+  } else if (j->T == 16) { if (j->mode) per = shuffle_block_wave_detect_x<16>((const gu8*)j->src, (gu8*)j->dst, j->bsize, lane, period); else shuffle_block_wave_T<16>((const gu8*)j->src, (gu8*)j->dst, j->bsize, lane); }
+  else { if (j->mode) per = shuffle_block_wave_detect_x<2>((const gu8*)j->src, (gu8*)j->dst, j->bsize, lane, period); else shuffle_block_wave_T<2>((const gu8*)j->src, (gu8*)j->dst, j->bsize, lane); }
+  if (lane == 0) { j->per = per; for (int k = 0; k < 16; k++) j->period[k] = period[k]; }
 }
 struct PJob { const uint8_t* in; uint32_t n; uint8_t* out; uint32_t cap, p; int lz4; uint32_t result; };
 void per_body(int lane, void* arg) {
@@ -60,11 +65,11 @@ void per_body(int lane, void* arg) {
 }
 }  // namespace
 // mode 0: shuffle, 1: shuffle with periodic-plane detection (period_out[k] != 0: plane k repeats with that period and only its first
-// 256 bytes were written), 2: unshuffle.  typesize 4 or 8; bsize a multiple of 256 * typesize for modes 0 / 1.  Returns the plane mask.
+// 256 bytes were written), 2: unshuffle.  typesize 2, 4, 8 or 16; bsize a multiple of 256 * typesize for modes 0 / 1.  Returns the plane mask.
 extern "C" unsigned emu_shuffle_block(int T, int mode, const uint8_t* src, uint8_t* dst, unsigned bsize, unsigned* period_out) {
-  SJob j = {T, mode, src, dst, bsize, {0, 0, 0, 0, 0, 0, 0, 0}, 0};
+  SJob j = {T, mode, src, dst, bsize, {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0};
   wave_emu::run(shuf_body, &j);
-  if (period_out) for (int k = 0; k < 8; k++) period_out[k] = j.period[k];
+  if (period_out) for (int k = 0; k < 16; k++) period_out[k] = j.period[k];      // room for 16 words
   return j.per;
 }
 // the whole stream of a plane of n bytes with period p whose first 256 bytes are `in256`
@@ -83,23 +88,23 @@ void blk_body(int lane, void* arg) {
   bamd::decode_one_stream(j->sd + j->sid, j->status, (volatile uint32_t*)j->scr, j->chunks, j->blocks, j->blk_done, lane, j->sid, j->spans, j->pat, nullptr);
 }
 }  // namespace
-// streams[k] / csize[k]: the T compressed splits of one block of `bsize` bytes (typesize T = 4 or 8, byte-shuffled), fmt = FMT_LZ4 /
+// streams[k] / csize[k]: the T compressed splits of one block of `bsize` bytes (typesize T = 2, 4, 8 or 16, byte-shuffled), fmt = FMT_LZ4 /
 // FMT_BLOSCLZ; dst receives the unshuffled block.  order[k]: the sequence in which the streams are decoded (any permutation).  Returns the
 // chunk status word (0 = fine).  spans_out (2 T words) shows which planes took the periodic-span / raw-in-place shortcuts.
 extern "C" int emu_decode_block(int T, int fmt, const uint8_t* const* streams, const int* csize, unsigned bsize, uint8_t* dst, const int* order, unsigned* spans_out) {
   using namespace bamd;
   const uint32_t ne = bsize / (uint32_t)T;
-  uint8_t* filt = (uint8_t*)malloc(bsize + 4096 + 8 * FILT_PLANE_PAD);          // the padded plane layout of fused chunks (dev_types.h)
-  memset(filt, 0xCD, bsize + 4096 + 8 * FILT_PLANE_PAD);
+  uint8_t* filt = (uint8_t*)malloc(bsize + 4096 + 16 * FILT_PLANE_PAD);          // the padded plane layout of fused chunks (dev_types.h)
+  memset(filt, 0xCD, bsize + 4096 + 16 * FILT_PLANE_PAD);
   ChunkDesc c; memset(&c, 0, sizeof c);
   c.src = nullptr; c.dst = dst; c.filt = filt; c.nbytes = (int32_t)bsize; c.blocksize = (int32_t)bsize; c.typesize = T; c.nblocks = 1;
   c.nsplits = T; c.fmt = fmt; c.mode = CH_SHUFFLE | CH_FUSED_UNSHUF; c.first_block = 0; c.first_stream = 0;
   BlockDesc b; memset(&b, 0, sizeof b);
   b.chunk = 0; b.blk = 0; b.first_stream = 0; b.nstreams = T; b.bsize = (int32_t)bsize;
-  StreamDesc sd[8];
+  StreamDesc sd[16];
   for (int k = 0; k < T; k++) { sd[k].in = streams[k]; sd[k].out = filt + (size_t)k * filt_plane_stride(c, bsize, T); sd[k].in_size = csize[k]; sd[k].out_size = (int32_t)ne; sd[k].chunk = 0; sd[k].fmt = fmt; sd[k].aux = 0; sd[k].result = 0; }
   int32_t status = 0; uint32_t blk_done = 0;
-  uint32_t spans[16]; memset(spans, 0, sizeof spans);
+  uint32_t spans[32]; memset(spans, 0, sizeof spans);
   uint8_t* pat = (uint8_t*)malloc((size_t)T * SPAN_PAT + 64);
   uint32_t* scr = (uint32_t*)aligned_alloc(64, 64 * 4 + LZB_BYTES + 256);
   for (int k = 0; k < T; k++) {
@@ -124,7 +129,7 @@ void enc_blk_body(int lane, void* arg) {
   else encode_one_stream<ENC_LZ>(j->sd + j->sid, j->tab, j->chunks, j->blk_ready, lane, j->blocks, j->sid, nullptr, j->seqbuf);
 }
 }  // namespace
-// src: one block of bsize bytes (typesize T = 4 or 8); fmt FMT_LZ4 / FMT_BLOSCLZ; mode 0 = plain match finder, 3 = LZ4HC-grade search.
+// src: one block of bsize bytes (typesize T = 2, 4, 8 or 16); fmt FMT_LZ4 / FMT_BLOSCLZ; mode 0 = plain match finder, 3 = LZ4HC-grade search.
 // out: T slots of `slot` bytes each; result[k]: the stream size of plane k (0 = store raw), as the kernel leaves it in StreamDesc::result.
 extern "C" void emu_encode_block(int T, int fmt, int mode, int clevel, const uint8_t* src, unsigned bsize, uint8_t* out, unsigned slot, int* result) {
   using namespace bamd;
@@ -136,7 +141,7 @@ extern "C" void emu_encode_block(int T, int fmt, int mode, int clevel, const uin
   c.nsplits = T; c.fmt = fmt; c.mode = CH_SHUFFLE | CH_FUSED_SHUF; c.clevel = clevel;
   BlockDesc b; memset(&b, 0, sizeof b);
   b.nstreams = T; b.bsize = (int32_t)bsize;
-  StreamDesc sd[8];
+  StreamDesc sd[16];
   for (int k = 0; k < T; k++) { sd[k].in = filt + (size_t)k * ne; sd[k].out = out + (size_t)k * slot; sd[k].in_size = (int32_t)ne; sd[k].out_size = (int32_t)slot; sd[k].chunk = 0; sd[k].fmt = fmt; sd[k].aux = clevel; sd[k].result = 0; }
   uint32_t blk_ready = 0;
   uint32_t* tab = (uint32_t*)aligned_alloc(64, 64 * 1024);
