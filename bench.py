@@ -41,7 +41,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (6.29 TB/s measured copy)
 COMPRESS_KERNELS = ["k_shuffle", "k_bitshuffle", "k_encode_streams", "k_lz4hc_encode", "k_zstd_encode", "k_zlib_encode", "k_chunk_scan", "k_chunk_compact"]
-DECOMPRESS_KERNELS = ["k_decode_plan", "k_classify_blocks", "k_decode_streams", "k_decode_blocks", "k_decode_blocks8", "k_zstd_entropy", "k_zstd_exec", "k_zstd_streams", "k_zlib_streams", "k_unshuffle",
+DECOMPRESS_KERNELS = ["k_decode_plan", "k_classify_blocks", "k_decode_streams", "k_decode_blocks", "k_decode_blocks8", "k_zstd_entropy", "k_zstd_seq", "k_zstd_exec", "k_zstd_streams", "k_zlib_streams", "k_unshuffle",
                       "k_bitunshuffle", "k_copy_chunks"]
 KERNELS = COMPRESS_KERNELS + DECOMPRESS_KERNELS
 REFSO = os.path.join(ROOT, "oracle", "_ref", "libblosc_ref.so")
@@ -552,7 +552,7 @@ def main():
     mixed = None
     if args.config == "2" and not overridden and not args.no_extra and world == 1:
         extra = {}
-        for name in ("3", "4"):
+        for name in ("3", "4", "2t", "2x"):       # 2t / 2x: config 2 at typesize 2 and 16 (the reference's bench takes the typesize as an argument over the same data, bench/bench.c:250-320)
             r = measure(rig, name, dict(CONFIGS[name]), min(args.steps, 5), 1, args)
             r.pop("_host_chunk")
             keep = ("value", "unit", "steps", "ms_per_step", "first_call_ms", "ratio", "roofline", "kernels", "decompress_stock_chunks", "verified", "compress", "decompress")

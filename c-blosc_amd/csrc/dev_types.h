@@ -83,6 +83,7 @@ struct BlockDesc {
 enum : int32_t {
   BLK_LDS = 1,          // decompress: the block is decoded by k_decode_blocks (one workgroup, LDS-resident planes), not by k_decode_streams
   BLK_Z = 2,            // decompress: a block of a Zstd / zlib chunk: every stream of it belongs to k_zstd_* / k_zlib_streams, k_decode_streams' queues leave it out
+  BLK_ZLIB = 4,         // ... of a zlib chunk (set together with BLK_Z): k_zlib_streams has per-XCD queues of its own (queue_order.h)
 };
 
 struct StreamDesc {

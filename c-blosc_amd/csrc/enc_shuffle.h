@@ -48,18 +48,23 @@ __device__ __forceinline__ void shuffle_rows2(const ElemRows2& x, uint32_t (&r)[
   r[0] = __builtin_amdgcn_perm(x.hi, x.lo, 0x06040200u);       // byte 0 of elements 0..3
   r[1] = __builtin_amdgcn_perm(x.hi, x.lo, 0x07050301u);       // byte 1
 }
+// (typesize 16: load k of lane (Q, i) - Q = l >> 2, i = l & 3 - is element e + 16Q + i + 4k, so that the four lanes of a quad read 64
+//  contiguous bytes per instruction; quad_byte_transpose (k_decode.hip) then turns every plane dword into the bytes of the lane's
+//  own consecutive elements e + 4l .. e + 4l + 3 - the mirror image of unshuffle_store16)
 __device__ __forceinline__ ElemRows16 shuffle_load16(const gu8* src, uint32_t e, int lane) {
-  const gu8* in = src + (size_t)(e + 4u * (uint32_t)lane) * 16u;
+  const gu8* in = src + (size_t)(e + 16u * ((uint32_t)lane >> 2) + ((uint32_t)lane & 3u)) * 16u;
   ElemRows16 x;
 #pragma unroll
-  for (int k = 0; k < 4; k++) x.v[k] = g_ld16(in + 16 * k);
+  for (int k = 0; k < 4; k++) x.v[k] = g_ld16(in + 64 * k);
   return x;
 }
-__device__ __forceinline__ void shuffle_rows16(const ElemRows16& x, uint32_t (&r)[16]) {
+__device__ __forceinline__ void shuffle_rows16(const ElemRows16& x, uint32_t (&r)[16], int lane) {
   transpose4x4(x.v[0].x, x.v[1].x, x.v[2].x, x.v[3].x, r[0], r[1], r[2], r[3]);
   transpose4x4(x.v[0].y, x.v[1].y, x.v[2].y, x.v[3].y, r[4], r[5], r[6], r[7]);
   transpose4x4(x.v[0].z, x.v[1].z, x.v[2].z, x.v[3].z, r[8], r[9], r[10], r[11]);
   transpose4x4(x.v[0].w, x.v[1].w, x.v[2].w, x.v[3].w, r[12], r[13], r[14], r[15]);
+#pragma unroll
+  for (int j = 0; j < 16; j++) r[j] = quad_byte_transpose(r[j], lane);
 }
 template <int T>
 __device__ __forceinline__ void shuffle_store_rows(gu8* dst, uint32_t N, uint32_t e, int lane, const uint32_t (&r)[16]) {
@@ -85,10 +90,10 @@ __device__ __forceinline__ uint32_t shuffle_block_rows16(const gu8* src, gu8* ds
   uint32_t e = 0, r[16];
   for (; e + 512u <= N; e += 512u) {     // 2 steps per iteration (8 KiB of loads in flight per wave, as for typesize 8)
     const ElemRows16 a = shuffle_load16(src, e, lane), b = shuffle_load16(src, e + 256u, lane);
-    shuffle_rows16(a, r); shuffle_store_rows<16>(dst, N, e, lane, r);
-    shuffle_rows16(b, r); shuffle_store_rows<16>(dst, N, e + 256u, lane, r);
+    shuffle_rows16(a, r, lane); shuffle_store_rows<16>(dst, N, e, lane, r);
+    shuffle_rows16(b, r, lane); shuffle_store_rows<16>(dst, N, e + 256u, lane, r);
   }
-  for (; e + 256u <= N; e += 256u) { shuffle_rows16(shuffle_load16(src, e, lane), r); shuffle_store_rows<16>(dst, N, e, lane, r); }
+  for (; e + 256u <= N; e += 256u) { shuffle_rows16(shuffle_load16(src, e, lane), r, lane); shuffle_store_rows<16>(dst, N, e, lane, r); }
   return e;
 }
 template <int T>
@@ -191,7 +196,7 @@ __device__ uint32_t shuffle_block_wave_detect_x(const gu8* src, gu8* dst, uint32
   const uint32_t N = bsize / T;
   uint32_t row0[16], r[16];
   uint32_t per = (1u << T) - 1u;                       // wave-uniform: planes whose rows all equalled row 0 so far
-  if constexpr (T == 2) shuffle_rows2(shuffle_load2(src, 0u, lane), row0); else shuffle_rows16(shuffle_load16(src, 0u, lane), row0);
+  if constexpr (T == 2) shuffle_rows2(shuffle_load2(src, 0u, lane), row0); else shuffle_rows16(shuffle_load16(src, 0u, lane), row0, lane);
   auto step = [&](uint32_t e) {                        // r: the rows of step e
     if (per == 0u) { shuffle_store_rows<T>(dst, N, e, lane, r); return; }
     gu8* o = dst + e + 4u * (uint32_t)lane;
@@ -214,7 +219,7 @@ __device__ uint32_t shuffle_block_wave_detect_x(const gu8* src, gu8* dst, uint32
     }
     for (; e + 256u <= N; e += 256u) { shuffle_rows2(shuffle_load2(src, e, lane), r); step(e); }
   } else {
-    for (; e + 256u <= N; e += 256u) { shuffle_rows16(shuffle_load16(src, e, lane), r); step(e); }
+    for (; e + 256u <= N; e += 256u) { shuffle_rows16(shuffle_load16(src, e, lane), r, lane); step(e); }
   }
 #pragma unroll
   for (int k = 0; k < T; k++) {

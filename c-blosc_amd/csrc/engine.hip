@@ -661,7 +661,7 @@ static void add_decode_chunk(const Header& h, int fmt, int chunk_index, int32_t 
     b.chunk = chunk_index; b.blk = j; b.first_stream = (int32_t)nstreams;
     const bool last = (j == c.nblocks - 1) && c.leftover > 0;
     b.nstreams = (split && !last) ? T : 1;
-    b.bsize = last ? c.leftover : bs; b.flags = (fmt == FMT_ZSTD || fmt == FMT_ZLIB) ? BLK_Z : 0;   // BLK_Z: not in k_decode_streams' queues
+    b.bsize = last ? c.leftover : bs; b.flags = fmt == FMT_ZSTD ? BLK_Z : (fmt == FMT_ZLIB ? (BLK_Z | BLK_ZLIB) : 0);   // BLK_Z: not in k_decode_streams' queues
     nstreams += (size_t)b.nstreams;
     blocks.push_back(b);
   }
@@ -674,9 +674,11 @@ struct DecodeLaunch {
   uint32_t* d_spans; uint8_t* d_pat;             // periodic spans of the fused unshuffle (k_decode.hip: SpanCtx)
   uint32_t* d_cost;                              // [256] cycles per plane index (scheduling feedback)
   uint32_t* d_zticket; bool any_zstd;            // Zstd frames: k_zstd_entropy + k_zstd_exec (two-phase), the rest through k_zstd_streams
-  bool any_zlib;                                 // zlib streams: k_zlib_streams (ticket word d_zticket[2])
+  bool any_zlib;                                 // zlib streams: k_zlib_streams with per-XCD queues of its own (ticket words d_zticket[8..15])
+  const int32_t* d_zqlist; const int32_t* d_zqoff; size_t nstr_zlib;
   ZMeta* d_zmeta; ptrdiff_t zseq_delta;          // nullptr: everything through k_zstd_streams
   ZgLds* d_zgscr;                                // table scratch of the global two-phase variant (nullptr: not allocated)
+  ZcTab* d_zctab;                                // its 16-bit sequence tables, one dense record per frame (k_zstd_seq; nullptr: the 32-bit ones inside d_zgscr)
   const int32_t* d_qlist; const int32_t* d_qoff;   // per-XCD stream queues
   size_t nblk, nstr; int nchunks;
   bool any_shuf, any_bit, any_copy; int tiles_shuf, tiles_bit;
@@ -780,8 +782,12 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
     if (L.any_zstd && L.d_zmeta && zstd2) {
       {
         ProfScope ps(st, stream, "k_zstd_entropy");
-        if (zstd2 == 2 && L.d_zgscr) hipLaunchKernelGGL(k_zstd_entropy_t<true>, grid1(L.nstr, ZG_FRAMES), dim3(64), 0, stream, L.d_streams, (int)L.nstr, L.d_chunks, L.d_blocks, L.d_zmeta, L.zseq_delta, L.d_zgscr);
-        else hipLaunchKernelGGL(k_zstd_entropy_t<false>, grid1(L.nstr, ZG_FRAMES), dim3(64), 0, stream, L.d_streams, (int)L.nstr, L.d_chunks, L.d_blocks, L.d_zmeta, L.zseq_delta, (ZgLds*)nullptr);
+        if (zstd2 == 2 && L.d_zgscr) hipLaunchKernelGGL(k_zstd_entropy_t<true>, grid1(L.nstr, ZG_FRAMES), dim3(64), 0, stream, L.d_streams, (int)L.nstr, L.d_chunks, L.d_blocks, L.d_zmeta, L.zseq_delta, L.d_zgscr, L.d_zctab);
+        else hipLaunchKernelGGL(k_zstd_entropy_t<false>, grid1(L.nstr, ZG_FRAMES), dim3(64), 0, stream, L.d_streams, (int)L.nstr, L.d_chunks, L.d_blocks, L.d_zmeta, L.zseq_delta, (ZgLds*)nullptr, (ZcTab*)nullptr);
+      }
+      if (zstd2 == 2 && L.d_zgscr && BAMD_ZSTD_SEQ_KERNEL && !BAMD_ZSTD_LDS_FSE) {
+        ProfScope ps(st, stream, "k_zstd_seq");      // the sequence streams of the frames phase A took, one lane per frame
+        hipLaunchKernelGGL(k_zstd_seq, grid1(L.nstr, ZSEQ_FRAMES), dim3(64), 0, stream, L.d_streams, (int)L.nstr, L.d_chunks, L.d_blocks, L.d_zmeta, L.zseq_delta, L.d_zgscr, L.d_zctab);
       }
       {
         ProfScope ps(st, stream, "k_zstd_exec");
@@ -812,8 +818,8 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
     }
     if (L.any_zlib) {
       ProfScope ps(st, stream, "k_zlib_streams");
-      hipLaunchKernelGGL(k_zlib_streams, dim3(persistent_grid(st, L.nstr, ZLIB_WAVES_PER_CU)), dim3(64), 0, stream, L.d_streams, (int)L.nstr, L.d_status,
-                         L.d_zticket + 2, L.d_cost + 259, L.d_chunks, L.d_blocks);
+      hipLaunchKernelGGL(k_zlib_streams, dim3(persistent_grid(st, L.nstr_zlib ? L.nstr_zlib : 1, ZLIB_WAVES_PER_CU)), dim3(64), 0, stream, L.d_streams, L.d_status,
+                         L.d_zticket + 8, L.d_zqlist, L.d_zqoff, L.d_cost + 259, L.d_chunks, L.d_blocks, L.d_blkdone, st.single_queue ? 1 : 0);
     }
     if (L.any_shuf) {
       ProfScope ps(st, stream, "k_unshuffle");
@@ -837,11 +843,12 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
 
 static void filter_tiles(ChunkDesc& c, bool& any_shuf, bool& any_bit, int& tiles_shuf, int& tiles_bit, bool may_fuse) {
   const int32_t T = c.typesize, N = c.blocksize / T;
-  // (Zstd / zlib chunks: only unsplit ones - the wave that decodes a block's one stream unshuffles it, k_decode.hip: fused_unshuffle_own_block;
-  //  BLOSC_AMD_FUSE_Z=0 keeps k_unshuffle for them: A/B switch)
+  // (Zstd chunks: only unsplit ones - the wave that decodes a block's one stream unshuffles it, k_decode.hip: fused_unshuffle_own_block;
+  //  zlib chunks: split ones too, k_zlib_streams has per-XCD queues and the hand-off of the LZ4 kernel; BLOSC_AMD_FUSE_Z=0 keeps k_unshuffle
+  //  for both: A/B switch)
   static const bool fuse_z = !(getenv("BLOSC_AMD_FUSE_Z") && atoi(getenv("BLOSC_AMD_FUSE_Z")) == 0);
   const bool zfmt = c.fmt == FMT_ZSTD || c.fmt == FMT_ZLIB;
-  if ((c.mode & CH_SHUFFLE) && fused_typesize(T) && fuse_enabled() && may_fuse && (!zfmt || (fuse_z && c.nsplits == 1))) { c.mode |= CH_FUSED_UNSHUF; return; }
+  if ((c.mode & CH_SHUFFLE) && fused_typesize(T) && fuse_enabled() && may_fuse && (!zfmt || (fuse_z && (c.fmt == FMT_ZLIB || c.nsplits == 1)))) { c.mode |= CH_FUSED_UNSHUF; return; }
   if (c.mode & CH_SHUFFLE) {
     any_shuf = true;
     int t = (N + shuffle_tile_elems(T) - 1) / shuffle_tile_elems(T); if (t < 1) t = 1;
@@ -867,7 +874,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   std::vector<ChunkDesc> chunks((size_t)n);
   std::vector<BlockDesc> blocks;
   std::vector<uint8_t> live((size_t)n, 0);
-  size_t nstr = 0, nstr_z = 0, filt_bytes = 0, zlit_bytes = 0, io_src = 0, io_dst = 0;      // nstr_z: streams of Zstd / zlib chunks (their own kernels')
+  size_t nstr = 0, nstr_z = 0, nstr_zlib = 0, filt_bytes = 0, zlit_bytes = 0, io_src = 0, io_dst = 0;      // nstr_z: streams of Zstd / zlib chunks (their own kernels')
   DecodeLaunch L{};
   for (int i = 0; i < n; i++) {
     ChunkDesc& c = chunks[(size_t)i];
@@ -886,6 +893,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
     if (c.fmt == FMT_ZSTD && !(c.mode & CH_MEMCPYED)) { L.any_zstd = true; zlit_bytes = align_up(zlit_bytes, 256) + (size_t)c.nbytes; }
     if (c.fmt == FMT_ZLIB && !(c.mode & CH_MEMCPYED)) L.any_zlib = true;
     if (c.fmt == FMT_ZSTD || c.fmt == FMT_ZLIB) nstr_z += nstr - (size_t)c.first_stream;     // (memcpyed chunks have no streams)
+    if (c.fmt == FMT_ZLIB) nstr_zlib += nstr - (size_t)c.first_stream;
     if (!device_ptrs) { io_src = align_up(io_src, 256) + (size_t)c.cbytes; io_dst = align_up(io_dst, 256) + (size_t)c.nbytes; }
   }
   const size_t nblk = blocks.size();
@@ -900,6 +908,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   const size_t o_streams = cv.take(sizeof(StreamDesc) * (nstr ? nstr : 1));
   const size_t o_status = cv.take(sizeof(int32_t) * (size_t)n + 64 + sizeof(uint32_t) * (nblk ? nblk : 1));   // + 8 tickets + per-block arrival counters
   const size_t o_queues = cv.take(sizeof(int32_t) * (9 + (nstr ? nstr : 1)));
+  const size_t o_zqueues = cv.take(sizeof(int32_t) * (9 + (nstr ? nstr : 1)));      // k_zlib_streams' queues
   const size_t nbl = blist[0].size() + blist[1].size();
   const size_t o_blist = cv.take(sizeof(int32_t) * (3 * nbl + 1) + 64);   // counters + tickets | per group: candidates, two sorted lists
   const size_t o_skind = cv.take(sizeof(uint32_t) * (nstr ? nstr : 1));
@@ -912,6 +921,9 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   const size_t o_zmeta = cv.take(L.any_zstd ? sizeof(ZMeta) * (nstr ? nstr : 1) : 64);
   const size_t o_zticket = cv.take(64);
   const size_t o_zgscr = cv.take((L.any_zstd && zstd2_mode() == 2) ? sizeof(ZgLds) * (nstr ? nstr : 1) : 64);
+  static const bool zctab_on = !(getenv("BLOSC_AMD_ZSTD_CTAB") && atoi(getenv("BLOSC_AMD_ZSTD_CTAB")) == 0);      // 0: k_zstd_seq reads the 32-bit tables (A/B switch)
+  const bool use_zctab = L.any_zstd && zstd2_mode() == 2 && zctab_on && BAMD_ZSTD_SEQ_KERNEL && !BAMD_ZSTD_LDS_FSE;
+  const size_t o_zctab = cv.take(use_zctab ? sizeof(ZcTab) * (nstr ? nstr : 1) : 64);
   const size_t o_far = cv.take(far_stride ? far_stride * far_wgs : 256);
   if (st.dev.ensure(cv.off)) return -1;
   uint8_t* D = st.dev.base;
@@ -937,11 +949,14 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   }
   std::vector<int32_t> queues;
   build_xcd_queues(blocks, nstr, st.dec_cost, st.dec_cost_valid, queues, st.single_queue ? 1 : 8);
+  std::vector<int32_t> zqueues;
+  if (L.any_zlib) build_xcd_queues(blocks, nstr, nullptr, false, zqueues, st.single_queue ? 1 : 8, BLK_ZLIB);
   Carver pc;
   const size_t p_chunks = pc.take(sizeof(ChunkDesc) * (size_t)n);
   const size_t p_blocks = pc.take(sizeof(BlockDesc) * (nblk ? nblk : 1));
   const size_t p_status = pc.take(sizeof(int32_t) * (size_t)n);
   const size_t p_queues = pc.take(sizeof(int32_t) * queues.size());
+  const size_t p_zqueues = pc.take(sizeof(int32_t) * (zqueues.size() + 1));
   const size_t p_cost = pc.take(sizeof(uint32_t) * kCostWords);
   const size_t p_blist = pc.take(sizeof(int32_t) * (nbl + 1) + 64);
   if (st.pin.ensure(pc.off)) return -1;
@@ -956,6 +971,10 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   HIP_TRY(hipMemcpyAsync(D + o_chunks, P + p_chunks, sizeof(ChunkDesc) * (size_t)n, hipMemcpyHostToDevice, stream));
   if (nblk) HIP_TRY(hipMemcpyAsync(D + o_blocks, P + p_blocks, sizeof(BlockDesc) * nblk, hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemcpyAsync(D + o_queues, P + p_queues, sizeof(int32_t) * queues.size(), hipMemcpyHostToDevice, stream));
+  if (!zqueues.empty()) {
+    memcpy(P + p_zqueues, zqueues.data(), sizeof(int32_t) * zqueues.size());
+    HIP_TRY(hipMemcpyAsync(D + o_zqueues, P + p_zqueues, sizeof(int32_t) * zqueues.size(), hipMemcpyHostToDevice, stream));
+  }
   HIP_TRY(hipMemsetAsync(D + o_status, 0, sizeof(int32_t) * (size_t)n + 64 + sizeof(uint32_t) * (nblk ? nblk : 1), stream));
 
   L.d_chunks = (ChunkDesc*)(D + o_chunks); L.d_blocks = (BlockDesc*)(D + o_blocks);
@@ -963,6 +982,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   L.d_ticket = (uint32_t*)(D + o_status + sizeof(int32_t) * (size_t)n + 32);
   L.d_blkdone = (uint32_t*)(D + o_status + sizeof(int32_t) * (size_t)n + 64);
   L.d_qoff = (const int32_t*)(D + o_queues); L.d_qlist = L.d_qoff + 9;
+  L.d_zqoff = (const int32_t*)(D + o_zqueues); L.d_zqlist = L.d_zqoff + 9; L.nstr_zlib = nstr_zlib;
   L.d_spans = span_enabled() ? (uint32_t*)(D + o_spans) : nullptr; L.d_pat = D + o_pat;
   L.d_cost = (uint32_t*)(D + o_cost);
   HIP_TRY(hipMemsetAsync(D + o_cost, 0, sizeof(uint32_t) * kCostWords, stream));
@@ -970,6 +990,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   if (L.any_zstd || L.any_zlib) HIP_TRY(hipMemsetAsync(D + o_zticket, 0, 64, stream));
   L.d_zmeta = L.any_zstd ? (ZMeta*)(D + o_zmeta) : nullptr; L.zseq_delta = (ptrdiff_t)o_zseq - (ptrdiff_t)o_zlit + 8;
   L.d_zgscr = (L.any_zstd && zstd2_mode() == 2) ? (ZgLds*)(D + o_zgscr) : nullptr;
+  L.d_zctab = use_zctab ? (ZcTab*)(D + o_zctab) : nullptr;
   L.nblk = nblk; L.nstr = nstr; L.nchunks = n;
   L.d_bctl = (uint32_t*)(D + o_blist);
   L.d_bcand[0] = (const int32_t*)(D + o_blist + 64); L.d_bcand[1] = L.d_bcand[0] + blist[0].size();
@@ -985,7 +1006,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   HIP_TRY(hipStreamSynchronize(stream));
   HT_MARK(1, 4);     // waiting for the device
   prof_collect(st);
-  if (nblk && check_done((const uint32_t*)(P + p_cost), nstr - nstr_lds - nstr_z, L.any_zstd ? nstr : 0, "decompress", blist[0].size() + blist[1].size(), L.any_zlib ? nstr : 0)) return -1;
+  if (nblk && check_done((const uint32_t*)(P + p_cost), nstr - nstr_lds - nstr_z, L.any_zstd ? nstr : 0, "decompress", blist[0].size() + blist[1].size(), nstr_zlib)) return -1;
   if (nstr >= 4096) { memcpy(st.dec_cost, P + p_cost, sizeof st.dec_cost); st.dec_cost_valid = true; }
   const int32_t* stt = (const int32_t*)(P + p_status);
   for (int i = 0; i < n; i++) {
@@ -1081,8 +1102,8 @@ int engine_getitem(const void* src, int start, int nitems, void* dest, bool src_
   const size_t p_blocks = pc.take(sizeof(BlockDesc) * nblk);
   const size_t p_status = pc.take(sizeof(int32_t));
   const size_t p_cost = pc.take(sizeof(uint32_t) * kCostWords);
-  std::vector<int32_t> queues;
-  build_xcd_queues(blocks, nstr, st.dec_cost, st.dec_cost_valid, queues, st.single_queue ? 1 : 8);
+  std::vector<int32_t> queues;     // (one chunk, one format: the zlib kernel's queues when it is a zlib chunk, k_decode_streams' otherwise)
+  build_xcd_queues(blocks, nstr, st.dec_cost, st.dec_cost_valid, queues, st.single_queue ? 1 : 8, fmt == FMT_ZLIB ? (uint32_t)BLK_ZLIB : 0u);
   const size_t p_queues = pc.take(sizeof(int32_t) * queues.size());
   if (st.pin.ensure(pc.off)) return -1;
   uint8_t* P = st.pin.base;
@@ -1102,6 +1123,7 @@ int engine_getitem(const void* src, int start, int nitems, void* dest, bool src_
   L.d_cost = (uint32_t*)(D + o_cost);   // a handful of blocks: the plane costs are not fed back, only the task count is checked
   HIP_TRY(hipMemsetAsync(D + o_cost, 0, sizeof(uint32_t) * kCostWords, stream));
   L.any_zstd = fmt == FMT_ZSTD; L.any_zlib = fmt == FMT_ZLIB; L.d_zticket = (uint32_t*)(D + o_zticket);
+  L.d_zqoff = L.d_qoff; L.d_zqlist = L.d_qlist; L.nstr_zlib = L.any_zlib ? nstr : 0;
   if (L.any_zstd || L.any_zlib) HIP_TRY(hipMemsetAsync(D + o_zticket, 0, 64, stream));
   L.nblk = nblk; L.nstr = nstr; L.nchunks = 1; L.nstr_queued = (L.any_zstd || L.any_zlib) ? 0 : nstr;    // a handful of blocks: always through k_decode_streams (Zstd / zlib: their own kernels)
   if (launch_decode(st, L, stream)) return -1;

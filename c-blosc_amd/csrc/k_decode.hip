@@ -782,6 +782,19 @@ __device__ __forceinline__ void transpose4x4(uint32_t r0, uint32_t r1, uint32_t 
   t2 = __builtin_amdgcn_perm(b23, b01, 0x05040100u); t3 = __builtin_amdgcn_perm(b23, b01, 0x07060302u);
 }
 
+// 4 x 4 byte transpose ACROSS the four lanes of a quad: lane i ends up with (byte i of lane 0's dword, byte i of lane 1's, of lane 2's,
+// of lane 3's).  Four DPP quad broadcasts and three v_perm.  It is its own inverse, and it is what makes the 16-byte accesses of
+// typesize 16 coalesce: a lane that holds a plane dword "elements 4l .. 4l+3" afterwards holds "elements 16Q + i, + 4, + 8, + 12"
+// (Q = l >> 2, i = l & 3), so the four lanes of a quad store (or load) 64 CONTIGUOUS bytes per instruction instead of 16-byte
+// pieces 64 bytes apart (measured before: the fused typesize-16 unshuffle cost more than the stand-alone kernel it replaced).
+__device__ __forceinline__ uint32_t quad_byte_transpose(uint32_t d, int lane) {
+  const uint32_t i = (uint32_t)lane & 3u, sel = (i | ((4u + i) << 8)) * 0x00010001u;
+  const uint32_t b0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x00, 0xf, 0xf, true), b1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0x55, 0xf, 0xf, true);
+  const uint32_t b2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0xAA, 0xf, 0xf, true), b3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d, 0xFF, 0xf, 0xf, true);
+  const uint32_t lo = __builtin_amdgcn_perm(b1, b0, sel), hi = __builtin_amdgcn_perm(b3, b2, sel);      // low two bytes: (b0[i], b1[i]) / (b2[i], b3[i])
+  return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+}
+
 // One step: lane l owns elements e + 4l .. e + 4l + 3: a 4-byte load from every plane (each wave load
 // instruction reads 256 contiguous bytes of one plane), a byte transpose in registers, and T*4 contiguous
 // output bytes per lane (consecutive lanes are consecutive in memory: fully coalesced 16-byte stores).
@@ -910,12 +923,16 @@ __device__ void unshuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize,
 // read their dword from the first row of the pattern table in every iteration (the same 256 bytes: cache-resident) instead
 // of holding it in a register per plane.
 __device__ __forceinline__ void unshuffle_store16(gu8* dst, uint32_t e, int lane, const uint32_t (&x)[16]) {
-  gu8* o = dst + (size_t)(e + 4u * (uint32_t)lane) * 16u;
+  // x[j]: plane j's bytes of elements e + 4l .. e + 4l + 3.  After the quad transpose the lane holds elements e + 16Q + i + 4k (k = 0..3):
+  // store k of a quad covers 64 contiguous bytes
+  gu8* o = dst + (size_t)(e + 16u * ((uint32_t)lane >> 2) + ((uint32_t)lane & 3u)) * 16u;
   uint32_t t[4][4];
 #pragma unroll
-  for (int q = 0; q < 4; q++) transpose4x4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3], t[q][0], t[q][1], t[q][2], t[q][3]);
+  for (int q = 0; q < 4; q++)
+    transpose4x4(quad_byte_transpose(x[4 * q], lane), quad_byte_transpose(x[4 * q + 1], lane), quad_byte_transpose(x[4 * q + 2], lane), quad_byte_transpose(x[4 * q + 3], lane),
+                 t[q][0], t[q][1], t[q][2], t[q][3]);
 #pragma unroll
-  for (int k = 0; k < 4; k++) st16_dst(o + 16 * k, make_uint4(t[0][k], t[1][k], t[2][k], t[3][k]));      // element k
+  for (int k = 0; k < 4; k++) st16_dst(o + 64 * k, make_uint4(t[0][k], t[1][k], t[2][k], t[3][k]));      // element e + 16Q + i + 4k
 }
 __device__ __attribute__((noinline)) void unshuffle_block_wave_16(const gu8* src_, gu8* dst_, uint32_t bsize_, int lane, const uint32_t* spans_,
                                                                   const gu8* pat_, const StreamDesc* sds_, uint32_t pstride_) {

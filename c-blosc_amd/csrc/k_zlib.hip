@@ -126,17 +126,25 @@ __device__ __forceinline__ int zlib_decode_wave(const uint8_t* in_, int n_, uint
   return (int)op;
 }
 
-// Persistent waves over ALL streams of the launch; the streams of Zlib chunks are taken here, splits stored raw included
-// (k_decode_streams leaves them alone); an unsplit block is unshuffled by the wave that decoded it (fused_unshuffle_own_block).
+// Persistent waves over the streams of the launch's zlib chunks, splits stored raw included (k_decode_streams leaves them alone).
 constexpr int ZLIB_WAVES_PER_CU = 16;
-__global__ __launch_bounds__(64, 4) void k_zlib_streams(StreamDesc* __restrict__ streams, int nstreams, int32_t* __restrict__ status,
-                                                     uint32_t* __restrict__ ticket, uint32_t* __restrict__ done,
-                                                     const ChunkDesc* __restrict__ chunks, const BlockDesc* __restrict__ blocks) {
+// Round 3: per-XCD queues like k_decode_streams (qoff[9] | stream indices; the host deals whole BLOCKS to the XCDs,
+// queue_order.h: build_xcd_queues with BLK_ZLIB).  zlib chunks are split like LZ4's (blosc/blosc.c:929-959: only Zstd is not), so a block
+// is typesize streams on typesize waves; with all of them on one XCD the wave that completes the last one can transpose the block
+// out of that XCD's L2 (the hand-off of decode_one_stream: stores drained, relaxed counter, acquire = L1 invalidate) and the
+// stand-alone k_unshuffle pass (3.4 ms per 8 GiB behind a 20 - 33 ms kernel) is gone.
+__global__ __launch_bounds__(64, 4) void k_zlib_streams(StreamDesc* __restrict__ streams, int32_t* __restrict__ status,
+                                                     uint32_t* __restrict__ tickets /*[8]*/, const int32_t* __restrict__ qlist, const int32_t* __restrict__ qoff /*[9]*/,
+                                                     uint32_t* __restrict__ done, const ChunkDesc* __restrict__ chunks, const BlockDesc* __restrict__ blocks,
+                                                     uint32_t* __restrict__ blk_done, int single_queue) {
   __shared__ zi::Tabs tabs;
   const int lane = threadIdx.x & 63;
-  uint32_t sid = take_ticket(ticket, lane);
+  const uint32_t xcc = single_queue ? 0u : (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);
+  const uint32_t qbase = (uint32_t)qoff[xcc], qlen = (uint32_t)qoff[xcc + 1] - qbase;
+  uint32_t t = take_ticket(tickets + xcc, lane);
   uint32_t ndone = 0;
-  while (sid < (uint32_t)nstreams) {
+  while (t < qlen) {
+    const uint32_t sid = (uint32_t)qlist[qbase + t];
     StreamDesc* sd = streams + sid;
     const int32_t csize = (int32_t)uni((uint32_t)sd->in_size), want = (int32_t)uni((uint32_t)sd->out_size);
     if (uni((uint32_t)sd->fmt) == (uint32_t)FMT_ZLIB && csize >= 0) {
@@ -149,10 +157,28 @@ __global__ __launch_bounds__(64, 4) void k_zlib_streams(StreamDesc* __restrict__
         sd->result = got;
         if (got != want) atomicMin(&status[sd->chunk], (int32_t)ST_BADCODEC);   // blosc.c:780-782
       }
-      if (got == want) fused_unshuffle_own_block(chunks + uni((uint32_t)sd->chunk), blocks + uni((uint32_t)sd->aux), lane);
+      const ChunkDesc* c = chunks + uni((uint32_t)sd->chunk);
+      const uint32_t gb = uni((uint32_t)sd->aux);
+      const BlockDesc* b = blocks + gb;
+      const uint32_t nstreams = uni((uint32_t)b->nstreams);
+      if (got == want && (uni(c->mode) & CH_FUSED_UNSHUF)) {
+        if (nstreams == 1u) fused_unshuffle_own_block(c, b, lane);
+        else {
+          BAMD_WAIT_STORES();
+          uint32_t old = 0;
+          if (lane == 0) old = __hip_atomic_fetch_add(&blk_done[gb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          old = (uint32_t)__builtin_amdgcn_readlane((int)old, 0);
+          if (old + 1u == nstreams) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const uint32_t blk = uni((uint32_t)b->blk), bsize = uni((uint32_t)b->bsize);
+            unshuffle_block_wave(c->filt + (size_t)blk * filt_block_stride(*c), c->dst + (size_t)blk * (size_t)uni((uint32_t)c->blocksize), bsize,
+                                 (int)uni((uint32_t)c->typesize), lane, nullptr, nullptr, nullptr, filt_plane_stride(*c, bsize, (int)nstreams));
+          }
+        }
+      }
     }
     ndone++;
-    sid = take_ticket(ticket, lane);
+    t = take_ticket(tickets + xcc, lane);
   }
   if (lane == 0 && ndone) atomicAdd(done, ndone);
 }

@@ -24,15 +24,24 @@
 #ifndef BAMD_ZSTD_LDS_FSE
 #define BAMD_ZSTD_LDS_FSE 0      // the three sequence tables of a frame compact in LDS (40 KiB per wave: 4 waves per CU).  Measured (8 GiB of reference-written frames, k_zstd_entropy): bench19 27.1 ms with, 28.8 without; linspace 14.5 with, 6.1 without - the lookups are not what the kernel waits for, the occupancy is what it needs.  Off.
 #endif
+#ifndef BAMD_ZSTD_SEQ_KERNEL
+#define BAMD_ZSTD_SEQ_KERNEL 1    // the FSE sequence streams of the global two-phase path in a kernel of their own, one lane per frame (k_zstd_seq); 0: inside k_zstd_entropy, on one lane in four
+#endif
+#ifndef BAMD_ZSEQ_FAST
+#define BAMD_ZSEQ_FAST 1          // zseq_run: three refill points per sequence while >= 12 stream bytes are left (0: the general bit reader for every field)
+#endif
+#ifndef BAMD_ZENT_SKIP
+#define BAMD_ZENT_SKIP 0         // timing experiments only (the results are wrong): bit 0 = no FSE sequence loop, bit 1 = no Huffman literal streams - what is left is the per-frame set-up
+#endif
 namespace bamd {
 
-enum : uint32_t { ZM_FALLBACK = 0, ZM_READY = 1, ZM_ERROR = 2 };
+enum : uint32_t { ZM_FALLBACK = 0, ZM_READY = 1, ZM_ERROR = 2, ZM_SEQ = 3 };      // ZM_SEQ: everything but the sequence stream is done (k_zstd_seq turns it into READY or ERROR)
 struct ZMeta {
   uint32_t state;
   uint32_t nseq, regen;
   uint32_t lit_mode;     // 0: decoded into the literal scratch, 1: raw at in + lit_src, 2: RLE byte lit_src
   uint32_t lit_src;
-  uint32_t pad_[3];
+  uint32_t pad_[3];      // ZM_SEQ: offset of the sequence bit stream in the frame, its length, the three accuracy logs
 };
 
 // LDS of one frame group: the Huffman table and the three FSE tables are never needed at the same time
@@ -44,6 +53,12 @@ struct ZgLds {
   uint8_t w[256];
 };
 constexpr int ZG_FRAMES = 16;        // frames per wavefront (4 lanes each)
+// The three sequence tables of a frame as 16-bit cells (zd::fse_build's `compact`), one dense record per frame: what k_zstd_seq reads.
+// 2.5 KiB per frame = 160 MiB for the 65 536 frames of the benchmark batch, all of them live at once: inside the 256 MiB Infinity
+// Cache, where the 32-bit tables inside the 8.4 KiB ZgLds records (550 MiB) were not - the sequence loop is bound by random
+// 64-byte sector reads (41 GB per launch for 0.33 GB of input, profiles/r03_traffic_cfg4.json), not by its instructions
+// (one lane per frame instead of one in four: 18 -> 16.3 ms, profiles/r03v_zent_split.txt).
+struct ZcTab { uint16_t ll[512], of[256], ml[512]; };
 
 __device__ __forceinline__ uint64_t zpack(uint32_t ll, uint32_t ml, uint32_t off) { return (uint64_t)ll | ((uint64_t)ml << 18) | ((uint64_t)off << 36); }
 
@@ -52,12 +67,113 @@ __device__ __forceinline__ uint64_t* zseq_ptr(const uint8_t* lit, ptrdiff_t zseq
   return (uint64_t*)(((uintptr_t)lit + (uintptr_t)zseq_delta) & ~(uintptr_t)7);
 }
 
+// The FSE sequence stream of one frame on ONE LANE: zd::seq_next on plain locals (same order of reads, same checks - zstd_serial.h
+// is the specification and what the CPU tests pin to the reference); symbol codes above the format's limits cannot occur: a
+// 6-bit symbol of a table whose description was accepted is at most 35 / 31 / 52 by fse_read_ncount's max_sym.
+// Everything the loop carries is a plain local: SeqState's repeat offsets are an array indexed by a decoded value, which put the
+// WHOLE state - bit reader included - on the stack (every field access a scratch load or store, every refill a flat load with a
+// vmcnt(0) + lgkmcnt(0) behind it: the ISA of round 2's loop).  The bit stream is read through a global pointer, four bytes per
+// refill, the NEXT refill's word already on its way.  gl / go / gm: the frame's three tables (32-bit cells, global scratch) or,
+// with BAMD_ZSTD_LDS_FSE, tl / to / tm: their compact LDS copies.
+template <bool GC = false>       // GC: tl / to / tm are 16-bit cells in GLOBAL memory (ZcTab)
+__device__ __forceinline__ bool zseq_run(zd::SeqState& st, int nseq, const uint32_t* gl_, const uint32_t* go_, const uint32_t* gm_,
+                                         const uint16_t* tl, const uint16_t* to, const uint16_t* tm, int al_l, int al_o, int al_m, uint64_t* sq_) {
+  bool fine = true;
+  const BAMD_GAS uint32_t* gl = (const BAMD_GAS uint32_t*)gl_; const BAMD_GAS uint32_t* go = (const BAMD_GAS uint32_t*)go_;      // (global_load, not flat_load)
+  const BAMD_GAS uint32_t* gm = (const BAMD_GAS uint32_t*)gm_; BAMD_GAS uint64_t* sq = (BAMD_GAS uint64_t*)sq_;
+  const gu8* bp = as_global(st.b.p);
+  int bytepos = st.b.bytepos, nacc = st.b.nacc, off = st.b.off;
+  uint64_t acc = st.b.acc;          // the low nacc bits are unread stream bits (what lies above them is stale: every extraction masks)
+  uint32_t sl = st.sl, so = st.so, sm = st.sm, r0 = 1u, r1 = 4u, r2 = 8u;
+  uint32_t nxt = bytepos >= 4 ? g_ld4(bp + bytepos - 4) : 0u;          // the word the next refill will take (valid while bytepos >= 4)
+  auto rd = [&](int nb_) -> uint32_t {                                   // zd::back_read on the locals: any state of the stream, its last bytes included
+    if (nb_ == 0) return 0u;
+    if (nacc < nb_ && bytepos >= 4) {
+      bytepos -= 4; acc = (acc << 32) | nxt; nacc += 32;
+      if (bytepos >= 4) nxt = g_ld4(bp + bytepos - 4);
+    }
+    while (nacc < nb_ && bytepos > 0) { bytepos--; acc = (acc << 8) | bp[bytepos]; nacc += 8; }
+    if (nacc < nb_) { acc <<= (nb_ - nacc); nacc = nb_; }
+    const uint32_t v = (uint32_t)(acc >> (nacc - nb_)) & (nb_ >= 32 ? 0xffffffffu : ((1u << nb_) - 1u));
+    nacc -= nb_;
+    acc &= (nacc ? ((1ull << nacc) - 1ull) : 0ull);
+    off -= nb_;
+    return v;
+  };
+  // The same reads while at least 12 bytes of the stream are left - i.e. for all but the last two or three sequences of a frame: three
+  // refill points per sequence instead of a test in front of each of the six fields.  A refill leaves >= 32 unread bits; the fields
+  // between two refill points need at most 31 (offset bits), 16 + 16 (match and literal length bits) and 9 + 9 + 8 (the three
+  // state updates).  rd() above was ~130 instructions per field with its byte loop and its end-of-stream cases, six times per
+  // sequence, and the loop as a whole ~800 (profiles/r03u_zent_split.txt: 18 of the entropy kernel's 27 ms).
+  auto refill = [&]() {
+    if (nacc <= 32) { bytepos -= 4; acc = (acc << 32) | nxt; nacc += 32; if (bytepos >= 4) nxt = g_ld4(bp + bytepos - 4); }
+  };
+  auto take = [&](int nb_) -> uint32_t {                                 // nb_ <= 31 and nacc >= nb_ (nacc - nb_ = 64 only with nb_ = 0: masked to nothing)
+    const uint32_t v = (uint32_t)(acc >> ((nacc - nb_) & 63)) & ((1u << nb_) - 1u);
+    nacc -= nb_; off -= nb_;
+    return v;
+  };
+  for (int i = 0; fine && i < ((BAMD_ZENT_SKIP & 1) ? 0 : nseq); i++) {
+    uint32_t cl, co, cm;
+    if (GC) { cl = ((const BAMD_GAS uint16_t*)tl)[sl]; co = ((const BAMD_GAS uint16_t*)to)[so]; cm = ((const BAMD_GAS uint16_t*)tm)[sm]; }
+    else if (BAMD_ZSTD_LDS_FSE) { cl = tl[sl]; co = to[so]; cm = tm[sm]; }
+    else {                                                                // the same compact form out of the 32-bit cells
+      const uint32_t el = gl[sl], eo = go[so], em = gm[sm];
+      cl = (el & 63u) | ((((el >> 16) + (1u << al_l)) >> ((el >> 8) & 0xffu)) << 6);
+      co = (eo & 63u) | ((((eo >> 16) + (1u << al_o)) >> ((eo >> 8) & 0xffu)) << 6);
+      cm = (em & 63u) | ((((em >> 16) + (1u << al_m)) >> ((em >> 8) & 0xffu)) << 6);
+    }
+    const int lc = (int)(cl & 63u), oc = (int)(co & 63u), mc = (int)(cm & 63u);
+    if (oc > 31 || mc > 52 || lc > 35) { fine = false; break; }
+    const uint32_t xl = cl >> 6, xm = cm >> 6, xo = co >> 6;
+    const int nl = al_l - zd::hb32(xl), nm = al_m - zd::hb32(xm), no = al_o - zd::hb32(xo);
+    uint32_t ov, q_ml, q_ll;
+    if (BAMD_ZSEQ_FAST && bytepos >= 12) {
+      refill(); ov = (1u << oc) + take(oc);
+      refill(); q_ml = zd::ml_base(mc) + take(zd::ml_bits(mc)); q_ll = zd::ll_base(lc) + take(zd::ll_bits(lc));
+      if (i + 1 != nseq) {
+        refill();
+        sl = ((xl << nl) - (1u << al_l)) + take(nl);
+        sm = ((xm << nm) - (1u << al_m)) + take(nm);
+        so = ((xo << no) - (1u << al_o)) + take(no);
+      }
+    } else {
+      ov = (1u << oc) + rd(oc);
+      q_ml = zd::ml_base(mc) + rd(zd::ml_bits(mc));
+      q_ll = zd::ll_base(lc) + rd(zd::ll_bits(lc));
+      if (i + 1 != nseq) {
+        sl = ((xl << nl) - (1u << al_l)) + rd(nl);
+        sm = ((xm << nm) - (1u << al_m)) + rd(nm);
+        so = ((xo << no) - (1u << al_o)) + rd(no);
+      }
+    }
+    if (off < 0) { fine = false; break; }
+    uint32_t q_off;
+    if (ov > 3) { q_off = ov - 3u; r2 = r1; r1 = r0; r0 = q_off; }
+    else {
+      uint32_t idx = ov - 1u;
+      if (q_ll == 0) idx++;
+      if (idx == 0) q_off = r0;
+      else {
+        q_off = idx == 1u ? r1 : (idx == 2u ? r2 : r0 - 1u);
+        if (q_off == 0) { fine = false; break; }
+        if (idx > 1) r2 = r1;
+        r1 = r0; r0 = q_off;
+      }
+    }
+    sq[i] = zpack(q_ll, q_ml, q_off);
+  }
+  st.b.off = off;
+  return fine;
+}
+
 // GLOBAL = false: the tables of the 16 frames in LDS (128 KiB: ONE wave per CU).  GLOBAL = true: the same structure per frame
 // in a global scratch (gscr[sid]): every table access becomes a trip to L2 / HBM, but nothing limits the number of waves
 // per CU any more - 65 536 frames are 4096 waves, all of them resident at once (BLOSC_AMD_ZSTD2=2).
 template <bool GLOBAL>
 __global__ __launch_bounds__(64) void k_zstd_entropy_t(const StreamDesc* __restrict__ streams, int nstreams, const ChunkDesc* __restrict__ chunks,
-                                                       const BlockDesc* __restrict__ blocks, ZMeta* __restrict__ meta, ptrdiff_t zseq_delta, ZgLds* __restrict__ gscr) {
+                                                       const BlockDesc* __restrict__ blocks, ZMeta* __restrict__ meta, ptrdiff_t zseq_delta, ZgLds* __restrict__ gscr,
+                                                       ZcTab* __restrict__ ctab) {
   __shared__ uint64_t lds_raw[GLOBAL ? 1 : (sizeof(ZgLds) * ZG_FRAMES + 7) / 8];
   ZgLds* lds = (ZgLds*)lds_raw;
   // Round 3 (GLOBAL only): the three SEQUENCE tables of every frame of the wave, compact, in LDS.  With all tables in the global
@@ -125,7 +241,7 @@ __global__ __launch_bounds__(64) void k_zstd_entropy_t(const StreamDesc* __restr
   const uint32_t gstate = (uint32_t)__builtin_amdgcn_ds_bpermute(src0, (int)state);
   const int gtype = __builtin_amdgcn_ds_bpermute(src0, lh.type);
   uint32_t lit_ok = 1;
-  if (take && gstate == ZM_READY && gtype == 2) {
+  if (take && gstate == ZM_READY && gtype == 2 && !(BAMD_ZENT_SKIP & 2)) {
     const int g_regen = __builtin_amdgcn_ds_bpermute(src0, lh.regen), g_nstreams = __builtin_amdgcn_ds_bpermute(src0, lh.nstreams);
     const int g_hs = __builtin_amdgcn_ds_bpermute(src0, hs_off), g_hlen = __builtin_amdgcn_ds_bpermute(src0, hlen);
     const int g_mb = __builtin_amdgcn_ds_bpermute(src0, huf.maxbits);
@@ -173,7 +289,11 @@ __global__ __launch_bounds__(64) void k_zstd_entropy_t(const StreamDesc* __restr
           for (int s_ = 0; s_ < t_nsym[k]; s_++) L->norm[k][s_] = k == 0 ? zd::ll_default(s_) : (k == 1 ? zd::of_default(s_) : zd::ml_default(s_));
         } else if (mode == 1) {
           if (size - p < 1 || b[p] > max_sym) fine = false;
-          else { L->t.fse[k][0] = (uint32_t)b[p]; t_al[k] = 0; t_kind[k] = 1; p += 1; }
+          else {
+            L->t.fse[k][0] = (uint32_t)b[p]; t_al[k] = 0; t_kind[k] = 1;
+            if (ctab) (k == 0 ? ctab[sid].ll : (k == 1 ? ctab[sid].of : ctab[sid].ml))[0] = (uint16_t)(b[p] | (1u << 6));      // one cell: x = 1
+            p += 1;
+          }
         } else if (mode == 2) {
           const int h = zd::fse_read_ncount(b + p, size - p, max_al, max_sym, L->norm[k], &t_nsym[k], &t_al[k]);
           if (h < 0) fine = false; else { t_kind[k] = 2; p += h; }
@@ -195,7 +315,8 @@ __global__ __launch_bounds__(64) void k_zstd_entropy_t(const StreamDesc* __restr
     }
     if (take && gs == ZM_READY && gn > 0 && sub < 3 && (kd == 0 || kd == 2)) {
       zd::Fse ft = {L->t.fse[sub], 0};
-      built = zd::fse_build(ft, L->norm[sub], ns, al, L->next[sub]) ? 1u : 0u;
+      uint16_t* cc = ctab ? (sub == 0 ? ctab[sid].ll : (sub == 1 ? ctab[sid].of : ctab[sid].ml)) : nullptr;
+      built = zd::fse_build(ft, L->norm[sub], ns, al, L->next[sub], cc) ? 1u : 0u;
     }
     if (GLOBAL && BAMD_ZSTD_LDS_FSE && take && gs == ZM_READY && gn > 0 && sub < 3 && kd >= 0 && built) {      // the lane that built a table packs it into LDS (RLE: one cell)
       const int size = 1 << al, o = sub == 0 ? 0 : (sub == 1 ? 512 : 768);                    // LL | OF | ML
@@ -209,6 +330,7 @@ __global__ __launch_bounds__(64) void k_zstd_entropy_t(const StreamDesc* __restr
   // (lane 0 of a group reads below what lanes 1 and 2 packed into LDS above: lock step on the device; on the wavefront emulator the
   //  two cross-lane reads of `built` just above are the rendezvous - lane 0 cannot get past them before lanes 1 and 2 arrive there)
   // ---- lane 0: the FSE sequence stream ----
+  uint32_t pend_off = 0, pend_len = 0, pend_al = 0;
   if (take && sub == 0) {
     if (state == ZM_READY && nseq > 0) {
       bool fine = (built & b1 & b2) != 0u;
@@ -216,93 +338,69 @@ __global__ __launch_bounds__(64) void k_zstd_entropy_t(const StreamDesc* __restr
       zd::SeqTabs tb = {{L->t.fse[0], t_al[0]}, {L->t.fse[1], t_al[1]}, {L->t.fse[2], t_al[2]}, true, true, true};
       zd::SeqState st;
       st.rep[0] = 1u; st.rep[1] = 4u; st.rep[2] = 8u;
-      if (fine) fine = size - p >= 1 && zd::seq_begin(st, tb, b + p, size - p);
-      if (GLOBAL) {
-        // zd::seq_next with the tables in LDS (same order of reads, same checks - zstd_serial.h is the specification and what the
-        // CPU tests pin to the reference); symbol codes above the format's limits cannot occur: a 6-bit symbol of a table whose
-        // description was accepted is at most 35 / 31 / 52 by fse_read_ncount's max_sym.
-        // Everything the loop carries is a plain local: SeqState's repeat offsets are an array indexed by a decoded value, which put
-        // the WHOLE state - bit reader included - on the stack (every field access a scratch load or store, every refill a flat load
-        // with a vmcnt(0) + lgkmcnt(0) behind it: the ISA of round 2's loop).  The bit stream is read through a global pointer, four
-        // bytes per refill, the NEXT refill's word already on its way.
+      bool seq_later = false; uint32_t seq_off = 0, seq_len = 0, seq_al = 0;
+      if (fine) fine = size - p >= 1;
+      if (fine && !(GLOBAL && !BAMD_ZSTD_LDS_FSE && BAMD_ZSTD_SEQ_KERNEL)) fine = zd::seq_begin(st, tb, b + p, size - p);
+      if (GLOBAL && !BAMD_ZSTD_LDS_FSE && BAMD_ZSTD_SEQ_KERNEL) {
+        // the sequence stream is k_zstd_seq's (below: one LANE per frame instead of one lane in four); what it needs travels in the record
+        if (fine) { seq_off = (uint32_t)((b + p) - in); seq_len = (uint32_t)(size - p); seq_al = (uint32_t)t_al[0] | ((uint32_t)t_al[1] << 8) | ((uint32_t)t_al[2] << 16); seq_later = true; }
+      } else if (GLOBAL) {
         const uint16_t* tl = &lfse[BAMD_ZSTD_LDS_FSE ? g : 0][0]; const uint16_t* to = &lfse[BAMD_ZSTD_LDS_FSE ? g : 0][BAMD_ZSTD_LDS_FSE ? 512 : 0]; const uint16_t* tm = &lfse[BAMD_ZSTD_LDS_FSE ? g : 0][BAMD_ZSTD_LDS_FSE ? 768 : 0];
-        const uint32_t* gl = L->t.fse[0]; const uint32_t* go = L->t.fse[1]; const uint32_t* gm = L->t.fse[2];      // (BAMD_ZSTD_LDS_FSE = 0: the tables where round 2 had them)
-        const int al_l = t_al[0], al_o = t_al[1], al_m = t_al[2];
-        const gu8* bp = as_global(st.b.p);
-        int bytepos = st.b.bytepos, nacc = st.b.nacc, off = st.b.off;
-        uint64_t acc = st.b.acc;
-        uint32_t sl = st.sl, so = st.so, sm = st.sm, r0 = 1u, r1 = 4u, r2 = 8u;
-        uint32_t nxt = bytepos >= 4 ? g_ld4(bp + bytepos - 4) : 0u;          // the word the next refill will take
-        auto rd = [&](int nb_) -> uint32_t {                                   // zd::back_read on the locals
-          if (nb_ == 0) return 0u;
-          if (nacc < nb_ && bytepos >= 4) {
-            bytepos -= 4; acc = (acc << 32) | nxt; nacc += 32;
-            if (bytepos >= 4) nxt = g_ld4(bp + bytepos - 4);
-          }
-          while (nacc < nb_ && bytepos > 0) { bytepos--; acc = (acc << 8) | bp[bytepos]; nacc += 8; }
-          if (nacc < nb_) { acc <<= (nb_ - nacc); nacc = nb_; }
-          const uint32_t v = (uint32_t)(acc >> (nacc - nb_)) & (nb_ >= 32 ? 0xffffffffu : ((1u << nb_) - 1u));
-          nacc -= nb_;
-          acc &= (nacc ? ((1ull << nacc) - 1ull) : 0ull);
-          off -= nb_;
-          return v;
-        };
-        for (int i = 0; fine && i < nseq; i++) {
-          uint32_t cl, co, cm;
-          if (BAMD_ZSTD_LDS_FSE) { cl = tl[sl]; co = to[so]; cm = tm[sm]; }
-          else {                                                                // the same compact form out of the 32-bit cells
-            const uint32_t el = gl[sl], eo = go[so], em = gm[sm];
-            cl = (el & 63u) | ((((el >> 16) + (1u << al_l)) >> ((el >> 8) & 0xffu)) << 6);
-            co = (eo & 63u) | ((((eo >> 16) + (1u << al_o)) >> ((eo >> 8) & 0xffu)) << 6);
-            cm = (em & 63u) | ((((em >> 16) + (1u << al_m)) >> ((em >> 8) & 0xffu)) << 6);
-          }
-          const int lc = (int)(cl & 63u), oc = (int)(co & 63u), mc = (int)(cm & 63u);
-          if (oc > 31 || mc > 52 || lc > 35) { fine = false; break; }
-          const uint32_t ov = (1u << oc) + rd(oc);
-          const uint32_t q_ml = zd::ml_base(mc) + rd(zd::ml_bits(mc));
-          const uint32_t q_ll = zd::ll_base(lc) + rd(zd::ll_bits(lc));
-          if (i + 1 != nseq) {
-            const uint32_t xl = cl >> 6, xm = cm >> 6, xo = co >> 6;
-            const int nl = al_l - zd::hb32(xl), nm = al_m - zd::hb32(xm), no = al_o - zd::hb32(xo);
-            sl = ((xl << nl) - (1u << al_l)) + rd(nl);
-            sm = ((xm << nm) - (1u << al_m)) + rd(nm);
-            so = ((xo << no) - (1u << al_o)) + rd(no);
-          }
-          if (off < 0) { fine = false; break; }
-          uint32_t q_off;
-          if (ov > 3) { q_off = ov - 3u; r2 = r1; r1 = r0; r0 = q_off; }
-          else {
-            uint32_t idx = ov - 1u;
-            if (q_ll == 0) idx++;
-            if (idx == 0) q_off = r0;
-            else {
-              q_off = idx == 1u ? r1 : (idx == 2u ? r2 : r0 - 1u);
-              if (q_off == 0) { fine = false; break; }
-              if (idx > 1) r2 = r1;
-              r1 = r0; r0 = q_off;
-            }
-          }
-          sq[i] = zpack(q_ll, q_ml, q_off);
-        }
-        st.b.off = off;
+        if (fine) fine = zseq_run(st, nseq, L->t.fse[0], L->t.fse[1], L->t.fse[2], tl, to, tm, t_al[0], t_al[1], t_al[2], sq);
       } else
       for (int i = 0; fine && i < nseq; i++) {
         zd::Seq q;
         if (!zd::seq_next(st, tb, i + 1 == nseq, q)) { fine = false; break; }
         sq[i] = zpack(q.ll, q.ml, q.off);
       }
-      if (fine && st.b.off != 0) fine = false;                              // the bit stream must be consumed exactly
+      if (fine && !seq_later && st.b.off != 0) fine = false;                 // the bit stream must be consumed exactly
       if (!fine) state = ZM_ERROR;
+      else if (seq_later) { pend_off = seq_off; pend_len = seq_len; pend_al = seq_al; state = ZM_SEQ; }
     }
     ZMeta m;
     m.state = state; m.nseq = (uint32_t)nseq; m.regen = (uint32_t)lh.regen; m.lit_mode = lit_mode; m.lit_src = lit_src;
-    m.pad_[0] = m.pad_[1] = m.pad_[2] = 0;
+    m.pad_[0] = pend_off; m.pad_[1] = pend_len; m.pad_[2] = pend_al;
     meta[sid] = m;
   } else if (sid < nstreams && sub == 0) {
     ZMeta m;
     m.state = ZM_FALLBACK; m.nseq = 0; m.regen = 0; m.lit_mode = 0; m.lit_src = 0; m.pad_[0] = m.pad_[1] = m.pad_[2] = 0;
     meta[sid] = m;
   }
+}
+
+// phase A2 (round 3): the sequence streams, ONE LANE PER FRAME.  Inside k_zstd_entropy the stream of a frame ran on lane 0 of the frame's four
+// lanes (the other three are there for the four Huffman streams): 16 of 64 lanes busy for two thirds of that kernel's time
+// (profiles/r03u_zent_split.txt: 27.3 ms, 9.2 without the sequence loop, 4.2 without the Huffman streams as well).  Here a wave
+// carries 64 frames through the same loop (zseq_run), the tables where phase A built them (global scratch).
+#ifndef BAMD_ZSEQ_FRAMES
+#define BAMD_ZSEQ_FRAMES 64       // frames per wavefront of k_zstd_seq (lanes above that idle: fewer frames per wave = more waves to hide the table reads behind)
+#endif
+constexpr int ZSEQ_FRAMES = BAMD_ZSEQ_FRAMES;
+__global__ __launch_bounds__(64) void k_zstd_seq(const StreamDesc* __restrict__ streams, int nstreams, const ChunkDesc* __restrict__ chunks,
+                                                 const BlockDesc* __restrict__ blocks, ZMeta* __restrict__ meta, ptrdiff_t zseq_delta, ZgLds* __restrict__ gscr,
+                                                 const ZcTab* __restrict__ ctab) {
+  const int sid = (int)blockIdx.x * ZSEQ_FRAMES + (int)(threadIdx.x & 63);
+  if ((int)(threadIdx.x & 63) >= ZSEQ_FRAMES || sid >= nstreams) return;
+  if (meta[sid].state != ZM_SEQ) return;
+  const StreamDesc& sd = streams[sid];
+  const ChunkDesc& c = chunks[sd.chunk];
+  const BlockDesc& bk = blocks[sd.aux];
+  uint8_t* lit = c.stage + (size_t)bk.blk * (size_t)c.blocksize + (size_t)(sid - bk.first_stream) * (size_t)sd.out_size;
+  uint64_t* sq = zseq_ptr(lit, zseq_delta);
+  ZgLds* L = gscr + sid;
+  const int nseq = (int)meta[sid].nseq;
+  const uint32_t al = meta[sid].pad_[2];
+  const int al_l = (int)(al & 0xffu), al_o = (int)((al >> 8) & 0xffu), al_m = (int)((al >> 16) & 0xffu);
+  zd::SeqTabs tb = {{L->t.fse[0], al_l}, {L->t.fse[1], al_o}, {L->t.fse[2], al_m}, true, true, true};
+  zd::SeqState st;
+  st.rep[0] = 1u; st.rep[1] = 4u; st.rep[2] = 8u;
+  bool fine = zd::seq_begin(st, tb, sd.in + meta[sid].pad_[0], (int)meta[sid].pad_[1]);
+  if (fine) {
+    if (ctab) fine = zseq_run<true>(st, nseq, nullptr, nullptr, nullptr, ctab[sid].ll, ctab[sid].of, ctab[sid].ml, al_l, al_o, al_m, sq);
+    else fine = zseq_run(st, nseq, L->t.fse[0], L->t.fse[1], L->t.fse[2], nullptr, nullptr, nullptr, al_l, al_o, al_m, sq);
+  }
+  if (fine && st.b.off != 0) fine = false;                                  // the bit stream must be consumed exactly
+  meta[sid].state = fine ? ZM_READY : ZM_ERROR;
 }
 
 // phase B: one wavefront per frame, persistent + ticket

@@ -84,11 +84,15 @@ inline void build_encode_queues(const std::vector<BlockDesc>& blocks, const std:
 #define BAMD_DEC_LEAD 256
 #endif
 constexpr size_t kDecLead = BAMD_DEC_LEAD;
+// pick = 0: the blocks of k_decode_streams (neither k_decode_blocks' nor the entropy-coded formats'); pick = BLK_ZLIB: the zlib kernel's.
 inline void build_xcd_queues(const std::vector<BlockDesc>& blocks, size_t nstr, const uint32_t* cost, bool cost_valid,
-                             std::vector<int32_t>& out, int nq = 8) {
+                             std::vector<int32_t>& out, int nq = 8, uint32_t pick = 0u) {
   std::vector<int32_t> q[8];
   std::vector<uint32_t> mine[8];
-  for (size_t g = 0; g < blocks.size(); g++) if (blocks[g].nstreams > 0 && !(blocks[g].flags & (BLK_LDS | BLK_Z))) mine[g % (size_t)nq].push_back((uint32_t)g);
+  for (size_t g = 0; g < blocks.size(); g++) {
+    const uint32_t f = (uint32_t)blocks[g].flags;
+    if (blocks[g].nstreams > 0 && (pick ? (f & pick) != 0u : !(f & (BLK_LDS | BLK_Z)))) mine[g % (size_t)nq].push_back((uint32_t)g);
+  }
   std::vector<int> order; int nheavy = 0, lastT = -1;
   auto prep = [&](const BlockDesc& b) {
     if (b.nstreams != lastT) { plane_order(cost, cost_valid && sched_enabled(), b.nstreams, order, &nheavy); lastT = b.nstreams; }

@@ -71,7 +71,9 @@ ZD_FN int fse_nb(uint32_t e) { return (int)((e >> 8) & 0xffu); }
 ZD_FN uint32_t fse_base(uint32_t e) { return e >> 16; }
 
 // norm: normalized counts (-1 = "less than one"); `next` is scratch for 256 uint16
-ZD_FN bool fse_build(Fse& t, const int16_t* norm, int nsym, int al, uint16_t* next) {
+// compact (optional): the same table as 16-bit cells symbol | x << 6, x = the cell's next-state counter (nbBits = al - floor(log2 x),
+// baseline = (x << nbBits) - 2^al): what the one-lane-per-frame sequence kernel reads (k_zstd2.hip: k_zstd_seq)
+ZD_FN bool fse_build(Fse& t, const int16_t* norm, int nsym, int al, uint16_t* next, uint16_t* compact = nullptr) {
   const int size = 1 << al;
   int high = size - 1;
   t.al = al;
@@ -94,6 +96,7 @@ ZD_FN bool fse_build(Fse& t, const int16_t* norm, int nsym, int al, uint16_t* ne
     const uint32_t x = next[s]++;
     const uint32_t nb = (uint32_t)(al - hb32(x));
     t.e[i] = s | (nb << 8) | ((((x << nb) - (uint32_t)size) & 0xffffu) << 16);
+    if (compact) compact[i] = (uint16_t)(s | (x << 6));
   }
   return true;
 }

@@ -61,6 +61,11 @@ for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1]))[:6]: print(f"{sys.ar
 PY
                   rm -rf gpurun_out/${TAG}_pmc_$PMC
                 done | tee gpurun_out/${TAG}_dec_traffic.txt ;;
+    zentsplit)  # where the time of k_zstd_entropy goes: builds with the FSE loop / the Huffman streams / both left out (make -C c-blosc_amd tune NAME=zskipN DEFS=-DBAMD_ZENT_SKIP=N; wrong results on purpose)
+                for lib in c-blosc_amd/libblosc_amd.so gpurun_tune_z*.so; do
+                  [ -f $lib ] && { echo -n "$lib "; NOCHECK=1 CODEC=zstd CLEVEL=3 BLOSC_AMD_LIB=$PWD/$lib timeout 150 python scripts/dec_sweep.py 2>&1 | tail -1; }
+                done | tee gpurun_out/${TAG}_zent_split.txt ;;
+    threads)    timeout 600 python -m pytest tests/test_gpu_threads.py -m gpu -x -q --no-header -p no:cacheprovider 2>&1 | tee gpurun_out/${TAG}_pytest_threads.log | tail -5 ;;
     zstdtests)  timeout 900 python -m pytest tests/test_gpu_zstd.py tests/test_gpu_zstd_tables.py tests/test_gpu_zlib.py -m gpu -x -q --no-header -p no:cacheprovider 2>&1 | tee gpurun_out/${TAG}_pytest_zstd.log | tail -5 ;;
     dectests)   timeout 900 python -m pytest tests/test_gpu_decompress.py tests/test_gpu_spans.py tests/test_gpu_baseline_geometry.py tests/test_gpu_getitem_batch.py -m gpu -x -q --no-header -p no:cacheprovider 2>&1 | tee gpurun_out/${TAG}_pytest_dec.log | tail -8 ;;
     enc)        for d in ${DATA:-bench19 linspace randwalk}; do for lib in c-blosc_amd/libblosc_amd.so gpurun_tune_*.so; do

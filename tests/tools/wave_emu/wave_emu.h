@@ -143,6 +143,7 @@ inline uint32_t dpp(uint32_t old, uint32_t src, int ctrl, bool bound_ctrl, const
     if (l >= 1) return (uint32_t)fetch(k, l - 1, where);
     return bound_ctrl ? 0u : old;
   }
+  if (ctrl >= 0 && ctrl <= 0xff) return (uint32_t)fetch(k, (l & ~3) + ((ctrl >> (2 * (l & 3))) & 3), where);      // quad_perm:[a,b,c,d]
   fail("DPP control not modelled", where);
 }
 // explicit lock-step point for code that communicates through memory between cross-lane instructions
