@@ -787,7 +787,11 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
       }
       if (zstd2 == 2 && L.d_zgscr && BAMD_ZSTD_SEQ_KERNEL && !BAMD_ZSTD_LDS_FSE) {
         ProfScope ps(st, stream, "k_zstd_seq");      // the sequence streams of the frames phase A took, one lane per frame
-        hipLaunchKernelGGL(k_zstd_seq, grid1(L.nstr, ZSEQ_FRAMES), dim3(64), 0, stream, L.d_streams, (int)L.nstr, L.d_chunks, L.d_blocks, L.d_zmeta, L.zseq_delta, L.d_zgscr, L.d_zctab);
+        // BLOSC_AMD_ZSEQ_LDS=1: the wave's tables in LDS (k_zstd_seq_lds) - measured slower on the benchmark batch (16.2 against 11.7 ms:
+        // 30 frames per wave and two waves per CU put 65 536 frames through in rounds, k_zstd2.hip); without the 16-bit records there is only the global form
+        static const bool zseq_lds = getenv("BLOSC_AMD_ZSEQ_LDS") && atoi(getenv("BLOSC_AMD_ZSEQ_LDS")) != 0;
+        if (zseq_lds && L.d_zctab) hipLaunchKernelGGL(k_zstd_seq_lds, grid1(L.nstr, ZSEQ_LDS_FRAMES), dim3(64), 0, stream, L.d_streams, (int)L.nstr, L.d_chunks, L.d_blocks, L.d_zmeta, L.zseq_delta, L.d_zctab);
+        else hipLaunchKernelGGL(k_zstd_seq, grid1(L.nstr, ZSEQ_FRAMES), dim3(64), 0, stream, L.d_streams, (int)L.nstr, L.d_chunks, L.d_blocks, L.d_zmeta, L.zseq_delta, L.d_zgscr, L.d_zctab);
       }
       {
         ProfScope ps(st, stream, "k_zstd_exec");

@@ -62,9 +62,90 @@ __device__ __forceinline__ void wave_fill(gu8* dst, uint32_t v, uint32_t n, int 
 #ifndef BAMD_ZSTD_EXEC16
 #define BAMD_ZSTD_EXEC16 1
 #endif
+// ---------------------------------------------------------------------------------------------
+// Groups with several DEPENDENT matches, assembled in LDS (round 3; the Zstd twin of lz4_step_lds in k_decode.hip).  A frame the
+// reference writes for a shuffled 128 KiB block is ~4000 sequences with matches of a few dozen bytes whose sources lie in the
+// output of the sequences just before them: zstd_exec16 below ran those one after the other, each waiting for its own load to come
+// back from L2 before it could store (k_zstd_exec: 16 ms per 8 GiB of reference-written bench19 frames against 6.3 ms for frames
+// written here, whose matches are long).  Here the last ZXB_HIST bytes of output come in with ONE load, literals and independent
+// matches go to memory AND to the buffer, and the dependent matches become LDS copies in stream order (a match whose distance
+// is shorter than its length is the periodic extension of the bytes before it: every lane reads only bytes that are final)
+// whose values the lanes also store to memory.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t ZXB_HIST = 1024u, ZXB_STEP = 2048u, ZXB_MAXM = 512u, ZXB_WORDS = (ZXB_HIST + ZXB_STEP + 64u) / 4u;
+#ifndef BAMD_ZXB_MIN_REST
+#define BAMD_ZXB_MIN_REST 2      // dependent matches a group needs before the LDS form is used (0: never)
+#endif
+typedef volatile __attribute__((address_space(3))) uint8_t zlds_u8;
+__device__ __forceinline__ void zlds_st16(zlds_u8* l, const uint4& v) { v4u32 t = {v.x, v.y, v.z, v.w}; *(volatile __attribute__((address_space(3))) v4u32_una*)l = t; }
+// lane_copy_disjoint (wave_prims.h) with a second destination in LDS
+__device__ __forceinline__ void lane_copy_dual(gu8* d, zlds_u8* l, const gu8* s, uint32_t n) {
+  if (n >= 16u) {
+    uint32_t k = 0;
+    for (; k + 64u <= n; k += 64u) {
+      const uint4 a = ld16u(s + k), b = ld16u(s + k + 16), c = ld16u(s + k + 32), e = ld16u(s + k + 48);
+      st16u(d + k, a); st16u(d + k + 16, b); st16u(d + k + 32, c); st16u(d + k + 48, e);
+      zlds_st16(l + k, a); zlds_st16(l + k + 16, b); zlds_st16(l + k + 32, c); zlds_st16(l + k + 48, e);
+    }
+    const uint32_t r = n - k;
+    uint4 a = make_uint4(0, 0, 0, 0), b = a, c = a;
+    if (r >= 16u) a = ld16u(s + k);
+    if (r >= 32u) b = ld16u(s + k + 16);
+    if (r >= 48u) c = ld16u(s + k + 32);
+    const uint4 z = ld16u(s + n - 16u);
+    if (r >= 16u) { st16u(d + k, a); zlds_st16(l + k, a); }
+    if (r >= 32u) { st16u(d + k + 16, b); zlds_st16(l + k + 16, b); }
+    if (r >= 48u) { st16u(d + k + 32, c); zlds_st16(l + k + 32, c); }
+    st16u(d + n - 16u, z); zlds_st16(l + n - 16u, z);
+  } else if (n >= 8u) {
+    const uint64_t a = g_ld8(s), b = g_ld8(s + n - 8u);
+    *(BAMD_GAS u64una*)d = a; *(BAMD_GAS u64una*)(d + n - 8u) = b;
+    *(volatile __attribute__((address_space(3))) u64una*)l = a; *(volatile __attribute__((address_space(3))) u64una*)(l + n - 8u) = b;
+  } else if (n >= 4u) {
+    const uint32_t a = g_ld4(s), b = g_ld4(s + n - 4u);
+    g_st4(d, a); g_st4(d + n - 4u, b);
+    *(volatile __attribute__((address_space(3))) u32una*)l = a; *(volatile __attribute__((address_space(3))) u32una*)(l + n - 4u) = b;
+  } else if (n) {
+    const uint8_t a = s[0], b = s[n >> 1], c = s[n - 1u];
+    d[0] = a; d[n >> 1] = b; d[n - 1u] = c;
+    l[0] = a; l[n >> 1] = b; l[n - 1u] = c;
+  }
+}
+// (a real call: the common group must not pay for its registers).  indep / dep: this lane's match is copied at once / in stream order.
+__device__ __attribute__((noinline)) void zstd_exec16_lds(gu8* out_, const gu8* lit_, volatile uint32_t* xbuf_generic, uint32_t ll, uint32_t ml, uint32_t off,
+                                                          uint32_t excl, uint32_t lexcl, bool indep, bool dep, uint32_t op_, uint32_t lp_, int lane) {
+  gu8* out = uni_ptr(out_); const gu8* lit = uni_ptr(lit_);
+  const uint32_t op = uni(op_), lp = uni(lp_);
+  zlds_u8* lb = (zlds_u8*)(volatile __attribute__((address_space(3))) uint32_t*)xbuf_generic;
+  constexpr uint32_t H = ZXB_HIST;
+  const uint4 hv = g_ld16(out + op - H + 16u * (uint32_t)lane);                       // the history: one load, in flight with the copies below
+  if (ll) lane_copy_dual(out + op + excl, lb + H + excl, lit + lp + lexcl, ll);        // literals (ll <= 256 here)
+  if (indep) { gu8* d = out + op + excl + ll; lane_copy_dual(d, lb + H + excl + ll, d - off, ml); }
+  zlds_st16(lb + 16u * (uint32_t)lane, hv);
+  BAMD_LDS_SYNC();
+  uint32_t rest = (uint32_t)__ballot(dep) & 0xffffu;
+  while (rest) {
+    const int sl = __builtin_ctz(rest);
+    rest &= rest - 1u;
+    const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)ml, sl), o = (uint32_t)__builtin_amdgcn_readlane((int)off, sl);
+    const uint32_t mr = (uint32_t)__builtin_amdgcn_readlane((int)excl, sl) + (uint32_t)__builtin_amdgcn_readlane((int)ll, sl);
+    // periodic extension of the o bytes before the match (o >= m: a plain copy); floor(k / o) by multiplication: exact for k < 512
+    // (m <= ZXB_MAXM; the quotient is only needed when o < m)
+    const uint32_t M = o < m ? (1u << 20) / o + 1u : 0u;
+    for (uint32_t k = (uint32_t)lane; k < m; k += 64u) {
+      const uint32_t kk = o < m ? k - ((k * M) >> 20) * o : k;
+      const uint8_t v = lb[H + mr - o + kk];
+      lb[H + mr + k] = v;
+      out[op + mr + k] = v;
+    }
+    BAMD_LDS_SYNC();
+  }
+}
+
 // (ll_b, ml_b, off_b: lane i of the batch holds sequence i; this group is sequences base .. base + m)
+// xbuf: ZXB_WORDS words of LDS of this wave for the LDS-assembled form above, or nullptr
 __device__ __forceinline__ bool zstd_exec16(uint32_t ll_b, uint32_t ml_b, uint32_t off_b, int base, int m, uint8_t* out_, uint32_t cap, uint32_t& op,
-                                            const uint8_t* lit_, uint32_t& lp, uint32_t regen, int lane) {
+                                            const uint8_t* lit_, uint32_t& lp, uint32_t regen, int lane, volatile uint32_t* xbuf = nullptr) {
   gu8* out = as_global(out_); const gu8* lit = as_global(lit_);
   const bool mine = lane < m;
   const uint32_t sel = (uint32_t)(base + lane) & 63u;
@@ -81,6 +162,18 @@ __device__ __forceinline__ bool zstd_exec16(uint32_t ll_b, uint32_t ml_b, uint32
   if ((uint64_t)lp + total_lit > (uint64_t)regen || (uint64_t)op + total_out > (uint64_t)cap) return false;
   if (__ballot(mine && (off == 0u || off > op + excl + ll))) return false;     // a source before the start of the output
   uint32_t biglit = (uint32_t)__ballot(mine && ll > 256u) & 0xffffu;      // long runs: the whole wave copies them
+  if (BAMD_ZXB_MIN_REST && xbuf && !biglit && op >= ZXB_HIST && total_out <= ZXB_STEP) {
+    // several matches that read this group's own output (or the bytes just before it): assemble the group in LDS
+    const bool indep0 = mine && ml <= 128u && off >= excl + tot;
+    const bool dep0 = mine && ml && !indep0;
+    const uint32_t ndep = (uint32_t)__builtin_popcountll(__ballot(dep0));
+    const bool fits = __ballot(dep0 && (ml > ZXB_MAXM || off > excl + ll + ZXB_HIST)) == 0ull;      // short, and the source inside the buffer
+    if (ndep >= (uint32_t)BAMD_ZXB_MIN_REST && fits) {
+      zstd_exec16_lds(out, lit, xbuf, ll, ml, off, excl, lexcl, indep0, dep0, op, lp, lane);
+      op += total_out; lp += total_lit;
+      return true;
+    }
+  }
   while (biglit) {
     const int sl = __builtin_ctz(biglit);
     biglit &= biglit - 1u;

@@ -27,6 +27,12 @@
 #ifndef BAMD_ZSTD_SEQ_KERNEL
 #define BAMD_ZSTD_SEQ_KERNEL 1    // the FSE sequence streams of the global two-phase path in a kernel of their own, one lane per frame (k_zstd_seq); 0: inside k_zstd_entropy, on one lane in four
 #endif
+#ifndef BAMD_ZHUF_FAST
+#define BAMD_ZHUF_FAST 1          // k_zstd_entropy: the Huffman literal streams through zhuf_run (0: zd::huf_decode_stream as it stands in zstd_serial.h)
+#endif
+#ifndef BAMD_ZSEQ_RUNBUF
+#define BAMD_ZSEQ_RUNBUF 1        // k_zstd_seq / k_zstd_seq_lds: the triples leave through an LDS run buffer, eight at a time (0: one store per sequence)
+#endif
 #ifndef BAMD_ZSEQ_FAST
 #define BAMD_ZSEQ_FAST 1          // zseq_run: three refill points per sequence while >= 12 stream bytes are left (0: the general bit reader for every field)
 #endif
@@ -75,9 +81,15 @@ __device__ __forceinline__ uint64_t* zseq_ptr(const uint8_t* lit, ptrdiff_t zseq
 // vmcnt(0) + lgkmcnt(0) behind it: the ISA of round 2's loop).  The bit stream is read through a global pointer, four bytes per
 // refill, the NEXT refill's word already on its way.  gl / go / gm: the frame's three tables (32-bit cells, global scratch) or,
 // with BAMD_ZSTD_LDS_FSE, tl / to / tm: their compact LDS copies.
-template <bool GC = false>       // GC: tl / to / tm are 16-bit cells in GLOBAL memory (ZcTab)
+template <int GC = 0>            // GC 1: tl / to / tm are 16-bit cells in GLOBAL memory (ZcTab); GC 2: the same in LDS (k_zstd_seq_lds)
 __device__ __forceinline__ bool zseq_run(zd::SeqState& st, int nseq, const uint32_t* gl_, const uint32_t* go_, const uint32_t* gm_,
-                                         const uint16_t* tl, const uint16_t* to, const uint16_t* tm, int al_l, int al_o, int al_m, uint64_t* sq_) {
+                                         const uint16_t* tl, const uint16_t* to, const uint16_t* tm, int al_l, int al_o, int al_m, uint64_t* sq_,
+                                         volatile uint64_t* sqbuf_ = nullptr, int lane = 0) {
+  // sqbuf (LDS, 8 x 64 words, entry k of lane l at [k * 64 + l]): the triples leave in runs of eight.  gfx950 counts loads and stores
+  // with ONE in-order counter: a store per sequence meant that every wait for a loaded value - the next stream word, a table cell -
+  // was also a wait for the previous sequence's store to be acknowledged by L2 (~0.9 us per sequence even with the tables in LDS,
+  // profiles/r03x_zent_split.txt); with the run buffer that wait comes once per eight sequences, and a lane writes 64 contiguous bytes.
+  volatile __attribute__((address_space(3))) uint64_t* sqbuf = (volatile __attribute__((address_space(3))) uint64_t*)sqbuf_;
   bool fine = true;
   const BAMD_GAS uint32_t* gl = (const BAMD_GAS uint32_t*)gl_; const BAMD_GAS uint32_t* go = (const BAMD_GAS uint32_t*)go_;      // (global_load, not flat_load)
   const BAMD_GAS uint32_t* gm = (const BAMD_GAS uint32_t*)gm_; BAMD_GAS uint64_t* sq = (BAMD_GAS uint64_t*)sq_;
@@ -115,7 +127,10 @@ __device__ __forceinline__ bool zseq_run(zd::SeqState& st, int nseq, const uint3
   };
   for (int i = 0; fine && i < ((BAMD_ZENT_SKIP & 1) ? 0 : nseq); i++) {
     uint32_t cl, co, cm;
-    if (GC) { cl = ((const BAMD_GAS uint16_t*)tl)[sl]; co = ((const BAMD_GAS uint16_t*)to)[so]; cm = ((const BAMD_GAS uint16_t*)tm)[sm]; }
+    if (GC == 2) {
+      typedef const volatile __attribute__((address_space(3))) uint16_t* lp16;
+      cl = ((lp16)tl)[sl]; co = ((lp16)to)[so]; cm = ((lp16)tm)[sm];
+    } else if (GC == 1) { cl = ((const BAMD_GAS uint16_t*)tl)[sl]; co = ((const BAMD_GAS uint16_t*)to)[so]; cm = ((const BAMD_GAS uint16_t*)tm)[sm]; }
     else if (BAMD_ZSTD_LDS_FSE) { cl = tl[sl]; co = to[so]; cm = tm[sm]; }
     else {                                                                // the same compact form out of the 32-bit cells
       const uint32_t el = gl[sl], eo = go[so], em = gm[sm];
@@ -161,10 +176,75 @@ __device__ __forceinline__ bool zseq_run(zd::SeqState& st, int nseq, const uint3
         r1 = r0; r0 = q_off;
       }
     }
-    sq[i] = zpack(q_ll, q_ml, q_off);
+    if (!sqbuf_) sq[i] = zpack(q_ll, q_ml, q_off);
+    else {
+      sqbuf[(uint32_t)(i & 7) * 64u + (uint32_t)lane] = zpack(q_ll, q_ml, q_off);
+      if ((i & 7) == 7) {
+        uint64_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = sqbuf[(uint32_t)k * 64u + (uint32_t)lane];
+        BAMD_GAS uint8_t* o = (BAMD_GAS uint8_t*)(sq + (i - 7));
+#pragma unroll
+        for (int k = 0; k < 4; k++) g_st16(o + 16 * k, make_uint4((uint32_t)v[2 * k], (uint32_t)(v[2 * k] >> 32), (uint32_t)v[2 * k + 1], (uint32_t)(v[2 * k + 1] >> 32)));
+      }
+    }
+  }
+  if (sqbuf_ && fine) {                                    // the last, incomplete run
+    const int done = (BAMD_ZENT_SKIP & 1) ? 0 : nseq;
+    for (int i = done & ~7; i < done; i++) sq[i] = sqbuf[(uint32_t)(i & 7) * 64u + (uint32_t)lane];
   }
   st.b.off = off;
   return fine;
+}
+
+// One Huffman literal stream on one lane: zd::huf_decode_stream (zstd_serial.h, the CPU-checked statement of the rules: exactly n
+// symbols, the stream consumed exactly) in the form the device needs - the bit reader of zseq_run above (one refill test per
+// symbol while four stream bytes are left, the general reader for the last ones), the table (GLOBAL = true: 4 KiB of global
+// scratch per frame) read through a global pointer, and the output leaving EIGHT bytes at a time: one byte store per symbol put
+// L2's acknowledgement of the previous store in front of every table read (the one in-order counter again; 7 us per symbol,
+// profiles/r03u_zent_split.txt: 4.5 of the kernel's 27 ms for 2 400 literals per frame).
+template <bool GLOBAL>
+__device__ __forceinline__ bool zhuf_run(const uint16_t* te_, int mb, const uint8_t* src, int len, uint8_t* out_, int n) {
+  zd::Back b0;
+  if (!zd::back_init(b0, src, len)) return false;
+  const gu8* bp = as_global(src); gu8* out = as_global(out_);
+  const BAMD_GAS uint16_t* tg = (const BAMD_GAS uint16_t*)te_;
+  int bytepos = b0.bytepos, nacc = b0.nacc, off = b0.off;
+  uint64_t acc = b0.acc;
+  uint32_t nxt = bytepos >= 4 ? g_ld4(bp + bytepos - 4) : 0u;
+  auto rd = [&](int nb_) -> uint32_t {                                   // zd::back_read on the locals (see zseq_run)
+    if (nb_ == 0) return 0u;
+    if (nacc < nb_ && bytepos >= 4) {
+      bytepos -= 4; acc = (acc << 32) | nxt; nacc += 32;
+      if (bytepos >= 4) nxt = g_ld4(bp + bytepos - 4);
+    }
+    while (nacc < nb_ && bytepos > 0) { bytepos--; acc = (acc << 8) | bp[bytepos]; nacc += 8; }
+    if (nacc < nb_) { acc <<= (nb_ - nacc); nacc = nb_; }
+    const uint32_t v = (uint32_t)(acc >> (nacc - nb_)) & (nb_ >= 32 ? 0xffffffffu : ((1u << nb_) - 1u));
+    nacc -= nb_;
+    acc &= (nacc ? ((1ull << nacc) - 1ull) : 0ull);
+    off -= nb_;
+    return v;
+  };
+  const uint32_t mask = (1u << mb) - 1u;
+  uint32_t state = rd(mb);
+  uint64_t pend = 0;
+  int i = 0;
+  for (; i < n && off > -mb; i++) {
+    const uint32_t e = GLOBAL ? (uint32_t)tg[state] : (uint32_t)te_[state];
+    pend |= (uint64_t)(e & 0xffu) << (8 * (i & 7));
+    if ((i & 7) == 7) { g_st8(out + (i - 7), pend); pend = 0; }
+    const int nb = (int)(e >> 8);
+    uint32_t v;
+    if (bytepos >= 4) {                                                  // nb <= 11 <= the 32 bits a refill leaves
+      if (nacc <= 32) { bytepos -= 4; acc = (acc << 32) | nxt; nacc += 32; if (bytepos >= 4) nxt = g_ld4(bp + bytepos - 4); }
+      v = (uint32_t)(acc >> ((nacc - nb) & 63)) & ((1u << nb) - 1u);
+      nacc -= nb; off -= nb;
+    } else v = rd(nb);
+    state = ((state << nb) & mask) | v;
+  }
+  for (int k = i & ~7; k < i; k++) out[k] = (uint8_t)(pend >> (8 * (k & 7)));      // the last, incomplete run
+  return i == n && off == -mb;
 }
 
 // GLOBAL = false: the tables of the 16 frames in LDS (128 KiB: ONE wave per CU).  GLOBAL = true: the same structure per frame
@@ -249,7 +329,7 @@ __global__ __launch_bounds__(64) void k_zstd_entropy_t(const StreamDesc* __restr
     const uint8_t* hs = in + g_boff + g_hs;
     zd::Huf h2 = {L->t.huf, g_mb};
     if (g_nstreams == 1) {
-      if (sub == 0) lit_ok = zd::huf_decode_stream(h2, hs, g_hlen, lit, g_regen) ? 1u : 0u;
+      if (sub == 0) lit_ok = (BAMD_ZHUF_FAST ? zhuf_run<GLOBAL>(h2.e, h2.maxbits, hs, g_hlen, lit, g_regen) : zd::huf_decode_stream(h2, hs, g_hlen, lit, g_regen)) ? 1u : 0u;
     } else if (g_hlen < 6) lit_ok = 0;
     else {
       const int s1 = hs[0] | (hs[1] << 8), s2 = hs[2] | (hs[3] << 8), s3 = hs[4] | (hs[5] << 8), s4 = g_hlen - 6 - s1 - s2 - s3;
@@ -259,7 +339,7 @@ __global__ __launch_bounds__(64) void k_zstd_entropy_t(const StreamDesc* __restr
         const int so = sub == 0 ? 0 : (sub == 1 ? s1 : (sub == 2 ? s1 + s2 : s1 + s2 + s3));
         const int sl = sub == 0 ? s1 : (sub == 1 ? s2 : (sub == 2 ? s3 : s4));
         const int cnt = sub < 3 ? q : g_regen - 3 * q;
-        lit_ok = zd::huf_decode_stream(h2, hs + 6 + so, sl, lit + sub * q, cnt) ? 1u : 0u;
+        lit_ok = (BAMD_ZHUF_FAST ? zhuf_run<GLOBAL>(h2.e, h2.maxbits, hs + 6 + so, sl, lit + sub * q, cnt) : zd::huf_decode_stream(h2, hs + 6 + so, sl, lit + sub * q, cnt)) ? 1u : 0u;
       }
     }
   }
@@ -379,6 +459,7 @@ constexpr int ZSEQ_FRAMES = BAMD_ZSEQ_FRAMES;
 __global__ __launch_bounds__(64) void k_zstd_seq(const StreamDesc* __restrict__ streams, int nstreams, const ChunkDesc* __restrict__ chunks,
                                                  const BlockDesc* __restrict__ blocks, ZMeta* __restrict__ meta, ptrdiff_t zseq_delta, ZgLds* __restrict__ gscr,
                                                  const ZcTab* __restrict__ ctab) {
+  __shared__ uint64_t sqb[8 * 64];           // the triples' run buffer (zseq_run)
   const int sid = (int)blockIdx.x * ZSEQ_FRAMES + (int)(threadIdx.x & 63);
   if ((int)(threadIdx.x & 63) >= ZSEQ_FRAMES || sid >= nstreams) return;
   if (meta[sid].state != ZM_SEQ) return;
@@ -396,9 +477,60 @@ __global__ __launch_bounds__(64) void k_zstd_seq(const StreamDesc* __restrict__ 
   st.rep[0] = 1u; st.rep[1] = 4u; st.rep[2] = 8u;
   bool fine = zd::seq_begin(st, tb, sd.in + meta[sid].pad_[0], (int)meta[sid].pad_[1]);
   if (fine) {
-    if (ctab) fine = zseq_run<true>(st, nseq, nullptr, nullptr, nullptr, ctab[sid].ll, ctab[sid].of, ctab[sid].ml, al_l, al_o, al_m, sq);
-    else fine = zseq_run(st, nseq, L->t.fse[0], L->t.fse[1], L->t.fse[2], nullptr, nullptr, nullptr, al_l, al_o, al_m, sq);
+    volatile uint64_t* rb = BAMD_ZSEQ_RUNBUF ? sqb : nullptr;
+    if (ctab) fine = zseq_run<1>(st, nseq, nullptr, nullptr, nullptr, ctab[sid].ll, ctab[sid].of, ctab[sid].ml, al_l, al_o, al_m, sq, rb, (int)(threadIdx.x & 63));
+    else fine = zseq_run(st, nseq, L->t.fse[0], L->t.fse[1], L->t.fse[2], nullptr, nullptr, nullptr, al_l, al_o, al_m, sq, rb, (int)(threadIdx.x & 63));
   }
+  if (fine && st.b.off != 0) fine = false;                                  // the bit stream must be consumed exactly
+  meta[sid].state = fine ? ZM_READY : ZM_ERROR;
+}
+
+// The same with the frames' tables in LDS (round 3).  k_zstd_seq is bound by its table reads: 3 random 2-byte reads per sequence out
+// of 160 MiB of live tables is 0.8 G sector fetches per launch - 14.8 ms, whether 16, 32 or 64 frames share a wave and whether the
+// loop is 800 or 200 instructions long (profiles/r03v_zent_split.txt, r03w_zent_split.txt).  With the wave's tables in LDS a step
+// costs its instructions and one LDS latency.  The price is parallelism: 2.5 KiB per frame (the format's largest tables, which is
+// what the reference writes for a 4 000-sequence block) = ZSEQ_LDS_FRAMES frames per wave and two waves per CU, so the frames of a
+// large batch go through in rounds (the same idea inside k_zstd_entropy, BAMD_ZSTD_LDS_FSE, bought 6 % while the loop was 800
+// instructions long).  MEASURED (profiles/r03y_zent_split.txt, 8 GiB of reference-written bench19 frames): 16.2 - 16.8 ms against 11.7 ms
+// for k_zstd_seq with the run buffer - with one wave per SIMD the dependent-issue latency of the loop's ~200 instructions is ~0.9 us per
+// sequence by itself, times 4.3 rounds.  Behind BLOSC_AMD_ZSEQ_LDS=1; the default is the global form.
+#ifndef BAMD_ZSEQ_LDS_FRAMES
+#define BAMD_ZSEQ_LDS_FRAMES 30
+#endif
+constexpr int ZSEQ_LDS_FRAMES = BAMD_ZSEQ_LDS_FRAMES;      // x 2560 bytes = 75 KiB: two workgroups per CU
+__global__ __launch_bounds__(64) void k_zstd_seq_lds(const StreamDesc* __restrict__ streams, int nstreams, const ChunkDesc* __restrict__ chunks,
+                                                     const BlockDesc* __restrict__ blocks, ZMeta* __restrict__ meta, ptrdiff_t zseq_delta,
+                                                     const ZcTab* __restrict__ ctab) {
+  __shared__ uint32_t tabs[ZSEQ_LDS_FRAMES][sizeof(ZcTab) / 4];
+  __shared__ uint64_t sqb[8 * 64];           // the triples' run buffer (zseq_run)
+  const int lane = (int)(threadIdx.x & 63);
+  const int sid0 = (int)blockIdx.x * ZSEQ_LDS_FRAMES;
+  // the whole wave copies the records of its frames, 256 bytes per instruction (frames that are not phase A's are copied too: simpler than
+  // asking, and their bytes are never looked at)
+  for (int f = 0; f < ZSEQ_LDS_FRAMES && sid0 + f < nstreams; f++) {
+    const BAMD_GAS uint32_t* src = (const BAMD_GAS uint32_t*)(ctab + sid0 + f);
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(ZcTab) / 4) / 64; k++) ((volatile __attribute__((address_space(3))) uint32_t*)tabs[f])[lane + 64 * k] = src[lane + 64 * k];
+  }
+  BAMD_LDS_SYNC();
+  const int sid = sid0 + lane;
+  if (lane >= ZSEQ_LDS_FRAMES || sid >= nstreams) return;
+  if (meta[sid].state != ZM_SEQ) return;
+  const StreamDesc& sd = streams[sid];
+  const ChunkDesc& c = chunks[sd.chunk];
+  const BlockDesc& bk = blocks[sd.aux];
+  uint8_t* lit = c.stage + (size_t)bk.blk * (size_t)c.blocksize + (size_t)(sid - bk.first_stream) * (size_t)sd.out_size;
+  uint64_t* sq = zseq_ptr(lit, zseq_delta);
+  const int nseq = (int)meta[sid].nseq;
+  const uint32_t al = meta[sid].pad_[2];
+  const int al_l = (int)(al & 0xffu), al_o = (int)((al >> 8) & 0xffu), al_m = (int)((al >> 16) & 0xffu);
+  const uint16_t* t16 = (const uint16_t*)tabs[lane];
+  // seq_begin only reads the accuracy logs of the tables
+  zd::SeqTabs tb = {{nullptr, al_l}, {nullptr, al_o}, {nullptr, al_m}, true, true, true};
+  zd::SeqState st;
+  st.rep[0] = 1u; st.rep[1] = 4u; st.rep[2] = 8u;
+  bool fine = zd::seq_begin(st, tb, sd.in + meta[sid].pad_[0], (int)meta[sid].pad_[1]);
+  if (fine) fine = zseq_run<2>(st, nseq, nullptr, nullptr, nullptr, t16, t16 + 512, t16 + 768, al_l, al_o, al_m, sq, BAMD_ZSEQ_RUNBUF ? sqb : nullptr, lane);
   if (fine && st.b.off != 0) fine = false;                                  // the bit stream must be consumed exactly
   meta[sid].state = fine ? ZM_READY : ZM_ERROR;
 }
@@ -408,6 +540,7 @@ constexpr int ZEXEC_WAVES_PER_CU = 32;
 __global__ __launch_bounds__(64, 8) void k_zstd_exec(StreamDesc* __restrict__ streams, int nstreams, int32_t* __restrict__ status, uint32_t* __restrict__ ticket,
                                                      const ChunkDesc* __restrict__ chunks, const BlockDesc* __restrict__ blocks,
                                                      const ZMeta* __restrict__ meta, ptrdiff_t zseq_delta) {
+  __shared__ uint32_t xbuf[ZXB_WORDS];      // the LDS-assembled groups of zstd_exec16 (k_zstd.hip): 3 KiB per wave, 32 waves per CU
   const int lane = threadIdx.x & 63;
   uint32_t sid = take_ticket(ticket, lane);
   while (sid < (uint32_t)nstreams) {
@@ -433,7 +566,7 @@ __global__ __launch_bounds__(64, 8) void k_zstd_exec(StreamDesc* __restrict__ st
         const uint64_t q = (uint32_t)lane < m ? sq[done + (uint32_t)lane] : 0ull;
         const uint32_t ll_b = (uint32_t)q & 0x3ffffu, ml_b = (uint32_t)(q >> 18) & 0x3ffffu, off_b = (uint32_t)(q >> 36);
         for (uint32_t g = 0; ok && g < m; g += 16u)
-          ok = zstd_exec16(ll_b, ml_b, off_b, (int)g, (int)(m - g < 16u ? m - g : 16u), sd->out, want, op, lit, lp, regen, lane);
+          ok = zstd_exec16(ll_b, ml_b, off_b, (int)g, (int)(m - g < 16u ? m - g : 16u), sd->out, want, op, lit, lp, regen, lane, xbuf);
       }
       if (ok) {
         const uint32_t rest = regen - lp;
