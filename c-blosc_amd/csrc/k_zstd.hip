@@ -73,6 +73,9 @@ __device__ __forceinline__ void wave_fill(gu8* dst, uint32_t v, uint32_t n, int 
 // whose values the lanes also store to memory.
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t ZXB_HIST = 1024u, ZXB_STEP = 2048u, ZXB_MAXM = 512u, ZXB_WORDS = (ZXB_HIST + ZXB_STEP + 64u) / 4u;
+#ifndef BAMD_ZXB_SLIDE
+#define BAMD_ZXB_SLIDE 1         // consecutive LDS-assembled groups keep their history in the buffer (0: every group loads it)
+#endif
 #ifndef BAMD_ZXB_MIN_REST
 #define BAMD_ZXB_MIN_REST 2      // dependent matches a group needs before the LDS form is used (0: never)
 #endif
@@ -113,15 +116,18 @@ __device__ __forceinline__ void lane_copy_dual(gu8* d, zlds_u8* l, const gu8* s,
 }
 // (a real call: the common group must not pay for its registers).  indep / dep: this lane's match is copied at once / in stream order.
 __device__ __attribute__((noinline)) void zstd_exec16_lds(gu8* out_, const gu8* lit_, volatile uint32_t* xbuf_generic, uint32_t ll, uint32_t ml, uint32_t off,
-                                                          uint32_t excl, uint32_t lexcl, bool indep, bool dep, uint32_t op_, uint32_t lp_, int lane) {
+                                                          uint32_t excl, uint32_t lexcl, bool indep, bool dep, uint32_t op_, uint32_t lp_, int lane,
+                                                          uint32_t hist_valid_, uint32_t total_out_) {
   gu8* out = uni_ptr(out_); const gu8* lit = uni_ptr(lit_);
-  const uint32_t op = uni(op_), lp = uni(lp_);
+  const uint32_t op = uni(op_), lp = uni(lp_), total_out = uni(total_out_);
+  const bool hist_valid = uni(hist_valid_) != 0u;           // the buffer's first ZXB_HIST bytes already are out[op - H, op): the group before left them there
   zlds_u8* lb = (zlds_u8*)(volatile __attribute__((address_space(3))) uint32_t*)xbuf_generic;
   constexpr uint32_t H = ZXB_HIST;
-  const uint4 hv = g_ld16(out + op - H + 16u * (uint32_t)lane);                       // the history: one load, in flight with the copies below
+  uint4 hv = make_uint4(0, 0, 0, 0);
+  if (!hist_valid) hv = g_ld16(out + op - H + 16u * (uint32_t)lane);                   // the history: one load, in flight with the copies below
   if (ll) lane_copy_dual(out + op + excl, lb + H + excl, lit + lp + lexcl, ll);        // literals (ll <= 256 here)
   if (indep) { gu8* d = out + op + excl + ll; lane_copy_dual(d, lb + H + excl + ll, d - off, ml); }
-  zlds_st16(lb + 16u * (uint32_t)lane, hv);
+  if (!hist_valid) zlds_st16(lb + 16u * (uint32_t)lane, hv);
   BAMD_LDS_SYNC();
   uint32_t rest = (uint32_t)__ballot(dep) & 0xffffu;
   while (rest) {
@@ -140,12 +146,20 @@ __device__ __attribute__((noinline)) void zstd_exec16_lds(gu8* out_, const gu8* 
     }
     BAMD_LDS_SYNC();
   }
+  // slide: the last H bytes of history + group become the next group's history, so that a run of such groups loads its history once
+  // (every group's load of the bytes the group before had just stored was a trip to L2 that the group's first LDS copy waited for)
+  {
+    const v4u32 t = *(volatile __attribute__((address_space(3))) v4u32_una*)(lb + total_out + 16u * (uint32_t)lane);
+    BAMD_LDS_SYNC();
+    *(volatile __attribute__((address_space(3))) v4u32_una*)(lb + 16u * (uint32_t)lane) = t;
+    BAMD_LDS_SYNC();
+  }
 }
 
 // (ll_b, ml_b, off_b: lane i of the batch holds sequence i; this group is sequences base .. base + m)
 // xbuf: ZXB_WORDS words of LDS of this wave for the LDS-assembled form above, or nullptr
 __device__ __forceinline__ bool zstd_exec16(uint32_t ll_b, uint32_t ml_b, uint32_t off_b, int base, int m, uint8_t* out_, uint32_t cap, uint32_t& op,
-                                            const uint8_t* lit_, uint32_t& lp, uint32_t regen, int lane, volatile uint32_t* xbuf = nullptr) {
+                                            const uint8_t* lit_, uint32_t& lp, uint32_t regen, int lane, volatile uint32_t* xbuf = nullptr, uint32_t* hist_valid = nullptr) {
   gu8* out = as_global(out_); const gu8* lit = as_global(lit_);
   const bool mine = lane < m;
   const uint32_t sel = (uint32_t)(base + lane) & 63u;
@@ -169,11 +183,13 @@ __device__ __forceinline__ bool zstd_exec16(uint32_t ll_b, uint32_t ml_b, uint32
     const uint32_t ndep = (uint32_t)__builtin_popcountll(__ballot(dep0));
     const bool fits = __ballot(dep0 && (ml > ZXB_MAXM || off > excl + ll + ZXB_HIST)) == 0ull;      // short, and the source inside the buffer
     if (ndep >= (uint32_t)BAMD_ZXB_MIN_REST && fits) {
-      zstd_exec16_lds(out, lit, xbuf, ll, ml, off, excl, lexcl, indep0, dep0, op, lp, lane);
+      zstd_exec16_lds(out, lit, xbuf, ll, ml, off, excl, lexcl, indep0, dep0, op, lp, lane, (BAMD_ZXB_SLIDE && hist_valid) ? *hist_valid : 0u, total_out);
+      if (hist_valid) *hist_valid = 1u;
       op += total_out; lp += total_lit;
       return true;
     }
   }
+  if (hist_valid) *hist_valid = 0u;          // this group goes to memory only
   while (biglit) {
     const int sl = __builtin_ctz(biglit);
     biglit &= biglit - 1u;

@@ -559,14 +559,14 @@ __global__ __launch_bounds__(64, 8) void k_zstd_exec(StreamDesc* __restrict__ st
       const uint8_t* lit = litbuf;
       if (lmode == 1u) lit = sd->in + lsrc;
       else if (lmode == 2u) wave_fill(as_global(litbuf), lsrc, regen, lane);
-      uint32_t op = 0, lp = 0;
+      uint32_t op = 0, lp = 0, hist_valid = 0;
       bool ok = true;
       for (uint32_t done = 0; ok && done < nseq; done += 64u) {
         const uint32_t m = nseq - done < 64u ? nseq - done : 64u;
         const uint64_t q = (uint32_t)lane < m ? sq[done + (uint32_t)lane] : 0ull;
         const uint32_t ll_b = (uint32_t)q & 0x3ffffu, ml_b = (uint32_t)(q >> 18) & 0x3ffffu, off_b = (uint32_t)(q >> 36);
         for (uint32_t g = 0; ok && g < m; g += 16u)
-          ok = zstd_exec16(ll_b, ml_b, off_b, (int)g, (int)(m - g < 16u ? m - g : 16u), sd->out, want, op, lit, lp, regen, lane, xbuf);
+          ok = zstd_exec16(ll_b, ml_b, off_b, (int)g, (int)(m - g < 16u ? m - g : 16u), sd->out, want, op, lit, lp, regen, lane, xbuf, &hist_valid);
       }
       if (ok) {
         const uint32_t rest = regen - lp;

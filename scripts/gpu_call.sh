@@ -65,6 +65,7 @@ PY
                 for lib in c-blosc_amd/libblosc_amd.so gpurun_tune_z*.so; do
                   [ -f $lib ] && { echo -n "$lib "; NOCHECK=1 CODEC=zstd CLEVEL=3 BLOSC_AMD_LIB=$PWD/$lib timeout 150 python scripts/dec_sweep.py 2>&1 | tail -1; }
                 done | tee gpurun_out/${TAG}_zent_split.txt ;;
+    hostthreads) for c in 1 4; do BLOSC_AMD_CONTEXTS=$c timeout 200 python scripts/host_abi_threads.py 2>&1 | grep -v amdgpu.ids; done | tee gpurun_out/${TAG}_host_abi_threads.txt ;;
     threads)    timeout 600 python -m pytest tests/test_gpu_threads.py -m gpu -x -q --no-header -p no:cacheprovider 2>&1 | tee gpurun_out/${TAG}_pytest_threads.log | tail -5 ;;
     zstdtests)  timeout 900 python -m pytest tests/test_gpu_zstd.py tests/test_gpu_zstd_tables.py tests/test_gpu_zlib.py -m gpu -x -q --no-header -p no:cacheprovider 2>&1 | tee gpurun_out/${TAG}_pytest_zstd.log | tail -5 ;;
     dectests)   timeout 900 python -m pytest tests/test_gpu_decompress.py tests/test_gpu_spans.py tests/test_gpu_baseline_geometry.py tests/test_gpu_getitem_batch.py -m gpu -x -q --no-header -p no:cacheprovider 2>&1 | tee gpurun_out/${TAG}_pytest_dec.log | tail -8 ;;

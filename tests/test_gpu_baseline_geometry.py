@@ -23,6 +23,13 @@ CASES = [  # name, codec, shuffle, typesize, clevel, dataset, GPU encodes it
     ("lz4-shuffle-T8-randwalk", "lz4", 1, 8, 5, "randwalk", True),
     ("zstd-shuffle-T8", "zstd", 1, 8, 3, "bench19", True),
     ("zlib-shuffle-T8", "zlib", 1, 8, 5, "bench19", True),
+    # typesize 2 and 16: their byte (un)shuffle runs inside the codec kernels since round 3 (lane-table spans, quad transposes: DESIGN.md 3.2),
+    # for the entropy-coded formats by the decoding wave (Zstd: unsplit blocks) or through the zlib kernel's per-XCD hand-off
+    ("lz4-shuffle-T2", "lz4", 1, 2, 5, "bench19", True),
+    ("lz4-shuffle-T16", "lz4", 1, 16, 5, "bench19", True),
+    ("blosclz-shuffle-T16-linspace", "blosclz", 1, 16, 5, "linspace", True),
+    ("zstd-shuffle-T16", "zstd", 1, 16, 3, "bench19", True),
+    ("zlib-shuffle-T2", "zlib", 1, 2, 5, "linspace", True),
     # the encoder options that are not the default at these settings: the LZ4HC-grade search in front of the Zstd
     # writer (the default from clevel 6 on), Huffman-coded literals, and the round-2 forms of both writers
     ("zstd-cl7-search", "zstd", 1, 8, 7, "bench19", True),
