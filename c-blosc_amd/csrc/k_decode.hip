@@ -819,6 +819,9 @@ __device__ __forceinline__ void st16_dst(gu8* p, uint4 v) { if (BAMD_DST_STREAM 
 #define BAMD_UNSH_LD_NT 1     // the fused unshuffle reads the planes (scratch / raw splits: read once) with non-temporal loads: -2 % (same-session A/B)
 #endif
 __device__ __forceinline__ uint32_t ld4_plane(const gu8* p) { return BAMD_UNSH_LD_NT ? g_ld4_nt(p) : g_ld4(p); }
+#ifndef BAMD_UNSH_QUAD8
+#define BAMD_UNSH_QUAD8 0      // typesize 8: the two 16-byte stores of a step re-dealt inside the quad (64 contiguous bytes per quad and instruction).  MEASURED: 5-6 % SLOWER on bench19 (4.76 -> 5.00, 4.34 -> 4.61 ms; two copies of each build taking turns, profiles/r03zb_ab_quad_dealt_typesize8_rejected.txt) - what paid for typesize 16 (16-byte pieces 64 bytes apart) does not for pieces 32 bytes apart
+#endif
 template <int T>
 __device__ __forceinline__ void unshuffle_store(gu8* dst, uint32_t e, int lane, const Rows<T>& x) {
   gu8* o = dst + (size_t)(e + 4u * (uint32_t)lane) * T;
@@ -832,8 +835,26 @@ __device__ __forceinline__ void unshuffle_store(gu8* dst, uint32_t e, int lane, 
   if (T == 8) {
     uint32_t u0, u1, u2, u3;
     transpose4x4(x.r[4], x.r[5], x.r[6], x.r[7], u0, u1, u2, u3);
+    if (BAMD_UNSH_QUAD8) {
+      // a lane's two 16-byte pieces lie 32 bytes apart from its neighbour's: every store instruction half-fills 32 sectors.  Re-dealt
+      // inside the quad (the quad's 128 bytes are pieces 0..7, lane i holds 2i and 2i + 1; store k writes piece 4k + i from lane (4k + i) >> 1),
+      // a quad writes 64 contiguous bytes per instruction - the typesize-16 lesson of quad_byte_transpose
+      const uint32_t p0[4] = {t0, u0, t1, u1}, p1[4] = {t2, u2, t3, u3};
+      uint32_t a[4], b[4];
+      const bool odd = (lane & 1) != 0;
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        const uint32_t a0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p0[d], 0x50, 0xf, 0xf, true), a1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p1[d], 0x50, 0xf, 0xf, true);
+        const uint32_t b0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p0[d], 0xFA, 0xf, 0xf, true), b1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p1[d], 0xFA, 0xf, 0xf, true);
+        a[d] = odd ? a1 : a0; b[d] = odd ? b1 : b0;
+      }
+      gu8* oq = dst + (size_t)(e + 16u * ((uint32_t)lane >> 2)) * 8u + 16u * ((uint32_t)lane & 3u);
+      st16_dst(oq, make_uint4(a[0], a[1], a[2], a[3]));
+      st16_dst(oq + 64, make_uint4(b[0], b[1], b[2], b[3]));
+    } else {
     st16_dst(o, make_uint4(t0, u0, t1, u1));         // elements 0, 1 (8 bytes each)
     st16_dst(o + 16, make_uint4(t2, u2, t3, u3));    // elements 2, 3
+    }
   } else {
     st16_dst(o, make_uint4(t0, t1, t2, t3));         // elements 0..3 (4 bytes each)
   }
