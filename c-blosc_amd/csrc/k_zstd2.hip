@@ -84,7 +84,10 @@ __device__ __forceinline__ uint64_t* zseq_ptr(const uint8_t* lit, ptrdiff_t zseq
 template <int GC = 0>            // GC 1: tl / to / tm are 16-bit cells in GLOBAL memory (ZcTab); GC 2: the same in LDS (k_zstd_seq_lds)
 __device__ __forceinline__ bool zseq_run(zd::SeqState& st, int nseq, const uint32_t* gl_, const uint32_t* go_, const uint32_t* gm_,
                                          const uint16_t* tl, const uint16_t* to, const uint16_t* tm, int al_l, int al_o, int al_m, uint64_t* sq_,
-                                         volatile uint64_t* sqbuf_ = nullptr, int lane = 0) {
+                                         volatile uint64_t* sqbuf_ = nullptr, int lane = 0, const volatile uint32_t* codes_ = nullptr) {
+  // codes (LDS, 36 + 53 words: base | extra bits << 24 of the literal-length and match-length codes, zseq_fill_codes): one read instead of
+  // the comparison chains of zd::ll_base / ll_bits / ml_base / ml_bits - the loop is a chain of dependent instructions, every one counts
+  const volatile __attribute__((address_space(3))) uint32_t* codes = (const volatile __attribute__((address_space(3))) uint32_t*)codes_;
   // sqbuf (LDS, 8 x 64 words, entry k of lane l at [k * 64 + l]): the triples leave in runs of eight.  gfx950 counts loads and stores
   // with ONE in-order counter: a store per sequence meant that every wait for a loaded value - the next stream word, a table cell -
   // was also a wait for the previous sequence's store to be acknowledged by L2 (~0.9 us per sequence even with the tables in LDS,
@@ -145,7 +148,11 @@ __device__ __forceinline__ bool zseq_run(zd::SeqState& st, int nseq, const uint3
     uint32_t ov, q_ml, q_ll;
     if (BAMD_ZSEQ_FAST && bytepos >= 12) {
       refill(); ov = (1u << oc) + take(oc);
-      refill(); q_ml = zd::ml_base(mc) + take(zd::ml_bits(mc)); q_ll = zd::ll_base(lc) + take(zd::ll_bits(lc));
+      refill();
+      if (codes_) {
+        const uint32_t pm = codes[36 + mc], pl = codes[lc];
+        q_ml = (pm & 0xffffffu) + take((int)(pm >> 24)); q_ll = (pl & 0xffffffu) + take((int)(pl >> 24));
+      } else { q_ml = zd::ml_base(mc) + take(zd::ml_bits(mc)); q_ll = zd::ll_base(lc) + take(zd::ll_bits(lc)); }
       if (i + 1 != nseq) {
         refill();
         sl = ((xl << nl) - (1u << al_l)) + take(nl);
@@ -452,6 +459,14 @@ __global__ __launch_bounds__(64) void k_zstd_entropy_t(const StreamDesc* __restr
 // lanes (the other three are there for the four Huffman streams): 16 of 64 lanes busy for two thirds of that kernel's time
 // (profiles/r03u_zent_split.txt: 27.3 ms, 9.2 without the sequence loop, 4.2 without the Huffman streams as well).  Here a wave
 // carries 64 frames through the same loop (zseq_run), the tables where phase A built them (global scratch).
+__device__ __forceinline__ void zseq_fill_codes(volatile uint32_t* codes, int lane) {      // before any lane leaves: the whole wave fills, then a rendezvous
+  if (lane < 36) codes[lane] = zd::ll_base(lane) | ((uint32_t)zd::ll_bits(lane) << 24);
+  if (lane < 53) codes[36 + lane] = zd::ml_base(lane) | ((uint32_t)zd::ml_bits(lane) << 24);
+  BAMD_LDS_SYNC();
+}
+#ifndef BAMD_ZSEQ_CODES
+#define BAMD_ZSEQ_CODES 1         // k_zstd_seq: length-code bases and extra-bit counts from an LDS table
+#endif
 #ifndef BAMD_ZSEQ_FRAMES
 #define BAMD_ZSEQ_FRAMES 64       // frames per wavefront of k_zstd_seq (lanes above that idle: fewer frames per wave = more waves to hide the table reads behind)
 #endif
@@ -460,6 +475,8 @@ __global__ __launch_bounds__(64) void k_zstd_seq(const StreamDesc* __restrict__ 
                                                  const BlockDesc* __restrict__ blocks, ZMeta* __restrict__ meta, ptrdiff_t zseq_delta, ZgLds* __restrict__ gscr,
                                                  const ZcTab* __restrict__ ctab) {
   __shared__ uint64_t sqb[8 * 64];           // the triples' run buffer (zseq_run)
+  __shared__ uint32_t codes[36 + 53];
+  if (BAMD_ZSEQ_CODES) zseq_fill_codes(codes, (int)(threadIdx.x & 63));
   const int sid = (int)blockIdx.x * ZSEQ_FRAMES + (int)(threadIdx.x & 63);
   if ((int)(threadIdx.x & 63) >= ZSEQ_FRAMES || sid >= nstreams) return;
   if (meta[sid].state != ZM_SEQ) return;
@@ -478,7 +495,7 @@ __global__ __launch_bounds__(64) void k_zstd_seq(const StreamDesc* __restrict__ 
   bool fine = zd::seq_begin(st, tb, sd.in + meta[sid].pad_[0], (int)meta[sid].pad_[1]);
   if (fine) {
     volatile uint64_t* rb = BAMD_ZSEQ_RUNBUF ? sqb : nullptr;
-    if (ctab) fine = zseq_run<1>(st, nseq, nullptr, nullptr, nullptr, ctab[sid].ll, ctab[sid].of, ctab[sid].ml, al_l, al_o, al_m, sq, rb, (int)(threadIdx.x & 63));
+    if (ctab) fine = zseq_run<1>(st, nseq, nullptr, nullptr, nullptr, ctab[sid].ll, ctab[sid].of, ctab[sid].ml, al_l, al_o, al_m, sq, rb, (int)(threadIdx.x & 63), BAMD_ZSEQ_CODES ? codes : nullptr);
     else fine = zseq_run(st, nseq, L->t.fse[0], L->t.fse[1], L->t.fse[2], nullptr, nullptr, nullptr, al_l, al_o, al_m, sq, rb, (int)(threadIdx.x & 63));
   }
   if (fine && st.b.off != 0) fine = false;                                  // the bit stream must be consumed exactly

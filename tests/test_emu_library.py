@@ -215,6 +215,40 @@ def test_reference_written_zstd_chunks_through_the_two_phase_path(emulib, oracle
     assert rejected >= 5
 
 
+def test_reference_written_zlib_chunks_through_the_queued_kernel(emulib, oracle):
+    """The committed chunks written by the real reference with zlib (tests/golden/ref_zlib_chunks.npz) through k_zlib_streams as the engine
+    launches it since round 3 - per-XCD queues, the block unshuffled by the wave that completes its last stream - intact, and damaged
+    with the oracle's verdict and bytes."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "ref_zlib_chunks.npz"))
+    rng = np.random.default_rng(34)
+    items = []
+    for k, m in enumerate(z["meta"]):
+        dname, n, T, clevel, shuffle, bs = m.split(",")
+        if FULL or k in (0, 5, 10, 20, 3, 13, 21, 15):
+            items.append((z[f"c{k}"], dname, int(n)))
+    assert len(items) >= 8
+    rejected = 0
+    for chunk, dname, n in items:
+        data = DATASETS[dname](n)
+        r, out = _decompress(emulib, chunk, n)
+        assert r == n and np.array_equal(out, data), (dname, n)
+        for trial in range(12 if FULL else 4):
+            c = chunk.copy()
+            pos = int(rng.integers(16, c.size))
+            if trial % 4 == 3: c[pos] = int(rng.integers(0, 256))
+            else: c[pos] ^= 1 << int(rng.integers(0, 8))
+            if int(c[12:16].view("<i4")[0]) > c.size:
+                continue
+            ro, oo = orc_decompress(oracle, c, n)
+            rg, og = _decompress(emulib, c, n)
+            if ro == n:
+                assert rg == n and np.array_equal(og, oo), (dname, n, trial, pos)
+            else:
+                assert rg < 0, (dname, n, trial, pos, ro, rg)
+                rejected += 1
+    assert rejected >= 5
+
+
 @pytest.mark.parametrize("cname", ["lz4", "blosclz"])
 def test_damaged_chunks_get_the_references_verdict(emulib, oracle, cname):
     """Headers, block offsets, split sizes and stream bytes of reference-written chunks flipped, cut and overwritten: the return code class
