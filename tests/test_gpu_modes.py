@@ -50,3 +50,24 @@ def test_zstd_decoder_modes(mode):
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_zstd.py"), "-m", "gpu", "-q", "-x", "--no-header",
                         "-p", "no:cacheprovider"], env=env, timeout=900, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert p.returncode == 0 and " passed" in p.stdout and "failed" not in p.stdout, (p.stdout[-3000:], p.stderr[-2000:])
+
+
+ROUND3 = [{"BLOSC_AMD_FUSE_T": "0"}, {"BLOSC_AMD_FUSE_Z": "0"}, {"BLOSC_AMD_CONTEXTS": "1"}, {"BLOSC_AMD_ZSTD_CTAB": "0"}, {"BLOSC_AMD_ZSEQ_LDS": "1"},
+          {"BLOSC_AMD_FUSE_T": "0", "BLOSC_AMD_FUSE_Z": "0", "BLOSC_AMD_SINGLE_QUEUE": "1"}]
+
+
+@pytest.mark.parametrize("env_extra", ROUND3, ids=["+".join(k[10:] + "=" + v for k, v in e.items()) for e in ROUND3])
+def test_round3_switches(env_extra):
+    """The A/B switches round 3 added: typesize 2 / 16 back on the stand-alone filter kernels, Zstd / zlib chunks unshuffled
+    by k_unshuffle, one context, the sequence kernel on the 32-bit tables or with its tables in LDS - round trips of every codec
+    (tests/tools/mode_check.py with the entropy-coded formats switched in) and, for the Zstd switches, the Zstd decode suite."""
+    env = dict(os.environ)
+    env.update(env_extra)
+    env["BLOSC_MODE_CHECK_Z"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "mode_check.py")], env=env, timeout=600,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 0 and "modes ok" in p.stdout, (env_extra, p.stdout[-2000:], p.stderr[-3000:])
+    if any("ZSTD" in k or "ZSEQ" in k or "FUSE_Z" in k for k in env_extra):
+        p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_zstd.py"), "-m", "gpu", "-q", "-x", "--no-header",
+                            "-p", "no:cacheprovider"], env=env, timeout=900, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert p.returncode == 0 and " passed" in p.stdout and "failed" not in p.stdout, (env_extra, p.stdout[-3000:], p.stderr[-2000:])

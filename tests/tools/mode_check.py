@@ -27,7 +27,7 @@ n_ok = 0
 for codec in ("lz4", "blosclz"):
     for dname, T, shuffle, n in [("bench19", 8, 1, (8 << 20) + 40), ("bench19", 4, 1, 3 << 20), ("linspace", 8, 1, 4 << 20),
                                  ("randwalk", 8, 1, 2 << 20), ("bench19", 4, 2, 2 << 20), ("zeros", 8, 1, 4 << 20),
-                                 ("bench19", 2, 1, 1 << 20), ("smallints", 4, 0, 1 << 20)]:
+                                 ("bench19", 2, 1, 1 << 20), ("bench19", 16, 1, 2 << 20), ("smallints", 4, 0, 1 << 20)]:
         n = max(n // SHRINK, 8192) + (n % 64)
         data = DATASETS[dname](n)
         ro, och = orc_compress(O, data, T, 5, shuffle, codec)
@@ -38,6 +38,20 @@ for codec in ("lz4", "blosclz"):
         rr, o2 = orc_decompress(O, ch, n)
         assert rr == n and np.array_equal(o2, data), ("oracle reads GPU chunk", codec, dname, T, shuffle, rr)
         n_ok += 1
+# BLOSC_MODE_CHECK_Z=1 (the round-3 switches of tests/test_gpu_modes.py): the entropy-coded formats as well - chunks written here are read by
+# the oracle and by our own decoder (fused or stand-alone unshuffle, k_zstd_seq with either table form, zlib's queues)
+if os.environ.get("BLOSC_MODE_CHECK_Z") == "1":
+    for codec in ("zstd", "zlib"):
+        for dname, T, shuffle, n in [("bench19", 8, 1, (4 << 20) + 24), ("linspace", 16, 1, 2 << 20), ("smallints", 2, 1, 1 << 20), ("randwalk", 8, 0, 1 << 20)]:
+            n = max(n // SHRINK, 8192) + (n % 64)
+            data = DATASETS[dname](n)
+            rc, ch = pkg.compress(data, T, 5 if codec == "zlib" else 3, shuffle, codec.encode())
+            assert rc > 0, ("encode", codec, dname, T, shuffle, rc)
+            rr, o2 = orc_decompress(O, ch, n)
+            assert rr == n and np.array_equal(o2, data), ("oracle reads GPU chunk", codec, dname, T, shuffle, rr)
+            r, out = pkg.decompress(ch, n)
+            assert r == n and np.array_equal(out, data), ("decode", codec, dname, T, shuffle, r)
+            n_ok += 1
 # a periodic plane followed by a match reaching back into it (the "materialise" path of the spans)
 neb = 64 << 10
 planes = []
