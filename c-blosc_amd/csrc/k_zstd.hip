@@ -72,7 +72,14 @@ __device__ __forceinline__ void wave_fill(gu8* dst, uint32_t v, uint32_t n, int 
 // is shorter than its length is the periodic extension of the bytes before it: every lane reads only bytes that are final)
 // whose values the lanes also store to memory.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t ZXB_HIST = 1024u, ZXB_STEP = 2048u, ZXB_MAXM = 512u, ZXB_WORDS = (ZXB_HIST + ZXB_STEP + 64u) / 4u;
+constexpr uint32_t ZXB_HIST = 1024u, ZXB_STEP = 2048u, ZXB_MAXM = 512u;
+constexpr uint32_t ZXB_LW = 1024u, ZXB_LW_OFF = ZXB_HIST + ZXB_STEP + 128u;      // the literal window: ZXB_LW bytes of the frame's literal buffer, behind the group buffer
+constexpr uint32_t ZXB_WORDS = (ZXB_LW_OFF + ZXB_LW + 16u) / 4u;
+// what a run of LDS-assembled groups keeps in the buffer: the history (the last ZXB_HIST bytes of output) and a window of the literals
+struct ZxState { uint32_t hist_valid, lw_valid, lw_base; };
+#ifndef BAMD_ZXB_LITWIN
+#define BAMD_ZXB_LITWIN 1        // literals and near independent matches of an LDS-assembled group come out of LDS (0: loaded from memory per group)
+#endif
 #ifndef BAMD_ZXB_SLIDE
 #define BAMD_ZXB_SLIDE 1         // consecutive LDS-assembled groups keep their history in the buffer (0: every group loads it)
 #endif
@@ -114,20 +121,66 @@ __device__ __forceinline__ void lane_copy_dual(gu8* d, zlds_u8* l, const gu8* s,
     l[0] = a; l[n >> 1] = b; l[n - 1u] = c;
   }
 }
+// the same with the source in LDS (the literal window, the history): no memory load at all
+__device__ __forceinline__ uint4 zlds_ld16(const zlds_u8* l) { const v4u32 t = *(const volatile __attribute__((address_space(3))) v4u32_una*)l; return make_uint4(t.x, t.y, t.z, t.w); }
+__device__ __forceinline__ void lane_copy_dual_lds(gu8* d, zlds_u8* l, const zlds_u8* s, uint32_t n) {
+  if (n >= 16u) {
+    uint32_t k = 0;
+    for (; k + 32u <= n; k += 32u) {
+      const uint4 a = zlds_ld16(s + k), b = zlds_ld16(s + k + 16);
+      st16u(d + k, a); st16u(d + k + 16, b);
+      zlds_st16(l + k, a); zlds_st16(l + k + 16, b);
+    }
+    const uint32_t r = n - k;                     // 0..31 bytes left: one whole piece and one that ends exactly at n
+    uint4 a = make_uint4(0, 0, 0, 0);
+    if (r >= 16u) a = zlds_ld16(s + k);
+    const uint4 z = zlds_ld16(s + n - 16u);
+    if (r >= 16u) { st16u(d + k, a); zlds_st16(l + k, a); }
+    st16u(d + n - 16u, z); zlds_st16(l + n - 16u, z);
+  } else if (n >= 8u) {
+    const uint64_t a = *(const volatile __attribute__((address_space(3))) u64una*)s, b = *(const volatile __attribute__((address_space(3))) u64una*)(s + n - 8u);
+    *(BAMD_GAS u64una*)d = a; *(BAMD_GAS u64una*)(d + n - 8u) = b;
+    *(volatile __attribute__((address_space(3))) u64una*)l = a; *(volatile __attribute__((address_space(3))) u64una*)(l + n - 8u) = b;
+  } else if (n >= 4u) {
+    const uint32_t a = *(const volatile __attribute__((address_space(3))) u32una*)s, b = *(const volatile __attribute__((address_space(3))) u32una*)(s + n - 4u);
+    g_st4(d, a); g_st4(d + n - 4u, b);
+    *(volatile __attribute__((address_space(3))) u32una*)l = a; *(volatile __attribute__((address_space(3))) u32una*)(l + n - 4u) = b;
+  } else if (n) {
+    const uint8_t a = s[0], b = s[n >> 1], c = s[n - 1u];
+    d[0] = a; d[n >> 1] = b; d[n - 1u] = c;
+    l[0] = a; l[n >> 1] = b; l[n - 1u] = c;
+  }
+}
 // (a real call: the common group must not pay for its registers).  indep / dep: this lane's match is copied at once / in stream order.
 __device__ __attribute__((noinline)) void zstd_exec16_lds(gu8* out_, const gu8* lit_, volatile uint32_t* xbuf_generic, uint32_t ll, uint32_t ml, uint32_t off,
                                                           uint32_t excl, uint32_t lexcl, bool indep, bool dep, uint32_t op_, uint32_t lp_, int lane,
-                                                          uint32_t hist_valid_, uint32_t total_out_) {
+                                                          uint32_t hist_valid_, uint32_t total_out_, uint32_t lw_, uint32_t regen_) {
+  // lw_: 0 = literals from memory; else bit 0 set and (lw_ >> 1) = the window's base when it already covers this group's literals,
+  // 0xffffffff = use the window but (re)load it from lp first
   gu8* out = uni_ptr(out_); const gu8* lit = uni_ptr(lit_);
-  const uint32_t op = uni(op_), lp = uni(lp_), total_out = uni(total_out_);
+  const uint32_t op = uni(op_), lp = uni(lp_), total_out = uni(total_out_), lw = uni(lw_), regen = uni(regen_);
   const bool hist_valid = uni(hist_valid_) != 0u;           // the buffer's first ZXB_HIST bytes already are out[op - H, op): the group before left them there
   zlds_u8* lb = (zlds_u8*)(volatile __attribute__((address_space(3))) uint32_t*)xbuf_generic;
+  zlds_u8* lwin = lb + ZXB_LW_OFF;
   constexpr uint32_t H = ZXB_HIST;
-  uint4 hv = make_uint4(0, 0, 0, 0);
-  if (!hist_valid) hv = g_ld16(out + op - H + 16u * (uint32_t)lane);                   // the history: one load, in flight with the copies below
-  if (ll) lane_copy_dual(out + op + excl, lb + H + excl, lit + lp + lexcl, ll);        // literals (ll <= 256 here)
-  if (indep) { gu8* d = out + op + excl + ll; lane_copy_dual(d, lb + H + excl + ll, d - off, ml); }
-  if (!hist_valid) zlds_st16(lb + 16u * (uint32_t)lane, hv);
+  uint32_t lbase = lw >> 1;
+  if (lw == 0xffffffffu) {                                   // the literal window from lp on (never a byte behind the literal buffer)
+    lbase = lp;
+    const uint32_t q = lp + 16u * (uint32_t)lane;
+    if (q + 16u <= regen) zlds_st16(lwin + 16u * (uint32_t)lane, g_ld16(lit + q));
+    else for (uint32_t t = q; t < regen && t < q + 16u; t++) lwin[t - lp] = lit[t];
+  }
+  if (!hist_valid) zlds_st16(lb + 16u * (uint32_t)lane, g_ld16(out + op - H + 16u * (uint32_t)lane));      // the history: one load
+  BAMD_LDS_SYNC();
+  if (ll) {                                                  // literals (ll <= 256 here)
+    if (lw) lane_copy_dual_lds(out + op + excl, lb + H + excl, lwin + (lp + lexcl - lbase), ll);
+    else lane_copy_dual(out + op + excl, lb + H + excl, lit + lp + lexcl, ll);
+  }
+  if (indep) {
+    gu8* d = out + op + excl + ll;
+    if (lw && off <= excl + ll + H) lane_copy_dual_lds(d, lb + H + excl + ll, lb + H + excl + ll - off, ml);      // the source lies in the buffer's history
+    else lane_copy_dual(d, lb + H + excl + ll, d - off, ml);
+  }
   BAMD_LDS_SYNC();
   uint32_t rest = (uint32_t)__ballot(dep) & 0xffffu;
   while (rest) {
@@ -159,7 +212,7 @@ __device__ __attribute__((noinline)) void zstd_exec16_lds(gu8* out_, const gu8* 
 // (ll_b, ml_b, off_b: lane i of the batch holds sequence i; this group is sequences base .. base + m)
 // xbuf: ZXB_WORDS words of LDS of this wave for the LDS-assembled form above, or nullptr
 __device__ __forceinline__ bool zstd_exec16(uint32_t ll_b, uint32_t ml_b, uint32_t off_b, int base, int m, uint8_t* out_, uint32_t cap, uint32_t& op,
-                                            const uint8_t* lit_, uint32_t& lp, uint32_t regen, int lane, volatile uint32_t* xbuf = nullptr, uint32_t* hist_valid = nullptr) {
+                                            const uint8_t* lit_, uint32_t& lp, uint32_t regen, int lane, volatile uint32_t* xbuf = nullptr, ZxState* zx = nullptr) {
   gu8* out = as_global(out_); const gu8* lit = as_global(lit_);
   const bool mine = lane < m;
   const uint32_t sel = (uint32_t)(base + lane) & 63u;
@@ -183,13 +236,19 @@ __device__ __forceinline__ bool zstd_exec16(uint32_t ll_b, uint32_t ml_b, uint32
     const uint32_t ndep = (uint32_t)__builtin_popcountll(__ballot(dep0));
     const bool fits = __ballot(dep0 && (ml > ZXB_MAXM || off > excl + ll + ZXB_HIST)) == 0ull;      // short, and the source inside the buffer
     if (ndep >= (uint32_t)BAMD_ZXB_MIN_REST && fits) {
-      zstd_exec16_lds(out, lit, xbuf, ll, ml, off, excl, lexcl, indep0, dep0, op, lp, lane, (BAMD_ZXB_SLIDE && hist_valid) ? *hist_valid : 0u, total_out);
-      if (hist_valid) *hist_valid = 1u;
+      uint32_t lw = 0u;                        // literals out of the window?  (see zstd_exec16_lds)
+      if (BAMD_ZXB_LITWIN && zx && total_lit <= ZXB_LW) {
+        const bool covered = zx->lw_valid && lp >= zx->lw_base && lp + total_lit <= zx->lw_base + ZXB_LW;
+        lw = covered ? ((zx->lw_base << 1) | 1u) : 0xffffffffu;
+        if (!covered) { zx->lw_valid = 1u; zx->lw_base = lp; }
+      }
+      zstd_exec16_lds(out, lit, xbuf, ll, ml, off, excl, lexcl, indep0, dep0, op, lp, lane, (BAMD_ZXB_SLIDE && zx) ? zx->hist_valid : 0u, total_out, lw, regen);
+      if (zx) zx->hist_valid = 1u;
       op += total_out; lp += total_lit;
       return true;
     }
   }
-  if (hist_valid) *hist_valid = 0u;          // this group goes to memory only
+  if (zx) zx->hist_valid = 0u;               // this group goes to memory only
   while (biglit) {
     const int sl = __builtin_ctz(biglit);
     biglit &= biglit - 1u;

@@ -553,8 +553,11 @@ __global__ __launch_bounds__(64) void k_zstd_seq_lds(const StreamDesc* __restric
 }
 
 // phase B: one wavefront per frame, persistent + ticket
-constexpr int ZEXEC_WAVES_PER_CU = 32;
-__global__ __launch_bounds__(64, 8) void k_zstd_exec(StreamDesc* __restrict__ streams, int nstreams, int32_t* __restrict__ status, uint32_t* __restrict__ ticket,
+#ifndef BAMD_ZEXEC_MINWAVES
+#define BAMD_ZEXEC_MINWAVES 8     // waves per SIMD the register allocator plans for (64 VGPRs at 8)
+#endif
+constexpr int ZEXEC_WAVES_PER_CU = 4 * BAMD_ZEXEC_MINWAVES;
+__global__ __launch_bounds__(64, BAMD_ZEXEC_MINWAVES) void k_zstd_exec(StreamDesc* __restrict__ streams, int nstreams, int32_t* __restrict__ status, uint32_t* __restrict__ ticket,
                                                      const ChunkDesc* __restrict__ chunks, const BlockDesc* __restrict__ blocks,
                                                      const ZMeta* __restrict__ meta, ptrdiff_t zseq_delta) {
   __shared__ uint32_t xbuf[ZXB_WORDS];      // the LDS-assembled groups of zstd_exec16 (k_zstd.hip): 3 KiB per wave, 32 waves per CU
@@ -576,14 +579,15 @@ __global__ __launch_bounds__(64, 8) void k_zstd_exec(StreamDesc* __restrict__ st
       const uint8_t* lit = litbuf;
       if (lmode == 1u) lit = sd->in + lsrc;
       else if (lmode == 2u) wave_fill(as_global(litbuf), lsrc, regen, lane);
-      uint32_t op = 0, lp = 0, hist_valid = 0;
+      uint32_t op = 0, lp = 0;
+      ZxState zx = {0u, 0u, 0u};
       bool ok = true;
       for (uint32_t done = 0; ok && done < nseq; done += 64u) {
         const uint32_t m = nseq - done < 64u ? nseq - done : 64u;
         const uint64_t q = (uint32_t)lane < m ? sq[done + (uint32_t)lane] : 0ull;
         const uint32_t ll_b = (uint32_t)q & 0x3ffffu, ml_b = (uint32_t)(q >> 18) & 0x3ffffu, off_b = (uint32_t)(q >> 36);
         for (uint32_t g = 0; ok && g < m; g += 16u)
-          ok = zstd_exec16(ll_b, ml_b, off_b, (int)g, (int)(m - g < 16u ? m - g : 16u), sd->out, want, op, lit, lp, regen, lane, xbuf, &hist_valid);
+          ok = zstd_exec16(ll_b, ml_b, off_b, (int)g, (int)(m - g < 16u ? m - g : 16u), sd->out, want, op, lit, lp, regen, lane, xbuf, &zx);
       }
       if (ok) {
         const uint32_t rest = regen - lp;
