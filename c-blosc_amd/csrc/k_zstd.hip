@@ -77,6 +77,9 @@ constexpr uint32_t ZXB_LW = 1024u, ZXB_LW_OFF = ZXB_HIST + ZXB_STEP + 128u;     
 constexpr uint32_t ZXB_WORDS = (ZXB_LW_OFF + ZXB_LW + 16u) / 4u;
 // what a run of LDS-assembled groups keeps in the buffer: the history (the last ZXB_HIST bytes of output) and a window of the literals
 struct ZxState { uint32_t hist_valid, lw_valid, lw_base; };
+#ifndef BAMD_ZXB_GROUPSTORE
+#define BAMD_ZXB_GROUPSTORE 1    // an LDS-assembled group goes to memory in one pass of coalesced stores (0: every piece is stored where it is made)
+#endif
 #ifndef BAMD_ZXB_LITWIN
 #define BAMD_ZXB_LITWIN 1        // literals and near independent matches of an LDS-assembled group come out of LDS (0: loaded from memory per group)
 #endif
@@ -89,12 +92,13 @@ struct ZxState { uint32_t hist_valid, lw_valid, lw_base; };
 typedef volatile __attribute__((address_space(3))) uint8_t zlds_u8;
 __device__ __forceinline__ void zlds_st16(zlds_u8* l, const uint4& v) { v4u32 t = {v.x, v.y, v.z, v.w}; *(volatile __attribute__((address_space(3))) v4u32_una*)l = t; }
 // lane_copy_disjoint (wave_prims.h) with a second destination in LDS
+template <bool G = true>      // G: to memory as well as to LDS
 __device__ __forceinline__ void lane_copy_dual(gu8* d, zlds_u8* l, const gu8* s, uint32_t n) {
   if (n >= 16u) {
     uint32_t k = 0;
     for (; k + 64u <= n; k += 64u) {
       const uint4 a = ld16u(s + k), b = ld16u(s + k + 16), c = ld16u(s + k + 32), e = ld16u(s + k + 48);
-      st16u(d + k, a); st16u(d + k + 16, b); st16u(d + k + 32, c); st16u(d + k + 48, e);
+      if (G) { st16u(d + k, a); st16u(d + k + 16, b); st16u(d + k + 32, c); st16u(d + k + 48, e); }
       zlds_st16(l + k, a); zlds_st16(l + k + 16, b); zlds_st16(l + k + 32, c); zlds_st16(l + k + 48, e);
     }
     const uint32_t r = n - k;
@@ -103,51 +107,54 @@ __device__ __forceinline__ void lane_copy_dual(gu8* d, zlds_u8* l, const gu8* s,
     if (r >= 32u) b = ld16u(s + k + 16);
     if (r >= 48u) c = ld16u(s + k + 32);
     const uint4 z = ld16u(s + n - 16u);
-    if (r >= 16u) { st16u(d + k, a); zlds_st16(l + k, a); }
-    if (r >= 32u) { st16u(d + k + 16, b); zlds_st16(l + k + 16, b); }
-    if (r >= 48u) { st16u(d + k + 32, c); zlds_st16(l + k + 32, c); }
-    st16u(d + n - 16u, z); zlds_st16(l + n - 16u, z);
+    if (r >= 16u) { if (G) st16u(d + k, a); zlds_st16(l + k, a); }
+    if (r >= 32u) { if (G) st16u(d + k + 16, b); zlds_st16(l + k + 16, b); }
+    if (r >= 48u) { if (G) st16u(d + k + 32, c); zlds_st16(l + k + 32, c); }
+    if (G) st16u(d + n - 16u, z);
+    zlds_st16(l + n - 16u, z);
   } else if (n >= 8u) {
     const uint64_t a = g_ld8(s), b = g_ld8(s + n - 8u);
-    *(BAMD_GAS u64una*)d = a; *(BAMD_GAS u64una*)(d + n - 8u) = b;
+    if (G) { *(BAMD_GAS u64una*)d = a; *(BAMD_GAS u64una*)(d + n - 8u) = b; }
     *(volatile __attribute__((address_space(3))) u64una*)l = a; *(volatile __attribute__((address_space(3))) u64una*)(l + n - 8u) = b;
   } else if (n >= 4u) {
     const uint32_t a = g_ld4(s), b = g_ld4(s + n - 4u);
-    g_st4(d, a); g_st4(d + n - 4u, b);
+    if (G) { g_st4(d, a); g_st4(d + n - 4u, b); }
     *(volatile __attribute__((address_space(3))) u32una*)l = a; *(volatile __attribute__((address_space(3))) u32una*)(l + n - 4u) = b;
   } else if (n) {
     const uint8_t a = s[0], b = s[n >> 1], c = s[n - 1u];
-    d[0] = a; d[n >> 1] = b; d[n - 1u] = c;
+    if (G) { d[0] = a; d[n >> 1] = b; d[n - 1u] = c; }
     l[0] = a; l[n >> 1] = b; l[n - 1u] = c;
   }
 }
 // the same with the source in LDS (the literal window, the history): no memory load at all
 __device__ __forceinline__ uint4 zlds_ld16(const zlds_u8* l) { const v4u32 t = *(const volatile __attribute__((address_space(3))) v4u32_una*)l; return make_uint4(t.x, t.y, t.z, t.w); }
+template <bool G = true>
 __device__ __forceinline__ void lane_copy_dual_lds(gu8* d, zlds_u8* l, const zlds_u8* s, uint32_t n) {
   if (n >= 16u) {
     uint32_t k = 0;
     for (; k + 32u <= n; k += 32u) {
       const uint4 a = zlds_ld16(s + k), b = zlds_ld16(s + k + 16);
-      st16u(d + k, a); st16u(d + k + 16, b);
+      if (G) { st16u(d + k, a); st16u(d + k + 16, b); }
       zlds_st16(l + k, a); zlds_st16(l + k + 16, b);
     }
     const uint32_t r = n - k;                     // 0..31 bytes left: one whole piece and one that ends exactly at n
     uint4 a = make_uint4(0, 0, 0, 0);
     if (r >= 16u) a = zlds_ld16(s + k);
     const uint4 z = zlds_ld16(s + n - 16u);
-    if (r >= 16u) { st16u(d + k, a); zlds_st16(l + k, a); }
-    st16u(d + n - 16u, z); zlds_st16(l + n - 16u, z);
+    if (r >= 16u) { if (G) st16u(d + k, a); zlds_st16(l + k, a); }
+    if (G) st16u(d + n - 16u, z);
+    zlds_st16(l + n - 16u, z);
   } else if (n >= 8u) {
     const uint64_t a = *(const volatile __attribute__((address_space(3))) u64una*)s, b = *(const volatile __attribute__((address_space(3))) u64una*)(s + n - 8u);
-    *(BAMD_GAS u64una*)d = a; *(BAMD_GAS u64una*)(d + n - 8u) = b;
+    if (G) { *(BAMD_GAS u64una*)d = a; *(BAMD_GAS u64una*)(d + n - 8u) = b; }
     *(volatile __attribute__((address_space(3))) u64una*)l = a; *(volatile __attribute__((address_space(3))) u64una*)(l + n - 8u) = b;
   } else if (n >= 4u) {
     const uint32_t a = *(const volatile __attribute__((address_space(3))) u32una*)s, b = *(const volatile __attribute__((address_space(3))) u32una*)(s + n - 4u);
-    g_st4(d, a); g_st4(d + n - 4u, b);
+    if (G) { g_st4(d, a); g_st4(d + n - 4u, b); }
     *(volatile __attribute__((address_space(3))) u32una*)l = a; *(volatile __attribute__((address_space(3))) u32una*)(l + n - 4u) = b;
   } else if (n) {
     const uint8_t a = s[0], b = s[n >> 1], c = s[n - 1u];
-    d[0] = a; d[n >> 1] = b; d[n - 1u] = c;
+    if (G) { d[0] = a; d[n >> 1] = b; d[n - 1u] = c; }
     l[0] = a; l[n >> 1] = b; l[n - 1u] = c;
   }
 }
@@ -172,14 +179,17 @@ __device__ __attribute__((noinline)) void zstd_exec16_lds(gu8* out_, const gu8* 
   }
   if (!hist_valid) zlds_st16(lb + 16u * (uint32_t)lane, g_ld16(out + op - H + 16u * (uint32_t)lane));      // the history: one load
   BAMD_LDS_SYNC();
+  // BAMD_ZXB_GROUPSTORE: everything is assembled in LDS only and the finished group leaves in ONE pass of coalesced 16-byte stores (below),
+  // instead of a dozen small stores - literal runs, match pieces, 64 single bytes per dependent match - per group
+  constexpr bool GS = BAMD_ZXB_GROUPSTORE != 0;
   if (ll) {                                                  // literals (ll <= 256 here)
-    if (lw) lane_copy_dual_lds(out + op + excl, lb + H + excl, lwin + (lp + lexcl - lbase), ll);
-    else lane_copy_dual(out + op + excl, lb + H + excl, lit + lp + lexcl, ll);
+    if (lw) lane_copy_dual_lds<!GS>(out + op + excl, lb + H + excl, lwin + (lp + lexcl - lbase), ll);
+    else lane_copy_dual<!GS>(out + op + excl, lb + H + excl, lit + lp + lexcl, ll);
   }
   if (indep) {
     gu8* d = out + op + excl + ll;
-    if (lw && off <= excl + ll + H) lane_copy_dual_lds(d, lb + H + excl + ll, lb + H + excl + ll - off, ml);      // the source lies in the buffer's history
-    else lane_copy_dual(d, lb + H + excl + ll, d - off, ml);
+    if (lw && off <= excl + ll + H) lane_copy_dual_lds<!GS>(d, lb + H + excl + ll, lb + H + excl + ll - off, ml);      // the source lies in the buffer's history
+    else lane_copy_dual<!GS>(d, lb + H + excl + ll, d - off, ml);
   }
   BAMD_LDS_SYNC();
   uint32_t rest = (uint32_t)__ballot(dep) & 0xffffu;
@@ -195,9 +205,15 @@ __device__ __attribute__((noinline)) void zstd_exec16_lds(gu8* out_, const gu8* 
       const uint32_t kk = o < m ? k - ((k * M) >> 20) * o : k;
       const uint8_t v = lb[H + mr - o + kk];
       lb[H + mr + k] = v;
-      out[op + mr + k] = v;
+      if (BAMD_ZXB_GROUPSTORE == 0) out[op + mr + k] = v;
     }
     BAMD_LDS_SYNC();
+  }
+  if (BAMD_ZXB_GROUPSTORE) {                                 // the group, whole: 1 KiB per store instruction, never a byte behind it
+    for (uint32_t q = 16u * (uint32_t)lane; q < total_out; q += 1024u) {
+      if (q + 16u <= total_out) st16u(out + op + q, zlds_ld16(lb + H + q));
+      else for (uint32_t t = q; t < total_out; t++) out[op + t] = lb[H + t];
+    }
   }
   // slide: the last H bytes of history + group become the next group's history, so that a run of such groups loads its history once
   // (every group's load of the bytes the group before had just stored was a trip to L2 that the group's first LDS copy waited for)
