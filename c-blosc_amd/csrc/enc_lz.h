@@ -30,7 +30,11 @@ constexpr int ENC_TAB_BYTES = BAMD_ENC_SPLIT_TAB ? ENC_TAB * 3 : ENC_TAB * 4;
 #ifndef BAMD_ENC_MINWAVES
 #define BAMD_ENC_MINWAVES (BAMD_ENC_SPLIT_TAB ? 6 : 5)   // waves per SIMD the register allocator leaves room for
 #endif
-constexpr int ENC_LDS_WAVES = (160 * 1024) / ENC_TAB_BYTES;
+#ifndef BAMD_ENC_RUNBUF
+#define BAMD_ENC_RUNBUF 0      // the LZ4 emitter's sequences through a 512-byte LDS ring, 256 bytes per store (see lz4_emit_seq).  MEASURED: 8.2 -> 8.75 ms on bench19, slower on every data set (two copies of each build taking turns, profiles/r03zj_enc_ab_run_buffer_rejected.txt): off
+#endif
+constexpr uint32_t ENC_RB_BYTES = BAMD_ENC_RUNBUF ? 512u : 0u;
+constexpr int ENC_LDS_WAVES = (160 * 1024) / (ENC_TAB_BYTES + (int)ENC_RB_BYTES);
 constexpr int ENC_WAVES_PER_CU = ENC_LDS_WAVES < 4 * BAMD_ENC_MINWAVES ? ENC_LDS_WAVES : 4 * BAMD_ENC_MINWAVES;   // persistent grid size per CU
 
 // the table of one wave (LDS)
@@ -269,8 +273,25 @@ __device__ __forceinline__ void emit_literals(gu8* dst, const gu8* lit, uint32_t
   }
 }
 
+// Run buffer of the LZ4 emitter (round 3, the lesson of k_zstd_seq's triples: ONE in-order counter for loads and stores).  A sequence of
+// bench19's noisy planes is ~10 bytes, stored with one instruction - and the next step's candidate loads wait for L2's acknowledgement of it
+// (the emitter with its stores left out: 8.19 -> 7.53 ms, profiles/r03zi_enc_ab1.txt).  The common sequence shape now goes to a 512-byte LDS
+// ring of the wave (behind the hash table) and leaves 256 bytes at a time, one coalesced dword store per lane; everything else
+// (long literal runs, long matches, the stream's tail) first drains the ring and stores as before.  Same bytes (checked on the
+// emulator).  It does NOT pay here: 6 % slower - the ring's LDS traffic and bookkeeping in a loop that already spills cost more than the
+// acknowledgements do (what worked for k_zstd_seq, whose loop does nothing else between a store and the next load).  BAMD_ENC_RUNBUF=0.
+struct EncRun {
+  volatile __attribute__((address_space(3))) uint8_t* ring;    // nullptr: no run buffer (BloscLZ, the other writers)
+  uint32_t fl, base;                                           // output bytes [0, fl) are in memory, [fl, op) in the ring at (pos - base) & 511; fl - base is a multiple of 256
+};
+__device__ __forceinline__ void enc_run_drain(EncRun& r, gu8* dst, uint32_t op, int lane) {     // everything pending to memory; the ring restarts at op
+  if (!r.ring) return;
+  BAMD_LDS_SYNC();
+  for (uint32_t k = r.fl + (uint32_t)lane; k < op; k += 64u) ENC_ST1(dst + k, r.ring[(k - r.base) & 511u]);
+  r.fl = op; r.base = op;
+}
 __device__ __forceinline__ uint32_t lz4_emit_seq(gu8* dst, uint32_t op, uint32_t cap, const gu8* lit,
-                                                 uint32_t ll, uint32_t off, uint32_t mlen, int lit_lane0, uint32_t ownbyte, int lane) {
+                                                 uint32_t ll, uint32_t off, uint32_t mlen, int lit_lane0, uint32_t ownbyte, int lane, EncRun* run = nullptr) {
   if (op + 1u + ll + (2u + 1u + 5u) + ll / 255u > cap) return 0xffffffffu;
   const uint32_t mcode = mlen - 4u;
   if (BAMD_ENC_EMIT1 && ll < 15u && mcode < 15u + 255u && (ll == 0u || (lit_lane0 >= 0 && (uint32_t)lit_lane0 + ll <= 64u))) {
@@ -284,9 +305,21 @@ __device__ __forceinline__ uint32_t lz4_emit_seq(gu8* dst, uint32_t op, uint32_t
     b = (uint32_t)lane == ll + 2u ? off >> 8 : b;
     b = (uint32_t)lane == ll + 3u ? mcode - 15u : b;
     const uint32_t total = ll + 3u + (mcode >= 15u ? 1u : 0u);
+    if (run && run->ring) {
+      if ((uint32_t)lane < total) run->ring[(op + (uint32_t)lane - run->base) & 511u] = (uint8_t)b;
+      op += total;
+      if (op - run->fl >= 256u) {                            // 256 bytes leave: a dword per lane (the ring offset of fl is 0 or 256)
+        BAMD_LDS_SYNC();
+        const uint32_t w = *(volatile __attribute__((address_space(3))) uint32_t*)(run->ring + (((run->fl - run->base) & 511u) + 4u * (uint32_t)lane));
+        if (!BAMD_ENC_NOSTORE) g_st4(dst + run->fl + 4u * (uint32_t)lane, w);
+        run->fl += 256u;
+      }
+      return op;
+    }
     if ((uint32_t)lane < total) ENC_ST1(dst + op + lane, (uint8_t)b);
     return op + total;
   }
+  if (run) enc_run_drain(*run, dst, op, lane);
   const uint32_t tok = ((ll < 15u ? ll : 15u) << 4) | (mcode < 15u ? mcode : 15u);
   if (lane == 0) ENC_ST1(dst + op, (uint8_t)tok);
   op += 1u;
@@ -297,6 +330,7 @@ __device__ __forceinline__ uint32_t lz4_emit_seq(gu8* dst, uint32_t op, uint32_t
   op += 2u;
   if (op + (1u + 5u) + (mcode + 240u) / 255u > cap) return 0xffffffffu;
   if (mcode >= 15u) op += emit_ext255(dst + op, mcode - 15u, lane);
+  if (run && run->ring) { run->fl = op; run->base = op; }
   return op;
 }
 // final literal run (lz4.c:1302-1329)
@@ -509,6 +543,8 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
 
   if (start == 0u) tab.clear(lane);
 
+  EncRun run = {nullptr, 0u, 0u};
+  if (FMT == EF_LZ4 && BAMD_ENC_RUNBUF) run.ring = (volatile __attribute__((address_space(3))) uint8_t*)tab_generic + ENC_TAB_BYTES;
   EncWindow win;
   win.init(src, n, lane);
   uint32_t ip = start, anchor = start, op = 0, nfail = 0;
@@ -664,7 +700,7 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
       const uint32_t ll = pm - anchor;
       const uint32_t dist = pm - cm;
       if (FMT == EF_LZ4) {
-        op = lz4_emit_seq(dst, op, cap, src + anchor, ll, dist, mlen, anchor >= ip ? (int)(anchor - ip) : -1, (uint32_t)own.a & 0xffu, lane);
+        op = lz4_emit_seq(dst, op, cap, src + anchor, ll, dist, mlen, anchor >= ip ? (int)(anchor - ip) : -1, (uint32_t)own.a & 0xffu, lane, &run);
         if (op == 0xffffffffu) return 0u;
       } else if (FMT == EF_ZSTD || FMT == EF_ZLIB2) {
         if (zs_emit_seq(*zs, src + anchor, ll, dist, mlen, anchor >= ip ? (int)(anchor - ip) : -1, (uint32_t)own.a & 0xffu, lane) == 0xffffffffu) return 0xffffffffu;
@@ -704,6 +740,7 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
   // closing literals
   if (FMT == EF_ZSTD || FMT == EF_ZLIB || FMT == EF_ZLIB2) return anchor;
   if (FMT == EF_LZ4) {
+    enc_run_drain(run, dst, op, lane);
     op = lz4_emit_tail(dst, op, cap, src + anchor, n - anchor, lane);
     if (op == 0xffffffffu) return 0u;
   } else {
