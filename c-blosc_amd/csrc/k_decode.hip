@@ -212,6 +212,9 @@ constexpr uint32_t LZB_HIST = 1024u, LZB_STEP = 2048u, LZB_BYTES = LZB_HIST + LZ
 #define BAMD_LZB_MIN_REST 4     // dependent matches a step needs before the LDS form pays (2: BloscLZ byte-shuffled bench19 +8 %, see profiles/r02g_lds_step.txt)
 #endif
 constexpr int LZB_MIN_REST = BAMD_LZB_MIN_REST;
+#ifndef BAMD_LZB_RCP
+#define BAMD_LZB_RCP 1          // lz4_step_lds: k mod o with a float reciprocal per lane instead of a scalar integer division per match
+#endif
 typedef volatile __attribute__((address_space(3))) uint8_t lds_u8;
 template <int N>
 __device__ __forceinline__ uint32_t row_max16(uint32_t v) {     // maximum over the 16 lanes of a DPP row, valid in lane 15 of the row
@@ -297,9 +300,18 @@ __device__ __attribute__((noinline)) void lz4_step_lds(gu8* out_, volatile uint3
     {
       // periodic extension of the o bytes before the match (o >= m: a plain copy); floor(k / o) by multiplication - exact for
       // k < 512 because the quotient is only needed when o < m <= 273
+#if BAMD_LZB_RCP
+      const float ro = o < m ? __builtin_amdgcn_rcpf((float)o) : 0.0f;       // k mod o per lane (k_zstd.hip: zstd_exec16_lds has the story: the integer division was 23 scalar instructions per match)
+#else
       const uint32_t M = o < m ? (1u << 20) / o + 1u : 0u;
+#endif
       for (uint32_t k = (uint32_t)lane; k < m; k += 64u) {
+#if BAMD_LZB_RCP
+        uint32_t kk = k;
+        if (o < m) { kk = k - (uint32_t)((float)k * ro) * o; kk = kk >= o ? kk - o : kk; }
+#else
         const uint32_t kk = o < m ? k - ((k * M) >> 20) * o : k;
+#endif
         const uint8_t v = lb[H + mr - o + kk];
         lb[H + mr + k] = v;
         out[op + mr + k] = v;

@@ -159,7 +159,15 @@ __device__ __forceinline__ void lane_copy_dual_lds(gu8* d, zlds_u8* l, const zld
   }
 }
 // (a real call: the common group must not pay for its registers).  indep / dep: this lane's match is copied at once / in stream order.
-__device__ __attribute__((noinline)) void zstd_exec16_lds(gu8* out_, const gu8* lit_, volatile uint32_t* xbuf_generic, uint32_t ll, uint32_t ml, uint32_t off,
+#ifndef BAMD_ZXB_INLINE
+#define BAMD_ZXB_INLINE 1        // zstd_exec16_lds inlined into its callers: bench19 10.8 -> 10.5 ms, linspace 6.8 -> 5.8 (profiles/r03zm_zent_split_rcp_modulo_inline.txt); 0: a real call
+#endif
+#if BAMD_ZXB_INLINE
+#define ZXB_FN __device__ __forceinline__
+#else
+#define ZXB_FN __device__ __attribute__((noinline))
+#endif
+ZXB_FN void zstd_exec16_lds(gu8* out_, const gu8* lit_, volatile uint32_t* xbuf_generic, uint32_t ll, uint32_t ml, uint32_t off,
                                                           uint32_t excl, uint32_t lexcl, bool indep, bool dep, uint32_t op_, uint32_t lp_, int lane,
                                                           uint32_t hist_valid_, uint32_t total_out_, uint32_t lw_, uint32_t regen_) {
   // lw_: 0 = literals from memory; else bit 0 set and (lw_ >> 1) = the window's base when it already covers this group's literals,
@@ -198,11 +206,14 @@ __device__ __attribute__((noinline)) void zstd_exec16_lds(gu8* out_, const gu8* 
     rest &= rest - 1u;
     const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)ml, sl), o = (uint32_t)__builtin_amdgcn_readlane((int)off, sl);
     const uint32_t mr = (uint32_t)__builtin_amdgcn_readlane((int)excl, sl) + (uint32_t)__builtin_amdgcn_readlane((int)ll, sl);
-    // periodic extension of the o bytes before the match (o >= m: a plain copy); floor(k / o) by multiplication: exact for k < 512
-    // (m <= ZXB_MAXM; the quotient is only needed when o < m)
-    const uint32_t M = o < m ? (1u << 20) / o + 1u : 0u;
+    // periodic extension of the o bytes before the match (o >= m: a plain copy; m <= ZXB_MAXM)
+    // k mod o per lane with a float reciprocal (k, o < 512: the quotient is exact or one too small, which the compare repairs).  The
+    // integer division this replaces was 23 scalar instructions per match on a scalar unit that SQ counters show 83 % busy in this kernel
+    // (profiles/r03zl_zstd_sq_counters.txt: 393 scalar + 307 vector instructions per group of 16 sequences)
+    const float ro = o < m ? __builtin_amdgcn_rcpf((float)o) : 0.0f;
     for (uint32_t k = (uint32_t)lane; k < m; k += 64u) {
-      const uint32_t kk = o < m ? k - ((k * M) >> 20) * o : k;
+      uint32_t kk = k;
+      if (o < m) { kk = k - (uint32_t)((float)k * ro) * o; kk = kk >= o ? kk - o : kk; }
       const uint8_t v = lb[H + mr - o + kk];
       lb[H + mr + k] = v;
       if (BAMD_ZXB_GROUPSTORE == 0) out[op + mr + k] = v;

