@@ -79,6 +79,19 @@ ZI_FN bool writer() { return true; }
 #endif
 typedef ZI_TAB uint16_t tab16;
 typedef ZI_TAB uint8_t tab8;
+// On the device the tables are LDS, and the symbol loop must SAY so: through `const Tabs&` the pointers are generic, the address-space
+// inference leaves volatile accesses alone, and every table lookup of k_zlib_streams was a flat_load (96 of them, not one ds_read;
+// 0.49 G flat loads per 8 GiB, profiles/r03zp_zlib_decode_sq_counters.txt) - twice the latency of an LDS read in a loop that is one
+// dependent lookup after the other.
+#ifndef BAMD_ZI_LDS
+#define BAMD_ZI_LDS 1        // 0: generic pointers (flat loads) as before - A/B switch
+#endif
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__) && !defined(BAMD_WAVE_EMU) && BAMD_ZI_LDS
+#define ZI_LDS __attribute__((address_space(3)))
+#else
+#define ZI_LDS
+#endif
+typedef const ZI_LDS tab16* ltab16;
 struct Tabs {
   tab16 lcount[16], lsym[288], lfast[1 << kLitFast];
   tab16 dcount[16], dsym[32], dfast[1 << kDistFast];
@@ -114,7 +127,7 @@ ZI_COLD int huff_build(tab16* count, tab16* sym, tab16* fast, int fastbits, cons
   return left;
 }
 // next symbol, or -1 when the bits match no code
-template <class B> ZI_FN int huff_decode(B& b, const tab16* count, const tab16* sym, const tab16* fast, int fastbits) {
+template <class B, class PT> ZI_FN int huff_decode(B& b, PT count, PT sym, PT fast, int fastbits) {      // PT: const tab16* or its LDS-qualified form
   const uint32_t v = bits_peek(b, kMaxBits);
   const uint32_t e = fast[v & ((1u << fastbits) - 1u)];
   if (e) { bits_drop(b, e & 15u); return (int)(e >> 4); }
@@ -222,14 +235,14 @@ ZI_FN uint32_t dist_extra(int c) { return c < 4 ? 0u : (uint32_t)(c >> 1) - 1u; 
 
 // next literal / match / end-of-block of a coded block
 template <class B> ZI_FN int next_op(B& b, const Tabs& t, Op& op) {
-  const int s = huff_decode(b, t.lcount, t.lsym, t.lfast, kLitFast);
+  const int s = huff_decode(b, (ltab16)t.lcount, (ltab16)t.lsym, (ltab16)t.lfast, kLitFast);
   if (s < 0 || bits_overrun(b)) return OP_ERROR;
   if (s < 256) { op.len = (uint32_t)s; return OP_LIT; }
   if (s == 256) return OP_EOB;
   if (s > 285) return OP_ERROR;
   const int lc = s - 257;
   op.len = len_base(lc) + bits_get(b, len_extra(lc));
-  const int d = huff_decode(b, t.dcount, t.dsym, t.dfast, kDistFast);
+  const int d = huff_decode(b, (ltab16)t.dcount, (ltab16)t.dsym, (ltab16)t.dfast, kDistFast);
   if (d < 0 || d > 29) return OP_ERROR;
   const uint32_t de = dist_extra(d);
   op.dist = dist_base(d) + bits_get(b, de);
