@@ -1,7 +1,8 @@
 """Host logic without a GPU: the queue builders of the persistent kernels (c-blosc_amd/csrc/queue_order.h)
 are plain C++; tests/tools/sched_check.cpp compiles them with g++ and checks the invariants the kernels rely
 on (every stream exactly once on its block's XCD, shuffle task before the block's streams, offsets a prefix
-sum, expensive planes kept out of the queue tails) over 400 random batch geometries."""
+sum, expensive planes kept out of the queue tails) over 400 random batch geometries; and, since round 3, that mixed batches are
+partitioned: Zstd blocks in nobody's queue, zlib blocks in the zlib kernel's queues and only there, the rest in k_decode_streams'."""
 import os
 import subprocess
 import tempfile

@@ -87,6 +87,40 @@ int main() {
     }
     for (int s = 0; s < nstr; s++) if (seen[(size_t)s] != 1) return fail("dec: stream missing", trial);
   }
+  // ---- round 3: blocks of Zstd chunks (BLK_Z) are in nobody's queue - their kernels take tickets over all streams -, blocks of zlib chunks
+  //      (BLK_Z | BLK_ZLIB) are in the zlib kernel's queues and only there, everything else is k_decode_streams': a partition, every
+  //      stream on its block's XCD, in mixed batches of any geometry ----
+  for (int trial = 0; trial < 200; trial++) {
+    const int nblk = 1 + (int)(rng() % 300), nq = (trial % 5 == 4) ? 1 : 8;
+    std::vector<BlockDesc> blocks; std::vector<int> owner; std::vector<int> kind;      // kind per stream: 0 LZ, 1 Zstd, 2 zlib
+    int nstr = 0;
+    for (int j = 0; j < nblk; j++) {
+      BlockDesc b; memset(&b, 0, sizeof b);
+      const int k = (int)(rng() % 3), ns = (rng() % 4 == 0) ? 1 : (int)(1 + rng() % 16);
+      b.blk = j; b.first_stream = nstr; b.nstreams = ns; b.flags = k == 1 ? BLK_Z : (k == 2 ? (BLK_Z | BLK_ZLIB) : ((rng() % 9 == 0) ? BLK_LDS : 0));
+      for (int t = 0; t < ns; t++) { owner.push_back(j); kind.push_back((b.flags & BLK_LDS) ? 3 : k); }
+      nstr += ns; blocks.push_back(b);
+    }
+    std::vector<int32_t> qa, qz;
+    build_xcd_queues(blocks, (size_t)nstr, nullptr, false, qa, nq);
+    build_xcd_queues(blocks, (size_t)nstr, nullptr, false, qz, nq, BLK_ZLIB);
+    std::vector<int> seen((size_t)nstr, 0);
+    for (int pass = 0; pass < 2; pass++) {
+      const std::vector<int32_t>& d = pass ? qz : qa;
+      if (d[0] != 0) return fail("z: header", trial);
+      for (int x = 0; x < 8; x++) {
+        if (d[x + 1] < d[x]) return fail("z: offsets not monotone", trial);
+        for (int i = d[x]; i < d[x + 1]; i++) {
+          const int32_t t = d[9 + i];
+          if (t < 0 || t >= nstr) return fail("z: stream index out of range", trial);
+          if (kind[(size_t)t] != (pass ? 2 : 0)) return fail(pass ? "z: a stream that is not zlib's in the zlib queues" : "z: a Zstd / zlib / LDS-block stream in k_decode_streams' queues", trial);
+          if ((owner[(size_t)t] % nq) != x) return fail("z: stream on the wrong XCD", trial);
+          if (seen[(size_t)t]++) return fail("z: stream twice", trial);
+        }
+      }
+    }
+    for (int t = 0; t < nstr; t++) if (seen[(size_t)t] != ((kind[(size_t)t] == 0 || kind[(size_t)t] == 2) ? 1 : 0)) return fail("z: partition", trial);
+  }
   // the tail property the feedback is for: with one plane 10x as expensive, no XCD's encode queue ends with it
   {
     std::vector<ChunkDesc> chunks(1); memset(&chunks[0], 0, sizeof(ChunkDesc)); chunks[0].typesize = 8; chunks[0].mode = CH_SHUFFLE | CH_FUSED_SHUF;
