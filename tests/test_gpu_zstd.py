@@ -38,11 +38,16 @@ def test_getitem_on_zstd_chunks(pkg, lib):
 
 
 def test_device_batch_mixed_codecs(pkg, oracle):
-    """one batched call over Zstd, LZ4 and BloscLZ chunks together"""
+    """one batched call over Zstd, zlib, LZ4 and BloscLZ chunks together (three kernels, three sets of queues over one block table:
+    k_decode_streams' per-XCD queues leave the Zstd / zlib blocks out, the zlib kernel's hold exactly its own - engine.hip, round 3)"""
     import torch
     from helpers import orc_compress
     dev = torch.device("cuda:0")
     items = [(c, DATASETS[d](n)) for c, d, n, T in list(_chunks())[:8]]
+    zl = np.load(os.path.join(GOLDEN, "ref_zlib_chunks.npz"))
+    for k in (0, 1, 4, 10, 15, 20):
+        dname, n, T, clevel, shuffle, bs = zl["meta"][k].split(",")
+        items.insert(2 * (k % 4), (zl[f"c{k}"], DATASETS[dname](int(n))))            # interleaved with the Zstd chunks
     for codec in ("lz4", "blosclz"):
         data = DATASETS["bench19"](1 << 20)
         r, ch = orc_compress(oracle, data, 8, 5, 1, codec)
