@@ -27,6 +27,9 @@
 #ifndef BAMD_ZSTD_SEQ_KERNEL
 #define BAMD_ZSTD_SEQ_KERNEL 1    // the FSE sequence streams of the global two-phase path in a kernel of their own, one lane per frame (k_zstd_seq); 0: inside k_zstd_entropy, on one lane in four
 #endif
+#ifndef BAMD_ZENT_GLOBAL_IN
+#define BAMD_ZENT_GLOBAL_IN 1
+#endif
 #ifndef BAMD_ZHUF_FAST
 #define BAMD_ZHUF_FAST 1          // k_zstd_entropy: the Huffman literal streams through zhuf_run (0: zd::huf_decode_stream as it stands in zstd_serial.h)
 #endif
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(64) void k_zstd_entropy_t(const StreamDesc* __restr
   int hs_off = 0, hlen = 0;                 // Huffman payload (behind the table description)
   if (sid < nstreams) {
     const StreamDesc& sd = streams[sid];
-    in = sd.in; n = sd.in_size; want = sd.out_size;
+    in = BAMD_ZENT_GLOBAL_IN ? (const uint8_t*)as_global(sd.in) : sd.in; n = sd.in_size; want = sd.out_size;      // (through the global address space: what is inlined below - zstd_serial.h's header, table and Huffman-table code - then uses global_load, not flat_load: 58 flat instructions -> 0)
     take = sd.fmt == FMT_ZSTD && n >= 0 && n != want;
     if (take) {
       const ChunkDesc& c = chunks[sd.chunk];
