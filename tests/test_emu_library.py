@@ -110,7 +110,7 @@ def test_typesize_2_and_16_take_the_fused_paths(emulib, oracle, ref, T):
     constant, periodic, noisy and incompressible planes + an unsplit leftover block, written here and by the reference."""
     rng = np.random.default_rng(70 + T)
     ne = 16384                                                    # bytes per plane of a full block: spans need >= 16 KiB matches
-    nfull = 2
+    nfull = 2 if (FULL or T == 2) else 1
     planes = []
     for j in range(T):
         kind = j % 5
@@ -224,9 +224,9 @@ def test_reference_written_zlib_chunks_through_the_queued_kernel(emulib, oracle)
     items = []
     for k, m in enumerate(z["meta"]):
         dname, n, T, clevel, shuffle, bs = m.split(",")
-        if FULL or k in (0, 13, 15, 21):                              # (inflate on the emulator is slow: ~100 KB/s)
+        if FULL or k in (0, 13, 15):                                  # (inflate on the emulator is slow: ~100 KB/s)
             items.append((z[f"c{k}"], dname, int(n)))
-    assert len(items) >= 4
+    assert len(items) >= 3
     rejected = 0
     for chunk, dname, n in items:
         data = DATASETS[dname](n)
@@ -246,7 +246,7 @@ def test_reference_written_zlib_chunks_through_the_queued_kernel(emulib, oracle)
             else:
                 assert rg < 0, (dname, n, trial, pos, ro, rg)
                 rejected += 1
-    assert rejected >= 3
+    assert rejected >= 2
 
 
 @pytest.mark.parametrize("cname", ["lz4", "blosclz"])
