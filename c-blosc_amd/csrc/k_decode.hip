@@ -1056,6 +1056,9 @@ __device__ __attribute__((noinline)) void unshuffle_block_wave(const uint8_t* sr
 // of in a kernel of their own behind them (k_unshuffle: 3.4 ms per 8 GiB).  No spans, and fewer steps in flight than
 // unshuffle_block_wave: k_zstd_exec runs 8 waves per SIMD on 64 registers.
 // ---------------------------------------------------------------------------------------------
+#ifdef BAMD_WAVE_EMU
+inline unsigned long long g_emu_own_block_unshuffles = 0;      // emulator only: blocks unshuffled by the wave that decoded them (fused_unshuffle_own_block)
+#endif
 template <int T, int STEPS>
 __device__ __forceinline__ void unshuffle_plain_T(const gu8* src, gu8* dst, uint32_t bsize, int lane) {
   const uint32_t N = bsize / T;
@@ -1105,6 +1108,9 @@ __device__ __attribute__((noinline)) void unshuffle_block_plain(const uint8_t* s
 // Called by the wave that has just written the whole of stream `sd` (the only stream of its block) into the scratch.
 __device__ __forceinline__ void fused_unshuffle_own_block(const ChunkDesc* c, const BlockDesc* b, int lane) {
   if (!(uni(c->mode) & CH_FUSED_UNSHUF) || uni((uint32_t)b->nstreams) != 1u) return;
+#ifdef BAMD_WAVE_EMU
+  if (lane == 0) g_emu_own_block_unshuffles++;
+#endif
   BAMD_WAIT_STORES();     // this wave's own stores are what it reads back: no other wave, no other cache involved
   BAMD_MEM_SYNC();
   const uint32_t blk = uni((uint32_t)b->blk);

@@ -72,6 +72,12 @@ __device__ __forceinline__ void wave_fill(gu8* dst, uint32_t v, uint32_t n, int 
 // is shorter than its length is the periodic extension of the bytes before it: every lane reads only bytes that are final)
 // whose values the lanes also store to memory.
 // ---------------------------------------------------------------------------------------------
+#ifdef BAMD_WAVE_EMU
+// emulator only: how often the round-3 paths ran (the CPU tests assert that reference-written frames really take them):
+// [0] groups assembled in LDS, [1] of them with the history kept from the group before, [2] with literals out of the window, [3] frames whose
+// sequences k_zstd_seq decoded, [4] blocks unshuffled by the wave that decoded them
+inline unsigned long long g_emu_zstd_paths[5] = {0, 0, 0, 0, 0};
+#endif
 constexpr uint32_t ZXB_HIST = 1024u, ZXB_STEP = 2048u, ZXB_MAXM = 512u;
 constexpr uint32_t ZXB_LW = 1024u, ZXB_LW_OFF = ZXB_HIST + ZXB_STEP + 128u;      // the literal window: ZXB_LW bytes of the frame's literal buffer, behind the group buffer
 constexpr uint32_t ZXB_WORDS = (ZXB_LW_OFF + ZXB_LW + 16u) / 4u;
@@ -178,6 +184,9 @@ ZXB_FN void zstd_exec16_lds(gu8* out_, const gu8* lit_, volatile uint32_t* xbuf_
   zlds_u8* lb = (zlds_u8*)(volatile __attribute__((address_space(3))) uint32_t*)xbuf_generic;
   zlds_u8* lwin = lb + ZXB_LW_OFF;
   constexpr uint32_t H = ZXB_HIST;
+#ifdef BAMD_WAVE_EMU
+  if (lane == 0) { g_emu_zstd_paths[0]++; g_emu_zstd_paths[1] += hist_valid ? 1 : 0; g_emu_zstd_paths[2] += lw ? 1 : 0; }
+#endif
   uint32_t lbase = lw >> 1;
   if (lw == 0xffffffffu) {                                   // the literal window from lp on (never a byte behind the literal buffer)
     lbase = lp;

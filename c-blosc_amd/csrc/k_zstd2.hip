@@ -503,6 +503,9 @@ __global__ __launch_bounds__(64) void k_zstd_seq(const StreamDesc* __restrict__ 
   }
   if (fine && st.b.off != 0) fine = false;                                  // the bit stream must be consumed exactly
   meta[sid].state = fine ? ZM_READY : ZM_ERROR;
+#ifdef BAMD_WAVE_EMU
+  g_emu_zstd_paths[3]++;
+#endif
 }
 
 // The same with the frames' tables in LDS (round 3).  k_zstd_seq is bound by its table reads: 3 random 2-byte reads per sequence out

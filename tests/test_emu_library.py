@@ -187,6 +187,7 @@ def test_reference_written_zstd_chunks_through_the_two_phase_path(emulib, oracle
     and bytes (the oracle is pinned to the reference on damaged frames, tests/test_oracle_zstd.py)."""
     z = np.load(os.path.join(ROOT, "tests", "golden", "ref_zstd_chunks.npz"))
     rng = np.random.default_rng(33)
+    before = (C.c_ulonglong * 5)(); emulib.emu_zstd_path_counts(before)
     items = []
     for k, m in enumerate(z["meta"]):
         dname, n, T, clevel, shuffle, bs = m.split(",")
@@ -213,6 +214,11 @@ def test_reference_written_zstd_chunks_through_the_two_phase_path(emulib, oracle
                 assert rg < 0, (dname, n, trial, pos, ro, rg)
                 rejected += 1
     assert rejected >= 5
+    # the paths this test is about really ran: LDS-assembled groups (some with the history kept, some with literals out of the window),
+    # frames through k_zstd_seq, blocks unshuffled by the wave that decoded them
+    after = (C.c_ulonglong * 5)(); emulib.emu_zstd_path_counts(after)
+    ran = [int(a) - int(b) for a, b in zip(after, before)]
+    assert ran[0] >= 20 and ran[1] >= 5 and ran[2] >= 5 and ran[3] >= 20 and ran[4] >= 5, ran
 
 
 def test_reference_written_zlib_chunks_through_the_queued_kernel(emulib, oracle):

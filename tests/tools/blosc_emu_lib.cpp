@@ -9,3 +9,9 @@
 #include <hip/hip_runtime.h>
 #include "engine.hip"
 #include "blosc_api.hip"
+
+// how often the round-3 Zstd paths ran so far (k_zstd.hip: g_emu_zstd_paths; [4] = blocks unshuffled by their decoding wave): tests/test_emu_library.py
+extern "C" void emu_zstd_path_counts(unsigned long long* out) {
+  for (int i = 0; i < 4; i++) out[i] = bamd::g_emu_zstd_paths[i];
+  out[4] = bamd::g_emu_own_block_unshuffles;
+}
