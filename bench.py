@@ -23,7 +23,11 @@ collective - the only exchange is the all_gather of the per-chunk cbytes table o
 roofline of the dominant kernel, decompression of chunks written by the reference itself (the drop-in
 direction) and the reference's own multi-threaded CPU path on this box's host cores.
 
-Run:  python bench.py [--config C --gpus N --steps K --warmup W]      (N>1: under torch.distributed.run)
+Run:  python bench.py [--config C --gpus N --steps K --warmup W]
+      N > 1: `python bench.py --gpus N` starts the N ranks itself (it re-executes itself under torch.distributed.run, one process
+      per GPU, the way the reference's entry point starts its own workers - blosc/blosc.c:1890-1949 init_threads); launched under
+      torch.distributed.run by somebody else (RANK / WORLD_SIZE in the environment) it is one of those ranks.
+      `--dry-gloo` runs the same launch + partition + exchanges + JSON assembly on the CPU over gloo (no GPU, no kernels; CPU suite).
 """
 import argparse
 import ctypes as C
@@ -41,7 +45,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (6.29 TB/s measured copy)
 COMPRESS_KERNELS = ["k_shuffle", "k_bitshuffle", "k_encode_streams", "k_lz4hc_encode", "k_zstd_encode", "k_zlib_encode", "k_chunk_scan", "k_chunk_compact"]
-DECOMPRESS_KERNELS = ["k_decode_plan", "k_classify_blocks", "k_decode_streams", "k_decode_blocks", "k_decode_blocks8", "k_zstd_entropy", "k_zstd_seq", "k_zstd_exec", "k_zstd_streams", "k_zlib_streams", "k_unshuffle",
+DECOMPRESS_KERNELS = ["k_decode_plan", "k_decode_streams", "k_zstd_entropy", "k_zstd_seq", "k_zstd_exec", "k_zstd_streams", "k_zlib_streams", "k_unshuffle",
                       "k_bitunshuffle", "k_copy_chunks"]
 KERNELS = COMPRESS_KERNELS + DECOMPRESS_KERNELS
 REFSO = os.path.join(ROOT, "oracle", "_ref", "libblosc_ref.so")
@@ -95,20 +99,24 @@ def make_chunk(kind, nbytes):
     return DATASETS[kind](nbytes)
 
 
-def measured_traffic(kernel, config_name, nchunks, chunk_mib):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of THIS workload
-    (profiles/r03_traffic_cfg<config>.json, else r02g_ / r02f_ / r02_..., made by scripts/profile_config.sh + scripts/make_traffic_json.py:
-    FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 corrections applied).  PMC counters cannot be
-    read from inside a timed run, so a workload without a committed pass reports null."""
+def measured_traffic(kernel, config_name, nchunks, chunk_mib, stock=False):
+    """(HBM bytes per launch of `kernel`, the file they come from) out of the committed rocprofv3 PMC passes of THIS workload
+    (profiles/r04_traffic_cfg<config>.json, else r03_ / r02g_ ..., made by scripts/profile_config.sh + scripts/make_traffic_json.py:
+    FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 corrections applied).  PMC counters cannot be read from inside a timed
+    run, so the figure is the committed one (`traffic_source` in the line says which file) and a workload without a committed
+    pass reports null.  stock=True: the launches that decoded REFERENCE-written chunks ("kernels_stock" of the r04 files; older
+    files mixed own-chunk and stock-chunk launches of the decode kernel in one average)."""
     if nchunks != 128 or chunk_mib != 64:
-        return None
-    for rnd in ("r03", "r02g", "r02f", "r02"):       # r03: passes taken on the final code of round 3 (scripts/gpu_call.sh profile)
+        return None, None
+    for rnd in ("r04", "r03", "r02g", "r02f", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_traffic_cfg{config_name}.json")
         if os.path.exists(path):
             with open(path) as fh:
-                k = json.load(fh)["kernels"].get(kernel)
-            return k["hbm_bytes"] if k else None
-    return None
+                doc = json.load(fh)
+            k = (doc.get("kernels_stock") or {}).get(kernel) if stock else None
+            k = k or doc["kernels"].get(kernel)
+            return (k["hbm_bytes"] if k else None), f"profiles/{rnd}_traffic_cfg{config_name}.json"
+    return None, None
 
 
 # ---------------------------------------------------------------------------------------------
@@ -355,6 +363,9 @@ def measure(rig, name, cfg, steps, warmup, args, mixed=None, payload=False):
     elapsed = time.perf_counter() - t0
     lib.blosc_gpu_profile(0)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    per_rank_t = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(per_rank_t, t)
+    per_rank_gbps = [steps * total / float(x.item()) / 1e9 for x in per_rank_t]
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -429,11 +440,14 @@ def measure(rig, name, cfg, steps, warmup, args, mixed=None, payload=False):
         tk = sum(kms.values()) / 1e3
         wall = (te - ts) / reps
         kdom = max(kms, key=kms.get)
+        s_traffic, s_src = (None, None) if (rig.overridden or mixed) else measured_traffic(kdom, name, nchunks, args.chunk_mib, stock=True)
         stock = {"GBps_wall": total / wall / 1e9, "GBps_kernels": total / tk / 1e9, "ratio": csz / ref_chunk.size,
                  "roofline_frac": (total + nchunks * ref_chunk.size) / tk / 1e9 / HBM_PEAK_GBPS, "kernels_ms": kms,
                  "roofline": {"bound": "hbm", "kernel": kdom, "avg_launch_ms": kms[kdom], "algorithmic_bytes_per_launch": float(total + nchunks * ref_chunk.size),
                               "achieved": (total + nchunks * ref_chunk.size) / (kms[kdom] / 1e3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                              "frac": (total + nchunks * ref_chunk.size) / (kms[kdom] / 1e3) / 1e9 / HBM_PEAK_GBPS}}
+                              "frac": (total + nchunks * ref_chunk.size) / (kms[kdom] / 1e3) / 1e9 / HBM_PEAK_GBPS,
+                              "path_frac": (total + nchunks * ref_chunk.size) / tk / 1e9 / HBM_PEAK_GBPS,      # over ALL kernels of the direction
+                              "traffic": s_traffic, "traffic_source": s_src}}
 
     # ---- roofline of the dominant kernel ----
     dom = max(prof, key=lambda k: prof[k]["ms_avg"])
@@ -441,9 +455,16 @@ def measure(rig, name, cfg, steps, warmup, args, mixed=None, payload=False):
     # nbytes + cbytes per chunk for a codec (or fused) kernel, 2 x nbytes for a filter-only kernel
     alg_bytes = 2.0 * total if filt_only else total + sum_cb
     ach = alg_bytes / (prof[dom]["ms_avg"] / 1e3) / 1e9
+    r_traffic, r_src = (None, None) if (rig.overridden or mixed) else measured_traffic(dom, name, nchunks, args.chunk_mib)
     roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": ach / HBM_PEAK_GBPS, "traffic": None if (rig.overridden or mixed) else measured_traffic(dom, name, nchunks, args.chunk_mib),
-            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": prof[dom]["ms_avg"]}
+            "frac": ach / HBM_PEAK_GBPS, "traffic": r_traffic, "traffic_source": r_src,
+            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": prof[dom]["ms_avg"],
+            # every pass of a direction counted (a three-pass pipeline cannot hide behind its best kernel): algorithmic bytes / sum of the direction's kernels
+            "path_frac": {"decompress": (total + sum_cb) / t_d / 1e9 / HBM_PEAK_GBPS}}
+    if not decode_only:
+        roof["path_frac"]["compress"] = (total + sum_cb) / t_c / 1e9 / HBM_PEAK_GBPS
+    if stock is not None:      # the north-star direction inside the object the driver records: decode of reference-written chunks
+        roof["decode_stock"] = stock["roofline"]
     what = "decompress pass of reference-written chunks (the GPU does not encode this codec)" if decode_only else "compress pass + decompress pass"
     res = {
         "value": world * steps * total / elapsed / 1e9, "unit": "GB/s", "steps": steps, "warmup": warmup,
@@ -459,7 +480,7 @@ def measure(rig, name, cfg, steps, warmup, args, mixed=None, payload=False):
         "decompress": {"GBps_kernels": total / t_d / 1e9, "roofline_frac_path": (total + sum_cb) / t_d / 1e9 / HBM_PEAK_GBPS},
         "decompress_stock_chunks": stock,
         "multi_gpu": {"partition": "contiguous chunk ranges, no data-path collective", "consolidation": "all_gather of the cbytes table, backend nccl (RCCL)",
-                      "consolidation_ms": consolidation_ms, "world": world,
+                      "consolidation_ms": consolidation_ms, "world": world, "rccl_world_size": dist.get_world_size(), "per_rank_GBps": per_rank_gbps,
                       "payload_consolidation": "pack + all-gather-v of the compressed chunks onto rank 0 (grouped send/recv, counts from the table)",
                       "payload_consolidation_ms": payload_ms, "payload_bytes": sum_cb_global,
                       "note": None if world > 1 else "communicator of size 1: no N > 1 line exists until the driver has a multi-GPU node"},
@@ -471,6 +492,88 @@ def measure(rig, name, cfg, steps, warmup, args, mixed=None, payload=False):
         res["compress"] = {"GBps_kernels": total / t_c / 1e9, "roofline_frac_path": (total + sum_cb) / t_c / 1e9 / HBM_PEAK_GBPS}
     res["_host_chunk"] = host_chunk
     return res
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` with no launcher around it: re-execute this file under torch.distributed.run, one process per GPU
+    (LOCAL_RANK -> blosc_gpu_set_device), on 127.0.0.1 and a free port.  The children inherit stdout: rank 0 prints the one JSON line.
+    (The reference's entry points start their own workers the same way: blosc/blosc.c:1890-1949 init_threads, :871-899 parallel_blosc.)"""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL across processes needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def _load_multigpu():
+    mspec = importlib.util.spec_from_file_location("c_blosc_amd_multigpu", os.path.join(ROOT, "c-blosc_amd", "multigpu.py"))
+    m = importlib.util.module_from_spec(mspec)
+    mspec.loader.exec_module(m)
+    return m
+
+
+def dry_gloo(args):
+    """The N-rank protocol without a GPU (CPU suite): every rank takes its range of ONE logical chunk list, "compresses" it (a cbytes
+    figure per chunk from a fixed rule - no kernels exist here, and nothing is timed as if they did), and the exchanges and the JSON
+    assembly of the real run follow on gloo: all_gather of the cbytes table, all-gather-v of the payloads onto rank 0, MAX over ranks
+    of the elapsed time, per-rank figures gathered to rank 0, one line from rank 0."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    sys.stdout.flush()
+    saved_fd1 = os.dup(1)        # gloo reports its connections through C stdio: stdout is for the one JSON line (see main)
+    os.dup2(2, 1)
+    try:
+        if world > 1:
+            dist.init_process_group("gloo")
+        else:
+            rdv = tempfile.NamedTemporaryFile(prefix="bamd_rdv_", delete=False); rdv.close(); os.unlink(rdv.name)
+            dist.init_process_group("gloo", init_method=f"file://{rdv.name}", rank=0, world_size=1)
+        dist.barrier()
+        C.CDLL(None).fflush(None)
+    finally:
+        os.dup2(saved_fd1, 1)
+        os.close(saved_fd1)
+    mg = _load_multigpu()
+    per_gpu = args.chunks or 8
+    csz = 4096
+    total_chunks = per_gpu * world
+    lo, hi = mg.chunk_range(total_chunks, world, rank)
+    rule = lambda c: 64 + (c * 37) % 191                          # the stand-in for a compressed size
+    dist.barrier(); t0 = time.perf_counter()
+    cbytes = [rule(c) for c in range(lo, hi)]
+    rows = [torch.full((csz,), c % 251, dtype=torch.uint8) for c in range(lo, hi)]
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    per_rank = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(per_rank, torch.tensor([elapsed, float(hi - lo)], dtype=torch.float64))
+    table, offsets = mg.gather_cbytes(cbytes, total_chunks)
+    assert table == [rule(c) for c in range(total_chunks)], "cbytes table differs from the rule"
+    packed = mg.pack_local(rows, cbytes)
+    container, offs = mg.gather_payload(packed, table, total_chunks, dst=0)
+    if rank == 0:
+        assert container.numel() == sum(table)
+        for c in (0, total_chunks // 2, total_chunks - 1):       # chunk c's bytes are where the table says
+            assert int(container[offs[c]]) == c % 251 and int(container[offs[c] + table[c] - 1]) == c % 251
+        print(json.dumps({
+            "metric": "compress+decompress GB/s (uncompressed) at 1/2/4/8 GPUs vs HBM roofline; ratio",
+            "value": None, "unit": "GB/s", "n_gpus": world, "steps": 0, "warmup": 0, "ms_per_step": None, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic", "dry": True,
+            "config": {"workload": f"dry run on gloo: {per_gpu} stand-in chunks per rank, no kernels", "chunks_per_gpu": per_gpu, "chunks_total": total_chunks},
+            "multi_gpu": {"world": world, "backend": "gloo", "chunks_per_rank": [int(p[1].item()) for p in per_rank], "payload_bytes": int(sum(table)),
+                          "partition": "contiguous chunk ranges, no data-path collective"},
+        }))
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
 
 
 def main():
@@ -491,7 +594,18 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-stock", action="store_true", help="skip the decompression of reference-written chunks")
     ap.add_argument("--no-extra", action="store_true", help="default config only: skip the short legs for configs #3 / #4 and the mixed batch")
+    ap.add_argument("--spawn", action="store_true", help="start the ranks through torch.distributed.run also when N = 1 (the N > 1 launch path on a one-GPU box)")
+    ap.add_argument("--dry-gloo", action="store_true", help="no GPU: launch, partition, cbytes / payload exchanges and the JSON line over gloo on the CPU (tests)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    # ---- N > 1 and nobody has started the ranks: start them (one process per GPU), rank 0's JSON line is this process's output ----
+    if (args.gpus > 1 or args.spawn) and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: launch with --nproc-per-node {args.gpus} (or let bench.py start the ranks itself)")
+    if args.dry_gloo:
+        return dry_gloo(args)
     cfg = dict(CONFIGS[args.config])
     os.environ.update(cfg.pop("env", {}))
     for k in ("typesize", "clevel", "shuffle", "codec", "data"):
@@ -504,6 +618,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.device_count() < world:
+        sys.exit(f"bench.py: --gpus {world} but this node shows {torch.cuda.device_count()} GPU(s)")
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
     # RCCL communicator also at N = 1 (size 1): the code path is the same for every N.
@@ -531,9 +647,7 @@ def main():
     rig.torch, rig.dist, rig.dev, rig.world, rig.rank, rig.overridden = torch, dist, dev, world, rank, overridden
     rig.mod = load_pkg()
     rig.lib = rig.mod.load()
-    mspec = importlib.util.spec_from_file_location("c_blosc_amd_multigpu", os.path.join(ROOT, "c-blosc_amd", "multigpu.py"))
-    rig.multigpu = importlib.util.module_from_spec(mspec)
-    mspec.loader.exec_module(rig.multigpu)
+    rig.multigpu = _load_multigpu()
     assert rig.lib.blosc_gpu_set_device(local) == 0
 
     per_gpu = args.chunks or (128 if world == 1 else 512)

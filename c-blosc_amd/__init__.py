@@ -27,6 +27,7 @@ STOCK_SYMBOLS = [
 GPU_SYMBOLS = [
     "blosc_gpu_set_device", "blosc_gpu_compress_batch", "blosc_gpu_decompress_batch", "blosc_gpu_getitem",
     "blosc_gpu_compress_batch_host", "blosc_gpu_decompress_batch_host",
+    "blosc_gpu_device_count", "blosc_gpu_partition", "blosc_gpu_compress_batch_multi", "blosc_gpu_decompress_batch_multi",
     "blosc_gpu_profile", "blosc_gpu_profile_reset", "blosc_gpu_profile_get",
 ]
 
@@ -75,6 +76,10 @@ def load():
                                              C.POINTER(i), vp]
     L.blosc_gpu_compress_batch_host.argtypes = [i, i, sz, C.c_char_p, sz, i, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.POINTER(i)]
     L.blosc_gpu_decompress_batch_host.argtypes = [i, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.POINTER(i)]
+    L.blosc_gpu_partition.argtypes = [sz, i, i, C.POINTER(sz), C.POINTER(sz)]
+    L.blosc_gpu_compress_batch_multi.argtypes = [i, C.POINTER(i), i, i, sz, C.c_char_p, sz, i, C.POINTER(vp), C.POINTER(sz),
+                                                 C.POINTER(vp), C.POINTER(sz), C.POINTER(i)]
+    L.blosc_gpu_decompress_batch_multi.argtypes = [i, C.POINTER(i), i, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.POINTER(i)]
     L.blosc_gpu_getitem.argtypes = [vp, i, i, vp, vp]
     L.blosc_gpu_profile.argtypes = [i]
     L.blosc_gpu_profile.restype = None

@@ -293,6 +293,67 @@ int blosc_gpu_decompress_batch_host(int nchunks, const void* const* src, const s
   return decompress_batch(nchunks, src, srcsize, dest, destsize, nbytes_out, nullptr, false);
 }
 
+// ---- one call, all GPUs of the node (include/blosc_gpu.h) --------------------------------------------
+// The reference's one call fans its blocks out over a pool of worker threads (blosc/blosc.c:904-918 do_job, :871-899
+// parallel_blosc, :1890-1949 init_threads).  Chunks of a batch are independent, so the same shape one level up: the chunk list is
+// cut into contiguous ranges (blosc_gpu_partition = SURVEY 8e's floor(c G / n) rule, the one c-blosc_amd/multigpu.py and
+// bench.py use across processes), one host thread per GPU runs the batched call on its range, bound to its device.
+int blosc_gpu_device_count(void) { return engine_device_count(); }
+int blosc_gpu_partition(size_t nchunks, int world, int rank, size_t* lo, size_t* hi) {
+  if (world <= 0 || rank < 0 || rank >= world || !lo || !hi) return -1;
+  const size_t w = (size_t)world, r = (size_t)rank;
+  size_t l = (r * nchunks + w - 1) / w, h = ((r + 1) * nchunks + w - 1) / w;      // smallest c with floor(c w / nchunks) >= r
+  if (h > nchunks) h = nchunks;
+  *lo = l; *hi = h;
+  return 0;
+}
+struct MultiArg {
+  int dev, rc; bool compress; size_t lo, hi;
+  int clevel, doshuffle; size_t typesize; const char* compressor; size_t blocksize;
+  const void* const* src; const size_t* insize; void* const* dest; const size_t* destsize; int* out;
+};
+static void* multi_worker(void* p) {
+  MultiArg& a = *(MultiArg*)p;
+  a.rc = 0;
+  if (a.hi == a.lo) return nullptr;
+  if (engine_thread_device(a.dev) != 0) { a.rc = -1; return nullptr; }
+  const int n = (int)(a.hi - a.lo);
+  const bool devp = engine_is_device_pointer(a.src[a.lo]);      // a range is either host memory or memory of (or visible to) its GPU
+  if (a.compress) a.rc = compress_batch(a.clevel, a.doshuffle, a.typesize, a.compressor, a.blocksize, n, a.src + a.lo, a.insize + a.lo, a.dest + a.lo,
+                                        a.destsize + a.lo, a.out + a.lo, nullptr, devp);
+  else a.rc = decompress_batch(n, a.src + a.lo, a.insize ? a.insize + a.lo : nullptr, a.dest + a.lo, a.destsize + a.lo, a.out + a.lo, nullptr, devp);
+  (void)engine_thread_device(-1);
+  return nullptr;
+}
+static int run_multi(MultiArg proto, int ndev, const int* devices, int nchunks) {
+  if (nchunks <= 0) return 0;
+  const int have = engine_device_count();
+  if (ndev <= 0 || ndev > 64) return -1;
+  MultiArg args[64];
+  pthread_t th[64];
+  for (int r = 0; r < ndev; r++) {
+    args[r] = proto;
+    args[r].dev = devices ? devices[r] : r;
+    if (args[r].dev < 0 || args[r].dev >= have) { fprintf(stderr, "blosc_amd: multi-GPU call names device %d, this node shows %d\n", args[r].dev, have); return -1; }
+    (void)blosc_gpu_partition((size_t)nchunks, ndev, r, &args[r].lo, &args[r].hi);
+  }
+  int started = 0, rc = 0;
+  for (; started < ndev; started++) if (pthread_create(&th[started], nullptr, multi_worker, &args[started]) != 0) { rc = -1; break; }
+  for (int r = 0; r < started; r++) { pthread_join(th[r], nullptr); if (args[r].rc < 0) rc = args[r].rc; }
+  return rc;
+}
+int blosc_gpu_compress_batch_multi(int ndev, const int* devices, int clevel, int doshuffle, size_t typesize, const char* compressor, size_t blocksize,
+                                   int nchunks, const void* const* src, const size_t* nbytes, void* const* dest, const size_t* destsize, int* cbytes_out) {
+  MultiArg a{}; a.compress = true; a.clevel = clevel; a.doshuffle = doshuffle; a.typesize = typesize; a.compressor = compressor; a.blocksize = blocksize;
+  a.src = src; a.insize = nbytes; a.dest = dest; a.destsize = destsize; a.out = cbytes_out;
+  return run_multi(a, ndev, devices, nchunks);
+}
+int blosc_gpu_decompress_batch_multi(int ndev, const int* devices, int nchunks, const void* const* src, const size_t* srcsize, void* const* dest,
+                                     const size_t* destsize, int* nbytes_out) {
+  MultiArg a{}; a.compress = false; a.src = src; a.insize = srcsize; a.dest = dest; a.destsize = destsize; a.out = nbytes_out;
+  return run_multi(a, ndev, devices, nchunks);
+}
+
 int blosc_gpu_getitem(const void* src, int start, int nitems, void* dest, void* stream) {
   return engine_getitem(src, start, nitems, dest, true, true, (hipStream_t)stream);
 }
@@ -319,6 +380,16 @@ __attribute__((visibility("default"))) void blosc_internal_unshuffle_generic(con
                                                                              const uint8_t* const src, uint8_t* const dest) {
   blosc_internal_unshuffle(typesize, blocksize, src, dest);
 }
+// ... and the names its SSE2 / AVX2 translation units export for tests/test_shuffle_roundtrip_{sse2,avx2}.c (blosc/shuffle-sse2.h:25-32,
+// blosc/shuffle-avx2.h:25-32): there is one implementation here - the HIP kernels
+#define BAMD_SHUFFLE_ALIAS(isa)                                                                                                                  \
+  __attribute__((visibility("default"))) void blosc_internal_shuffle_##isa(const size_t typesize, const size_t blocksize, const uint8_t* const src, \
+                                                                           uint8_t* const dest) { blosc_internal_shuffle(typesize, blocksize, src, dest); } \
+  __attribute__((visibility("default"))) void blosc_internal_unshuffle_##isa(const size_t typesize, const size_t blocksize, const uint8_t* const src, \
+                                                                             uint8_t* const dest) { blosc_internal_unshuffle(typesize, blocksize, src, dest); }
+BAMD_SHUFFLE_ALIAS(sse2)
+BAMD_SHUFFLE_ALIAS(avx2)
+#undef BAMD_SHUFFLE_ALIAS
 __attribute__((visibility("default"))) int blosc_internal_bitshuffle(const size_t typesize, const size_t blocksize,
                                                                      const uint8_t* src, const uint8_t* dest,
                                                                      const uint8_t* tmp) {

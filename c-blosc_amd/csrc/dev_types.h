@@ -56,7 +56,7 @@ struct ChunkDesc {
 #define BAMD_FILT_PAD 0        // measured: no effect (profiles/r03p_dec_ab_plane_padding_no_effect.txt - three copies of each build taking turns; what differs by 10 % is WHICH instance runs, not its layout)
 #endif
 constexpr uint32_t FILT_PLANE_PAD = BAMD_FILT_PAD;
-#if defined(__HIPCC__) || defined(__CUDACC__) || defined(BAMD_WAVE_EMU)
+#if defined(__HIPCC__) || defined(BAMD_WAVE_EMU)
 #define BAMD_HD __host__ __device__
 #else
 #define BAMD_HD
@@ -81,7 +81,6 @@ struct BlockDesc {
   int32_t flags;        // BLK_* bits
 };
 enum : int32_t {
-  BLK_LDS = 1,          // decompress: the block is decoded by k_decode_blocks (one workgroup, LDS-resident planes), not by k_decode_streams
   BLK_Z = 2,            // decompress: a block of a Zstd / zlib chunk: every stream of it belongs to k_zstd_* / k_zlib_streams, k_decode_streams' queues leave it out
   BLK_ZLIB = 4,         // ... of a zlib chunk (set together with BLK_Z): k_zlib_streams has per-XCD queues of its own (queue_order.h)
 };

@@ -40,6 +40,8 @@ int engine_getitem(const void* src, int start, int nitems, void* dest, bool src_
 int engine_filter(int kind, size_t typesize, size_t blocksize, const void* src, void* dst);
 
 int engine_set_device(int dev);      // selects the HIP device for this process (default: current)
+int engine_thread_device(int dev);   // >= 0: the calling THREAD's calls run on this device (multi-GPU entry points); -1: back to the process-wide one
+int engine_device_count();
 void engine_release();               // frees workspace memory (blosc_free_resources / blosc_destroy)
 bool engine_is_device_pointer(const void* p);
 

@@ -20,7 +20,6 @@
 
 #include "k_filters.hip"
 #include "k_decode.hip"
-#include "k_decode_blocks.hip"
 #include "k_encode.hip"
 #include "k_zstd.hip"
 #include "k_zstd2.hip"
@@ -31,7 +30,7 @@ namespace bamd {
 // ---------------------------------------------------------------------------------------------
 // small utilities
 // ---------------------------------------------------------------------------------------------
-static bool g_warned = false;
+static std::atomic<bool> g_warned{false};
 #define HIP_TRY(expr)                                                                             \
   do {                                                                                            \
     hipError_t _e = (expr);                                                                       \
@@ -74,13 +73,13 @@ struct PinnedArena {
 struct ProfEntry { double ms = 0; int launches = 0; };
 
 // per-launch feedback words of the persistent kernels: [0,256) cycles per plane index, [256] tasks taken by the
-// stream kernel, [257] streams taken by the Zstd kernel, [258] blocks taken by k_decode_blocks, [259] streams taken by the
-// Zlib kernel - the host compares them with what it queued
+// stream kernel, [257] streams taken by the Zstd kernel, [259] streams taken by the Zlib kernel - the host compares them with
+// what it queued
 constexpr size_t kCostWords = 264;
-static int check_done(const uint32_t* fb, size_t expect, size_t expect_zstd, const char* what, size_t expect_blocks = 0, size_t expect_zlib = 0) {
-  if (fb[256] == expect && fb[257] == expect_zstd && fb[258] == expect_blocks && fb[259] == expect_zlib) return 0;
-  fprintf(stderr, "blosc_amd: %s: the device took %u of %zu queued tasks (Zstd: %u of %zu, blocks: %u of %zu, Zlib: %u of %zu) - results discarded\n",
-          what, fb[256], expect, fb[257], expect_zstd, fb[258], expect_blocks, fb[259], expect_zlib);
+static int check_done(const uint32_t* fb, size_t expect, size_t expect_zstd, const char* what, size_t expect_zlib = 0) {
+  if (fb[256] == expect && fb[257] == expect_zstd && fb[259] == expect_zlib) return 0;
+  fprintf(stderr, "blosc_amd: %s: the device took %u of %zu queued tasks (Zstd: %u of %zu, Zlib: %u of %zu) - results discarded\n",
+          what, fb[256], expect, fb[257], expect_zstd, fb[259], expect_zlib);
   return -1;
 }
 
@@ -112,7 +111,7 @@ struct EngineState {
 // Contexts (round 3).  blosc_compress_ctx / blosc_decompress_ctx / blosc_getitem are re-entrant in the reference: every call builds
 // a context of its own and callers on different threads run side by side (blosc/blosc.c:1288-1305, :1560-1572, :1618-1690).
 // A call here needs a workspace - arenas, pinned tables, an event pool, the cost feedback of its last batch - and there are
-// ctx_count() of them (BLOSC_AMD_CONTEXTS, default 4, at most 8).  A caller takes the first one that is free, so a single-threaded
+// ctx_count() of them (BLOSC_AMD_CONTEXTS, default and at most 8 - one per GPU of a node for the multi-GPU calls).  A caller takes the first one that is free, so a single-threaded
 // program only ever touches context 0 and never pays for the others; with every context busy a caller queues on one of them in
 // turn.  A host-buffer call that names no stream runs on its context's own non-blocking stream: the staging copies of one caller
 // overlap the kernels of another instead of lining up on the null stream (the PCIe-bound stock ABI is where that pays).
@@ -121,13 +120,17 @@ struct EngineState {
 constexpr int kMaxCtx = 8;
 static EngineState g_ctx[kMaxCtx];
 static std::atomic<int> g_device{-1};      // -1: whatever device is current when the library is first used
+// The device of the CALLING THREAD's calls when >= 0 (engine_thread_device): the multi-GPU entry points run one host thread per
+// GPU inside one process, each bound to its device, without touching the process-wide choice other threads rely on.
+static thread_local int tl_device = -1;
+static int wanted_device() { return tl_device >= 0 ? tl_device : g_device.load(); }
 static std::atomic<bool> g_prof{false};
 static std::atomic<unsigned> g_ctx_turn{0};
 static int ctx_count() {
 #ifdef BAMD_WAVE_EMU
   return 1;                                // the wavefront emulator (tests/tools) runs one launch at a time
 #else
-  static const int n = [] { const char* e = getenv("BLOSC_AMD_CONTEXTS"); int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > kMaxCtx ? kMaxCtx : v); }();
+  static const int n = [] { const char* e = getenv("BLOSC_AMD_CONTEXTS"); int v = e ? atoi(e) : kMaxCtx; return v < 1 ? 1 : (v > kMaxCtx ? kMaxCtx : v); }();
   return n;
 #endif
 }
@@ -135,7 +138,15 @@ struct CtxGuard {                          // owns one context for the duration 
   EngineState* st = nullptr;
   CtxGuard() {
     const int n = ctx_count();
-    for (int i = 0; i < n && !st; i++) if (g_ctx[i].mu.try_lock()) st = &g_ctx[i];
+    // a free context that already lives on the device this thread wants (its arenas stay), else a free one that has no device
+    // yet, else any free one (it moves: ensure_device), else wait for one in turn
+    const int want = wanted_device();
+    for (int pass = 0; pass < 3 && !st; pass++)
+      for (int i = 0; i < n && !st; i++) {
+        if (!g_ctx[i].mu.try_lock()) continue;
+        const bool ok = pass == 2 || (pass == 0 ? (g_ctx[i].device_ok && (want < 0 || g_ctx[i].device == want)) : !g_ctx[i].device_ok);
+        if (ok) st = &g_ctx[i]; else g_ctx[i].mu.unlock();
+      }
     if (!st) { st = &g_ctx[g_ctx_turn.fetch_add(1u) % (unsigned)n]; st->mu.lock(); }
   }
   ~CtxGuard() { st->mu.unlock(); }
@@ -182,22 +193,25 @@ static int ensure_device(EngineState& st) {
   std::call_once(atfork_once, [] { (void)pthread_atfork(atfork_prepare, atfork_parent, atfork_child); });
   // the HIP current device is per host thread: every entry point (they all come through here, holding a
   // context) re-selects the engine's device for the calling thread
-  const int want_dev = g_device.load();
+  const int want_dev = wanted_device();
   if (st.device_ok && (want_dev < 0 || want_dev == st.device)) { HIP_TRY(hipSetDevice(st.device)); return 0; }
   if (st.device_ok) {                      // the process moved to another device (engine_set_device through another context)
-    st.dev.release(); st.io.release();     // arenas belong to the device they were allocated on
+    (void)hipSetDevice(st.device);
+    st.dev.release(); st.io.release();     // arenas, stream and events belong to the device they were created on
     if (st.own) { (void)hipStreamDestroy(st.own); st.own = nullptr; }
+    for (auto& p : st.prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    st.prof_pending.clear();
+    for (hipEvent_t e : st.ev_pool) (void)hipEventDestroy(e);
+    st.ev_pool.clear();
     st.device_ok = false;
   }
   st.device = want_dev;
   int cnt = 0;
   hipError_t e = hipGetDeviceCount(&cnt);
   if (e != hipSuccess || cnt <= 0) {
-    if (!g_warned) {
+    if (!g_warned.exchange(true))
       fprintf(stderr, "blosc_amd: no usable HIP device (%s); this library has no CPU path\n",
               e == hipSuccess ? "device count 0" : hipGetErrorString(e));
-      g_warned = true;
-    }
     return -1;
   }
   if (st.device >= 0) HIP_TRY(hipSetDevice(st.device));
@@ -221,7 +235,8 @@ struct HostTime { double t[2][6] = {}; long calls[2] = {}; };
 static HostTime g_ht;
 static bool hosttime_on() { static const bool on = getenv("BLOSC_AMD_HOSTTIME") && atoi(getenv("BLOSC_AMD_HOSTTIME")) != 0; return on; }
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-#define HT_MARK(dir, i) do { if (hosttime_on()) { const double t_ = now_ms(); g_ht.t[dir][i] += t_ - ht_last; ht_last = t_; } } while (0)
+static std::mutex g_ht_mu;     // several contexts run at once: the accumulators are shared
+#define HT_MARK(dir, i) do { if (hosttime_on()) { const double t_ = now_ms(); { std::lock_guard<std::mutex> l_(g_ht_mu); g_ht.t[dir][i] += t_ - ht_last; } ht_last = t_; } } while (0)
 struct ProfScope {
   EngineState& st; hipStream_t s; const char* name; hipEvent_t a{}, b{}; bool on;
   ProfScope(EngineState& st_, hipStream_t s_, const char* n) : st(st_), s(s_), name(n), on(g_prof.load(std::memory_order_relaxed)) {
@@ -271,11 +286,6 @@ static dim3 grid1(size_t n, int per) { return dim3((unsigned)((n + per - 1) / pe
 // running it as work of the encode / decode kernels
 // BLOSC_AMD_SPANS=0: decoded periodic planes go through the scratch like every other plane
 static bool span_enabled() { static const bool on = !(getenv("BLOSC_AMD_SPANS") && atoi(getenv("BLOSC_AMD_SPANS")) == 0); return on; }
-// BLOSC_AMD_BLOCKDEC=1: split byte-shuffled LZ4 blocks are decoded by k_decode_blocks (one workgroup per block, planes
-// in LDS rings, no scratch image in HBM) instead of k_decode_streams.  Off by default: it moves a third of the bytes
-// but its concurrency is bound by LDS (8 KiB of ring per plane with real LZ work) and it is slower on every SURVEY §8d
-// data set so far (profiles/r02_b_block_decoder.md); the whole GPU suite passes with it on (tests/test_gpu_modes.py).
-static bool blockdec_enabled() { static const bool on = getenv("BLOSC_AMD_BLOCKDEC") && atoi(getenv("BLOSC_AMD_BLOCKDEC")) != 0; return on; }
 // BLOSC_AMD_PERIODIC=0: every plane goes through the match finder (A/B switch for the periodic-plane shortcut of the fused shuffle)
 #ifndef BAMD_LZ4HC_DEFAULT
 #define BAMD_LZ4HC_DEFAULT 1   // "lz4hc" without BLOSC_AMD_LZ4HC in the environment: 1 = LZ4HC-grade search, 0 = plain LZ4 match finder
@@ -316,7 +326,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   EngineState& st = *ctx.st;
   if (ensure_device(st) || call_stream(st, !device_ptrs, &stream)) return -1;
 
-  double ht_last = hosttime_on() ? now_ms() : 0.0; if (hosttime_on()) g_ht.calls[0]++;
+  double ht_last = hosttime_on() ? now_ms() : 0.0; if (hosttime_on()) { std::lock_guard<std::mutex> l_(g_ht_mu); g_ht.calls[0]++; }
   std::vector<ChunkDesc> chunks((size_t)n);
   std::vector<BlockDesc> blocks;
   std::vector<StreamDesc> streams;
@@ -682,30 +692,8 @@ struct DecodeLaunch {
   const int32_t* d_qlist; const int32_t* d_qoff;   // per-XCD stream queues
   size_t nblk, nstr; int nchunks;
   bool any_shuf, any_bit, any_copy; int tiles_shuf, tiles_bit;
-  // k_decode_blocks: per typesize group g (0: 4, 1: 8) the candidate blocks, the two lists k_classify_blocks sorts them
-  // into (2 x nlist[g] entries), counters cnt[2g + v] / tickets [4 + 2g + v] in d_bctl, one far area per workgroup
-  const int32_t* d_bcand[2]; int32_t* d_blists[2]; uint32_t nlist[2]; uint32_t* d_bctl; uint32_t* d_skind; uint8_t* d_far; size_t far_stride;
   size_t nstr_queued;                              // streams left to k_decode_streams
 };
-
-// Marks the blocks k_decode_blocks takes (split byte-shuffled LZ4 blocks of fused chunks, typesize 4 or 8) and lists
-// them per typesize; returns the far-area bytes one workgroup needs.
-static size_t pick_lds_blocks(const std::vector<ChunkDesc>& chunks, std::vector<BlockDesc>& blocks, std::vector<int32_t> list[2], size_t* nstr_lds) {
-  size_t far = 0; *nstr_lds = 0;
-  if (!blockdec_enabled()) return 0;
-  for (size_t g = 0; g < blocks.size(); g++) {
-    BlockDesc& b = blocks[g];
-    const ChunkDesc& c = chunks[(size_t)b.chunk];
-    if (!(c.mode & CH_FUSED_UNSHUF) || c.fmt != FMT_LZ4) continue;
-    const int T = c.typesize;
-    if ((T != 4 && T != 8) || b.nstreams != T || b.bsize % T || b.bsize / T < 256) continue;
-    b.flags |= BLK_LDS;
-    list[T == 8].push_back((int32_t)g);
-    *nstr_lds += (size_t)T;
-    if ((size_t)b.bsize > far) far = (size_t)b.bsize;
-  }
-  return align_up(far, 256);
-}
 
 static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t stream) {
   if (L.nblk) {
@@ -734,46 +722,6 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
 #else
       hipLaunchKernelGGL(k_decode_streams, dgrid, dim3(64 * DEC_WAVES), (size_t)dec_lds, stream, L.d_streams, L.d_status, L.d_ticket, L.d_qlist, L.d_qoff, L.d_chunks, L.d_blocks, L.d_blkdone, L.d_spans, L.d_pat, L.d_cost, st.single_queue ? 1 : 0);
 #endif
-    }
-    for (int g = 0; g < 2; g++) {
-      if (!L.nlist[g]) continue;
-      {
-        ProfScope ps(st, stream, "k_classify_blocks");
-        hipLaunchKernelGGL(k_classify_blocks, grid1(L.nlist[g], 64), dim3(64), 0, stream, L.d_streams, L.d_blocks, L.d_bcand[g], L.nlist[g], L.d_skind,
-                           L.d_blists[g], L.d_bctl + 2 * g);
-      }
-      // the lists are filled on the device: both variants get a full persistent grid (workgroups of an empty list leave at once)
-      for (int v = 0; v < (g ? 2 : 1); v++) {
-        ProfScope ps(st, stream, v ? "k_decode_blocks8" : "k_decode_blocks");   // 4 / 8 waves per block (<= 4 / more planes with real LZ work)
-        const int W = v ? 8 : 4;
-        const unsigned grid = (unsigned)std::min<size_t>((size_t)st.cus * (W == 4 ? BD_WG4_PER_CU : BD_WG8_PER_CU), L.nlist[g]);
-        uint32_t* d_prof = nullptr;
-#ifdef BAMD_PROFILE_DECODE
-        const size_t profn = (size_t)grid * W * 16;
-        if (getenv("BLOSC_AMD_BD_PROFILE")) { (void)hipMalloc((void**)&d_prof, profn * 4); (void)hipMemsetAsync(d_prof, 0, profn * 4, stream); }
-#define BD_PROF_ARG , d_prof
-#else
-#define BD_PROF_ARG
-#endif
-        const int32_t* lst = L.d_blists[g] + (size_t)v * L.nlist[g];
-        uint32_t* tick = L.d_bctl + 4 + 2 * g + v;
-        const uint32_t* cnt = L.d_bctl + 2 * g + v;
-        if (g == 0) hipLaunchKernelGGL((k_decode_blocks<4, 4>), dim3(grid), dim3(256), 0, stream, L.d_streams, L.d_skind, L.d_status, tick, lst, cnt, L.d_chunks, L.d_blocks, L.d_far, L.far_stride, L.d_cost + 258 BD_PROF_ARG);
-        else if (v == 0) hipLaunchKernelGGL((k_decode_blocks<8, 4>), dim3(grid), dim3(256), 0, stream, L.d_streams, L.d_skind, L.d_status, tick, lst, cnt, L.d_chunks, L.d_blocks, L.d_far, L.far_stride, L.d_cost + 258 BD_PROF_ARG);
-        else hipLaunchKernelGGL((k_decode_blocks<8, 8>), dim3(grid), dim3(512), 0, stream, L.d_streams, L.d_skind, L.d_status, tick, lst, cnt, L.d_chunks, L.d_blocks, L.d_far, L.far_stride, L.d_cost + 258 BD_PROF_ARG);
-#undef BD_PROF_ARG
-#ifdef BAMD_PROFILE_DECODE
-        if (d_prof) {
-          std::vector<uint32_t> h(profn);
-          (void)hipStreamSynchronize(stream);
-          (void)hipMemcpy(h.data(), d_prof, profn * 4, hipMemcpyDeviceToHost);
-          char nm[512]; snprintf(nm, sizeof nm, "%s.T%dW%d", getenv("BLOSC_AMD_BD_PROFILE"), g ? 8 : 4, W);
-          FILE* f = fopen(nm, "wb");
-          if (f) { fwrite(h.data(), 4, h.size(), f); fclose(f); }
-          (void)hipFree(d_prof);
-        }
-#endif
-      }
     }
     // single-block frames through k_zstd_entropy (16 frames per wave) + k_zstd_exec (zstd2_mode above); every other frame
     // shape is left to k_zstd_streams
@@ -870,7 +818,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   EngineState& st = *ctx.st;
   if (ensure_device(st) || call_stream(st, !device_ptrs, &stream)) return -1;
 
-  double ht_last = hosttime_on() ? now_ms() : 0.0; if (hosttime_on()) g_ht.calls[1]++;
+  double ht_last = hosttime_on() ? now_ms() : 0.0; if (hosttime_on()) { std::lock_guard<std::mutex> l_(g_ht_mu); g_ht.calls[1]++; }
   std::vector<Header> hdrs;
   if (fetch_headers(st, n, jobs, device_ptrs, stream, hdrs)) return -1;
   HT_MARK(1, 0);     // header gather (kernel + copy + sync)
@@ -901,11 +849,6 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
     if (!device_ptrs) { io_src = align_up(io_src, 256) + (size_t)c.cbytes; io_dst = align_up(io_dst, 256) + (size_t)c.nbytes; }
   }
   const size_t nblk = blocks.size();
-  std::vector<int32_t> blist[2];
-  size_t nstr_lds = 0;
-  const size_t far_stride = pick_lds_blocks(chunks, blocks, blist, &nstr_lds);
-  const size_t far_wgs = (size_t)st.cus * BD_WG4_PER_CU;         // most workgroups any variant launches
-
   Carver cv;
   const size_t o_chunks = cv.take(sizeof(ChunkDesc) * (size_t)n);
   const size_t o_blocks = cv.take(sizeof(BlockDesc) * (nblk ? nblk : 1));
@@ -913,9 +856,6 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   const size_t o_status = cv.take(sizeof(int32_t) * (size_t)n + 64 + sizeof(uint32_t) * (nblk ? nblk : 1));   // + 8 tickets + per-block arrival counters
   const size_t o_queues = cv.take(sizeof(int32_t) * (9 + (nstr ? nstr : 1)));
   const size_t o_zqueues = cv.take(sizeof(int32_t) * (9 + (nstr ? nstr : 1)));      // k_zlib_streams' queues
-  const size_t nbl = blist[0].size() + blist[1].size();
-  const size_t o_blist = cv.take(sizeof(int32_t) * (3 * nbl + 1) + 64);   // counters + tickets | per group: candidates, two sorted lists
-  const size_t o_skind = cv.take(sizeof(uint32_t) * (nstr ? nstr : 1));
   const size_t o_cost = cv.take(sizeof(uint32_t) * kCostWords);
   const size_t o_spans = cv.take(8 * (nstr ? nstr : 1));
   const size_t o_pat = cv.take(span_enabled() ? (size_t)2048 * (nstr ? nstr : 1) : 256);
@@ -928,7 +868,6 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   static const bool zctab_on = !(getenv("BLOSC_AMD_ZSTD_CTAB") && atoi(getenv("BLOSC_AMD_ZSTD_CTAB")) == 0);      // 0: k_zstd_seq reads the 32-bit tables (A/B switch)
   const bool use_zctab = L.any_zstd && zstd2_mode() == 2 && zctab_on && BAMD_ZSTD_SEQ_KERNEL && !BAMD_ZSTD_LDS_FSE;
   const size_t o_zctab = cv.take(use_zctab ? sizeof(ZcTab) * (nstr ? nstr : 1) : 64);
-  const size_t o_far = cv.take(far_stride ? far_stride * far_wgs : 256);
   if (st.dev.ensure(cv.off)) return -1;
   uint8_t* D = st.dev.base;
   uint8_t *io_s = nullptr, *io_d = nullptr;
@@ -962,16 +901,11 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   const size_t p_queues = pc.take(sizeof(int32_t) * queues.size());
   const size_t p_zqueues = pc.take(sizeof(int32_t) * (zqueues.size() + 1));
   const size_t p_cost = pc.take(sizeof(uint32_t) * kCostWords);
-  const size_t p_blist = pc.take(sizeof(int32_t) * (nbl + 1) + 64);
   if (st.pin.ensure(pc.off)) return -1;
   uint8_t* P = st.pin.base;
   memcpy(P + p_chunks, chunks.data(), sizeof(ChunkDesc) * (size_t)n);
   if (nblk) memcpy(P + p_blocks, blocks.data(), sizeof(BlockDesc) * nblk);
   memcpy(P + p_queues, queues.data(), sizeof(int32_t) * queues.size());
-  memset(P + p_blist, 0, 64);
-  if (!blist[0].empty()) memcpy(P + p_blist + 64, blist[0].data(), sizeof(int32_t) * blist[0].size());
-  if (!blist[1].empty()) memcpy(P + p_blist + 64 + sizeof(int32_t) * blist[0].size(), blist[1].data(), sizeof(int32_t) * blist[1].size());
-  HIP_TRY(hipMemcpyAsync(D + o_blist, P + p_blist, sizeof(int32_t) * nbl + 64, hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemcpyAsync(D + o_chunks, P + p_chunks, sizeof(ChunkDesc) * (size_t)n, hipMemcpyHostToDevice, stream));
   if (nblk) HIP_TRY(hipMemcpyAsync(D + o_blocks, P + p_blocks, sizeof(BlockDesc) * nblk, hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemcpyAsync(D + o_queues, P + p_queues, sizeof(int32_t) * queues.size(), hipMemcpyHostToDevice, stream));
@@ -996,12 +930,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   L.d_zgscr = (L.any_zstd && zstd2_mode() == 2) ? (ZgLds*)(D + o_zgscr) : nullptr;
   L.d_zctab = use_zctab ? (ZcTab*)(D + o_zctab) : nullptr;
   L.nblk = nblk; L.nstr = nstr; L.nchunks = n;
-  L.d_bctl = (uint32_t*)(D + o_blist);
-  L.d_bcand[0] = (const int32_t*)(D + o_blist + 64); L.d_bcand[1] = L.d_bcand[0] + blist[0].size();
-  L.d_blists[0] = (int32_t*)(D + o_blist + 64) + nbl; L.d_blists[1] = L.d_blists[0] + 2 * blist[0].size();
-  L.d_skind = (uint32_t*)(D + o_skind);
-  L.nlist[0] = (uint32_t)blist[0].size(); L.nlist[1] = (uint32_t)blist[1].size();
-  L.d_far = D + o_far; L.far_stride = far_stride; L.nstr_queued = nstr - nstr_lds - nstr_z;
+  L.nstr_queued = nstr - nstr_z;
   HT_MARK(1, 2);     // tables, queues, uploads
   if (launch_decode(st, L, stream)) return -1;
   HIP_TRY(hipMemcpyAsync(P + p_status, D + o_status, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, stream));
@@ -1010,7 +939,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   HIP_TRY(hipStreamSynchronize(stream));
   HT_MARK(1, 4);     // waiting for the device
   prof_collect(st);
-  if (nblk && check_done((const uint32_t*)(P + p_cost), nstr - nstr_lds - nstr_z, L.any_zstd ? nstr : 0, "decompress", blist[0].size() + blist[1].size(), nstr_zlib)) return -1;
+  if (nblk && check_done((const uint32_t*)(P + p_cost), nstr - nstr_z, L.any_zstd ? nstr : 0, "decompress", nstr_zlib)) return -1;
   if (nstr >= 4096) { memcpy(st.dec_cost, P + p_cost, sizeof st.dec_cost); st.dec_cost_valid = true; }
   const int32_t* stt = (const int32_t*)(P + p_status);
   for (int i = 0; i < n; i++) {
@@ -1135,7 +1064,7 @@ int engine_getitem(const void* src, int start, int nitems, void* dest, bool src_
   HIP_TRY(hipMemcpyAsync(P + p_cost, D + o_cost, sizeof(uint32_t) * kCostWords, hipMemcpyDeviceToHost, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   prof_collect(st);
-  if (check_done((const uint32_t*)(P + p_cost), L.nstr_queued, L.any_zstd ? nstr : 0, "getitem", 0, L.any_zlib ? nstr : 0)) return -1;
+  if (check_done((const uint32_t*)(P + p_cost), L.nstr_queued, L.any_zstd ? nstr : 0, "getitem", L.any_zlib ? nstr : 0)) return -1;
   const int32_t stt = *(const int32_t*)(P + p_status);
   if (stt < 0) return stt;                                                        // blosc.c:1689-1692: blosc_d's code is returned as is
   HIP_TRY(hipMemcpyAsync(dest, D + o_out + (size_t)(lo - (int64_t)j0 * bs), want, out_kind, stream));
@@ -1208,6 +1137,15 @@ int engine_set_device(int dev) {
   CtxGuard ctx;
   return ensure_device(*ctx.st);
 }
+
+// Binds the calling thread's calls to `dev` (-1: back to the process-wide device).  Used by the multi-GPU entry points
+// (blosc_api.hip: one host thread per GPU); a context that lives on `dev` is preferred, so every GPU keeps its own arenas.
+int engine_thread_device(int dev) {
+  if (dev >= 0) { int cnt = 0; if (hipGetDeviceCount(&cnt) != hipSuccess || dev >= cnt) return -1; }
+  tl_device = dev;
+  return 0;
+}
+int engine_device_count() { int cnt = 0; if (hipGetDeviceCount(&cnt) != hipSuccess) { (void)hipGetLastError(); return 0; } return cnt; }
 
 void engine_release() {
   if (hosttime_on()) {

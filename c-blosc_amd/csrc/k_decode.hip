@@ -4,10 +4,11 @@
 // Replaces  blosc_d's split loop (blosc/blosc.c:760-787) and the codecs it calls:
 //   LZ4_decompress_safe   (internal-complibs/lz4-1.10.0/lz4.c:2451 -> LZ4_decompress_generic :2023-2445)
 //   blosclz_decompress    (blosc/blosclz.c:679-789)
-// One wavefront decodes one stream (= one split of one block).  The sequence parse is a scalar
-// (SGPR) program over a 512-byte register window of the compressed bytes; literal and match bytes
-// move with all 64 lanes.  Output goes straight to global memory (the plane-major scratch, or the
-// destination when the chunk has no filter); history reads hit L1/L2.
+// One wavefront decodes one stream (= one split of one block).  LZ4 (dec_ring.h, round 4): the wave's recent
+// output lives in an LDS ring, sequences are parsed and executed 16 at a time out of LDS, complete 1 KiB rows
+// leave for global memory (the plane-major scratch, or the destination when the chunk has no filter) as
+// coalesced stores nobody waits for.  BloscLZ (below): a 512-byte register window over the compressed bytes,
+// output straight to global memory.
 //
 // Algorithmic HBM bytes per stream: csize read + neblock written.
 #include <hip/hip_runtime.h>
@@ -60,28 +61,7 @@ __global__ void k_decode_plan(const ChunkDesc* __restrict__ chunks, const BlockD
   if (bad) atomicMin(&status[b.chunk], (int32_t)ST_BADCHAIN);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Batched LZ4 step: decode up to 16 consecutive sequences whose tokens, literals, offsets (and at most
-// one match-length extension byte) all lie in the 64 stream bytes starting at `ip`.
-//
-//   1. every lane l treats stream byte ip+l as if it were a token and works out where the next token
-//      would be (speculative parse, pure VALU + cross-lane reads of the 64 window bytes);
-//   2. a scalar walk follows that next-token chain from lane 0 (ip is a real token by invariant), which
-//      marks the real tokens, ranks them and prefix-sums their output sizes;
-//   3. literal bytes of ALL accepted sequences go out with one scattered byte store;
-//   4. matches that are short (<= 24 bytes) and whose source lies entirely before the step's output
-//      ("independent") are copied by 4 lanes per sequence with overlapping 4/8-byte pieces — one or two
-//      gathers, one or two scatters for up to 16 matches;
-//   5. the remaining matches (long, or reading bytes this very step produces) run in stream order
-//      through wave_match_copy with their fields already parsed.
-// Same-wave memory ordering (wave_prims.h) makes 3 -> 4 -> 5 safe without waits.
-//
-// The caller guarantees ip + 72 <= n (so no accepted sequence can be the stream's final one and the
-// input-side rule "literals end >= 8 bytes before the input end", lz4.c:2279, holds) and has done
-// w.seek(ip).  Output-side rules (lz4.c:2279, :2423) and offset validity are checked per sequence in
-// the walk; a sequence that breaks one is simply not accepted, so the scalar path re-parses it and
-// reports the error exactly as before.  Returns the number of sequences done (0: nothing accepted).
-// ---------------------------------------------------------------------------------------------
+// most sequences one batched step takes (dec_ring.h: dr_step; blz_batch_step below)
 constexpr uint32_t BATCH_MAXSEQ = 16;
 
 // Optional phase profiling (build with -DBAMD_PROFILE_DECODE -> libblosc_amd_prof.so, scripts/dec_phase.py):
@@ -188,420 +168,17 @@ __device__ __forceinline__ bool span_long_match(gu8* out, uint32_t mpos, uint32_
   if (!sp.enabled || sp.hi || ml < 16384u || off > (BAMD_SELFSPAN ? 65536u : SPAN_PAT) || (off & (off - 1u))) return false;
   const uint32_t lo = (mpos + 1023u) & ~1023u, hi = (mpos + ml) & ~1023u;
   if (hi < lo + 8192u) return false;
+  // a self span's base travels in 24 bits next to log2(period) (unshuffle_block_wave_T: `ob`): planes of 16 MiB and more (typesize 2 with
+  // blocks >= 32 MiB) keep such a match in the scratch instead (the base was truncated, silently wrong bytes)
+  if (off > SPAN_PAT && mpos >= (1u << 24)) return false;
   span_long_match_call(out, mpos, off, ml, lane, sp.pat);
   sp.lo = lo; sp.hi = hi; sp.off = off;
   return true;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Dependent near matches of a step, resolved in LDS.  Bit-shuffled data decodes into streams whose matches reach back a few
-// dozen bytes (reference-written config #3 chunks: median distance 44): the source of sequence r of a step lies in the output
-// of sequences r-1, r-2 of the SAME step, so 9 in 10 matches took the in-order path - one store -> load round trip through
-// memory each (2300 cycles; 75 % of that kernel's time).  When a step has two or more such matches and all of them start at
-// most LZB_HIST bytes before the step's output, the step is assembled in an LDS buffer instead: the history bytes come in
-// with ONE load (in flight together with the loads of the independent matches), literals and independent matches are written
-// to the buffer as well as to memory, and the dependent matches become LDS copies in stream order - a match whose distance
-// is shorter than its length is the periodic extension of the bytes before it, so every lane reads only bytes that are
-// already final - whose values the lanes also store to memory.  No round trip between them.
-// ---------------------------------------------------------------------------------------------
-constexpr uint32_t LZB_HIST = 1024u, LZB_STEP = 2048u, LZB_BYTES = LZB_HIST + LZB_STEP + 128u;   // LDS bytes per wave behind the 64 scratch dwords
-#ifndef BAMD_DEC_LDS_STEP
-#define BAMD_DEC_LDS_STEP 1
-#endif
-#ifndef BAMD_LZB_MIN_REST
-#define BAMD_LZB_MIN_REST 4     // dependent matches a step needs before the LDS form pays (2: BloscLZ byte-shuffled bench19 +8 %, see profiles/r02g_lds_step.txt)
-#endif
-constexpr int LZB_MIN_REST = BAMD_LZB_MIN_REST;
-#ifndef BAMD_LZB_RCP
-#define BAMD_LZB_RCP 1          // lz4_step_lds: k mod o with a float reciprocal per lane instead of a scalar integer division per match
-#endif
-typedef volatile __attribute__((address_space(3))) uint8_t lds_u8;
-template <int N>
-__device__ __forceinline__ uint32_t row_max16(uint32_t v) {     // maximum over the 16 lanes of a DPP row, valid in lane 15 of the row
-  uint32_t t;
-  t = row_shr<1>(v); v = t > v ? t : v; t = row_shr<2>(v); v = t > v ? t : v;
-  t = row_shr<4>(v); v = t > v ? t : v; t = row_shr<8>(v); v = t > v ? t : v;
-  return v;
-}
-
-// the LDS-assembled form of steps 3-5 of lz4_batch_step (a real call: the common step must not pay for its registers).  fast_r / rest_r: this lane's sequence is an independent short match / a match that has to run in stream order.
-__device__ __attribute__((noinline)) void lz4_step_lds(gu8* out_, volatile uint32_t* scr_generic, uint32_t B, uint32_t c, uint32_t excl, uint32_t ll_r, uint32_t ml_r,
-                                                       uint32_t off_r, uint32_t mrel_r, uint32_t ext_r, bool fast_r, bool rest_r, uint32_t cnt_, uint32_t consumed_, uint32_t op_, uint32_t H_, int lane) {
-  volatile __attribute__((address_space(3))) uint32_t* scr = (volatile __attribute__((address_space(3))) uint32_t*)scr_generic;   // LDS
-  gu8* out = uni_ptr(out_);
-  const uint32_t cnt = uni(cnt_), consumed = uni(consumed_), op = uni(op_), H = uni(H_);
-  const bool use_lds = true;
-  lds_u8* lb = (lds_u8*)(scr + 64);
-  uint4 hv = make_uint4(0, 0, 0, 0);
-  const bool h16 = 16u * (uint32_t)lane + 16u <= H;
-  if (h16) hv = g_ld16(out + op - H + 16u * (uint32_t)lane);                           // history: one load, with the ones below
-  // ---- 3. literals: token info goes back to byte-lane space through a 64-dword LDS scratch, then one
-  //         scattered byte store covers the literals of every accepted sequence ----
-  // (volatile: lanes talk to each other through this scratch; without it the compiler forwards a lane's
-  //  own "= 0" store to its later load, which is legal for unsynchronised memory and wrong here)
-  // scratch word of a token: valid | length-extension flag << 25 | literal count << 16 | output offset (< 2^16: 16 x 542)
-  scr[lane] = 0u;
-  BAMD_LDS_SYNC();
-  if ((uint32_t)lane < cnt) scr[c] = 0x80000000u | excl | (ll_r << 16) | (ext_r << 25);
-  BAMD_LDS_SYNC();
-  const uint64_t mask = __ballot(scr[lane] >> 31);
-  {
-    const uint64_t below = mask & ((2ull << lane) - 1ull);     // accepted tokens at or before this byte lane
-    const uint32_t s = 63u - (uint32_t)__builtin_clzll(below | 1ull);
-    const uint32_t inf = scr[s];
-    const uint32_t k = (uint32_t)lane - s - 1u - ((inf >> 25) & 1u);
-    if ((uint32_t)lane < consumed && (uint32_t)lane > s + ((inf >> 25) & 1u) && k < ((inf >> 16) & 0x1ffu)) {
-      out[op + (inf & 0xffffu) + k] = (uint8_t)B;
-      if (use_lds) lb[H + (inf & 0xffffu) + k] = (uint8_t)B;
-    }
-  }
-  // ---- 4. short independent matches: 4 lanes per sequence, overlapping 4/8/16-byte pieces ----
-  {
-    const uint32_t r = (uint32_t)lane >> 2, q = (uint32_t)lane & 3u;
-    const uint32_t fA = bperm(r, fast_r ? (ml_r | 0x200u | (mrel_r << 10)) : 0u);
-    const uint32_t fB = bperm(r, off_r);
-    const uint32_t mlen = fA & 0x1ffu;
-    const bool go = (fA & 0x200u) != 0u;
-    gu8* d = out + op + (fA >> 10);
-    const gu8* sp = d - fB;
-    const bool w16 = go && mlen >= 16u && q < ((mlen + 15u) >> 4);
-    const bool w8 = go && mlen >= 8u && mlen < 16u && q < 2u;
-    const bool w4 = go && mlen < 8u && q < 2u;
-    const uint32_t np16 = (mlen + 15u) >> 4;
-    const uint32_t po16 = (q == np16 - 1u) ? mlen - 16u : 16u * q;
-    const uint32_t po8 = q ? mlen - 8u : 0u, po4 = q ? mlen - 4u : 0u;
-    uint4 v16 = make_uint4(0, 0, 0, 0); uint64_t v8 = 0; uint32_t v4 = 0;
-    if (w16) v16 = g_ld16(sp + po16);
-    if (w8) v8 = g_ld8(sp + po8);
-    if (w4) v4 = g_ld4(sp + po4);
-    if (w16) g_st16(d + po16, v16);
-    if (w8) *(BAMD_GAS u64una*)(d + po8) = v8;
-    if (w4) g_st4(d + po4, v4);
-    if (use_lds) {                                     // the same pieces into the step buffer (byte-unaligned LDS stores: fine on gfx950)
-      lds_u8* l = lb + H + (fA >> 10);
-      if (w16) { v4u32 t = {v16.x, v16.y, v16.z, v16.w}; *(volatile __attribute__((address_space(3))) v4u32_una*)(l + po16) = t; }
-      if (w8) *(volatile __attribute__((address_space(3))) u64una*)(l + po8) = v8;
-      if (w4) *(volatile __attribute__((address_space(3))) u32una*)(l + po4) = v4;
-    }
-  }
-  if (use_lds) {
-    if (h16) { v4u32 t = {hv.x, hv.y, hv.z, hv.w}; *(volatile __attribute__((address_space(3))) v4u32_una*)(lb + 16u * (uint32_t)lane) = t; }
-    const uint32_t hfull = H & ~15u;                   // H < 16-multiple only when op itself is small
-    if (hfull + (uint32_t)lane < H) lb[hfull + (uint32_t)lane] = out[op - H + hfull + (uint32_t)lane];
-  }
-  // ---- 5. everything else (long, or reading bytes this very step produces), in stream order ----
-  uint32_t rest = (uint32_t)__ballot(rest_r);
-  while (rest) {
-    const int sl = __builtin_ctz(rest);
-    rest &= rest - 1u;
-    const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)ml_r, sl);
-    const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)off_r, sl);
-    const uint32_t mr = (uint32_t)__builtin_amdgcn_readlane((int)mrel_r, sl);
-    {
-      // periodic extension of the o bytes before the match (o >= m: a plain copy); floor(k / o) by multiplication - exact for
-      // k < 512 because the quotient is only needed when o < m <= 273
-#if BAMD_LZB_RCP
-      const float ro = o < m ? __builtin_amdgcn_rcpf((float)o) : 0.0f;       // k mod o per lane (k_zstd.hip: zstd_exec16_lds has the story: the integer division was 23 scalar instructions per match)
-#else
-      const uint32_t M = o < m ? (1u << 20) / o + 1u : 0u;
-#endif
-      for (uint32_t k = (uint32_t)lane; k < m; k += 64u) {
-#if BAMD_LZB_RCP
-        uint32_t kk = k;
-        if (o < m) { kk = k - (uint32_t)((float)k * ro) * o; kk = kk >= o ? kk - o : kk; }
-#else
-        const uint32_t kk = o < m ? k - ((k * M) >> 20) * o : k;
-#endif
-        const uint8_t v = lb[H + mr - o + kk];
-        lb[H + mr + k] = v;
-        out[op + mr + k] = v;
-      }
-    }
-  }
-}
-
-__device__ __forceinline__ uint32_t lz4_batch_step(const Window& w, gu8* out, volatile uint32_t* scr_generic, uint32_t& ip, uint32_t& op,
-                                                   uint32_t cap, uint32_t n, int lane, SpanCtx& sp PROF_ARG) {
-  volatile __attribute__((address_space(3))) uint32_t* scr = (volatile __attribute__((address_space(3))) uint32_t*)scr_generic;   // LDS
-  const uint32_t B = w.gather_bytes(ip);                       // stream byte ip + lane
-  // ---- 1. speculative parse: every lane reads "its" byte as a token ----
-  // A literal length of 15 takes ONE extension byte here (runs of 15 .. 269 bytes, as long as they end inside the 64
-  // bytes): on bench19 those are 3 % of the sequences but were a third of the memory round trips when each of them
-  // went through the scalar path.
-  const uint32_t ll0 = B >> 4, mlc = B & 15u;
-  const uint32_t e_ll = bperm(((uint32_t)lane + 1u) & 63u, B);
-  const bool ll_ext = ll0 == 15u;
-  const uint32_t ll = ll_ext ? 15u + e_ll : ll0;
-  const uint32_t offpos = (uint32_t)lane + 1u + (ll_ext ? 1u : 0u) + ll;   // where this token's offset would start
-  const uint32_t o_lo = bperm(offpos & 63u, B), o_hi = bperm((offpos + 1u) & 63u, B), e1 = bperm((offpos + 2u) & 63u, B);
-  const bool has_ext = mlc == 15u;
-  const uint32_t ml = has_ext ? 19u + e1 : mlc + 4u;           // <= 273
-  const uint32_t size = 3u + ll + (has_ext ? 1u : 0u) + (ll_ext ? 1u : 0u);   // token (+ ext) + literals + offset (+ ext)
-  // lz4.c:2240-2250: the length extension may not be read at or behind n - 15
-  const bool complete = !(ll_ext && (e_ll == 255u || ip + (uint32_t)lane + 16u >= n)) && !(has_ext && e1 == 255u) && (uint32_t)lane + size <= 64u;
-  const uint32_t off = o_lo | (o_hi << 8);
-  const uint32_t nxt = complete ? (uint32_t)lane + size : 64u; // position of the following token, 64 = stop here
-  PROF_LAP(8);
-  // ---- 2. token chain in "rank space": lane r (< 16) finds the position of the r-th token by pointer
-  //         doubling over the next-position table: J1 = J0 o J0, J2 = J1 o J1, J3 = J2 o J2 ----
-  const uint32_t J0 = nxt;
-  const uint32_t J1 = hop(J0, J0), J2 = hop(J1, J1), J3 = hop(J2, J2);
-  uint32_t c = 0;                                              // ip is a real token by invariant
-  { const uint32_t t = hop(J0, c); c = (lane & 1) ? t : c; }
-  { const uint32_t t = hop(J1, c); c = (lane & 2) ? t : c; }
-  { const uint32_t t = hop(J2, c); c = (lane & 4) ? t : c; }
-  { const uint32_t t = hop(J3, c); c = (lane & 8) ? t : c; }
-  // fields of the token at c, fetched into the rank lane: ll (9 bits) | ml (9) | complete | length-extension flag | nxt (7)
-  const uint32_t pk = bperm(c & 63u, ll | (ml << 9) | ((complete ? 1u : 0u) << 18) | ((ll_ext ? 1u : 0u) << 19) | (nxt << 20));
-  const uint32_t off_r = bperm(c & 63u, off);
-  const uint32_t ll_r = pk & 0x1ffu, ml_r = (pk >> 9) & 0x1ffu, nxt_r = pk >> 20, ext_r = (pk >> 19) & 1u;
-  const bool valid = lane < (int)BATCH_MAXSEQ && c < 64u && ((pk >> 18) & 1u);
-  const uint32_t tot_r = valid ? ll_r + ml_r : 0u;
-  uint32_t incl = tot_r;                                       // inclusive prefix sum over the 16 rank lanes (one DPP row)
-  incl += row_shr<1>(incl); incl += row_shr<2>(incl); incl += row_shr<4>(incl); incl += row_shr<8>(incl);
-  const uint32_t excl = incl - tot_r;                          // output offset of sequence r relative to op
-  const uint32_t mrel_r = excl + ll_r;                         // its match start, relative to op
-  // acceptance: offset inside the produced data (lz4.c:2356, and offset 0), and far enough from the output
-  // end that neither lz4.c:2279 nor :2423 can apply (the scalar path handles those sequences)
-  const bool ok = valid && off_r != 0u && off_r <= op + mrel_r && op + excl + tot_r + 12u <= cap;
-  const uint32_t okmask = (uint32_t)__ballot(ok) & 0xffffu;
-  const uint32_t cnt = (uint32_t)__builtin_ctz(~okmask);       // leading accepted sequences (<= 16)
-  PROF_LAP(9);
-  if (cnt == 0u) return 0u;
-  // a source inside a skipped periodic span: fill the span in first (rare)
-  if (sp.hi && __ballot((uint32_t)lane < cnt && op + mrel_r - off_r < sp.hi)) span_materialize(out, lane, sp);
-  const uint32_t consumed = (uint32_t)__builtin_amdgcn_readlane((int)nxt_r, (int)(cnt - 1u));
-  const uint32_t acc = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(cnt - 1u));
-  // ---- two or more matches that are not independent of this step, all starting at most LZB_HIST bytes before its output:
-  //      the step is assembled in LDS (lz4_step_lds, see above) ----
-  if (BAMD_DEC_LDS_STEP && acc <= LZB_STEP && !sp.hi) {
-    const bool fast0 = (uint32_t)lane < cnt && ml_r <= 64u && off_r >= mrel_r + ml_r;
-    const bool rest_r = (uint32_t)lane < cnt && !fast0;
-    if (__builtin_popcountll(__ballot(rest_r)) >= LZB_MIN_REST) {
-      const uint32_t reach = rest_r ? (off_r > mrel_r ? off_r - mrel_r : 0u) : 0u;      // bytes before op the match needs
-      const uint32_t hneed = (uint32_t)__builtin_amdgcn_readlane((int)row_max16<0>(reach), 15);
-      if (hneed <= LZB_HIST) {
-        uint32_t H = (hneed + 15u) & ~15u;
-        if (H > op) H = op;                             // hneed <= op by the acceptance test: only the rounding is cut
-        lz4_step_lds(out, scr_generic, B, c, excl, ll_r, ml_r, off_r, mrel_r, ext_r, fast0, rest_r, cnt, consumed, op, H, lane);
-        PROF_ADD(0, 1); PROF_ADD(1, cnt);
-        ip += consumed;
-        op += acc;
-        PROF_LAP(11);
-        return cnt;
-      }
-    }
-  }
-  // ---- 3. literals: token info goes back to byte-lane space through a 64-dword LDS scratch, then one
-  //         scattered byte store covers the literals of every accepted sequence ----
-  // (volatile: lanes talk to each other through this scratch; without it the compiler forwards a lane's
-  //  own "= 0" store to its later load, which is legal for unsynchronised memory and wrong here)
-  // scratch word of a token: valid | length-extension flag << 25 | literal count << 16 | output offset (< 2^16: 16 x 542)
-  scr[lane] = 0u;
-  BAMD_LDS_SYNC();
-  if ((uint32_t)lane < cnt) scr[c] = 0x80000000u | excl | (ll_r << 16) | (ext_r << 25);
-  BAMD_LDS_SYNC();
-  const uint64_t mask = __ballot(scr[lane] >> 31);
-  {
-    const uint64_t below = mask & ((2ull << lane) - 1ull);     // accepted tokens at or before this byte lane
-    const uint32_t s = 63u - (uint32_t)__builtin_clzll(below | 1ull);
-    const uint32_t inf = scr[s];
-    const uint32_t k = (uint32_t)lane - s - 1u - ((inf >> 25) & 1u);
-    if ((uint32_t)lane < consumed && (uint32_t)lane > s + ((inf >> 25) & 1u) && k < ((inf >> 16) & 0x1ffu)) out[op + (inf & 0xffffu) + k] = (uint8_t)B;
-  }
-  // ---- 4. short independent matches: 4 lanes per sequence, overlapping 4/8/16-byte pieces ----
-  const bool fast_r = (uint32_t)lane < cnt && ml_r <= 64u && off_r >= mrel_r + ml_r;   // source ends at or before op
-  {
-    const uint32_t r = (uint32_t)lane >> 2, q = (uint32_t)lane & 3u;
-    const uint32_t fA = bperm(r, fast_r ? (ml_r | 0x200u | (mrel_r << 10)) : 0u);
-    const uint32_t fB = bperm(r, off_r);
-    const uint32_t mlen = fA & 0x1ffu;
-    const bool go = (fA & 0x200u) != 0u;
-    gu8* d = out + op + (fA >> 10);
-    const gu8* sp = d - fB;
-    const bool w16 = go && mlen >= 16u && q < ((mlen + 15u) >> 4);
-    const bool w8 = go && mlen >= 8u && mlen < 16u && q < 2u;
-    const bool w4 = go && mlen < 8u && q < 2u;
-    const uint32_t np16 = (mlen + 15u) >> 4;
-    const uint32_t po16 = (q == np16 - 1u) ? mlen - 16u : 16u * q;
-    const uint32_t po8 = q ? mlen - 8u : 0u, po4 = q ? mlen - 4u : 0u;
-    uint4 v16 = make_uint4(0, 0, 0, 0); uint64_t v8 = 0; uint32_t v4 = 0;
-    if (w16) v16 = g_ld16(sp + po16);
-    if (w8) v8 = g_ld8(sp + po8);
-    if (w4) v4 = g_ld4(sp + po4);
-    if (w16) g_st16(d + po16, v16);
-    if (w8) *(BAMD_GAS u64una*)(d + po8) = v8;
-    if (w4) g_st4(d + po4, v4);
-  }
-  PROF_LAP(10);
-  // ---- 5. everything else (long, or reading bytes this very step produces), in stream order ----
-  uint32_t rest = (uint32_t)__ballot((uint32_t)lane < cnt && !fast_r);
-  PROF_ADD(0, 1); PROF_ADD(1, cnt); PROF_ADD(2, __builtin_popcount(rest));
-  while (rest) {
-    const int sl = __builtin_ctz(rest);
-    rest &= rest - 1u;
-    const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)ml_r, sl);
-    const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)off_r, sl);
-    const uint32_t mr = (uint32_t)__builtin_amdgcn_readlane((int)mrel_r, sl);
-    wave_match_copy(out, op + mr, o, m, lane);
-  }
-  ip += consumed;
-  op += acc;
-  PROF_LAP(11);
-  return cnt;
-}
-
 }  // namespace bamd
-#ifndef BAMD_DEC_BULK
-#define BAMD_DEC_BULK 1       // the pipelined steady-state loop of dec_bulk.h in front of the round-2 step
-#endif
-#include "dec_bulk.h"
+#include "dec_ring.h"
 namespace bamd {
-
-// ---------------------------------------------------------------------------------------------
-// LZ4 block decode, one wave.  Returns bytes produced (== cap on success) or a negative number.
-// Acceptance rules are those of the reference's safe loop (lz4.c:2215-2435):
-//   literal-length extension stops reading at n-15, match-length extension at n-4;
-//   a literal run reaching within 12 bytes of the output end or 8 of the input end must be the
-//   last one and end exactly at the input end; offset <= bytes produced; a match must end at
-//   least 5 bytes before the output end.  Offset 0 is accepted like the reference does (the match bytes
-//   are then whatever the output buffer held).
-// ---------------------------------------------------------------------------------------------
-// LZ4's 255-run length extension (lz4.c:2240-2250 / :2330-2342), 64 stream bytes per step instead of one:
-// value += 255 * (number of leading 0xFF bytes) + the first other byte; ip ends behind that byte.
-// Bytes beyond the stream read as zero (Window::fetch), i.e. as a terminator: the caller's bound check on
-// the final ip (monotonic, so equivalent to the reference's per-byte check) catches a run into the end.
-__device__ __forceinline__ void lz4_ext_run(Window& w, uint32_t& ip, uint32_t& value, uint32_t cap, int lane) {
-  for (;;) {
-    w.seek(ip);
-    const uint32_t B = w.gather_bytes(ip);
-    const uint64_t m = __ballot(B != 255u);
-    if (m) {
-      const uint32_t k = (uint32_t)__builtin_ctzll(m);
-      value += 255u * k + (uint32_t)__builtin_amdgcn_readlane((int)B, (int)k);
-      ip += k + 1u;
-      return;
-    }
-    value += 255u * 64u; ip += 64u;
-    if (value > cap) return;                       // the caller rejects; keeps the loop bounded by cap
-  }
-}
-
-// allow_bulk: the pipelined loop of dec_bulk.h may be tried (decode_one_stream: not for bit-shuffled chunks, whose streams are chains of
-// near matches - the LDS-assembled step's case - so that every visit would be a wasted parse)
-__device__ int lz4_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* out, int32_t cap_, volatile uint32_t* scr, int lane, SpanCtx& sp PROF_ARG, bool allow_bulk = true) {
-  if (cap_ == 0) return (n_ == 1 && in[0] == 0) ? 0 : -1;
-  if (n_ <= 0) return -1;
-  const uint32_t n = (uint32_t)n_, cap = (uint32_t)cap_;
-  Window w;
-  w.init(in, n, lane);
-  uint32_t ip = 0, op = 0;
-  uint32_t bulk_wait = 0, bulk_pen = 4;     // steps to leave to the round-2 code after a visit of the bulk loop that took (almost) nothing
-  for (;;) {
-    w.seek(ip);
-    uint32_t hdr = w.peek32(ip);
-    if (ip + 72u <= n) {
-      const uint32_t tk = hdr & 0xffu;
-      // the batched step needs a first token it can take: at most one extension byte per length
-      bool try_batch = true;
-      uint32_t ll1 = tk >> 4, tpos = ip + 1u;
-      if (ll1 == 15u) { const uint32_t e = (hdr >> 8) & 0xffu; try_batch = e != 255u && 17u + e + 3u <= 64u; ll1 = 15u + e; tpos++; }
-      if (try_batch && (tk & 15u) == 15u) try_batch = (w.peek32(tpos + ll1 + 2u) & 0xffu) != 255u;
-      if (BAMD_DEC_BULK && allow_bulk && try_batch) {
-        if (bulk_wait == 0u) {
-          const uint32_t rb = lz4_bulk(w, n, out, cap, scr, ip, op, sp.hi, lane PROF_PASS);
-          const uint32_t steps = rb & 0x7fffffffu;
-          // a visit that took nothing (typically: the stream's steps want the LDS-assembled form) or hardly anything, or whose
-          // steps were mostly in-order copies: leave the next steps to the code below, four times as many after every such visit
-          if (steps <= 1u || (rb >> 31)) { bulk_wait = bulk_pen; bulk_pen = bulk_pen < 64u ? 4u * bulk_pen : 256u; }
-          else if (steps >= 4u) bulk_pen = 4u;
-          if (steps) continue;
-        } else bulk_wait--;
-      }
-      if (try_batch && lz4_batch_step(w, out, scr, ip, op, cap, n, lane, sp PROF_PASS)) continue;
-    }
-    PROF_ADD(3, 1);
-    const uint32_t token = hdr & 0xffu;
-    ip += 1;
-    uint32_t ll = token >> 4;
-    if (ll == 15u) {
-      if (n < 15u || ip >= n - 15u) return -2;
-      lz4_ext_run(w, ip, ll, cap, lane);
-      if (ip > n - 15u || ll > cap) return -2;
-    }
-    // ---- literals ----
-    if (op + ll + 12u > cap || ip + ll + 8u > n) {
-      // must be the final run
-      if (ip + ll != n || op + ll > cap) return -3;
-      wave_copy_disjoint(out + op, in + ip, ll, lane);
-      op += ll;
-      break;
-    }
-    const uint32_t lit_src = ip;
-    // Literal bytes are fetched BEFORE the window may slide for the offset, and stored after the offset has
-    // been parsed: the loads of a long run and the window fetch behind it travel together (one memory
-    // round trip instead of two).  <= 64 bytes inside the window: a register gather; 16..1024 bytes: one
-    // 16-byte load per lane (the last piece overlaps its neighbour); anything else: copied right away.
-    const bool lit_in_win = ll <= 64u && lit_src + ll <= w.base + 512u;
-    const bool lit_early = !lit_in_win && ll >= 16u && ll <= 1024u;
-    uint32_t litv = 0;
-    uint4 lit16 = make_uint4(0, 0, 0, 0);
-    uint32_t lit_off = 16u * (uint32_t)lane;
-    const bool lit_mine = lit_early && lit_off < ll;
-    if (ll && lit_in_win) litv = w.gather_bytes(lit_src);
-    else if (lit_early) { if (lit_off + 16u > ll) lit_off = ll - 16u; if (lit_mine) lit16 = g_ld16(in + lit_src + lit_off); }
-    else if (ll) wave_copy_disjoint(out + op, in + lit_src, ll, lane);
-    ip += ll;
-    w.seek(ip);
-    uint32_t t2 = w.peek32(ip);
-    const uint32_t off = t2 & 0xffffu;
-    ip += 2;
-    uint32_t ml = token & 15u;
-    if (ml == 15u) {
-      const uint32_t s0 = (t2 >> 16) & 0xffu;   // first extension byte is already in the peeked word
-      ip++; ml += s0;
-      if (ip > n - 4u) return -4;
-      if (s0 == 255u) {
-        lz4_ext_run(w, ip, ml, cap, lane);
-        if (ip > n - 4u || ml > cap) return -4;
-      }
-    }
-    ml += 4u;
-    const uint32_t mpos = op + ll;
-    if (off > mpos) return -5;
-    if (mpos + ml + 5u > cap) return -6;
-    if (off == 0u) {
-      // The reference does not reject offset 0 (lz4.c:2356 only checks the lower bound): it "copies" the match from
-      // its own destination, i.e. leaves whatever the output buffer held.  Same verdict here: literals are stored,
-      // the match bytes stay as they are (unspecified content, exactly as with stock LZ4).
-      if (ll) {
-        if (lit_in_win) { if ((uint32_t)lane < ll) out[op + lane] = (uint8_t)litv; }
-        else if (lit_mine) g_st16(out + op + lit_off, lit16);
-      }
-      op = mpos + ml;
-      continue;
-    }
-    if (sp.hi && mpos - off < sp.hi) span_materialize(out, lane, sp);
-
-    if (lit_in_win && ll + ml <= 64u && off >= ml && (ll == 0u || off >= ll + ml)) {
-      // short sequence whose match cannot see its own literals: one gather, one 64-lane store
-      uint32_t v = litv;
-      const uint32_t k = (uint32_t)lane - ll;
-      if (k < ml) v = out[mpos - off + k];
-      if ((uint32_t)lane < ll + ml) out[op + lane] = (uint8_t)v;
-    } else {
-      if (ll) {
-        if (lit_in_win) { if ((uint32_t)lane < ll) out[op + lane] = (uint8_t)litv; }
-        else if (lit_mine) g_st16(out + op + lit_off, lit16);
-      }
-      if (!span_long_match(out, mpos, off, ml, lane, sp)) wave_match_copy(out, mpos, off, ml, lane);
-    }
-    op = mpos + ml;
-    PROF_LAP(12);
-  }
-  PROF_LAP(12);
-  return (int)op;
-}
 
 // ---------------------------------------------------------------------------------------------
 // BloscLZ decode, one wave (blosclz.c:679-789).  Returns bytes produced; 0 on any violation,
@@ -1153,7 +730,7 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
     if (!raw_in_place) wave_copy_disjoint(out, in, (uint32_t)want, lane);
     got = want;
   } else if (sd->fmt == FMT_LZ4) {
-    got = lz4_decode_wave(in, csize, out, want, scr, lane, sp PROF_PASS, (mode & CH_BITSHUFFLE) == 0u);
+    got = lz4_decode_wave(in, csize, out, want, scr, lane, sp PROF_PASS);
   } else {
     got = blosclz_decode_wave(in, csize, out, want, scr, lane, sp);
   }
@@ -1220,7 +797,7 @@ __global__ __launch_bounds__(64 * DEC_WAVES, BAMD_DEC_MINWAVES) void k_decode_st
     , uint32_t* __restrict__ profbuf
 #endif
     ) {
-  __shared__ uint32_t scr[DEC_WAVES][64 + LZB_BYTES / 4];   // per-wave scratch of the batched LZ4 step + its LDS step buffer (lz4_batch_step)
+  __shared__ __attribute__((aligned(16))) uint32_t scr[DEC_WAVES][DR_LDS_BYTES / 4];   // per wave: 64 scratch dwords of the batched steps | input ring | history ring (dec_ring.h)
   static_assert(DEC_WAVES == 1, "one stream per wave, one wave per workgroup");
   const int lane = threadIdx.x & 63;
   // HW_REG_XCC_ID[3:0]; queue 0 for everybody in the single-queue fallback (no in-kernel hand-offs there)

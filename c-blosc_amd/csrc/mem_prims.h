@@ -49,6 +49,19 @@ __device__ __forceinline__ void g_st4(gu8* p, uint32_t v) { *(BAMD_GAS u32una*)p
 __device__ __forceinline__ void g_st8(gu8* p, uint64_t v) { *(BAMD_GAS u64una*)p = v; }
 __device__ __forceinline__ void g_st8_nt(gu8* p, uint64_t v) { __builtin_nontemporal_store(v, (BAMD_GAS u64una*)p); }
 
+// ---- LDS (address space 3): byte-unaligned dword .. dwordx4 accesses are fine on gfx950 (scripts/micro/lds_unaligned.hip) ----
+#define BAMD_LAS __attribute__((address_space(3)))
+typedef BAMD_LAS uint8_t lu8;
+// compiler-level ordering between LDS phases in which lanes read what OTHER lanes wrote (the hardware runs one
+// wave's DS operations in order; this keeps the compiler from reordering them on per-thread alias reasoning)
+#define LDS_ORDER() asm volatile("" ::: "memory")
+__device__ __forceinline__ uint4 l_ld16(const lu8* p) { v4u32 t = *(const BAMD_LAS v4u32_una*)p; return make_uint4(t.x, t.y, t.z, t.w); }
+__device__ __forceinline__ void l_st16(lu8* p, uint4 v) { v4u32 t = {v.x, v.y, v.z, v.w}; *(BAMD_LAS v4u32_una*)p = t; }
+__device__ __forceinline__ uint64_t l_ld8(const lu8* p) { return *(const BAMD_LAS u64una*)p; }
+__device__ __forceinline__ void l_st8(lu8* p, uint64_t v) { *(BAMD_LAS u64una*)p = v; }
+__device__ __forceinline__ uint32_t l_ld4(const lu8* p) { return *(const BAMD_LAS u32una*)p; }
+__device__ __forceinline__ void l_st4(lu8* p, uint32_t v) { *(BAMD_LAS u32una*)p = v; }
+
 // every vector memory operation of this wave has completed (stores have reached L2)
 #ifndef BAMD_WAIT_STORES        // (the wavefront emulator of tests/tools/wave_emu defines it away)
 #define BAMD_WAIT_STORES() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")

@@ -91,7 +91,7 @@ inline void build_xcd_queues(const std::vector<BlockDesc>& blocks, size_t nstr, 
   std::vector<uint32_t> mine[8];
   for (size_t g = 0; g < blocks.size(); g++) {
     const uint32_t f = (uint32_t)blocks[g].flags;
-    if (blocks[g].nstreams > 0 && (pick ? (f & pick) != 0u : !(f & (BLK_LDS | BLK_Z)))) mine[g % (size_t)nq].push_back((uint32_t)g);
+    if (blocks[g].nstreams > 0 && (pick ? (f & pick) != 0u : !(f & BLK_Z))) mine[g % (size_t)nq].push_back((uint32_t)g);
   }
   std::vector<int> order; int nheavy = 0, lastT = -1;
   auto prep = [&](const BlockDesc& b) {

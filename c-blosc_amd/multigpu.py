@@ -69,12 +69,23 @@ def rank_byte_ranges(table: List[int], nchunks: int, world: int):
     return out
 
 
-def pack_local(comp_rows, local_cbytes: List[int]):
-    """This rank's chunks back to back, in chunk order: comp_rows[i][:cbytes[i]] concatenated (device-side copies)."""
+def _default_device():
+    """Where a rank WITHOUT chunks allocates its (empty) tensors: the current GPU under nccl / RCCL (a CPU tensor cannot be posted
+    there), the CPU under gloo."""
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized() and dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def pack_local(comp_rows, local_cbytes: List[int], device=None):
+    """This rank's chunks back to back, in chunk order: comp_rows[i][:cbytes[i]] concatenated (device-side copies).
+    `device`: where to allocate when the rank owns no chunk (default: see _default_device)."""
     import torch
     total = sum(max(c, 0) for c in local_cbytes)
     first = comp_rows[0] if len(local_cbytes) else None
-    out = torch.empty((total,), dtype=torch.uint8, device=first.device if first is not None else None)
+    out = torch.empty((total,), dtype=torch.uint8, device=first.device if first is not None else (device if device is not None else _default_device()))
     acc = 0
     for row, c in zip(comp_rows, local_cbytes):
         if c > 0:
@@ -123,7 +134,8 @@ def scatter_payload(container, table: List[int], nchunks: int, src: int = 0, dev
     world, rank = dist.get_world_size(), dist.get_rank()
     ranges = rank_byte_ranges(table, nchunks, world)
     lo, hi = chunk_range(nchunks, world, rank)
-    mine = torch.empty((ranges[rank][1],), dtype=torch.uint8, device=container.device if container is not None else device)
+    mine = torch.empty((ranges[rank][1],), dtype=torch.uint8,
+                       device=container.device if container is not None else (device if device is not None else _default_device()))
     ops = []
     if rank == src:
         o, n = ranges[rank]

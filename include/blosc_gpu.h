@@ -51,6 +51,22 @@ BLOSC_EXPORT int blosc_gpu_compress_batch_host(int clevel, int doshuffle, size_t
 BLOSC_EXPORT int blosc_gpu_decompress_batch_host(int nchunks, const void* const* src, const size_t* srcsize,
                                                  void* const* dest, const size_t* destsize, int* nbytes_out);
 
+/* ---- one call, all GPUs of the node -------------------------------------------------------------------------------------------
+ * The reference's one call fans its blocks out over a pool of worker threads (blosc/blosc.c:904-918 do_job, :871-899
+ * parallel_blosc); chunks of a batch are independent, so a many-chunk buffer shards over the GPUs with no exchange between them:
+ * chunk c belongs to GPU floor(c * ndev / nchunks) - contiguous ranges, the rule blosc_gpu_partition states (and bench.py /
+ * c-blosc_amd/multigpu.py use across processes, one process per GPU, with RCCL only for the cbytes table).  The _multi calls run
+ * one host thread per GPU inside THIS process, each bound to its device (the process-wide device of blosc_gpu_set_device is not
+ * touched).  devices: ndev HIP device ids, NULL = 0 .. ndev-1.  The buffers of range r are host memory (staged) or memory of /
+ * visible to devices[r]; results are per chunk exactly as in the single-GPU calls.  Returns 0, or < 0 if a device could not be used. */
+BLOSC_EXPORT int blosc_gpu_device_count(void);
+BLOSC_EXPORT int blosc_gpu_partition(size_t nchunks, int world, int rank, size_t* lo, size_t* hi);   /* chunk range [lo, hi) of `rank` */
+BLOSC_EXPORT int blosc_gpu_compress_batch_multi(int ndev, const int* devices, int clevel, int doshuffle, size_t typesize,
+                                                const char* compressor, size_t blocksize, int nchunks, const void* const* src,
+                                                const size_t* nbytes, void* const* dest, const size_t* destsize, int* cbytes_out);
+BLOSC_EXPORT int blosc_gpu_decompress_batch_multi(int ndev, const int* devices, int nchunks, const void* const* src,
+                                                  const size_t* srcsize, void* const* dest, const size_t* destsize, int* nbytes_out);
+
 /* blosc_getitem (blosc/blosc.h:312) on a device-resident chunk into device memory. */
 BLOSC_EXPORT int blosc_gpu_getitem(const void* src, int start, int nitems, void* dest, void* stream);
 

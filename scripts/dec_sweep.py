@@ -24,7 +24,7 @@ for _ in range(3): bd.decompress()
 lib.blosc_gpu_profile(0)
 if not os.environ.get("NOCHECK"): assert bd.results() == [csz] * nchunks      # NOCHECK=1: timing experiments with builds that leave work out on purpose
 ok = bool((back[0] == torch.from_numpy(host).to(dev)).all()) and bool((back[-1] == torch.from_numpy(host).to(dev)).all())
-names = ["k_decode_plan", "k_classify_blocks", "k_decode_streams", "k_decode_blocks", "k_decode_blocks8", "k_unshuffle", "k_bitunshuffle", "k_zstd_entropy", "k_zstd_seq", "k_zstd_exec", "k_zstd_streams", "k_zlib_streams"]
+names = ["k_decode_plan", "k_decode_streams", "k_unshuffle", "k_bitunshuffle", "k_zstd_entropy", "k_zstd_seq", "k_zstd_exec", "k_zstd_streams", "k_zlib_streams"]
 tot = 0.0; parts = []
 for k in names:
     ms, cnt = mod.profile_get(k)

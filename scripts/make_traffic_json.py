@@ -30,7 +30,6 @@ for k in sorted(set(f) | set(w)):
                 "2": "k_zlib_encode", "6": "k_zlib_encode", "9": "k_zlib_encode", "10": "k_zlib_encode", "3": "k_lz4hc_encode"}.get(mode, "k_encode_streams")
     elif name.startswith("k_bitfilter_fast<0>"): name = "k_bitshuffle"
     elif name.startswith("k_bitfilter_fast<1>"): name = "k_bitunshuffle"
-    elif name.startswith("k_decode_blocks<8, 8>"): name = "k_decode_blocks8"
     name = name.split("<")[0]
     fb = f.get(k, 0.0) * 1024 * 2; wb = w.get(k, 0.0) * 1024
     e = res["kernels"].setdefault(name, {"hbm_read_bytes": 0.0, "hbm_write_bytes": 0.0, "hbm_bytes": 0.0})

@@ -311,9 +311,6 @@ def test_sampled_parameter_grid(emulib, oracle, ref):
         _everybody_reads(emulib, oracle, ref, chunk, data)
 
 
-# (not here: BLOSC_AMD_BLOCKDEC=1.  k_decode_blocks' eight wavefronts hand bytes to each other through LDS rings guarded by progress words -
-#  lock step BETWEEN wavefronts of a workgroup, which the emulator's round-robin does not reproduce and the source does not annotate;
-#  that decoder is opt-in and has its device tests in tests/test_gpu_modes.py)
 FLIPS = [(), ("BLOSC_AMD_SINGLE_QUEUE",), ("BLOSC_AMD_FUSE",), ("BLOSC_AMD_SPANS",), ("BLOSC_AMD_SCHED",), ("BLOSC_AMD_PERIODIC",),
          ("BLOSC_AMD_BITFAST",), ("BLOSC_AMD_SINGLE_QUEUE", "BLOSC_AMD_FUSE", "BLOSC_AMD_SPANS", "BLOSC_AMD_SCHED")]
 
@@ -323,7 +320,7 @@ def test_fallback_switches(emulib, flip):
     """tests/test_gpu_modes.py's switch combinations (one task queue with stand-alone filter kernels, unfused filters, no periodic spans /
     planes, plain block order, the generic bit filters) on the emulated library, inputs shrunk: the same
     script, a process per combination because the switches are read once."""
-    defaults = {"BLOSC_AMD_SINGLE_QUEUE": "0", "BLOSC_AMD_FUSE": "1", "BLOSC_AMD_SPANS": "1", "BLOSC_AMD_SCHED": "1", "BLOSC_AMD_BLOCKDEC": "0",
+    defaults = {"BLOSC_AMD_SINGLE_QUEUE": "0", "BLOSC_AMD_FUSE": "1", "BLOSC_AMD_SPANS": "1", "BLOSC_AMD_SCHED": "1",
                 "BLOSC_AMD_PERIODIC": "1", "BLOSC_AMD_BITFAST": "1"}
     env = dict(os.environ)
     for k, v in defaults.items():

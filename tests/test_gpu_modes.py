@@ -1,7 +1,7 @@
 """GPU: the fallback switches of the engine are part of the product, so they are part of the
 suite: BLOSC_AMD_SINGLE_QUEUE (one task queue, stand-alone filters: what a partitioned device gets),
 BLOSC_AMD_FUSE (filters in kernels of their own), BLOSC_AMD_SPANS (periodic planes through the scratch),
-BLOSC_AMD_SCHED (plain block order), BLOSC_AMD_BLOCKDEC (the LDS-resident block decoder, off by default, switched on).  The switches are read
+BLOSC_AMD_SCHED (plain block order).  The switches are read
 once per process, so every combination runs tests/tools/mode_check.py in a process of its own."""
 import itertools
 import os
@@ -12,8 +12,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SWITCHES = ["BLOSC_AMD_SINGLE_QUEUE", "BLOSC_AMD_FUSE", "BLOSC_AMD_SPANS", "BLOSC_AMD_SCHED", "BLOSC_AMD_BLOCKDEC"]
-DEFAULTS = {"BLOSC_AMD_SINGLE_QUEUE": "0", "BLOSC_AMD_FUSE": "1", "BLOSC_AMD_SPANS": "1", "BLOSC_AMD_SCHED": "1", "BLOSC_AMD_BLOCKDEC": "0"}
+SWITCHES = ["BLOSC_AMD_SINGLE_QUEUE", "BLOSC_AMD_FUSE", "BLOSC_AMD_SPANS", "BLOSC_AMD_SCHED"]
+DEFAULTS = {"BLOSC_AMD_SINGLE_QUEUE": "0", "BLOSC_AMD_FUSE": "1", "BLOSC_AMD_SPANS": "1", "BLOSC_AMD_SCHED": "1"}
 
 
 def _combos():

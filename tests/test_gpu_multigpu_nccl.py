@@ -65,3 +65,20 @@ def test_partition_batch_and_rccl_gather(pkg, oracle):
         assert float(t.item()) == float(sum(table))
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_spawner_n1():
+    """bench.py's own launcher (the path `python bench.py --gpus N` takes for N > 1: re-execution under torch.distributed.run, one
+    process per GPU, LOCAL_RANK -> blosc_gpu_set_device, RCCL communicator, one JSON line from rank 0) on the one GPU of this box."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--spawn", "--steps", "1", "--warmup", "1", "--chunks", "4",
+                        "--chunk-mib", "8", "--no-cpu-baseline", "--no-extra"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["multi_gpu"]["rccl_world_size"] == 1 and len(d["multi_gpu"]["per_rank_GBps"]) == 1
+    assert d["verified"]["roundtrip_bit_exact"] is True

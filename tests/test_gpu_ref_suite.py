@@ -58,7 +58,7 @@ def test_bitshuffle_leftovers(env, tmp_path):
     assert rc == 0 and out.count("Successful roundtrip!") == 2 and "error" not in out.lower(), (rc, out[-2000:], err[-2000:])
 
 
-@pytest.mark.parametrize("prog", ["test_compress_roundtrip", "test_getitem", "test_shuffle_roundtrip_generic"])
+@pytest.mark.parametrize("prog", ["test_compress_roundtrip", "test_getitem", "test_shuffle_roundtrip_generic", "test_shuffle_roundtrip_sse2", "test_shuffle_roundtrip_avx2"])
 def test_csv_program(env, prog):
     """Every row of the reference's parameter list (tests/CMakeLists.txt:66-100 turns each into a ctest case)."""
     stride = os.environ.get("REF_SUITE_STRIDE", "1")

@@ -354,14 +354,17 @@ def test_fused_block_decode(emu, oracle, codec, fmt, T):
     print(codec, T, seen)
 
 
-def test_bulk_loop_takes_reference_streams(emu, oracle, ref):
-    """dec_bulk.h: the pipelined steady-state loop must actually run (and be right) on what the benchmark decodes: byte planes of
-    bench19 as the reference's own LZ4 writes them (offsets of a few KiB, 13 sequences per 64 stream bytes), a ragged tail, a
-    stream that changes between plain steps and long matches, and output rooms too small for the stream."""
-    emu.emu_bulk_steps.restype = C.c_ulonglong
+def test_ring_steps_take_reference_streams(emu, oracle, ref):
+    """dec_ring.h: the batched steps of the LDS ring decoder must actually run (and be right) on what the benchmark decodes: byte planes
+    of bench19 as the reference's own LZ4 writes them (offsets of a few KiB, 13 sequences per 64 stream bytes), a ragged tail, a
+    stream that changes between plain steps and long matches, and output rooms too small for the stream; planes longer than the ring
+    must take matches out of the rows already written to global memory."""
+    emu.emu_ring_steps.restype = C.c_ulonglong
+    emu.emu_ring_far.restype = C.c_ulonglong
+    far0 = emu.emu_ring_far()
     n = 32768
     planes = DATASETS["bench19"](8 * n).reshape(-1, 8).T.copy()
-    before = emu.emu_bulk_steps()
+    before = emu.emu_ring_steps()
     seqs = 0
     for j in (1, 2, 5):
         for cut in (n, n - 1237):
@@ -374,8 +377,9 @@ def test_bulk_loop_takes_reference_streams(emu, oracle, ref):
             for cap in (data.size - 1, data.size // 2, 40, 15):          # too small a room: the oracle's verdict, no byte outside
                 _same_as_oracle(emu, oracle, LZ4, stream, cap)
             seqs += 1
-    steps = emu.emu_bulk_steps() - before
+    steps = emu.emu_ring_steps() - before
     assert seqs >= 4 and steps >= 50 * seqs, (seqs, steps)
+    assert emu.emu_ring_far() - far0 >= 20, emu.emu_ring_far() - far0        # bench19 planes reach back up to 32 KiB: beyond the 8 KiB ring
     # damaged copies of one stream: verdict and bytes of the oracle
     rng = np.random.default_rng(5)
     stream = _compress(oracle, LZ4, planes[1])

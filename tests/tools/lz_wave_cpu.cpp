@@ -9,7 +9,6 @@
 #include "dev_types.h"
 #include "k_filters.hip"
 #include "k_decode.hip"
-#include "k_decode_blocks.hip"
 #include "k_encode.hip"
 #include "k_zstd.hip"
 #include "k_zstd2.hip"
@@ -106,9 +105,9 @@ extern "C" int emu_decode_block(int T, int fmt, const uint8_t* const* streams, c
   int32_t status = 0; uint32_t blk_done = 0;
   uint32_t spans[32]; memset(spans, 0, sizeof spans);
   uint8_t* pat = (uint8_t*)malloc((size_t)T * SPAN_PAT + 64);
-  uint32_t* scr = (uint32_t*)aligned_alloc(64, 64 * 4 + LZB_BYTES + 256);
+  uint32_t* scr = (uint32_t*)aligned_alloc(64, bamd::DR_LDS_BYTES + 256);
   for (int k = 0; k < T; k++) {
-    memset(scr, 0xA5, 64 * 4 + LZB_BYTES + 256);
+    memset(scr, 0xA5, bamd::DR_LDS_BYTES + 256);
     BJob j = {sd, &status, scr, &c, &b, &blk_done, (uint32_t)order[k], spans, pat};
     wave_emu::run(blk_body, &j);
   }
@@ -191,15 +190,17 @@ void dec_body(int lane, void* arg) {
 // kind: 0 = LZ4 block, 1 = BloscLZ stream.  Returns what the device function returns (bytes produced, or its error code).
 extern "C" int emu_lz_decode(int kind, const uint8_t* src, int n, uint8_t* dst, int cap) {
   DJob j = {kind, src, n, dst, cap, nullptr, 0};
-  j.scr = (uint32_t*)aligned_alloc(64, 64 * 4 + bamd::LZB_BYTES + 256);      // the wave's LDS: 64 scratch dwords + the step buffer
-  memset(j.scr, 0xA5, 64 * 4 + bamd::LZB_BYTES + 256);
+  j.scr = (uint32_t*)aligned_alloc(64, bamd::DR_LDS_BYTES + 256);      // the wave's LDS: 64 scratch dwords + input ring + history ring (dec_ring.h)
+  memset(j.scr, 0xA5, bamd::DR_LDS_BYTES + 256);
   wave_emu::run(dec_body, &j);
   free(j.scr);
   return j.result;
 }
 
-// steps taken by the pipelined steady-state loop of dec_bulk.h so far (the tests check that reference-written streams go through it)
-extern "C" unsigned long long emu_bulk_steps() { return bamd::g_emu_bulk_steps; }
+// batched steps of the LZ4 ring decoder (dec_ring.h) so far, and matches it served from rows already written to global memory (the tests check
+// that reference-written streams really take those paths)
+extern "C" unsigned long long emu_ring_steps() { return bamd::g_emu_ring_steps; }
+extern "C" unsigned long long emu_ring_far() { return bamd::g_emu_ring_far; }
 
 // kind: 0 = LZ4, 1 = BloscLZ, 2 = LZ4 with the LZ4HC-grade search, 3 = Zstd frame, 4 = zlib stream, 5 = Zstd frame with per-block sequence tables,
 // 6 = 5 behind the LZ4HC-grade search, 7 = zlib stream behind the LZ4HC-grade search, 8 / 9 = 5 / 6 with Huffman-coded literals,

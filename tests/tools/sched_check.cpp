@@ -97,8 +97,8 @@ int main() {
     for (int j = 0; j < nblk; j++) {
       BlockDesc b; memset(&b, 0, sizeof b);
       const int k = (int)(rng() % 3), ns = (rng() % 4 == 0) ? 1 : (int)(1 + rng() % 16);
-      b.blk = j; b.first_stream = nstr; b.nstreams = ns; b.flags = k == 1 ? BLK_Z : (k == 2 ? (BLK_Z | BLK_ZLIB) : ((rng() % 9 == 0) ? BLK_LDS : 0));
-      for (int t = 0; t < ns; t++) { owner.push_back(j); kind.push_back((b.flags & BLK_LDS) ? 3 : k); }
+      b.blk = j; b.first_stream = nstr; b.nstreams = ns; b.flags = k == 1 ? BLK_Z : (k == 2 ? (BLK_Z | BLK_ZLIB) : 0);
+      for (int t = 0; t < ns; t++) { owner.push_back(j); kind.push_back(k); }
       nstr += ns; blocks.push_back(b);
     }
     std::vector<int32_t> qa, qz;
@@ -113,7 +113,7 @@ int main() {
         for (int i = d[x]; i < d[x + 1]; i++) {
           const int32_t t = d[9 + i];
           if (t < 0 || t >= nstr) return fail("z: stream index out of range", trial);
-          if (kind[(size_t)t] != (pass ? 2 : 0)) return fail(pass ? "z: a stream that is not zlib's in the zlib queues" : "z: a Zstd / zlib / LDS-block stream in k_decode_streams' queues", trial);
+          if (kind[(size_t)t] != (pass ? 2 : 0)) return fail(pass ? "z: a stream that is not zlib's in the zlib queues" : "z: a Zstd / zlib stream in k_decode_streams' queues", trial);
           if ((owner[(size_t)t] % nq) != x) return fail("z: stream on the wrong XCD", trial);
           if (seen[(size_t)t]++) return fail("z: stream twice", trial);
         }
