@@ -76,10 +76,11 @@ def load():
                                              C.POINTER(i), vp]
     L.blosc_gpu_compress_batch_host.argtypes = [i, i, sz, C.c_char_p, sz, i, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.POINTER(i)]
     L.blosc_gpu_decompress_batch_host.argtypes = [i, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.POINTER(i)]
-    L.blosc_gpu_partition.argtypes = [sz, i, i, C.POINTER(sz), C.POINTER(sz)]
-    L.blosc_gpu_compress_batch_multi.argtypes = [i, C.POINTER(i), i, i, sz, C.c_char_p, sz, i, C.POINTER(vp), C.POINTER(sz),
-                                                 C.POINTER(vp), C.POINTER(sz), C.POINTER(i)]
-    L.blosc_gpu_decompress_batch_multi.argtypes = [i, C.POINTER(i), i, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.POINTER(i)]
+    if hasattr(L, "blosc_gpu_partition"):        # (A/B scripts also load builds of earlier rounds through this loader)
+        L.blosc_gpu_partition.argtypes = [sz, i, i, C.POINTER(sz), C.POINTER(sz)]
+        L.blosc_gpu_compress_batch_multi.argtypes = [i, C.POINTER(i), i, i, sz, C.c_char_p, sz, i, C.POINTER(vp), C.POINTER(sz),
+                                                     C.POINTER(vp), C.POINTER(sz), C.POINTER(i)]
+        L.blosc_gpu_decompress_batch_multi.argtypes = [i, C.POINTER(i), i, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(sz), C.POINTER(i)]
     L.blosc_gpu_getitem.argtypes = [vp, i, i, vp, vp]
     L.blosc_gpu_profile.argtypes = [i]
     L.blosc_gpu_profile.restype = None

@@ -393,26 +393,57 @@ struct Rows { uint32_t r[T]; };
 template <int T>
 struct PlanePtrs { const gu8* p[T]; };
 
-template <int T>
-__device__ __forceinline__ Rows<T> unshuffle_load(const PlanePtrs<T>& pp, uint32_t rel, int lane) {
-  Rows<T> x;
-#pragma unroll
-  for (int j = 0; j < T; j++) x.r[j] = g_ld4(pp.p[j] + rel + 4u * (uint32_t)lane);
-  return x;
-}
 #ifndef BAMD_DST_STREAM
 #define BAMD_DST_STREAM 2     // 2: final output of the fused unshuffle with non-temporal stores: bench19 -3.8 %, linspace -1.5 % (profiles/r02f_decode_nt_variants.txt); 0: plain
 #endif
 __device__ __forceinline__ void st16_dst(gu8* p, uint4 v) { if (BAMD_DST_STREAM == 2) g_st16_nt(p, v); else g_st16(p, v); }
 #ifndef BAMD_UNSH_LD_NT
-#define BAMD_UNSH_LD_NT 1     // the fused unshuffle reads the planes (scratch / raw splits: read once) with non-temporal loads: -2 % (same-session A/B)
+#define BAMD_UNSH_LD_NT 0     // 1: the fused unshuffle reads the planes with non-temporal loads.  Round 2: -2 %.  Round 4, with the planes arriving as whole rows out of the ring decoder: plain loads are 3-6 % FASTER on every data set (profiles/r04i_dec_ab_dst_stores_plane_loads_nt.txt)
 #endif
 __device__ __forceinline__ uint32_t ld4_plane(const gu8* p) { return BAMD_UNSH_LD_NT ? g_ld4_nt(p) : g_ld4(p); }
 #ifndef BAMD_UNSH_QUAD8
 #define BAMD_UNSH_QUAD8 0      // typesize 8: the two 16-byte stores of a step re-dealt inside the quad (64 contiguous bytes per quad and instruction).  MEASURED: 5-6 % SLOWER on bench19 (4.76 -> 5.00, 4.34 -> 4.61 ms; two copies of each build taking turns, profiles/r03zb_ab_quad_dealt_typesize8_rejected.txt) - what paid for typesize 16 (16-byte pieces 64 bytes apart) does not for pieces 32 bytes apart
 #endif
+// Which 4 elements of a 256-element step a lane's plane dwords cover (byte offset into the plane).  Typesize 2 / 4: elements
+// 4 l .. 4 l + 3, i.e. T * 4 contiguous output bytes per lane and contiguous lanes - every store instruction is one contiguous run.
+// Typesize 8 (round 4): a lane's 32 output bytes are two 16-byte stores, and dealt that way every store instruction wrote only half of
+// each 32-byte sector - the fused unshuffle is bound by exactly those stores (profiles/r04h_*: leaving the LOADS out changed nothing,
+// leaving the stores out gave the kernel 1.5 of its 1.8 ms back; profiles/r04j_*: the same bytes as contiguous 1 KiB stores: -12 ... 16 %).
+// So lanes work in pairs: lane 2 i loads the dword of elements 4 i .. 4 i + 3, lane 2 i + 1 that of elements 128 + 4 i .. (each wave load still
+// covers two full 128-byte lines), the pair swaps halves (one DPP quad_perm per plane) and lane l then holds elements 2 l, 2 l + 1 of the
+// step's first 128 elements AND of its second 128: two stores of 1 KiB, each fully contiguous.
+#ifndef BAMD_UNSH_PAIR8
+#define BAMD_UNSH_PAIR8 1
+#endif
+template <int T>
+__device__ __forceinline__ uint32_t unsh_l4(int lane) {
+  if (T == 8 && BAMD_UNSH_PAIR8) return 4u * (((uint32_t)lane >> 1) + 32u * ((uint32_t)lane & 1u));
+  return 4u * (uint32_t)lane;
+}
 template <int T>
 __device__ __forceinline__ void unshuffle_store(gu8* dst, uint32_t e, int lane, const Rows<T>& x) {
+  if constexpr (T == 8 && BAMD_UNSH_PAIR8) {
+    const bool odd = (lane & 1) != 0;
+    // x.r[j] = plane j's bytes of elements 4 i .. 4 i + 3 (even lane) / 128 + 4 i .. (odd lane), y = the pair partner's.  First store: elements
+    // 2 l, 2 l + 1 = the even lane's low half (even l) or high half (odd l); second store: the odd lane's low / high half
+    const uint32_t sel0 = odd ? 0x0c0c0706u : 0x0c0c0100u, sel1 = odd ? 0x0c0c0302u : 0x0c0c0504u;
+    uint32_t h0[8], h1[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint32_t y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x.r[j], 0xB1, 0xf, 0xf, true);      // quad_perm [1, 0, 3, 2]: the pair partner's dword
+      h0[j] = __builtin_amdgcn_perm(y, x.r[j], sel0); h1[j] = __builtin_amdgcn_perm(y, x.r[j], sel1);       // (byte 0: element 2 l, byte 1: element 2 l + 1)
+    }
+    gu8* o = dst + (size_t)(e + 2u * (uint32_t)lane) * 8u;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      const uint32_t* h = s ? h1 : h0;
+      const uint32_t x01 = __builtin_amdgcn_perm(h[1], h[0], 0x05010400u), x23 = __builtin_amdgcn_perm(h[3], h[2], 0x05010400u);
+      const uint32_t x45 = __builtin_amdgcn_perm(h[5], h[4], 0x05010400u), x67 = __builtin_amdgcn_perm(h[7], h[6], 0x05010400u);
+      st16_dst(o + 1024 * s, make_uint4(__builtin_amdgcn_perm(x23, x01, 0x05040100u), __builtin_amdgcn_perm(x67, x45, 0x05040100u),
+                                        __builtin_amdgcn_perm(x23, x01, 0x07060302u), __builtin_amdgcn_perm(x67, x45, 0x07060302u)));
+    }
+    return;
+  }
   gu8* o = dst + (size_t)(e + 4u * (uint32_t)lane) * T;
   if constexpr (T == 2) {                            // elements 0..3 (2 bytes each): one 8-byte store per lane
     const uint32_t lo = __builtin_amdgcn_perm(x.r[1], x.r[0], 0x05010400u), hi = __builtin_amdgcn_perm(x.r[1], x.r[0], 0x07030602u);
@@ -475,48 +506,101 @@ __device__ void unshuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize,
     pr[j] = 0u; ob[j] = 0u;
     pl[j] = src + (size_t)j * pstride;
     if (w & SPAN_RAW) { pl[j] = uni_ptr(as_global(sds[j].in)); hi[j] = 0u; }
-    else if ((w & SPAN_SMALL) && hi[j] > lo[j]) { small |= 1u << j; pr[j] = g_ld4(pat + (size_t)j * SPAN_PAT + 4u * (uint32_t)lane); }
+    else if ((w & SPAN_SMALL) && hi[j] > lo[j]) { small |= 1u << j; pr[j] = g_ld4(pat + (size_t)j * SPAN_PAT + unsh_l4<T>(lane)); }
     else if ((w & SPAN_SELF) && hi[j] > lo[j]) {
       self |= 1u << j;
       ob[j] = uni(g_ld4(pat + (size_t)j * SPAN_PAT)) | ((31u - (uint32_t)__builtin_clz(uni(g_ld4(pat + (size_t)j * SPAN_PAT + 4)))) << 24);
     }
   }
-  // (Round 3 tried this loop as a software pipeline - two register sets, the next group's loads issued before the current group's
-  //  stores, one exact vmcnt per group, the recipe of dec_bulk.h: 10 % SLOWER kernels on every data set,
-  //  profiles/r03i_dec_ab_pipelined_unshuffle_rejected.txt.  Unlike the decoder's steps, consecutive groups here have no data
-  //  dependence, so the plain form already keeps 4 KiB of loads in flight per wave and the memory system, not the wave, is the limit.)
   // the register rows are in before the loop: otherwise the compiler, which cannot tell whether they are still in flight,
   // waits for vmcnt(0) at the top of EVERY iteration - i.e. for the previous iteration's stores
   __builtin_amdgcn_s_waitcnt(0);
   uint32_t e = 0;
-  // 4 steps (1024 elements) per iteration: all loads are issued before the first store.  Span bounds are
-  // multiples of 1024, so one decision per plane and iteration picks the plane, the pattern table or the register.
-  for (; e + 1024u <= N; e += 1024u) {
-    Rows<T> a, b, c, d;
-    const uint32_t l4 = 4u * (uint32_t)lane;
+  // A group = 4 steps (1024 elements): all its loads are issued before its first store.  Span bounds are multiples of 1024, so one
+  // decision per plane and group picks the plane, the pattern table or the register.
+  const uint32_t l4 = unsh_l4<T>(lane);
+  auto load_group = [&](Rows<T> (&g)[4], uint32_t eg) {
 #pragma unroll
     for (int j = 0; j < T; j++) {
-      const bool in_span = e >= lo[j] && e < hi[j];            // wave-uniform
+      const bool in_span = eg >= lo[j] && eg < hi[j];            // wave-uniform
       const bool reg = in_span && ((small >> j) & 1u);
-      if (reg) { a.r[j] = b.r[j] = c.r[j] = d.r[j] = pr[j]; }   // scalar branch: no load at all
+      if (reg) { g[0].r[j] = g[1].r[j] = g[2].r[j] = g[3].r[j] = pr[j]; }   // scalar branch: no load at all
       else if (in_span && ((self >> j) & 1u)) {                 // the plane's own period in front of the span, address per lane
         const uint32_t o = ob[j] & 0xffffffu, m = (1u << (ob[j] >> 24)) - 1u;
-        const uint32_t q = e + l4 - o;
-        a.r[j] = ld4_plane(pl[j] + o + (q & m)); b.r[j] = ld4_plane(pl[j] + o + ((q + 256u) & m));
-        c.r[j] = ld4_plane(pl[j] + o + ((q + 512u) & m)); d.r[j] = ld4_plane(pl[j] + o + ((q + 768u) & m));
+        const uint32_t q = eg + l4 - o;
+        g[0].r[j] = ld4_plane(pl[j] + o + (q & m)); g[1].r[j] = ld4_plane(pl[j] + o + ((q + 256u) & m));
+        g[2].r[j] = ld4_plane(pl[j] + o + ((q + 512u) & m)); g[3].r[j] = ld4_plane(pl[j] + o + ((q + 768u) & m));
       } else {
-        const gu8* p = in_span ? pat + (size_t)j * SPAN_PAT + (e & (SPAN_PAT - 1u)) : pl[j] + e;
-        a.r[j] = ld4_plane(p + l4); b.r[j] = ld4_plane(p + l4 + 256u); c.r[j] = ld4_plane(p + l4 + 512u); d.r[j] = ld4_plane(p + l4 + 768u);
+        const gu8* p = in_span ? pat + (size_t)j * SPAN_PAT + (eg & (SPAN_PAT - 1u)) : pl[j] + eg;
+        g[0].r[j] = ld4_plane(p + l4); g[1].r[j] = ld4_plane(p + l4 + 256u); g[2].r[j] = ld4_plane(p + l4 + 512u); g[3].r[j] = ld4_plane(p + l4 + 768u);
       }
     }
-    unshuffle_store<T>(dst, e, lane, a); unshuffle_store<T>(dst, e + 256u, lane, b);
-    unshuffle_store<T>(dst, e + 512u, lane, c); unshuffle_store<T>(dst, e + 768u, lane, d);
+  };
+  auto store_group = [&](const Rows<T> (&g)[4], uint32_t eg) {
+    unshuffle_store<T>(dst, eg, lane, g[0]); unshuffle_store<T>(dst, eg + 256u, lane, g[1]);
+    unshuffle_store<T>(dst, eg + 512u, lane, g[2]); unshuffle_store<T>(dst, eg + 768u, lane, g[3]);
+  };
+#ifndef BAMD_UNSH_PIPE
+#define BAMD_UNSH_PIPE 0      // two groups in flight: built in round 4 with 128 registers to spend, and 32 % SLOWER (5.55 against 4.20 ms, profiles/r04g_dec_ab_bisect_walk_pipe_rowfill.txt): the span branches around the loads leave the compiler no exact vmcnt (waits of vmcnt(0..3) in the ISA) and the second register set spills
+#endif
+  if (BAMD_UNSH_PIPE && T <= 8) {
+    // Software pipeline, two register sets: the loads of group g + 1 are issued BEFORE the stores of group g.  gfx950 has one in-order
+    // counter for vector loads and stores: with "load a group, store it, load the next" every group's loads queue up behind the
+    // acknowledgement of the previous group's stores - load latency and store latency add up (1.0 M cycles per 1 MiB block in
+    // profiles/r04a_dec_phase_ring8k_first.txt, and the fused unshuffle is 1.8 ms of the 4.2 ms kernel: profiles/r04c_*).  (Round 3
+    // tried this at 96 registers, where it spilled: 10 % slower, profiles/r03i_dec_ab_pipelined_unshuffle_rejected.txt.)
+    Rows<T> A[4], B[4];
+    if (N >= 1024u) load_group(A, 0u);
+    for (; e + 2048u <= N; e += 2048u) {
+      load_group(B, e + 1024u);
+      store_group(A, e);
+      // the group behind B - or, at the end, B's own once more (dropped): the same number of loads in every iteration
+      load_group(A, e + 3072u <= N ? e + 2048u : e + 1024u);
+      store_group(B, e + 1024u);
+    }
+    if (e + 1024u <= N) { store_group(A, e); e += 1024u; }      // an odd number of groups: A holds the last one
+  } else {
+    // (the round-3 form, spelled out: one group at a time)
+#ifdef BAMD_UNSH_NOSTORE
+    uint32_t acc_ = 0;
+#endif
+    for (; e + 1024u <= N; e += 1024u) {
+      Rows<T> a, b, c, d;
+#pragma unroll
+      for (int j = 0; j < T; j++) {
+        const bool in_span = e >= lo[j] && e < hi[j];            // wave-uniform
+#ifdef BAMD_UNSH_NOLOAD         // timing experiment (wrong bytes on purpose): the stores without the loads
+        const bool reg = true;
+#else
+        const bool reg = in_span && ((small >> j) & 1u);
+#endif
+        if (reg) { a.r[j] = b.r[j] = c.r[j] = d.r[j] = pr[j]; }   // scalar branch: no load at all
+        else if (in_span && ((self >> j) & 1u)) {                 // the plane's own period in front of the span, address per lane
+          const uint32_t o = ob[j] & 0xffffffu, m = (1u << (ob[j] >> 24)) - 1u;
+          const uint32_t q = e + l4 - o;
+          a.r[j] = ld4_plane(pl[j] + o + (q & m)); b.r[j] = ld4_plane(pl[j] + o + ((q + 256u) & m));
+          c.r[j] = ld4_plane(pl[j] + o + ((q + 512u) & m)); d.r[j] = ld4_plane(pl[j] + o + ((q + 768u) & m));
+        } else {
+          const gu8* p = in_span ? pat + (size_t)j * SPAN_PAT + (e & (SPAN_PAT - 1u)) : pl[j] + e;
+          a.r[j] = ld4_plane(p + l4); b.r[j] = ld4_plane(p + l4 + 256u); c.r[j] = ld4_plane(p + l4 + 512u); d.r[j] = ld4_plane(p + l4 + 768u);
+        }
+      }
+#ifdef BAMD_UNSH_NOSTORE        // timing experiment (wrong bytes on purpose): the loads without the stores
+      { uint32_t x_ = 0; for (int j = 0; j < T; j++) x_ ^= a.r[j] ^ b.r[j] ^ c.r[j] ^ d.r[j]; acc_ ^= x_; }
+#else
+      unshuffle_store<T>(dst, e, lane, a); unshuffle_store<T>(dst, e + 256u, lane, b);
+      unshuffle_store<T>(dst, e + 512u, lane, c); unshuffle_store<T>(dst, e + 768u, lane, d);
+#endif
+    }
+#ifdef BAMD_UNSH_NOSTORE
+    if (acc_ == 0x12345u) g_st4(dst + l4, acc_);
+#endif
   }
   // behind the last multiple of 1024 nothing is skipped
   for (; e + 256u <= N; e += 256u) {
     Rows<T> x;
 #pragma unroll
-    for (int j = 0; j < T; j++) x.r[j] = g_ld4(pl[j] + e + 4u * (uint32_t)lane);
+    for (int j = 0; j < T; j++) x.r[j] = g_ld4(pl[j] + e + l4);
     unshuffle_store<T>(dst, e, lane, x);
   }
   // tail: fewer than 256 elements, then the bytes that do not form a whole element (never a split block: src is the scratch)
@@ -645,14 +729,14 @@ __device__ __forceinline__ void unshuffle_plain_T(const gu8* src, gu8* dst, uint
 #pragma unroll
     for (int s = 0; s < STEPS; s++)
 #pragma unroll
-      for (int j = 0; j < T; j++) x[s].r[j] = ld4_plane(src + (size_t)j * N + e + 256u * s + 4u * (uint32_t)lane);
+      for (int j = 0; j < T; j++) x[s].r[j] = ld4_plane(src + (size_t)j * N + e + 256u * s + unsh_l4<T>(lane));
 #pragma unroll
     for (int s = 0; s < STEPS; s++) unshuffle_store<T>(dst, e + 256u * s, lane, x[s]);
   }
   for (; e + 256u <= N; e += 256u) {
     Rows<T> x;
 #pragma unroll
-    for (int j = 0; j < T; j++) x.r[j] = g_ld4(src + (size_t)j * N + e + 4u * (uint32_t)lane);
+    for (int j = 0; j < T; j++) x.r[j] = g_ld4(src + (size_t)j * N + e + unsh_l4<T>(lane));
     unshuffle_store<T>(dst, e, lane, x);
   }
 #pragma unroll
@@ -760,6 +844,9 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
   if (lane == 0) old = __hip_atomic_fetch_add(&blk_done[gb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   old = (uint32_t)__builtin_amdgcn_readlane((int)old, 0);
   if (old + 1u != nstreams) return;
+#ifdef BAMD_DEC_NOUNSH
+  return;               // timing experiment (wrong bytes on purpose): what the fused unshuffle costs the kernel
+#endif
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // buffer_inv sc1: this CU's L1 forgets the block's scratch lines
   const size_t boff = (size_t)uni((uint32_t)b->blk) * (size_t)uni((uint32_t)c->blocksize);
   const bool split = spans && nstreams == uni((uint32_t)c->typesize);
@@ -777,7 +864,7 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
 }
 
 #ifndef BAMD_DEC_MINWAVES
-#define BAMD_DEC_MINWAVES 5   // waves per SIMD (96 VGPRs).  Round 2: 6 = 5 < 7 < 8 (spills cost more than occupancy gives).  Round 3, with the pipelined loops of dec_bulk.h and the fused unshuffle (both keep two register sets in flight): 5 beats 6 by 4-6 % on every data set (profiles/r03h_dec_ab_rowfill_off.txt)
+#define BAMD_DEC_MINWAVES 4   // waves per SIMD.  Round 4: the 9.25 KiB of LDS a wave owns (dec_ring.h) allow 16 - 17 waves per CU anyway, and at 96 registers the ring decoder spills inside its step (6.7 against 4.5 ms, profiles/r04b_dec_ab_ring_variants.txt).  Before:  Round 2: 6 = 5 < 7 < 8 (spills cost more than occupancy gives).  Round 3, with the pipelined loops of dec_bulk.h and the fused unshuffle (both keep two register sets in flight): 5 beats 6 by 4-6 % on every data set (profiles/r03h_dec_ab_rowfill_off.txt)
 #endif                       // 6 = 5 (5.90 / 5.95 ms) < 7 (6.33) < 8 (7.0): spills cost more than occupancy gives
 constexpr int DEC_WAVES_PER_CU = 4 * BAMD_DEC_MINWAVES;
 // Persistent launch: the grid is sized to what the chip can hold (engine.hip) and every wave pulls stream

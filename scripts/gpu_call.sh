@@ -7,7 +7,7 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-TAG=${TAG:-r03}
+TAG=${TAG:-r04}
 make -C oracle oracle > /dev/null 2>&1
 
 bench_cfg() {   # bench_cfg <cfg> [extra bench.py args]: one short JSON line without the CPU leg

@@ -9,7 +9,8 @@ export TMPDIR=/tmp
 export DATA=${DATA:-bench19} CHUNKS=${CHUNKS:-128} CODEC=${CODEC:-zstd} CLEVEL=${CLEVEL:-3} KFILTER=${KFILTER:-k_zstd}
 i=0
 for PMC in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES" \
-           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM_RD GRBM_GUI_ACTIVE"; do
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM_RD GRBM_GUI_ACTIVE" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS"; do
   i=$((i+1))
   timeout 150 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d gpurun_out/zpmc_$i -o pmc -- python scripts/dec_sweep.py > gpurun_out/zpmc_$i.log 2>&1
   f=$(find gpurun_out/zpmc_$i -name "*counter_collection.csv" | head -1)
