@@ -189,36 +189,54 @@ __device__ __forceinline__ void dr_match(RingIO& io, uint32_t& op, uint32_t off,
     op = mpos + done;
     dr_flush_rows(io, op);
   }
-  const bool pow2 = (off & (off - 1u)) == 0u && off <= DR_ROW;            // the period divides a row: every row of the match is the same
+#ifndef BAMD_DR_ROWFILL
+#define BAMD_DR_ROWFILL 1
+#endif
+  // Power-of-two periods up to a row, long matches (byte planes of a few significant bits decode into dozens of 4 KiB runs of period 128;
+  // constant planes when spans are off).  The general loop below doubles its stride from `off` up to a row - five dependent LDS copies
+  // before the first full row, 240 k of a 450 k-cycle stream on bench19's planes 2 / 6.  Here: ONE copy of the period (so that two
+  // periods lie back to back), then every lane reads its 16 bytes of any later position straight out of those periods
+  // (plane[q] = plane[b + ((q - b) & (per - 1))]: unaligned 16-byte LDS reads), the piece up to the next row boundary and the one behind
+  // the last are one read + one write each, and the rows in between are the SAME registers stored to the ring and to global memory.
+  if (BAMD_DR_ROWFILL && (off & (off - 1u)) == 0u && off <= DR_ROW && len >= 2u * DR_ROW && mpos - off >= dr_near_lo(io, mpos + off)) {
+    if (off >= 64u) { dr_copy_chunk(io, mpos, mpos - off, off, false, lane); done = off; op = mpos + done; dr_flush_rows(io, op); }
+    const uint32_t per = off < 64u ? 32u : off, pm = per - 1u, b0 = mpos - off, l16 = 16u * (uint32_t)lane;     // (off < 64: the head above wrote 64 bytes, off divides 32)
+    // 16 bytes of plane position q out of the two periods that end closest in front of `front` (everything written so far is periodic)
+    auto base_for = [&](uint32_t front) { const uint32_t t = front - per - 16u; return t - ((t - b0) & pm); };
+    auto fill = [&](uint32_t pos, uint32_t c) {            // plane positions [pos, pos + c), c <= DR_ROW: one read and one write per lane
+      const uint32_t b = base_for(pos), n16 = c >> 4, t0 = c & ~15u;
+      DR_SYNC();
+      uint4 v = make_uint4(0u, 0u, 0u, 0u); uint32_t tb = 0u;
+      if ((uint32_t)lane < n16) v = dr_get16(io.hist, b + ((pos + l16 - b) & pm));
+      if (t0 + (uint32_t)lane < c) tb = io.hist[(b + ((pos + t0 + (uint32_t)lane - b) & pm)) & DR_MASK];
+      DR_SYNC();
+      if ((uint32_t)lane < n16) dr_put16(io.hist, pos + l16, v);
+      if (t0 + (uint32_t)lane < c) io.hist[(pos + t0 + (uint32_t)lane) & DR_MASK] = (uint8_t)tb;
+      DR_SYNC();
+    };
+    uint32_t pos = mpos + done;
+    const uint32_t end = mpos + len, mis = pos & (DR_ROW - 1u);
+    if (mis) { const uint32_t c = DR_ROW - mis; fill(pos, c); pos += c; op = pos; dr_flush_rows(io, op); }      // (len >= 2 rows: the boundary lies inside the match)
+    if (end - pos >= DR_ROW) {                              // pos is a row boundary and everything below it has been flushed
+      const uint32_t b = base_for(pos);
+      DR_SYNC();
+      const uint4 row = dr_get16(io.hist, b + ((pos + l16 - b) & pm));
+      DR_SYNC();
+      for (; end - pos >= DR_ROW; pos += DR_ROW) {
+        l_st16(io.hist + ((pos + l16) & DR_MASK), row);
+        if (!(BAMD_DR_SKIP & 8)) g_st16(io.out + pos + l16, row);
+      }
+      io.flushed = pos; op = pos;
+      DR_SYNC();
+    }
+    if (end > pos) { fill(pos, end - pos); op = end; dr_flush_rows(io, op); }
+    return;
+  }
   while (done < len) {
     const uint32_t pos = mpos + done, rem = len - done;
     while (off_e < DR_ROW && 2u * off_e <= off + done) off_e *= 2u;      // the history written so far is periodic: lengthen the stride
     uint32_t c = rem < DR_ROW ? rem : DR_ROW;
     if (c > off_e) c = off_e;
-#ifndef BAMD_DR_ROWFILL
-#define BAMD_DR_ROWFILL 1
-#endif
-    if (BAMD_DR_ROWFILL && pow2 && off_e == DR_ROW && rem >= 2u * DR_ROW) {
-      // Identical rows (byte planes of a few significant bits decode into dozens of 4 KiB runs of period 128; constant planes when
-      // spans are off): up to the next row boundary as usual, then ONE row out of the ring into registers, and every further row
-      // is a ring store + a global store of those registers - no reads, no flush pass over the ring
-      const uint32_t mis = pos & (DR_ROW - 1u);
-      if (mis) c = DR_ROW - mis;
-      else if (io.flushed == pos && pos - DR_ROW >= dr_near_lo(io, pos + DR_ROW)) {
-        DR_SYNC();
-        const uint32_t l16 = 16u * (uint32_t)lane;
-        const uint4 row = l_ld16(io.hist + ((pos - DR_ROW + l16) & DR_MASK));
-        uint32_t p = pos;
-        for (; mpos + len - p >= DR_ROW; p += DR_ROW) {
-          l_st16(io.hist + ((p + l16) & DR_MASK), row);
-          if (!(BAMD_DR_SKIP & 8)) g_st16(io.out + p + l16, row);
-        }
-        io.flushed = p;
-        done = p - mpos; op = p;
-        DR_SYNC();
-        continue;
-      }
-    }
     const uint32_t src = pos - off_e;
     const bool far = src < dr_near_lo(io, pos + c);
     if (far && src + c > io.flushed) c = io.flushed - src;              // (src < near_lo <= flushed: at least one byte)

@@ -388,3 +388,50 @@ def test_ring_steps_take_reference_streams(emu, oracle, ref):
         for pos in rng.integers(0, s.size, 1 + trial % 3):
             s[pos] ^= 1 << int(rng.integers(0, 8))
         _same_as_oracle(emu, oracle, LZ4, s, n)
+
+
+def test_long_periodic_matches_take_the_row_path(emu, oracle):
+    """dec_ring.h: dr_match's path for power-of-two periods (one copy of the period, 16-byte pieces read out of two periods, identical rows
+    stored from registers): every period 1 ... 1024, matches of 2 ... 40 rows starting at odd plane positions, several in one stream (the
+    ring wraps, rows are flushed in between), and the neighbours of the powers of two (which must NOT take it) - the oracle's bytes."""
+    rng = np.random.default_rng(77)
+    offs = [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 3, 48, 96, 127, 129, 1000, 1023, 1025, 2048]
+    for trial, off in enumerate(offs * (2 if FULL else 1)):
+        stream = bytearray()
+        produced = 0
+        first = max(off, 5) + int(rng.integers(0, 700))
+        stream += _lz4_seq(rng.integers(0, 256, first, dtype=np.uint8).tobytes(), off, int(rng.integers(2048, 6000)))
+        nseq = 3 if off <= 1024 else 2
+        plan = [(first, None)]
+        # parse back what we wrote to know the output size (simplest: let the oracle say)
+        for k in range(nseq):
+            lit = rng.integers(0, 256, int(rng.integers(0, 90)), dtype=np.uint8).tobytes()
+            o2 = off if k % 2 == 0 else int(rng.choice([1, 4, 128, 256, 1024]))
+            stream += _lz4_seq(lit, o2, int(rng.integers(2048, 42000 if k == 1 else 9000)))
+        stream += _lz4_tail(rng.integers(0, 256, 12, dtype=np.uint8).tobytes())
+        s = np.frombuffer(bytes(stream), np.uint8)
+        # the output size: decode once with the oracle into a generous room, shrink to what it produced
+        big = 200000
+        out = np.zeros(big, np.uint8)
+        oracle.orc_lz4_decompress.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        # LZ4_decompress_safe wants the exact size: find it by summing the sequences
+        def total(b):
+            i = 0; n = 0
+            while True:
+                t = b[i]; i += 1; ll = t >> 4
+                if ll == 15:
+                    while True:
+                        e = b[i]; i += 1; ll += e
+                        if e != 255: break
+                i += ll; n += ll
+                if i >= len(b): return n
+                i += 2; ml = t & 15
+                if ml == 15:
+                    while True:
+                        e = b[i]; i += 1; ml += e
+                        if e != 255: break
+                n += ml + 4
+        cap = total(bytes(stream))
+        _same_as_oracle(emu, oracle, LZ4, s, cap)
+        r, got = _decode(emu, LZ4, s, cap)
+        assert r == cap, (off, r, cap)
