@@ -511,6 +511,9 @@ __device__ __forceinline__ uint32_t dr_step(RingIO& io, uint32_t& ip, uint32_t& 
     const uint32_t po16 = (q == np16 - 1u) ? mlen - 16u : 16u * q;
     const uint32_t po8 = q ? mlen - 8u : 0u, po4 = q ? mlen - 4u : 0u;
     uint4 v16 = make_uint4(0, 0, 0, 0); uint64_t v8 = 0; uint32_t v4 = 0;
+    // (Tried in round 4: the far pieces kept in their registers and stored into the ring behind the NEXT step's parse, so that their round
+    //  trip runs under it.  5-9 % SLOWER on every data set, typesize 2 included where one step in two has a far source - the state it
+    //  carries across steps costs more than the wait: profiles/r04n_dec_ab_deferred_far_pieces_rejected.txt.)
     if (anyfar) {                                              // (wave-uniform: a step without far sources never waits for memory)
       const gu8* sg = io.out + spos;
       BAMD_MEM_SYNC();
