@@ -24,6 +24,7 @@ enum : uint32_t {
   CH_SKIP = 8u,        // chunk needs no device work (error found on host, or empty)
   CH_FUSED_UNSHUF = 16u,  // decompress: the decode kernel itself unshuffles each block when its last stream is done
   CH_FUSED_SHUF = 32u,    // compress: the encode kernel itself shuffles each block (queue task) before its streams are encoded
+  CH_FUSED_BITUNSH = 64u, // decompress, bitshuffle chunks: the wave that completes a block's last stream bit-unshuffles the block (k_decode.hip)
 };
 
 struct ChunkDesc {

@@ -309,6 +309,9 @@ static bool fused_typesize(int T) {
   static const bool wide = !(getenv("BLOSC_AMD_FUSE_T") && atoi(getenv("BLOSC_AMD_FUSE_T")) == 0);
   return T == 8 || T == 4 || (wide && (T == 2 || T == 16));
 }
+// BLOSC_AMD_FUSE_BIT=0: bitshuffle chunks keep the stand-alone k_bitunshuffle pass (the state before round 4: A/B switch)
+static bool fuse_bit_enabled() { static const bool on = !(getenv("BLOSC_AMD_FUSE_BIT") && atoi(getenv("BLOSC_AMD_FUSE_BIT")) == 0); return on; }
+static bool bitunshuffle_fused_host(int T) { return T == 1 || T == 2 || T == 4; }
 static bool fuse_enabled() { static const bool on = !(getenv("BLOSC_AMD_FUSE") && atoi(getenv("BLOSC_AMD_FUSE")) == 0); return on; }
 
 // the stream a call runs on: the caller's, or - host buffers and no stream named - the context's own
@@ -805,6 +808,8 @@ static void filter_tiles(ChunkDesc& c, bool& any_shuf, bool& any_bit, int& tiles
     any_shuf = true;
     int t = (N + shuffle_tile_elems(T) - 1) / shuffle_tile_elems(T); if (t < 1) t = 1;
     if (t > tiles_shuf) tiles_shuf = t;
+  } else if ((c.mode & CH_BITSHUFFLE) && bitunshuffle_fused_host(T) && fuse_enabled() && fuse_bit_enabled() && may_fuse && !zfmt) {
+    c.mode |= CH_FUSED_BITUNSH;      // round 4: the decode kernel bit-unshuffles every block when its last stream is done (k_decode.hip: bitunshuffle_block_wave)
   } else if (c.mode & CH_BITSHUFFLE) {
     any_bit = true;
     int t = (N + bitshuffle_tile_elems(T) - 1) / bitshuffle_tile_elems(T); if (t < 1) t = 1;

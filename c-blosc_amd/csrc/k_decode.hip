@@ -779,6 +779,97 @@ __device__ __forceinline__ void fused_unshuffle_own_block(const ChunkDesc* c, co
                         uni((uint32_t)b->bsize), (int)uni((uint32_t)c->typesize), lane);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused bit-unshuffle of one block by ONE wavefront (typesize 1, 2 or 4), round 4: the wave that completes a block's last stream runs it
+// out of its XCD's L2, exactly like the byte unshuffle above - there is no k_bitunshuffle pass over the batch any more (3.9 ms per 8 GiB on
+// config #3, 2 x nbytes of traffic that SURVEY 8d says must not be credited).  Inverse of blosc_internal_bitshuffle
+// (blosc/shuffle.c:393-443, bitshuffle-generic.c:125-139, :208-220): the filtered block is 8 T bit rows of N / 8 bytes (row 8 j + b = bit b
+// of byte j of every element).  Per pass of 2048 elements every lane owns 32 of them: one dword of every bit row (a wave load reads 256
+// contiguous bytes of a row), 8 x 8 bit-matrix transposes in registers (k_filters.hip: bit_transpose8), its 32 T element bytes into the
+// wave's LDS (stream decoding is over: the rings are free) in chunks 16 bytes apart (bank-conflict-free 128-bit accesses), and out again as
+// 16-byte pieces in element order: every store instruction writes 1 KiB of contiguous destination.  The reference's corner rules are kept:
+// filter not applied when bsize < T (blosc.c:608-609), whole block copied when the element count is not a multiple of 8
+// (shuffle.c:412-414), trailing bsize mod T bytes copied.
+// ---------------------------------------------------------------------------------------------
+template <int T>
+__device__ __forceinline__ void bitunshuffle_pass(lu8* S, const gu8* src, gu8* dst, uint32_t rowlen, uint32_t e0, uint32_t nchunks, int lane) {
+  constexpr uint32_t CB = 32u * T, CS = CB + 16u, NDW = CB / 4u;
+  const uint32_t m0 = e0 >> 3, t = (uint32_t)lane;
+  if (t < nchunks) {
+    uint32_t w[NDW];
+#pragma unroll
+    for (uint32_t k = 0; k < NDW; k++) w[k] = 0u;
+#pragma unroll
+    for (int j = 0; j < T; j++) {
+      uint32_t rw[8];
+#pragma unroll
+      for (int b = 0; b < 8; b++) rw[b] = g_ld4(src + (size_t)(8 * j + b) * rowlen + m0 + 4u * t);
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        uint64_t v = 0;
+#pragma unroll
+        for (int b = 0; b < 8; b++) v |= (uint64_t)((rw[b] >> (8 * g)) & 0xffu) << (8 * b);
+        v = bit_transpose8(v);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const int idx = (8 * g + k) * T + j;
+          w[idx >> 2] |= (uint32_t)((v >> (8 * k)) & 0xff) << (8 * (idx & 3));
+        }
+      }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < NDW / 4u; k++) l_st16(S + t * CS + 16u * k, make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]));
+  }
+  LDS_ORDER(); BAMD_LDS_SYNC();
+  gu8* out = dst + (size_t)e0 * T;
+  const uint32_t npieces = nchunks * CB / 16u;
+#pragma unroll
+  for (uint32_t i = 0; i < 2u * T; i++) {
+    const uint32_t q = (uint32_t)lane + 64u * i, off = 16u * q, c = off / CB;
+    if (q < npieces) st16_dst(out + off, l_ld16(S + c * CS + (off - c * CB)));
+  }
+  LDS_ORDER(); BAMD_LDS_SYNC();
+}
+template <int T>
+__device__ void bitunshuffle_block_wave_T(lu8* S, const gu8* src, gu8* dst, uint32_t bsize, int lane) {
+  const uint32_t N = bsize / T;
+  if (bsize < T || (N & 7u)) {                         // not filtered at all / copied verbatim by the filter
+    for (uint32_t k = 16u * (uint32_t)lane; k < bsize; k += 1024u) {
+      if (k + 16u <= bsize) g_st16(dst + k, g_ld16(src + k));
+      else for (uint32_t t = k; t < bsize; t++) dst[t] = src[t];
+    }
+    return;
+  }
+  const uint32_t rowlen = N >> 3;
+  uint32_t e0 = 0;
+  for (; e0 + 2048u <= N; e0 += 2048u) bitunshuffle_pass<T>(S, src, dst, rowlen, e0, 64u, lane);
+  if (N - e0 >= 32u) { const uint32_t nch = (N - e0) >> 5; bitunshuffle_pass<T>(S, src, dst, rowlen, e0, nch, lane); e0 += 32u * nch; }
+  // fewer than 32 elements left (a multiple of 8): one byte of every bit row per lane, eight elements each
+  if ((uint32_t)lane < ((N - e0) >> 3)) {
+    const uint32_t m = (e0 >> 3) + (uint32_t)lane;
+#pragma unroll
+    for (int j = 0; j < T; j++) {
+      uint64_t v = 0;
+#pragma unroll
+      for (int b = 0; b < 8; b++) v |= (uint64_t)src[(size_t)(8 * j + b) * rowlen + m] << (8 * b);
+      v = bit_transpose8(v);
+#pragma unroll
+      for (int k = 0; k < 8; k++) dst[(size_t)(8u * m + (uint32_t)k) * T + (uint32_t)j] = (uint8_t)(v >> (8 * k));
+    }
+  }
+  for (uint32_t k = N * T + (uint32_t)lane; k < bsize; k += 64u) dst[k] = src[k];
+}
+__device__ __forceinline__ bool bitunshuffle_fused_T(int T) { return T == 1 || T == 2 || T == 4; }
+__device__ __attribute__((noinline)) void bitunshuffle_block_wave(volatile uint32_t* lds_, const uint8_t* src_, uint8_t* dst_, uint32_t bsize_, int typesize_, int lane) {
+  const uint64_t lv = (uint64_t)lds_;
+  lu8* S = (lu8*)(BAMD_LAS uint32_t*)(volatile uint32_t*)(((uint64_t)uni((uint32_t)(lv >> 32)) << 32) | uni((uint32_t)lv));
+  const gu8* src = uni_ptr(as_global(src_)); gu8* dst = uni_ptr(as_global(dst_));
+  const uint32_t bsize = uni(bsize_); const int T = (int)uni((uint32_t)typesize_);
+  if (T == 4) bitunshuffle_block_wave_T<4>(S, src, dst, bsize, lane);
+  else if (T == 2) bitunshuffle_block_wave_T<2>(S, src, dst, bsize, lane);
+  else bitunshuffle_block_wave_T<1>(S, src, dst, bsize, lane);
+}
+
 // One stream, start to finish.  Deliberately NOT inlined into the queue loop below: with the decoders
 // inlined, the compiler restructured the loop with partial exec masks and re-read the ticket with lane 0
 // masked off (an endless loop on stream 0).  A real call keeps the loop's control flow trivial.
@@ -830,7 +921,7 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
     if (plane_cost) atomicAdd(plane_cost + ((sid - (uint32_t)b->first_stream) & 255u), (uint32_t)((__builtin_amdgcn_s_memtime() - cost_t0) >> 10));
   }
   // ---- fused unshuffle: the wave that completes a block's LAST stream transposes the block ----
-  if (!(mode & CH_FUSED_UNSHUF) || got != want) return;
+  if (!(mode & (CH_FUSED_UNSHUF | CH_FUSED_BITUNSH)) || got != want) return;
   if (spans && lane == 0) {
     spans[2 * (size_t)sid] = raw_in_place ? SPAN_RAW : (sp.lo | ((sp.hi && sp.off <= 256u) ? SPAN_SMALL : 0u) | ((sp.hi && sp.off > SPAN_PAT) ? SPAN_SELF : 0u));
     spans[2 * (size_t)sid + 1] = sp.hi;
@@ -849,6 +940,10 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
 #endif
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // buffer_inv sc1: this CU's L1 forgets the block's scratch lines
   const size_t boff = (size_t)uni((uint32_t)b->blk) * (size_t)uni((uint32_t)c->blocksize);
+  if (mode & CH_FUSED_BITUNSH) {
+    bitunshuffle_block_wave(scr, c->filt + (size_t)uni((uint32_t)b->blk) * filt_block_stride(*c), c->dst + boff, uni((uint32_t)b->bsize), (int)uni((uint32_t)c->typesize), lane);
+    return;
+  }
   const bool split = spans && nstreams == uni((uint32_t)c->typesize);
   const uint32_t fs = uni((uint32_t)b->first_stream);
 #ifdef BAMD_PROFILE_DECODE

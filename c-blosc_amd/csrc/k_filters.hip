@@ -379,6 +379,7 @@ __device__ void bitfilter_block(const ChunkDesc* chunks, const BlockDesc* blocks
   const BlockDesc b = blocks[blockIdx.x];
   const ChunkDesc& c = chunks[b.chunk];
   if (!(c.mode & CH_BITSHUFFLE) || (c.mode & (CH_MEMCPYED | CH_SKIP))) return;
+  if (DIR == 1 && (c.mode & CH_FUSED_BITUNSH)) return;        // the decode kernel has unshuffled this chunk's blocks itself (k_decode.hip)
   const int bsize = b.bsize;
   const int T = c.typesize;
   const size_t boff = (size_t)b.blk * c.blocksize;
@@ -514,6 +515,7 @@ __global__ __launch_bounds__(FT_THREADS, 2) void k_bitfilter_fast(const ChunkDes
   const BlockDesc b = blocks[blockIdx.x];
   const ChunkDesc& c = chunks[b.chunk];
   if (!(c.mode & CH_BITSHUFFLE) || (c.mode & (CH_MEMCPYED | CH_SKIP))) return;
+  if (DIR == 1 && (c.mode & CH_FUSED_BITUNSH)) return;
   const int T = c.typesize, bsize = b.bsize;
   if (!bit_fast_T(T) || bsize < T) return;
   const int N = bsize / T;
