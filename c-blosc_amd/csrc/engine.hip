@@ -376,7 +376,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
     c.first_block = (int32_t)blocks.size(); c.first_stream = (int32_t)streams.size();
     if (memcpyed) c.mode |= CH_MEMCPYED;
     else if (p.doshuffle == 1 && T > 1) { c.mode |= CH_SHUFFLE; if (fused_typesize(T) && fuse_enabled() && !st.single_queue) c.mode |= CH_FUSED_SHUF; }
-    else if (p.doshuffle == 2) c.mode |= CH_BITSHUFFLE;
+    else if (p.doshuffle == 2) { c.mode |= CH_BITSHUFFLE; if (bitunshuffle_fused_host(T) && fuse_enabled() && fuse_bit_enabled() && !st.single_queue) c.mode |= CH_FUSED_SHUF; }
     live[(size_t)i] = 1;
     results[i] = 0;
     if (!device_ptrs) { io_src = align_up(io_src, 256) + (size_t)nb; io_dst = align_up(io_dst, 256) + destsize; }

@@ -380,6 +380,7 @@ __device__ void bitfilter_block(const ChunkDesc* chunks, const BlockDesc* blocks
   const ChunkDesc& c = chunks[b.chunk];
   if (!(c.mode & CH_BITSHUFFLE) || (c.mode & (CH_MEMCPYED | CH_SKIP))) return;
   if (DIR == 1 && (c.mode & CH_FUSED_BITUNSH)) return;        // the decode kernel has unshuffled this chunk's blocks itself (k_decode.hip)
+  if (DIR == 0 && (c.mode & CH_FUSED_SHUF)) return;           // the encode kernel bitshuffles this chunk's blocks itself (enc_shuffle.h)
   const int bsize = b.bsize;
   const int T = c.typesize;
   const size_t boff = (size_t)b.blk * c.blocksize;
@@ -516,6 +517,7 @@ __global__ __launch_bounds__(FT_THREADS, 2) void k_bitfilter_fast(const ChunkDes
   const ChunkDesc& c = chunks[b.chunk];
   if (!(c.mode & CH_BITSHUFFLE) || (c.mode & (CH_MEMCPYED | CH_SKIP))) return;
   if (DIR == 1 && (c.mode & CH_FUSED_BITUNSH)) return;
+  if (DIR == 0 && (c.mode & CH_FUSED_SHUF)) return;
   const int T = c.typesize, bsize = b.bsize;
   if (!bit_fast_T(T) || bsize < T) return;
   const int N = bsize / T;

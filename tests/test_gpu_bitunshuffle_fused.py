@@ -55,3 +55,27 @@ def test_mixed_batch_of_fused_and_stand_alone_bit_chunks(pkg, oracle):
     assert L.blosc_gpu_decompress_batch_host(n, src, ssz, dst, dsz, res) == 0
     for k in range(n):
         assert res[k] == datas[k].size and np.array_equal(outs[k], datas[k]), k
+
+
+@pytest.mark.parametrize("codec", ["lz4", "blosclz", "zstd"])
+@pytest.mark.parametrize("T", [1, 2, 4, 8, 3])
+def test_bitshuffle_chunks_written_here_are_read_by_the_reference(pkg, lib, oracle, codec, T):
+    """The compress side: bitshuffle of typesize 1 / 2 / 4 is a task of the encode kernel (enc_shuffle.h: bitshuffle_block_wave_T), no
+    k_bitshuffle pass; the chunks must decode bit-exactly with the oracle (= the reference's reader) and with our own decoder."""
+    from helpers import orc_decompress
+    sizes = [8 << 20, (4 << 20) + 40, 641091, 2048 * T * 5 + 32 * T * 3 + 8 * T + (T - 1), 1000 * T, 31 * T, 7, 65536 * T + 8 * T]
+    for n in sizes:
+        for dname in ("bench19", "smallints"):
+            data = DATASETS[dname](n)
+            lib.blosc_gpu_profile(1); lib.blosc_gpu_profile_reset()
+            r, chunk = pkg.compress(data, T, 5 if codec != "zstd" else 3, 2, codec.encode())
+            lib.blosc_gpu_profile(0)
+            assert r > 0, (codec, T, n, r)
+            memcpyed = bool(chunk[2] & 2)
+            if not memcpyed:
+                assert (_launches(pkg, "k_bitshuffle") == 0) == (T in (1, 2, 4)), (codec, T, n)
+            if codec != "zstd":                                    # (the plain-C oracle reads LZ4 / BloscLZ; Zstd chunks go through our decoder below and the reference in test_gpu_zstd.py)
+                ro, back = orc_decompress(oracle, chunk, n)
+                assert ro == n and np.array_equal(back, data), (codec, T, n, dname)
+            rg, got = pkg.decompress(chunk, n)
+            assert rg == n and np.array_equal(got, data), (codec, T, n, dname)
