@@ -409,6 +409,9 @@ __device__ __forceinline__ uint32_t dr_step(RingIO& io, uint32_t& ip, uint32_t& 
   hdr = (uint32_t)__builtin_amdgcn_readlane((int)D, 0);
   if (!(__ballot(complete) & 1ull)) return 0u;                 // the token at ip itself: left to the one-sequence path
   const uint32_t nxt = complete ? (uint32_t)lane + size : 64u; // position of the following token, 64 = stop here
+  // the hop table: "stop" is lane 63 - never a complete token (a sequence is >= 3 bytes), its own entry points at itself, and whoever
+  // lands on it is dropped by the `complete` test below - so a hop is one ds_bpermute with no range check behind it
+  const uint32_t nxh = nxt < 63u ? nxt : 63u;
   PROF_LAP(8);
   // ---- 2. token chain: lane r (< 16) learns the position of the r-th token.  Round 4: a scalar walk - v_readlane with the position
   //         in an SGPR, v_writelane into the rank lane, <= 16 hops of ~10 cycles each - instead of pointer doubling in rank space
@@ -431,18 +434,18 @@ __device__ __forceinline__ uint32_t dr_step(RingIO& io, uint32_t& ip, uint32_t& 
       }
     }
   } else {
-    const uint32_t J0 = nxt;
-    const uint32_t J1 = hop(J0, J0), J2 = hop(J1, J1), J3 = hop(J2, J2);
+    const uint32_t J0 = nxh;
+    const uint32_t J1 = bperm(J0, J0), J2 = bperm(J1, J1), J3 = bperm(J2, J2);
     c = 0;
-    { const uint32_t t = hop(J0, c); c = (lane & 1) ? t : c; }
-    { const uint32_t t = hop(J1, c); c = (lane & 2) ? t : c; }
-    { const uint32_t t = hop(J2, c); c = (lane & 4) ? t : c; }
-    { const uint32_t t = hop(J3, c); c = (lane & 8) ? t : c; }
+    { const uint32_t t = bperm(c, J0); c = (lane & 1) ? t : c; }
+    { const uint32_t t = bperm(c, J1); c = (lane & 2) ? t : c; }
+    { const uint32_t t = bperm(c, J2); c = (lane & 4) ? t : c; }
+    { const uint32_t t = bperm(c, J3); c = (lane & 8) ? t : c; }
   }
   const uint32_t pk = bperm(c & 63u, ll | (ml << 9) | ((complete ? 1u : 0u) << 18) | ((ll_ext ? 1u : 0u) << 19) | (nxt << 20));
   const uint32_t off_r = bperm(c & 63u, off);
   const uint32_t ll_r = pk & 0x1ffu, ml_r = (pk >> 9) & 0x1ffu, nxt_r = pk >> 20, ext_r = (pk >> 19) & 1u;
-  const bool valid = lane < (int)BATCH_MAXSEQ && c < 64u && ((pk >> 18) & 1u);
+  const bool valid = lane < (int)BATCH_MAXSEQ && c < 64u && ((pk >> 18) & 1u);      // (c = 63, the stop lane, carries complete = 0)
   const uint32_t tot_r = valid ? ll_r + ml_r : 0u;
   uint32_t incl = tot_r;                                       // inclusive prefix sum over the 16 rank lanes (one DPP row)
   incl += row_shr<1>(incl); incl += row_shr<2>(incl); incl += row_shr<4>(incl); incl += row_shr<8>(incl);
