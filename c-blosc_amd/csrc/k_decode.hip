@@ -926,13 +926,26 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
     spans[2 * (size_t)sid] = raw_in_place ? SPAN_RAW : (sp.lo | ((sp.hi && sp.off <= 256u) ? SPAN_SMALL : 0u) | ((sp.hi && sp.off > SPAN_PAT) ? SPAN_SELF : 0u));
     spans[2 * (size_t)sid + 1] = sp.hi;
   }
-  // All streams of one block are handed out from the SAME per-XCD queue (see k_decode_streams), so the
-  // producers and this consumer share one L2: a store that has completed (vmcnt) is in that L2, and the
-  // consumer only has to drop its own L1 lines.  No L2 write-back (`buffer_wbl2`) is needed - with 65 536
-  // streams per launch an agent-scope release per stream flushed whole L2s and tripled the kernel time.
+  // The hand-off, and why it holds on gfx950 without a release fence:
+  //  * all streams of one block are handed out from the SAME per-XCD queue (k_decode_streams; engine.hip: probe_topology checks that
+  //    workgroups really are dealt round-robin to 8 XCDs whose id the waves read) - producers and consumer share ONE L2;
+  //  * the vector L1 (TCP) is write-through: a global store leaves the CU for the L2 of its XCD, and vmcnt counts a store down only
+  //    when that L2 has acknowledged it (CDNA3/4 ISA, s_waitcnt: "memory writes: decremented when the data has been written to the L2
+  //    cache") - after `s_waitcnt vmcnt(0)` below every row this wave flushed IS in the XCD's L2;
+  //  * the counter is an atomic executed AT that L2 (agent scope: `global_atomic_add ... sc1`), issued after the wait: whoever sees
+  //    the incremented value reads the same L2 the rows are in;
+  //  * the consumer's `buffer_inv sc1` (the acquire fence behind the test) drops its CU's L1 lines, so its loads go to that L2.
+  // What an agent-scope RELEASE would add is `buffer_wbl2`: a write-back of the XCD's whole L2 to memory, needed only when the reader
+  // sits behind a DIFFERENT L2.  Timed in round 4 (profiles/r04s_dec_ab_handoff_release_vs_relaxed.txt): 7.63 against 4.09 ms per
+  // 8 GiB with one release per stream - kept relaxed.  tests/test_gpu_handoff_stress.py runs two contexts' persistent kernels on the
+  // same XCDs for 2 000 launches and compares every byte; the single-queue fallback (no in-kernel hand-off at all) is what a device
+  // without this topology gets.
   BAMD_WAIT_STORES();
   uint32_t old = 0;
-  if (lane == 0) old = __hip_atomic_fetch_add(&blk_done[gb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifndef BAMD_HANDOFF_RELEASE
+#define BAMD_HANDOFF_RELEASE 0     // 1: a release at agent scope (the formally sufficient form: L2 write-back in front of the counter).  Timed in round 4: profiles/r04s_*
+#endif
+  if (lane == 0) old = __hip_atomic_fetch_add(&blk_done[gb], 1u, BAMD_HANDOFF_RELEASE ? __ATOMIC_RELEASE : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   old = (uint32_t)__builtin_amdgcn_readlane((int)old, 0);
   if (old + 1u != nstreams) return;
 #ifdef BAMD_DEC_NOUNSH

@@ -34,5 +34,21 @@ for k in sorted(set(f) | set(w)):
     fb = f.get(k, 0.0) * 1024 * 2; wb = w.get(k, 0.0) * 1024
     e = res["kernels"].setdefault(name, {"hbm_read_bytes": 0.0, "hbm_write_bytes": 0.0, "hbm_bytes": 0.0})
     e["hbm_read_bytes"] += fb; e["hbm_write_bytes"] += wb; e["hbm_bytes"] += fb + wb
+# decode of REFERENCE-written chunks (the drop-in direction), counted apart: scripts/gpu_call.sh dectraffic runs the same two PMC passes over
+# scripts/dec_sweep.py, whose k_decode_* launches all decode stock chunks (profiles/<tag>_dec_traffic.txt: "<COUNTER> <kernel>: launches n mean X M units")
+stock_txt = os.path.join(ROOT, "profiles", f"{tag}_cfg{cfg}_dec_traffic_stock.txt")
+if os.path.exists(stock_txt):
+    ks = {}
+    for ln in open(stock_txt):
+        p = ln.split()
+        if len(p) >= 6 and p[0] in ("FETCH_SIZE", "WRITE_SIZE") and p[4] == "mean":
+            name = p[1].rstrip(":").split("bamd::")[-1].split("<")[0].split("(")[0]
+            kib = float(p[5]) * 1e6
+            e = ks.setdefault(name, {"hbm_read_bytes": 0.0, "hbm_write_bytes": 0.0, "hbm_bytes": 0.0})
+            if p[0] == "FETCH_SIZE": e["hbm_read_bytes"] = kib * 1024 * 2
+            else: e["hbm_write_bytes"] = kib * 1024
+            e["hbm_bytes"] = e["hbm_read_bytes"] + e["hbm_write_bytes"]
+    res["kernels_stock"] = ks
+    res["kernels_stock_note"] = "launches of scripts/dec_sweep.py: reference-written chunks only (bench.py's own passes above decode chunks written here)"
 json.dump(res, open(os.path.join(ROOT, "profiles", f"{tag}_traffic_cfg{cfg}.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
