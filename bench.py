@@ -64,11 +64,9 @@ CONFIGS = {
     "4c": dict(codec="zstd", shuffle=1, typesize=8, clevel=3, data="randwalk"),
     "4d": dict(codec="zstd", shuffle=1, typesize=8, clevel=3, data="random"),
     "1g": dict(codec="blosclz", shuffle=1, typesize=8, clevel=5, data="bench19"),
-    # typesize 2 and 16 (round 3: their byte (un)shuffle runs inside the codec kernels like that of 4 and 8; "...0" = the three-pass state before)
+    # typesize 2 and 16 (round 3: their byte (un)shuffle runs inside the codec kernels like that of 4 and 8)
     "2t": dict(codec="lz4", shuffle=1, typesize=2, clevel=5, data="bench19"),
     "2x": dict(codec="lz4", shuffle=1, typesize=16, clevel=5, data="bench19"),
-    "2t0": dict(codec="lz4", shuffle=1, typesize=2, clevel=5, data="bench19", env={"BLOSC_AMD_FUSE_T": "0"}),
-    "2x0": dict(codec="lz4", shuffle=1, typesize=16, clevel=5, data="bench19", env={"BLOSC_AMD_FUSE_T": "0"}),
     "z":  dict(codec="zlib", shuffle=1, typesize=8, clevel=5, data="bench19"),
     "zb": dict(codec="zlib", shuffle=1, typesize=8, clevel=5, data="linspace"),
     # the encoder options of DESIGN.md 3.6 / 3.9 (an "env" entry is put into the environment before the library is used)

@@ -41,9 +41,6 @@ inline unsigned long long g_emu_ring_far = 0;         // ... and matches served 
 #endif
 
 #define DR_SYNC() do { LDS_ORDER(); BAMD_LDS_SYNC(); } while (0)
-#ifndef BAMD_DR_SKIP
-#define BAMD_DR_SKIP 0              // timing experiments (wrong bytes on purpose; scripts/gpu_call.sh decab with NOCHECK=1): leave out 1 = a step's literal scatter,
-#endif                              // 2 = its short matches, 4 = its in-order matches, 8 = the row flush, 16 = the bytes of the one-sequence path (parse and positions stay)
 
 struct RingIO {
   volatile BAMD_LAS uint32_t* scr;     // 64 dwords: token info of a step on its way back to byte-lane space
@@ -118,7 +115,6 @@ __device__ __forceinline__ void dr_put16(lu8* hist, uint32_t pos, uint4 v) {
 __device__ __forceinline__ void dr_flush_rows(RingIO& io, uint32_t op) {
   while (op - io.flushed >= DR_ROW) {
     DR_SYNC();
-    if (!(BAMD_DR_SKIP & 8))
     g_st16(io.out + io.flushed + 16u * (uint32_t)io.lane, l_ld16(io.hist + ((io.flushed + 16u * (uint32_t)io.lane) & DR_MASK)));
     io.flushed += DR_ROW;
   }
@@ -135,9 +131,6 @@ __device__ __forceinline__ void dr_flush_tail(RingIO& io, uint32_t op) {
 }
 // lowest plane position a copy ending at W may still read from the ring
 __device__ __forceinline__ uint32_t dr_near_lo(const RingIO& io, uint32_t W) {
-#ifdef BAMD_DR_NOFAR
-  return 0u;            // timing experiment (wrong bytes on purpose): every source is read from the ring - what the far reads cost
-#endif
   const uint32_t lo = W > DR_RING ? W - DR_RING : 0u;
   return lo > io.rfloor ? lo : io.rfloor;
 }
@@ -171,7 +164,6 @@ __device__ __forceinline__ void dr_copy_chunk(RingIO& io, uint32_t pos, uint32_t
 // LZ match of any length and distance at op (byte-wise forward semantics, lz4.c:2387-2434 / blosc/fastcopy.c:530-639): through the
 // ring in pieces of at most one row, every completed row flushed on the way.  off >= 1, off <= op (checked by the caller).
 __device__ __forceinline__ void dr_match(RingIO& io, uint32_t& op, uint32_t off, uint32_t len, int lane) {
-  if (BAMD_DR_SKIP & 16) { op += len; dr_flush_rows(io, op); return; }
   uint32_t done = 0, off_e = off;
   const uint32_t mpos = op;
   if (off < 64u && off < len) {
@@ -189,16 +181,13 @@ __device__ __forceinline__ void dr_match(RingIO& io, uint32_t& op, uint32_t off,
     op = mpos + done;
     dr_flush_rows(io, op);
   }
-#ifndef BAMD_DR_ROWFILL
-#define BAMD_DR_ROWFILL 1
-#endif
   // Power-of-two periods up to a row, long matches (byte planes of a few significant bits decode into dozens of 4 KiB runs of period 128;
   // constant planes when spans are off).  The general loop below doubles its stride from `off` up to a row - five dependent LDS copies
   // before the first full row, 240 k of a 450 k-cycle stream on bench19's planes 2 / 6.  Here: ONE copy of the period (so that two
   // periods lie back to back), then every lane reads its 16 bytes of any later position straight out of those periods
   // (plane[q] = plane[b + ((q - b) & (per - 1))]: unaligned 16-byte LDS reads), the piece up to the next row boundary and the one behind
   // the last are one read + one write each, and the rows in between are the SAME registers stored to the ring and to global memory.
-  if (BAMD_DR_ROWFILL && (off & (off - 1u)) == 0u && off <= DR_ROW && len >= 2u * DR_ROW && mpos - off >= dr_near_lo(io, mpos + off)) {
+  if ((off & (off - 1u)) == 0u && off <= DR_ROW && len >= 2u * DR_ROW && mpos - off >= dr_near_lo(io, mpos + off)) {
     if (off >= 64u) { dr_copy_chunk(io, mpos, mpos - off, off, false, lane); done = off; op = mpos + done; dr_flush_rows(io, op); }
     const uint32_t per = off < 64u ? 32u : off, pm = per - 1u, b0 = mpos - off, l16 = 16u * (uint32_t)lane;     // (off < 64: the head above wrote 64 bytes, off divides 32)
     // 16 bytes of plane position q out of the two periods that end closest in front of `front` (everything written so far is periodic)
@@ -224,7 +213,7 @@ __device__ __forceinline__ void dr_match(RingIO& io, uint32_t& op, uint32_t off,
       DR_SYNC();
       for (; end - pos >= DR_ROW; pos += DR_ROW) {
         l_st16(io.hist + ((pos + l16) & DR_MASK), row);
-        if (!(BAMD_DR_SKIP & 8)) g_st16(io.out + pos + l16, row);
+        g_st16(io.out + pos + l16, row);
       }
       io.flushed = pos; op = pos;
       DR_SYNC();
@@ -250,7 +239,6 @@ __device__ __forceinline__ void dr_match(RingIO& io, uint32_t& op, uint32_t off,
 // `ll` literal bytes from stream position ip to plane position op (both advance); runs that do not sit in the input ring come
 // straight from the compressed stream, one row at a time
 __device__ __forceinline__ void dr_literals(RingIO& io, uint32_t& ip, uint32_t& op, uint32_t ll, int lane) {
-  if (BAMD_DR_SKIP & 16) { ip += ll; op += ll; dr_flush_rows(io, op); return; }
   if (ll <= 64u) {                                            // (dr_input(ip0) with ip <= ip0 + 4 covers ip + 64 + 4)
     const uint32_t v = dr_in4(io, ip + (uint32_t)lane);
     DR_SYNC();
@@ -348,7 +336,7 @@ __device__ __attribute__((noinline)) void dr_span_call(volatile uint32_t* lds_, 
 }
 // returns true when the match was taken as a span (op then stands behind it)
 __device__ __forceinline__ bool dr_span_long_match(RingIO& io, uint32_t& op, uint32_t off, uint32_t ml, int lane, SpanCtx& sp) {
-  if (!sp.enabled || sp.hi || ml < 16384u || off > (BAMD_SELFSPAN ? 65536u : SPAN_PAT) || (off & (off - 1u))) return false;
+  if (!sp.enabled || sp.hi || ml < 16384u || off > 65536u || (off & (off - 1u))) return false;
   const uint32_t mpos = op, lo = (mpos + 1023u) & ~1023u, hi = (mpos + ml) & ~1023u;
   if (hi < lo + 8192u) return false;
   if (off > SPAN_PAT && mpos >= (1u << 24)) return false;         // (see span_long_match: the self-span base travels in 24 bits)
@@ -365,16 +353,6 @@ __device__ __forceinline__ void dr_span_materialize(RingIO& io, SpanCtx& sp, int
   sp.lo = 0; sp.hi = 0; sp.enabled = 0;
 }
 
-// lane r of `old` becomes `v` (v wave-uniform, r a constant): v_writelane_b32 (this clang has no builtin for it)
-#ifdef BAMD_WAVE_EMU
-#define dr_writelane(v, r, old) ((uint32_t)__builtin_amdgcn_writelane((v), (r), (old)))
-#else
-template <typename = void>
-__device__ __forceinline__ uint32_t dr_writelane(uint32_t v, int r, uint32_t old) {
-  asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(v), "n"(r));
-  return old;
-}
-#endif
 // ---------------------------------------------------------------------------------------------
 // Batched step: up to 16 consecutive sequences whose tokens, literals, offsets (and at most one extension byte per length) all
 // lie in the 64 stream bytes at ip.
@@ -413,30 +391,14 @@ __device__ __forceinline__ uint32_t dr_step(RingIO& io, uint32_t& ip, uint32_t& 
   // lands on it is dropped by the `complete` test below - so a hop is one ds_bpermute with no range check behind it
   const uint32_t nxh = nxt < 63u ? nxt : 63u;
   PROF_LAP(8);
-  // ---- 2. token chain: lane r (< 16) learns the position of the r-th token.  Round 4: a scalar walk - v_readlane with the position
-  //         in an SGPR, v_writelane into the rank lane, <= 16 hops of ~10 cycles each - instead of pointer doubling in rank space
-  //         (7 dependent ds_bpermute): the decoder now lives in LDS, whose round trips cost ~250 cycles with 16 waves per CU sharing
-  //         the pipe (profiles/r04d_*: the parse alone was 1.3 of the kernel's 4.2 ms), and the scalar unit has room ----
-#ifndef BAMD_DR_SWALK
-#define BAMD_DR_SWALK 0             // measured: +2.6 % (4.31 against 4.20 ms on bench19, profiles/r04g_dec_ab_bisect_walk_pipe_rowfill.txt) - the kernel is bound by its VALU / SALU
-#endif                              // instruction count (SQ counters: profiles/r04e_*), which the walk raises; the doubling form stays
-  uint32_t c;
-  uint64_t tokmask = 0ull;                                     // byte positions of the tokens found (wave-uniform)
-  if (BAMD_DR_SWALK) {
-    c = 64u;
-    uint32_t pos = 0u;                                         // ip is a real token by invariant
-#pragma unroll
-    for (int r = 0; r < (int)BATCH_MAXSEQ; r++) {
-      if (pos < 64u) {                                         // (scalar branch)
-        c = dr_writelane(pos, r, c);
-        tokmask |= 1ull << pos;
-        pos = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)pos);
-      }
-    }
-  } else {
+  // ---- 2. token chain in rank space: J1 = J0 o J0, J2 = J1 o J1, J3 = J2 o J2; lane r (< 16) finds the r-th token.  (Round 4 also built
+  //         a scalar walk - v_readlane with the position in an SGPR, v_writelane into the rank lane, <= 16 hops of ~10 cycles, and the
+  //         literal placement through one more ds_bpermute instead of the 64-dword scratch: 2.6 % SLOWER, the kernel is bound by the
+  //         number of VALU / SALU instructions it issues and the walk adds to it: profiles/r04g_dec_ab_bisect_walk_pipe_rowfill.txt) ----
+  uint32_t c = 0;                                              // ip is a real token by invariant
+  {
     const uint32_t J0 = nxh;
     const uint32_t J1 = bperm(J0, J0), J2 = bperm(J1, J1), J3 = bperm(J2, J2);
-    c = 0;
     { const uint32_t t = bperm(c, J0); c = (lane & 1) ? t : c; }
     { const uint32_t t = bperm(c, J1); c = (lane & 2) ? t : c; }
     { const uint32_t t = bperm(c, J2); c = (lane & 4) ? t : c; }
@@ -465,27 +427,17 @@ __device__ __forceinline__ uint32_t dr_step(RingIO& io, uint32_t& ip, uint32_t& 
   const uint32_t consumed = (uint32_t)__builtin_amdgcn_readlane((int)nxt_r, (int)(cnt - 1u));
   const uint32_t acc = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(cnt - 1u));
   const uint32_t W = op + acc, nlo = dr_near_lo(io, W);
-  // ---- 3. literals: every byte lane finds the last accepted token at or before it (a mask operation), fetches that token's placement
-  //         from its rank lane (ONE ds_bpermute; the doubling form goes through the 64-dword scratch: 4 LDS operations) and the literal
-  //         bytes of all sequences leave in one scattered byte store ----
-  // info word of a token: length-extension flag << 25 | literal count << 16 | output offset (<= DR_STEP_MAX)
-  if (!(BAMD_DR_SKIP & 1)) {
-    uint64_t mask; uint32_t inf, s;
-    if (BAMD_DR_SWALK) {
-      mask = consumed >= 64u ? tokmask : (tokmask & ((1ull << consumed) - 1ull));      // the tokens in front of `consumed` are exactly the accepted ones
-      const uint64_t below = mask & ((2ull << lane) - 1ull);
-      s = 63u - (uint32_t)__builtin_clzll(below | 1ull);
-      inf = bperm(((uint32_t)__builtin_popcountll(below) - 1u) & 15u, excl | (ll_r << 16) | (ext_r << 25));      // rank of token s = tokens at or below the lane, minus one (lane 0 is a token)
-    } else {
-      io.scr[lane] = 0u;
-      BAMD_LDS_SYNC();
-      if (mine) io.scr[c] = 0x80000000u | excl | (ll_r << 16) | (ext_r << 25);
-      BAMD_LDS_SYNC();
-      mask = __ballot(io.scr[lane] >> 31);
-      const uint64_t below = mask & ((2ull << lane) - 1ull);     // accepted tokens at or before this byte lane
-      s = 63u - (uint32_t)__builtin_clzll(below | 1ull);
-      inf = io.scr[s];
-    }
+  // ---- 3. literals: token info goes back to byte-lane space through the 64-dword scratch, then one scattered byte store ----
+  // scratch word of a token: valid | length-extension flag << 25 | literal count << 16 | output offset (<= DR_STEP_MAX)
+  {
+    io.scr[lane] = 0u;
+    BAMD_LDS_SYNC();
+    if (mine) io.scr[c] = 0x80000000u | excl | (ll_r << 16) | (ext_r << 25);
+    BAMD_LDS_SYNC();
+    const uint64_t mask = __ballot(io.scr[lane] >> 31);
+    const uint64_t below = mask & ((2ull << lane) - 1ull);     // accepted tokens at or before this byte lane
+    const uint32_t s = 63u - (uint32_t)__builtin_clzll(below | 1ull);
+    const uint32_t inf = io.scr[s];
     const uint32_t xe = (inf >> 25) & 1u;
     const uint32_t k = (uint32_t)lane - s - 1u - xe;
     if ((uint32_t)lane < consumed && (uint32_t)lane > s + xe && k < ((inf >> 16) & 0x1ffu)) io.hist[(op + (inf & 0xffffu) + k) & DR_MASK] = (uint8_t)B;
@@ -498,7 +450,7 @@ __device__ __forceinline__ uint32_t dr_step(RingIO& io, uint32_t& ip, uint32_t& 
   const bool far_r = src_r + ml_r <= nlo;
   const bool fast_r = mine && ml_r <= 64u && off_r >= mrel_r + ml_r && (dpos_r & DR_MASK) + ml_r <= DR_RING && (far_r || (src_r >= nlo && (src_r & DR_MASK) + ml_r <= DR_RING));
   const bool anyfar = __ballot(fast_r && far_r) != 0ull;
-  if (!(BAMD_DR_SKIP & 2)) {
+  {
     const uint32_t r = (uint32_t)lane >> 2, q = (uint32_t)lane & 3u;
     const uint32_t fA = bperm(r, fast_r ? (ml_r | 0x200u | (mrel_r << 10) | (far_r ? 0x80000000u : 0u)) : 0u);
     const uint32_t fB = bperm(r, off_r);
@@ -540,7 +492,7 @@ __device__ __forceinline__ uint32_t dr_step(RingIO& io, uint32_t& ip, uint32_t& 
   PROF_LAP(10);
   // ---- 5. everything else in stream order: byte lanes, the periodic extension of the off bytes in front of the match when it
   //         overlaps itself (every lane then reads only bytes that are already final) ----
-  uint32_t rest = (BAMD_DR_SKIP & 4) ? 0u : (uint32_t)__ballot(mine && !fast_r);
+  uint32_t rest = (uint32_t)__ballot(mine && !fast_r);
   PROF_ADD(0, 1); PROF_ADD(1, cnt); PROF_ADD(2, __builtin_popcount(rest));
   while (rest) {
     const int sl = __builtin_ctz(rest);

@@ -47,28 +47,20 @@ struct ChunkDesc {
   int32_t hdr_flags;    // compress only: header flag byte to write
 };
 
-// Scratch layout of a chunk whose blocks the decode kernel unshuffles itself (CH_FUSED_UNSHUF).  Planes used to lie 2^k bytes
-// apart (128 KiB for the benchmark's blocks): the eight streams of a block and the eight plane reads of every unshuffle step
-// then differ only in high address bits and land on the same HBM channel.  Round 3 measured the SAME binary 8 % apart depending
-// on where its arenas happened to be allocated (profiles/r03o_dec_ab_same_binary_differs_by_placement.txt); the planes of such a
-// chunk now lie N + FILT_PLANE_PAD bytes apart (a multiple of 256, so rows stay aligned; 17 x 256, so that consecutive planes
-// move on by an odd number of 256-byte units AND by one 4 KiB unit).
-#ifndef BAMD_FILT_PAD
-#define BAMD_FILT_PAD 0        // measured: no effect (profiles/r03p_dec_ab_plane_padding_no_effect.txt - three copies of each build taking turns; what differs by 10 % is WHICH instance runs, not its layout)
-#endif
-constexpr uint32_t FILT_PLANE_PAD = BAMD_FILT_PAD;
+// Scratch layout of a filtered chunk: plane-major per block, planes bsize / typesize bytes apart.  (Round 3 padded the planes of fused chunks
+// apart to keep them off one HBM channel: no effect, profiles/r03p_dec_ab_plane_padding_no_effect.txt - removed in round 4.)
 #if defined(__HIPCC__) || defined(BAMD_WAVE_EMU)
 #define BAMD_HD __host__ __device__
 #else
 #define BAMD_HD
 #endif
 BAMD_HD inline size_t filt_block_stride(const ChunkDesc& c) {
-  return (size_t)c.blocksize + ((c.mode & CH_FUSED_UNSHUF) ? (size_t)c.typesize * FILT_PLANE_PAD : 0u);
+  return (size_t)c.blocksize;
 }
 // plane stride inside one block: split blocks of fused chunks are padded, everything else is the plain plane-major image
 BAMD_HD inline uint32_t filt_plane_stride(const ChunkDesc& c, uint32_t bsize, int nstreams) {
-  const uint32_t N = bsize / (uint32_t)(c.typesize > 0 ? c.typesize : 1);      // bytes per plane (an unsplit block is ONE stream, but still typesize planes)
-  return N + (((c.mode & CH_FUSED_UNSHUF) && nstreams == c.typesize && nstreams > 1) ? FILT_PLANE_PAD : 0u);
+  (void)nstreams;
+  return bsize / (uint32_t)(c.typesize > 0 ? c.typesize : 1);      // bytes per plane (an unsplit block is ONE stream, but still typesize planes)
 }
 
 struct BlockDesc {

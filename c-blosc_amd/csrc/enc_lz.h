@@ -2,14 +2,8 @@
 // lz_encode_wave (LZ4 / BloscLZ streams, and the front end of the Zstd / zlib writers through their sinks) and hc_encode_wave
 // (the LZ4HC-grade search), with the table, window and emit helpers they share.  DESIGN.md 3.3.
 // build switches of the round-3 changes (defaults are what bench.py measures; the others are kept for same-session A/B runs, scripts/enc_ab.py)
-#ifndef BAMD_ENC_WINSETTLE
-#define BAMD_ENC_WINSETTLE 1   // EncWindow: the prefetched dword is corrected behind the step's candidate wait (0: at once, as before round 3)
-#endif
 #ifndef BAMD_ENC_EXT1K
 #define BAMD_ENC_EXT1K 3      // wave_common_fwd: short first trips before the 2 KiB rows (1: 1 KiB, 2: 512 bytes, 3: 256 bytes then 1 KiB - 5 % / 11 % / 19 % of the kernel on bench19)
-#endif
-#ifndef BAMD_ENC_EMIT1
-#define BAMD_ENC_EMIT1 1      // lz4_emit_seq: a sequence with < 15 literals (in registers) and a match below 274 bytes leaves as ONE byte-store instruction
 #endif
 constexpr int ENC_WAVES = 1;       // one stream per workgroup: a slot frees up as soon as ITS stream is done
 // Table entry = position mod 65536 | 16 further hash bits as a tag << 16.  The tag lets a lane reject a
@@ -30,11 +24,7 @@ constexpr int ENC_TAB_BYTES = BAMD_ENC_SPLIT_TAB ? ENC_TAB * 3 : ENC_TAB * 4;
 #ifndef BAMD_ENC_MINWAVES
 #define BAMD_ENC_MINWAVES (BAMD_ENC_SPLIT_TAB ? 6 : 5)   // waves per SIMD the register allocator leaves room for
 #endif
-#ifndef BAMD_ENC_RUNBUF
-#define BAMD_ENC_RUNBUF 0      // the LZ4 emitter's sequences through a 512-byte LDS ring, 256 bytes per store (see lz4_emit_seq).  MEASURED: 8.2 -> 8.75 ms on bench19, slower on every data set (two copies of each build taking turns, profiles/r03zj_enc_ab_run_buffer_rejected.txt): off
-#endif
-constexpr uint32_t ENC_RB_BYTES = BAMD_ENC_RUNBUF ? 512u : 0u;
-constexpr int ENC_LDS_WAVES = (160 * 1024) / (ENC_TAB_BYTES + (int)ENC_RB_BYTES);
+constexpr int ENC_LDS_WAVES = (160 * 1024) / ENC_TAB_BYTES;
 constexpr int ENC_WAVES_PER_CU = ENC_LDS_WAVES < 4 * BAMD_ENC_MINWAVES ? ENC_LDS_WAVES : 4 * BAMD_ENC_MINWAVES;   // persistent grid size per CU
 
 // the table of one wave (LDS)
@@ -273,28 +263,13 @@ __device__ __forceinline__ void emit_literals(gu8* dst, const gu8* lit, uint32_t
   }
 }
 
-// Run buffer of the LZ4 emitter (round 3, the lesson of k_zstd_seq's triples: ONE in-order counter for loads and stores).  A sequence of
-// bench19's noisy planes is ~10 bytes, stored with one instruction - and the next step's candidate loads wait for L2's acknowledgement of it
-// (the emitter with its stores left out: 8.19 -> 7.53 ms, profiles/r03zi_enc_ab1.txt).  The common sequence shape now goes to a 512-byte LDS
-// ring of the wave (behind the hash table) and leaves 256 bytes at a time, one coalesced dword store per lane; everything else
-// (long literal runs, long matches, the stream's tail) first drains the ring and stores as before.  Same bytes (checked on the
-// emulator).  It does NOT pay here: 6 % slower - the ring's LDS traffic and bookkeeping in a loop that already spills cost more than the
-// acknowledgements do (what worked for k_zstd_seq, whose loop does nothing else between a store and the next load).  BAMD_ENC_RUNBUF=0.
-struct EncRun {
-  volatile __attribute__((address_space(3))) uint8_t* ring;    // nullptr: no run buffer (BloscLZ, the other writers)
-  uint32_t fl, base;                                           // output bytes [0, fl) are in memory, [fl, op) in the ring at (pos - base) & 511; fl - base is a multiple of 256
-};
-__device__ __forceinline__ void enc_run_drain(EncRun& r, gu8* dst, uint32_t op, int lane) {     // everything pending to memory; the ring restarts at op
-  if (!r.ring) return;
-  BAMD_LDS_SYNC();
-  for (uint32_t k = r.fl + (uint32_t)lane; k < op; k += 64u) ENC_ST1(dst + k, r.ring[(k - r.base) & 511u]);
-  r.fl = op; r.base = op;
-}
+// (Round 3 also sent the common sequence shape through a 512-byte LDS ring that left 256 bytes at a time - the cure for k_zstd_seq's store
+//  acknowledgements: bit-identical output, 6 % SLOWER here - profiles/r03zj_enc_ab_run_buffer_rejected.txt; removed in round 4.)
 __device__ __forceinline__ uint32_t lz4_emit_seq(gu8* dst, uint32_t op, uint32_t cap, const gu8* lit,
-                                                 uint32_t ll, uint32_t off, uint32_t mlen, int lit_lane0, uint32_t ownbyte, int lane, EncRun* run = nullptr) {
+                                                 uint32_t ll, uint32_t off, uint32_t mlen, int lit_lane0, uint32_t ownbyte, int lane) {
   if (op + 1u + ll + (2u + 1u + 5u) + ll / 255u > cap) return 0xffffffffu;
   const uint32_t mcode = mlen - 4u;
-  if (BAMD_ENC_EMIT1 && ll < 15u && mcode < 15u + 255u && (ll == 0u || (lit_lane0 >= 0 && (uint32_t)lit_lane0 + ll <= 64u))) {
+  if (ll < 15u && mcode < 15u + 255u && (ll == 0u || (lit_lane0 >= 0 && (uint32_t)lit_lane0 + ll <= 64u))) {
     // the common shape (bench19's noisy planes: 1150 of 1163 sequences): token, <= 14 literals out of this step's registers, offset, at most one
     // length byte - lane j holds byte j of the sequence, one store.  Same bytes and the same two budget checks as the general path below.
     if (op + 1u + ll + 2u + (1u + 5u) + (mcode + 240u) / 255u > cap) return 0xffffffffu;
@@ -305,21 +280,9 @@ __device__ __forceinline__ uint32_t lz4_emit_seq(gu8* dst, uint32_t op, uint32_t
     b = (uint32_t)lane == ll + 2u ? off >> 8 : b;
     b = (uint32_t)lane == ll + 3u ? mcode - 15u : b;
     const uint32_t total = ll + 3u + (mcode >= 15u ? 1u : 0u);
-    if (run && run->ring) {
-      if ((uint32_t)lane < total) run->ring[(op + (uint32_t)lane - run->base) & 511u] = (uint8_t)b;
-      op += total;
-      if (op - run->fl >= 256u) {                            // 256 bytes leave: a dword per lane (the ring offset of fl is 0 or 256)
-        BAMD_LDS_SYNC();
-        const uint32_t w = *(volatile __attribute__((address_space(3))) uint32_t*)(run->ring + (((run->fl - run->base) & 511u) + 4u * (uint32_t)lane));
-        if (!BAMD_ENC_NOSTORE) g_st4(dst + run->fl + 4u * (uint32_t)lane, w);
-        run->fl += 256u;
-      }
-      return op;
-    }
     if ((uint32_t)lane < total) ENC_ST1(dst + op + lane, (uint8_t)b);
     return op + total;
   }
-  if (run) enc_run_drain(*run, dst, op, lane);
   const uint32_t tok = ((ll < 15u ? ll : 15u) << 4) | (mcode < 15u ? mcode : 15u);
   if (lane == 0) ENC_ST1(dst + op, (uint8_t)tok);
   op += 1u;
@@ -330,7 +293,6 @@ __device__ __forceinline__ uint32_t lz4_emit_seq(gu8* dst, uint32_t op, uint32_t
   op += 2u;
   if (op + (1u + 5u) + (mcode + 240u) / 255u > cap) return 0xffffffffu;
   if (mcode >= 15u) op += emit_ext255(dst + op, mcode - 15u, lane);
-  if (run && run->ring) { run->fl = op; run->base = op; }
   return op;
 }
 // final literal run (lz4.c:1302-1329)
@@ -402,13 +364,8 @@ __device__ __forceinline__ uint32_t blz_emit_match(gu8* dst, uint32_t op, uint32
 #endif
 constexpr uint32_t RANK_CAP = BAMD_ENC_RANK_CAP;   // bytes of a candidate that are compared for ranking (16 instead: more extensions, lower ratio, no faster)
 
-#ifndef BAMD_ENC_BACKN
-#define BAMD_ENC_BACKN 0      // backward extension from registers (lz_encode_wave, round 3): bit-identical output, both forms measured and off.
-                              // 8: the 8 bytes in front of a candidate come with one more load per lane and step - no gain (profiles/r03l_enc_ab_back8_no_gain.txt).
-                              // 4: the candidate's 24 bytes [cand - 4, cand + 20) come as 8 + 16 instead of 16 + 4, no extra instruction - 3 % SLOWER
-                              // (profiles/r03x_enc_ab_back4_ext512.txt): the kernel is not waiting for these round trips, it pays for bytes and instructions
-#endif
-#define BAMD_ENC_BACK8 (BAMD_ENC_BACKN != 0)
+// (Backward extension out of registers - the 8 (or 4) bytes in front of a candidate fetched together with its 20 - was built in round 3 in
+//  two forms: bit-identical output, no gain / 3 % slower, profiles/r03l_enc_ab_back8_no_gain.txt, r03x_enc_ab_back4_ext512.txt; removed in round 4.)
 struct Bytes20 { uint64_t a, b; uint32_t c; };
 
 // 20 bytes at src[pos..], zero beyond n (only the last step of a stream takes the slow branch)
@@ -509,8 +466,7 @@ struct EncWindow {
     if (d < 512u) { w0 = w1; w1 = w2; wbase += 256u; }
     else if (d < 768u) { w0 = w2; wbase += 512u; w1 = fetch(wbase + 256u, lane); }
     else { wbase = lo & ~255u; w0 = fetch(wbase, lane); w1 = fetch(wbase + 256u, lane); }
-    if (BAMD_ENC_WINSETTLE) { w2 = fetch_raw(wbase + 512u, lane); pending = true; }
-    else w2 = fetch(wbase + 512u, lane);
+    w2 = fetch_raw(wbase + 512u, lane); pending = true;      // (corrected behind the step's candidate wait: settle())
   }
 };
 
@@ -543,8 +499,6 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
 
   if (start == 0u) tab.clear(lane);
 
-  EncRun run = {nullptr, 0u, 0u};
-  if (FMT == EF_LZ4 && BAMD_ENC_RUNBUF) run.ring = (volatile __attribute__((address_space(3))) uint8_t*)tab_generic + ENC_TAB_BYTES;
   EncWindow win;
   win.init(src, n, lane);
   uint32_t ip = start, anchor = start, op = 0, nfail = 0;
@@ -602,24 +556,8 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
     PROF_LAP(8); PROF_ADD(0, 1);
     // ---- round 2: candidate bytes, exact lengths up to RANK_CAP ----
     uint32_t len = 0;
-    // Round 3: the 8 bytes IN FRONT of the candidate travel with its 20 bytes (one more 8-byte load in the same round trip).  The
-    // backward extension of a match - tried for 4 in 10 sequences on bench19, longer than 4 bytes for 1 in 25 - needed a round
-    // trip of its own per sequence (2200 cycles, the largest single item of the encoder's phase profile,
-    // profiles/r03k_enc_phase_before.txt); with these bytes and the window registers it is decided in registers unless it
-    // runs past 8 bytes.  cbk: little endian, its top byte is src[cand - 1]; has_back: cbk belongs to `cand`.
-    uint64_t cbk = 0;
-    bool has_back = false;
     if (tab_ok) {
-      Bytes20 cb;
-      if (BAMD_ENC_BACKN == 4 && cand >= 4u && cand + 20u <= n) {
-        const uint64_t lo = g_ld8(src + cand - 4u);
-        const uint4 hi = g_ld16(src + cand + 4u);
-        cbk = lo << 32; has_back = true;
-        cb.a = (lo >> 32) | ((uint64_t)hi.x << 32); cb.b = (uint64_t)hi.y | ((uint64_t)hi.z << 32); cb.c = hi.w;
-      } else {
-        cb = load20(src, cand, n);
-        if (BAMD_ENC_BACKN == 8 && cand >= 8u) { cbk = g_ld8(src + cand - 8u); has_back = true; }
-      }
+      const Bytes20 cb = load20(src, cand, n);
       len = common20(own, cb);
       if (len > limit) len = limit;
       if (len < minlen) len = 0;
@@ -628,7 +566,7 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
     if (live && prev < 0x100u) {                    // distance 1: run of the previous byte
       uint32_t rl = runlen20(own, prev);
       if (rl > limit) rl = limit;
-      if (rl >= minlen && rl > len) { len = rl; cand = p - 1u; has_back = false; }
+      if (rl >= minlen && rl > len) { len = rl; cand = p - 1u; }
     }
     win.settle(lane);                               // behind the wait for the candidates: free
     // ---- select + emit.  The winner maximises (len - lane), ties to the lower lane.  When its match
@@ -652,29 +590,8 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
       uint32_t maxb = pm - anchor;
       if (cm < maxb) maxb = cm;
       if (maxb > 64u) maxb = 64u;
-      // ---- backward extension from registers where that settles it: own bytes out of the window dwords `r` (q = offset of pm in
-      //      r's byte space, everything wave-uniform), the candidate's out of cbk ----
       uint32_t back = 0;
-      bool back_known = maxb == 0u;
-      if (BAMD_ENC_BACK8 && !back_known && (uint32_t)__builtin_amdgcn_readlane((int)(has_back ? 1u : 0u), f)) {
-        const uint32_t q = bo0 + (uint32_t)f;                       // >= 4 (or ip + f at the stream's start)
-        constexpr uint32_t NB = BAMD_ENC_BACKN == 4 ? 4u : 8u;      // bytes of cbk that are real
-        uint32_t nb = maxb < NB ? maxb : NB;
-        if (q < nb) nb = q;
-        const uint32_t q8 = q >= 8u ? q - 8u : 0u;                  // first of the (up to) 8 own bytes in r's byte space
-        const uint32_t i0 = q8 >> 2;
-        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)r, (int)i0), d1 = (uint32_t)__builtin_amdgcn_readlane((int)r, (int)(i0 + 1u));
-        const uint32_t d2 = (uint32_t)__builtin_amdgcn_readlane((int)r, (int)(i0 + 2u));
-        const uint32_t shb = (q8 & 3u) * 8u;
-        uint64_t own8 = shb ? ((((uint64_t)d1 << 32) | d0) >> shb) | ((uint64_t)d2 << (64u - shb)) : (((uint64_t)d1 << 32) | d0);   // bytes q8 .. q8 + 7
-        if (q < 8u) own8 <<= 8u * (8u - q);                         // fewer than 8 bytes in front of pm: line the last one up with the top byte
-        const uint64_t c8 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cbk >> 32), f) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)cbk, f);
-        const uint64_t x = NB == 4u ? (own8 ^ c8) | 0x00000000ffffffffull : own8 ^ c8;
-        const uint32_t eq = x ? (uint32_t)__builtin_clzll(x) >> 3 : 8u;   // equal bytes counted from src[pm - 1] / src[cm - 1] downwards (<= NB)
-        if (eq < nb) { back = eq; back_known = true; }
-        else if (nb == maxb) { back = nb; back_known = true; }            // ran to the allowed limit
-        // else: equal as far as the registers reach - the memory path below finds the end
-      }
+      const bool back_known = maxb == 0u;
       // otherwise backward bytes are requested first and looked at last, so that they travel together with the
       // forward rows (one memory round trip for both directions)
       // Every lane loads (lanes >= maxb a harmless byte): a load under a per-lane condition is compared where it is issued - the
@@ -700,7 +617,7 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
       const uint32_t ll = pm - anchor;
       const uint32_t dist = pm - cm;
       if (FMT == EF_LZ4) {
-        op = lz4_emit_seq(dst, op, cap, src + anchor, ll, dist, mlen, anchor >= ip ? (int)(anchor - ip) : -1, (uint32_t)own.a & 0xffu, lane, &run);
+        op = lz4_emit_seq(dst, op, cap, src + anchor, ll, dist, mlen, anchor >= ip ? (int)(anchor - ip) : -1, (uint32_t)own.a & 0xffu, lane);
         if (op == 0xffffffffu) return 0u;
       } else if (FMT == EF_ZSTD || FMT == EF_ZLIB2) {
         if (zs_emit_seq(*zs, src + anchor, ll, dist, mlen, anchor >= ip ? (int)(anchor - ip) : -1, (uint32_t)own.a & 0xffu, lane) == 0xffffffffu) return 0xffffffffu;
@@ -740,7 +657,6 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
   // closing literals
   if (FMT == EF_ZSTD || FMT == EF_ZLIB || FMT == EF_ZLIB2) return anchor;
   if (FMT == EF_LZ4) {
-    enc_run_drain(run, dst, op, lane);
     op = lz4_emit_tail(dst, op, cap, src + anchor, n - anchor, lane);
     if (op == 0xffffffffu) return 0u;
   } else {

@@ -6,38 +6,17 @@
 // step lane l loads the T*4 contiguous bytes of elements e+4l..e+4l+3 (coalesced 16-byte loads), transposes
 // bytes in registers and stores 4 bytes into every plane (each wave store writes 256 contiguous bytes).
 // ---------------------------------------------------------------------------------------------
-#ifndef BAMD_SHUF_LD_NT
-#define BAMD_SHUF_LD_NT 0     // 1: the fused shuffle reads the source (read once) with non-temporal loads
-#endif
-#ifndef BAMD_SHUF_QUAD8
-#define BAMD_SHUF_QUAD8 0      // typesize 8: the two 16-byte loads of a step dealt so that a quad reads 64 contiguous bytes per instruction.  MEASURED: encode 8.2 -> 10.3 ms (profiles/r03zb_ab_quad_dealt_typesize8_rejected.txt): off
-#endif
+// (Round 3 tried the typesize-8 loads dealt so that a quad reads 64 contiguous bytes per instruction: encode 8.2 -> 10.3 ms,
+//  profiles/r03zb_ab_quad_dealt_typesize8_rejected.txt; and non-temporal source loads: no gain.  Both removed in round 4.)
 template <int T>
 struct ElemRows { uint4 a, b; };
 
 template <int T>
 __device__ __forceinline__ ElemRows<T> shuffle_load(const gu8* src, uint32_t e, int lane) {
   ElemRows<T> x;
-  if (T == 8 && BAMD_SHUF_QUAD8) {
-    // the mirror image of unshuffle_store's quad form: load k of lane i is piece 4k + i of the quad's 128 bytes (64 contiguous bytes per quad
-    // and instruction), then the pieces go to the lanes that own them (lane i: pieces 2i and 2i + 1)
-    const gu8* inq = src + (size_t)(e + 16u * ((uint32_t)lane >> 2)) * 8u + 16u * ((uint32_t)lane & 3u);
-    const uint4 l0 = g_ld16(inq), l1 = g_ld16(inq + 64);
-    const uint32_t q0[4] = {l0.x, l0.y, l0.z, l0.w}, q1[4] = {l1.x, l1.y, l1.z, l1.w};
-    uint32_t a[4], b[4];
-    const bool hi = (lane & 2) != 0;
-#pragma unroll
-    for (int d = 0; d < 4; d++) {
-      const uint32_t a0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q0[d], 0x88, 0xf, 0xf, true), a1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q1[d], 0x88, 0xf, 0xf, true);
-      const uint32_t b0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q0[d], 0xDD, 0xf, 0xf, true), b1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)q1[d], 0xDD, 0xf, 0xf, true);
-      a[d] = hi ? a1 : a0; b[d] = hi ? b1 : b0;
-    }
-    x.a = make_uint4(a[0], a[1], a[2], a[3]); x.b = make_uint4(b[0], b[1], b[2], b[3]);
-    return x;
-  }
   const gu8* in = src + (size_t)(e + 4u * (uint32_t)lane) * T;
-  x.a = BAMD_SHUF_LD_NT ? g_ld16_nt(in) : g_ld16(in);
-  if (T == 8) x.b = BAMD_SHUF_LD_NT ? g_ld16_nt(in + 16) : g_ld16(in + 16); else x.b = make_uint4(0, 0, 0, 0);
+  x.a = g_ld16(in);
+  if (T == 8) x.b = g_ld16(in + 16); else x.b = make_uint4(0, 0, 0, 0);
   return x;
 }
 template <int T>

@@ -107,7 +107,7 @@ __device__ __forceinline__ uint32_t zs_write_sequences(gu8* out, uint32_t room, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// The same section, written without the scalar unit (BAMD_ZSTD_VSEQ, default).  The scalar version above costs ~60 SALU
+// The same section, written without the scalar unit (the form in use).  The scalar version above costs ~60 SALU
 // instructions per sequence, and the 20 waves of a CU share ONE scalar unit: 262 M sequences per 8 GiB of bench19 were
 // ~30 of the kernel's 42 ms.  Here, per batch of 64 sequences:
 //   * every lane prepares its sequence (codes, table rows, extra bits) as before;
@@ -120,9 +120,6 @@ __device__ __forceinline__ uint32_t zs_write_sequences(gu8* out, uint32_t room, 
 // written after the block's match finding; a later block of the same stream finds some stale entries there, which the
 // candidate check (tag, then bytes) rejects like any other stale entry.
 // ---------------------------------------------------------------------------------------------
-#ifndef BAMD_ZSTD_VSEQ
-#define BAMD_ZSTD_VSEQ 1
-#endif
 constexpr uint32_t ZV_STRIP = 136u;
 
 // OR the low n (<= 49) bits of v into the strip at bit position bitpos
@@ -716,8 +713,7 @@ __device__ uint32_t zstd_encode_wave(const gu8* __restrict__ src, uint32_t n, gu
         ss = zs_write_sequences_v<true>(seq_out, cap - (uint32_t)(seq_out - dst), seqbuf, z.nseq, T, scr, lane, &zt);
         if (ss != 0xffffffffu) bsize = lit_bytes + ss;
       } else {
-      ss = BAMD_ZSTD_VSEQ ? zs_write_sequences_v<false>(z.lit + z.nlit, z.litcap - z.nlit, seqbuf, z.nseq, T, (volatile BAMD_LAS uint32_t*)(BAMD_LAS uint8_t*)(void*)tab_generic, lane)
-                                         : zs_write_sequences(z.lit + z.nlit, z.litcap - z.nlit, seqbuf, z.nseq, T, lane);
+      ss = zs_write_sequences_v<false>(z.lit + z.nlit, z.litcap - z.nlit, seqbuf, z.nseq, T, (volatile BAMD_LAS uint32_t*)(BAMD_LAS uint8_t*)(void*)tab_generic, lane);
       if (ss != 0xffffffffu) bsize = zenc::kLitHeader + z.nlit + ss;
       }
       PROF_LAP(5);

@@ -303,14 +303,10 @@ static bool periodic_enabled() { static const bool on = !(getenv("BLOSC_AMD_PERI
 // 8 GiB of reference-written frames, mode 0 / 2: bench19 107 / 50 ms, linspace 17.8 / 15.9, random walk 23.7 / 16.5
 // (profiles/r02f_zstd_decode_modes.txt)
 static int zstd2_mode() { static const int m = getenv("BLOSC_AMD_ZSTD2") ? atoi(getenv("BLOSC_AMD_ZSTD2")) : 2; return m; }
-// typesizes whose byte (un)shuffle runs inside the codec kernels (enc_shuffle.h, k_decode.hip: unshuffle_block_wave); BLOSC_AMD_FUSE_T=0
-// restricts it to 4 and 8 (the state before round 3's typesize 2 / 16 paths: A/B switch)
-static bool fused_typesize(int T) {
-  static const bool wide = !(getenv("BLOSC_AMD_FUSE_T") && atoi(getenv("BLOSC_AMD_FUSE_T")) == 0);
-  return T == 8 || T == 4 || (wide && (T == 2 || T == 16));
-}
-// BLOSC_AMD_FUSE_BIT=0: bitshuffle chunks keep the stand-alone k_bitunshuffle pass (the state before round 4: A/B switch)
-static bool fuse_bit_enabled() { static const bool on = !(getenv("BLOSC_AMD_FUSE_BIT") && atoi(getenv("BLOSC_AMD_FUSE_BIT")) == 0); return on; }
+// typesizes whose byte (un)shuffle runs inside the codec kernels (enc_shuffle.h, k_decode.hip: unshuffle_block_wave); the others, and everything
+// under BLOSC_AMD_FUSE=0 / BLOSC_AMD_SINGLE_QUEUE=1, go through the stand-alone filter kernels
+static bool fused_typesize(int T) { return T == 8 || T == 4 || T == 2 || T == 16; }
+// bitshuffle chunks of these typesizes are (un)shuffled inside the codec kernels as well (round 4: bitshuffle_block_wave_T / bitunshuffle_block_wave)
 static bool bitunshuffle_fused_host(int T) { return T == 1 || T == 2 || T == 4; }
 static bool fuse_enabled() { static const bool on = !(getenv("BLOSC_AMD_FUSE") && atoi(getenv("BLOSC_AMD_FUSE")) == 0); return on; }
 
@@ -376,7 +372,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
     c.first_block = (int32_t)blocks.size(); c.first_stream = (int32_t)streams.size();
     if (memcpyed) c.mode |= CH_MEMCPYED;
     else if (p.doshuffle == 1 && T > 1) { c.mode |= CH_SHUFFLE; if (fused_typesize(T) && fuse_enabled() && !st.single_queue) c.mode |= CH_FUSED_SHUF; }
-    else if (p.doshuffle == 2) { c.mode |= CH_BITSHUFFLE; if (bitunshuffle_fused_host(T) && fuse_enabled() && fuse_bit_enabled() && !st.single_queue) c.mode |= CH_FUSED_SHUF; }
+    else if (p.doshuffle == 2) { c.mode |= CH_BITSHUFFLE; if (bitunshuffle_fused_host(T) && fuse_enabled() && !st.single_queue) c.mode |= CH_FUSED_SHUF; }
     live[(size_t)i] = 1;
     results[i] = 0;
     if (!device_ptrs) { io_src = align_up(io_src, 256) + (size_t)nb; io_dst = align_up(io_dst, 256) + destsize; }
@@ -444,7 +440,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   const bool zsearch = (zstd && env_flag_or("BLOSC_AMD_ZSTD_SEARCH", p.clevel >= 6)) || (zlibc && env_flag_or("BLOSC_AMD_ZLIB_SEARCH", true));
   // Huffman-coded literals (with the per-block tables, or tables + search): BLOSC_AMD_ZSTD_HUFFMAN=1 on top of either switch
   const bool zhuf = zstd && (ztab || zsearch) && env_flag("BLOSC_AMD_ZSTD_HUFFMAN");
-  static const int enc_wpc_lz = getenv("BLOSC_AMD_ENC_WPC") ? atoi(getenv("BLOSC_AMD_ENC_WPC")) : ENC_WAVES_PER_CU;
+  const int enc_wpc_lz = ENC_WAVES_PER_CU;
   const int enc_wpc = zsearch ? (160 * 1024) / (HC_TAB_BYTES + ZS_LDS_BYTES) : (hc ? HC_WAVES_PER_CU : enc_wpc_lz);   // what fits into a CU's LDS
   const bool zdyn = zlibc && env_flag_or("BLOSC_AMD_ZLIB_DYNAMIC", true);      // zlib with dynamic Huffman codes: two passes, the tokens in the sequence scratch
   const size_t zwaves = (zstd || zdyn) ? (size_t)(st.cus > 0 ? st.cus : 256) * (size_t)enc_wpc : 0;
@@ -527,7 +523,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
     hipLaunchKernelGGL(k_shuffle, dim3((unsigned)nblk, (unsigned)tiles_shuf), dim3(FT_THREADS), 0, stream, d_chunks, d_blocks);
   }
   if (any_bit && nblk) {
-    static const bool bitfast = !(getenv("BLOSC_AMD_BITFAST") && atoi(getenv("BLOSC_AMD_BITFAST")) == 0);
+    const bool bitfast = true;       // full tiles of typesize 1 / 2 / 4 / 8 through k_bitfilter_fast, the rest through the generic kernel
     ProfScope ps(st, stream, "k_bitshuffle");
     if (bitfast) hipLaunchKernelGGL(k_bitfilter_fast<0>, dim3((unsigned)nblk, (unsigned)tiles_bit), dim3(FT_THREADS), 0, stream, d_chunks, d_blocks);
     hipLaunchKernelGGL(k_bitshuffle, dim3((unsigned)nblk, (unsigned)tiles_bit), dim3(FT_THREADS), 0, stream, d_chunks, d_blocks, bitfast ? 1 : 0);
@@ -706,14 +702,11 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
     }
     if (L.nstr_queued) {
       ProfScope ps(st, stream, "k_decode_streams");
-      // Occupancy knob: unused dynamic LDS caps how many decoder waves share a CU (and its L2 slice).
-      static const int dec_lds = getenv("BLOSC_AMD_DEC_LDS") ? atoi(getenv("BLOSC_AMD_DEC_LDS")) : 0;
-      static const int dec_wpc = getenv("BLOSC_AMD_DEC_WPC") ? atoi(getenv("BLOSC_AMD_DEC_WPC")) : DEC_WAVES_PER_CU;
-      const dim3 dgrid(persistent_grid(st, L.nstr_queued ? L.nstr_queued : 1, dec_wpc));
+      const dim3 dgrid(persistent_grid(st, L.nstr_queued ? L.nstr_queued : 1, DEC_WAVES_PER_CU));
 #ifdef BAMD_PROFILE_DECODE
       uint32_t* d_prof = nullptr;
       if (getenv("BLOSC_AMD_DEC_PROFILE")) { (void)hipMalloc((void**)&d_prof, L.nstr * 64); (void)hipMemsetAsync(d_prof, 0, L.nstr * 64, stream); }
-      hipLaunchKernelGGL(k_decode_streams, dgrid, dim3(64 * DEC_WAVES), (size_t)dec_lds, stream, L.d_streams, L.d_status, L.d_ticket, L.d_qlist, L.d_qoff, L.d_chunks, L.d_blocks, L.d_blkdone, L.d_spans, L.d_pat, L.d_cost, st.single_queue ? 1 : 0, d_prof);
+      hipLaunchKernelGGL(k_decode_streams, dgrid, dim3(64 * DEC_WAVES), 0, stream, L.d_streams, L.d_status, L.d_ticket, L.d_qlist, L.d_qoff, L.d_chunks, L.d_blocks, L.d_blkdone, L.d_spans, L.d_pat, L.d_cost, st.single_queue ? 1 : 0, d_prof);
       if (d_prof) {
         std::vector<uint32_t> h(L.nstr * 16);
         (void)hipStreamSynchronize(stream);
@@ -723,7 +716,7 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
         (void)hipFree(d_prof);
       }
 #else
-      hipLaunchKernelGGL(k_decode_streams, dgrid, dim3(64 * DEC_WAVES), (size_t)dec_lds, stream, L.d_streams, L.d_status, L.d_ticket, L.d_qlist, L.d_qoff, L.d_chunks, L.d_blocks, L.d_blkdone, L.d_spans, L.d_pat, L.d_cost, st.single_queue ? 1 : 0);
+      hipLaunchKernelGGL(k_decode_streams, dgrid, dim3(64 * DEC_WAVES), 0, stream, L.d_streams, L.d_status, L.d_ticket, L.d_qlist, L.d_qoff, L.d_chunks, L.d_blocks, L.d_blkdone, L.d_spans, L.d_pat, L.d_cost, st.single_queue ? 1 : 0);
 #endif
     }
     // single-block frames through k_zstd_entropy (16 frames per wave) + k_zstd_exec (zstd2_mode above); every other frame
@@ -738,11 +731,7 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
       }
       if (zstd2 == 2 && L.d_zgscr && BAMD_ZSTD_SEQ_KERNEL && !BAMD_ZSTD_LDS_FSE) {
         ProfScope ps(st, stream, "k_zstd_seq");      // the sequence streams of the frames phase A took, one lane per frame
-        // BLOSC_AMD_ZSEQ_LDS=1: the wave's tables in LDS (k_zstd_seq_lds) - measured slower on the benchmark batch (16.2 against 11.7 ms:
-        // 30 frames per wave and two waves per CU put 65 536 frames through in rounds, k_zstd2.hip); without the 16-bit records there is only the global form
-        static const bool zseq_lds = getenv("BLOSC_AMD_ZSEQ_LDS") && atoi(getenv("BLOSC_AMD_ZSEQ_LDS")) != 0;
-        if (zseq_lds && L.d_zctab) hipLaunchKernelGGL(k_zstd_seq_lds, grid1(L.nstr, ZSEQ_LDS_FRAMES), dim3(64), 0, stream, L.d_streams, (int)L.nstr, L.d_chunks, L.d_blocks, L.d_zmeta, L.zseq_delta, L.d_zctab);
-        else hipLaunchKernelGGL(k_zstd_seq, grid1(L.nstr, ZSEQ_FRAMES), dim3(64), 0, stream, L.d_streams, (int)L.nstr, L.d_chunks, L.d_blocks, L.d_zmeta, L.zseq_delta, L.d_zgscr, L.d_zctab);
+        hipLaunchKernelGGL(k_zstd_seq, grid1(L.nstr, ZSEQ_FRAMES), dim3(64), 0, stream, L.d_streams, (int)L.nstr, L.d_chunks, L.d_blocks, L.d_zmeta, L.zseq_delta, L.d_zgscr, L.d_zctab);
       }
       {
         ProfScope ps(st, stream, "k_zstd_exec");
@@ -781,7 +770,7 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
       hipLaunchKernelGGL(k_unshuffle, dim3((unsigned)L.nblk, (unsigned)L.tiles_shuf), dim3(FT_THREADS), 0, stream, L.d_chunks, L.d_blocks);
     }
     if (L.any_bit) {
-      static const bool bitfast = !(getenv("BLOSC_AMD_BITFAST") && atoi(getenv("BLOSC_AMD_BITFAST")) == 0);
+      const bool bitfast = true;       // full tiles of typesize 1 / 2 / 4 / 8 through k_bitfilter_fast, the rest through the generic kernel
       ProfScope ps(st, stream, "k_bitunshuffle");
       if (bitfast) hipLaunchKernelGGL(k_bitfilter_fast<1>, dim3((unsigned)L.nblk, (unsigned)L.tiles_bit), dim3(FT_THREADS), 0, stream, L.d_chunks, L.d_blocks);
       hipLaunchKernelGGL(k_bitunshuffle, dim3((unsigned)L.nblk, (unsigned)L.tiles_bit), dim3(FT_THREADS), 0, stream, L.d_chunks, L.d_blocks, bitfast ? 1 : 0);
@@ -799,16 +788,14 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
 static void filter_tiles(ChunkDesc& c, bool& any_shuf, bool& any_bit, int& tiles_shuf, int& tiles_bit, bool may_fuse) {
   const int32_t T = c.typesize, N = c.blocksize / T;
   // (Zstd chunks: only unsplit ones - the wave that decodes a block's one stream unshuffles it, k_decode.hip: fused_unshuffle_own_block;
-  //  zlib chunks: split ones too, k_zlib_streams has per-XCD queues and the hand-off of the LZ4 kernel; BLOSC_AMD_FUSE_Z=0 keeps k_unshuffle
-  //  for both: A/B switch)
-  static const bool fuse_z = !(getenv("BLOSC_AMD_FUSE_Z") && atoi(getenv("BLOSC_AMD_FUSE_Z")) == 0);
+  //  zlib chunks: split ones too, k_zlib_streams has per-XCD queues and the hand-off of the LZ4 kernel)
   const bool zfmt = c.fmt == FMT_ZSTD || c.fmt == FMT_ZLIB;
-  if ((c.mode & CH_SHUFFLE) && fused_typesize(T) && fuse_enabled() && may_fuse && (!zfmt || (fuse_z && (c.fmt == FMT_ZLIB || c.nsplits == 1)))) { c.mode |= CH_FUSED_UNSHUF; return; }
+  if ((c.mode & CH_SHUFFLE) && fused_typesize(T) && fuse_enabled() && may_fuse && (!zfmt || c.fmt == FMT_ZLIB || c.nsplits == 1)) { c.mode |= CH_FUSED_UNSHUF; return; }
   if (c.mode & CH_SHUFFLE) {
     any_shuf = true;
     int t = (N + shuffle_tile_elems(T) - 1) / shuffle_tile_elems(T); if (t < 1) t = 1;
     if (t > tiles_shuf) tiles_shuf = t;
-  } else if ((c.mode & CH_BITSHUFFLE) && bitunshuffle_fused_host(T) && fuse_enabled() && fuse_bit_enabled() && may_fuse && !zfmt) {
+  } else if ((c.mode & CH_BITSHUFFLE) && bitunshuffle_fused_host(T) && fuse_enabled() && may_fuse && !zfmt) {
     c.mode |= CH_FUSED_BITUNSH;      // round 4: the decode kernel bit-unshuffles every block when its last stream is done (k_decode.hip: bitunshuffle_block_wave)
   } else if (c.mode & CH_BITSHUFFLE) {
     any_bit = true;
@@ -870,8 +857,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   const size_t o_zmeta = cv.take(L.any_zstd ? sizeof(ZMeta) * (nstr ? nstr : 1) : 64);
   const size_t o_zticket = cv.take(64);
   const size_t o_zgscr = cv.take((L.any_zstd && zstd2_mode() == 2) ? sizeof(ZgLds) * (nstr ? nstr : 1) : 64);
-  static const bool zctab_on = !(getenv("BLOSC_AMD_ZSTD_CTAB") && atoi(getenv("BLOSC_AMD_ZSTD_CTAB")) == 0);      // 0: k_zstd_seq reads the 32-bit tables (A/B switch)
-  const bool use_zctab = L.any_zstd && zstd2_mode() == 2 && zctab_on && BAMD_ZSTD_SEQ_KERNEL && !BAMD_ZSTD_LDS_FSE;
+  const bool use_zctab = L.any_zstd && zstd2_mode() == 2 && BAMD_ZSTD_SEQ_KERNEL && !BAMD_ZSTD_LDS_FSE;
   const size_t o_zctab = cv.take(use_zctab ? sizeof(ZcTab) * (nstr ? nstr : 1) : 64);
   if (st.dev.ensure(cv.off)) return -1;
   uint8_t* D = st.dev.base;
@@ -1023,7 +1009,7 @@ int engine_getitem(const void* src, int start, int nitems, void* dest, bool src_
   const size_t o_spans = cv.take(8 * nstr);
   const size_t o_pat = cv.take(span_enabled() ? (size_t)2048 * nstr : 256);
   const size_t o_out = cv.take(span + 256);
-  const size_t o_filt = cv.take(span + (size_t)nblk * (size_t)FILT_PLANE_PAD * (size_t)(c.typesize > 0 ? c.typesize : 1) + 256);   // room for the padded plane layout of a fused chunk
+  const size_t o_filt = cv.take(span + 256);   // room for the padded plane layout of a fused chunk
   const size_t o_zlit = cv.take((fmt == FMT_ZSTD ? span : 0) + 256);
   const size_t o_zticket = cv.take(64);
   if (st.dev.ensure(cv.off)) return -1;

@@ -83,10 +83,7 @@ typedef ZI_TAB uint8_t tab8;
 // inference leaves volatile accesses alone, and every table lookup of k_zlib_streams was a flat_load (96 of them, not one ds_read;
 // 0.49 G flat loads per 8 GiB, profiles/r03zp_zlib_decode_sq_counters.txt) - twice the latency of an LDS read in a loop that is one
 // dependent lookup after the other.
-#ifndef BAMD_ZI_LDS
-#define BAMD_ZI_LDS 1        // 0: generic pointers (flat loads) as before - A/B switch
-#endif
-#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__) && !defined(BAMD_WAVE_EMU) && BAMD_ZI_LDS
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__) && !defined(BAMD_WAVE_EMU)
 #define ZI_LDS __attribute__((address_space(3)))
 #else
 #define ZI_LDS

@@ -162,10 +162,7 @@ __device__ __attribute__((noinline)) void span_long_match_call(gu8* out_, uint32
   wave_copy_disjoint(out + hi, sp.pat + (hi & (SPAN_PAT - 1u)), mpos + ml - hi, lane);
 }
 __device__ __forceinline__ bool span_long_match(gu8* out, uint32_t mpos, uint32_t off, uint32_t ml, int lane, SpanCtx& sp) {
-#ifndef BAMD_SELFSPAN
-#define BAMD_SELFSPAN 1
-#endif
-  if (!sp.enabled || sp.hi || ml < 16384u || off > (BAMD_SELFSPAN ? 65536u : SPAN_PAT) || (off & (off - 1u))) return false;
+  if (!sp.enabled || sp.hi || ml < 16384u || off > 65536u || (off & (off - 1u))) return false;
   const uint32_t lo = (mpos + 1023u) & ~1023u, hi = (mpos + ml) & ~1023u;
   if (hi < lo + 8192u) return false;
   // a self span's base travels in 24 bits next to log2(period) (unshuffle_block_wave_T: `ob`): planes of 16 MiB and more (typesize 2 with
@@ -393,17 +390,11 @@ struct Rows { uint32_t r[T]; };
 template <int T>
 struct PlanePtrs { const gu8* p[T]; };
 
-#ifndef BAMD_DST_STREAM
-#define BAMD_DST_STREAM 2     // 2: final output of the fused unshuffle with non-temporal stores: bench19 -3.8 %, linspace -1.5 % (profiles/r02f_decode_nt_variants.txt); 0: plain
-#endif
-__device__ __forceinline__ void st16_dst(gu8* p, uint4 v) { if (BAMD_DST_STREAM == 2) g_st16_nt(p, v); else g_st16(p, v); }
-#ifndef BAMD_UNSH_LD_NT
-#define BAMD_UNSH_LD_NT 0     // 1: the fused unshuffle reads the planes with non-temporal loads.  Round 2: -2 %.  Round 4, with the planes arriving as whole rows out of the ring decoder: plain loads are 3-6 % FASTER on every data set (profiles/r04i_dec_ab_dst_stores_plane_loads_nt.txt)
-#endif
-__device__ __forceinline__ uint32_t ld4_plane(const gu8* p) { return BAMD_UNSH_LD_NT ? g_ld4_nt(p) : g_ld4(p); }
-#ifndef BAMD_UNSH_QUAD8
-#define BAMD_UNSH_QUAD8 0      // typesize 8: the two 16-byte stores of a step re-dealt inside the quad (64 contiguous bytes per quad and instruction).  MEASURED: 5-6 % SLOWER on bench19 (4.76 -> 5.00, 4.34 -> 4.61 ms; two copies of each build taking turns, profiles/r03zb_ab_quad_dealt_typesize8_rejected.txt) - what paid for typesize 16 (16-byte pieces 64 bytes apart) does not for pieces 32 bytes apart
-#endif
+// the final output of the fused unshuffles leaves with non-temporal stores (round 2: bench19 -3.8 %, linspace -1.5 %, profiles/r02f_decode_nt_variants.txt;
+// round 4, plain against non-temporal with the ring decoder: no difference, profiles/r04i_dec_ab_dst_stores_plane_loads_nt.txt); the planes are read with
+// plain loads (the rows the ring decoder flushed are in L2: non-temporal loads cost 3-6 %, same file)
+__device__ __forceinline__ void st16_dst(gu8* p, uint4 v) { g_st16_nt(p, v); }
+__device__ __forceinline__ uint32_t ld4_plane(const gu8* p) { return g_ld4(p); }
 // Which 4 elements of a 256-element step a lane's plane dwords cover (byte offset into the plane).  Typesize 2 / 4: elements
 // 4 l .. 4 l + 3, i.e. T * 4 contiguous output bytes per lane and contiguous lanes - every store instruction is one contiguous run.
 // Typesize 8 (round 4): a lane's 32 output bytes are two 16-byte stores, and dealt that way every store instruction wrote only half of
@@ -412,17 +403,14 @@ __device__ __forceinline__ uint32_t ld4_plane(const gu8* p) { return BAMD_UNSH_L
 // So lanes work in pairs: lane 2 i loads the dword of elements 4 i .. 4 i + 3, lane 2 i + 1 that of elements 128 + 4 i .. (each wave load still
 // covers two full 128-byte lines), the pair swaps halves (one DPP quad_perm per plane) and lane l then holds elements 2 l, 2 l + 1 of the
 // step's first 128 elements AND of its second 128: two stores of 1 KiB, each fully contiguous.
-#ifndef BAMD_UNSH_PAIR8
-#define BAMD_UNSH_PAIR8 1
-#endif
 template <int T>
 __device__ __forceinline__ uint32_t unsh_l4(int lane) {
-  if (T == 8 && BAMD_UNSH_PAIR8) return 4u * (((uint32_t)lane >> 1) + 32u * ((uint32_t)lane & 1u));
+  if (T == 8) return 4u * (((uint32_t)lane >> 1) + 32u * ((uint32_t)lane & 1u));
   return 4u * (uint32_t)lane;
 }
 template <int T>
 __device__ __forceinline__ void unshuffle_store(gu8* dst, uint32_t e, int lane, const Rows<T>& x) {
-  if constexpr (T == 8 && BAMD_UNSH_PAIR8) {
+  if constexpr (T == 8) {
     const bool odd = (lane & 1) != 0;
     // x.r[j] = plane j's bytes of elements 4 i .. 4 i + 3 (even lane) / 128 + 4 i .. (odd lane), y = the pair partner's.  First store: elements
     // 2 l, 2 l + 1 = the even lane's low half (even l) or high half (odd l); second store: the odd lane's low / high half
@@ -448,36 +436,11 @@ __device__ __forceinline__ void unshuffle_store(gu8* dst, uint32_t e, int lane, 
   if constexpr (T == 2) {                            // elements 0..3 (2 bytes each): one 8-byte store per lane
     const uint32_t lo = __builtin_amdgcn_perm(x.r[1], x.r[0], 0x05010400u), hi = __builtin_amdgcn_perm(x.r[1], x.r[0], 0x07030602u);
     const uint64_t v = (uint64_t)lo | ((uint64_t)hi << 32);
-    if (BAMD_DST_STREAM == 2) g_st8_nt(o, v); else g_st8(o, v);
-  } else {
-  uint32_t t0, t1, t2, t3;
-  transpose4x4(x.r[0], x.r[1], x.r[2], x.r[3], t0, t1, t2, t3);
-  if (T == 8) {
-    uint32_t u0, u1, u2, u3;
-    transpose4x4(x.r[4], x.r[5], x.r[6], x.r[7], u0, u1, u2, u3);
-    if (BAMD_UNSH_QUAD8) {
-      // a lane's two 16-byte pieces lie 32 bytes apart from its neighbour's: every store instruction half-fills 32 sectors.  Re-dealt
-      // inside the quad (the quad's 128 bytes are pieces 0..7, lane i holds 2i and 2i + 1; store k writes piece 4k + i from lane (4k + i) >> 1),
-      // a quad writes 64 contiguous bytes per instruction - the typesize-16 lesson of quad_byte_transpose
-      const uint32_t p0[4] = {t0, u0, t1, u1}, p1[4] = {t2, u2, t3, u3};
-      uint32_t a[4], b[4];
-      const bool odd = (lane & 1) != 0;
-#pragma unroll
-      for (int d = 0; d < 4; d++) {
-        const uint32_t a0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p0[d], 0x50, 0xf, 0xf, true), a1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p1[d], 0x50, 0xf, 0xf, true);
-        const uint32_t b0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p0[d], 0xFA, 0xf, 0xf, true), b1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p1[d], 0xFA, 0xf, 0xf, true);
-        a[d] = odd ? a1 : a0; b[d] = odd ? b1 : b0;
-      }
-      gu8* oq = dst + (size_t)(e + 16u * ((uint32_t)lane >> 2)) * 8u + 16u * ((uint32_t)lane & 3u);
-      st16_dst(oq, make_uint4(a[0], a[1], a[2], a[3]));
-      st16_dst(oq + 64, make_uint4(b[0], b[1], b[2], b[3]));
-    } else {
-    st16_dst(o, make_uint4(t0, u0, t1, u1));         // elements 0, 1 (8 bytes each)
-    st16_dst(o + 16, make_uint4(t2, u2, t3, u3));    // elements 2, 3
-    }
-  } else {
-    st16_dst(o, make_uint4(t0, t1, t2, t3));         // elements 0..3 (4 bytes each)
-  }
+    g_st8_nt(o, v);
+  } else {                                           // typesize 4: elements 0..3 (4 bytes each), one 16-byte store per lane
+    uint32_t t0, t1, t2, t3;
+    transpose4x4(x.r[0], x.r[1], x.r[2], x.r[3], t0, t1, t2, t3);
+    st16_dst(o, make_uint4(t0, t1, t2, t3));
   }
 }
 
@@ -519,61 +482,18 @@ __device__ void unshuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize,
   // A group = 4 steps (1024 elements): all its loads are issued before its first store.  Span bounds are multiples of 1024, so one
   // decision per plane and group picks the plane, the pattern table or the register.
   const uint32_t l4 = unsh_l4<T>(lane);
-  auto load_group = [&](Rows<T> (&g)[4], uint32_t eg) {
-#pragma unroll
-    for (int j = 0; j < T; j++) {
-      const bool in_span = eg >= lo[j] && eg < hi[j];            // wave-uniform
-      const bool reg = in_span && ((small >> j) & 1u);
-      if (reg) { g[0].r[j] = g[1].r[j] = g[2].r[j] = g[3].r[j] = pr[j]; }   // scalar branch: no load at all
-      else if (in_span && ((self >> j) & 1u)) {                 // the plane's own period in front of the span, address per lane
-        const uint32_t o = ob[j] & 0xffffffu, m = (1u << (ob[j] >> 24)) - 1u;
-        const uint32_t q = eg + l4 - o;
-        g[0].r[j] = ld4_plane(pl[j] + o + (q & m)); g[1].r[j] = ld4_plane(pl[j] + o + ((q + 256u) & m));
-        g[2].r[j] = ld4_plane(pl[j] + o + ((q + 512u) & m)); g[3].r[j] = ld4_plane(pl[j] + o + ((q + 768u) & m));
-      } else {
-        const gu8* p = in_span ? pat + (size_t)j * SPAN_PAT + (eg & (SPAN_PAT - 1u)) : pl[j] + eg;
-        g[0].r[j] = ld4_plane(p + l4); g[1].r[j] = ld4_plane(p + l4 + 256u); g[2].r[j] = ld4_plane(p + l4 + 512u); g[3].r[j] = ld4_plane(p + l4 + 768u);
-      }
-    }
-  };
-  auto store_group = [&](const Rows<T> (&g)[4], uint32_t eg) {
-    unshuffle_store<T>(dst, eg, lane, g[0]); unshuffle_store<T>(dst, eg + 256u, lane, g[1]);
-    unshuffle_store<T>(dst, eg + 512u, lane, g[2]); unshuffle_store<T>(dst, eg + 768u, lane, g[3]);
-  };
-#ifndef BAMD_UNSH_PIPE
-#define BAMD_UNSH_PIPE 0      // two groups in flight: built in round 4 with 128 registers to spend, and 32 % SLOWER (5.55 against 4.20 ms, profiles/r04g_dec_ab_bisect_walk_pipe_rowfill.txt): the span branches around the loads leave the compiler no exact vmcnt (waits of vmcnt(0..3) in the ISA) and the second register set spills
-#endif
-  if (BAMD_UNSH_PIPE && T <= 8) {
-    // Software pipeline, two register sets: the loads of group g + 1 are issued BEFORE the stores of group g.  gfx950 has one in-order
-    // counter for vector loads and stores: with "load a group, store it, load the next" every group's loads queue up behind the
-    // acknowledgement of the previous group's stores - load latency and store latency add up (1.0 M cycles per 1 MiB block in
-    // profiles/r04a_dec_phase_ring8k_first.txt, and the fused unshuffle is 1.8 ms of the 4.2 ms kernel: profiles/r04c_*).  (Round 3
-    // tried this at 96 registers, where it spilled: 10 % slower, profiles/r03i_dec_ab_pipelined_unshuffle_rejected.txt.)
-    Rows<T> A[4], B[4];
-    if (N >= 1024u) load_group(A, 0u);
-    for (; e + 2048u <= N; e += 2048u) {
-      load_group(B, e + 1024u);
-      store_group(A, e);
-      // the group behind B - or, at the end, B's own once more (dropped): the same number of loads in every iteration
-      load_group(A, e + 3072u <= N ? e + 2048u : e + 1024u);
-      store_group(B, e + 1024u);
-    }
-    if (e + 1024u <= N) { store_group(A, e); e += 1024u; }      // an odd number of groups: A holds the last one
-  } else {
-    // (the round-3 form, spelled out: one group at a time)
-#ifdef BAMD_UNSH_NOSTORE
-    uint32_t acc_ = 0;
-#endif
+  // (Two things round 4 tried on this loop and dropped.  A software pipeline - two register sets, the loads of group g + 1 issued before the
+  //  stores of group g -: 32 % SLOWER, 5.55 against 4.20 ms; the span branches around the loads leave the compiler no exact vmcnt and the second
+  //  register set spills - round 3 had seen -10 % at 96 registers (profiles/r04g_dec_ab_bisect_walk_pipe_rowfill.txt, r03i_*).  And spreading the
+  //  block's stores thin behind the steps of the streams the wave decodes next: no gain - what the unshuffle costs is its STORES, however they
+  //  are issued (profiles/r04h_dec_ab_unshuffle_loads_vs_stores.txt, r04l_dec_ab_background_stores_experiment.txt).)
+  {
     for (; e + 1024u <= N; e += 1024u) {
       Rows<T> a, b, c, d;
 #pragma unroll
       for (int j = 0; j < T; j++) {
         const bool in_span = e >= lo[j] && e < hi[j];            // wave-uniform
-#ifdef BAMD_UNSH_NOLOAD         // timing experiment (wrong bytes on purpose): the stores without the loads
-        const bool reg = true;
-#else
         const bool reg = in_span && ((small >> j) & 1u);
-#endif
         if (reg) { a.r[j] = b.r[j] = c.r[j] = d.r[j] = pr[j]; }   // scalar branch: no load at all
         else if (in_span && ((self >> j) & 1u)) {                 // the plane's own period in front of the span, address per lane
           const uint32_t o = ob[j] & 0xffffffu, m = (1u << (ob[j] >> 24)) - 1u;
@@ -585,16 +505,9 @@ __device__ void unshuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize,
           a.r[j] = ld4_plane(p + l4); b.r[j] = ld4_plane(p + l4 + 256u); c.r[j] = ld4_plane(p + l4 + 512u); d.r[j] = ld4_plane(p + l4 + 768u);
         }
       }
-#ifdef BAMD_UNSH_NOSTORE        // timing experiment (wrong bytes on purpose): the loads without the stores
-      { uint32_t x_ = 0; for (int j = 0; j < T; j++) x_ ^= a.r[j] ^ b.r[j] ^ c.r[j] ^ d.r[j]; acc_ ^= x_; }
-#else
       unshuffle_store<T>(dst, e, lane, a); unshuffle_store<T>(dst, e + 256u, lane, b);
       unshuffle_store<T>(dst, e + 512u, lane, c); unshuffle_store<T>(dst, e + 768u, lane, d);
-#endif
     }
-#ifdef BAMD_UNSH_NOSTORE
-    if (acc_ == 0x12345u) g_st4(dst + l4, acc_);
-#endif
   }
   // behind the last multiple of 1024 nothing is skipped
   for (; e + 256u <= N; e += 256u) {
@@ -942,15 +855,9 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
   // without this topology gets.
   BAMD_WAIT_STORES();
   uint32_t old = 0;
-#ifndef BAMD_HANDOFF_RELEASE
-#define BAMD_HANDOFF_RELEASE 0     // 1: a release at agent scope (the formally sufficient form: L2 write-back in front of the counter).  Timed in round 4: profiles/r04s_*
-#endif
-  if (lane == 0) old = __hip_atomic_fetch_add(&blk_done[gb], 1u, BAMD_HANDOFF_RELEASE ? __ATOMIC_RELEASE : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane == 0) old = __hip_atomic_fetch_add(&blk_done[gb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   old = (uint32_t)__builtin_amdgcn_readlane((int)old, 0);
   if (old + 1u != nstreams) return;
-#ifdef BAMD_DEC_NOUNSH
-  return;               // timing experiment (wrong bytes on purpose): what the fused unshuffle costs the kernel
-#endif
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // buffer_inv sc1: this CU's L1 forgets the block's scratch lines
   const size_t boff = (size_t)uni((uint32_t)b->blk) * (size_t)uni((uint32_t)c->blocksize);
   if (mode & CH_FUSED_BITUNSH) {

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES, enc_mode_hc(MODE) ? 2 : ((MODE == E
     ) {
   constexpr bool ZSTD = enc_mode_zstd(MODE);
   constexpr int TABBYTES = enc_mode_hc(MODE) ? HC_TAB_BYTES : ENC_TAB_BYTES;      // the match finder's table; the writers' LDS sits behind it
-  __shared__ __attribute__((aligned(16))) enc_entry_t tabs[ENC_WAVES][(TABBYTES + (ZSTD ? ZS_LDS_BYTES : (enc_mode_zlib(MODE) ? DFL_LDS_BYTES : (MODE == ENC_LZ ? ENC_RB_BYTES : 0)))) / 4];      // ENC_LZ: the LZ4 emitter's run buffer behind the table (enc_lz.h)
+  __shared__ __attribute__((aligned(16))) enc_entry_t tabs[ENC_WAVES][(TABBYTES + (ZSTD ? ZS_LDS_BYTES : (enc_mode_zlib(MODE) ? DFL_LDS_BYTES : 0))) / 4];      // ENC_LZ: the LZ4 emitter's run buffer behind the table (enc_lz.h)
   static_assert(ENC_WAVES == 1, "one stream per wave, one wave per workgroup");
   const int lane = threadIdx.x & 63;
   uint64_t* seqbuf = nullptr;

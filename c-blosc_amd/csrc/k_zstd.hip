@@ -59,9 +59,6 @@ __device__ __forceinline__ void wave_fill(gu8* dst, uint32_t v, uint32_t n, int 
 // position; every lane copies its own literals; matches whose source ends before this group's output are
 // independent of the group and are copied by their lanes at once; the others - long, or reading what this
 // group produces - follow in stream order through wave_match_copy.
-#ifndef BAMD_ZSTD_EXEC16
-#define BAMD_ZSTD_EXEC16 1
-#endif
 // ---------------------------------------------------------------------------------------------
 // Groups with several DEPENDENT matches, assembled in LDS (round 3; the Zstd twin of lz4_step_lds in k_decode.hip).  A frame the
 // reference writes for a shuffled 128 KiB block is ~4000 sequences with matches of a few dozen bytes whose sources lie in the
@@ -85,12 +82,6 @@ constexpr uint32_t ZXB_WORDS = (ZXB_LW_OFF + ZXB_LW + 16u) / 4u;
 struct ZxState { uint32_t hist_valid, lw_valid, lw_base; };
 #ifndef BAMD_ZXB_GROUPSTORE
 #define BAMD_ZXB_GROUPSTORE 1    // an LDS-assembled group goes to memory in one pass of coalesced stores (0: every piece is stored where it is made)
-#endif
-#ifndef BAMD_ZXB_LITWIN
-#define BAMD_ZXB_LITWIN 1        // literals and near independent matches of an LDS-assembled group come out of LDS (0: loaded from memory per group)
-#endif
-#ifndef BAMD_ZXB_SLIDE
-#define BAMD_ZXB_SLIDE 1         // consecutive LDS-assembled groups keep their history in the buffer (0: every group loads it)
 #endif
 #ifndef BAMD_ZXB_MIN_REST
 #define BAMD_ZXB_MIN_REST 2      // dependent matches a group needs before the LDS form is used (0: never)
@@ -273,12 +264,12 @@ __device__ __forceinline__ bool zstd_exec16(uint32_t ll_b, uint32_t ml_b, uint32
     const bool fits = __ballot(dep0 && (ml > ZXB_MAXM || off > excl + ll + ZXB_HIST)) == 0ull;      // short, and the source inside the buffer
     if (ndep >= (uint32_t)BAMD_ZXB_MIN_REST && fits) {
       uint32_t lw = 0u;                        // literals out of the window?  (see zstd_exec16_lds)
-      if (BAMD_ZXB_LITWIN && zx && total_lit <= ZXB_LW) {
+      if (zx && total_lit <= ZXB_LW) {
         const bool covered = zx->lw_valid && lp >= zx->lw_base && lp + total_lit <= zx->lw_base + ZXB_LW;
         lw = covered ? ((zx->lw_base << 1) | 1u) : 0xffffffffu;
         if (!covered) { zx->lw_valid = 1u; zx->lw_base = lp; }
       }
-      zstd_exec16_lds(out, lit, xbuf, ll, ml, off, excl, lexcl, indep0, dep0, op, lp, lane, (BAMD_ZXB_SLIDE && zx) ? zx->hist_valid : 0u, total_out, lw, regen);
+      zstd_exec16_lds(out, lit, xbuf, ll, ml, off, excl, lexcl, indep0, dep0, op, lp, lane, zx ? zx->hist_valid : 0u, total_out, lw, regen);
       if (zx) zx->hist_valid = 1u;
       op += total_out; lp += total_lit;
       return true;

@@ -27,21 +27,6 @@
 #ifndef BAMD_ZSTD_SEQ_KERNEL
 #define BAMD_ZSTD_SEQ_KERNEL 1    // the FSE sequence streams of the global two-phase path in a kernel of their own, one lane per frame (k_zstd_seq); 0: inside k_zstd_entropy, on one lane in four
 #endif
-#ifndef BAMD_ZENT_GLOBAL_IN
-#define BAMD_ZENT_GLOBAL_IN 1
-#endif
-#ifndef BAMD_ZHUF_FAST
-#define BAMD_ZHUF_FAST 1          // k_zstd_entropy: the Huffman literal streams through zhuf_run (0: zd::huf_decode_stream as it stands in zstd_serial.h)
-#endif
-#ifndef BAMD_ZSEQ_RUNBUF
-#define BAMD_ZSEQ_RUNBUF 1        // k_zstd_seq / k_zstd_seq_lds: the triples leave through an LDS run buffer, eight at a time (0: one store per sequence)
-#endif
-#ifndef BAMD_ZSEQ_FAST
-#define BAMD_ZSEQ_FAST 1          // zseq_run: three refill points per sequence while >= 12 stream bytes are left (0: the general bit reader for every field)
-#endif
-#ifndef BAMD_ZENT_SKIP
-#define BAMD_ZENT_SKIP 0         // timing experiments only (the results are wrong): bit 0 = no FSE sequence loop, bit 1 = no Huffman literal streams - what is left is the per-frame set-up
-#endif
 namespace bamd {
 
 enum : uint32_t { ZM_FALLBACK = 0, ZM_READY = 1, ZM_ERROR = 2, ZM_SEQ = 3 };      // ZM_SEQ: everything but the sequence stream is done (k_zstd_seq turns it into READY or ERROR)
@@ -131,7 +116,7 @@ __device__ __forceinline__ bool zseq_run(zd::SeqState& st, int nseq, const uint3
     nacc -= nb_; off -= nb_;
     return v;
   };
-  for (int i = 0; fine && i < ((BAMD_ZENT_SKIP & 1) ? 0 : nseq); i++) {
+  for (int i = 0; fine && i < nseq; i++) {
     uint32_t cl, co, cm;
     if (GC == 2) {
       typedef const volatile __attribute__((address_space(3))) uint16_t* lp16;
@@ -149,7 +134,7 @@ __device__ __forceinline__ bool zseq_run(zd::SeqState& st, int nseq, const uint3
     const uint32_t xl = cl >> 6, xm = cm >> 6, xo = co >> 6;
     const int nl = al_l - zd::hb32(xl), nm = al_m - zd::hb32(xm), no = al_o - zd::hb32(xo);
     uint32_t ov, q_ml, q_ll;
-    if (BAMD_ZSEQ_FAST && bytepos >= 12) {
+    if (bytepos >= 12) {
       refill(); ov = (1u << oc) + take(oc);
       refill();
       if (codes_) {
@@ -200,7 +185,7 @@ __device__ __forceinline__ bool zseq_run(zd::SeqState& st, int nseq, const uint3
     }
   }
   if (sqbuf_ && fine) {                                    // the last, incomplete run
-    const int done = (BAMD_ZENT_SKIP & 1) ? 0 : nseq;
+    const int done = nseq;
     for (int i = done & ~7; i < done; i++) sq[i] = sqbuf[(uint32_t)(i & 7) * 64u + (uint32_t)lane];
   }
   st.b.off = off;
@@ -288,7 +273,7 @@ __global__ __launch_bounds__(64) void k_zstd_entropy_t(const StreamDesc* __restr
   int hs_off = 0, hlen = 0;                 // Huffman payload (behind the table description)
   if (sid < nstreams) {
     const StreamDesc& sd = streams[sid];
-    in = BAMD_ZENT_GLOBAL_IN ? (const uint8_t*)as_global(sd.in) : sd.in; n = sd.in_size; want = sd.out_size;      // (through the global address space: what is inlined below - zstd_serial.h's header, table and Huffman-table code - then uses global_load, not flat_load: 58 flat instructions -> 0)
+    in = (const uint8_t*)as_global(sd.in); n = sd.in_size; want = sd.out_size;      // (through the global address space: what is inlined below - zstd_serial.h's header, table and Huffman-table code - then uses global_load, not flat_load: 58 flat instructions -> 0)
     take = sd.fmt == FMT_ZSTD && n >= 0 && n != want;
     if (take) {
       const ChunkDesc& c = chunks[sd.chunk];
@@ -331,7 +316,7 @@ __global__ __launch_bounds__(64) void k_zstd_entropy_t(const StreamDesc* __restr
   const uint32_t gstate = (uint32_t)__builtin_amdgcn_ds_bpermute(src0, (int)state);
   const int gtype = __builtin_amdgcn_ds_bpermute(src0, lh.type);
   uint32_t lit_ok = 1;
-  if (take && gstate == ZM_READY && gtype == 2 && !(BAMD_ZENT_SKIP & 2)) {
+  if (take && gstate == ZM_READY && gtype == 2) {
     const int g_regen = __builtin_amdgcn_ds_bpermute(src0, lh.regen), g_nstreams = __builtin_amdgcn_ds_bpermute(src0, lh.nstreams);
     const int g_hs = __builtin_amdgcn_ds_bpermute(src0, hs_off), g_hlen = __builtin_amdgcn_ds_bpermute(src0, hlen);
     const int g_mb = __builtin_amdgcn_ds_bpermute(src0, huf.maxbits);
@@ -339,7 +324,7 @@ __global__ __launch_bounds__(64) void k_zstd_entropy_t(const StreamDesc* __restr
     const uint8_t* hs = in + g_boff + g_hs;
     zd::Huf h2 = {L->t.huf, g_mb};
     if (g_nstreams == 1) {
-      if (sub == 0) lit_ok = (BAMD_ZHUF_FAST ? zhuf_run<GLOBAL>(h2.e, h2.maxbits, hs, g_hlen, lit, g_regen) : zd::huf_decode_stream(h2, hs, g_hlen, lit, g_regen)) ? 1u : 0u;
+      if (sub == 0) lit_ok = zhuf_run<GLOBAL>(h2.e, h2.maxbits, hs, g_hlen, lit, g_regen) ? 1u : 0u;
     } else if (g_hlen < 6) lit_ok = 0;
     else {
       const int s1 = hs[0] | (hs[1] << 8), s2 = hs[2] | (hs[3] << 8), s3 = hs[4] | (hs[5] << 8), s4 = g_hlen - 6 - s1 - s2 - s3;
@@ -349,7 +334,7 @@ __global__ __launch_bounds__(64) void k_zstd_entropy_t(const StreamDesc* __restr
         const int so = sub == 0 ? 0 : (sub == 1 ? s1 : (sub == 2 ? s1 + s2 : s1 + s2 + s3));
         const int sl = sub == 0 ? s1 : (sub == 1 ? s2 : (sub == 2 ? s3 : s4));
         const int cnt = sub < 3 ? q : g_regen - 3 * q;
-        lit_ok = (BAMD_ZHUF_FAST ? zhuf_run<GLOBAL>(h2.e, h2.maxbits, hs + 6 + so, sl, lit + sub * q, cnt) : zd::huf_decode_stream(h2, hs + 6 + so, sl, lit + sub * q, cnt)) ? 1u : 0u;
+        lit_ok = zhuf_run<GLOBAL>(h2.e, h2.maxbits, hs + 6 + so, sl, lit + sub * q, cnt) ? 1u : 0u;
       }
     }
   }
@@ -467,9 +452,6 @@ __device__ __forceinline__ void zseq_fill_codes(volatile uint32_t* codes, int la
   if (lane < 53) codes[36 + lane] = zd::ml_base(lane) | ((uint32_t)zd::ml_bits(lane) << 24);
   BAMD_LDS_SYNC();
 }
-#ifndef BAMD_ZSEQ_CODES
-#define BAMD_ZSEQ_CODES 1         // k_zstd_seq: length-code bases and extra-bit counts from an LDS table
-#endif
 #ifndef BAMD_ZSEQ_FRAMES
 #define BAMD_ZSEQ_FRAMES 64       // frames per wavefront of k_zstd_seq (lanes above that idle: fewer frames per wave = more waves to hide the table reads behind)
 #endif
@@ -479,7 +461,7 @@ __global__ __launch_bounds__(64) void k_zstd_seq(const StreamDesc* __restrict__ 
                                                  const ZcTab* __restrict__ ctab) {
   __shared__ uint64_t sqb[8 * 64];           // the triples' run buffer (zseq_run)
   __shared__ uint32_t codes[36 + 53];
-  if (BAMD_ZSEQ_CODES) zseq_fill_codes(codes, (int)(threadIdx.x & 63));
+  zseq_fill_codes(codes, (int)(threadIdx.x & 63));
   const int sid = (int)blockIdx.x * ZSEQ_FRAMES + (int)(threadIdx.x & 63);
   if ((int)(threadIdx.x & 63) >= ZSEQ_FRAMES || sid >= nstreams) return;
   if (meta[sid].state != ZM_SEQ) return;
@@ -497,8 +479,8 @@ __global__ __launch_bounds__(64) void k_zstd_seq(const StreamDesc* __restrict__ 
   st.rep[0] = 1u; st.rep[1] = 4u; st.rep[2] = 8u;
   bool fine = zd::seq_begin(st, tb, sd.in + meta[sid].pad_[0], (int)meta[sid].pad_[1]);
   if (fine) {
-    volatile uint64_t* rb = BAMD_ZSEQ_RUNBUF ? sqb : nullptr;
-    if (ctab) fine = zseq_run<1>(st, nseq, nullptr, nullptr, nullptr, ctab[sid].ll, ctab[sid].of, ctab[sid].ml, al_l, al_o, al_m, sq, rb, (int)(threadIdx.x & 63), BAMD_ZSEQ_CODES ? codes : nullptr);
+    volatile uint64_t* rb = sqb;
+    if (ctab) fine = zseq_run<1>(st, nseq, nullptr, nullptr, nullptr, ctab[sid].ll, ctab[sid].of, ctab[sid].ml, al_l, al_o, al_m, sq, rb, (int)(threadIdx.x & 63), codes);
     else fine = zseq_run(st, nseq, L->t.fse[0], L->t.fse[1], L->t.fse[2], nullptr, nullptr, nullptr, al_l, al_o, al_m, sq, rb, (int)(threadIdx.x & 63));
   }
   if (fine && st.b.off != 0) fine = false;                                  // the bit stream must be consumed exactly
@@ -508,55 +490,8 @@ __global__ __launch_bounds__(64) void k_zstd_seq(const StreamDesc* __restrict__ 
 #endif
 }
 
-// The same with the frames' tables in LDS (round 3).  k_zstd_seq is bound by its table reads: 3 random 2-byte reads per sequence out
-// of 160 MiB of live tables is 0.8 G sector fetches per launch - 14.8 ms, whether 16, 32 or 64 frames share a wave and whether the
-// loop is 800 or 200 instructions long (profiles/r03v_zent_split.txt, r03w_zent_split.txt).  With the wave's tables in LDS a step
-// costs its instructions and one LDS latency.  The price is parallelism: 2.5 KiB per frame (the format's largest tables, which is
-// what the reference writes for a 4 000-sequence block) = ZSEQ_LDS_FRAMES frames per wave and two waves per CU, so the frames of a
-// large batch go through in rounds (the same idea inside k_zstd_entropy, BAMD_ZSTD_LDS_FSE, bought 6 % while the loop was 800
-// instructions long).  MEASURED (profiles/r03y_zent_split.txt, 8 GiB of reference-written bench19 frames): 16.2 - 16.8 ms against 11.7 ms
-// for k_zstd_seq with the run buffer - with one wave per SIMD the dependent-issue latency of the loop's ~200 instructions is ~0.9 us per
-// sequence by itself, times 4.3 rounds.  Behind BLOSC_AMD_ZSEQ_LDS=1; the default is the global form.
-#ifndef BAMD_ZSEQ_LDS_FRAMES
-#define BAMD_ZSEQ_LDS_FRAMES 30
-#endif
-constexpr int ZSEQ_LDS_FRAMES = BAMD_ZSEQ_LDS_FRAMES;      // x 2560 bytes = 75 KiB: two workgroups per CU
-__global__ __launch_bounds__(64) void k_zstd_seq_lds(const StreamDesc* __restrict__ streams, int nstreams, const ChunkDesc* __restrict__ chunks,
-                                                     const BlockDesc* __restrict__ blocks, ZMeta* __restrict__ meta, ptrdiff_t zseq_delta,
-                                                     const ZcTab* __restrict__ ctab) {
-  __shared__ uint32_t tabs[ZSEQ_LDS_FRAMES][sizeof(ZcTab) / 4];
-  __shared__ uint64_t sqb[8 * 64];           // the triples' run buffer (zseq_run)
-  const int lane = (int)(threadIdx.x & 63);
-  const int sid0 = (int)blockIdx.x * ZSEQ_LDS_FRAMES;
-  // the whole wave copies the records of its frames, 256 bytes per instruction (frames that are not phase A's are copied too: simpler than
-  // asking, and their bytes are never looked at)
-  for (int f = 0; f < ZSEQ_LDS_FRAMES && sid0 + f < nstreams; f++) {
-    const BAMD_GAS uint32_t* src = (const BAMD_GAS uint32_t*)(ctab + sid0 + f);
-#pragma unroll
-    for (int k = 0; k < (int)(sizeof(ZcTab) / 4) / 64; k++) ((volatile __attribute__((address_space(3))) uint32_t*)tabs[f])[lane + 64 * k] = src[lane + 64 * k];
-  }
-  BAMD_LDS_SYNC();
-  const int sid = sid0 + lane;
-  if (lane >= ZSEQ_LDS_FRAMES || sid >= nstreams) return;
-  if (meta[sid].state != ZM_SEQ) return;
-  const StreamDesc& sd = streams[sid];
-  const ChunkDesc& c = chunks[sd.chunk];
-  const BlockDesc& bk = blocks[sd.aux];
-  uint8_t* lit = c.stage + (size_t)bk.blk * (size_t)c.blocksize + (size_t)(sid - bk.first_stream) * (size_t)sd.out_size;
-  uint64_t* sq = zseq_ptr(lit, zseq_delta);
-  const int nseq = (int)meta[sid].nseq;
-  const uint32_t al = meta[sid].pad_[2];
-  const int al_l = (int)(al & 0xffu), al_o = (int)((al >> 8) & 0xffu), al_m = (int)((al >> 16) & 0xffu);
-  const uint16_t* t16 = (const uint16_t*)tabs[lane];
-  // seq_begin only reads the accuracy logs of the tables
-  zd::SeqTabs tb = {{nullptr, al_l}, {nullptr, al_o}, {nullptr, al_m}, true, true, true};
-  zd::SeqState st;
-  st.rep[0] = 1u; st.rep[1] = 4u; st.rep[2] = 8u;
-  bool fine = zd::seq_begin(st, tb, sd.in + meta[sid].pad_[0], (int)meta[sid].pad_[1]);
-  if (fine) fine = zseq_run<2>(st, nseq, nullptr, nullptr, nullptr, t16, t16 + 512, t16 + 768, al_l, al_o, al_m, sq, BAMD_ZSEQ_RUNBUF ? sqb : nullptr, lane);
-  if (fine && st.b.off != 0) fine = false;                                  // the bit stream must be consumed exactly
-  meta[sid].state = fine ? ZM_READY : ZM_ERROR;
-}
+// (Round 3 also built this kernel with the frames' tables in LDS - 30 frames per wave, two waves per CU: 16.2 - 16.8 ms against 11.7 ms, the
+//  dependent-issue latency of the loop at one wave per SIMD outweighs the table reads; removed in round 4, record: profiles/r03y_zent_split.txt.)
 
 // phase B: one wavefront per frame, persistent + ticket
 #ifndef BAMD_ZEXEC_MINWAVES

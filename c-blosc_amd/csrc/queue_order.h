@@ -18,7 +18,7 @@ namespace bamd {
 // task is queued kEncLookahead blocks ahead of its streams: by the time a wave draws one of the streams
 // the transpose is normally finished, and it is always already owned by a running wave (no deadlock).
 constexpr size_t kEncLookaheadDefault = 32;
-inline size_t enc_lookahead() { static const size_t v = getenv("BLOSC_AMD_ENC_LOOKAHEAD") ? (size_t)atoi(getenv("BLOSC_AMD_ENC_LOOKAHEAD")) : kEncLookaheadDefault; return v ? v : 1; }
+inline size_t enc_lookahead() { return kEncLookaheadDefault; }     // (swept 1 ... 64 in round 4: 8.4 ... 8.0 ms, profiles/r04q_enc_lookahead_sweep.txt - the distance hardly matters)
 // BLOSC_AMD_SCHED=0: plain block order (no cost feedback)
 inline bool sched_enabled() { static const bool on = !(getenv("BLOSC_AMD_SCHED") && atoi(getenv("BLOSC_AMD_SCHED")) == 0); return on; }
 

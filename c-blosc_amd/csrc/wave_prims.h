@@ -106,10 +106,7 @@ __device__ __forceinline__ void wave_match_copy(gu8* out, uint32_t pos, uint32_t
     // `done` may not be a multiple of G when head was cut; any multiple of `off` <= off+done is valid
     // only if the copied prefix really is periodic up to `done`, which it is.  Restart from G.
   }
-#ifndef BAMD_ROWFILL
-#define BAMD_ROWFILL 1     // measured with two copies of every build taking turns (profiles/r03q_dec_ab_toggles_two_copies_each.txt): -3 % on bench19, neutral elsewhere.  (An earlier single-copy A/B had said +7 %: the same binary differs by that much between instances)
-#endif
-  if (BAMD_ROWFILL && done == 0u && off >= 64u && off <= 1024u && (off & (off - 1u)) == 0u && len >= 2048u) {
+  if (done == 0u && off >= 64u && off <= 1024u && (off & (off - 1u)) == 0u && len >= 2048u) {
     // The period divides 1024: every 1 KiB row of the match is the same, and lane l's 16 bytes of it lie at
     // pos - off + (16 l mod off) - in front of the match, so ONE load serves all rows (round 3: byte planes of a few significant
     // bits decode into dozens of 4 KiB runs of period 128, each of which took five dependent round trips to get going)

@@ -32,10 +32,6 @@ for stage in "$@"; do
     suite)      timeout 2400 python -m pytest tests -m gpu -x -q --no-header -p no:cacheprovider 2>&1 | tee gpurun_out/${TAG}_pytest_gpu.log | tail -15 ;;
     smoke)      timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -5 ;;
     ring)       echo "== ring micro"; timeout 120 scripts/micro/ring 2>&1 | tee gpurun_out/${TAG}_ring_micro.txt ;;
-    decsweep)   # k_decode_streams on reference-written bench19 chunks: waves per CU x queue order
-                for wpc in 24 20 16 12; do for sched in 1 0; do
-                  echo -n "WPC=$wpc SCHED=$sched  "; BLOSC_AMD_DEC_WPC=$wpc BLOSC_AMD_SCHED=$sched timeout 120 python scripts/dec_sweep.py 2>&1 | tail -1
-                done; done | tee gpurun_out/${TAG}_dec_sweep.txt ;;
     decphase)   timeout 120 python scripts/dec_phase.py 2>&1 | tee gpurun_out/${TAG}_dec_phase.txt | tail -30 ;;
     dec)        # decode-only timing of reference-written chunks: the library under test and every gpurun_tune_*.so next to it (same-session A/B)
                 for spec in ${DECSETS:-bench19:1:8 linspace:1:8 randwalk:1:8 bench19:2:4}; do
@@ -46,8 +42,6 @@ for stage in "$@"; do
                 done | tee -a gpurun_out/${TAG}_dec_ab.txt ;;
     decab)      # the same in ONE process, the builds taking turns on the same buffers (scripts/dec_ab.py): process-to-process differences cancel
                 DECSETS="${DECSETS:-bench19:1:8 linspace:1:8 randwalk:1:8 bench19:2:4}" timeout 600 python scripts/dec_ab.py c-blosc_amd/libblosc_amd.so gpurun_tune_*.so 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/${TAG}_dec_ab1.txt ;;
-    decwpc)     # waves per CU of the decode kernel (grid size only) on the library under test, reference-written bench19 chunks
-                for wpc in 24 20 16 12 8; do echo -n "WPC=$wpc  "; BLOSC_AMD_DEC_WPC=$wpc timeout 120 python scripts/dec_sweep.py 2>&1 | tail -1; done | tee gpurun_out/${TAG}_dec_wpc.txt ;;
     dectraffic) # FETCH_SIZE / WRITE_SIZE of the decode kernels (one counter per pass, --kernel-trace only), reference-written bench19 chunks
                 for PMC in FETCH_SIZE WRITE_SIZE; do
                   timeout 300 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d gpurun_out/${TAG}_pmc_$PMC -o pmc -- python scripts/dec_sweep.py > gpurun_out/${TAG}_pmc_$PMC.log 2>&1
@@ -61,10 +55,6 @@ for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1]))[:6]: print(f"{sys.ar
 PY
                   rm -rf gpurun_out/${TAG}_pmc_$PMC
                 done | tee gpurun_out/${TAG}_dec_traffic.txt ;;
-    zentsplit)  # where the time of k_zstd_entropy goes: builds with the FSE loop / the Huffman streams / both left out (make -C c-blosc_amd tune NAME=zskipN DEFS=-DBAMD_ZENT_SKIP=N; wrong results on purpose)
-                for lib in c-blosc_amd/libblosc_amd.so gpurun_tune_z*.so; do
-                  [ -f $lib ] && { echo -n "$lib "; NOCHECK=1 CODEC=zstd CLEVEL=3 BLOSC_AMD_LIB=$PWD/$lib timeout 150 python scripts/dec_sweep.py 2>&1 | tail -1; }
-                done | tee gpurun_out/${TAG}_zent_split.txt ;;
     hostthreads) for c in 1 4; do BLOSC_AMD_CONTEXTS=$c timeout 200 python scripts/host_abi_threads.py 2>&1 | grep -v amdgpu.ids; done | tee gpurun_out/${TAG}_host_abi_threads.txt ;;
     threads)    timeout 600 python -m pytest tests/test_gpu_threads.py -m gpu -x -q --no-header -p no:cacheprovider 2>&1 | tee gpurun_out/${TAG}_pytest_threads.log | tail -5 ;;
     zstdtests)  timeout 900 python -m pytest tests/test_gpu_zstd.py tests/test_gpu_zstd_tables.py tests/test_gpu_zlib.py -m gpu -x -q --no-header -p no:cacheprovider 2>&1 | tee gpurun_out/${TAG}_pytest_zstd.log | tail -5 ;;

@@ -312,16 +312,16 @@ def test_sampled_parameter_grid(emulib, oracle, ref):
 
 
 FLIPS = [(), ("BLOSC_AMD_SINGLE_QUEUE",), ("BLOSC_AMD_FUSE",), ("BLOSC_AMD_SPANS",), ("BLOSC_AMD_SCHED",), ("BLOSC_AMD_PERIODIC",),
-         ("BLOSC_AMD_BITFAST",), ("BLOSC_AMD_SINGLE_QUEUE", "BLOSC_AMD_FUSE", "BLOSC_AMD_SPANS", "BLOSC_AMD_SCHED")]
+         ("BLOSC_AMD_SINGLE_QUEUE", "BLOSC_AMD_FUSE", "BLOSC_AMD_SPANS", "BLOSC_AMD_SCHED")]
 
 
 @pytest.mark.parametrize("flip", FLIPS if FULL else [FLIPS[0], FLIPS[1], FLIPS[2], FLIPS[3], FLIPS[-1]], ids=lambda f: "+".join(x.replace("BLOSC_AMD_", "") for x in f) or "defaults")
 def test_fallback_switches(emulib, flip):
     """tests/test_gpu_modes.py's switch combinations (one task queue with stand-alone filter kernels, unfused filters, no periodic spans /
-    planes, plain block order, the generic bit filters) on the emulated library, inputs shrunk: the same
+    planes, plain block order) on the emulated library, inputs shrunk: the same
     script, a process per combination because the switches are read once."""
     defaults = {"BLOSC_AMD_SINGLE_QUEUE": "0", "BLOSC_AMD_FUSE": "1", "BLOSC_AMD_SPANS": "1", "BLOSC_AMD_SCHED": "1",
-                "BLOSC_AMD_PERIODIC": "1", "BLOSC_AMD_BITFAST": "1"}
+                "BLOSC_AMD_PERIODIC": "1"}
     env = dict(os.environ)
     for k, v in defaults.items():
         env[k] = ("1" if v == "0" else "0") if k in flip else v

@@ -93,8 +93,8 @@ void blk_body(int lane, void* arg) {
 extern "C" int emu_decode_block(int T, int fmt, const uint8_t* const* streams, const int* csize, unsigned bsize, uint8_t* dst, const int* order, unsigned* spans_out) {
   using namespace bamd;
   const uint32_t ne = bsize / (uint32_t)T;
-  uint8_t* filt = (uint8_t*)malloc(bsize + 4096 + 16 * FILT_PLANE_PAD);          // the padded plane layout of fused chunks (dev_types.h)
-  memset(filt, 0xCD, bsize + 4096 + 16 * FILT_PLANE_PAD);
+  uint8_t* filt = (uint8_t*)malloc(bsize + 4096);          // the padded plane layout of fused chunks (dev_types.h)
+  memset(filt, 0xCD, bsize + 4096);
   ChunkDesc c; memset(&c, 0, sizeof c);
   c.src = nullptr; c.dst = dst; c.filt = filt; c.nbytes = (int32_t)bsize; c.blocksize = (int32_t)bsize; c.typesize = T; c.nblocks = 1;
   c.nsplits = T; c.fmt = fmt; c.mode = CH_SHUFFLE | CH_FUSED_UNSHUF; c.first_block = 0; c.first_stream = 0;

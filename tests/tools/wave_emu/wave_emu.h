@@ -193,7 +193,6 @@ uint64_t last_rendezvous();
 
 // ---- the AMDGPU builtins the device code uses ----
 #define __builtin_amdgcn_readlane(v, l) ((int)wave_emu::xlane((uint32_t)(v), (int)(l), WAVE_EMU_HERE))
-#define __builtin_amdgcn_writelane(v, l, old) ((wave_emu::lane() == (int)(l)) ? (int)(v) : (int)(old))      /* v and l are wave-uniform on the device (SGPR operands) */
 #define __builtin_amdgcn_readfirstlane(v) (wave_emu::readfirst((uint32_t)(v), WAVE_EMU_HERE))
 #define __builtin_amdgcn_ds_bpermute(idx, v) ((int)wave_emu::xlane((uint32_t)(v), ((int)(idx) >> 2), WAVE_EMU_HERE))
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
