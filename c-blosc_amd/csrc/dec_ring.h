@@ -28,7 +28,11 @@ namespace bamd {
 constexpr uint32_t DR_RING = BAMD_DEC_RING, DR_MASK = DR_RING - 1u;
 constexpr uint32_t DR_ROW = 1024u;                 // a row of the ring goes to global memory when it is complete
 constexpr uint32_t DR_STEP_MAX = 2048u;            // output bytes of one batched step at most
-constexpr uint32_t DR_IN = 1024u;                  // input ring: four blocks of 256 bytes
+#ifndef BAMD_DEC_INBLOCKS
+#define BAMD_DEC_INBLOCKS 4
+#endif
+constexpr uint32_t DR_INB = BAMD_DEC_INBLOCKS;     // input ring: this many blocks of 256 bytes (a power of two >= 2)
+constexpr uint32_t DR_IN = 256u * DR_INB;
 constexpr uint32_t DR_LDS_BYTES = 256u + DR_IN + DR_RING;   // 64 scratch dwords | input ring | history ring
 static_assert((DR_RING & DR_MASK) == 0u && DR_RING >= 4096u, "ring size");
 // a step's sources are either in the ring (>= W - DR_RING, W = the step's end) or in rows already written (< W - DR_RING):
@@ -44,7 +48,7 @@ inline unsigned long long g_emu_ring_far = 0;         // ... and matches served 
 
 struct RingIO {
   volatile BAMD_LAS uint32_t* scr;     // 64 dwords: token info of a step on its way back to byte-lane space
-  BAMD_LAS uint32_t* in32;             // input ring (256 dwords)
+  BAMD_LAS uint32_t* in32;             // input ring (DR_IN / 4 dwords)
   lu8* hist;                           // history ring
   const gu8* in; uint32_t n;
   gu8* out; uint32_t cap;
@@ -67,25 +71,31 @@ __device__ __forceinline__ uint32_t dr_in_load(const gu8* in, uint32_t n, uint32
   }
   return v;
 }
-__device__ __forceinline__ void dr_in_store(RingIO& io, uint32_t j, uint32_t v) { io.in32[64u * (j & 3u) + (uint32_t)io.lane] = v; }
+__device__ __forceinline__ void dr_in_store(RingIO& io, uint32_t j, uint32_t v) { io.in32[64u * (j & (DR_INB - 1u)) + (uint32_t)io.lane] = v; }
 // makes stream bytes [ip, ip + 72) readable; ip only ever grows
 __device__ __forceinline__ void dr_input(RingIO& io, uint32_t ip) {
   const uint32_t bi = ip >> 8;
   if (bi > io.b_hi) { io.pend = 0u; io.b_hi = bi; }            // jumped over everything present (a long literal run): start again at ip's block
   // the block requested earlier goes in once nothing still needed lives in its slot (its old tenant is block b_hi - 4)
-  if (io.pend && io.b_hi < bi + 4u) { dr_in_store(io, io.b_hi, io.pv); io.b_hi++; io.pend = 0u; }
-  if (((ip + 71u) >> 8) >= io.b_hi) {                          // stream start, or behind a jump: three blocks in one round trip
-    const uint32_t v0 = dr_in_load(io.in, io.n, io.b_hi, io.lane), v1 = dr_in_load(io.in, io.n, io.b_hi + 1u, io.lane), v2 = dr_in_load(io.in, io.n, io.b_hi + 2u, io.lane);
-    dr_in_store(io, io.b_hi, v0); dr_in_store(io, io.b_hi + 1u, v1); dr_in_store(io, io.b_hi + 2u, v2);
-    io.b_hi += 3u; io.pend = 0u;
+  if (io.pend && io.b_hi < bi + DR_INB) { dr_in_store(io, io.b_hi, io.pv); io.b_hi++; io.pend = 0u; }
+  if (((ip + 71u) >> 8) >= io.b_hi) {                          // stream start, behind a jump, or the prefetch fell behind: up to three blocks in one round trip
+    const uint32_t room = DR_INB - (io.b_hi - bi);             // blocks that may come in without evicting ip's own (b_hi - bi is 0 or 1 here)
+    const uint32_t v0 = dr_in_load(io.in, io.n, io.b_hi, io.lane);
+    uint32_t v1 = 0u, v2 = 0u;
+    if (room >= 2u) v1 = dr_in_load(io.in, io.n, io.b_hi + 1u, io.lane);
+    if (room >= 3u) v2 = dr_in_load(io.in, io.n, io.b_hi + 2u, io.lane);
+    dr_in_store(io, io.b_hi, v0);
+    if (room >= 2u) dr_in_store(io, io.b_hi + 1u, v1);
+    if (room >= 3u) dr_in_store(io, io.b_hi + 2u, v2);
+    io.b_hi += room >= 3u ? 3u : room; io.pend = 0u;
   }
-  if (!io.pend && io.b_hi < bi + 4u && 256u * io.b_hi < io.n) { io.pv = dr_in_load(io.in, io.n, io.b_hi, io.lane); io.pend = 1u; }
+  if (!io.pend && io.b_hi < bi + DR_INB && 256u * io.b_hi < io.n) { io.pv = dr_in_load(io.in, io.n, io.b_hi, io.lane); io.pend = 1u; }
   DR_SYNC();
 }
 // the four stream bytes at p (little endian), p per lane or uniform; needs dr_input(q) with q <= p, p + 4 <= q + 72
 __device__ __forceinline__ uint32_t dr_in4(const RingIO& io, uint32_t p) {
-  const uint32_t i = (p >> 2) & 255u;
-  return __builtin_amdgcn_alignbyte(io.in32[(i + 1u) & 255u], io.in32[i], p & 3u);
+  const uint32_t i = (p >> 2) & (DR_IN / 4u - 1u);
+  return __builtin_amdgcn_alignbyte(io.in32[(i + 1u) & (DR_IN / 4u - 1u)], io.in32[i], p & 3u);
 }
 __device__ __forceinline__ uint32_t dr_peek32(const RingIO& io, uint32_t p) { return uni(dr_in4(io, p)); }
 

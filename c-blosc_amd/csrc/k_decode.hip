@@ -707,6 +707,7 @@ __device__ __forceinline__ void fused_unshuffle_own_block(const ChunkDesc* c, co
 template <int T>
 __device__ __forceinline__ void bitunshuffle_pass(lu8* S, const gu8* src, gu8* dst, uint32_t rowlen, uint32_t e0, uint32_t nchunks, int lane) {
   constexpr uint32_t CB = 32u * T, CS = CB + 16u, NDW = CB / 4u;
+  static_assert(64u * CS <= DR_LDS_BYTES, "the staging tile of a pass must fit the LDS a wave owns (a 4 KiB history ring - profiles/r04u_* - would need 32-chunk passes)");
   const uint32_t m0 = e0 >> 3, t = (uint32_t)lane;
   if (t < nchunks) {
     uint32_t w[NDW];
