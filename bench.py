@@ -367,6 +367,15 @@ def measure(rig, name, cfg, steps, warmup, args, mixed=None, payload=False):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    # ---- one step WITHOUT the queue order learnt from the previous calls (BLOSC_AMD_SCHED=0: plain block order, what a first call on new data gets) ----
+    os.environ["BLOSC_AMD_SCHED"] = "0"
+    sync_all(); tc = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    sched_cold_ms = (time.perf_counter() - tc) * 1e3
+    del os.environ["BLOSC_AMD_SCHED"]
+    step()                                                   # (the next call's queues are built from this one's costs again)
+
     # ---- consolidation: every rank learns the global cbytes table (RCCL all_gather, 4 bytes per chunk) ----
     torch.cuda.synchronize()
     tg = time.perf_counter()
@@ -468,6 +477,8 @@ def measure(rig, name, cfg, steps, warmup, args, mixed=None, payload=False):
         "value": world * steps * total / elapsed / 1e9, "unit": "GB/s", "steps": steps, "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3,
         "first_call_ms": first_ms,             # the first step of this workload in this process: cold queues (no cost feedback yet), arenas still growing
+        "sched_cold": {"ms_per_step": sched_cold_ms, "GBps": world * total / (sched_cold_ms / 1e3) / 1e9,      # one step in plain block order (BLOSC_AMD_SCHED=0), arenas warm
+                       "note": "all 128 chunks of the bench are the same 64 MiB (bench/bench.c:383) and the queue order is trained on them; this is the step without that"},
         "config": {"workload": f"config #{name}: {FILTER_NAME[shuffle]} + {cfg['codec']} clevel={clevel} typesize={T}, "
                                f"{nchunks} x {args.chunk_mib} MiB {'+'.join(datasets)} chunks per GPU ({total / 2**30:.0f} GiB), "
                                f"step = {what}, device-resident",
@@ -667,7 +678,7 @@ def main():
         for name in ("3", "4", "2t", "2x"):       # 2t / 2x: config 2 at typesize 2 and 16 (the reference's bench takes the typesize as an argument over the same data, bench/bench.c:250-320)
             r = measure(rig, name, dict(CONFIGS[name]), min(args.steps, 5), 1, args)
             r.pop("_host_chunk")
-            keep = ("value", "unit", "steps", "ms_per_step", "first_call_ms", "ratio", "roofline", "kernels", "decompress_stock_chunks", "verified", "compress", "decompress")
+            keep = ("value", "unit", "steps", "ms_per_step", "first_call_ms", "sched_cold", "ratio", "roofline", "kernels", "decompress_stock_chunks", "verified", "compress", "decompress")
             extra[name] = {k: r[k] for k in keep if k in r}
             extra[name]["workload"] = r["config"]["workload"]
         m = measure(rig, "2", cfg, min(args.steps, 5), 1, args, mixed=["bench19", "linspace", "randwalk", "random"])

@@ -324,8 +324,55 @@ __device__ __attribute__((noinline)) void bitshuffle_block_task_x(const gu8* src
   else bitshuffle_block_wave_T<1>(src, dst, bsize, lane);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused byte shuffle of one block by ONE wavefront for every OTHER typesize up to 32 (round 4; the mirror image of unshuffle_block_generic
+// in k_decode.hip; blosc/shuffle-generic.h:27-58).  The wave that runs a shuffle task is not encoding: its LDS (the 6 KiB match-finder
+// table at least) is free.  Per pass as many elements as that holds: their source bytes in as contiguous 16-byte pieces (1 KiB per load
+// instruction), then for every plane a lane gathers the plane's bytes of ITS four elements (of every 256) out of the tile and stores
+// one dword - a wave store writes 256 contiguous bytes of the plane.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool shuffle_generic_T(uint32_t T) { return T >= 3u && T <= 32u && T != 4u && T != 8u && T != 16u; }
+__device__ __attribute__((noinline)) void shuffle_block_generic(volatile uint32_t* lds_, const gu8* src_, gu8* dst_, uint32_t bsize_, uint32_t T_, int lane) {
+  const uint64_t lv = (uint64_t)lds_;
+  lu8* S = (lu8*)(BAMD_LAS uint32_t*)(volatile uint32_t*)(((uint64_t)uni((uint32_t)(lv >> 32)) << 32) | uni((uint32_t)lv));
+  const gu8* src = uni_ptr(src_); gu8* dst = uni_ptr(dst_);
+  const uint32_t bsize = uni(bsize_), T = uni(T_), N = bsize / T;
+  // as many 128-element half tiles per pass as the table's LDS holds: typesize 3 moves 6 KiB per pass, typesize 32 one half tile of 4 KiB
+  const uint32_t H = ((uint32_t)ENC_TAB_BYTES / 128u) / T;
+  static_assert(128u * 32u <= (uint32_t)ENC_TAB_BYTES, "a half tile of the widest element must fit the smallest table a wave owns");
+  uint32_t e = 0;
+  while (e + 128u <= N) {
+    const uint32_t h_here = (N - e) / 128u < H ? (N - e) / 128u : H, K = 128u * h_here;
+    const gu8* in = src + (size_t)e * T;
+    for (uint32_t q = (uint32_t)lane; q < K * T / 16u; q += 64u) l_st16(S + 16u * q, g_ld16(in + 16u * q));
+    LDS_ORDER(); BAMD_LDS_SYNC();
+    for (uint32_t el = 4u * (uint32_t)lane; el < K; el += 256u) {      // the lane's four elements el .. el + 3 of every 256
+      const lu8* mine = S + el * T;
+      if ((T & 3u) == 0u) {                              // whole dwords per element: one dword of each of the four elements -> 4 x 4 byte transpose -> four planes
+        const BAMD_LAS uint32_t* w = (const BAMD_LAS uint32_t*)mine;
+        for (uint32_t j = 0; j < T; j += 4u) {
+          uint32_t r0, r1, r2, r3;
+          transpose4x4(w[j / 4u], w[(T + j) / 4u], w[(2u * T + j) / 4u], w[(3u * T + j) / 4u], r0, r1, r2, r3);
+          gu8* o = dst + (size_t)j * N + e + el;
+          g_st4(o, r0); g_st4(o + (size_t)N, r1); g_st4(o + 2 * (size_t)N, r2); g_st4(o + 3 * (size_t)N, r3);
+        }
+        continue;
+      }
+      for (uint32_t j = 0; j < T; j++) {
+        const uint32_t v = (uint32_t)mine[j] | ((uint32_t)mine[T + j] << 8) | ((uint32_t)mine[2u * T + j] << 16) | ((uint32_t)mine[3u * T + j] << 24);
+        g_st4(dst + (size_t)j * N + e + el, v);
+      }
+    }
+    LDS_ORDER(); BAMD_LDS_SYNC();
+    e += K;
+  }
+  // tail: fewer than K elements, then the bytes that do not form a whole element (copied as they are)
+  for (uint32_t k = e * T + (uint32_t)lane; k < N * T; k += 64u) { const uint32_t el = k / T, j = k - el * T; dst[(size_t)j * N + el] = src[k]; }
+  for (uint32_t k = N * T + (uint32_t)lane; k < bsize; k += 64u) dst[k] = src[k];
+}
+
 __device__ __attribute__((noinline)) void shuffle_block_task(const ChunkDesc* chunks, const BlockDesc* blocks, uint32_t gb,
-                                                             uint32_t* blk_ready, StreamDesc* streams, int detect, int lane) {
+                                                             uint32_t* blk_ready, StreamDesc* streams, int detect, int lane, volatile uint32_t* lds) {
   const BlockDesc* b = blocks + gb;
   const ChunkDesc* c = chunks + uni((uint32_t)b->chunk);
   const uint32_t blk = uni((uint32_t)b->blk), bsize = uni((uint32_t)b->bsize), bs = uni((uint32_t)c->blocksize);
@@ -337,6 +384,7 @@ __device__ __attribute__((noinline)) void shuffle_block_task(const ChunkDesc* ch
                    (uni((uint32_t)c->fmt) == (uint32_t)FMT_LZ4 || uni((uint32_t)c->fmt) == (uint32_t)FMT_BLOSCLZ);
   StreamDesc* planes = streams + uni((uint32_t)b->first_stream);
   if (uni(c->mode) & CH_BITSHUFFLE) bitshuffle_block_task_x(src, dst, bsize, T, lane);      // (typesize 1 / 2 / 4: the only bitshuffle chunks that carry CH_FUSED_SHUF)
+  else if (shuffle_generic_T(T)) shuffle_block_generic(lds, src, dst, bsize, T, lane);
   else if (T == 8u) { if (det) shuffle_block_detect_T<8>(src, dst, bsize, planes, lane); else shuffle_block_wave_T<8>(src, dst, bsize, lane); }
   else if (T == 4u) { if (det) shuffle_block_detect_T<4>(src, dst, bsize, planes, lane); else shuffle_block_wave_T<4>(src, dst, bsize, lane); }
   else shuffle_block_task_x(src, dst, bsize, T, det, planes, lane);       // typesize 2 / 16: out of line, so that the registers of the 16-plane form do not count here

@@ -305,7 +305,8 @@ static bool periodic_enabled() { static const bool on = !(getenv("BLOSC_AMD_PERI
 static int zstd2_mode() { static const int m = getenv("BLOSC_AMD_ZSTD2") ? atoi(getenv("BLOSC_AMD_ZSTD2")) : 2; return m; }
 // typesizes whose byte (un)shuffle runs inside the codec kernels (enc_shuffle.h, k_decode.hip: unshuffle_block_wave); the others, and everything
 // under BLOSC_AMD_FUSE=0 / BLOSC_AMD_SINGLE_QUEUE=1, go through the stand-alone filter kernels
-static bool fused_typesize(int T) { return T == 8 || T == 4 || T == 2 || T == 16; }
+static bool fused_typesize(int T) { return T >= 2 && T <= 32; }          // 2 / 4 / 8 / 16: register transposes; the others up to 32 (round 4): an LDS tile of the wave
+static bool fused_fast_typesize(int T) { return T == 8 || T == 4 || T == 2 || T == 16; }     // what the Zstd / zlib kernels' own-block unshuffle handles
 // bitshuffle chunks of these typesizes are (un)shuffled inside the codec kernels as well (round 4: bitshuffle_block_wave_T / bitunshuffle_block_wave)
 static bool bitunshuffle_fused_host(int T) { return T == 1 || T == 2 || T == 4; }
 static bool fuse_enabled() { static const bool on = !(getenv("BLOSC_AMD_FUSE") && atoi(getenv("BLOSC_AMD_FUSE")) == 0); return on; }
@@ -416,9 +417,9 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   const size_t o_blocks = cv.take(sizeof(BlockDesc) * (nblk ? nblk : 1));
   const size_t o_streams = cv.take(sizeof(StreamDesc) * (nstr ? nstr : 1));
   const size_t o_blkoff = cv.take(sizeof(int32_t) * (nblk ? nblk : 1));
-  const size_t o_results = cv.take(sizeof(int32_t) * (size_t)n + 64);   // + the 8 ticket counters of the encode queues
-  std::vector<int32_t> queues;
-  build_encode_queues(blocks, chunks, st.enc_cost, st.enc_cost_valid, queues, st.single_queue ? 1 : 8);
+  const size_t o_results = cv.take(sizeof(int32_t) * (size_t)n + 96);   // + the 8 ticket counters of the encode queues + the 8 of the shuffle lists
+  std::vector<int32_t> queues; size_t sh_at = 0;
+  build_encode_queues(blocks, chunks, st.enc_cost, st.enc_cost_valid, queues, st.single_queue ? 1 : 8, &sh_at);
   const size_t o_queues = cv.take(sizeof(int32_t) * queues.size());
   const size_t o_ready = cv.take(sizeof(uint32_t) * (nblk ? nblk : 1));
   const size_t o_cost = cv.take(sizeof(uint32_t) * kCostWords);
@@ -507,7 +508,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   HIP_TRY(hipMemcpyAsync(D + o_chunks, P + p_chunks, sizeof(ChunkDesc) * (size_t)n, hipMemcpyHostToDevice, stream));
   if (nblk) HIP_TRY(hipMemcpyAsync(D + o_blocks, P + p_blocks, sizeof(BlockDesc) * nblk, hipMemcpyHostToDevice, stream));
   if (nstr) HIP_TRY(hipMemcpyAsync(D + o_streams, P + p_streams, sizeof(StreamDesc) * nstr, hipMemcpyHostToDevice, stream));
-  HIP_TRY(hipMemsetAsync(D + o_results, 0, sizeof(int32_t) * (size_t)n + 64, stream));
+  HIP_TRY(hipMemsetAsync(D + o_results, 0, sizeof(int32_t) * (size_t)n + 96, stream));
   uint32_t* d_ticket = (uint32_t*)(D + o_results + sizeof(int32_t) * (size_t)n + 32);
 
   ChunkDesc* d_chunks = (ChunkDesc*)(D + o_chunks);
@@ -532,7 +533,8 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
     ProfScope ps(st, stream, zstd ? "k_zstd_encode" : (zlibc ? "k_zlib_encode" : (hc ? "k_lz4hc_encode" : "k_encode_streams")));
     const int32_t* d_qoff = (const int32_t*)(D + o_queues); const int32_t* d_qlist = d_qoff + 9;
     uint32_t* d_ready = (uint32_t*)(D + o_ready);
-    const size_t ntasks = queues.size() - 9;
+    const size_t ntasks = (size_t)queues[8];
+    const int32_t* d_shoff = d_qoff + sh_at;
     uint64_t* d_seqbufs = (zstd || zdyn) ? (uint64_t*)(D + o_seqbufs) : nullptr;
     const zenc::CTabs* d_ctabs = zstd ? (const zenc::CTabs*)(D + o_ctabs) : nullptr;
     const int detect = (!zstd && !zlibc && periodic_enabled()) ? 1 : 0;
@@ -540,9 +542,9 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
 #ifdef BAMD_PROFILE_DECODE
     uint32_t* d_prof = nullptr;
     if (getenv("BLOSC_AMD_ENC_PROFILE")) { (void)hipMalloc((void**)&d_prof, nstr * 64); (void)hipMemsetAsync(d_prof, 0, nstr * 64, stream); }
-#define BAMD_ENC_LAUNCH(MODE) hipLaunchKernelGGL(k_encode_streams_t<MODE>, grid, block, 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, d_seqbufs, d_ctabs, detect, d_prof)
+#define BAMD_ENC_LAUNCH(MODE) hipLaunchKernelGGL(k_encode_streams_t<MODE>, grid, block, 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_shoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, d_seqbufs, d_ctabs, detect, d_prof)
 #else
-#define BAMD_ENC_LAUNCH(MODE) hipLaunchKernelGGL(k_encode_streams_t<MODE>, grid, block, 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, d_seqbufs, d_ctabs, detect)
+#define BAMD_ENC_LAUNCH(MODE) hipLaunchKernelGGL(k_encode_streams_t<MODE>, grid, block, 0, stream, d_streams, d_ticket, d_qlist, d_qoff, d_shoff, d_chunks, d_blocks, d_ready, (uint32_t*)(D + o_cost), st.single_queue ? 1 : 0, d_seqbufs, d_ctabs, detect)
 #endif
     if (zstd && zsearch) { if (zhuf) BAMD_ENC_LAUNCH(ENC_ZSTD_HCH); else BAMD_ENC_LAUNCH(ENC_ZSTD_HC); }
     else if (zstd && ztab) { if (zhuf) BAMD_ENC_LAUNCH(ENC_ZSTD_TH); else BAMD_ENC_LAUNCH(ENC_ZSTD_T); }
@@ -579,7 +581,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   HIP_TRY(hipStreamSynchronize(stream));
   HT_MARK(0, 4);     // waiting for the device
   prof_collect(st);
-  if (nstr && check_done((const uint32_t*)(P + p_cost), queues.size() - 9, 0, "compress")) return -1;
+  if (nstr && check_done((const uint32_t*)(P + p_cost), (size_t)queues[8], 0, "compress")) return -1;
   if (nstr >= 4096) { memcpy(st.enc_cost, P + p_cost, sizeof st.enc_cost); st.enc_cost_valid = true; }   // small calls say little
   const int32_t* r = (const int32_t*)(P + p_results);
   for (int i = 0; i < n; i++) if (live[(size_t)i]) results[i] = r[i];
@@ -790,7 +792,7 @@ static void filter_tiles(ChunkDesc& c, bool& any_shuf, bool& any_bit, int& tiles
   // (Zstd chunks: only unsplit ones - the wave that decodes a block's one stream unshuffles it, k_decode.hip: fused_unshuffle_own_block;
   //  zlib chunks: split ones too, k_zlib_streams has per-XCD queues and the hand-off of the LZ4 kernel)
   const bool zfmt = c.fmt == FMT_ZSTD || c.fmt == FMT_ZLIB;
-  if ((c.mode & CH_SHUFFLE) && fused_typesize(T) && fuse_enabled() && may_fuse && (!zfmt || c.fmt == FMT_ZLIB || c.nsplits == 1)) { c.mode |= CH_FUSED_UNSHUF; return; }
+  if ((c.mode & CH_SHUFFLE) && fuse_enabled() && may_fuse && (zfmt ? (fused_fast_typesize(T) && (c.fmt == FMT_ZLIB || c.nsplits == 1)) : fused_typesize(T))) { c.mode |= CH_FUSED_UNSHUF; return; }
   if (c.mode & CH_SHUFFLE) {
     any_shuf = true;
     int t = (N + shuffle_tile_elems(T) - 1) / shuffle_tile_elems(T); if (t < 1) t = 1;

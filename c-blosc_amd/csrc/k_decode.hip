@@ -693,6 +693,65 @@ __device__ __forceinline__ void fused_unshuffle_own_block(const ChunkDesc* c, co
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fused byte-unshuffle of one block by ONE wavefront for every OTHER typesize up to 32 (3, 5, 6, 7, 9 ... 15, 17 ... 32; round 4: the
+// north star says typesize 1 - 32, these took three passes).  blosc/shuffle-generic.h:61-81 for any typesize; the tiled form of
+// shuffle-sse2.c:217-270 for the wide ones.  No register transposes here - a typesize that is not a power of two has no fixed byte pattern
+// per lane - but the wave's own LDS (9 KiB, idle once its stream is done): per pass of 256 elements a dword of every plane per lane (a wave
+// load reads 256 contiguous bytes of a plane), its four bytes into an element-major tile in LDS, and the tile out again as 16-byte pieces:
+// every store instruction writes 1 KiB of contiguous destination.  Blocks of typesize > 16 are never split (blosc/blosc.c:929-959):
+// their one stream's wave unshuffles its own block.  No periodic spans on this path (sp.enabled stays 0 in decode_one_stream).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool unshuffle_generic_T(uint32_t T) { return T >= 3u && T <= 32u && T != 4u && T != 8u && T != 16u; }
+__device__ __attribute__((noinline)) void unshuffle_block_generic(volatile uint32_t* lds_, const uint8_t* src_, uint8_t* dst_, uint32_t bsize_, uint32_t T_, uint32_t pstride_, int lane) {
+  const uint64_t lv = (uint64_t)lds_;
+  lu8* S = (lu8*)(BAMD_LAS uint32_t*)(volatile uint32_t*)(((uint64_t)uni((uint32_t)(lv >> 32)) << 32) | uni((uint32_t)lv));
+  const gu8* src = uni_ptr(as_global(src_)); gu8* dst = uni_ptr(as_global(dst_));
+  const uint32_t bsize = uni(bsize_), T = uni(T_), N = bsize / T;
+  const uint32_t pstride = uni(pstride_) ? uni(pstride_) : N;
+  static_assert(256u * 32u <= DR_LDS_BYTES, "the element-major tile of a pass must fit the LDS a wave owns");
+  const uint32_t l4 = 4u * (uint32_t)lane;
+  // as many 256-element tiles per pass as the LDS holds (narrow elements: a pass of ONE tile of typesize 3 would move 768 bytes)
+  const uint32_t M = (DR_LDS_BYTES / 256u) / T;
+  uint32_t e = 0;
+  while (e + 256u <= N) {
+    const uint32_t m_here = (N - e) / 256u < M ? (N - e) / 256u : M;
+    for (uint32_t m = 0; m < m_here; m++) {
+      lu8* Sm = S + m * 256u * T;
+      if ((T & 3u) == 0u) {                              // whole dwords per element: four planes -> 4 x 4 byte transpose -> one dword of each of the lane's four elements
+        for (uint32_t j = 0; j < T; j += 4u) {
+          const gu8* p = src + (size_t)j * pstride + e + 256u * m + l4;
+          const uint32_t r0 = g_ld4(p), r1 = g_ld4(p + pstride), r2 = g_ld4(p + 2 * (size_t)pstride), r3 = g_ld4(p + 3 * (size_t)pstride);
+          uint32_t t0, t1, t2, t3;
+          transpose4x4(r0, r1, r2, r3, t0, t1, t2, t3);
+          BAMD_LAS uint32_t* d = (BAMD_LAS uint32_t*)(Sm + l4 * T + j);
+          d[0] = t0; d[T / 4u] = t1; d[2u * (T / 4u)] = t2; d[3u * (T / 4u)] = t3;
+        }
+        continue;
+      }
+      for (uint32_t j = 0; j < T; j += 4u) {             // four planes per round: their loads travel together
+        uint32_t v[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; k++) v[k] = (j + k < T) ? g_ld4(src + (size_t)(j + k) * pstride + e + 256u * m + l4) : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; k++)
+          if (j + k < T) {
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; i++) Sm[(l4 + i) * T + j + k] = (uint8_t)(v[k] >> (8u * i));
+          }
+      }
+    }
+    LDS_ORDER(); BAMD_LDS_SYNC();
+    gu8* out = dst + (size_t)e * T;
+    for (uint32_t q = (uint32_t)lane; q < 16u * T * m_here; q += 64u) st16_dst(out + 16u * q, l_ld16(S + 16u * q));
+    LDS_ORDER(); BAMD_LDS_SYNC();
+    e += 256u * m_here;
+  }
+  // fewer than 256 elements, then the bytes that do not form a whole element
+  for (uint32_t k = (uint32_t)lane; k < (N - e) * T; k += 64u) { const uint32_t el = k / T, j = k - el * T; dst[(size_t)e * T + k] = src[(size_t)j * pstride + e + el]; }
+  for (uint32_t k = N * T + (uint32_t)lane; k < bsize; k += 64u) dst[k] = src[k];
+}
+
+// ---------------------------------------------------------------------------------------------
 // Fused bit-unshuffle of one block by ONE wavefront (typesize 1, 2 or 4), round 4: the wave that completes a block's last stream runs it
 // out of its XCD's L2, exactly like the byte unshuffle above - there is no k_bitunshuffle pass over the batch any more (3.9 ms per 8 GiB on
 // config #3, 2 x nbytes of traffic that SURVEY 8d says must not be credited).  Inverse of blosc_internal_bitshuffle
@@ -806,7 +865,7 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
   const BlockDesc* b = blocks + gb;
   const uint32_t nstreams = uni((uint32_t)b->nstreams);
   SpanCtx sp;
-  sp.enabled = ((mode & CH_FUSED_UNSHUF) && nstreams == uni((uint32_t)c->typesize) && spans) ? 1u : 0u;
+  sp.enabled = ((mode & CH_FUSED_UNSHUF) && nstreams == uni((uint32_t)c->typesize) && spans && !unshuffle_generic_T(uni((uint32_t)c->typesize))) ? 1u : 0u;
   sp.lo = 0; sp.hi = 0; sp.off = 0; sp.pat = uni_ptr(as_global(pat)) + (size_t)sid * SPAN_PAT;
   const uint64_t cost_t0 = __builtin_amdgcn_s_memtime();
   int got;
@@ -870,6 +929,11 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
 #ifdef BAMD_PROFILE_DECODE
   const uint64_t ut0 = __builtin_amdgcn_s_memtime();
 #endif
+  if (unshuffle_generic_T(uni((uint32_t)c->typesize))) {
+    unshuffle_block_generic(scr, c->filt + (size_t)uni((uint32_t)b->blk) * filt_block_stride(*c), c->dst + boff, uni((uint32_t)b->bsize), uni((uint32_t)c->typesize),
+                            filt_plane_stride(*c, uni((uint32_t)b->bsize), (int)nstreams), lane);
+    return;
+  }
   unshuffle_block_wave(c->filt + (size_t)uni((uint32_t)b->blk) * filt_block_stride(*c), c->dst + boff, uni((uint32_t)b->bsize), (int)uni((uint32_t)c->typesize), lane,
                        split ? spans + 2 * (size_t)fs : nullptr, pat + (size_t)fs * SPAN_PAT, sd - (sid - fs),
                        filt_plane_stride(*c, uni((uint32_t)b->bsize), (int)nstreams));

@@ -62,6 +62,9 @@ enum { ENC_LZ = 0, ENC_ZSTD = 1, ENC_ZLIB = 2, ENC_HC = 3, ENC_ZSTD_T = 4, ENC_Z
 constexpr bool enc_mode_hc(int mode) { return mode == ENC_HC || mode == ENC_ZSTD_HC || mode == ENC_ZLIB_HC || mode == ENC_ZSTD_HCH || mode == ENC_ZLIB_DYN_HC; }
 constexpr bool enc_mode_zlib(int mode) { return mode == ENC_ZLIB || mode == ENC_ZLIB_HC || mode == ENC_ZLIB_DYN || mode == ENC_ZLIB_DYN_HC; }
 constexpr bool enc_mode_zstd(int mode) { return mode == ENC_ZSTD || mode == ENC_ZSTD_T || mode == ENC_ZSTD_HC || mode == ENC_ZSTD_TH || mode == ENC_ZSTD_HCH; }
+#ifndef BAMD_ENC_HELP
+#define BAMD_ENC_HELP 256     // a wave whose stream's block is not shuffled yet takes shuffle tasks instead of sleeping, up to this many blocks ahead (0: never)
+#endif
 template <int MODE>
 __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, enc_entry_t* tab, const ChunkDesc* chunks, uint32_t* blk_ready, int lane,
                                                             const BlockDesc* blocks, uint32_t sid, uint32_t* plane_cost, uint64_t* seqbuf
@@ -120,7 +123,7 @@ template <int MODE>
 // (waves per SIMD the register allocator plans for: the 24 KiB table of the HC modes leaves room for 1.5, the Zstd modes' LDS for 5)
 __global__ __launch_bounds__(64 * ENC_WAVES, enc_mode_hc(MODE) ? 2 : ((MODE == ENC_ZSTD_T || MODE == ENC_ZSTD_TH) ? 5 : BAMD_ENC_MINWAVES)) void k_encode_streams_t(
     StreamDesc* __restrict__ streams, uint32_t* __restrict__ tickets /*[8]*/, const int32_t* __restrict__ qlist,
-    const int32_t* __restrict__ qoff /*[9]*/, const ChunkDesc* __restrict__ chunks, const BlockDesc* __restrict__ blocks,
+    const int32_t* __restrict__ qoff /*[9]*/, const int32_t* __restrict__ shoff /*[9] | shuffle list*/, const ChunkDesc* __restrict__ chunks, const BlockDesc* __restrict__ blocks,
     uint32_t* __restrict__ blk_ready, uint32_t* __restrict__ plane_cost, int single_queue,
     uint64_t* __restrict__ seqbufs, const zenc::CTabs* __restrict__ ctabs, int detect_periodic
 #ifdef BAMD_PROFILE_DECODE
@@ -142,13 +145,41 @@ __global__ __launch_bounds__(64 * ENC_WAVES, enc_mode_hc(MODE) ? 2 : ((MODE == E
   // HW_REG_XCC_ID[3:0]; queue 0 for everybody in the single-queue fallback (no in-kernel hand-offs there)
   const uint32_t xcc = single_queue ? 0u : (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);
   const uint32_t qbase = (uint32_t)qoff[xcc], qlen = (uint32_t)qoff[xcc + 1] - qbase;
+  // Shuffle tasks are claimed in list order through a counter of their own (queue_order.h): a negative queue entry means "one
+  // shuffle task", and a wave whose stream's block is not ready yet claims shuffle tasks too instead of sleeping.  No deadlock: a
+  // shuffle task never waits, and a stream waits only for a block whose task either is claimed by a running wave or is still on
+  // the list - where the waiting wave itself reaches it (claims are in list order, the list is finite).
+  const uint32_t shbase = (uint32_t)shoff[xcc], shlen = (uint32_t)shoff[xcc + 1] - shbase;
+  const int32_t* shlist = shoff + 9;
+  auto shuffle_one = [&]() -> bool {
+    const uint32_t s = take_ticket(tickets + 8 + xcc, lane);
+    if (s >= shlen) return false;
+    shuffle_block_task(chunks, blocks, uni((uint32_t)shlist[shbase + s]), blk_ready, streams, detect_periodic, lane, (volatile uint32_t*)tabs[0]);
+    return true;
+  };
   uint32_t t = take_ticket(tickets + xcc, lane);
   uint32_t ndone = 0;      // tasks this wave took: summed into plane_cost[256], the host checks the total
   while (t < qlen) {
     const int32_t task = (int32_t)uni((uint32_t)qlist[qbase + t]);
     if (task < 0) {
-      shuffle_block_task(chunks, blocks, (uint32_t)(-(task + 1)), blk_ready, streams, detect_periodic, lane);
+      shuffle_one();
     } else {
+      const StreamDesc* sd = streams + task;
+      if (uni(chunks[uni((uint32_t)sd->chunk)].mode) & CH_FUSED_SHUF) {
+        const uint32_t gb = uni((uint32_t)sd->aux) >> 4;
+        // only for the LDS-tile shuffle of the "other" typesizes (a task of theirs takes a wave several times as long as the register forms
+        // of 2 / 4 / 8 / 16, so the few waves that drew the negative entries cannot keep incompressible data coming: random bytes, typesize 6:
+        // 13.3 -> 9.6 ms).  With the fast forms helping costs 4 % on compressible data and gains nothing on random bytes
+        // (profiles/r04z2_enc_ab_help_bound_variants.txt).
+        const ChunkDesc* cd = chunks + uni((uint32_t)sd->chunk);
+        bool more = !(uni(cd->mode) & CH_BITSHUFFLE) && shuffle_generic_T(uni((uint32_t)cd->typesize));
+        while (__hip_atomic_load(&blk_ready[gb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+          // ... but not further ahead of its own block than BAMD_ENC_HELP blocks of the list: planes shuffled much earlier than they are
+          // encoded have left the L2 / MALL by then (unbounded: config 2 + 7 %, profiles/r04z_enc_ab_help_unbounded_vs_off.txt)
+          if (BAMD_ENC_HELP && more && __hip_atomic_load(tickets + 8 + xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (single_queue ? gb : gb / 8u) + (uint32_t)BAMD_ENC_HELP) more = shuffle_one();
+          else __builtin_amdgcn_s_sleep(16);
+        }
+      }
 #ifdef BAMD_PROFILE_DECODE
       encode_one_stream<MODE>(streams + task, tabs[0], chunks, blk_ready, lane, blocks, (uint32_t)task, plane_cost, seqbuf, profbuf ? profbuf + (size_t)task * 16 : nullptr);
 #else

@@ -12,15 +12,18 @@
 
 namespace bamd {
 
-// Per-XCD task queues of the encode kernel: out = off[9] | entries.  Block g belongs to queue g % nq (nq = 8:
-// one queue per XCD; nq = 1: the single-queue fallback of engine.hip, which also switches the fusion off); an
-// entry >= 0 is a stream index, an entry < 0 the shuffle task of block -(entry+1).  A block's shuffle
-// task is queued kEncLookahead blocks ahead of its streams: by the time a wave draws one of the streams
-// the transpose is normally finished, and it is always already owned by a running wave (no deadlock).
+// Per-XCD task queues of the encode kernel: out = off[9] | entries | shoff[9] | shuffle list.  Block g belongs to queue
+// g % nq (nq = 8: one queue per XCD; nq = 1: the single-queue fallback of engine.hip, which also switches the fusion off); an
+// entry >= 0 is a stream index, an entry < 0 "one shuffle task" (written as -(block+1) of the block it stands for).  A block's
+// shuffle task is queued kEncLookahead blocks ahead of its streams: by the time a wave draws one of the streams the transpose is
+// normally finished.  The shuffle list names the same blocks per XCD in the same order; shuffle tasks are CLAIMED from it through
+// a counter of their own, by the waves that draw a negative entry and by waves that would otherwise wait for a block that is not
+// ready (k_encode.hip): when the streams are cheap (incompressible data) the transposes then run on every waiting wave instead of
+// on the few that drew the negative entries.  *sh_at = index of shoff[0] in `out`.
 constexpr size_t kEncLookaheadDefault = 32;
 inline size_t enc_lookahead() { return kEncLookaheadDefault; }     // (swept 1 ... 64 in round 4: 8.4 ... 8.0 ms, profiles/r04q_enc_lookahead_sweep.txt - the distance hardly matters)
 // BLOSC_AMD_SCHED=0: plain block order (no cost feedback)
-inline bool sched_enabled() { static const bool on = !(getenv("BLOSC_AMD_SCHED") && atoi(getenv("BLOSC_AMD_SCHED")) == 0); return on; }
+inline bool sched_enabled() { const char* e = getenv("BLOSC_AMD_SCHED"); return !(e && atoi(e) == 0); }      // read on every call (bench.py times one step without it: `sched_cold`)
 
 // plane indices 0..T-1 in descending cost; *nheavy = how many of them count as expensive (> max/2)
 inline void plane_order(const uint32_t* cost, bool valid, int T, std::vector<int>& order, int* nheavy) {
@@ -41,15 +44,15 @@ inline void plane_order(const uint32_t* cost, bool valid, int T, std::vector<int
 // The kernel's tail (waves finishing their last stream while the queue is already empty) then consists of
 // cheap streams instead of 3 ms ones.
 inline void build_encode_queues(const std::vector<BlockDesc>& blocks, const std::vector<ChunkDesc>& chunks,
-                                const uint32_t* cost, bool cost_valid, std::vector<int32_t>& out, int nq = 8) {
-  std::vector<int32_t> q[8];
+                                const uint32_t* cost, bool cost_valid, std::vector<int32_t>& out, int nq = 8, size_t* sh_at = nullptr) {
+  std::vector<int32_t> q[8], sh[8];
   std::vector<uint32_t> mine[8];
   for (size_t g = 0; g < blocks.size(); g++) if (blocks[g].nstreams > 0) mine[g % (size_t)nq].push_back((uint32_t)g);
   std::vector<int> order; int nheavy = 0, lastT = -1;
   for (int x = 0; x < 8; x++) {
     const std::vector<uint32_t>& B = mine[x];
     auto push_shuffle = [&](size_t i) {
-      if (chunks[(size_t)blocks[B[i]].chunk].mode & CH_FUSED_SHUF) q[x].push_back(-(int32_t)B[i] - 1);
+      if (chunks[(size_t)blocks[B[i]].chunk].mode & CH_FUSED_SHUF) { q[x].push_back(-(int32_t)B[i] - 1); sh[x].push_back((int32_t)B[i]); }
     };
     int maxT = 1;
     const size_t kEncLookahead = enc_lookahead();
@@ -73,6 +76,11 @@ inline void build_encode_queues(const std::vector<BlockDesc>& blocks, const std:
   for (int x = 0; x < 8; x++) { out[(size_t)x + 1] = out[(size_t)x] + (int32_t)q[x].size(); }
   for (int x = 0; x < 8; x++) out.insert(out.end(), q[x].begin(), q[x].end());
   if (out.size() == 9) out.push_back(0);
+  const size_t at = out.size();
+  if (sh_at) *sh_at = at;
+  out.resize(at + 9, 0);
+  for (int x = 0; x < 8; x++) out[at + (size_t)x + 1] = out[at + (size_t)x] + (int32_t)sh[x].size();
+  for (int x = 0; x < 8; x++) out.insert(out.end(), sh[x].begin(), sh[x].end());
 }
 
 // Per-XCD stream queues of the decode kernel: out = off[9] | stream indices.  Block g belongs to XCD g & 7

@@ -19,15 +19,17 @@ def _api(emu):
     return emu
 
 
-@pytest.mark.parametrize("T", [2, 4, 8, 16])
+@pytest.mark.parametrize("T", [2, 4, 8, 16, 3, 5, 6, 7, 12, 17, 24, 25, 31, 32])      # 2 / 4 / 8 / 16: register transposes; the others: the LDS-tile forms of round 4
 def test_shuffle_and_unshuffle_equal_the_oracles(emu, oracle, T):
     e = _api(emu)
     rng = np.random.default_rng(T)
-    for bsize in [256 * T, 1024 * T, 1280 * T, 4096 * T, 256 * 1024]:
+    for bsize in [256 * T, 1024 * T, 1280 * T, 4096 * T, 256 * 1024] + ([128 * T, 384 * T + 7] if T not in (2, 4, 8, 16) else []):
         for data in (rng.integers(0, 256, bsize, dtype=np.uint8), DATASETS["bench19"](bsize), DATASETS["linspace"](bsize)):
             want = np.zeros(bsize, np.uint8)
             oracle.orc_shuffle(T, bsize, ptr(data), ptr(want))
             got = np.full(bsize + 64, 0xEE, np.uint8)
+            if T in (2, 4, 8, 16) and (bsize // T) % 256:      # (the register forms of the fused SHUFFLE are only ever given whole rows + the generic tail; sizes with a ragged tail go through mode 2 below)
+                continue
             e.emu_shuffle_block(T, 0, ptr(data), ptr(got), bsize, None)
             assert np.array_equal(got[:bsize], want) and np.all(got[bsize:] == 0xEE), (T, bsize)
             back = np.full(bsize + 64, 0xEE, np.uint8)

@@ -40,10 +40,16 @@ void lane_body(int lane, void* arg) {
 // ---- the fused byte (un)shuffle of one block by one wave (k_encode.hip: shuffle_block_wave_T / shuffle_block_wave_detect with its
 // periodic-plane detection and emit_periodic_stream; k_decode.hip: unshuffle_block_wave) ----
 namespace {
-struct SJob { int T, mode; const uint8_t* src; uint8_t* dst; uint32_t bsize; uint32_t period[16]; uint32_t per; };
+struct SJob { int T, mode; const uint8_t* src; uint8_t* dst; uint32_t bsize; uint32_t period[16]; uint32_t per; uint32_t* lds; };
 void shuf_body(int lane, void* arg) {
   SJob* j = (SJob*)arg;
   using namespace bamd;
+  if (unshuffle_generic_T((uint32_t)j->T)) {         // every other typesize up to 32: the LDS-tile forms (round 4)
+    if (j->mode == 2) unshuffle_block_generic((volatile uint32_t*)j->lds, j->src, j->dst, j->bsize, (uint32_t)j->T, 0u, lane);
+    else shuffle_block_generic((volatile uint32_t*)j->lds, (const gu8*)j->src, (gu8*)j->dst, j->bsize, (uint32_t)j->T, lane);
+    if (lane == 0) { j->per = 0; for (int k = 0; k < 16; k++) j->period[k] = 0; }
+    return;
+  }
   if (j->mode == 2) { unshuffle_block_wave(j->src, j->dst, j->bsize, j->T, lane, nullptr, nullptr, nullptr); return; }
   uint32_t period[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   uint32_t per = 0;
@@ -66,8 +72,11 @@ void per_body(int lane, void* arg) {
 // mode 0: shuffle, 1: shuffle with periodic-plane detection (period_out[k] != 0: plane k repeats with that period and only its first
 // 256 bytes were written), 2: unshuffle.  typesize 2, 4, 8 or 16; bsize a multiple of 256 * typesize for modes 0 / 1.  Returns the plane mask.
 extern "C" unsigned emu_shuffle_block(int T, int mode, const uint8_t* src, uint8_t* dst, unsigned bsize, unsigned* period_out) {
-  SJob j = {T, mode, src, dst, bsize, {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0};
+  SJob j = {T, mode, src, dst, bsize, {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, nullptr};
+  j.lds = (uint32_t*)aligned_alloc(64, 16384);        // the wave's LDS (the decoder's rings / the encoder's table)
+  memset(j.lds, 0xA5, 16384);
   wave_emu::run(shuf_body, &j);
+  free(j.lds);
   if (period_out) for (int k = 0; k < 16; k++) period_out[k] = j.period[k];      // room for 16 words
   return j.per;
 }
@@ -123,7 +132,7 @@ struct CJob { int mode; bamd::StreamDesc* sd; uint32_t* tab; bamd::ChunkDesc* ch
 void enc_blk_body(int lane, void* arg) {
   CJob* j = (CJob*)arg;
   using namespace bamd;
-  if (j->shuffle_task) { shuffle_block_task(j->chunks, j->blocks, 0u, j->blk_ready, j->sd, 1, lane); return; }
+  if (j->shuffle_task) { shuffle_block_task(j->chunks, j->blocks, 0u, j->blk_ready, j->sd, 1, lane, (volatile uint32_t*)j->tab); return; }
   if (j->mode == ENC_HC) encode_one_stream<ENC_HC>(j->sd + j->sid, j->tab, j->chunks, j->blk_ready, lane, j->blocks, j->sid, nullptr, j->seqbuf);
   else encode_one_stream<ENC_LZ>(j->sd + j->sid, j->tab, j->chunks, j->blk_ready, lane, j->blocks, j->sid, nullptr, j->seqbuf);
 }

@@ -48,7 +48,17 @@ int main() {
     size_t nfused = 0;
     for (auto& b : blocks) if (b.nstreams > 0 && (chunks[b.chunk].mode & CH_FUSED_SHUF)) nfused++;
     if ((size_t)q[8] != (size_t)nstr + nfused) return fail("enc: task count", trial);
-    if (q.size() != (size_t)9 + ((size_t)q[8] ? (size_t)q[8] : 1)) return fail("enc: vector size", trial);
+    // behind the entries: shoff[9] | the shuffle list (the same blocks per XCD, in the order of the negative entries)
+    const size_t sh_at = (size_t)9 + ((size_t)q[8] ? (size_t)q[8] : 1);
+    if (q.size() != sh_at + 9 + nfused || q[sh_at] != 0 || (size_t)q[sh_at + 8] != nfused) return fail("enc: vector size / shuffle list header", trial);
+    for (int x = 0; x < 8; x++) {
+      size_t k = (size_t)q[sh_at + (size_t)x];
+      for (int i = q[x]; i < q[x + 1]; i++) if (q[9 + i] < 0) {
+        if (k >= (size_t)q[sh_at + (size_t)x + 1] || q[sh_at + 9 + k] != -(q[9 + i] + 1)) return fail("enc: shuffle list differs from the negative entries", trial);
+        k++;
+      }
+      if (k != (size_t)q[sh_at + (size_t)x + 1]) return fail("enc: shuffle list length", trial);
+    }
     std::vector<int> owner((size_t)nstr, -1);
     for (size_t g = 0; g < blocks.size(); g++) for (int k = 0; k < blocks[g].nstreams; k++) owner[(size_t)blocks[g].first_stream + k] = (int)g;
     std::vector<int> seen((size_t)nstr, 0); std::vector<int> shuffled(blocks.size(), 0);
