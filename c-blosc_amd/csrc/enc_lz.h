@@ -2,6 +2,9 @@
 // lz_encode_wave (LZ4 / BloscLZ streams, and the front end of the Zstd / zlib writers through their sinks) and hc_encode_wave
 // (the LZ4HC-grade search), with the table, window and emit helpers they share.  DESIGN.md 3.3.
 // build switches of the round-3 changes (defaults are what bench.py measures; the others are kept for same-session A/B runs, scripts/enc_ab.py)
+#ifndef BAMD_ENC_BACK4
+#define BAMD_ENC_BACK4 1      // four bytes in front of every candidate travel with the candidate's own bytes (lz_encode_wave)
+#endif
 #ifndef BAMD_ENC_EXT1K
 #define BAMD_ENC_EXT1K 3      // wave_common_fwd: short first trips before the 2 KiB rows (1: 1 KiB, 2: 512 bytes, 3: 256 bytes then 1 KiB - 5 % / 11 % / 19 % of the kernel on bench19)
 #endif
@@ -528,6 +531,9 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
     const uint32_t o0 = __builtin_amdgcn_alignbyte(x1, x0, sh), o1 = __builtin_amdgcn_alignbyte(x2, x1, sh);
     const uint32_t o2 = __builtin_amdgcn_alignbyte(x3, x2, sh), o3 = __builtin_amdgcn_alignbyte(x4, x3, sh);
     const uint32_t o4 = __builtin_amdgcn_alignbyte(x5, x4, sh);
+#if BAMD_ENC_BACK4
+    const uint32_t ownpre = __builtin_amdgcn_alignbyte(x0, (uint32_t)__builtin_amdgcn_ds_bpermute(ksel - 4, (int)r), sh);   // src[p-4 .. p-1] (p >= 4)
+#endif
     Bytes20 own;
     own.a = ((uint64_t)o1 << 32) | o0; own.b = ((uint64_t)o3 << 32) | o2; own.c = RANK_CAP > 16u ? o4 : 0u;
     // the two bytes before ip (uniform): r's lanes 0/1 hold them
@@ -556,8 +562,19 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
     PROF_LAP(8); PROF_ADD(0, 1);
     // ---- round 2: candidate bytes, exact lengths up to RANK_CAP ----
     uint32_t len = 0;
+    // nb: how many bytes in front of the candidate equal those in front of p, counted backwards, 0 .. 4 (4 = at least four); 7 = not looked at.
+    // The four bytes travel with the candidate's 20: most backward extensions are shorter than four bytes (bench19: 455 of 1162 sequences
+    // extend backwards, 49 by more than 4), and a sequence that needs neither more backward bytes nor forward rows then costs no memory
+    // round trip of its own in the selection loop below.
+    uint32_t nb = 7u;
     if (tab_ok) {
+#if BAMD_ENC_BACK4
+      const uint32_t cpre = cand >= 4u ? ld4u(src + cand - 4u) : 0u;
+#endif
       const Bytes20 cb = load20(src, cand, n);
+#if BAMD_ENC_BACK4
+      if (cand >= 4u) { const uint32_t x = cpre ^ ownpre; nb = x ? (uint32_t)__builtin_clz(x) >> 3 : 4u; }
+#endif
       len = common20(own, cb);
       if (len > limit) len = limit;
       if (len < minlen) len = 0;
@@ -566,7 +583,7 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
     if (live && prev < 0x100u) {                    // distance 1: run of the previous byte
       uint32_t rl = runlen20(own, prev);
       if (rl > limit) rl = limit;
-      if (rl >= minlen && rl > len) { len = rl; cand = p - 1u; }
+      if (rl >= minlen && rl > len) { len = rl; cand = p - 1u; nb = 7u; }
     }
     win.settle(lane);                               // behind the wait for the candidates: free
     // ---- select + emit.  The winner maximises (len - lane), ties to the lower lane.  When its match
@@ -591,7 +608,12 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
       if (cm < maxb) maxb = cm;
       if (maxb > 64u) maxb = 64u;
       uint32_t back = 0;
-      const bool back_known = maxb == 0u;
+      bool back_known = maxb == 0u;
+      if (BAMD_ENC_BACK4 && FMT != EF_BLOSCLZ && !back_known) {
+        const uint32_t nb_f = (uint32_t)__builtin_amdgcn_readlane((int)nb, f);
+        const uint32_t q = nb_f < maxb ? nb_f : maxb;
+        if (nb_f <= 4u && (q < 4u || q == maxb)) { back = q; back_known = true; }     // a mismatch within four bytes, or no room for more
+      }
       // otherwise backward bytes are requested first and looked at last, so that they travel together with the
       // forward rows (one memory round trip for both directions)
       // Every lane loads (lanes >= maxb a harmless byte): a load under a per-lane condition is compared where it is issued - the
