@@ -88,8 +88,11 @@ inline void build_encode_queues(const std::vector<BlockDesc>& blocks, const std:
 // With cost feedback the expensive planes of block i + kDecLead are queued together with the cheap planes of
 // block i: blocks still complete in order (the unshuffles stay spread over the whole kernel), but the
 // streams drawn last - the kernel's tail - are cheap ones.
+// (The lead was 256 blocks until round 4: the expensive planes then sat in the scratch for 2048 blocks' worth of output before their block
+//  completed and came back from HBM instead of the L2 / Infinity Cache.  64 / 16 / 2: - 9 % on reference-written config-2 chunks,
+//  profiles/r04zc_dec_ab_heavy_plane_lead_256_64_16_2.txt; the tail the lead is there for is as short at 16.)
 #ifndef BAMD_DEC_LEAD
-#define BAMD_DEC_LEAD 256
+#define BAMD_DEC_LEAD 16
 #endif
 constexpr size_t kDecLead = BAMD_DEC_LEAD;
 // pick = 0: the blocks of k_decode_streams (neither k_decode_blocks' nor the entropy-coded formats'); pick = BLK_ZLIB: the zlib kernel's.

@@ -140,7 +140,8 @@ int main() {
     std::vector<int32_t> q; build_encode_queues(blocks, chunks, cost, true, q);
     for (int x = 0; x < 8; x++) for (int i = q[x + 1] - 512; i < q[x + 1]; i++) if (q[9 + i] >= 0 && q[9 + i] % 8 == 5) return fail("enc: expensive plane in the tail", -1);
     std::vector<int32_t> d; build_xcd_queues(blocks, 8 * 4096, cost, true, d);
-    for (int x = 0; x < 8; x++) for (int i = d[x + 1] - 512; i < d[x + 1]; i++) if (d[9 + i] % 8 == 5) return fail("dec: expensive plane in the tail", -1);
+    // (the decode queues keep the expensive planes kDecLead blocks ahead, no more: further ahead their bytes leave the caches before the block completes)
+    for (int x = 0; x < 8; x++) for (int i = d[x + 1] - 7 * (int)kDecLead; i < d[x + 1]; i++) if (d[9 + i] % 8 == 5) return fail("dec: expensive plane in the tail", -1);
   }
   printf("sched_check OK\n");
   return 0;
