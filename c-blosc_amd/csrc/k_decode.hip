@@ -35,9 +35,10 @@ __global__ void k_decode_plan(const ChunkDesc* __restrict__ chunks, const BlockD
   const int32_t bsize = b.bsize;
   const int32_t neblock = bsize / b.nstreams;
   const bool to_filt = (c.mode & (CH_SHUFFLE | CH_BITSHUFFLE)) != 0;
-  // (Round 3 tried the scratch of block g at slot g % S of ONE arena - 768 ... 1536 slots, without any synchronisation, i.e. the most a ring of
-  //  block slots could ever give: no change, profiles/r03zd_dec_ab_block_slot_ring_no_gain.txt.  Address reuse does not bring the round trip
-  //  into the Infinity Cache while a block's scratch lives as long as its slowest stream.)
+  // (The scratch of block g at slot g % S of ONE arena, without any synchronisation - the most a ring of block slots could ever give: round 3,
+  //  768 ... 1536 slots: no change; round 4 with the LDS ring decoder and the short lead, 256 ... 2048 slots: - 5 ... - 12 % below 640 slots, where
+  //  several live blocks share a slot, - 0 ... - 7 % and not monotonic from 768 up (profiles/r04zd_*, r04ze_*).  About 1 600 blocks are live at a
+  //  time - a block lives as long as its slowest stream - so a real ring needs that many slots and gains a few per cent at best: not built.)
   uint8_t* out = to_filt ? c.filt + (size_t)b.blk * filt_block_stride(c) : c.dst + (size_t)b.blk * c.blocksize;
   const uint32_t pstride = (to_filt && b.nstreams > 1) ? filt_plane_stride(c, (uint32_t)bsize, b.nstreams) : (uint32_t)neblock;   // split blocks: one stream per plane
   int32_t off = ld_i32(c.src + 16 + 4 * (size_t)b.blk);
@@ -926,6 +927,7 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
   }
   const bool split = spans && nstreams == uni((uint32_t)c->typesize);
   const uint32_t fs = uni((uint32_t)b->first_stream);
+
 #ifdef BAMD_PROFILE_DECODE
   const uint64_t ut0 = __builtin_amdgcn_s_memtime();
 #endif
