@@ -42,7 +42,8 @@ inline void plane_order(const uint32_t* cost, bool valid, int T, std::vector<int
 // With cost feedback the queue has two passes: the first, in block order, carries the shuffle tasks and the
 // streams of the expensive planes; the second carries the cheap planes, plane by plane in descending cost.
 // The kernel's tail (waves finishing their last stream while the queue is already empty) then consists of
-// cheap streams instead of 3 ms ones.
+// cheap streams instead of 3 ms ones.  (One pass in the decode queues' manner - expensive planes of block i + lead with the cheap
+// planes of block i, lead 16 / 64 / 256 - is 4 ... 7 % slower: profiles/r04zg_enc_ab_one_pass_lead_order_rejected.txt.)
 inline void build_encode_queues(const std::vector<BlockDesc>& blocks, const std::vector<ChunkDesc>& chunks,
                                 const uint32_t* cost, bool cost_valid, std::vector<int32_t>& out, int nq = 8, size_t* sh_at = nullptr) {
   std::vector<int32_t> q[8], sh[8];
