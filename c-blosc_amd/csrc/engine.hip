@@ -329,7 +329,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   double ht_last = hosttime_on() ? now_ms() : 0.0; if (hosttime_on()) { std::lock_guard<std::mutex> l_(g_ht_mu); g_ht.calls[0]++; }
   std::vector<ChunkDesc> chunks((size_t)n);
   std::vector<BlockDesc> blocks;
-  std::vector<StreamDesc> streams;
+  size_t nstr = 0;                                   // the stream table itself is made on the device (k_encode_plan)
   std::vector<uint8_t> live((size_t)n, 0);
   size_t filt_bytes = 0, stage_bytes = 0, io_src = 0, io_dst = 0;
   int tiles_shuf = 0, tiles_bit = 0;
@@ -370,7 +370,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
     c.nblocks = nblocks; c.leftover = leftover; c.nsplits = split ? T : 1;
     c.fmt = codec_to_format(codec); c.clevel = (codec == kLZ4HC) ? 9 : p.clevel; c.hdr_flags = flags;
     c.mode = 0;
-    c.first_block = (int32_t)blocks.size(); c.first_stream = (int32_t)streams.size();
+    c.first_block = (int32_t)blocks.size(); c.first_stream = (int32_t)nstr;
     if (memcpyed) c.mode |= CH_MEMCPYED;
     else if (p.doshuffle == 1 && T > 1) { c.mode |= CH_SHUFFLE; if (fused_typesize(T) && fuse_enabled() && !st.single_queue) c.mode |= CH_FUSED_SHUF; }
     else if (p.doshuffle == 2) { c.mode |= CH_BITSHUFFLE; if (bitunshuffle_fused_host(T) && fuse_enabled() && !st.single_queue) c.mode |= CH_FUSED_SHUF; }
@@ -384,23 +384,15 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
       else if (c.mode & CH_SHUFFLE) { any_shuf = true; int t = (N + shuffle_tile_elems(T) - 1) / shuffle_tile_elems(T); if (t < 1) t = 1; if (t > tiles_shuf) tiles_shuf = t; }
       else { any_bit = true; int t = (N + bitshuffle_tile_elems(T) - 1) / bitshuffle_tile_elems(T); if (t < 1) t = 1; if (t > tiles_bit) tiles_bit = t; }
     }
-    // blocks + streams; pointers are patched once the arenas are placed (offsets stored for now)
+    // blocks; their streams (in = the block's bytes in the filtered image or the source, out = its staging slot) are k_encode_plan's
+    if (blocks.capacity() < blocks.size() + (size_t)nblocks) blocks.reserve(std::max(blocks.size() + (size_t)nblocks, (size_t)(n - i) * (size_t)nblocks + blocks.size()));   // (equal chunks: one allocation)
     for (int32_t j = 0; j < nblocks; j++) {
       BlockDesc b;
-      b.chunk = i; b.blk = j; b.first_stream = (int32_t)streams.size();
+      b.chunk = i; b.blk = j; b.first_stream = (int32_t)nstr;
       const bool last = (j == nblocks - 1) && leftover > 0;
       b.nstreams = memcpyed ? 0 : ((split && !last) ? T : 1);
-      const int32_t bsize = last ? leftover : bs;
-      b.bsize = bsize; b.flags = 0;
-      const int32_t neblock = b.nstreams ? bsize / b.nstreams : 0;
-      for (int32_t s = 0; s < b.nstreams; s++) {
-        StreamDesc sd;
-        memset(&sd, 0, sizeof sd);
-        sd.in = (const uint8_t*)(uintptr_t)((size_t)j * bs + (size_t)s * neblock);   // offset, patched below
-        sd.out = (uint8_t*)(uintptr_t)((size_t)j * bs + (size_t)s * neblock);
-        sd.in_size = neblock; sd.out_size = neblock; sd.chunk = i; sd.fmt = c.fmt; sd.aux = c.clevel | (int32_t)(blocks.size() << 4);
-        streams.push_back(sd);
-      }
+      b.bsize = last ? leftover : bs; b.flags = 0;
+      nstr += (size_t)b.nstreams;
       blocks.push_back(b);
     }
     if (!memcpyed) {
@@ -409,7 +401,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
     }
   }
 
-  const size_t nblk = blocks.size(), nstr = streams.size();
+  const size_t nblk = blocks.size();
   HT_MARK(0, 0);     // per-chunk geometry + block / stream tables
   // ---- device workspace ----
   Carver cv;
@@ -476,15 +468,6 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
       const bool filtered = (c.mode & (CH_SHUFFLE | CH_BITSHUFFLE)) != 0;
       if (filtered) { fo = align_up(fo, 256); c.filt = D + o_filt + fo; fo += (size_t)c.nbytes; }
       so = align_up(so, 256); c.stage = D + o_stage + so; so += (size_t)c.nbytes;
-      const uint8_t* inbase = filtered ? c.filt : c.src;
-      for (int32_t j = 0; j < c.nblocks; j++) {
-        const BlockDesc& b = blocks[(size_t)c.first_block + j];
-        for (int32_t s = 0; s < b.nstreams; s++) {
-          StreamDesc& sd = streams[(size_t)b.first_stream + s];
-          sd.in = inbase + (uintptr_t)sd.in;
-          sd.out = c.stage + (uintptr_t)sd.out;
-        }
-      }
     }
   }
   HT_MARK(0, 1);     // queues, workspace, pointer patching
@@ -492,7 +475,6 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   Carver pc;
   const size_t p_chunks = pc.take(sizeof(ChunkDesc) * (size_t)n);
   const size_t p_blocks = pc.take(sizeof(BlockDesc) * (nblk ? nblk : 1));
-  const size_t p_streams = pc.take(sizeof(StreamDesc) * (nstr ? nstr : 1));
   const size_t p_results = pc.take(sizeof(int32_t) * (size_t)n);
   const size_t p_queues = pc.take(sizeof(int32_t) * queues.size());
   const size_t p_cost = pc.take(sizeof(uint32_t) * kCostWords);
@@ -500,14 +482,12 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   uint8_t* P = st.pin.base;
   memcpy(P + p_chunks, chunks.data(), sizeof(ChunkDesc) * (size_t)n);
   if (nblk) memcpy(P + p_blocks, blocks.data(), sizeof(BlockDesc) * nblk);
-  if (nstr) memcpy(P + p_streams, streams.data(), sizeof(StreamDesc) * nstr);
   memcpy(P + p_queues, queues.data(), sizeof(int32_t) * queues.size());
   HIP_TRY(hipMemcpyAsync(D + o_queues, P + p_queues, sizeof(int32_t) * queues.size(), hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemsetAsync(D + o_ready, 0, sizeof(uint32_t) * (nblk ? nblk : 1), stream));
   HIP_TRY(hipMemsetAsync(D + o_cost, 0, sizeof(uint32_t) * kCostWords, stream));
   HIP_TRY(hipMemcpyAsync(D + o_chunks, P + p_chunks, sizeof(ChunkDesc) * (size_t)n, hipMemcpyHostToDevice, stream));
   if (nblk) HIP_TRY(hipMemcpyAsync(D + o_blocks, P + p_blocks, sizeof(BlockDesc) * nblk, hipMemcpyHostToDevice, stream));
-  if (nstr) HIP_TRY(hipMemcpyAsync(D + o_streams, P + p_streams, sizeof(StreamDesc) * nstr, hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemsetAsync(D + o_results, 0, sizeof(int32_t) * (size_t)n + 96, stream));
   uint32_t* d_ticket = (uint32_t*)(D + o_results + sizeof(int32_t) * (size_t)n + 32);
 
@@ -519,6 +499,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
 
   HT_MARK(0, 2);     // table copies to pinned memory + upload enqueues
   // ---- pipeline ----
+  if (nstr) hipLaunchKernelGGL(k_encode_plan, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, stream, d_chunks, d_blocks, d_streams, (int)nblk);
   if (any_shuf && nblk) {
     ProfScope ps(st, stream, "k_shuffle");
     hipLaunchKernelGGL(k_shuffle, dim3((unsigned)nblk, (unsigned)tiles_shuf), dim3(FT_THREADS), 0, stream, d_chunks, d_blocks);

@@ -48,10 +48,13 @@ inline void build_encode_queues(const std::vector<BlockDesc>& blocks, const std:
                                 const uint32_t* cost, bool cost_valid, std::vector<int32_t>& out, int nq = 8, size_t* sh_at = nullptr) {
   std::vector<int32_t> q[8], sh[8];
   std::vector<uint32_t> mine[8];
-  for (size_t g = 0; g < blocks.size(); g++) if (blocks[g].nstreams > 0) mine[g % (size_t)nq].push_back((uint32_t)g);
+  for (int x = 0; x < nq; x++) mine[x].reserve(blocks.size() / (size_t)nq + 1);
+  size_t nstr_all = 0;
+  for (size_t g = 0; g < blocks.size(); g++) if (blocks[g].nstreams > 0) { mine[g % (size_t)nq].push_back((uint32_t)g); nstr_all += (size_t)blocks[g].nstreams; }
   std::vector<int> order; int nheavy = 0, lastT = -1;
   for (int x = 0; x < 8; x++) {
     const std::vector<uint32_t>& B = mine[x];
+    if (!B.empty()) { q[x].reserve(2 * (nstr_all / (size_t)nq) + B.size() + 64); sh[x].reserve(B.size()); }
     auto push_shuffle = [&](size_t i) {
       if (chunks[(size_t)blocks[B[i]].chunk].mode & CH_FUSED_SHUF) { q[x].push_back(-(int32_t)B[i] - 1); sh[x].push_back((int32_t)B[i]); }
     };
@@ -73,6 +76,8 @@ inline void build_encode_queues(const std::vector<BlockDesc>& blocks, const std:
         if (k >= nheavy && k < b.nstreams) q[x].push_back(b.first_stream + order[(size_t)k]);
       }
   }
+  out.clear();
+  out.reserve(32 + nstr_all + 2 * blocks.size());
   out.assign(9, 0);
   for (int x = 0; x < 8; x++) { out[(size_t)x + 1] = out[(size_t)x] + (int32_t)q[x].size(); }
   for (int x = 0; x < 8; x++) out.insert(out.end(), q[x].begin(), q[x].end());
@@ -101,6 +106,7 @@ inline void build_xcd_queues(const std::vector<BlockDesc>& blocks, size_t nstr, 
                              std::vector<int32_t>& out, int nq = 8, uint32_t pick = 0u) {
   std::vector<int32_t> q[8];
   std::vector<uint32_t> mine[8];
+  for (int x = 0; x < nq; x++) { mine[x].reserve(blocks.size() / (size_t)nq + 1); q[x].reserve(nstr / (size_t)nq + 64); }
   for (size_t g = 0; g < blocks.size(); g++) {
     const uint32_t f = (uint32_t)blocks[g].flags;
     if (blocks[g].nstreams > 0 && (pick ? (f & pick) != 0u : !(f & BLK_Z))) mine[g % (size_t)nq].push_back((uint32_t)g);
@@ -122,6 +128,8 @@ inline void build_xcd_queues(const std::vector<BlockDesc>& blocks, size_t nstr, 
       else for (int k = 0; k < b.nstreams; k++) q[x].push_back(b.first_stream + k);   // no feedback: plain order
     }
   }
+  out.clear();
+  out.reserve(10 + nstr);
   out.assign(9, 0);
   for (int x = 0; x < 8; x++) out[(size_t)x + 1] = out[(size_t)x] + (int32_t)q[x].size();
   for (int x = 0; x < 8; x++) out.insert(out.end(), q[x].begin(), q[x].end());
