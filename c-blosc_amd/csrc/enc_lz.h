@@ -2,12 +2,6 @@
 // lz_encode_wave (LZ4 / BloscLZ streams, and the front end of the Zstd / zlib writers through their sinks) and hc_encode_wave
 // (the LZ4HC-grade search), with the table, window and emit helpers they share.  DESIGN.md 3.3.
 // build switches of the round-3 changes (defaults are what bench.py measures; the others are kept for same-session A/B runs, scripts/enc_ab.py)
-#ifndef BAMD_ENC_BACK4
-#define BAMD_ENC_BACK4 1      // four bytes in front of every candidate travel with the candidate's own bytes (lz_encode_wave)
-#endif
-#ifndef BAMD_ENC_EXT1K
-#define BAMD_ENC_EXT1K 3      // wave_common_fwd: short first trips before the 2 KiB rows (1: 1 KiB, 2: 512 bytes, 3: 256 bytes then 1 KiB - 5 % / 11 % / 19 % of the kernel on bench19)
-#endif
 constexpr int ENC_WAVES = 1;       // one stream per workgroup: a slot frees up as soon as ITS stream is done
 // Table entry = position mod 65536 | 16 further hash bits as a tag << 16.  The tag lets a lane reject a
 // stale or colliding entry WITHOUT touching memory: untagged, nearly every lane of every step fetched 20
@@ -81,7 +75,7 @@ __device__ __forceinline__ uint32_t common16(const uint4& x, const uint4& y) {
 __device__ __forceinline__ uint32_t wave_common_fwd(const gu8* src, uint32_t n, uint32_t a, uint32_t b,
                                                     uint32_t maxlen, int lane) {
   uint32_t done = 0;
-#if BAMD_ENC_EXT1K == 3
+  // first trips: 256 bytes, then 1 KiB (round 3: 1 KiB / 512 / 256 + 1 KiB first trips cost 5 % / 11 % / 19 % less of the kernel on bench19 than 2 KiB rows at once)
   if (maxlen && a + 256u <= n) {     // variant: 256 bytes
     const uint32_t x = g_ld4(src + a + 4 * lane) ^ g_ld4(src + b + 4 * lane);
     const uint32_t q = 4u * (uint32_t)lane;
@@ -102,31 +96,6 @@ __device__ __forceinline__ uint32_t wave_common_fwd(const gu8* src, uint32_t n, 
       done += 1024u;
     }
   }
-#elif BAMD_ENC_EXT1K == 2
-  if (maxlen && a + 512u <= n) {     // variant: 512 bytes
-    const uint64_t x = g_ld8(src + a + 8 * lane) ^ g_ld8(src + b + 8 * lane);
-    const uint32_t q = 8u * (uint32_t)lane;
-    uint32_t e0 = x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8u;
-    const uint32_t r0 = q < maxlen ? maxlen - q : 0u;
-    if (e0 > r0) e0 = r0;
-    const uint64_t s0 = __ballot(e0 < 8u);
-    if (s0) { const int f = __builtin_ctzll(s0); return 8u * (uint32_t)f + (uint32_t)__builtin_amdgcn_readlane((int)e0, f); }
-    done = 512u;
-  }
-#elif BAMD_ENC_EXT1K
-  // First trip: ONE 1 KiB row of each side.  Nearly every extension ends inside it (bench19's noisy planes: 385 of 386 per stream end
-  // within 256 bytes) - the 2 KiB-per-side trips below fetched 4 KiB for them.
-  if (maxlen && a + 1024u <= n) {
-    const uint4 x0 = g_ld16(src + a + 16 * lane), y0 = g_ld16(src + b + 16 * lane);
-    const uint32_t q = 16u * (uint32_t)lane;
-    uint32_t e0 = common16(x0, y0);
-    const uint32_t r0 = q < maxlen ? maxlen - q : 0u;
-    if (e0 > r0) e0 = r0;
-    const uint64_t s0 = __ballot(e0 < 16u);
-    if (s0) { const int f = __builtin_ctzll(s0); return 16u * (uint32_t)f + (uint32_t)__builtin_amdgcn_readlane((int)e0, f); }
-    done = 1024u;
-  }
-#endif
   while (done < maxlen && a + done + 2048u <= n) {
     const gu8* pa = src + a + done + 16 * lane;
     const gu8* pb = src + b + done + 16 * lane;
@@ -168,10 +137,7 @@ __device__ __forceinline__ uint32_t wave_common_fwd(const gu8* src, uint32_t n, 
   return maxlen;
 }
 
-#ifndef BAMD_ENC_NOSTORE
-#define BAMD_ENC_NOSTORE 0    // experiment only (wrong output): the LZ4 emitter computes everything and stores nothing - what the stores cost
-#endif
-#define ENC_ST1(ptr, val) do { if (!BAMD_ENC_NOSTORE) *(ptr) = (val); } while (0)
+#define ENC_ST1(ptr, val) do { *(ptr) = (val); } while (0)
 // write `v` as LZ4's 255-run length extension starting at p; returns bytes written
 __device__ __forceinline__ uint32_t emit_ext255(gu8* p, uint32_t v, int lane) {
   const uint32_t n255 = v / 255u, rem = v - n255 * 255u;
@@ -262,7 +228,7 @@ __device__ __forceinline__ void emit_literals(gu8* dst, const gu8* lit, uint32_t
     const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((uint32_t)lit_lane0 + (uint32_t)lane) & 63u) << 2, (int)ownbyte);
     if ((uint32_t)lane < ll) ENC_ST1(dst + lane, (uint8_t)v);
   } else {
-    if (!BAMD_ENC_NOSTORE) wave_copy_disjoint(dst, lit, ll, lane);
+    wave_copy_disjoint(dst, lit, ll, lane);
   }
 }
 
@@ -532,9 +498,7 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
     const uint32_t o0 = __builtin_amdgcn_alignbyte(x1, x0, sh), o1 = __builtin_amdgcn_alignbyte(x2, x1, sh);
     const uint32_t o2 = __builtin_amdgcn_alignbyte(x3, x2, sh), o3 = __builtin_amdgcn_alignbyte(x4, x3, sh);
     const uint32_t o4 = __builtin_amdgcn_alignbyte(x5, x4, sh);
-#if BAMD_ENC_BACK4
     const uint32_t ownpre = __builtin_amdgcn_alignbyte(x0, (uint32_t)__builtin_amdgcn_ds_bpermute(ksel - 4, (int)r), sh);   // src[p-4 .. p-1] (p >= 4)
-#endif
     Bytes20 own;
     own.a = ((uint64_t)o1 << 32) | o0; own.b = ((uint64_t)o3 << 32) | o2; own.c = RANK_CAP > 16u ? o4 : 0u;
     // the two bytes before ip (uniform): r's lanes 0/1 hold them
@@ -569,13 +533,9 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
     // round trip of its own in the selection loop below.
     uint32_t nb = 7u;
     if (tab_ok) {
-#if BAMD_ENC_BACK4
       const uint32_t cpre = cand >= 4u ? ld4u(src + cand - 4u) : 0u;
-#endif
       const Bytes20 cb = load20(src, cand, n);
-#if BAMD_ENC_BACK4
       if (cand >= 4u) { const uint32_t x = cpre ^ ownpre; nb = x ? (uint32_t)__builtin_clz(x) >> 3 : 4u; }
-#endif
       len = common20(own, cb);
       if (len > limit) len = limit;
       if (len < minlen) len = 0;
@@ -610,7 +570,7 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
       if (maxb > 64u) maxb = 64u;
       uint32_t back = 0;
       bool back_known = maxb == 0u;
-      if (BAMD_ENC_BACK4 && FMT != EF_BLOSCLZ && !back_known) {
+      if (FMT != EF_BLOSCLZ && !back_known) {
         const uint32_t nb_f = (uint32_t)__builtin_amdgcn_readlane((int)nb, f);
         const uint32_t q = nb_f < maxb ? nb_f : maxb;
         if (nb_f <= 4u && (q < 4u || q == maxb)) { back = q; back_known = true; }     // a mismatch within four bytes, or no room for more
