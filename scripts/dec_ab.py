@@ -34,6 +34,11 @@ for spec in os.environ.get("DECSETS", "bench19:1:8").split():
     r = R.blosc_compress_ctx(int(os.environ.get("CLEVEL", "5")), sh, ts, csz, host.ctypes.data, tmp.ctypes.data, csz + 16, os.environ.get("CODEC", "lz4").encode(), 0, 8)
     comp[:, :r].copy_(torch.from_numpy(tmp[:r].copy()).to(dev).unsqueeze(0).expand(nchunks, r))
     want = torch.from_numpy(host).to(dev)
+    if os.environ.get("OWN"):      # OWN=1: the chunks the FIRST library writes instead of the reference's (every build decodes the same bytes)
+        back[:] = want
+        eb = mods[0].DeviceBatch([back[i].data_ptr() for i in range(nchunks)], [csz] * nchunks, [comp[i].data_ptr() for i in range(nchunks)], [csz + 16] * nchunks)
+        assert eb.compress(ts, int(os.environ.get("CLEVEL", "5")), sh, os.environ.get("CODEC", "lz4").encode(), 0) == 0
+        r = eb.results()[0]
     batches = [m.DeviceBatch([comp[i].data_ptr() for i in range(nchunks)], [csz + 16] * nchunks, [back[i].data_ptr() for i in range(nchunks)], [csz] * nchunks) for m in mods]
     res = [[] for _ in mods]
     for m, b in zip(mods, batches):
