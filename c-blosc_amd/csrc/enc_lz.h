@@ -461,11 +461,11 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
   // below clevel 9 a match must be longer than the format minimum to be taken.  4-byte matches are mostly accidental in noisy planes, save one
   // byte each and cost a full sequence: requiring 6 halved the encode time of noisy float64 data for
   // < 1 % of ratio (bench19: 53.3 -> 48.5, still far above the reference's 36.7 at this clevel); 7 (round 4,
-  // profiles/r04zb_enc_ab_min_match_6_7_8.txt): random-walk data another - 11 %, bench19 - 2 % at ratio 47.8; 8 would cost 13 % of bench19's ratio.
+  // profiles/r04zb_enc_ab_min_match_6_7_8.txt): random-walk data another - 11 %, bench19 - 2 % at ratio 47.8; 8 would cost 13 % of bench19's ratio.  LZ4 only: BloscLZ stores a stream raw below its ratio floor (blosclz.c:426-435), which low-entropy noise then misses.
   // (Zstd sequences are cheaper than LZ4's - a repeated distance costs 5 bits - so short matches pay off there.)
   static_assert(EF_ZSTD == 2, "");
   const uint32_t zmin = (uint32_t)__builtin_amdgcn_readfirstlane(BAMD_ZSTD_MINLEN);
-  const uint32_t minlen = FMT == EF_ZSTD ? zmin : (clevel >= 9 ? 4u : (clevel >= 6 ? 5u : 7u));
+  const uint32_t minlen = FMT == EF_ZSTD ? zmin : (clevel >= 9 ? 4u : (clevel >= 6 ? 5u : (FMT == EF_LZ4 ? 7u : 6u)));
 
   if (start == 0u) tab.clear(lane);
 
