@@ -703,7 +703,11 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
 #endif
     }
     // single-block frames through k_zstd_entropy (16 frames per wave) + k_zstd_exec (zstd2_mode above); every other frame
-    // shape is left to k_zstd_streams
+    // shape is left to k_zstd_streams.
+    // (Round 4 sent the batch through in 4 / 8 slices, every slice's entropy -> seq -> exec chain on a stream of its own with the entropy
+    //  kernels in slice order, so that one slice's sequence chains run underneath the other slices' phases: 30.2 -> 28.5 ms on the reference
+    //  frames of config 4, 11.0 -> 13.4 ms on linspace.  The timeline (profiles/r04zp_*): the phases do overlap, but every kernel is slower
+    //  in company - k_zstd_seq is bound by its scattered table reads, not by an idle chip - and 8 streams share 4 hardware queues.  Not kept.)
     const int zstd2 = zstd2_mode();
     const uint32_t* d_taken = nullptr;
     if (L.any_zstd && L.d_zmeta && zstd2) {

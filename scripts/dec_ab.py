@@ -26,7 +26,12 @@ R.blosc_compress_ctx.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_v
 dev = torch.device("cuda:0")
 comp = torch.empty((nchunks, csz + 256), dtype=torch.uint8, device=dev)
 back = torch.empty((nchunks, csz), dtype=torch.uint8, device=dev)
-names = ["k_decode_plan", "k_decode_streams", "k_unshuffle", "k_bitunshuffle", "k_zstd_entropy", "k_zstd_exec", "k_zstd_streams", "k_zlib_streams"]
+names = ["k_decode_plan", "k_decode_streams", "k_unshuffle", "k_bitunshuffle", "k_zstd_streams", "k_zlib_streams"]
+zparts = ["k_zstd_entropy", "k_zstd_seq", "k_zstd_exec"]      # (the experimental builds with the sliced Zstd pipeline of round 4 bracketed them as k_zstd_pipeline: fork ... join)
+def decode_ms(m, calls):
+    t = sum(m.profile_get(n)[0] / calls for n in names if m.profile_get(n)[1])
+    if m.profile_get("k_zstd_pipeline")[1]: return t + m.profile_get("k_zstd_pipeline")[0] / calls
+    return t + sum(m.profile_get(n)[0] / calls for n in zparts if m.profile_get(n)[1])
 for spec in os.environ.get("DECSETS", "bench19:1:8").split():
     dname, sh, ts = spec.split(":"); sh, ts = int(sh), int(ts)
     host = DATASETS[dname](csz)
@@ -50,5 +55,5 @@ for spec in os.environ.get("DECSETS", "bench19:1:8").split():
             L.blosc_gpu_profile(1); L.blosc_gpu_profile_reset()
             for _ in range(3): b.decompress()
             L.blosc_gpu_profile(0)
-            res[k].append(sum(m.profile_get(n)[0] / 3 for n in names if m.profile_get(n)[1]))
+            res[k].append(decode_ms(m, 3))
     print(f"{dname} shuffle={sh} T={ts} ratio={csz / r:.1f}: " + "   ".join(f"{os.path.basename(p)} {np.median(v):.3f} ms (min {min(v):.3f})" for p, v in zip(libs, res)), flush=True)
