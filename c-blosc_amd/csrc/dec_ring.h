@@ -568,6 +568,8 @@ __device__ int lz4_decode_wave(const gu8* __restrict__ in_, int32_t n_, gu8* out
   io.b_hi = 0u; io.pend = 0u; io.pv = 0u; io.flushed = 0u; io.rfloor = 0u; io.lane = lane;
   uint32_t ip = 0, op = 0;
   for (;;) {
+    // (the rows of the last step could also leave behind dr_input's wait for its prefetched block - vmcnt counts loads and stores in one
+    //  order, so that wait sits out the youngest store's round trip: no difference, profiles/r04zq_*)
     dr_input(io, ip);
     uint32_t hdr;
     if (ip + 72u <= n) {
