@@ -291,6 +291,27 @@ __device__ __forceinline__ void dr_ext_run(RingIO& io, uint32_t& ip, uint32_t& v
     }
     value += 255u * 64u; ip += 64u;
     if (value > cap) return;                       // the caller rejects; keeps the loop bounded by cap
+    // 64 bytes of 0xFF: a long run (the one match of a constant or periodic plane is 130 KB = 513 such bytes).  The rest of it straight from
+    // the stream, a dword per lane = 256 bytes per memory round trip instead of 64 per trip through the input ring (reference-written config-2 chunks - 1.5 %,
+    // profiles/r04zs_*).  A dword that reaches beyond the stream reads as a terminator at its first byte: ip then ends within four
+    // bytes of the end, which every caller rejects (lz4.c:2240-2250, :2330-2342), as it would a run of real 0xFF bytes into the end.
+    for (;;) {
+      const uint32_t p = ip + 4u * (uint32_t)lane;
+      uint32_t w = 0u;
+      if (p + 4u <= io.n) w = g_ld4(io.in + p);
+      const uint64_t m2 = __ballot(w != 0xffffffffu);
+      if (m2) {
+        const uint32_t k = (uint32_t)__builtin_ctzll(m2);
+        const uint32_t wk = (uint32_t)__builtin_amdgcn_readlane((int)w, (int)k);
+        const uint32_t b = (uint32_t)__builtin_ctz(~wk) >> 3;                  // first byte of that dword that is not 0xFF
+        const uint32_t nff = 4u * k + b;
+        value += 255u * nff + ((wk >> (8u * b)) & 0xffu);
+        ip += nff + 1u;
+        return;
+      }
+      value += 255u * 256u; ip += 256u;
+      if (value > cap) return;
+    }
   }
 }
 
@@ -593,8 +614,10 @@ __device__ int lz4_decode_wave(const gu8* __restrict__ in_, int32_t n_, gu8* out
       dr_literals(io, ip, op, ll, lane);
       break;
     }
-    dr_literals(io, ip, op, ll, lane);
-    dr_input(io, ip);
+    if (ll) {                                            // (a match right behind a match: nothing to copy, and ip has not moved since the last dr_input)
+      dr_literals(io, ip, op, ll, lane);
+      dr_input(io, ip);
+    }
     const uint32_t t2 = dr_peek32(io, ip);
     const uint32_t off = t2 & 0xffffu;
     ip += 2;
