@@ -197,6 +197,8 @@ __device__ __forceinline__ void dr_match(RingIO& io, uint32_t& op, uint32_t off,
   // periods lie back to back), then every lane reads its 16 bytes of any later position straight out of those periods
   // (plane[q] = plane[b + ((q - b) & (per - 1))]: unaligned 16-byte LDS reads), the piece up to the next row boundary and the one behind
   // the last are one read + one write each, and the rows in between are the SAME registers stored to the ring and to global memory.
+  // (Every ring write counted from the match's own start instead - one register set for all of them, no piece up to the row boundary - is
+  //  9 % slower: 16-byte LDS writes that are not 16-byte aligned.  profiles/r04zt_*)
   if ((off & (off - 1u)) == 0u && off <= DR_ROW && len >= 2u * DR_ROW && mpos - off >= dr_near_lo(io, mpos + off)) {
     if (off >= 64u) { dr_copy_chunk(io, mpos, mpos - off, off, false, lane); done = off; op = mpos + done; dr_flush_rows(io, op); }
     const uint32_t per = off < 64u ? 32u : off, pm = per - 1u, b0 = mpos - off, l16 = 16u * (uint32_t)lane;     // (off < 64: the head above wrote 64 bytes, off divides 32)
