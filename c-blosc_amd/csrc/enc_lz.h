@@ -19,7 +19,7 @@ typedef uint32_t enc_entry_t;
 #endif
 constexpr int ENC_TAB_BYTES = BAMD_ENC_SPLIT_TAB ? ENC_TAB * 3 : ENC_TAB * 4;
 #ifndef BAMD_ENC_MINWAVES
-#define BAMD_ENC_MINWAVES (BAMD_ENC_SPLIT_TAB ? 6 : 5)   // waves per SIMD the register allocator leaves room for
+#define BAMD_ENC_MINWAVES (BAMD_ENC_SPLIT_TAB ? 6 : 5)   // waves per SIMD the register allocator leaves room for (5: + 3 %, 7 = 26 waves per CU at 72 registers: + 1.8 %, profiles/r04zu_*)
 #endif
 constexpr int ENC_LDS_WAVES = (160 * 1024) / ENC_TAB_BYTES;
 constexpr int ENC_WAVES_PER_CU = ENC_LDS_WAVES < 4 * BAMD_ENC_MINWAVES ? ENC_LDS_WAVES : 4 * BAMD_ENC_MINWAVES;   // persistent grid size per CU
