@@ -6,7 +6,7 @@ match start.  The oracle decodes the same chunk; results must be bit-exact."""
 import numpy as np
 import pytest
 
-from helpers import ptr, wrap_planes_as_chunk
+from helpers import orc_decompress, ptr, wrap_planes_as_chunk
 from test_gpu_decompress import _lz4_seq, _lz4_tail
 
 pytestmark = pytest.mark.gpu
@@ -81,3 +81,23 @@ def test_span_typesize4(pkg, oracle):
     streams = [_plane_stream(rng, 1, 0, NEB - 100, []), _plane_stream(rng, 512, 9, 90000, [(3, 60000, 33)]),
                _plane_stream(rng, 5, 0, 20000, []), _plane_stream(rng, 4, 0, 131000, [])]
     assert _check(pkg, oracle, streams)
+
+
+def test_self_span_base_beyond_24_bits_is_not_taken(pkg, oracle):
+    """A periodic match with a period above the 2 KiB pattern table becomes a "self span" whose base travels in 24 bits next to log2(period)
+    (k_decode.hip: unshuffle_block_wave_T).  A plane of 16 MiB or more can start such a match beyond that range - the reference never
+    writes one (a split block is at most 1 MiB, blosc.c:1020-1040), a foreign writer may: a hand-built chunk of ONE 64 MiB block split into two
+    32 MiB planes, the period-8192 match starting at plane position 16 MiB + 13 192.  It must go through the ring like any other match
+    (dec_ring.h: dr_span_long_match refuses it); the oracle's reader says what the bytes are."""
+    neb = 32 << 20
+    rng = np.random.default_rng(24)
+    head = (1 << 24) + 5000 + 8192
+    lit = rng.integers(0, 256, head, dtype=np.uint8)
+    s0 = _lz4_seq(lit.tobytes(), 8192, neb - head - 12) + _lz4_tail(rng.integers(0, 256, 12, dtype=np.uint8).tobytes())
+    s1 = _lz4_seq(b"\x07", 1, neb - 1 - 12) + _lz4_tail(bytes(12))
+    chunk = wrap_planes_as_chunk([s0, s1], neb, 1)
+    n = 2 * neb
+    ro, want = orc_decompress(oracle, chunk, n)
+    assert ro == n
+    got_r, got = pkg.decompress(chunk, n)
+    assert got_r == n and np.array_equal(got, want)
