@@ -402,21 +402,45 @@ __device__ __forceinline__ void dr_span_materialize(RingIO& io, SpanCtx& sp, int
 // offset validity are checked per sequence; a sequence that breaks one is simply not accepted, so the one-sequence path re-parses it
 // and reports the error.
 // ---------------------------------------------------------------------------------------------
+template <int G>      // G = 0: LZ4's grammar; G = 1: BloscLZ's (blosclz.c:679-789), `ip` then is the position of the current control byte
 __device__ __forceinline__ uint32_t dr_step(RingIO& io, uint32_t& ip, uint32_t& op, uint32_t cap, uint32_t n, uint32_t& hdr, SpanCtx& sp, int lane PROF_ARG) {
   // ---- 1. speculative parse ----
   const uint32_t D = dr_in4(io, ip + (uint32_t)lane);
-  const uint32_t B = D & 0xffu, e_ll = (D >> 8) & 0xffu;
-  const uint32_t ll0 = B >> 4, mlc = B & 15u;
-  const bool ll_ext = ll0 == 15u;
-  const uint32_t ll = ll_ext ? 15u + e_ll : ll0;
-  const uint32_t offpos = (uint32_t)lane + 1u + (ll_ext ? 1u : 0u) + ll;   // where this token's offset would start
-  const uint32_t O = dr_in4(io, ip + (offpos < 64u ? offpos : 64u));
-  const uint32_t off = O & 0xffffu, e1 = (O >> 16) & 0xffu;
-  const bool has_ext = mlc == 15u;
-  const uint32_t ml = has_ext ? 19u + e1 : mlc + 4u;           // <= 273
-  const uint32_t size = 3u + ll + (has_ext ? 1u : 0u) + (ll_ext ? 1u : 0u);   // token (+ ext) + literals + offset (+ ext)
-  // lz4.c:2240-2250: the length extension may not be read at or behind n - 15
-  const bool complete = !(ll_ext && (e_ll == 255u || ip + (uint32_t)lane + 16u >= n)) && !(has_ext && e1 == 255u) && (uint32_t)lane + size <= 64u;
+  const uint32_t B = D & 0xffu;
+  uint32_t ll, ml, off, size;
+  bool complete, ll_ext = false;
+  if (G == 0) {
+    const uint32_t e_ll = (D >> 8) & 0xffu;
+    const uint32_t ll0 = B >> 4, mlc = B & 15u;
+    ll_ext = ll0 == 15u;
+    ll = ll_ext ? 15u + e_ll : ll0;
+    const uint32_t offpos = (uint32_t)lane + 1u + (ll_ext ? 1u : 0u) + ll;   // where this token's offset would start
+    const uint32_t O = dr_in4(io, ip + (offpos < 64u ? offpos : 64u));
+    off = O & 0xffffu;
+    const uint32_t e1 = (O >> 16) & 0xffu;
+    const bool has_ext = mlc == 15u;
+    ml = has_ext ? 19u + e1 : mlc + 4u;           // <= 273
+    size = 3u + ll + (has_ext ? 1u : 0u) + (ll_ext ? 1u : 0u);   // token (+ ext) + literals + offset (+ ext)
+    // lz4.c:2240-2250: the length extension may not be read at or behind n - 15
+    complete = !(ll_ext && (e_ll == 255u || ip + (uint32_t)lane + 16u >= n)) && !(has_ext && e1 == 255u) && (uint32_t)lane + size <= 64u;
+  } else {
+    // a control byte < 32 starts a literal run of ctrl + 1 bytes; otherwise a match: len = (ctrl >> 5) - 1 (+ one extension byte when that field
+    // is 7; longer extensions are the one-token path's) + 3, distance - 1 = ((ctrl & 31) << 8) + next byte, or a 16-bit big-endian value + 8191
+    // behind the escape 31 / 255.  Only called with ip + 72 <= n: every token taken here is followed by more input, so the reference's
+    // end-of-input quirks cannot apply.
+    const uint32_t b1 = (D >> 8) & 0xffu, b2 = (D >> 16) & 0xffu, b3 = D >> 24, b4 = dr_in4(io, ip + (uint32_t)lane + 4u) & 0xffu;
+    const bool is_lit = B < 32u;
+    const uint32_t l3 = B >> 5;
+    const bool has_ext = l3 == 7u;
+    const uint32_t code = has_ext ? b2 : b1;
+    const bool far = !is_lit && code == 255u && (B & 31u) == 31u;
+    const uint32_t f0 = has_ext ? b3 : b2, f1 = has_ext ? b4 : b3;
+    ll = is_lit ? B + 1u : 0u;                                                          // 1 .. 32
+    ml = is_lit ? 0u : l3 + 2u + (has_ext ? b1 : 0u);                                   // 3 .. 263
+    off = far ? ((f0 << 8) | f1) + 8192u : ((B & 31u) << 8) + code + 1u;                // the true distance
+    size = is_lit ? B + 2u : 2u + (has_ext ? 1u : 0u) + (far ? 2u : 0u);
+    complete = (is_lit || !(has_ext && b1 == 255u)) && (uint32_t)lane + size <= 64u;
+  }
   hdr = (uint32_t)__builtin_amdgcn_readlane((int)D, 0);
   if (!(__ballot(complete) & 1ull)) return 0u;                 // the token at ip itself: left to the one-sequence path
   const uint32_t nxt = complete ? (uint32_t)lane + size : 64u; // position of the following token, 64 = stop here
@@ -448,7 +472,8 @@ __device__ __forceinline__ uint32_t dr_step(RingIO& io, uint32_t& ip, uint32_t& 
   const uint32_t mrel_r = excl + ll_r;                         // its match start, relative to op
   // acceptance: offset inside the produced data (lz4.c:2356, and offset 0), far enough from the output end that neither lz4.c:2279
   // nor :2423 can apply, and the step within DR_STEP_MAX bytes
-  const bool ok = valid && off_r != 0u && off_r <= op + mrel_r && op + excl + tot_r + 12u <= cap && incl <= DR_STEP_MAX;
+  const bool ok = G == 0 ? (valid && off_r != 0u && off_r <= op + mrel_r && op + excl + tot_r + 12u <= cap && incl <= DR_STEP_MAX)
+                         : (valid && (ml_r == 0u || off_r <= op + mrel_r) && op + excl + tot_r <= cap && incl <= DR_STEP_MAX);      // blosclz.c:730-735
   const uint32_t okmask = (uint32_t)__ballot(ok) & 0xffffu;
   const uint32_t cnt = (uint32_t)__builtin_ctz(~okmask);       // leading accepted sequences (<= 16)
   PROF_LAP(9);
@@ -456,7 +481,7 @@ __device__ __forceinline__ uint32_t dr_step(RingIO& io, uint32_t& ip, uint32_t& 
   const bool mine = (uint32_t)lane < cnt;
   const uint32_t src_r = op + mrel_r - off_r;                  // source position (accepted lanes only)
   // a source inside a skipped periodic span: the span is written after all (rare)
-  if (sp.hi && __ballot(mine && src_r < sp.hi)) dr_span_materialize(io, sp, lane);
+  if (sp.hi && __ballot(mine && (G == 0 || ml_r != 0u) && src_r < sp.hi)) dr_span_materialize(io, sp, lane);
   const uint32_t consumed = (uint32_t)__builtin_amdgcn_readlane((int)nxt_r, (int)(cnt - 1u));
   const uint32_t acc = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(cnt - 1u));
   const uint32_t W = op + acc, nlo = dr_near_lo(io, W);
@@ -481,7 +506,7 @@ __device__ __forceinline__ uint32_t dr_step(RingIO& io, uint32_t& ip, uint32_t& 
   // a source is taken from the ring (wholly at or above nlo) or from the rows already written (wholly below nlo: nlo <= flushed, by the
   // static_assert above and because a span's floor is a flushed position); one that straddles nlo goes byte by byte in step 5
   const bool far_r = src_r + ml_r <= nlo;
-  const bool fast_r = mine && ml_r <= 64u && off_r >= mrel_r + ml_r && (dpos_r & DR_MASK) + ml_r <= DR_RING && (far_r || (src_r >= nlo && (src_r & DR_MASK) + ml_r <= DR_RING));
+  const bool fast_r = mine && (G == 0 || ml_r >= 4u) && ml_r <= 64u && off_r >= mrel_r + ml_r && (dpos_r & DR_MASK) + ml_r <= DR_RING && (far_r || (src_r >= nlo && (src_r & DR_MASK) + ml_r <= DR_RING));
   const bool anyfar = __ballot(fast_r && far_r) != 0ull;
   {
     const uint32_t r = (uint32_t)lane >> 2, q = (uint32_t)lane & 3u;
@@ -525,7 +550,7 @@ __device__ __forceinline__ uint32_t dr_step(RingIO& io, uint32_t& ip, uint32_t& 
   PROF_LAP(10);
   // ---- 5. everything else in stream order: byte lanes, the periodic extension of the off bytes in front of the match when it
   //         overlaps itself (every lane then reads only bytes that are already final) ----
-  uint32_t rest = (uint32_t)__ballot(mine && !fast_r);
+  uint32_t rest = (uint32_t)__ballot(mine && !fast_r && (G == 0 || ml_r != 0u));      // (BloscLZ: literal runs are tokens of their own, and matches of 3 bytes go here)
   PROF_ADD(0, 1); PROF_ADD(1, cnt); PROF_ADD(2, __builtin_popcount(rest));
   while (rest) {
     const int sl = __builtin_ctz(rest);
@@ -596,7 +621,7 @@ __device__ int lz4_decode_wave(const gu8* __restrict__ in_, int32_t n_, gu8* out
     dr_input(io, ip);
     uint32_t hdr;
     if (ip + 72u <= n) {
-      if (dr_step(io, ip, op, cap, n, hdr, sp, lane PROF_PASS)) { dr_flush_rows(io, op); PROF_LAP(13); continue; }
+      if (dr_step<0>(io, ip, op, cap, n, hdr, sp, lane PROF_PASS)) { dr_flush_rows(io, op); PROF_LAP(13); continue; }
     } else hdr = dr_peek32(io, ip);
     // ---- one sequence (long runs, long matches, the stream's tail, everything the step refused) ----
     PROF_ADD(3, 1);
@@ -662,6 +687,74 @@ __device__ int lz4_decode_wave(const gu8* __restrict__ in_, int32_t n_, gu8* out
   }
   dr_flush_tail(io, op);
   PROF_LAP(12);
+  return (int)op;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BloscLZ block decode on the same ring, one wave (round 4; until then this decoder wrote straight to global memory and read its
+// history back from there).  Returns the bytes produced (the caller compares with the expected size), 0 on the errors the reference
+// returns 0 for.  Grammar and rules: blosclz.c:679-789 - the first byte is always a literal-run control (its upper three bits are the
+// format marker, :688), a length field of 7 is extended by a 255-run, the distance escape 31 / 255 is followed by a 16-bit big-endian
+// distance - 8191, `distance > produced` and `produced + len > room` return 0, and a match whose token ends exactly at the input end
+// is dropped (:700-736: the loop stops before the copy).
+// ---------------------------------------------------------------------------------------------
+__device__ int blosclz_decode_wave(const gu8* __restrict__ in_, int32_t n_, gu8* out_, int32_t cap_, volatile uint32_t* lds, int lane, SpanCtx& sp) {
+  if (n_ <= 0) return 0;
+  const uint32_t n = uni((uint32_t)n_), cap = uni((uint32_t)cap_);
+  RingIO io;
+  io.scr = (volatile BAMD_LAS uint32_t*)lds;
+  io.in32 = (BAMD_LAS uint32_t*)lds + 64;
+  io.hist = (lu8*)((BAMD_LAS uint32_t*)lds + 64 + DR_IN / 4u);
+  io.in = uni_ptr(in_); io.n = n; io.out = uni_ptr(out_); io.cap = cap;
+  io.b_hi = 0u; io.pend = 0u; io.pv = 0u; io.flushed = 0u; io.rfloor = 0u; io.lane = lane;
+  uint32_t tp = 0, op = 0;                      // tp: position of the current control byte
+  for (;;) {
+    dr_input(io, tp);
+    uint32_t hdr = dr_peek32(io, tp);
+    // batched step from the current control byte; not for the stream's first byte (its marker bits are not a length)
+    if (tp > 0u && tp + 72u <= n && !((hdr & 0xffu) >= 224u && ((hdr >> 8) & 0xffu) == 255u)) {      // (longer length extensions: below)
+      if (dr_step<1>(io, tp, op, cap, n, hdr, sp, lane)) { dr_flush_rows(io, op); continue; }
+    }
+    // ---- one token ----
+    uint32_t ctrl = hdr & 0xffu;
+    if (tp == 0u) ctrl &= 31u;
+    uint32_t ip = tp + 1u;
+    if (ctrl >= 32u) {
+      uint32_t len = (ctrl >> 5) - 1u;
+      const uint32_t ofs = (ctrl & 31u) << 8;
+      if (len == 6u) {
+        // blosclz.c:712-720: every extension byte must have a byte behind it (ip + 1 < n), the sum may not pass the room; both bounds are
+        // monotonic in ip, so they are checked once behind the run (bytes beyond the stream read as zero, i.e. end the run)
+        dr_ext_run(io, ip, len, cap, lane);
+        if (ip >= n || len > cap) return 0;
+        dr_input(io, ip);
+      } else if (ip + 1u >= n) return 0;
+      const uint32_t t = dr_peek32(io, ip);
+      const uint32_t code = t & 0xffu;
+      ip++;
+      len += 3u;
+      uint32_t dist = ofs + code;               // distance - 1
+      if (code == 255u && ofs == (31u << 8)) {
+        if (ip + 1u >= n) return 0;
+        dist = ((((t >> 8) & 0xffu) << 8) | ((t >> 16) & 0xffu)) + 8191u;
+        ip += 2u;
+      }
+      if (op + len > cap) return 0;
+      if (dist + 1u > op) return 0;             // reference: ref - 1 < output
+      if (ip >= n) break;                       // quirk: the pending match is dropped
+      tp = ip;
+      if (sp.hi && op - (dist + 1u) < sp.hi) dr_span_materialize(io, sp, lane);
+      if (!dr_span_long_match(io, op, dist + 1u, len, lane, sp)) dr_match(io, op, dist + 1u, len, lane);
+    } else {
+      const uint32_t run = ctrl + 1u;           // 1 .. 32 literal bytes
+      if (op + run > cap) return 0;
+      if (ip + run > n) return 0;
+      dr_literals(io, ip, op, run, lane);       // (dr_input(tp) covers ip + 64 + 4)
+      if (ip >= n) break;
+      tp = ip;
+    }
+  }
+  dr_flush_tail(io, op);
   return (int)op;
 }
 

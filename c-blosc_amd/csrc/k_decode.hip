@@ -118,237 +118,18 @@ constexpr uint32_t SPAN_PAT = 2048u;
 __device__ __attribute__((noinline)) void span_fill_call(gu8* out_, uint32_t lo_, uint32_t off_, uint32_t n_, int lane) {
   wave_match_copy(uni_ptr(out_), uni(lo_), uni(off_), uni(n_), lane);      // out[lo - off, lo) was written by the head copy
 }
-__device__ __forceinline__ void span_materialize(gu8* out, int lane, SpanCtx& sp) {
-  if (sp.hi) span_fill_call(out, sp.lo, sp.off, sp.hi - sp.lo, lane);
-  sp.lo = 0; sp.hi = 0; sp.enabled = 0;
-}
-// returns true when the match was handled here (head, pattern table and tail written, middle skipped)
-//
-// Round 3: periods ABOVE the pattern table's 2 KiB (any power of two up to 64 KiB).  Byte planes of slowly varying data repeat
-// with the period of the generator (bench19's second byte: 32 KiB; a third of the plane is content, the rest ONE match - which
-// round 2 wrote to the scratch, 95 KiB, only to read it back twice).  Such a span needs no table: the plane itself holds the
-// period, in the `off` bytes in front of the skipped range.  With ob = the 4-aligned position at or behind mpos - off,
-//     plane[q] = plane[ob + ((q - ob) & (off - 1))]     for q in [lo, hi)
-// (every step back by `off` stays inside the match), and a dword at a 4-aligned q never straddles the wrap.
-// The unshuffle computes that address per lane (SPAN_SELF); ob and off travel in the first 8 bytes of the stream's table slot.
-__device__ __attribute__((noinline)) void span_long_match_call(gu8* out_, uint32_t mpos_, uint32_t off_, uint32_t ml_, int lane, gu8* pat_) {
-  gu8* out = uni_ptr(out_);
-  const uint32_t mpos = uni(mpos_), off = uni(off_), ml = uni(ml_);
-  struct { gu8* pat; uint32_t lo, hi, off; } sp;         // (locals with the old names)
-  sp.pat = uni_ptr(pat_);
-  const uint32_t lo = (mpos + 1023u) & ~1023u, hi = (mpos + ml) & ~1023u;
-  if (lo > mpos) wave_match_copy(out, mpos, off, lo - mpos, lane);
-  BAMD_MEM_SYNC();
-  if (off > SPAN_PAT) {
-    const uint32_t ob = (mpos - off + 3u) & ~3u, om = off - 1u;
-    if (lane == 0) { g_st4(sp.pat, ob); g_st4(sp.pat + 4, off); }
-    // behind the span: < 1 KiB, byte by byte through the same mapping (the sources lie in front of lo: written, not overwritten here)
-    const uint32_t tail = mpos + ml - hi;
-    for (uint32_t i = (uint32_t)lane; i < tail; i += 64u) out[hi + i] = out[ob + ((hi + i - ob) & om)];     // (once per plane: no need to batch the loads)
-    return;
-  }
-  const uint32_t base = mpos - off, pm = off - 1u;         // plane[q] = out[base + ((q - base) & pm)] for q >= base
-  uint32_t v[8];
-#pragma unroll
-  for (int k = 0; k < 8; k++) {                            // lane writes dwords lane, lane + 64, ...: all 32 byte loads first
-    const uint32_t i = 4u * ((uint32_t)lane + 64u * (uint32_t)k);
-    const uint32_t b0 = out[base + ((i - base) & pm)], b1 = out[base + ((i + 1u - base) & pm)];
-    const uint32_t b2 = out[base + ((i + 2u - base) & pm)], b3 = out[base + ((i + 3u - base) & pm)];
-    v[k] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
-  }
-#pragma unroll
-  for (int k = 0; k < 8; k++) g_st4(sp.pat + 4u * ((uint32_t)lane + 64u * (uint32_t)k), v[k]);
-  BAMD_MEM_SYNC();
-  // behind the span: < 1 KiB, contiguous in the table just written (hi is a multiple of 1024, so no wrap)
-  wave_copy_disjoint(out + hi, sp.pat + (hi & (SPAN_PAT - 1u)), mpos + ml - hi, lane);
-}
-__device__ __forceinline__ bool span_long_match(gu8* out, uint32_t mpos, uint32_t off, uint32_t ml, int lane, SpanCtx& sp) {
-  if (!sp.enabled || sp.hi || ml < 16384u || off > 65536u || (off & (off - 1u))) return false;
-  const uint32_t lo = (mpos + 1023u) & ~1023u, hi = (mpos + ml) & ~1023u;
-  if (hi < lo + 8192u) return false;
-  // a self span's base travels in 24 bits next to log2(period) (unshuffle_block_wave_T: `ob`): planes of 16 MiB and more (typesize 2 with
-  // blocks >= 32 MiB) keep such a match in the scratch instead (the base was truncated, silently wrong bytes)
-  if (off > SPAN_PAT && mpos >= (1u << 24)) return false;
-  span_long_match_call(out, mpos, off, ml, lane, sp.pat);
-  sp.lo = lo; sp.hi = hi; sp.off = off;
-  return true;
-}
+// Periods ABOVE the pattern table's 2 KiB (any power of two up to 64 KiB; round 3).  Byte planes of slowly varying data repeat with the
+// period of the generator (bench19's second byte: 32 KiB; a third of the plane is content, the rest ONE match).  Such a span needs no
+// table: the plane itself holds the period, in the `off` bytes in front of the skipped range.  With ob = the 4-aligned position at or behind
+// mpos - off,   plane[q] = plane[ob + ((q - ob) & (off - 1))]   for q in [lo, hi)   (every step back by `off` stays inside the match), and a
+// dword at a 4-aligned q never straddles the wrap.  The unshuffle computes that address per lane (SPAN_SELF); ob and off travel in the first
+// 8 bytes of the stream's table slot.  Both decoders take their spans through dec_ring.h: dr_span_long_match / dr_span_call.
 
 }  // namespace bamd
 #include "dec_ring.h"
 namespace bamd {
 
-// ---------------------------------------------------------------------------------------------
-// BloscLZ decode, one wave (blosclz.c:679-789).  Returns bytes produced; 0 on any violation,
-// like the reference.  Kept quirks: the first control byte is masked with 31; a match is executed
-// only if at least one more input byte follows it (otherwise decoding stops BEFORE the copy).
-// ---------------------------------------------------------------------------------------------
-// Batched BloscLZ step: the LZ4 step's machinery (speculative per-lane parse, pointer doubling in rank
-// space, one scattered literal store, 4-lane match pieces) over BloscLZ's token grammar
-// (blosclz.c:679-789): a control byte < 32 starts a literal run of ctrl+1 bytes; otherwise it is a match
-// with len = (ctrl>>5)-1 (+ one extension byte when that field is 7; longer extensions go to the scalar
-// path) + 3, distance-1 = ((ctrl&31)<<8) + next byte, or a 16-bit big-endian value + 8191 behind the
-// escape 31/255.  `tp` is the position of the current control byte; only called when tp + 72 <= n, so
-// every token taken here is followed by more input (the reference's end-of-input quirks cannot apply).
-__device__ __forceinline__ uint32_t blz_batch_step(const Window& w, gu8* out, volatile uint32_t* scr_generic, uint32_t& tp, uint32_t& op,
-                                                   uint32_t cap, int lane, SpanCtx& sp) {
-  volatile __attribute__((address_space(3))) uint32_t* scr = (volatile __attribute__((address_space(3))) uint32_t*)scr_generic;   // LDS
-  const uint32_t B = w.gather_bytes(tp);                       // stream byte tp + lane
-  const uint32_t b1 = bperm(((uint32_t)lane + 1u) & 63u, B), b2 = bperm(((uint32_t)lane + 2u) & 63u, B);
-  const uint32_t b3 = bperm(((uint32_t)lane + 3u) & 63u, B), b4 = bperm(((uint32_t)lane + 4u) & 63u, B);
-  const bool is_lit = B < 32u;
-  const uint32_t l3 = B >> 5;
-  const bool has_ext = l3 == 7u;
-  const uint32_t code = has_ext ? b2 : b1;
-  const bool far = !is_lit && code == 255u && (B & 31u) == 31u;
-  const uint32_t f0 = has_ext ? b3 : b2, f1 = has_ext ? b4 : b3;
-  const uint32_t ll = is_lit ? B + 1u : 0u;                                       // 1..32
-  const uint32_t ml = is_lit ? 0u : l3 + 2u + (has_ext ? b1 : 0u);                 // 3..263
-  const uint32_t off = far ? ((f0 << 8) | f1) + 8192u : ((B & 31u) << 8) + code + 1u;   // true distance
-  const uint32_t size = is_lit ? B + 2u : 2u + (has_ext ? 1u : 0u) + (far ? 2u : 0u);
-  const bool complete = (is_lit || !(has_ext && b1 == 255u)) && (uint32_t)lane + size <= 64u;
-  const uint32_t nxt = complete ? (uint32_t)lane + size : 64u;
-  // ---- token chain in rank space (see lz4_batch_step) ----
-  const uint32_t J0 = nxt;
-  const uint32_t J1 = hop(J0, J0), J2 = hop(J1, J1), J3 = hop(J2, J2);
-  uint32_t c = 0;
-  { const uint32_t t = hop(J0, c); c = (lane & 1) ? t : c; }
-  { const uint32_t t = hop(J1, c); c = (lane & 2) ? t : c; }
-  { const uint32_t t = hop(J2, c); c = (lane & 4) ? t : c; }
-  { const uint32_t t = hop(J3, c); c = (lane & 8) ? t : c; }
-  const uint32_t pk = bperm(c & 63u, ll | (ml << 6) | ((complete ? 1u : 0u) << 15) | (nxt << 16));
-  const uint32_t off_r = bperm(c & 63u, off);
-  const uint32_t ll_r = pk & 63u, ml_r = (pk >> 6) & 0x1ffu, nxt_r = pk >> 16;
-  const bool valid = lane < (int)BATCH_MAXSEQ && c < 64u && ((pk >> 15) & 1u);
-  const uint32_t tot_r = valid ? ll_r + ml_r : 0u;
-  uint32_t incl = tot_r;
-  incl += row_shr<1>(incl); incl += row_shr<2>(incl); incl += row_shr<4>(incl); incl += row_shr<8>(incl);
-  const uint32_t excl = incl - tot_r;                          // output offset of token r relative to op
-  // acceptance (blosclz.c:730-735): distance inside the produced data, output within bounds
-  const bool ok = valid && (ml_r == 0u || off_r <= op + excl) && op + excl + tot_r <= cap;
-  const uint32_t okmask = (uint32_t)__ballot(ok) & 0xffffu;
-  const uint32_t cnt = (uint32_t)__builtin_ctz(~okmask);
-  if (cnt == 0u) return 0u;
-  if (sp.hi && __ballot((uint32_t)lane < cnt && ml_r != 0u && op + excl - off_r < sp.hi)) span_materialize(out, lane, sp);
-  const uint32_t consumed = (uint32_t)__builtin_amdgcn_readlane((int)nxt_r, (int)(cnt - 1u));
-  const uint32_t acc = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(cnt - 1u));
-  // (no LDS-assembled form here, unlike lz4_batch_step: the mere presence of that call path cost reference-written byte-shuffled
-  //  BloscLZ chunks - config #1's data - 7 % in register allocation; bit-shuffled BloscLZ streams would gain 27 %, profiles/r02g_lds_step.txt)
-  // ---- literals of every accepted run in one scattered byte store ----
-  scr[lane] = 0u;
-  BAMD_LDS_SYNC();
-  if ((uint32_t)lane < cnt) scr[c] = 0x80000000u | excl | (ll_r << 16);
-  BAMD_LDS_SYNC();
-  const uint64_t mask = __ballot(scr[lane] >> 31);
-  {
-    const uint64_t below = mask & ((2ull << lane) - 1ull);
-    const uint32_t s = 63u - (uint32_t)__builtin_clzll(below | 1ull);
-    const uint32_t inf = scr[s];
-    const uint32_t k = (uint32_t)lane - s - 1u;
-    if ((uint32_t)lane < consumed && (uint32_t)lane > s && k < ((inf >> 16) & 63u)) out[op + (inf & 0xffffu) + k] = (uint8_t)B;
-  }
-  // ---- short independent matches: 4 lanes each, overlapping 4/8/16-byte pieces (len 3 goes to the rest) ----
-  const bool is_match_r = (uint32_t)lane < cnt && ml_r != 0u;
-  const bool fast_r = is_match_r && ml_r >= 4u && ml_r <= 64u && off_r >= excl + ml_r;   // source ends at or before op
-  {
-    const uint32_t r = (uint32_t)lane >> 2, q = (uint32_t)lane & 3u;
-    const uint32_t fA = bperm(r, fast_r ? (ml_r | 0x200u | (excl << 10)) : 0u);
-    const uint32_t fB = bperm(r, off_r);
-    const uint32_t mlen = fA & 0x1ffu;
-    const bool go = (fA & 0x200u) != 0u;
-    gu8* d = out + op + (fA >> 10);
-    const gu8* sp_ = d - fB;
-    const bool w16 = go && mlen >= 16u && q < ((mlen + 15u) >> 4);
-    const bool w8 = go && mlen >= 8u && mlen < 16u && q < 2u;
-    const bool w4 = go && mlen < 8u && q < 2u;
-    const uint32_t np16 = (mlen + 15u) >> 4;
-    const uint32_t po16 = (q == np16 - 1u) ? mlen - 16u : 16u * q;
-    const uint32_t po8 = q ? mlen - 8u : 0u, po4 = q ? mlen - 4u : 0u;
-    uint4 v16 = make_uint4(0, 0, 0, 0); uint64_t v8 = 0; uint32_t v4 = 0;
-    if (w16) v16 = g_ld16(sp_ + po16);
-    if (w8) v8 = g_ld8(sp_ + po8);
-    if (w4) v4 = g_ld4(sp_ + po4);
-    if (w16) g_st16(d + po16, v16);
-    if (w8) *(BAMD_GAS u64una*)(d + po8) = v8;
-    if (w4) g_st4(d + po4, v4);
-  }
-  // ---- everything else in stream order ----
-  uint32_t rest = (uint32_t)__ballot(is_match_r && !fast_r);
-  while (rest) {
-    const int sl = __builtin_ctz(rest);
-    rest &= rest - 1u;
-    const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)ml_r, sl);
-    const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)off_r, sl);
-    const uint32_t mr = (uint32_t)__builtin_amdgcn_readlane((int)excl, sl);
-    wave_match_copy(out, op + mr, o, m, lane);
-  }
-  tp += consumed;
-  op += acc;
-  return cnt;
-}
-
-__device__ int blosclz_decode_wave(const gu8* __restrict__ in, int32_t n_, gu8* out, int32_t cap_, volatile uint32_t* scr, int lane, SpanCtx& sp) {
-  if (n_ <= 0) return 0;
-  const uint32_t n = (uint32_t)n_, cap = (uint32_t)cap_;
-  Window w;
-  w.init(in, n, lane);
-  uint32_t ip = 1, op = 0;
-  uint32_t ctrl = w.peek32(0) & 31u;
-  for (;;) {
-    // batched step from the current control byte (at ip - 1); not for the stream's first byte (masked above)
-    if (ip > 1u && ip + 71u <= n) {
-      uint32_t tp = ip - 1u;
-      w.seek(tp);
-      bool try_batch = true;
-      if (ctrl >= 224u) try_batch = (w.peek32(ip) & 0xffu) != 255u;     // longer length extensions: scalar path
-      if (try_batch && blz_batch_step(w, out, scr, tp, op, cap, lane, sp)) {
-        ctrl = w.byte_at(tp); ip = tp + 1u;
-        continue;
-      }
-    }
-    if (ctrl >= 32u) {
-      uint32_t len = (ctrl >> 5) - 1u;
-      uint32_t ofs = (ctrl & 31u) << 8;
-      uint32_t code;
-      if (len == 6u) {
-        do {
-          if (ip + 1u >= n) return 0;
-          code = w.byte_at(ip); ip++;
-          len += code;
-          if (len > cap) return 0;
-        } while (code == 255u);
-      } else if (ip + 1u >= n) return 0;
-      code = w.byte_at(ip); ip++;
-      len += 3u;
-      uint32_t dist = ofs + code;             // distance - 1
-      if (code == 255u && ofs == (31u << 8)) {
-        if (ip + 1u >= n) return 0;
-        w.seek(ip);
-        uint32_t t = w.peek32(ip);
-        dist = (((t & 0xffu) << 8) | ((t >> 8) & 0xffu)) + 8191u;
-        ip += 2;
-      }
-      if (op + len > cap) return 0;
-      if (dist + 1u > op) return 0;           // reference: ref - 1 < output
-      if (ip >= n) break;                     // quirk: the pending match is dropped
-      ctrl = w.byte_at(ip); ip++;
-      if (sp.hi && op - (dist + 1u) < sp.hi) span_materialize(out, lane, sp);
-      if (!span_long_match(out, op, dist + 1u, len, lane, sp)) wave_match_copy(out, op, dist + 1u, len, lane);
-      op += len;
-    } else {
-      const uint32_t run = ctrl + 1u;         // 1..32 literal bytes
-      if (op + run > cap) return 0;
-      if (ip + run > n) return 0;
-      w.seek(ip);
-      uint32_t v = w.gather_bytes(ip);        // run <= 32 and seek => inside the window
-      if ((uint32_t)lane < run) out[op + lane] = (uint8_t)v;
-      op += run; ip += run;
-      if (ip >= n) break;
-      ctrl = w.byte_at(ip); ip++;
-    }
-  }
-  return (int)op;
-}
+// (Both stream decoders - lz4_decode_wave and blosclz_decode_wave - live in dec_ring.h, on the LDS ring.)
 
 // ---------------------------------------------------------------------------------------------
 // decode kernel: persistent waves + ticket queue, block = 64 * DEC_WAVES
