@@ -675,7 +675,7 @@ def main():
     mixed = None
     if args.config == "2" and not overridden and not args.no_extra and world == 1:
         extra = {}
-        for name in ("3", "4", "2t", "2x"):       # 2t / 2x: config 2 at typesize 2 and 16 (the reference's bench takes the typesize as an argument over the same data, bench/bench.c:250-320)
+        for name in ("3", "4", "1g", "2t", "2x"):       # 1g: config #1's call (BloscLZ) on the GPU; 2t / 2x: config 2 at typesize 2 and 16 (the reference's bench takes the typesize as an argument over the same data, bench/bench.c:250-320)
             r = measure(rig, name, dict(CONFIGS[name]), min(args.steps, 5), 1, args)
             r.pop("_host_chunk")
             keep = ("value", "unit", "steps", "ms_per_step", "first_call_ms", "sched_cold", "ratio", "roofline", "kernels", "decompress_stock_chunks", "verified", "compress", "decompress")
