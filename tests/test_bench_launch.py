@@ -20,7 +20,7 @@ def _run(args, env=None):
     return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=300, env=e)
 
 
-@pytest.mark.parametrize("n", [1, 2, 3])
+@pytest.mark.parametrize("n", [1, 2, 3, 8])       # 8: the node size the scaling run uses
 def test_dry_gloo_spawns_n_ranks(n):
     r = _run(["--gpus", str(n), "--dry-gloo", "--chunks", "5"])
     assert r.returncode == 0, r.stderr[-2000:]
