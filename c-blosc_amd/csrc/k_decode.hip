@@ -62,7 +62,7 @@ __global__ void k_decode_plan(const ChunkDesc* __restrict__ chunks, const BlockD
   if (bad) atomicMin(&status[b.chunk], (int32_t)ST_BADCHAIN);
 }
 
-// most sequences one batched step takes (dec_ring.h: dr_step; blz_batch_step below)
+// most sequences one batched step takes (dec_ring.h: dr_step, both grammars)
 constexpr uint32_t BATCH_MAXSEQ = 16;      // (32 - a fifth doubling round, the second DPP row, two passes of 4-lane pieces: half of bench19's steps hold more than 16 sequences, yet + 1 %: profiles/r04zw_*)
 
 // Optional phase profiling (build with -DBAMD_PROFILE_DECODE -> libblosc_amd_prof.so, scripts/dec_phase.py):
