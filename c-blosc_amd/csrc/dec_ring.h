@@ -708,12 +708,13 @@ __device__ int blosclz_decode_wave(const gu8* __restrict__ in_, int32_t n_, gu8*
   io.in = uni_ptr(in_); io.n = n; io.out = uni_ptr(out_); io.cap = cap;
   io.b_hi = 0u; io.pend = 0u; io.pv = 0u; io.flushed = 0u; io.rfloor = 0u; io.lane = lane;
   uint32_t tp = 0, op = 0;                      // tp: position of the current control byte
+  PROF_DECL                                     // (the instrumented build counts the LZ4 streams only; the step's laps need a place to go)
   for (;;) {
     dr_input(io, tp);
     uint32_t hdr = dr_peek32(io, tp);
     // batched step from the current control byte; not for the stream's first byte (its marker bits are not a length)
     if (tp > 0u && tp + 72u <= n && !((hdr & 0xffu) >= 224u && ((hdr >> 8) & 0xffu) == 255u)) {      // (longer length extensions: below)
-      if (dr_step<1>(io, tp, op, cap, n, hdr, sp, lane)) { dr_flush_rows(io, op); continue; }
+      if (dr_step<1>(io, tp, op, cap, n, hdr, sp, lane PROF_PASS)) { dr_flush_rows(io, op); continue; }
     }
     // ---- one token ----
     uint32_t ctrl = hdr & 0xffu;
