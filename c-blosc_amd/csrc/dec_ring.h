@@ -549,7 +549,9 @@ __device__ __forceinline__ uint32_t dr_step(RingIO& io, uint32_t& ip, uint32_t& 
   DR_SYNC();
   PROF_LAP(10);
   // ---- 5. everything else in stream order: byte lanes, the periodic extension of the off bytes in front of the match when it
-  //         overlaps itself (every lane then reads only bytes that are already final) ----
+  //         overlaps itself (every lane then reads only bytes that are already final).  (Bit planes send half of a step's sequences
+  //         here, 5.5 dependency levels for 10 sequences per step: taking two neighbours at a time when the second does not read what
+  //         the first writes is 2 % SLOWER - the test costs more than the round trips it saves: profiles/r04zx_*, r04zy_*.) ----
   uint32_t rest = (uint32_t)__ballot(mine && !fast_r && (G == 0 || ml_r != 0u));      // (BloscLZ: literal runs are tokens of their own, and matches of 3 bytes go here)
   PROF_ADD(0, 1); PROF_ADD(1, cnt); PROF_ADD(2, __builtin_popcount(rest));
   while (rest) {
