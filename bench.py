@@ -97,24 +97,38 @@ def make_chunk(kind, nbytes):
     return DATASETS[kind](nbytes)
 
 
+def src_fingerprint():
+    """12 hex digits over every file of c-blosc_amd/csrc (the kernels and the engine): stamps the traffic files and the extra file, so
+    that a figure measured on other kernels than the ones running is never quoted (.git does not travel to the GPU box)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "c-blosc_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode())
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:12]
+
+
 def measured_traffic(kernel, config_name, nchunks, chunk_mib, stock=False):
-    """(HBM bytes per launch of `kernel`, the file they come from) out of the committed rocprofv3 PMC passes of THIS workload
-    (profiles/r04_traffic_cfg<config>.json, else r03_ / r02g_ ..., made by scripts/profile_config.sh + scripts/make_traffic_json.py:
-    FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 corrections applied).  PMC counters cannot be read from inside a timed
-    run, so the figure is the committed one (`traffic_source` in the line says which file) and a workload without a committed
-    pass reports null.  stock=True: the launches that decoded REFERENCE-written chunks ("kernels_stock" of the r04 files; older
-    files mixed own-chunk and stock-chunk launches of the decode kernel in one average)."""
+    """(HBM bytes per launch of `kernel`, where they come from) out of the committed rocprofv3 PMC passes of THIS workload
+    (profiles/r05_traffic_cfg<config>.json, made by scripts/profile_config.sh + scripts/make_traffic_json.py: FETCH_SIZE and WRITE_SIZE
+    in separate passes, gfx950 corrections applied).  PMC counters cannot be read from inside a timed run, so the figure is the committed
+    one - and only when the file was made from the SAME kernel sources as the running build (`src_fingerprint` inside it); a file of
+    other sources, or of another geometry than 128 x 64 MiB, gives null and says why.  stock=True: the launches that decoded
+    REFERENCE-written chunks ("kernels_stock")."""
     if nchunks != 128 or chunk_mib != 64:
-        return None, None
-    for rnd in ("r04", "r03", "r02g", "r02f", "r02"):
-        path = os.path.join(ROOT, "profiles", f"{rnd}_traffic_cfg{config_name}.json")
-        if os.path.exists(path):
-            with open(path) as fh:
-                doc = json.load(fh)
-            k = (doc.get("kernels_stock") or {}).get(kernel) if stock else None
-            k = k or doc["kernels"].get(kernel)
-            return (k["hbm_bytes"] if k else None), f"profiles/{rnd}_traffic_cfg{config_name}.json"
-    return None, None
+        return None, "no PMC pass of this geometry"
+    path = os.path.join(ROOT, "profiles", f"r05_traffic_cfg{config_name}.json")
+    if not os.path.exists(path):
+        return None, "no PMC pass of this configuration on the round's kernels"
+    with open(path) as fh:
+        doc = json.load(fh)
+    if doc.get("src_fingerprint") != src_fingerprint():
+        return None, f"profiles/r05_traffic_cfg{config_name}.json is stale (sources {doc.get('src_fingerprint')}, running {src_fingerprint()})"
+    k = (doc.get("kernels_stock") or {}).get(kernel) if stock else None
+    k = k or doc["kernels"].get(kernel)
+    return (k["hbm_bytes"] if k else None), f"profiles/r05_traffic_cfg{config_name}.json"
 
 
 # ---------------------------------------------------------------------------------------------
@@ -367,13 +381,13 @@ def measure(rig, name, cfg, steps, warmup, args, mixed=None, payload=False):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    # ---- one step WITHOUT the queue order learnt from the previous calls (BLOSC_AMD_SCHED=0: plain block order, what a first call on new data gets) ----
-    os.environ["BLOSC_AMD_SCHED"] = "0"
+    # ---- one step WITHOUT the queue order learnt from the previous calls (blosc_gpu_profile(2): plain block order, what a first call on new data gets) ----
+    lib.blosc_gpu_profile(2)
     sync_all(); tc = time.perf_counter()
     step()
     torch.cuda.synchronize()
     sched_cold_ms = (time.perf_counter() - tc) * 1e3
-    del os.environ["BLOSC_AMD_SCHED"]
+    lib.blosc_gpu_profile(0)
     step()                                                   # (the next call's queues are built from this one's costs again)
 
     # ---- consolidation: every rank learns the global cbytes table (RCCL all_gather, 4 bytes per chunk) ----
@@ -472,12 +486,19 @@ def measure(rig, name, cfg, steps, warmup, args, mixed=None, payload=False):
         roof["path_frac"]["compress"] = (total + sum_cb) / t_c / 1e9 / HBM_PEAK_GBPS
     if stock is not None:      # the north-star direction inside the object the driver records: decode of reference-written chunks
         roof["decode_stock"] = stock["roofline"]
+    # every rank's own figure (weak scaling: each rank runs the same kernels on its own chunks), gathered to all
+    mine = torch.tensor([roof["frac"], stock["roofline"]["frac"] if stock is not None else 0.0], dtype=torch.float64, device=dev)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    roof["per_rank_frac"] = [round(float(x[0].item()), 4) for x in allr]
+    if stock is not None:
+        roof["decode_stock"]["per_rank_frac"] = [round(float(x[1].item()), 4) for x in allr]
     what = "decompress pass of reference-written chunks (the GPU does not encode this codec)" if decode_only else "compress pass + decompress pass"
     res = {
         "value": world * steps * total / elapsed / 1e9, "unit": "GB/s", "steps": steps, "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3,
         "first_call_ms": first_ms,             # the first step of this workload in this process: cold queues (no cost feedback yet), arenas still growing
-        "sched_cold": {"ms_per_step": sched_cold_ms, "GBps": world * total / (sched_cold_ms / 1e3) / 1e9,      # one step in plain block order (BLOSC_AMD_SCHED=0), arenas warm
+        "sched_cold": {"ms_per_step": sched_cold_ms, "GBps": world * total / (sched_cold_ms / 1e3) / 1e9,      # one step in plain block order, arenas warm
                        "note": "all 128 chunks of the bench are the same 64 MiB (bench/bench.c:383) and the queue order is trained on them; this is the step without that"},
         "config": {"workload": f"config #{name}: {FILTER_NAME[shuffle]} + {cfg['codec']} clevel={clevel} typesize={T}, "
                                f"{nchunks} x {args.chunk_mib} MiB {'+'.join(datasets)} chunks per GPU ({total / 2**30:.0f} GiB), "
@@ -501,6 +522,92 @@ def measure(rig, name, cfg, steps, warmup, args, mixed=None, payload=False):
         res["compress"] = {"GBps_kernels": total / t_c / 1e9, "roofline_frac_path": (total + sum_cb) / t_c / 1e9 / HBM_PEAK_GBPS}
     res["_host_chunk"] = host_chunk
     return res
+
+
+LINE_LIMIT = 4000      # bytes; the driver keeps an 8 KiB tail of stdout + stderr together and parses the line out of it (round 4: 20.7 KB -> parsed: null)
+
+
+def _r(x, nd=4):
+    """floats of the headline line carry what they mean, not 17 digits"""
+    if isinstance(x, float):
+        return float(f"{x:.{nd}g}") if abs(x) < 1 else round(x, 3)
+    if isinstance(x, dict):
+        return {k: _r(v, nd) for k, v in x.items()}
+    if isinstance(x, list):
+        return [_r(v, nd) for v in x]
+    return x
+
+
+def assemble(res, world, cpu, extra, mixed, args):
+    """(the ONE line for stdout, the full record).  The line holds the contract's fields, `config`, `roofline` (with `decode_stock`, the
+    north-star kernel on reference-written chunks), `cpu_baseline` without its arms, `verified`, a five-number summary per extra leg and
+    the name of the file with everything else (kernel tables, arms of the CPU baseline, legs in full, the mixed batch, multi-GPU detail):
+    profiles/bench_extra_<fingerprint of the kernel sources>.json and gpurun_out/bench_extra.json (the copy gpurun brings back)."""
+    fp = src_fingerprint()
+    detail = dict(res)
+    detail["src_fingerprint"] = fp
+    detail["argv"] = sys.argv[1:]
+    if extra is not None:
+        detail["extra_configs"], detail["mixed_batch"] = extra, mixed
+    if cpu is not None:
+        detail["cpu_baseline"] = cpu
+    extra_file = None
+    for d in ("profiles", "gpurun_out"):
+        try:
+            os.makedirs(os.path.join(ROOT, d), exist_ok=True)
+            name = f"bench_extra_{fp}.json" if d == "profiles" else "bench_extra.json"
+            with open(os.path.join(ROOT, d, name), "w") as fh:
+                json.dump(detail, fh, indent=1)
+            extra_file = extra_file or f"{d}/{name}"
+        except OSError:
+            pass
+    roof = dict(res["roofline"])
+    stock = res.get("decompress_stock_chunks")
+    k = res["kernels"]
+    out = {
+        "metric": "compress+decompress GB/s (uncompressed) at 1/2/4/8 GPUs vs HBM roofline; ratio",
+        "value": res["value"], "unit": res["unit"], "n_gpus": world, "steps": res["steps"], "warmup": res["warmup"],
+        "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "config": {kk: res["config"][kk] for kk in ("workload", "name", "chunks_per_gpu", "chunks_total", "chunk_bytes")},
+        "ratio": res["ratio"],
+        "compress_ms": sum(k[n]["ms_avg"] for n in COMPRESS_KERNELS if n in k) or None,
+        "decompress_ms": sum(k[n]["ms_avg"] for n in DECOMPRESS_KERNELS if n in k),
+        "decompress_stock_ms": sum(stock["kernels_ms"].values()) if stock else None,
+        "ratio_stock": stock["ratio"] if stock else None,
+        "roofline": roof,
+        "verified": res["verified"],
+    }
+    if world > 1:
+        out["per_rank_GBps"] = res["multi_gpu"]["per_rank_GBps"]
+        out["consolidation_ms"] = res["multi_gpu"]["consolidation_ms"]
+    if cpu is not None:
+        out["cpu_baseline"] = {kk: cpu[kk] for kk in ("value", "unit", "cores", "kind", "compress_GBps", "decompress_GBps", "ratio", "best_arm", "nproc", "cpu_model") if kk in cpu}
+        acc = cpu.get("shuffle_accel", "")
+        out["cpu_baseline"]["shuffle_accel"] = "avx2" if "Using AVX2" in acc or "avx2" in acc.lower().split("using")[-1] else acc[-60:]
+        out["cpu_baseline"]["sample"] = cpu["sample"]
+    if extra is not None:      # [round-trip GB/s, ratio, compress ms, decompress ms of own chunks, decompress ms of reference-written chunks]
+        def five(r):
+            kk = r["kernels"]; st = r.get("decompress_stock_chunks")
+            return [r["value"], r["ratio"], sum(kk[n]["ms_avg"] for n in COMPRESS_KERNELS if n in kk), sum(kk[n]["ms_avg"] for n in DECOMPRESS_KERNELS if n in kk),
+                    sum(st["kernels_ms"].values()) if st else None]
+        out["legs"] = {"columns": "GBps, ratio, compress_ms, decompress_ms, decompress_stock_ms", **{n: five(r) for n, r in extra.items()}}
+        if mixed is not None:
+            out["legs"]["mixed"] = [mixed["value"], mixed["ratio"], None, None, None]
+    out["extra_file"] = extra_file
+    out["src_fingerprint"] = fp
+    out = _r(out)
+    line = json.dumps(out)
+    for drop in ("legs", ("cpu_baseline", "sample"), ("roofline", "per_rank_frac")):      # never needed so far: the line is about 2.5 KB
+        if len(line) <= LINE_LIMIT:
+            break
+        if isinstance(drop, tuple):
+            out.get(drop[0], {}).pop(drop[1], None)
+        else:
+            out.pop(drop, None)
+        line = json.dumps(out)
+    assert len(line) <= LINE_LIMIT, len(line)
+    return line, detail
 
 
 def spawn_ranks(n):
@@ -587,11 +694,11 @@ def dry_gloo(args):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="GPUs of this node (default: WORLD_SIZE when a launcher started this process, else 1)")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="2", choices=sorted(CONFIGS))
-    ap.add_argument("--chunks", type=int, default=0, help="chunks per GPU (default 128; 512 when N > 1 = config #5's share)")
+    ap.add_argument("--chunks", type=int, default=0, help="chunks per GPU (default 128 = 8 GiB at EVERY N, so that the N = 1 point of a scaling run is the headline run; 512 = config #5's 32 GiB share)")
     ap.add_argument("--chunk-mib", type=int, default=64)
     ap.add_argument("--typesize", type=int, default=None)
     ap.add_argument("--clevel", type=int, default=None)
@@ -606,6 +713,8 @@ def main():
     ap.add_argument("--spawn", action="store_true", help="start the ranks through torch.distributed.run also when N = 1 (the N > 1 launch path on a one-GPU box)")
     ap.add_argument("--dry-gloo", action="store_true", help="no GPU: launch, partition, cbytes / payload exchanges and the JSON line over gloo on the CPU (tests)")
     args = ap.parse_args()
+    if args.gpus is None:
+        args.gpus = int(os.environ["WORLD_SIZE"]) if "RANK" in os.environ and "WORLD_SIZE" in os.environ else 1
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
     # ---- N > 1 and nobody has started the ranks: start them (one process per GPU), rank 0's JSON line is this process's output ----
@@ -659,7 +768,7 @@ def main():
     rig.multigpu = _load_multigpu()
     assert rig.lib.blosc_gpu_set_device(local) == 0
 
-    per_gpu = args.chunks or (128 if world == 1 else 512)
+    per_gpu = args.chunks or 128
     rig.nchunks_total = per_gpu * world
     rig.lo, rig.hi = rig.multigpu.chunk_range(rig.nchunks_total, world, rank)
     rig.nchunks, rig.csz = rig.hi - rig.lo, args.chunk_mib << 20
@@ -688,21 +797,12 @@ def main():
     if rank != 0:
         dist.destroy_process_group()
         return
-    out = {
-        "metric": "compress+decompress GB/s (uncompressed) at 1/2/4/8 GPUs vs HBM roofline; ratio",
-        "value": res.pop("value"), "unit": res.pop("unit"),
-        "n_gpus": world, "steps": res.pop("steps"), "warmup": res.pop("warmup"),
-        "ms_per_step": res.pop("ms_per_step"),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u8", "data": "synthetic",
-    }
-    out.update(res)
-    if extra is not None:
-        out["extra_configs"] = extra
-        out["mixed_batch"] = mixed
+    cpu = None
     if not args.no_cpu_baseline and world == 1:      # the host-core baseline is a 1-GPU artefact (rank 0, N = 1)
-        out["cpu_baseline"] = cpu_baseline(host_chunk, cfg["typesize"], cfg["clevel"], cfg["shuffle"], cfg["codec"].encode(), args.cpu_seconds)
-    print(json.dumps(out))
+        cpu = cpu_baseline(host_chunk, cfg["typesize"], cfg["clevel"], cfg["shuffle"], cfg["codec"].encode(), args.cpu_seconds)
+    line, detail = assemble(res, world, cpu, extra, mixed, args)
+    print(line)
+    sys.stdout.flush()
     rig.lib.blosc_init(); rig.lib.blosc_destroy()          # releases the arenas (and prints the BLOSC_AMD_HOSTTIME summary when that switch is on)
     dist.destroy_process_group()
 

@@ -87,6 +87,7 @@ struct EngineState {
   std::mutex mu;
   bool device_ok = false;
   int device = -1;
+  std::atomic<int> device_hint{-1};   // = device once the context is set up; read without the lock by callers choosing where to queue
   DeviceArena dev;      // descriptors + scratch
   DeviceArena io;       // staging for host-pointer calls
   PinnedArena pin;
@@ -123,7 +124,21 @@ static std::atomic<int> g_device{-1};      // -1: whatever device is current whe
 // The device of the CALLING THREAD's calls when >= 0 (engine_thread_device): the multi-GPU entry points run one host thread per
 // GPU inside one process, each bound to its device, without touching the process-wide choice other threads rely on.
 static thread_local int tl_device = -1;
-static int wanted_device() { return tl_device >= 0 ? tl_device : g_device.load(); }
+static bool g_forked = false;
+// The device a call of THIS thread runs on: the thread's own binding (multi-GPU entry points), else the process-wide one.  While
+// nobody has chosen one, "the current HIP device of the first caller" is resolved HERE and pinned - never "whatever device the context
+// that happens to be free lives on": after a _multi call the contexts live on devices 0 .. N-1, and a plain call with device-0
+// pointers must not be handed to (and must not silently re-select) another GPU.  -1 only when HIP has no device at all.
+static int wanted_device() {
+  if (tl_device >= 0) return tl_device;
+  int d = g_device.load();
+  if (d >= 0 || g_forked) return d;
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || cur < 0) { (void)hipGetLastError(); return -1; }
+  int none = -1;
+  (void)g_device.compare_exchange_strong(none, cur);
+  return g_device.load();
+}
 static std::atomic<bool> g_prof{false};
 static std::atomic<unsigned> g_ctx_turn{0};
 static int ctx_count() {
@@ -134,20 +149,32 @@ static int ctx_count() {
   return n;
 #endif
 }
+static std::mutex g_pick_mu;                // context selection is serialised: a probing thread never makes another one miss "its" context
 struct CtxGuard {                          // owns one context for the duration of a call
   EngineState* st = nullptr;
   CtxGuard() {
     const int n = ctx_count();
     // a free context that already lives on the device this thread wants (its arenas stay), else a free one that has no device
-    // yet, else any free one (it moves: ensure_device), else wait for one in turn
+    // yet, else any free one (it moves: ensure_device), else wait - for one that lives on the wanted device when there is one
     const int want = wanted_device();
-    for (int pass = 0; pass < 3 && !st; pass++)
-      for (int i = 0; i < n && !st; i++) {
-        if (!g_ctx[i].mu.try_lock()) continue;
-        const bool ok = pass == 2 || (pass == 0 ? (g_ctx[i].device_ok && (want < 0 || g_ctx[i].device == want)) : !g_ctx[i].device_ok);
-        if (ok) st = &g_ctx[i]; else g_ctx[i].mu.unlock();
+    int wait_on = -1;
+    {
+      std::lock_guard<std::mutex> pick(g_pick_mu);
+      for (int pass = 0; pass < 3 && !st; pass++)
+        for (int i = 0; i < n && !st; i++) {
+          if (!g_ctx[i].mu.try_lock()) continue;
+          const bool ok = pass == 2 || (pass == 0 ? (g_ctx[i].device_ok && g_ctx[i].device == want) : !g_ctx[i].device_ok);
+          if (ok) st = &g_ctx[i]; else g_ctx[i].mu.unlock();
+        }
+      if (!st) {
+        // every context is busy.  `device` of a busy context is only read as a hint here (its owner may be moving it): a wrong
+        // guess costs a migration in ensure_device, never correctness
+        const unsigned turn = g_ctx_turn.fetch_add(1u);
+        for (int k = 0; k < n && wait_on < 0; k++) { const int i = (int)((turn + (unsigned)k) % (unsigned)n); if (g_ctx[i].device_hint.load(std::memory_order_relaxed) == want) wait_on = i; }
+        if (wait_on < 0) wait_on = (int)(turn % (unsigned)n);
       }
-    if (!st) { st = &g_ctx[g_ctx_turn.fetch_add(1u) % (unsigned)n]; st->mu.lock(); }
+    }
+    if (!st) { st = &g_ctx[wait_on]; st->mu.lock(); }
   }
   ~CtxGuard() { st->mu.unlock(); }
   CtxGuard(const CtxGuard&) = delete;
@@ -179,7 +206,6 @@ static void probe_topology(EngineState& st) {
 // context does not survive fork(), so there is nothing to re-create here: the child is marked and every compute call
 // in it fails loudly (-1) instead of touching the parent's device state.  prepare/parent keep the context mutexes
 // consistent across the fork (a forking thread never inherits one locked by somebody else).
-static bool g_forked = false;
 static void atfork_prepare() { for (int i = 0; i < kMaxCtx; i++) g_ctx[i].mu.lock(); }
 static void atfork_parent() { for (int i = kMaxCtx - 1; i >= 0; i--) g_ctx[i].mu.unlock(); }
 static void atfork_child() { for (int i = kMaxCtx - 1; i >= 0; i--) g_ctx[i].mu.unlock(); g_forked = true; }
@@ -194,7 +220,7 @@ static int ensure_device(EngineState& st) {
   // the HIP current device is per host thread: every entry point (they all come through here, holding a
   // context) re-selects the engine's device for the calling thread
   const int want_dev = wanted_device();
-  if (st.device_ok && (want_dev < 0 || want_dev == st.device)) { HIP_TRY(hipSetDevice(st.device)); return 0; }
+  if (st.device_ok && want_dev == st.device) { HIP_TRY(hipSetDevice(st.device)); return 0; }
   if (st.device_ok) {                      // the process moved to another device (engine_set_device through another context)
     (void)hipSetDevice(st.device);
     st.dev.release(); st.io.release();     // arenas, stream and events belong to the device they were created on
@@ -218,9 +244,18 @@ static int ensure_device(EngineState& st) {
   else { HIP_TRY(hipGetDevice(&st.device)); int none = -1; (void)g_device.compare_exchange_strong(none, st.device); }
   probe_topology(st);
   hipDeviceProp_t pr;
-  st.cus = (hipGetDeviceProperties(&pr, st.device) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+  const bool have_props = hipGetDeviceProperties(&pr, st.device) == hipSuccess;
+  st.cus = (have_props && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+  // The in-kernel hand-offs (k_decode.hip: decode_one_stream, k_encode.hip) are "drain stores, relaxed atomic at the XCD's L2" - an argument
+  // about gfx942 / gfx950's write-through L1 and one L2 per XCC, outside the HIP memory model.  Any other part gets the single-queue path,
+  // which has no in-kernel hand-off at all, whatever the probe above saw.
+  if (!st.single_queue && !(have_props && (strncmp(pr.gcnArchName, "gfx950", 6) == 0 || strncmp(pr.gcnArchName, "gfx942", 6) == 0))) {
+    st.single_queue = true;
+    if (getenv("BLOSC_AMD_DEBUG")) fprintf(stderr, "blosc_amd: %s is not on the allow-list of the relaxed in-kernel hand-off; using one task queue and unfused filters\n", have_props ? pr.gcnArchName : "(unknown device)");
+  }
   st.enc_cost_valid = st.dec_cost_valid = false;
   st.device_ok = true;
+  st.device_hint.store(st.device, std::memory_order_relaxed);
   return 0;
 }
 
@@ -1150,7 +1185,7 @@ bool engine_is_device_pointer(const void* p) {
   return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
 }
 
-void engine_prof_enable(int on) { g_prof.store(on != 0); }
+void engine_prof_enable(int on) { g_prof.store((on & 1) != 0); sched_override_off().store((on & 2) != 0); }      // bit 1: plain queue order for the calls that follow (queue_order.h)
 void engine_prof_reset() {
   for (int i = 0; i < kMaxCtx; i++) { std::lock_guard<std::mutex> lock(g_ctx[i].mu); g_ctx[i].prof_acc.clear(); }
 }

@@ -4,6 +4,7 @@
 // partition (blosc/blosc.c:1706-1887 t_blosc: contiguous block ranges per pthread).
 // Compiled into engine.hip; tests/tools/sched_check.cpp checks the invariants with g++ on the CPU.
 #pragma once
+#include <atomic>
 #include <stdint.h>
 #include <stdlib.h>
 #include <algorithm>
@@ -23,7 +24,13 @@ namespace bamd {
 constexpr size_t kEncLookaheadDefault = 32;
 inline size_t enc_lookahead() { return kEncLookaheadDefault; }     // (swept 1 ... 64 in round 4: 8.4 ... 8.0 ms, profiles/r04q_enc_lookahead_sweep.txt - the distance hardly matters)
 // BLOSC_AMD_SCHED=0: plain block order (no cost feedback)
-inline bool sched_enabled() { const char* e = getenv("BLOSC_AMD_SCHED"); return !(e && atoi(e) == 0); }      // read on every call (bench.py times one step without it: `sched_cold`)
+// (read once: getenv is not safe against a setenv from another host thread.  blosc_gpu_profile(2) switches the feedback off for the calls
+//  that follow - bench.py's `sched_cold` leg: one step in the order a first call on new data gets)
+inline std::atomic<bool>& sched_override_off() { static std::atomic<bool> off{false}; return off; }
+inline bool sched_enabled() {
+  static const bool env_on = [] { const char* e = getenv("BLOSC_AMD_SCHED"); return !(e && atoi(e) == 0); }();
+  return env_on && !sched_override_off().load(std::memory_order_relaxed);
+}
 
 // plane indices 0..T-1 in descending cost; *nheavy = how many of them count as expensive (> max/2)
 inline void plane_order(const uint32_t* cost, bool valid, int T, std::vector<int>& order, int* nheavy) {

@@ -106,7 +106,19 @@ BLOSC_EXPORT void blosc_destroy(void);
  * BLOSC_TYPESIZE, BLOSC_COMPRESSOR, BLOSC_BLOCKSIZE, BLOSC_NTHREADS, BLOSC_SPLITMODE,
  * BLOSC_NOLOCK and BLOSC_WARN environment variables on every call, like the reference.
  * Returns: >0 compressed bytes; 0 does not fit in destsize / input too large / destsize < 16;
- * -10 bad clevel, shuffle or typesize; -5 codec not available; -1 other error. */
+ * -10 bad clevel, shuffle or typesize; -5 codec not available; -1 other error.
+ *
+ * Which BYTES a compress call writes (the reference pins none: no test of it compares compressed bytes, and with nthreads > 1 its block
+ * order depends on thread timing, blosc/blosc.c:1845-1860; single-threaded it is deterministic, :803-867):
+ *   - header, blocksize, split decision, bstarts layout (blocks in block order): a function of the arguments alone, equal to stock's;
+ *   - "blosclz", "lz4", and "zstd" up to clevel 5 (one match finder, one probe per position): the same input and arguments give the
+ *     same chunk, call after call, from any number of threads (tests/test_gpu_threads.py compares the bytes) - but NOT the reference's
+ *     bytes: a different, wave-parallel match finder;
+ *   - "lz4hc", "zlib" at every clevel and "zstd" from clevel 6: the deeper search inserts into hash buckets from several lanes at
+ *     once and the winner of a slot is not fixed, so two calls on the same input may choose different (equally valid) matches: compressed
+ *     size and bytes can differ by a fraction of a per cent between calls.  Every such chunk decodes to the input, here and with stock
+ *     c-blosc (BLOSC_AMD_LZ4HC=0 / BLOSC_AMD_ZLIB_SEARCH=0 / BLOSC_AMD_ZSTD_SEARCH=0 select the deterministic finder under those names).
+ *     Callers that hash or deduplicate COMPRESSED chunks should use one of the deterministic settings above. */
 BLOSC_EXPORT int blosc_compress(int clevel, int doshuffle, size_t typesize, size_t nbytes, const void* src,
                                 void* dest, size_t destsize);
 

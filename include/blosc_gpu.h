@@ -23,7 +23,13 @@ extern "C" {
 #define BLOSC_EXPORT __attribute__((visibility("default")))
 #endif
 
-/* Select the HIP device used by this process (default: the current device).  0 on success. */
+/* Select the HIP device used by this process.  0 on success.
+ * Default (never called): the HIP device that is current in the thread that makes the FIRST compute call; it is pinned then, for every
+ * thread.  The choice is process-wide: the library's call contexts (up to 8, one per concurrent caller) follow it lazily, each the next
+ * time it is used, dropping the arenas it held on the previous device.  Therefore: do NOT call this while other threads are inside (or
+ * about to enter) compute calls - a call in flight finishes on the device it started on, but a caller that raced with the switch may run on
+ * either device, and pointers of the other device are then invalid for it.  Switch devices only between batches, from one thread.  The
+ * _multi calls below bind their own worker threads to their devices and neither read nor change this setting. */
 BLOSC_EXPORT int blosc_gpu_set_device(int device);
 
 /* Batched blosc_compress_ctx (blosc/blosc.h:245-248).  Chunk i: nbytes[i] bytes at src[i] ->
@@ -72,7 +78,9 @@ BLOSC_EXPORT int blosc_gpu_getitem(const void* src, int start, int nitems, void*
 
 /* Per-kernel timing with hipEvents on the launch stream (bench.py's roofline numbers).
  * Kernel names: k_shuffle k_unshuffle k_bitshuffle k_bitunshuffle k_decode_plan k_decode_streams
- * k_encode_streams k_chunk_scan k_chunk_compact k_copy_chunks. */
+ * k_encode_streams k_chunk_scan k_chunk_compact k_copy_chunks.
+ * `enable`: bit 0 = collect timings; bit 1 = build the task queues of the calls that follow in plain block order, without the per-plane
+ * cost feedback of the previous call (what the first call on new data gets; bench.py's `sched_cold` figure).  0 = both off. */
 BLOSC_EXPORT void blosc_gpu_profile(int enable);
 BLOSC_EXPORT void blosc_gpu_profile_reset(void);
 BLOSC_EXPORT int blosc_gpu_profile_get(const char* kernel, double* total_ms, int* launches);

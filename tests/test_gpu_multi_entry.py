@@ -75,3 +75,36 @@ def test_multi_calls_on_device_buffers(pkg, lib):
                                                 (vp * n)(*[back[i].data_ptr() for i in range(n)]), (sz * n)(*([csz] * n)), res2) == 0
     torch.cuda.synchronize()
     assert list(res2) == [csz] * n and torch.equal(back, src)
+
+
+def test_plain_call_after_multi_call_stays_on_the_callers_device(pkg, lib):
+    """after a _multi call the library's contexts live on devices 0 .. N-1 (which worker got which context is a race).  A plain
+    call that never named a device must run on the caller's CURRENT device - not on whatever device the first free context landed on - and must
+    leave the calling thread's HIP device alone.  With one GPU the device lists alias device 0 (the selection code still runs); with two or
+    more the workers really spread, the order {last, ..., 0} puts context 0 on the LAST device, and the plain call's pointers are device-0 memory."""
+    import torch
+    ngpu = lib.blosc_gpu_device_count()
+    order = list(range(ngpu - 1, -1, -1)) if ngpu > 1 else [0, 0]
+    nd = len(order)
+    n, csz = 2 * nd + 1, 1 << 20
+    vp, sz = C.c_void_p, C.c_size_t
+    hosts = [DATASETS["bench19"](csz) for _ in range(n)]
+    outs = [np.zeros(csz + 16, np.uint8) for _ in range(n)]
+    res = (C.c_int * n)()
+    assert lib.blosc_gpu_compress_batch_multi(nd, (C.c_int * nd)(*order), 5, 1, 8, b"lz4", 0, n, (vp * n)(*[h.ctypes.data for h in hosts]), (sz * n)(*([csz] * n)),
+                                              (vp * n)(*[o.ctypes.data for o in outs]), (sz * n)(*([csz + 16] * n)), res) == 0
+    assert all(c > 0 for c in res)
+    torch.cuda.set_device(0)
+    dev0 = torch.device("cuda:0")
+    src = torch.from_numpy(hosts[0]).to(dev0)
+    comp = torch.zeros(csz + 16, dtype=torch.uint8, device=dev0); back = torch.zeros(csz, dtype=torch.uint8, device=dev0)
+    for _ in range(4):                                   # several calls: every free context gets its turn at being "the first free one"
+        b = pkg.DeviceBatch([src.data_ptr()], [csz], [comp.data_ptr()], [csz + 16])
+        assert b.compress(8, 5, 1, b"lz4") == 0
+        cb = b.results()[0]
+        assert cb > 0
+        d = pkg.DeviceBatch([comp.data_ptr()], [cb], [back.data_ptr()], [csz])
+        assert d.decompress() == 0 and d.results() == [csz]
+        torch.cuda.synchronize()
+        assert torch.equal(back, src)
+        assert torch.cuda.current_device() == 0

@@ -80,5 +80,30 @@ def test_bench_spawner_n1():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 1 and d["value"] > 0 and d["multi_gpu"]["rccl_world_size"] == 1 and len(d["multi_gpu"]["per_rank_GBps"]) == 1
-    assert d["verified"]["roundtrip_bit_exact"] is True
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["verified"]["roundtrip_bit_exact"] is True
+    with open(os.path.join(ROOT, d["extra_file"])) as fh:      # everything that is not headline material
+        x = json.load(fh)
+    assert x["multi_gpu"]["rccl_world_size"] == 1 and len(x["multi_gpu"]["per_rank_GBps"]) == 1 and x["src_fingerprint"] == d["src_fingerprint"]
+
+
+def test_bench_line_fits_the_drivers_tail():
+    """The whole default protocol - headline workload, the five extra legs, the mixed batch, the stock-chunk legs, the CPU baseline - on small
+    chunks: the ONE line must parse out of the last 4096 bytes of stdout (round 4's was 20.7 KB and the driver recorded `parsed: null`) and
+    carry the fields the driver records; stderr must stay short as well (the driver's 8 KiB tail is stdout + stderr)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--chunks", "4", "--chunk-mib", "8", "--cpu-seconds", "2"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(r.stderr) < 2048, r.stderr[-3000:]
+    tail = r.stdout[-4096:]
+    line = tail.strip().splitlines()[-1]
+    assert len(line) < 4096 and line.startswith("{")
+    d = json.loads(line)
+    for k in ("value", "ms_per_step", "config", "roofline", "cpu_baseline", "legs", "extra_file"):
+        assert k in d, k
+    assert d["roofline"]["frac"] > 0 and d["roofline"]["decode_stock"]["frac"] > 0 and d["cpu_baseline"]["value"] > 0
+    assert set(d["legs"]) >= {"3", "4", "1g", "2t", "2x", "mixed"}
+    assert os.path.exists(os.path.join(ROOT, d["extra_file"]))

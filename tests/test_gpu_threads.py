@@ -42,7 +42,7 @@ def _worker(lib, oracle, ref, job, rounds, errors, tid):
                 first = chunk
                 r2, out = orc_decompress(oracle, chunk, n)
                 assert r2 == n and np.array_equal(out, data), (tid, "the oracle cannot read it")
-            elif cname in (b"lz4", b"blosclz"):                                  # (the search modes let lanes race for a bucket slot: valid either way)
+            elif cname in (b"lz4", b"blosclz") or (cname == b"zstd" and clevel <= 5):      # (the search modes - lz4hc, zlib, zstd from clevel 6 - let lanes race for a bucket slot: valid either way; include/blosc.h says so)
                 assert np.array_equal(chunk, first), (tid, it, "the same call gave different bytes")      # queue order never changes the bytes of a stream
             back = np.full(n + 64, 0xEE, np.uint8)
             src = stock if (stock is not None and it % 2) else chunk
