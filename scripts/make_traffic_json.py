@@ -18,7 +18,9 @@ def rd(counter):
             out[row["kernel"]] = float(row["mean_value_KB"])
     return out
 f, w = rd("FETCH_SIZE"), rd("WRITE_SIZE")
+fp_file = os.path.join(ROOT, "profiles", f"{tag}_cfg{cfg}_src_fingerprint.txt")
 res = {"workload": f"bench.py --config {cfg} (128 x 64 MiB chunks per GPU), one step",
+       "src_fingerprint": open(fp_file).read().strip() if os.path.exists(fp_file) else None,      # bench.src_fingerprint() on the box that ran the passes
        "corrections": {"FETCH_SIZE": "KiB x 1024 x 2", "WRITE_SIZE": "KiB x 1024"}, "kernels": {}}
 for k in sorted(set(f) | set(w)):
     if "bamd::" not in k: continue

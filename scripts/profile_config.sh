@@ -5,7 +5,9 @@ set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-CFG=${CFG:-2}; TAG=${TAG:-r02}_cfg${CFG}
+CFG=${CFG:-2}; TAG=${TAG:-r05}_cfg${CFG}
+# which kernel sources these passes ran on (bench.py quotes a traffic figure only for the sources it runs itself)
+python -c "import bench; print(bench.src_fingerprint())" > gpurun_out/${TAG}_src_fingerprint.txt
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_trace -o trace -- python bench.py --config $CFG --no-cpu-baseline --no-extra > gpurun_out/${TAG}_bench_under_trace.log 2>&1
 grep '^{' gpurun_out/${TAG}_bench_under_trace.log | tail -1 > gpurun_out/${TAG}_bench_under_trace.json
 f=$(find gpurun_out/${TAG}_trace -name "*kernel_stats.csv" | head -1)
