@@ -57,7 +57,15 @@ struct RingIO {
   uint32_t flushed;                    // out[0, flushed) is in global memory (or skipped by a periodic span); a multiple of DR_ROW
   uint32_t rfloor;                     // ring positions below this are not valid (behind a periodic span: never written)
   int lane;
+#ifdef BAMD_LOO_PLANES
+  uint32_t noflush;
+#endif
 };
+#ifdef BAMD_LOO_PLANES
+#define DR_FLUSH_ON(io) (!(io).noflush)
+#else
+#define DR_FLUSH_ON(io) true
+#endif
 
 // ---- input ring ----------------------------------------------------------------------------------------------------------
 // lane's dword of input block j; bytes beyond the stream read as zero (and are never consumed: every consumer checks n first)
@@ -125,7 +133,7 @@ __device__ __forceinline__ void dr_put16(lu8* hist, uint32_t pos, uint4 v) {
 __device__ __forceinline__ void dr_flush_rows(RingIO& io, uint32_t op) {
   while (op - io.flushed >= DR_ROW) {
     DR_SYNC();
-    g_st16(io.out + io.flushed + 16u * (uint32_t)io.lane, l_ld16(io.hist + ((io.flushed + 16u * (uint32_t)io.lane) & DR_MASK)));
+    if (DR_FLUSH_ON(io)) g_st16(io.out + io.flushed + 16u * (uint32_t)io.lane, l_ld16(io.hist + ((io.flushed + 16u * (uint32_t)io.lane) & DR_MASK)));
     io.flushed += DR_ROW;
   }
 }
@@ -225,7 +233,7 @@ __device__ __forceinline__ void dr_match(RingIO& io, uint32_t& op, uint32_t off,
       DR_SYNC();
       for (; end - pos >= DR_ROW; pos += DR_ROW) {
         l_st16(io.hist + ((pos + l16) & DR_MASK), row);
-        g_st16(io.out + pos + l16, row);
+        if (DR_FLUSH_ON(io)) g_st16(io.out + pos + l16, row);
       }
       io.flushed = pos; op = pos;
       DR_SYNC();
@@ -331,6 +339,9 @@ __device__ __attribute__((noinline)) void dr_span_call(volatile uint32_t* lds_, 
     io.scr = (volatile BAMD_LAS uint32_t*)lds; io.in32 = (BAMD_LAS uint32_t*)lds + 64; io.hist = (lu8*)((BAMD_LAS uint32_t*)lds + 64 + DR_IN / 4u);
   }
   io.in = nullptr; io.n = 0u; io.out = uni_ptr(out_); io.cap = 0u; io.b_hi = 0u; io.pend = 0u; io.pv = 0u; io.flushed = uni(flushed_); io.rfloor = 0u; io.lane = lane;
+#ifdef BAMD_LOO_PLANES
+  io.noflush = 0u;
+#endif
   const uint32_t mpos = uni(mpos_), off = uni(off_), ml = uni(ml_);
   gu8* pat = uni_ptr(pat_);
   const uint32_t lo = (mpos + 1023u) & ~1023u, hi = (mpos + ml) & ~1023u, end = mpos + ml;
@@ -616,6 +627,9 @@ __device__ int lz4_decode_wave(const gu8* __restrict__ in_, int32_t n_, gu8* out
   io.hist = (lu8*)((BAMD_LAS uint32_t*)lds + 64 + DR_IN / 4u);
   io.in = uni_ptr(in_); io.n = n; io.out = uni_ptr(out_); io.cap = cap;
   io.b_hi = 0u; io.pend = 0u; io.pv = 0u; io.flushed = 0u; io.rfloor = 0u; io.lane = lane;
+#ifdef BAMD_LOO_PLANES
+  io.noflush = sp.loo;
+#endif
   uint32_t ip = 0, op = 0;
   for (;;) {
     // (the rows of the last step could also leave behind dr_input's wait for its prefetched block - vmcnt counts loads and stores in one
@@ -709,6 +723,9 @@ __device__ int blosclz_decode_wave(const gu8* __restrict__ in_, int32_t n_, gu8*
   io.hist = (lu8*)((BAMD_LAS uint32_t*)lds + 64 + DR_IN / 4u);
   io.in = uni_ptr(in_); io.n = n; io.out = uni_ptr(out_); io.cap = cap;
   io.b_hi = 0u; io.pend = 0u; io.pv = 0u; io.flushed = 0u; io.rfloor = 0u; io.lane = lane;
+#ifdef BAMD_LOO_PLANES
+  io.noflush = sp.loo;
+#endif
   uint32_t tp = 0, op = 0;                      // tp: position of the current control byte
   PROF_DECL                                     // (the instrumented build counts the LZ4 streams only; the step's laps need a place to go)
   for (;;) {

@@ -254,27 +254,31 @@ __device__ __attribute__((noinline)) void shuffle_block_task_x(const gu8* src_, 
   else { if (det) shuffle_block_detect_T<2>(src, dst, bsize, planes, lane); else shuffle_block_wave_T<2>(src, dst, bsize, lane); }
 }
 // ---------------------------------------------------------------------------------------------
-// Fused bitshuffle of one block by ONE wavefront (typesize 1, 2 or 4), round 4: a "shuffle block" task of a bitshuffle chunk - the
+// Fused bitshuffle of one block by ONE wavefront (typesize 1, 2, 4; 8 since round 5), round 4: a "shuffle block" task of a bitshuffle chunk - the
 // mirror image of bitunshuffle_block_wave in k_decode.hip, and the end of the k_bitshuffle pass over the batch (3.9 ms per 8 GiB on
 // config #3).  blosc_internal_bitshuffle (blosc/shuffle.c:393-443, bitshuffle-generic.c:125-139): element-major source -> 8 T bit rows
 // of N / 8 bytes.  Per pass of 2048 elements a lane owns 32 consecutive ones: 32 T bytes as 16-byte loads (its neighbours' lines are the
 // same ones: L1), 8 x 8 bit-matrix transposes in registers, and one dword of every bit row out - a wave store writes 256 contiguous bytes
 // of a row.  No LDS.  Corner rules as in the filter kernels: not applied when bsize < T, whole block copied when N is not a multiple of 8.
 // ---------------------------------------------------------------------------------------------
-template <int T>
+// EPL = elements a lane owns per pass: 32 (typesize 1 / 2 / 4: a dword of every bit row out) or 16 (typesize 8, round 5: 128 source bytes = 32
+// registers per lane, two bytes of each of its 64 rows out - a wave store still writes 128 contiguous bytes of a row)
+template <int T, int EPL>
 __device__ __forceinline__ void bitshuffle_pass(const gu8* src, gu8* dst, uint32_t rowlen, uint32_t e0, uint32_t nchunks, int lane) {
-  constexpr uint32_t CB = 32u * T, NDW = CB / 4u;
+  constexpr uint32_t CB = (uint32_t)EPL * T, NDW = CB / 4u;
+  constexpr int G = EPL / 8;
+  static_assert(EPL == 32 || EPL == 16, "a dword or two bytes of every bit row per lane");
   const uint32_t m0 = e0 >> 3, t = (uint32_t)lane;
   if (t >= nchunks) return;
-  const gu8* in = src + (size_t)(e0 + 32u * t) * T;
+  const gu8* in = src + (size_t)(e0 + (uint32_t)EPL * t) * T;
   uint32_t w[NDW];
 #pragma unroll
   for (uint32_t k = 0; k < NDW / 4u; k++) { const uint4 v = g_ld16(in + 16u * k); w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
 #pragma unroll
   for (int j = 0; j < T; j++) {
-    uint64_t x[4];
+    uint64_t x[G];
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
+    for (int g = 0; g < G; g++) {
       uint64_t v = 0;
 #pragma unroll
       for (int k = 0; k < 8; k++) { const int idx = (8 * g + k) * T + j; v |= (uint64_t)((w[idx >> 2] >> (8 * (idx & 3))) & 0xffu) << (8 * k); }
@@ -282,14 +286,17 @@ __device__ __forceinline__ void bitshuffle_pass(const gu8* src, gu8* dst, uint32
     }
 #pragma unroll
     for (int b = 0; b < 8; b++) {
-      const uint32_t rw = (uint32_t)((x[0] >> (8 * b)) & 0xff) | ((uint32_t)((x[1] >> (8 * b)) & 0xff) << 8) |
-                          ((uint32_t)((x[2] >> (8 * b)) & 0xff) << 16) | ((uint32_t)((x[3] >> (8 * b)) & 0xff) << 24);
-      g_st4(dst + (size_t)(8 * j + b) * rowlen + m0 + 4u * t, rw);
+      uint32_t rw = 0;
+#pragma unroll
+      for (int g = 0; g < G; g++) rw |= (uint32_t)((x[g] >> (8 * b)) & 0xff) << (8 * g);
+      gu8* rp = dst + (size_t)(8 * j + b) * rowlen + m0 + (uint32_t)G * t;
+      if (G == 4) g_st4(rp, rw); else g_st2(rp, rw);
     }
   }
 }
 template <int T>
 __device__ void bitshuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize, int lane) {
+  constexpr int EPL = T == 8 ? 16 : 32;
   const uint32_t N = bsize / T;
   if (bsize < T || (N & 7u)) {                         // not filtered at all (blosc.c:608-609) / copied verbatim by the filter (shuffle.c:412-414)
     for (uint32_t k = 16u * (uint32_t)lane; k < bsize; k += 1024u) {
@@ -300,9 +307,9 @@ __device__ void bitshuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize
   }
   const uint32_t rowlen = N >> 3;
   uint32_t e0 = 0;
-  for (; e0 + 2048u <= N; e0 += 2048u) bitshuffle_pass<T>(src, dst, rowlen, e0, 64u, lane);
-  if (N - e0 >= 32u) { const uint32_t nch = (N - e0) >> 5; bitshuffle_pass<T>(src, dst, rowlen, e0, nch, lane); e0 += 32u * nch; }
-  if ((uint32_t)lane < ((N - e0) >> 3)) {              // fewer than 32 elements left (a multiple of 8): eight elements per lane, one byte into every bit row
+  for (; e0 + 64u * EPL <= N; e0 += 64u * EPL) bitshuffle_pass<T, EPL>(src, dst, rowlen, e0, 64u, lane);
+  if (N - e0 >= (uint32_t)EPL) { const uint32_t nch = (N - e0) / (uint32_t)EPL; bitshuffle_pass<T, EPL>(src, dst, rowlen, e0, nch, lane); e0 += (uint32_t)EPL * nch; }
+  if ((uint32_t)lane < ((N - e0) >> 3)) {              // fewer than EPL elements left (a multiple of 8): eight elements per lane, one byte into every bit row
     const uint32_t m = (e0 >> 3) + (uint32_t)lane;
 #pragma unroll
     for (int j = 0; j < T; j++) {
@@ -319,7 +326,8 @@ __device__ void bitshuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize
 __device__ __attribute__((noinline)) void bitshuffle_block_task_x(const gu8* src_, gu8* dst_, uint32_t bsize_, uint32_t T_, int lane) {
   const gu8* src = uni_ptr(src_); gu8* dst = uni_ptr(dst_);
   const uint32_t bsize = uni(bsize_), T = uni(T_);
-  if (T == 4u) bitshuffle_block_wave_T<4>(src, dst, bsize, lane);
+  if (T == 8u) bitshuffle_block_wave_T<8>(src, dst, bsize, lane);
+  else if (T == 4u) bitshuffle_block_wave_T<4>(src, dst, bsize, lane);
   else if (T == 2u) bitshuffle_block_wave_T<2>(src, dst, bsize, lane);
   else bitshuffle_block_wave_T<1>(src, dst, bsize, lane);
 }
@@ -383,7 +391,7 @@ __device__ __attribute__((noinline)) void shuffle_block_task(const ChunkDesc* ch
   const bool det = detect && uni((uint32_t)b->nstreams) == T && N * T == bsize && (N & 255u) == 0u && N >= 1024u &&
                    (uni((uint32_t)c->fmt) == (uint32_t)FMT_LZ4 || uni((uint32_t)c->fmt) == (uint32_t)FMT_BLOSCLZ);
   StreamDesc* planes = streams + uni((uint32_t)b->first_stream);
-  if (uni(c->mode) & CH_BITSHUFFLE) bitshuffle_block_task_x(src, dst, bsize, T, lane);      // (typesize 1 / 2 / 4: the only bitshuffle chunks that carry CH_FUSED_SHUF)
+  if (uni(c->mode) & CH_BITSHUFFLE) bitshuffle_block_task_x(src, dst, bsize, T, lane);      // (typesize 1 / 2 / 4 / 8: the only bitshuffle chunks that carry CH_FUSED_SHUF)
   else if (shuffle_generic_T(T)) shuffle_block_generic(lds, src, dst, bsize, T, lane);
   else if (T == 8u) { if (det) shuffle_block_detect_T<8>(src, dst, bsize, planes, lane); else shuffle_block_wave_T<8>(src, dst, bsize, lane); }
   else if (T == 4u) { if (det) shuffle_block_detect_T<4>(src, dst, bsize, planes, lane); else shuffle_block_wave_T<4>(src, dst, bsize, lane); }

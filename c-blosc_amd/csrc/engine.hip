@@ -343,7 +343,7 @@ static int zstd2_mode() { static const int m = getenv("BLOSC_AMD_ZSTD2") ? atoi(
 static bool fused_typesize(int T) { return T >= 2 && T <= 32; }          // 2 / 4 / 8 / 16: register transposes; the others up to 32 (round 4): an LDS tile of the wave
 static bool fused_fast_typesize(int T) { return T == 8 || T == 4 || T == 2 || T == 16; }     // what the Zstd / zlib kernels' own-block unshuffle handles
 // bitshuffle chunks of these typesizes are (un)shuffled inside the codec kernels as well (round 4: bitshuffle_block_wave_T / bitunshuffle_block_wave)
-static bool bitunshuffle_fused_host(int T) { return T == 1 || T == 2 || T == 4; }
+static bool bitunshuffle_fused_host(int T) { return T == 1 || T == 2 || T == 4 || T == 8; }      // 8: round 5 (float64 + bitshuffle is a mainstream caller setting)
 static bool fuse_enabled() { static const bool on = !(getenv("BLOSC_AMD_FUSE") && atoi(getenv("BLOSC_AMD_FUSE")) == 0); return on; }
 
 // the stream a call runs on: the caller's, or - host buffers and no stream named - the context's own

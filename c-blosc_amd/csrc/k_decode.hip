@@ -13,6 +13,7 @@
 // Algorithmic HBM bytes per stream: csize read + neblock written.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "dev_types.h"
 #include "wave_prims.h"
 
@@ -110,7 +111,11 @@ __device__ __forceinline__ uint32_t hop(uint32_t table, uint32_t x) {
 // instead of the scratch.  A later match that reaches back into the skipped range makes the decoder
 // fill it in after all ("materialise"); only split blocks of fused chunks use spans.
 // ---------------------------------------------------------------------------------------------
-struct SpanCtx { uint32_t enabled, lo, hi, off; gu8* pat; };
+struct SpanCtx { uint32_t enabled, lo, hi, off; gu8* pat;
+#ifdef BAMD_LOO_PLANES      // timing-only builds (wrong output): the planes of this mask never reach the scratch and are never read back by the unshuffle
+  uint32_t loo;
+#endif
+};
 constexpr uint32_t SPAN_PAT = 2048u;
 
 // (real calls, made a few times per stream at most, with plain arguments: the helpers' registers must not count against the hot
@@ -238,6 +243,9 @@ __device__ __forceinline__ void unshuffle_store(gu8* dst, uint32_t e, int lane, 
 // Flag bit 2, `self`: a period above the table's 2 KiB (span_long_match): the skipped positions are read from the plane's own bytes
 // in front of the span, at ob + ((q - ob) & (off - 1)) per lane; ob and off are the first two words of the stream's table slot.
 constexpr uint32_t SPAN_SMALL = 1u, SPAN_RAW = 2u, SPAN_SELF = 4u;
+#ifndef BAMD_UNSH_BYTES
+#define BAMD_UNSH_BYTES 0         // plane bytes a wave keeps in flight per group of the fused unshuffle; 0 = one quarter-group (1024 elements) whatever the typesize
+#endif
 template <int T>
 __device__ void unshuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize, int lane, const uint32_t* spans, const gu8* pat, const StreamDesc* sds, uint32_t pstride) {
   const uint32_t N = bsize / T;
@@ -250,6 +258,9 @@ __device__ void unshuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize,
     lo[j] = w & ~1023u; hi[j] = spans ? uni(spans[2 * j + 1]) : 0u;
     pr[j] = 0u; ob[j] = 0u;
     pl[j] = src + (size_t)j * pstride;
+#ifdef BAMD_LOO_PLANES
+    if (spans && (((uint32_t)(BAMD_LOO_PLANES) >> j) & 1u)) { small |= 1u << j; lo[j] = 0u; hi[j] = N; pr[j] = g_ld4(pat + (size_t)j * SPAN_PAT + unsh_l4<T>(lane)); continue; }
+#endif
     if (w & SPAN_RAW) { pl[j] = uni_ptr(as_global(sds[j].in)); hi[j] = 0u; }
     else if ((w & SPAN_SMALL) && hi[j] > lo[j]) { small |= 1u << j; pr[j] = g_ld4(pat + (size_t)j * SPAN_PAT + unsh_l4<T>(lane)); }
     else if ((w & SPAN_SELF) && hi[j] > lo[j]) {
@@ -261,36 +272,45 @@ __device__ void unshuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize,
   // waits for vmcnt(0) at the top of EVERY iteration - i.e. for the previous iteration's stores
   __builtin_amdgcn_s_waitcnt(0);
   uint32_t e = 0;
-  // A group = 4 steps (1024 elements): all its loads are issued before its first store.  Span bounds are multiples of 1024, so one
-  // decision per plane and group picks the plane, the pattern table or the register.
+  // A group = G quarter-groups of 4 steps (1024 elements each): all its loads are issued before its first store.  Span bounds are multiples of
+  // 1024, so one decision per plane and quarter-group picks the plane, the pattern table or the register.
   const uint32_t l4 = unsh_l4<T>(lane);
   // (Two things round 4 tried on this loop and dropped.  A software pipeline - two register sets, the loads of group g + 1 issued before the
   //  stores of group g -: 32 % SLOWER, 5.55 against 4.20 ms; the span branches around the loads leave the compiler no exact vmcnt and the second
   //  register set spills - round 3 had seen -10 % at 96 registers (profiles/r04g_dec_ab_bisect_walk_pipe_rowfill.txt, r03i_*).  And spreading the
   //  block's stores thin behind the steps of the streams the wave decodes next: no gain - what the unshuffle costs is its STORES, however they
   //  are issued (profiles/r04h_dec_ab_unshuffle_loads_vs_stores.txt, r04l_dec_ab_background_stores_experiment.txt).)
-  {
-    for (; e + 1024u <= N; e += 1024u) {
-      Rows<T> a, b, c, d;
+  auto group = [&](auto gtag) {
+    constexpr int G = decltype(gtag)::value;
+    for (; e + 1024u * G <= N; e += 1024u * G) {
+      Rows<T> x[4 * G];
 #pragma unroll
-      for (int j = 0; j < T; j++) {
-        const bool in_span = e >= lo[j] && e < hi[j];            // wave-uniform
-        const bool reg = in_span && ((small >> j) & 1u);
-        if (reg) { a.r[j] = b.r[j] = c.r[j] = d.r[j] = pr[j]; }   // scalar branch: no load at all
-        else if (in_span && ((self >> j) & 1u)) {                 // the plane's own period in front of the span, address per lane
-          const uint32_t o = ob[j] & 0xffffffu, m = (1u << (ob[j] >> 24)) - 1u;
-          const uint32_t q = e + l4 - o;
-          a.r[j] = ld4_plane(pl[j] + o + (q & m)); b.r[j] = ld4_plane(pl[j] + o + ((q + 256u) & m));
-          c.r[j] = ld4_plane(pl[j] + o + ((q + 512u) & m)); d.r[j] = ld4_plane(pl[j] + o + ((q + 768u) & m));
-        } else {
-          const gu8* p = in_span ? pat + (size_t)j * SPAN_PAT + (e & (SPAN_PAT - 1u)) : pl[j] + e;
-          a.r[j] = ld4_plane(p + l4); b.r[j] = ld4_plane(p + l4 + 256u); c.r[j] = ld4_plane(p + l4 + 512u); d.r[j] = ld4_plane(p + l4 + 768u);
+      for (int h = 0; h < G; h++) {
+        const uint32_t eh = e + 1024u * (uint32_t)h;
+#pragma unroll
+        for (int j = 0; j < T; j++) {
+          const bool in_span = eh >= lo[j] && eh < hi[j];          // wave-uniform
+          const bool reg = in_span && ((small >> j) & 1u);
+          if (reg) { x[4 * h].r[j] = x[4 * h + 1].r[j] = x[4 * h + 2].r[j] = x[4 * h + 3].r[j] = pr[j]; }   // scalar branch: no load at all
+          else if (in_span && ((self >> j) & 1u)) {                 // the plane's own period in front of the span, address per lane
+            const uint32_t o = ob[j] & 0xffffffu, m = (1u << (ob[j] >> 24)) - 1u;
+            const uint32_t q = eh + l4 - o;
+            x[4 * h].r[j] = ld4_plane(pl[j] + o + (q & m)); x[4 * h + 1].r[j] = ld4_plane(pl[j] + o + ((q + 256u) & m));
+            x[4 * h + 2].r[j] = ld4_plane(pl[j] + o + ((q + 512u) & m)); x[4 * h + 3].r[j] = ld4_plane(pl[j] + o + ((q + 768u) & m));
+          } else {
+            const gu8* p = in_span ? pat + (size_t)j * SPAN_PAT + (eh & (SPAN_PAT - 1u)) : pl[j] + eh;
+            x[4 * h].r[j] = ld4_plane(p + l4); x[4 * h + 1].r[j] = ld4_plane(p + l4 + 256u); x[4 * h + 2].r[j] = ld4_plane(p + l4 + 512u); x[4 * h + 3].r[j] = ld4_plane(p + l4 + 768u);
+          }
         }
       }
-      unshuffle_store<T>(dst, e, lane, a); unshuffle_store<T>(dst, e + 256u, lane, b);
-      unshuffle_store<T>(dst, e + 512u, lane, c); unshuffle_store<T>(dst, e + 768u, lane, d);
+#pragma unroll
+      for (int k = 0; k < 4 * G; k++) unshuffle_store<T>(dst, e + 256u * (uint32_t)k, lane, x[k]);
     }
-  }
+  };
+  // bytes in flight per wave and group: G * 1024 * T (typesize 8: 8 KiB per quarter-group)
+  constexpr int GMAIN = BAMD_UNSH_BYTES / (1024 * T) > 1 ? BAMD_UNSH_BYTES / (1024 * T) : 1;
+  if constexpr (GMAIN > 1) group(std::integral_constant<int, GMAIN>{});
+  group(std::integral_constant<int, 1>{});
   // behind the last multiple of 1024 nothing is skipped
   for (; e + 256u <= N; e += 256u) {
     Rows<T> x;
@@ -534,7 +554,7 @@ __device__ __attribute__((noinline)) void unshuffle_block_generic(volatile uint3
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fused bit-unshuffle of one block by ONE wavefront (typesize 1, 2 or 4), round 4: the wave that completes a block's last stream runs it
+// Fused bit-unshuffle of one block by ONE wavefront (typesize 1, 2, 4; 8 since round 5), round 4: the wave that completes a block's last stream runs it
 // out of its XCD's L2, exactly like the byte unshuffle above - there is no k_bitunshuffle pass over the batch any more (3.9 ms per 8 GiB on
 // config #3, 2 x nbytes of traffic that SURVEY 8d says must not be credited).  Inverse of blosc_internal_bitshuffle
 // (blosc/shuffle.c:393-443, bitshuffle-generic.c:125-139, :208-220): the filtered block is 8 T bit rows of N / 8 bytes (row 8 j + b = bit b
@@ -545,9 +565,14 @@ __device__ __attribute__((noinline)) void unshuffle_block_generic(volatile uint3
 // filter not applied when bsize < T (blosc.c:608-609), whole block copied when the element count is not a multiple of 8
 // (shuffle.c:412-414), trailing bsize mod T bytes copied.
 // ---------------------------------------------------------------------------------------------
-template <int T>
+// EPL = elements a lane owns per pass: 32 (typesize 1 / 2 / 4: a dword of every bit row per lane) or 16 (typesize 8, round 5: two bytes of each of
+// its 64 rows per lane - a wave load still reads 128 contiguous bytes of a row - so that the pass's 8 KiB of element bytes fit the wave's LDS
+// and 32 registers)
+template <int T, int EPL>
 __device__ __forceinline__ void bitunshuffle_pass(lu8* S, const gu8* src, gu8* dst, uint32_t rowlen, uint32_t e0, uint32_t nchunks, int lane) {
-  constexpr uint32_t CB = 32u * T, CS = CB + 16u, NDW = CB / 4u;
+  constexpr uint32_t CB = (uint32_t)EPL * T, CS = CB + 16u, NDW = CB / 4u;
+  constexpr int G = EPL / 8;
+  static_assert(EPL == 32 || EPL == 16, "a dword or two bytes of every bit row per lane");
   static_assert(64u * CS <= DR_LDS_BYTES, "the staging tile of a pass must fit the LDS a wave owns (a 4 KiB history ring - profiles/r04u_* - would need 32-chunk passes)");
   const uint32_t m0 = e0 >> 3, t = (uint32_t)lane;
   if (t < nchunks) {
@@ -558,9 +583,12 @@ __device__ __forceinline__ void bitunshuffle_pass(lu8* S, const gu8* src, gu8* d
     for (int j = 0; j < T; j++) {
       uint32_t rw[8];
 #pragma unroll
-      for (int b = 0; b < 8; b++) rw[b] = g_ld4(src + (size_t)(8 * j + b) * rowlen + m0 + 4u * t);
+      for (int b = 0; b < 8; b++) {
+        const gu8* rp = src + (size_t)(8 * j + b) * rowlen + m0 + (uint32_t)G * t;
+        rw[b] = G == 4 ? g_ld4(rp) : g_ld2(rp);
+      }
 #pragma unroll
-      for (int g = 0; g < 4; g++) {
+      for (int g = 0; g < G; g++) {
         uint64_t v = 0;
 #pragma unroll
         for (int b = 0; b < 8; b++) v |= (uint64_t)((rw[b] >> (8 * g)) & 0xffu) << (8 * b);
@@ -579,7 +607,7 @@ __device__ __forceinline__ void bitunshuffle_pass(lu8* S, const gu8* src, gu8* d
   gu8* out = dst + (size_t)e0 * T;
   const uint32_t npieces = nchunks * CB / 16u;
 #pragma unroll
-  for (uint32_t i = 0; i < 2u * T; i++) {
+  for (uint32_t i = 0; i < CB / 16u; i++) {
     const uint32_t q = (uint32_t)lane + 64u * i, off = 16u * q, c = off / CB;
     if (q < npieces) st16_dst(out + off, l_ld16(S + c * CS + (off - c * CB)));
   }
@@ -587,6 +615,7 @@ __device__ __forceinline__ void bitunshuffle_pass(lu8* S, const gu8* src, gu8* d
 }
 template <int T>
 __device__ void bitunshuffle_block_wave_T(lu8* S, const gu8* src, gu8* dst, uint32_t bsize, int lane) {
+  constexpr int EPL = T == 8 ? 16 : 32;
   const uint32_t N = bsize / T;
   if (bsize < T || (N & 7u)) {                         // not filtered at all / copied verbatim by the filter
     for (uint32_t k = 16u * (uint32_t)lane; k < bsize; k += 1024u) {
@@ -597,9 +626,9 @@ __device__ void bitunshuffle_block_wave_T(lu8* S, const gu8* src, gu8* dst, uint
   }
   const uint32_t rowlen = N >> 3;
   uint32_t e0 = 0;
-  for (; e0 + 2048u <= N; e0 += 2048u) bitunshuffle_pass<T>(S, src, dst, rowlen, e0, 64u, lane);
-  if (N - e0 >= 32u) { const uint32_t nch = (N - e0) >> 5; bitunshuffle_pass<T>(S, src, dst, rowlen, e0, nch, lane); e0 += 32u * nch; }
-  // fewer than 32 elements left (a multiple of 8): one byte of every bit row per lane, eight elements each
+  for (; e0 + 64u * EPL <= N; e0 += 64u * EPL) bitunshuffle_pass<T, EPL>(S, src, dst, rowlen, e0, 64u, lane);
+  if (N - e0 >= (uint32_t)EPL) { const uint32_t nch = (N - e0) / (uint32_t)EPL; bitunshuffle_pass<T, EPL>(S, src, dst, rowlen, e0, nch, lane); e0 += (uint32_t)EPL * nch; }
+  // fewer than EPL elements left (a multiple of 8): one byte of every bit row per lane, eight elements each
   if ((uint32_t)lane < ((N - e0) >> 3)) {
     const uint32_t m = (e0 >> 3) + (uint32_t)lane;
 #pragma unroll
@@ -614,13 +643,14 @@ __device__ void bitunshuffle_block_wave_T(lu8* S, const gu8* src, gu8* dst, uint
   }
   for (uint32_t k = N * T + (uint32_t)lane; k < bsize; k += 64u) dst[k] = src[k];
 }
-__device__ __forceinline__ bool bitunshuffle_fused_T(int T) { return T == 1 || T == 2 || T == 4; }
+__device__ __forceinline__ bool bitunshuffle_fused_T(int T) { return T == 1 || T == 2 || T == 4 || T == 8; }
 __device__ __attribute__((noinline)) void bitunshuffle_block_wave(volatile uint32_t* lds_, const uint8_t* src_, uint8_t* dst_, uint32_t bsize_, int typesize_, int lane) {
   const uint64_t lv = (uint64_t)lds_;
   lu8* S = (lu8*)(BAMD_LAS uint32_t*)(volatile uint32_t*)(((uint64_t)uni((uint32_t)(lv >> 32)) << 32) | uni((uint32_t)lv));
   const gu8* src = uni_ptr(as_global(src_)); gu8* dst = uni_ptr(as_global(dst_));
   const uint32_t bsize = uni(bsize_); const int T = (int)uni((uint32_t)typesize_);
-  if (T == 4) bitunshuffle_block_wave_T<4>(S, src, dst, bsize, lane);
+  if (T == 8) bitunshuffle_block_wave_T<8>(S, src, dst, bsize, lane);
+  else if (T == 4) bitunshuffle_block_wave_T<4>(S, src, dst, bsize, lane);
   else if (T == 2) bitunshuffle_block_wave_T<2>(S, src, dst, bsize, lane);
   else bitunshuffle_block_wave_T<1>(S, src, dst, bsize, lane);
 }
@@ -649,6 +679,9 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
   SpanCtx sp;
   sp.enabled = ((mode & CH_FUSED_UNSHUF) && nstreams == uni((uint32_t)c->typesize) && spans && !unshuffle_generic_T(uni((uint32_t)c->typesize))) ? 1u : 0u;
   sp.lo = 0; sp.hi = 0; sp.off = 0; sp.pat = uni_ptr(as_global(pat)) + (size_t)sid * SPAN_PAT;
+#ifdef BAMD_LOO_PLANES
+  sp.loo = (sp.enabled && (((uint32_t)(BAMD_LOO_PLANES) >> ((sid - uni((uint32_t)b->first_stream)) & 31u)) & 1u)) ? 1u : 0u;
+#endif
   const uint64_t cost_t0 = __builtin_amdgcn_s_memtime();
   int got;
   bool raw_in_place = false;

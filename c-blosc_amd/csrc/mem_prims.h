@@ -45,6 +45,8 @@ __device__ __forceinline__ uint4 g_ld16_nt(const gu8* p) {
 __device__ __forceinline__ uint32_t g_ld4_nt(const gu8* p) { return __builtin_nontemporal_load((const BAMD_GAS u32una*)p); }
 __device__ __forceinline__ uint32_t g_ld4(const gu8* p) { return *(const BAMD_GAS u32una*)p; }
 __device__ __forceinline__ uint64_t g_ld8(const gu8* p) { return *(const BAMD_GAS u64una*)p; }
+__device__ __forceinline__ uint32_t g_ld2(const gu8* p) { return (uint32_t)*(const BAMD_GAS u16una*)p; }
+__device__ __forceinline__ void g_st2(gu8* p, uint32_t v) { *(BAMD_GAS u16una*)p = (uint16_t)v; }
 __device__ __forceinline__ void g_st4(gu8* p, uint32_t v) { *(BAMD_GAS u32una*)p = v; }
 __device__ __forceinline__ void g_st8(gu8* p, uint64_t v) { *(BAMD_GAS u64una*)p = v; }
 __device__ __forceinline__ void g_st8_nt(gu8* p, uint64_t v) { __builtin_nontemporal_store(v, (BAMD_GAS u64una*)p); }

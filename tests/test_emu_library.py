@@ -103,6 +103,26 @@ def test_split_blocks_followed_by_an_unsplit_leftover_block(emulib, oracle, ref)
         assert r2 == n and np.array_equal(out, data)
 
 
+@pytest.mark.parametrize("T", [8, 4, 1])
+def test_bitshuffle_inside_the_codec_kernels(emulib, oracle, ref, T):
+    """Bit(un)shuffle as work of the encode / decode kernels' own waves (enc_shuffle.h: bitshuffle_block_wave_T, k_decode.hip:
+    bitunshuffle_block_wave_T; typesize 8 since round 5 with 16 elements per lane and pass): split blocks whose element count is a multiple of
+    the pass (2048 / 1024), of the lane chunk (32 / 16), of 8 only, and not of 8 (the filter then copies the block, shuffle.c:412-414), a
+    leftover block, trailing bytes - written here and read by everybody, written by the oracle and read here."""
+    for n in [T * (2048 * 2 + 1024 + 48 + 8) + (T - 1), T * 1000 + 3, T * (16384 + 24), 8 * T, 5 * T]:
+        for dname in ("smallints", "bench19"):
+            data = DATASETS[dname](n)
+            for cname in (b"lz4", b"blosclz"):
+                for blocksize in (0, 4096):
+                    r, chunk = _compress(emulib, data, T, 5, 2, cname, blocksize=blocksize)
+                    assert r > 0, (T, n, dname, cname, blocksize)
+                    _everybody_reads(emulib, oracle, ref, chunk, data)
+                    ro, stock = orc_compress(oracle, data, T, 5, 2, cname.decode(), blocksize=blocksize)
+                    assert ro > 0 and header(stock)["blocksize"] == header(chunk)["blocksize"]
+                    r2, out = _decompress(emulib, stock, n)
+                    assert r2 == n and np.array_equal(out, data), (T, n, dname, cname, blocksize)
+
+
 @pytest.mark.parametrize("T", [2, 16])
 def test_typesize_2_and_16_take_the_fused_paths(emulib, oracle, ref, T):
     """Round 3: the byte (un)shuffle of typesize 2 and 16 runs inside the encode / decode kernels like that of 4 and 8 (enc_shuffle.h:

@@ -1,8 +1,8 @@
-"""GPU: bitshuffle chunks of typesize 1 / 2 / 4 are bit-unshuffled INSIDE the decode kernel (round 4: the wave that completes a block's last
+"""GPU: bitshuffle chunks of typesize 1 / 2 / 4 / 8 (8: round 5, two bytes of every bit row per lane) are bit-unshuffled INSIDE the decode kernel (round 4: the wave that completes a block's last
 stream transposes the block, k_decode.hip: bitunshuffle_block_wave) - no k_bitunshuffle pass.  Reference-written chunks (oracle = pinned to
 the reference), every corner rule of blosc/shuffle.c:393-443: element counts that are not multiples of 8 (whole block copied), of 32 and of
-2048 (the wave's partial passes), trailing bytes, leftover blocks, blocks smaller than the type size; typesize 8 and 3 keep the stand-alone
-kernels (and must still be right).  The kernel profile says which path ran."""
+2048 / 1024 (the wave's partial passes), trailing bytes, leftover blocks, blocks smaller than the type size; typesize 3 (and every other
+odd size) keeps the stand-alone kernels (and must still be right).  The kernel profile says which path ran."""
 import numpy as np
 import pytest
 
@@ -19,7 +19,7 @@ def _launches(pkg, name):
 @pytest.mark.parametrize("T", [1, 2, 4, 8, 3])
 def test_bitshuffle_chunks_decode_like_the_reference(pkg, lib, oracle, codec, T):
     rng = np.random.default_rng(100 + T)
-    sizes = [8 << 20, (4 << 20) + 40, 641091, 2048 * T * 5 + 32 * T * 3 + 8 * T + (T - 1), 1000 * T, 31 * T, 7, T - 1 if T > 1 else 1, 65536 * T + 8 * T]
+    sizes = [8 << 20, (4 << 20) + 40, 641091, 2048 * T * 5 + 32 * T * 3 + 8 * T + (T - 1), 1024 * T * 3 + 16 * T * 5 + 8 * T, 1000 * T, 31 * T, 7, T - 1 if T > 1 else 1, 65536 * T + 8 * T]
     for n in sizes:
         if n <= 0:
             continue
@@ -32,18 +32,18 @@ def test_bitshuffle_chunks_decode_like_the_reference(pkg, lib, oracle, codec, T)
                 got_r, got = pkg.decompress(chunk, n)
                 lib.blosc_gpu_profile(0)
                 assert got_r == n and np.array_equal(got, data), (codec, T, n, dname, blocksize)
-                fused = T in (1, 2, 4)
+                fused = T in (1, 2, 4, 8)
                 memcpyed = bool(chunk[2] & 2)
                 if not memcpyed and n >= T:
                     assert (_launches(pkg, "k_bitunshuffle") == 0) == fused, (codec, T, n, _launches(pkg, "k_bitunshuffle"))
 
 
 def test_mixed_batch_of_fused_and_stand_alone_bit_chunks(pkg, oracle):
-    """typesize 4 (fused) and typesize 8 (stand-alone kernels) bitshuffle chunks in ONE batch: the stand-alone pass must leave the fused chunks alone."""
+    """typesize 4 / 8 / 2 (fused) and typesize 3 / 6 (stand-alone kernels) bitshuffle chunks in ONE batch: the stand-alone pass must leave the fused chunks alone."""
     import ctypes as C
     datas, chunks = [], []
-    for k, T in enumerate([4, 8, 4, 8, 2, 8]):
-        n = (1 << 20) + 64 * k
+    for k, T in enumerate([4, 3, 8, 6, 2, 8, 3]):
+        n = (1 << 20) + 48 * k
         d = DATASETS["bench19" if k % 2 == 0 else "smallints"](n)
         r, ch = orc_compress(oracle, d, T, 5, 2, "lz4")
         datas.append(d); chunks.append(ch)
@@ -60,10 +60,10 @@ def test_mixed_batch_of_fused_and_stand_alone_bit_chunks(pkg, oracle):
 @pytest.mark.parametrize("codec", ["lz4", "blosclz", "zstd"])
 @pytest.mark.parametrize("T", [1, 2, 4, 8, 3])
 def test_bitshuffle_chunks_written_here_are_read_by_the_reference(pkg, lib, oracle, codec, T):
-    """The compress side: bitshuffle of typesize 1 / 2 / 4 is a task of the encode kernel (enc_shuffle.h: bitshuffle_block_wave_T), no
+    """The compress side: bitshuffle of typesize 1 / 2 / 4 / 8 is a task of the encode kernel (enc_shuffle.h: bitshuffle_block_wave_T), no
     k_bitshuffle pass; the chunks must decode bit-exactly with the oracle (= the reference's reader) and with our own decoder."""
     from helpers import orc_decompress
-    sizes = [8 << 20, (4 << 20) + 40, 641091, 2048 * T * 5 + 32 * T * 3 + 8 * T + (T - 1), 1000 * T, 31 * T, 7, 65536 * T + 8 * T]
+    sizes = [8 << 20, (4 << 20) + 40, 641091, 2048 * T * 5 + 32 * T * 3 + 8 * T + (T - 1), 1024 * T * 3 + 16 * T * 5 + 8 * T, 1000 * T, 31 * T, 7, 65536 * T + 8 * T]
     for n in sizes:
         for dname in ("bench19", "smallints"):
             data = DATASETS[dname](n)
@@ -73,7 +73,7 @@ def test_bitshuffle_chunks_written_here_are_read_by_the_reference(pkg, lib, orac
             assert r > 0, (codec, T, n, r)
             memcpyed = bool(chunk[2] & 2)
             if not memcpyed:
-                assert (_launches(pkg, "k_bitshuffle") == 0) == (T in (1, 2, 4)), (codec, T, n)
+                assert (_launches(pkg, "k_bitshuffle") == 0) == (T in (1, 2, 4, 8)), (codec, T, n)
             if codec != "zstd":                                    # (the plain-C oracle reads LZ4 / BloscLZ; Zstd chunks go through our decoder below and the reference in test_gpu_zstd.py)
                 ro, back = orc_decompress(oracle, chunk, n)
                 assert ro == n and np.array_equal(back, data), (codec, T, n, dname)
