@@ -59,6 +59,7 @@ CONFIGS = {
     "3":  dict(codec="lz4", shuffle=2, typesize=4, clevel=5, data="bench19"),
     "3b": dict(codec="lz4", shuffle=2, typesize=4, clevel=5, data="arange"),
     "3c": dict(codec="lz4", shuffle=2, typesize=4, clevel=5, data="smallints"),
+    "3e": dict(codec="lz4", shuffle=2, typesize=8, clevel=5, data="bench19"),      # bitshuffle at typesize 8 (float64 + bitshuffle: inside the codec kernels since round 5)
     "4":  dict(codec="zstd", shuffle=1, typesize=8, clevel=3, data="bench19"),
     "4b": dict(codec="zstd", shuffle=1, typesize=8, clevel=3, data="linspace"),
     "4c": dict(codec="zstd", shuffle=1, typesize=8, clevel=3, data="randwalk"),
@@ -784,7 +785,7 @@ def main():
     mixed = None
     if args.config == "2" and not overridden and not args.no_extra and world == 1:
         extra = {}
-        for name in ("3", "4", "1g", "2t", "2x"):       # 1g: config #1's call (BloscLZ) on the GPU; 2t / 2x: config 2 at typesize 2 and 16 (the reference's bench takes the typesize as an argument over the same data, bench/bench.c:250-320)
+        for name in ("3", "4", "1g", "2t", "2x", "3e"):       # 1g: config #1's call (BloscLZ) on the GPU; 2t / 2x: config 2 at typesize 2 and 16, 3e: config 3 at typesize 8 (the reference's bench takes the typesize as an argument over the same data, bench/bench.c:250-320)
             r = measure(rig, name, dict(CONFIGS[name]), min(args.steps, 5), 1, args)
             r.pop("_host_chunk")
             keep = ("value", "unit", "steps", "ms_per_step", "first_call_ms", "sched_cold", "ratio", "roofline", "kernels", "decompress_stock_chunks", "verified", "compress", "decompress")

@@ -31,6 +31,9 @@ constexpr uint32_t DR_STEP_MAX = 2048u;            // output bytes of one batche
 #ifndef BAMD_DEC_INBLOCKS
 #define BAMD_DEC_INBLOCKS 4
 #endif
+#ifndef BAMD_DEC_LAZYIN
+#define BAMD_DEC_LAZYIN 0
+#endif
 constexpr uint32_t DR_INB = BAMD_DEC_INBLOCKS;     // input ring: this many blocks of 256 bytes (a power of two >= 2)
 constexpr uint32_t DR_IN = 256u * DR_INB;
 constexpr uint32_t DR_LDS_BYTES = 256u + DR_IN + DR_RING;   // 64 scratch dwords | input ring | history ring
@@ -85,7 +88,13 @@ __device__ __forceinline__ void dr_input(RingIO& io, uint32_t ip) {
   const uint32_t bi = ip >> 8;
   if (bi > io.b_hi) { io.pend = 0u; io.b_hi = bi; }            // jumped over everything present (a long literal run): start again at ip's block
   // the block requested earlier goes in once nothing still needed lives in its slot (its old tenant is block b_hi - 4)
+#if BAMD_DEC_LAZYIN > 0
+  // ... and not before the BAMD_DEC_LAZYIN-th call after the request unless this call needs it: the first use of pv is where the wave waits for
+  // the load, and a step is shorter than a memory round trip under load
+  if (io.pend && io.b_hi < bi + DR_INB && (((ip + 71u) >> 8) >= io.b_hi || ++io.pend > (uint32_t)BAMD_DEC_LAZYIN)) { dr_in_store(io, io.b_hi, io.pv); io.b_hi++; io.pend = 0u; }
+#else
   if (io.pend && io.b_hi < bi + DR_INB) { dr_in_store(io, io.b_hi, io.pv); io.b_hi++; io.pend = 0u; }
+#endif
   if (((ip + 71u) >> 8) >= io.b_hi) {                          // stream start, behind a jump, or the prefetch fell behind: up to three blocks in one round trip
     const uint32_t room = DR_INB - (io.b_hi - bi);             // blocks that may come in without evicting ip's own (b_hi - bi is 0 or 1 here)
     const uint32_t v0 = dr_in_load(io.in, io.n, io.b_hi, io.lane);

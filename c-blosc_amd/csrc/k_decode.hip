@@ -308,7 +308,10 @@ __device__ void unshuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize,
     }
   };
   // bytes in flight per wave and group: G * 1024 * T (typesize 8: 8 KiB per quarter-group)
-  constexpr int GMAIN = BAMD_UNSH_BYTES / (1024 * T) > 1 ? BAMD_UNSH_BYTES / (1024 * T) : 1;
+  // Round 5 (profiles/r05a_dec_ab.txt, reference-written bench19 chunks): 16 KiB in flight are worth - 4.5 % at typesize 2 (8 quarter-groups) and
+  // - 1.8 % at typesize 4 (4), + 4 % at typesize 8 (2: the second register set pushes the callee's saves up); 32 KiB are slower everywhere.
+  constexpr int GDEF = T == 2 ? 8 : (T == 4 ? 4 : 1);
+  constexpr int GMAIN = BAMD_UNSH_BYTES ? (BAMD_UNSH_BYTES / (1024 * T) > 1 ? BAMD_UNSH_BYTES / (1024 * T) : 1) : GDEF;
   if constexpr (GMAIN > 1) group(std::integral_constant<int, GMAIN>{});
   group(std::integral_constant<int, 1>{});
   // behind the last multiple of 1024 nothing is skipped

@@ -105,5 +105,5 @@ def test_bench_line_fits_the_drivers_tail():
     for k in ("value", "ms_per_step", "config", "roofline", "cpu_baseline", "legs", "extra_file"):
         assert k in d, k
     assert d["roofline"]["frac"] > 0 and d["roofline"]["decode_stock"]["frac"] > 0 and d["cpu_baseline"]["value"] > 0
-    assert set(d["legs"]) >= {"3", "4", "1g", "2t", "2x", "mixed"}
+    assert set(d["legs"]) >= {"3", "4", "1g", "2t", "2x", "3e", "mixed"}
     assert os.path.exists(os.path.join(ROOT, d["extra_file"]))

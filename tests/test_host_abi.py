@@ -96,3 +96,21 @@ def test_no_gpu_fails_loudly(lib):
     chunk = np.fromfile(os.path.join(ROOT, "tests", "golden", "compat", "blosc-1.18.0-lz4.cdata"), np.uint8)
     assert lib.blosc_decompress_ctx(ptr(chunk), ptr(np.zeros(4000000, np.uint8)), 4000000, 1) == -1
     assert lib.blosc_getitem(ptr(chunk), 0, 10, ptr(out)) == -1
+
+
+def test_rccl_exchange_library_exports_its_header():
+    """include/blosc_gpu_rccl.h: every declared entry point is exported by c-blosc_amd/libblosc_amd_rccl.so (a library of its own: the drop-in must
+    not depend on RCCL), and the drop-in does not link RCCL."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "blosc_gpu_rccl.h")).read()
+    names = set(re.findall(r"BLOSC_EXPORT\s+\w[\w\s\*]*?\b(blosc_gpu_\w+)\s*\(", hdr))
+    assert len(names) == 8, names
+    so = os.path.join(root, "c-blosc_amd", "libblosc_amd_rccl.so")
+    assert os.path.exists(so), "build it: make -C c-blosc_amd"
+    syms = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    for n in names:
+        assert re.search(rf"\bT {n}\b", syms), n
+    needed = subprocess.run(["readelf", "-d", os.path.join(root, "c-blosc_amd", "libblosc_amd.so")], capture_output=True, text=True, check=True).stdout
+    assert "rccl" not in needed
