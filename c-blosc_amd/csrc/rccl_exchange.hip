@@ -8,6 +8,7 @@
 #include <string.h>
 #include <vector>
 #include "../../include/blosc_gpu_rccl.h"
+#include "../../include/blosc_gpu.h"
 
 static_assert(BLOSC_GPU_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "the id the caller carries between ranks is RCCL's");
 
@@ -222,6 +223,44 @@ int blosc_gpu_scatter_chunks(blosc_gpu_comm* c, size_t nchunks, const int* table
   X_NCCL(ncclGroupEnd());
   X_HIP(hipStreamSynchronize(c->stream));
   return 0;
+}
+
+// ---- the sharded calls: partition + the drop-in's batched call on the own range + the exchanges above ----
+int blosc_gpu_compress_sharded(blosc_gpu_comm* c, int clevel, int doshuffle, size_t typesize, const char* compressor, size_t blocksize,
+                               size_t nchunks, const void* const* src, const size_t* nbytes, void* const* dest, const size_t* destsize,
+                               int* table, void* container, size_t container_capacity, int root, size_t* offsets, size_t* container_bytes) {
+  if (!c || !table || (nchunks && (!src || !nbytes || !dest || !destsize)) || nchunks > 0x7fffffffu) return -1;
+  size_t lo, hi;
+  range_of(nchunks, c->world, c->rank, &lo, &hi);
+  X_HIP(hipSetDevice(c->device));
+  std::vector<int> local(hi - lo + 1, 0);
+  if (hi > lo) {
+    // blosc_gpu_set_device is process-wide: in the thread-per-GPU layout the call must not move other threads, so the device is bound the way
+    // the _multi calls bind it - through a one-device _multi call on this rank's device
+    const int dev = c->device;
+    if (blosc_gpu_compress_batch_multi(1, &dev, clevel, doshuffle, typesize, compressor, blocksize, (int)(hi - lo), src + lo, nbytes + lo, dest + lo, destsize + lo, local.data()) != 0) return -2;
+  }
+  int rc = blosc_gpu_allgather_cbytes(c, nchunks, local.data(), table);
+  if (rc) return rc;
+  const size_t total = bytes_of(table, 0, nchunks);
+  if (container_bytes) *container_bytes = total;
+  if ((root < 0 || root == c->rank) && total > container_capacity) return -1;
+  return blosc_gpu_gather_chunks(c, nchunks, table, (const void* const*)(dest + lo), container, root, offsets);
+}
+
+int blosc_gpu_decompress_sharded(blosc_gpu_comm* c, size_t nchunks, const int* table, const void* container, int root,
+                                 void* packed, size_t packed_capacity, void* const* dest, const size_t* destsize, int* nbytes_out) {
+  if (!c || (nchunks && (!table || !dest || !destsize || !nbytes_out)) || nchunks > 0x7fffffffu) return -1;
+  size_t lo, hi;
+  range_of(nchunks, c->world, c->rank, &lo, &hi);
+  if (bytes_of(table, lo, hi) > packed_capacity) return -1;
+  std::vector<size_t> loff(hi - lo + 1, 0);
+  int rc = blosc_gpu_scatter_chunks(c, nchunks, table, container, root, packed, loff.data());
+  if (rc || hi == lo) return rc;
+  std::vector<const void*> s(hi - lo); std::vector<size_t> ss(hi - lo);
+  for (size_t ch = lo; ch < hi; ch++) { s[ch - lo] = (const uint8_t*)packed + loff[ch - lo]; ss[ch - lo] = table[ch] > 0 ? (size_t)table[ch] : 0; }
+  const int dev = c->device;
+  return blosc_gpu_decompress_batch_multi(1, &dev, (int)(hi - lo), s.data(), ss.data(), dest + lo, destsize + lo, nbytes_out + lo) == 0 ? 0 : -2;
 }
 
 }  // extern "C"

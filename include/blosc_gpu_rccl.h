@@ -54,6 +54,21 @@ BLOSC_EXPORT int blosc_gpu_gather_chunks(blosc_gpu_comm* comm, size_t nchunks, c
 BLOSC_EXPORT int blosc_gpu_scatter_chunks(blosc_gpu_comm* comm, size_t nchunks, const int* table, const void* container, int root,
                                           void* local_packed, size_t* local_offsets);
 
+/* The whole sharded compress of SURVEY 8e in one collective call per rank: this rank's range [lo, hi) = blosc_gpu_partition(nchunks, world, rank)
+ * goes through blosc_gpu_compress_batch (src / nbytes / dest / destsize are indexed by GLOBAL chunk number; only the entries of the own range are
+ * touched, and they name memory of this rank's device), the table is all-gathered, the chunks are gathered into `container` on `root` (-1: every
+ * rank).  table (host, nchunks) and offsets (host, nchunks, may be NULL) are filled on every rank.  container must hold the worst case on the
+ * receivers: sum(destsize) of all chunks, or any bound the caller knows; *container_bytes (may be NULL) gets what was used.
+ * Parameters clevel ... blocksize as in blosc_gpu_compress_batch.  Needs libblosc_amd.so (the drop-in) next to this library. */
+BLOSC_EXPORT int blosc_gpu_compress_sharded(blosc_gpu_comm* comm, int clevel, int doshuffle, size_t typesize, const char* compressor, size_t blocksize,
+                                            size_t nchunks, const void* const* src, const size_t* nbytes, void* const* dest, const size_t* destsize,
+                                            int* table, void* container, size_t container_capacity, int root, size_t* offsets, size_t* container_bytes);
+/* ... and its inverse: `root` holds the container and the table; every rank receives its range's chunks (into `packed`, device memory of
+ * packed_capacity bytes), decompresses them into dest[lo .. hi) (device memory of this rank, destsize as in blosc_gpu_decompress_batch) and
+ * reports blosc_decompress's return value per chunk in nbytes_out[lo .. hi); the other entries of dest / nbytes_out are not touched. */
+BLOSC_EXPORT int blosc_gpu_decompress_sharded(blosc_gpu_comm* comm, size_t nchunks, const int* table, const void* container, int root,
+                                              void* packed, size_t packed_capacity, void* const* dest, const size_t* destsize, int* nbytes_out);
+
 #ifdef __cplusplus
 }
 #endif

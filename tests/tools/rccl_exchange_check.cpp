@@ -91,6 +91,34 @@ static int run_rank(blosc_gpu_comm* comm) {
     if (d_cont) CHECK(hipFree(d_cont) == hipSuccess);
   }
   for (void* p : d_chunks) CHECK(hipFree(p) == hipSuccess);
+  // ---- the two one-call forms: compress + table + consolidation on rank 0, then scatter + decompress back into every rank's own memory ----
+  {
+    std::vector<const void*> src(kChunks, nullptr); std::vector<void*> dst(kChunks, nullptr), back(kChunks, nullptr); std::vector<size_t> nb(kChunks), ds(kChunks);
+    size_t worst = 0, mine_worst = 0;
+    for (int ch = 0; ch < kChunks; ch++) { nb[ch] = g_plain[ch].size(); ds[ch] = nb[ch] + 16; worst += ds[ch]; }
+    for (size_t ch = lo; ch < hi; ch++) {      // only the own range lives on this device; the other entries stay NULL and must not be touched
+      void* p; CHECK(hipMalloc(&p, nb[ch]) == hipSuccess); CHECK(hipMemcpy(p, g_plain[ch].data(), nb[ch], hipMemcpyHostToDevice) == hipSuccess); src[ch] = p;
+      CHECK(hipMalloc(&dst[ch], ds[ch]) == hipSuccess); CHECK(hipMalloc(&back[ch], nb[ch]) == hipSuccess); CHECK(hipMemset(back[ch], 0xEE, nb[ch]) == hipSuccess);
+      mine_worst += ds[ch];
+    }
+    void* d_cont = nullptr; if (rank == 0) CHECK(hipMalloc(&d_cont, worst) == hipSuccess);
+    std::vector<int> tab(kChunks, -7); std::vector<size_t> off(kChunks); size_t used = 0;
+    CHECK(blosc_gpu_compress_sharded(comm, 5, 1, 8, "lz4", 0, kChunks, src.data(), nb.data(), dst.data(), ds.data(), tab.data(), d_cont, worst, 0, off.data(), &used) == 0);
+    for (int ch = 0; ch < kChunks; ch++) CHECK(tab[ch] == g_cbytes[ch]);      // (the LZ4 encoder writes the same bytes call after call: include/blosc.h)
+    CHECK(used == total);
+    if (rank == 0) { std::vector<uint8_t> got(total); CHECK(hipMemcpy(got.data(), d_cont, total, hipMemcpyDeviceToHost) == hipSuccess); CHECK(memcmp(got.data(), want.data(), total) == 0); }
+    void* d_packed = nullptr; CHECK(hipMalloc(&d_packed, mine_worst ? mine_worst : 1) == hipSuccess);
+    std::vector<int> res(kChunks, -7);
+    CHECK(blosc_gpu_decompress_sharded(comm, kChunks, tab.data(), d_cont, 0, d_packed, mine_worst, back.data(), nb.data(), res.data()) == 0);
+    for (int ch = 0; ch < kChunks; ch++) {
+      if ((size_t)ch < lo || (size_t)ch >= hi) { CHECK(res[ch] == -7); continue; }
+      CHECK(res[ch] == (int)nb[ch]);
+      std::vector<uint8_t> got(nb[ch]); CHECK(hipMemcpy(got.data(), back[ch], nb[ch], hipMemcpyDeviceToHost) == hipSuccess);
+      CHECK(memcmp(got.data(), g_plain[ch].data(), nb[ch]) == 0);
+    }
+    for (size_t ch = lo; ch < hi; ch++) { CHECK(hipFree((void*)src[ch]) == hipSuccess); CHECK(hipFree(dst[ch]) == hipSuccess); CHECK(hipFree(back[ch]) == hipSuccess); }
+    CHECK(hipFree(d_packed) == hipSuccess); if (d_cont) CHECK(hipFree(d_cont) == hipSuccess);
+  }
   return 0;
 }
 
