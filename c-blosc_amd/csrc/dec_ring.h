@@ -3,7 +3,7 @@
 // Replaces  LZ4_decompress_safe  (internal-complibs/lz4-1.10.0/lz4.c:2451 -> LZ4_decompress_generic :2023-2445) for one stream
 // (= one split of one block, blosc/blosc.c:760-787).
 //
-// Why (round 4; profiles/r03m_dec_phase_with_unshuffle_cycles.txt): the round-3 decoder wrote every literal and every match piece
+// Why (round 4; profiles/r03/r03m_dec_phase_with_unshuffle_cycles.txt): the round-3 decoder wrote every literal and every match piece
 // straight to global memory and read match sources back from there.  A batched step of 13 sequences then waits for one L2 round
 // trip under load (4 400 cycles per step on reference-written bench19 planes), a sequence of the scalar path for about five of
 // them (17 000 cycles: window fetch, length bytes, literals, match load, stores), and 112 such sequences per block were a third
@@ -215,7 +215,7 @@ __device__ __forceinline__ void dr_match(RingIO& io, uint32_t& op, uint32_t off,
   // (plane[q] = plane[b + ((q - b) & (per - 1))]: unaligned 16-byte LDS reads), the piece up to the next row boundary and the one behind
   // the last are one read + one write each, and the rows in between are the SAME registers stored to the ring and to global memory.
   // (Every ring write counted from the match's own start instead - one register set for all of them, no piece up to the row boundary - is
-  //  9 % slower: 16-byte LDS writes that are not 16-byte aligned.  profiles/r04zt_*)
+  //  9 % slower: 16-byte LDS writes that are not 16-byte aligned.  profiles/r04/r04zt_*)
   if ((off & (off - 1u)) == 0u && off <= DR_ROW && len >= 2u * DR_ROW && mpos - off >= dr_near_lo(io, mpos + off)) {
     if (off >= 64u) { dr_copy_chunk(io, mpos, mpos - off, off, false, lane); done = off; op = mpos + done; dr_flush_rows(io, op); }
     const uint32_t per = off < 64u ? 32u : off, pm = per - 1u, b0 = mpos - off, l16 = 16u * (uint32_t)lane;     // (off < 64: the head above wrote 64 bytes, off divides 32)
@@ -312,7 +312,7 @@ __device__ __forceinline__ void dr_ext_run(RingIO& io, uint32_t& ip, uint32_t& v
     if (value > cap) return;                       // the caller rejects; keeps the loop bounded by cap
     // 64 bytes of 0xFF: a long run (the one match of a constant or periodic plane is 130 KB = 513 such bytes).  The rest of it straight from
     // the stream, a dword per lane = 256 bytes per memory round trip instead of 64 per trip through the input ring (reference-written config-2 chunks - 1.5 %,
-    // profiles/r04zs_*).  A dword that reaches beyond the stream reads as a terminator at its first byte: ip then ends within four
+    // profiles/r04/r04zs_*).  A dword that reaches beyond the stream reads as a terminator at its first byte: ip then ends within four
     // bytes of the end, which every caller rejects (lz4.c:2240-2250, :2330-2342), as it would a run of real 0xFF bytes into the end.
     for (;;) {
       const uint32_t p = ip + 4u * (uint32_t)lane;
@@ -471,7 +471,7 @@ __device__ __forceinline__ uint32_t dr_step(RingIO& io, uint32_t& ip, uint32_t& 
   // ---- 2. token chain in rank space: J1 = J0 o J0, J2 = J1 o J1, J3 = J2 o J2; lane r (< 16) finds the r-th token.  (Round 4 also built
   //         a scalar walk - v_readlane with the position in an SGPR, v_writelane into the rank lane, <= 16 hops of ~10 cycles, and the
   //         literal placement through one more ds_bpermute instead of the 64-dword scratch: 2.6 % SLOWER, the kernel is bound by the
-  //         number of VALU / SALU instructions it issues and the walk adds to it: profiles/r04g_dec_ab_bisect_walk_pipe_rowfill.txt) ----
+  //         number of VALU / SALU instructions it issues and the walk adds to it: profiles/r04/r04g_dec_ab_bisect_walk_pipe_rowfill.txt) ----
   uint32_t c = 0;                                              // ip is a real token by invariant
   {
     const uint32_t J0 = nxh;
@@ -546,7 +546,7 @@ __device__ __forceinline__ uint32_t dr_step(RingIO& io, uint32_t& ip, uint32_t& 
     uint4 v16 = make_uint4(0, 0, 0, 0); uint64_t v8 = 0; uint32_t v4 = 0;
     // (Tried in round 4: the far pieces kept in their registers and stored into the ring behind the NEXT step's parse, so that their round
     //  trip runs under it.  5-9 % SLOWER on every data set, typesize 2 included where one step in two has a far source - the state it
-    //  carries across steps costs more than the wait: profiles/r04n_dec_ab_deferred_far_pieces_rejected.txt.)
+    //  carries across steps costs more than the wait: profiles/r04/r04n_dec_ab_deferred_far_pieces_rejected.txt.)
     if (anyfar) {                                              // (wave-uniform: a step without far sources never waits for memory)
       const gu8* sg = io.out + spos;
       BAMD_MEM_SYNC();
@@ -571,7 +571,7 @@ __device__ __forceinline__ uint32_t dr_step(RingIO& io, uint32_t& ip, uint32_t& 
   // ---- 5. everything else in stream order: byte lanes, the periodic extension of the off bytes in front of the match when it
   //         overlaps itself (every lane then reads only bytes that are already final).  (Bit planes send half of a step's sequences
   //         here, 5.5 dependency levels for 10 sequences per step: taking two neighbours at a time when the second does not read what
-  //         the first writes is 2 % SLOWER - the test costs more than the round trips it saves: profiles/r04zx_*, r04zy_*.) ----
+  //         the first writes is 2 % SLOWER - the test costs more than the round trips it saves: profiles/r04/r04zx_*, r04zy_*.) ----
   uint32_t rest = (uint32_t)__ballot(mine && !fast_r && (G == 0 || ml_r != 0u));      // (BloscLZ: literal runs are tokens of their own, and matches of 3 bytes go here)
   PROF_ADD(0, 1); PROF_ADD(1, cnt); PROF_ADD(2, __builtin_popcount(rest));
   while (rest) {
@@ -642,7 +642,7 @@ __device__ int lz4_decode_wave(const gu8* __restrict__ in_, int32_t n_, gu8* out
   uint32_t ip = 0, op = 0;
   for (;;) {
     // (the rows of the last step could also leave behind dr_input's wait for its prefetched block - vmcnt counts loads and stores in one
-    //  order, so that wait sits out the youngest store's round trip: no difference, profiles/r04zq_*)
+    //  order, so that wait sits out the youngest store's round trip: no difference, profiles/r04/r04zq_*)
     dr_input(io, ip);
     uint32_t hdr;
     if (ip + 72u <= n) {

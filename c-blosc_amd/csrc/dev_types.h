@@ -48,7 +48,7 @@ struct ChunkDesc {
 };
 
 // Scratch layout of a filtered chunk: plane-major per block, planes bsize / typesize bytes apart.  (Round 3 padded the planes of fused chunks
-// apart to keep them off one HBM channel: no effect, profiles/r03p_dec_ab_plane_padding_no_effect.txt - removed in round 4.)
+// apart to keep them off one HBM channel: no effect, profiles/r03/r03p_dec_ab_plane_padding_no_effect.txt - removed in round 4.)
 #if defined(__HIPCC__) || defined(BAMD_WAVE_EMU)
 #define BAMD_HD __host__ __device__
 #else

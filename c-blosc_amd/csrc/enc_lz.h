@@ -19,7 +19,7 @@ typedef uint32_t enc_entry_t;
 #endif
 constexpr int ENC_TAB_BYTES = BAMD_ENC_SPLIT_TAB ? ENC_TAB * 3 : ENC_TAB * 4;
 #ifndef BAMD_ENC_MINWAVES
-#define BAMD_ENC_MINWAVES (BAMD_ENC_SPLIT_TAB ? 6 : 5)   // waves per SIMD the register allocator leaves room for (5: + 3 %, 7 = 26 waves per CU at 72 registers: + 1.8 %, profiles/r04zu_*)
+#define BAMD_ENC_MINWAVES (BAMD_ENC_SPLIT_TAB ? 6 : 5)   // waves per SIMD the register allocator leaves room for (5: + 3 %, 7 = 26 waves per CU at 72 registers: + 1.8 %, profiles/r04/r04zu_*)
 #endif
 constexpr int ENC_LDS_WAVES = (160 * 1024) / ENC_TAB_BYTES;
 constexpr int ENC_WAVES_PER_CU = ENC_LDS_WAVES < 4 * BAMD_ENC_MINWAVES ? ENC_LDS_WAVES : 4 * BAMD_ENC_MINWAVES;   // persistent grid size per CU
@@ -233,7 +233,7 @@ __device__ __forceinline__ void emit_literals(gu8* dst, const gu8* lit, uint32_t
 }
 
 // (Round 3 also sent the common sequence shape through a 512-byte LDS ring that left 256 bytes at a time - the cure for k_zstd_seq's store
-//  acknowledgements: bit-identical output, 6 % SLOWER here - profiles/r03zj_enc_ab_run_buffer_rejected.txt; removed in round 4.)
+//  acknowledgements: bit-identical output, 6 % SLOWER here - profiles/r03/r03zj_enc_ab_run_buffer_rejected.txt; removed in round 4.)
 __device__ __forceinline__ uint32_t lz4_emit_seq(gu8* dst, uint32_t op, uint32_t cap, const gu8* lit,
                                                  uint32_t ll, uint32_t off, uint32_t mlen, int lit_lane0, uint32_t ownbyte, int lane) {
   if (op + 1u + ll + (2u + 1u + 5u) + ll / 255u > cap) return 0xffffffffu;
@@ -334,7 +334,7 @@ __device__ __forceinline__ uint32_t blz_emit_match(gu8* dst, uint32_t op, uint32
 constexpr uint32_t RANK_CAP = BAMD_ENC_RANK_CAP;   // bytes of a candidate that are compared for ranking (16 instead: more extensions, lower ratio, no faster)
 
 // (Backward extension out of registers - the 8 (or 4) bytes in front of a candidate fetched together with its 20 - was built in round 3 in
-//  two forms: bit-identical output, no gain / 3 % slower, profiles/r03l_enc_ab_back8_no_gain.txt, r03x_enc_ab_back4_ext512.txt; removed in round 4.)
+//  two forms: bit-identical output, no gain / 3 % slower, profiles/r03/r03l_enc_ab_back8_no_gain.txt, r03x_enc_ab_back4_ext512.txt; removed in round 4.)
 struct Bytes20 { uint64_t a, b; uint32_t c; };
 
 // 20 bytes at src[pos..], zero beyond n (only the last step of a stream takes the slow branch)
@@ -461,7 +461,7 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
   // below clevel 9 a match must be longer than the format minimum to be taken.  4-byte matches are mostly accidental in noisy planes, save one
   // byte each and cost a full sequence: requiring 6 halved the encode time of noisy float64 data for
   // < 1 % of ratio (bench19: 53.3 -> 48.5, still far above the reference's 36.7 at this clevel); 7 (round 4,
-  // profiles/r04zb_enc_ab_min_match_6_7_8.txt): random-walk data another - 11 %, bench19 - 2 % at ratio 47.8; 8 would cost 13 % of bench19's ratio.  LZ4 only: BloscLZ stores a stream raw below its ratio floor (blosclz.c:426-435), which low-entropy noise then misses.
+  // profiles/r04/r04zb_enc_ab_min_match_6_7_8.txt): random-walk data another - 11 %, bench19 - 2 % at ratio 47.8; 8 would cost 13 % of bench19's ratio.  LZ4 only: BloscLZ stores a stream raw below its ratio floor (blosclz.c:426-435), which low-entropy noise then misses.
   // (Zstd sequences are cheaper than LZ4's - a repeated distance costs 5 bits - so short matches pay off there.)
   static_assert(EF_ZSTD == 2, "");
   const uint32_t zmin = (uint32_t)__builtin_amdgcn_readfirstlane(BAMD_ZSTD_MINLEN);

@@ -7,7 +7,7 @@
 // bytes in registers and stores 4 bytes into every plane (each wave store writes 256 contiguous bytes).
 // ---------------------------------------------------------------------------------------------
 // (Round 3 tried the typesize-8 loads dealt so that a quad reads 64 contiguous bytes per instruction: encode 8.2 -> 10.3 ms,
-//  profiles/r03zb_ab_quad_dealt_typesize8_rejected.txt; and non-temporal source loads: no gain.  Both removed in round 4.)
+//  profiles/r03/r03zb_ab_quad_dealt_typesize8_rejected.txt; and non-temporal source loads: no gain.  Both removed in round 4.)
 template <int T>
 struct ElemRows { uint4 a, b; };
 

@@ -327,7 +327,7 @@ static bool span_enabled() { static const bool on = !(getenv("BLOSC_AMD_SPANS") 
 #endif
 static bool lz4hc_search_enabled() { const char* e = getenv("BLOSC_AMD_LZ4HC"); return e ? atoi(e) != 0 : (BAMD_LZ4HC_DEFAULT != 0); }
 #ifndef BAMD_ZSTD_TABLES_DEFAULT
-#define BAMD_ZSTD_TABLES_DEFAULT 1   // measured on MI355X (profiles/r03a_encopts_bench_cfg4t.json): bench19 ratio 18.3 -> 23.8 for +5.6 % encode time
+#define BAMD_ZSTD_TABLES_DEFAULT 1   // measured on MI355X (profiles/r03/r03a_encopts_bench_cfg4t.json): bench19 ratio 18.3 -> 23.8 for +5.6 % encode time
 #endif
 static bool zstd_tables_enabled() { const char* e = getenv("BLOSC_AMD_ZSTD_TABLES"); return e ? atoi(e) != 0 : (BAMD_ZSTD_TABLES_DEFAULT != 0); }
 static bool env_flag(const char* name) { const char* e = getenv(name); return e && atoi(e) != 0; }
@@ -336,7 +336,7 @@ static bool periodic_enabled() { static const bool on = !(getenv("BLOSC_AMD_PERI
 // BLOSC_AMD_ZSTD2: 2 (default) = two-phase path, 16 frames per wave, tables in a global scratch (k_zstd2.hip);
 // 1 = the same with the tables in LDS (one wave per CU); 0 = one wave per frame for everything (k_zstd_streams).
 // 8 GiB of reference-written frames, mode 0 / 2: bench19 107 / 50 ms, linspace 17.8 / 15.9, random walk 23.7 / 16.5
-// (profiles/r02f_zstd_decode_modes.txt)
+// (profiles/r02/r02f_zstd_decode_modes.txt)
 static int zstd2_mode() { static const int m = getenv("BLOSC_AMD_ZSTD2") ? atoi(getenv("BLOSC_AMD_ZSTD2")) : 2; return m; }
 // typesizes whose byte (un)shuffle runs inside the codec kernels (enc_shuffle.h, k_decode.hip: unshuffle_block_wave); the others, and everything
 // under BLOSC_AMD_FUSE=0 / BLOSC_AMD_SINGLE_QUEUE=1, go through the stand-alone filter kernels
@@ -461,7 +461,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   // until it has been timed on the device, read per call
   const bool ztab = zstd && zstd_tables_enabled();
   // the LZ4HC-grade search in front of the Zstd writer (with per-block tables) / the zlib writer: BLOSC_AMD_ZSTD_SEARCH=1, BLOSC_AMD_ZLIB_SEARCH=1
-  // Defaults after the device timings of round 3 (profiles/r03a_encopts_bench_*.json, 8 GiB bench19): Zstd - the search costs 2.6 x the
+  // Defaults after the device timings of round 3 (profiles/r03/r03a_encopts_bench_*.json, 8 GiB bench19): Zstd - the search costs 2.6 x the
   // encode time (35.8 -> 94.9 ms) for ratio 23.8 -> 35.1, so it serves the upper clevels (the reference maps clevel >= 6 to its
   // lazy / optimal strategies, blosc.c:502-504 + clevels.h) and stays off at the default clevel; zlib - whoever names zlib wants its
   // ratio: search + dynamic codes give 73.4 (reference 47.4, fixed codes without search 40.5) at 57 ms per 8 GiB, still 150 GB/s.
@@ -741,7 +741,7 @@ static int launch_decode(EngineState& st, const DecodeLaunch& L, hipStream_t str
     // shape is left to k_zstd_streams.
     // (Round 4 sent the batch through in 4 / 8 slices, every slice's entropy -> seq -> exec chain on a stream of its own with the entropy
     //  kernels in slice order, so that one slice's sequence chains run underneath the other slices' phases: 30.2 -> 28.5 ms on the reference
-    //  frames of config 4, 11.0 -> 13.4 ms on linspace.  The timeline (profiles/r04zp_*): the phases do overlap, but every kernel is slower
+    //  frames of config 4, 11.0 -> 13.4 ms on linspace.  The timeline (profiles/r04/r04zp_*): the phases do overlap, but every kernel is slower
     //  in company - k_zstd_seq is bound by its scattered table reads, not by an idle chip - and 8 streams share 4 hardware queues.  Not kept.)
     const int zstd2 = zstd2_mode();
     const uint32_t* d_taken = nullptr;

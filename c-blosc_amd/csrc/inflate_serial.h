@@ -81,7 +81,7 @@ typedef ZI_TAB uint16_t tab16;
 typedef ZI_TAB uint8_t tab8;
 // On the device the tables are LDS, and the symbol loop must SAY so: through `const Tabs&` the pointers are generic, the address-space
 // inference leaves volatile accesses alone, and every table lookup of k_zlib_streams was a flat_load (96 of them, not one ds_read;
-// 0.49 G flat loads per 8 GiB, profiles/r03zp_zlib_decode_sq_counters.txt) - twice the latency of an LDS read in a loop that is one
+// 0.49 G flat loads per 8 GiB, profiles/r03/r03zp_zlib_decode_sq_counters.txt) - twice the latency of an LDS read in a loop that is one
 // dependent lookup after the other.
 #if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__) && !defined(BAMD_WAVE_EMU)
 #define ZI_LDS __attribute__((address_space(3)))

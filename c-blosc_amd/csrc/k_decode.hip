@@ -38,7 +38,7 @@ __global__ void k_decode_plan(const ChunkDesc* __restrict__ chunks, const BlockD
   const bool to_filt = (c.mode & (CH_SHUFFLE | CH_BITSHUFFLE)) != 0;
   // (The scratch of block g at slot g % S of ONE arena, without any synchronisation - the most a ring of block slots could ever give: round 3,
   //  768 ... 1536 slots: no change; round 4 with the LDS ring decoder and the short lead, 256 ... 2048 slots: - 5 ... - 12 % below 640 slots, where
-  //  several live blocks share a slot, - 0 ... - 7 % and not monotonic from 768 up (profiles/r04zd_*, r04ze_*).  About 1 600 blocks are live at a
+  //  several live blocks share a slot, - 0 ... - 7 % and not monotonic from 768 up (profiles/r04/r04zd_*, r04ze_*).  About 1 600 blocks are live at a
   //  time - a block lives as long as its slowest stream - so a real ring needs that many slots and gains a few per cent at best: not built.)
   uint8_t* out = to_filt ? c.filt + (size_t)b.blk * filt_block_stride(c) : c.dst + (size_t)b.blk * c.blocksize;
   const uint32_t pstride = (to_filt && b.nstreams > 1) ? filt_plane_stride(c, (uint32_t)bsize, b.nstreams) : (uint32_t)neblock;   // split blocks: one stream per plane
@@ -64,7 +64,7 @@ __global__ void k_decode_plan(const ChunkDesc* __restrict__ chunks, const BlockD
 }
 
 // most sequences one batched step takes (dec_ring.h: dr_step, both grammars)
-constexpr uint32_t BATCH_MAXSEQ = 16;      // (32 - a fifth doubling round, the second DPP row, two passes of 4-lane pieces: half of bench19's steps hold more than 16 sequences, yet + 1 %: profiles/r04zw_*)
+constexpr uint32_t BATCH_MAXSEQ = 16;      // (32 - a fifth doubling round, the second DPP row, two passes of 4-lane pieces: half of bench19's steps hold more than 16 sequences, yet + 1 %: profiles/r04/r04zw_*)
 
 // Optional phase profiling (build with -DBAMD_PROFILE_DECODE -> libblosc_amd_prof.so, scripts/dec_phase.py):
 // 16 wave-uniform counters per stream, cycles from s_memtime.
@@ -177,16 +177,16 @@ struct Rows { uint32_t r[T]; };
 template <int T>
 struct PlanePtrs { const gu8* p[T]; };
 
-// the final output of the fused unshuffles leaves with non-temporal stores (round 2: bench19 -3.8 %, linspace -1.5 %, profiles/r02f_decode_nt_variants.txt;
-// round 4, plain against non-temporal with the ring decoder: no difference, profiles/r04i_dec_ab_dst_stores_plane_loads_nt.txt); the planes are read with
+// the final output of the fused unshuffles leaves with non-temporal stores (round 2: bench19 -3.8 %, linspace -1.5 %, profiles/r02/r02f_decode_nt_variants.txt;
+// round 4, plain against non-temporal with the ring decoder: no difference, profiles/r04/r04i_dec_ab_dst_stores_plane_loads_nt.txt); the planes are read with
 // plain loads (the rows the ring decoder flushed are in L2: non-temporal loads cost 3-6 %, same file)
 __device__ __forceinline__ void st16_dst(gu8* p, uint4 v) { g_st16_nt(p, v); }
 __device__ __forceinline__ uint32_t ld4_plane(const gu8* p) { return g_ld4(p); }
 // Which 4 elements of a 256-element step a lane's plane dwords cover (byte offset into the plane).  Typesize 2 / 4: elements
 // 4 l .. 4 l + 3, i.e. T * 4 contiguous output bytes per lane and contiguous lanes - every store instruction is one contiguous run.
 // Typesize 8 (round 4): a lane's 32 output bytes are two 16-byte stores, and dealt that way every store instruction wrote only half of
-// each 32-byte sector - the fused unshuffle is bound by exactly those stores (profiles/r04h_*: leaving the LOADS out changed nothing,
-// leaving the stores out gave the kernel 1.5 of its 1.8 ms back; profiles/r04j_*: the same bytes as contiguous 1 KiB stores: -12 ... 16 %).
+// each 32-byte sector - the fused unshuffle is bound by exactly those stores (profiles/r04/r04h_*: leaving the LOADS out changed nothing,
+// leaving the stores out gave the kernel 1.5 of its 1.8 ms back; profiles/r04/r04j_*: the same bytes as contiguous 1 KiB stores: -12 ... 16 %).
 // So lanes work in pairs: lane 2 i loads the dword of elements 4 i .. 4 i + 3, lane 2 i + 1 that of elements 128 + 4 i .. (each wave load still
 // covers two full 128-byte lines), the pair swaps halves (one DPP quad_perm per plane) and lane l then holds elements 2 l, 2 l + 1 of the
 // step's first 128 elements AND of its second 128: two stores of 1 KiB, each fully contiguous.
@@ -277,9 +277,9 @@ __device__ void unshuffle_block_wave_T(const gu8* src, gu8* dst, uint32_t bsize,
   const uint32_t l4 = unsh_l4<T>(lane);
   // (Two things round 4 tried on this loop and dropped.  A software pipeline - two register sets, the loads of group g + 1 issued before the
   //  stores of group g -: 32 % SLOWER, 5.55 against 4.20 ms; the span branches around the loads leave the compiler no exact vmcnt and the second
-  //  register set spills - round 3 had seen -10 % at 96 registers (profiles/r04g_dec_ab_bisect_walk_pipe_rowfill.txt, r03i_*).  And spreading the
+  //  register set spills - round 3 had seen -10 % at 96 registers (profiles/r04/r04g_dec_ab_bisect_walk_pipe_rowfill.txt, r03i_*).  And spreading the
   //  block's stores thin behind the steps of the streams the wave decodes next: no gain - what the unshuffle costs is its STORES, however they
-  //  are issued (profiles/r04h_dec_ab_unshuffle_loads_vs_stores.txt, r04l_dec_ab_background_stores_experiment.txt).)
+  //  are issued (profiles/r04/r04h_dec_ab_unshuffle_loads_vs_stores.txt, r04l_dec_ab_background_stores_experiment.txt).)
   auto group = [&](auto gtag) {
     constexpr int G = decltype(gtag)::value;
     for (; e + 1024u * G <= N; e += 1024u * G) {
@@ -576,7 +576,7 @@ __device__ __forceinline__ void bitunshuffle_pass(lu8* S, const gu8* src, gu8* d
   constexpr uint32_t CB = (uint32_t)EPL * T, CS = CB + 16u, NDW = CB / 4u;
   constexpr int G = EPL / 8;
   static_assert(EPL == 32 || EPL == 16, "a dword or two bytes of every bit row per lane");
-  static_assert(64u * CS <= DR_LDS_BYTES, "the staging tile of a pass must fit the LDS a wave owns (a 4 KiB history ring - profiles/r04u_* - would need 32-chunk passes)");
+  static_assert(64u * CS <= DR_LDS_BYTES, "the staging tile of a pass must fit the LDS a wave owns (a 4 KiB history ring - profiles/r04/r04u_* - would need 32-chunk passes)");
   const uint32_t m0 = e0 >> 3, t = (uint32_t)lane;
   if (t < nchunks) {
     uint32_t w[NDW];
@@ -727,7 +727,7 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
   //    the incremented value reads the same L2 the rows are in;
   //  * the consumer's `buffer_inv sc1` (the acquire fence behind the test) drops its CU's L1 lines, so its loads go to that L2.
   // What an agent-scope RELEASE would add is `buffer_wbl2`: a write-back of the XCD's whole L2 to memory, needed only when the reader
-  // sits behind a DIFFERENT L2.  Timed in round 4 (profiles/r04s_dec_ab_handoff_release_vs_relaxed.txt): 7.63 against 4.09 ms per
+  // sits behind a DIFFERENT L2.  Timed in round 4 (profiles/r04/r04s_dec_ab_handoff_release_vs_relaxed.txt): 7.63 against 4.09 ms per
   // 8 GiB with one release per stream - kept relaxed.  tests/test_gpu_handoff_stress.py runs two contexts' persistent kernels on the
   // same XCDs for 2 000 launches and compares every byte; the single-queue fallback (no in-kernel hand-off at all) is what a device
   // without this topology gets.
@@ -763,7 +763,7 @@ __device__ __attribute__((noinline)) void decode_one_stream(StreamDesc* sd, int3
 }
 
 #ifndef BAMD_DEC_MINWAVES
-#define BAMD_DEC_MINWAVES 4   // waves per SIMD.  Round 4: the 9.25 KiB of LDS a wave owns (dec_ring.h) allow 16 - 17 waves per CU anyway, and at 96 registers the ring decoder spills inside its step (6.7 against 4.5 ms, profiles/r04b_dec_ab_ring_variants.txt).  Before:  Round 2: 6 = 5 < 7 < 8 (spills cost more than occupancy gives).  Round 3, with the pipelined loops of dec_bulk.h and the fused unshuffle (both keep two register sets in flight): 5 beats 6 by 4-6 % on every data set (profiles/r03h_dec_ab_rowfill_off.txt)
+#define BAMD_DEC_MINWAVES 4   // waves per SIMD.  Round 4: the 9.25 KiB of LDS a wave owns (dec_ring.h) allow 16 - 17 waves per CU anyway, and at 96 registers the ring decoder spills inside its step (6.7 against 4.5 ms, profiles/r04/r04b_dec_ab_ring_variants.txt).  Before:  Round 2: 6 = 5 < 7 < 8 (spills cost more than occupancy gives).  Round 3, with the pipelined loops of dec_bulk.h and the fused unshuffle (both keep two register sets in flight): 5 beats 6 by 4-6 % on every data set (profiles/r03/r03h_dec_ab_rowfill_off.txt)
 #endif                       // 6 = 5 (5.90 / 5.95 ms) < 7 (6.33) < 8 (7.0): spills cost more than occupancy gives
 constexpr int DEC_WAVES_PER_CU = 4 * BAMD_DEC_MINWAVES;
 // Persistent launch: the grid is sized to what the chip can hold (engine.hip) and every wave pulls stream

@@ -170,12 +170,12 @@ __global__ __launch_bounds__(64 * ENC_WAVES, enc_mode_hc(MODE) ? 2 : ((MODE == E
         // only for the LDS-tile shuffle of the "other" typesizes (a task of theirs takes a wave several times as long as the register forms
         // of 2 / 4 / 8 / 16, so the few waves that drew the negative entries cannot keep incompressible data coming: random bytes, typesize 6:
         // 13.3 -> 9.6 ms).  With the fast forms helping costs 4 % on compressible data and gains nothing on random bytes
-        // (profiles/r04z2_enc_ab_help_bound_variants.txt).
+        // (profiles/r04/r04z2_enc_ab_help_bound_variants.txt).
         const ChunkDesc* cd = chunks + uni((uint32_t)sd->chunk);
         bool more = !(uni(cd->mode) & CH_BITSHUFFLE) && shuffle_generic_T(uni((uint32_t)cd->typesize));
         while (__hip_atomic_load(&blk_ready[gb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
           // ... but not further ahead of its own block than BAMD_ENC_HELP blocks of the list: planes shuffled much earlier than they are
-          // encoded have left the L2 / MALL by then (unbounded: config 2 + 7 %, profiles/r04z_enc_ab_help_unbounded_vs_off.txt)
+          // encoded have left the L2 / MALL by then (unbounded: config 2 + 7 %, profiles/r04/r04z_enc_ab_help_unbounded_vs_off.txt)
           if (BAMD_ENC_HELP && more && __hip_atomic_load(tickets + 8 + xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (single_queue ? gb : gb / 8u) + (uint32_t)BAMD_ENC_HELP) more = shuffle_one();
           else __builtin_amdgcn_s_sleep(16);
         }

@@ -68,7 +68,7 @@ __device__ __forceinline__ void zl_exec_matches(gu8* out, ZlPend& p, int lane) {
 }
 
 // (Round 3 also assembled the match batches in LDS, the way zstd_exec16_lds of k_zstd.hip does: bit-exact, and no faster - 33.7 against 33.8 ms
-//  per 8 GiB of reference-written bench19 streams, profiles/r03ze_zlib_lds_batches_no_gain_removed.txt.  What this kernel waits for is the
+//  per 8 GiB of reference-written bench19 streams, profiles/r03/r03ze_zlib_lds_batches_no_gain_removed.txt.  What this kernel waits for is the
 //  wave-uniform symbol program, ~0.5 us per symbol, not its copies; the code was taken out again.)
 // one stream -> out[0..cap); returns bytes produced, 0 on any error (zlib_wrap_decompress's contract)
 __device__ __forceinline__ int zlib_decode_wave(const uint8_t* in_, int n_, uint8_t* out_, int cap_, zi::Tabs& T, int lane) {

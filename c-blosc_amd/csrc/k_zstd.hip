@@ -157,7 +157,7 @@ __device__ __forceinline__ void lane_copy_dual_lds(gu8* d, zlds_u8* l, const zld
 }
 // (a real call: the common group must not pay for its registers).  indep / dep: this lane's match is copied at once / in stream order.
 #ifndef BAMD_ZXB_INLINE
-#define BAMD_ZXB_INLINE 1        // zstd_exec16_lds inlined into its callers: bench19 10.8 -> 10.5 ms, linspace 6.8 -> 5.8 (profiles/r03zm_zent_split_rcp_modulo_inline.txt); 0: a real call
+#define BAMD_ZXB_INLINE 1        // zstd_exec16_lds inlined into its callers: bench19 10.8 -> 10.5 ms, linspace 6.8 -> 5.8 (profiles/r03/r03zm_zent_split_rcp_modulo_inline.txt); 0: a real call
 #endif
 #if BAMD_ZXB_INLINE
 #define ZXB_FN __device__ __forceinline__
@@ -209,7 +209,7 @@ ZXB_FN void zstd_exec16_lds(gu8* out_, const gu8* lit_, volatile uint32_t* xbuf_
     // periodic extension of the o bytes before the match (o >= m: a plain copy; m <= ZXB_MAXM)
     // k mod o per lane with a float reciprocal (k, o < 512: the quotient is exact or one too small, which the compare repairs).  The
     // integer division this replaces was 23 scalar instructions per match on a scalar unit that SQ counters show 83 % busy in this kernel
-    // (profiles/r03zl_zstd_sq_counters.txt: 393 scalar + 307 vector instructions per group of 16 sequences)
+    // (profiles/r03/r03zl_zstd_sq_counters.txt: 393 scalar + 307 vector instructions per group of 16 sequences)
     const float ro = o < m ? __builtin_amdgcn_rcpf((float)o) : 0.0f;
     for (uint32_t k = (uint32_t)lane; k < m; k += 64u) {
       uint32_t kk = k;
@@ -300,7 +300,7 @@ __device__ __forceinline__ bool zstd_exec16(uint32_t ll_b, uint32_t ml_b, uint32
 // ---------------------------------------------------------------------------------------------
 // Wave-uniform sequence decoding.  The FSE sequence stream is serial, but nothing says it has to run on ONE LANE
 // with its bytes fetched from memory one load at a time (the first version: 2200 cycles per sequence,
-// profiles/r02_e_zstd_decode_phases.txt).  Here every lane runs the same scalar program: the stream lives in a
+// profiles/r02/r02_e_zstd_decode_phases.txt).  Here every lane runs the same scalar program: the stream lives in a
 // 256-byte register window (one dword per lane, refilled with one coalesced load as the reader moves towards the
 // start), bits come out of a 64-bit accumulator refilled with v_readlane, table entries are uniform LDS reads, and
 // lane i keeps the fields of the batch's i-th sequence in its own registers for the execution step.

@@ -3,7 +3,7 @@
 //
 // Why: with one wavefront per frame (k_zstd.hip) the entropy decoding - 4000 dependent FSE steps per frame on bench19 -
 // is a scalar program, and ALL waves of a CU share its one scalar unit (or, as vector code, its four SIMDs): ~120
-// instructions per sequence x 12 waves = 1500 cycles per sequence and wave (profiles/r02_e_zstd_decode_phases.txt).
+// instructions per sequence x 12 waves = 1500 cycles per sequence and wave (profiles/r02/r02_e_zstd_decode_phases.txt).
 // The instruction count per sequence is what it is; the way to use the machine is to let the LANES of a wave work on
 // DIFFERENT frames.
 //
@@ -50,8 +50,8 @@ constexpr int ZG_FRAMES = 16;        // frames per wavefront (4 lanes each)
 // The three sequence tables of a frame as 16-bit cells (zd::fse_build's `compact`), one dense record per frame: what k_zstd_seq reads.
 // 2.5 KiB per frame = 160 MiB for the 65 536 frames of the benchmark batch, all of them live at once: inside the 256 MiB Infinity
 // Cache, where the 32-bit tables inside the 8.4 KiB ZgLds records (550 MiB) were not - the sequence loop is bound by random
-// 64-byte sector reads (41 GB per launch for 0.33 GB of input, profiles/r03_traffic_cfg4.json), not by its instructions
-// (one lane per frame instead of one in four: 18 -> 16.3 ms, profiles/r03v_zent_split.txt).
+// 64-byte sector reads (41 GB per launch for 0.33 GB of input, profiles/r03/r03_traffic_cfg4.json), not by its instructions
+// (one lane per frame instead of one in four: 18 -> 16.3 ms, profiles/r03/r03v_zent_split.txt).
 struct ZcTab { uint16_t ll[512], of[256], ml[512]; };
 
 __device__ __forceinline__ uint64_t zpack(uint32_t ll, uint32_t ml, uint32_t off) { return (uint64_t)ll | ((uint64_t)ml << 18) | ((uint64_t)off << 36); }
@@ -79,7 +79,7 @@ __device__ __forceinline__ bool zseq_run(zd::SeqState& st, int nseq, const uint3
   // sqbuf (LDS, 8 x 64 words, entry k of lane l at [k * 64 + l]): the triples leave in runs of eight.  gfx950 counts loads and stores
   // with ONE in-order counter: a store per sequence meant that every wait for a loaded value - the next stream word, a table cell -
   // was also a wait for the previous sequence's store to be acknowledged by L2 (~0.9 us per sequence even with the tables in LDS,
-  // profiles/r03x_zent_split.txt); with the run buffer that wait comes once per eight sequences, and a lane writes 64 contiguous bytes.
+  // profiles/r03/r03x_zent_split.txt); with the run buffer that wait comes once per eight sequences, and a lane writes 64 contiguous bytes.
   volatile __attribute__((address_space(3))) uint64_t* sqbuf = (volatile __attribute__((address_space(3))) uint64_t*)sqbuf_;
   bool fine = true;
   const BAMD_GAS uint32_t* gl = (const BAMD_GAS uint32_t*)gl_; const BAMD_GAS uint32_t* go = (const BAMD_GAS uint32_t*)go_;      // (global_load, not flat_load)
@@ -107,7 +107,7 @@ __device__ __forceinline__ bool zseq_run(zd::SeqState& st, int nseq, const uint3
   // refill points per sequence instead of a test in front of each of the six fields.  A refill leaves >= 32 unread bits; the fields
   // between two refill points need at most 31 (offset bits), 16 + 16 (match and literal length bits) and 9 + 9 + 8 (the three
   // state updates).  rd() above was ~130 instructions per field with its byte loop and its end-of-stream cases, six times per
-  // sequence, and the loop as a whole ~800 (profiles/r03u_zent_split.txt: 18 of the entropy kernel's 27 ms).
+  // sequence, and the loop as a whole ~800 (profiles/r03/r03u_zent_split.txt: 18 of the entropy kernel's 27 ms).
   auto refill = [&]() {
     if (nacc <= 32) { bytepos -= 4; acc = (acc << 32) | nxt; nacc += 32; if (bytepos >= 4) nxt = g_ld4(bp + bytepos - 4); }
   };
@@ -197,7 +197,7 @@ __device__ __forceinline__ bool zseq_run(zd::SeqState& st, int nseq, const uint3
 // symbol while four stream bytes are left, the general reader for the last ones), the table (GLOBAL = true: 4 KiB of global
 // scratch per frame) read through a global pointer, and the output leaving EIGHT bytes at a time: one byte store per symbol put
 // L2's acknowledgement of the previous store in front of every table read (the one in-order counter again; 7 us per symbol,
-// profiles/r03u_zent_split.txt: 4.5 of the kernel's 27 ms for 2 400 literals per frame).
+// profiles/r03/r03u_zent_split.txt: 4.5 of the kernel's 27 ms for 2 400 literals per frame).
 template <bool GLOBAL>
 __device__ __forceinline__ bool zhuf_run(const uint16_t* te_, int mb, const uint8_t* src, int len, uint8_t* out_, int n) {
   zd::Back b0;
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(64) void k_zstd_entropy_t(const StreamDesc* __restr
   ZgLds* lds = (ZgLds*)lds_raw;
   // Round 3 (GLOBAL only): the three SEQUENCE tables of every frame of the wave, compact, in LDS.  With all tables in the global
   // scratch every FSE step was three dependent 4-byte reads out of an 8.4 KiB per-frame structure: 31 GB fetched to decode 0.3 GB
-  // (profiles/r02g_traffic_cfg4.json), ~7 us per sequence.  A cell is kept as symbol | x << 6 (x = the cell's "next state"
+  // (profiles/r02/r02g_traffic_cfg4.json), ~7 us per sequence.  A cell is kept as symbol | x << 6 (x = the cell's "next state"
   // counter, < 1024): 16 bits, from which nbBits = al - floor(log2 x) and baseline = (x << nbBits) - 2^al follow - so the
   // largest tables the format allows (LL 512 + OF 256 + ML 512 cells) take 2.5 KiB per frame, 40 KiB per wave, 4 waves per CU.
   // The Huffman table (4 KiB, used once per literal) and the build scratch stay global.
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(64) void k_zstd_entropy_t(const StreamDesc* __restr
 
 // phase A2 (round 3): the sequence streams, ONE LANE PER FRAME.  Inside k_zstd_entropy the stream of a frame ran on lane 0 of the frame's four
 // lanes (the other three are there for the four Huffman streams): 16 of 64 lanes busy for two thirds of that kernel's time
-// (profiles/r03u_zent_split.txt: 27.3 ms, 9.2 without the sequence loop, 4.2 without the Huffman streams as well).  Here a wave
+// (profiles/r03/r03u_zent_split.txt: 27.3 ms, 9.2 without the sequence loop, 4.2 without the Huffman streams as well).  Here a wave
 // carries 64 frames through the same loop (zseq_run), the tables where phase A built them (global scratch).
 __device__ __forceinline__ void zseq_fill_codes(volatile uint32_t* codes, int lane) {      // before any lane leaves: the whole wave fills, then a rendezvous
   if (lane < 36) codes[lane] = zd::ll_base(lane) | ((uint32_t)zd::ll_bits(lane) << 24);
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(64) void k_zstd_seq(const StreamDesc* __restrict__ 
 }
 
 // (Round 3 also built this kernel with the frames' tables in LDS - 30 frames per wave, two waves per CU: 16.2 - 16.8 ms against 11.7 ms, the
-//  dependent-issue latency of the loop at one wave per SIMD outweighs the table reads; removed in round 4, record: profiles/r03y_zent_split.txt.)
+//  dependent-issue latency of the loop at one wave per SIMD outweighs the table reads; removed in round 4, record: profiles/r03/r03y_zent_split.txt.)
 
 // phase B: one wavefront per frame, persistent + ticket
 #ifndef BAMD_ZEXEC_MINWAVES

@@ -22,7 +22,7 @@ namespace bamd {
 // ready (k_encode.hip): when the streams are cheap (incompressible data) the transposes then run on every waiting wave instead of
 // on the few that drew the negative entries.  *sh_at = index of shoff[0] in `out`.
 constexpr size_t kEncLookaheadDefault = 32;
-inline size_t enc_lookahead() { return kEncLookaheadDefault; }     // (swept 1 ... 64 in round 4: 8.4 ... 8.0 ms, profiles/r04q_enc_lookahead_sweep.txt - the distance hardly matters)
+inline size_t enc_lookahead() { return kEncLookaheadDefault; }     // (swept 1 ... 64 in round 4: 8.4 ... 8.0 ms, profiles/r04/r04q_enc_lookahead_sweep.txt - the distance hardly matters)
 // BLOSC_AMD_SCHED=0: plain block order (no cost feedback)
 // (read once: getenv is not safe against a setenv from another host thread.  blosc_gpu_profile(2) switches the feedback off for the calls
 //  that follow - bench.py's `sched_cold` leg: one step in the order a first call on new data gets)
@@ -50,7 +50,7 @@ inline void plane_order(const uint32_t* cost, bool valid, int T, std::vector<int
 // streams of the expensive planes; the second carries the cheap planes, plane by plane in descending cost.
 // The kernel's tail (waves finishing their last stream while the queue is already empty) then consists of
 // cheap streams instead of 3 ms ones.  (One pass in the decode queues' manner - expensive planes of block i + lead with the cheap
-// planes of block i, lead 16 / 64 / 256 - is 4 ... 7 % slower: profiles/r04zg_enc_ab_one_pass_lead_order_rejected.txt.)
+// planes of block i, lead 16 / 64 / 256 - is 4 ... 7 % slower: profiles/r04/r04zg_enc_ab_one_pass_lead_order_rejected.txt.)
 inline void build_encode_queues(const std::vector<BlockDesc>& blocks, const std::vector<ChunkDesc>& chunks,
                                 const uint32_t* cost, bool cost_valid, std::vector<int32_t>& out, int nq = 8, size_t* sh_at = nullptr) {
   std::vector<int32_t> q[8], sh[8];
@@ -103,7 +103,7 @@ inline void build_encode_queues(const std::vector<BlockDesc>& blocks, const std:
 // streams drawn last - the kernel's tail - are cheap ones.
 // (The lead was 256 blocks until round 4: the expensive planes then sat in the scratch for 2048 blocks' worth of output before their block
 //  completed and came back from HBM instead of the L2 / Infinity Cache.  64 / 16 / 2: - 9 % on reference-written config-2 chunks,
-//  profiles/r04zc_dec_ab_heavy_plane_lead_256_64_16_2.txt; the tail the lead is there for is as short at 16.)
+//  profiles/r04/r04zc_dec_ab_heavy_plane_lead_256_64_16_2.txt; the tail the lead is there for is as short at 16.)
 #ifndef BAMD_DEC_LEAD
 #define BAMD_DEC_LEAD 16
 #endif

@@ -1,6 +1,6 @@
 #!/bin/bash
 # kernel start / end times of one Zstd decompress call (reference-written config-4 frames), in launch order with their hardware queues
-# (round 4: the timeline of the sliced multi-stream pipeline that was measured and not kept, profiles/r04zp_*)
+# (round 4: the timeline of the sliced multi-stream pipeline that was measured and not kept, profiles/r04/r04zp_*)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp
 LIB=${1:-c-blosc_amd/libblosc_amd.so}
 CHUNKS=${CHUNKS:-128} DATA=bench19 CODEC=zstd CLEVEL=3 BLOSC_AMD_LIB=$PWD/$LIB timeout 200 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/ztrace -o t -- python scripts/dec_sweep.py > gpurun_out/ztrace.log 2>&1
