@@ -140,8 +140,28 @@ int main() {
     std::vector<int32_t> q; build_encode_queues(blocks, chunks, cost, true, q);
     for (int x = 0; x < 8; x++) for (int i = q[x + 1] - 512; i < q[x + 1]; i++) if (q[9 + i] >= 0 && q[9 + i] % 8 == 5) return fail("enc: expensive plane in the tail", -1);
     std::vector<int32_t> d; build_xcd_queues(blocks, 8 * 4096, cost, true, d);
-    // (the decode queues keep the expensive planes kDecLead blocks ahead, no more: further ahead their bytes leave the caches before the block completes)
-    for (int x = 0; x < 8; x++) for (int i = d[x + 1] - 7 * (int)kDecLead; i < d[x + 1]; i++) if (d[9 + i] % 8 == 5) return fail("dec: expensive plane in the tail", -1);
+    // The decode queues' invariant (the old check only looked at the last 7 * kDecLead entries): with blocks numbered per XCD in
+    // queue order, the expensive plane of block i stands in front of every cheap plane of the blocks >= i - kDecLead and behind every cheap
+    // plane of the blocks < i - kDecLead - i.e. it leads its own block by exactly kDecLead blocks: never behind its block's cheap planes (the
+    // kernel's tail is cheap streams), never further ahead (its bytes would leave the caches before the block completes).
+    for (int x = 0; x < 8; x++) {
+      std::vector<long> heavy_pos(4096 / 8, -1), cheap_lo(4096 / 8, 1L << 40), cheap_hi(4096 / 8, -1);
+      for (int i = d[x]; i < d[x + 1]; i++) {
+        const int sid = d[9 + i], g = sid / 8, bi = g / 8;                   // block g lives on XCD g % 8 as its bi-th block
+        if (g % 8 != x) return fail("dec: stream on the wrong XCD", x);
+        if (sid % 8 == 5) { if (heavy_pos[(size_t)bi] >= 0) return fail("dec: expensive plane twice", x); heavy_pos[(size_t)bi] = i; }
+        else { if (i < cheap_lo[(size_t)bi]) cheap_lo[(size_t)bi] = i; if (i > cheap_hi[(size_t)bi]) cheap_hi[(size_t)bi] = i; }
+      }
+      const long L = (long)kDecLead, nb = 4096 / 8;
+      for (long bi = 0; bi < nb; bi++) {
+        if (heavy_pos[(size_t)bi] < 0 || cheap_hi[(size_t)bi] < 0) return fail("dec: a block without its planes", x);
+        if (heavy_pos[(size_t)bi] > cheap_lo[(size_t)bi]) return fail("dec: expensive plane behind its own block's cheap planes", (int)bi);
+        if (bi - L >= 0 && heavy_pos[(size_t)bi] > cheap_lo[(size_t)(bi - L)]) return fail("dec: expensive plane leads by less than kDecLead blocks", (int)bi);
+        if (bi - L - 1 >= 0 && heavy_pos[(size_t)bi] < cheap_hi[(size_t)(bi - L - 1)]) return fail("dec: expensive plane leads by more than kDecLead blocks", (int)bi);
+      }
+      // the tail: behind the last expensive plane, the cheap planes of kDecLead blocks at least
+      if (d[x + 1] - 1 - heavy_pos[(size_t)(nb - 1)] < 7 * L) return fail("dec: tail shorter than kDecLead blocks of cheap planes", x);
+    }
   }
   printf("sched_check OK\n");
   return 0;
