@@ -196,7 +196,17 @@ __device__ __forceinline__ void dr_match(RingIO& io, uint32_t& op, uint32_t off,
   if (off < 64u && off < len) {
     // short period: the off bytes in front of the match, replicated from registers, give the first G = off * floor(64 / off) bytes
     DR_SYNC();
-    const uint32_t pat = ((uint32_t)lane < off) ? (uint32_t)io.hist[(mpos - off + (uint32_t)lane) & DR_MASK] : 0u;     // (off < 64: always in the ring)
+    // (off < 64: in the ring - unless the ring is empty down there: right behind a periodic span that ended on a row boundary (rfloor == mpos or
+    //  a few bytes below it) those bytes exist only in global memory, where the span's materialisation or the head copy put them.  Round 5: the
+    //  reference's linspace chunks at typesize 4 hold exactly that - "2 literals, 32 766 bytes at distance 2, 1 literal, 32 767 bytes at distance 2" -
+    //  and the second match was replicated from stale ring bytes: tests/test_gpu_spans.py::test_short_period_match_right_behind_a_span.)
+    const uint32_t pnlo = dr_near_lo(io, mpos);
+    uint32_t pat = 0u;
+    if (mpos - off < pnlo) {                                    // wave-uniform, rare
+      BAMD_MEM_SYNC();
+      const uint32_t pp = mpos - off + (uint32_t)lane;
+      if ((uint32_t)lane < off) pat = pp < pnlo ? (uint32_t)io.out[pp] : (uint32_t)io.hist[pp & DR_MASK];
+    } else if ((uint32_t)lane < off) pat = (uint32_t)io.hist[(mpos - off + (uint32_t)lane) & DR_MASK];
     const uint32_t M = 65536u / off + 1u;                 // floor(i / off) == (i * M) >> 16 for i < 64
     const uint32_t G = ((64u * M) >> 16) * off;
     const uint32_t i_mod = (uint32_t)lane - (((uint32_t)lane * M) >> 16) * off;

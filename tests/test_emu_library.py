@@ -103,6 +103,23 @@ def test_split_blocks_followed_by_an_unsplit_leftover_block(emulib, oracle, ref)
         assert r2 == n and np.array_equal(out, data)
 
 
+def test_short_period_match_right_behind_a_span_on_reference_data(emulib, oracle):
+    """Round 5's silent decode error, on the emulator: blocks 7 .. 9 of the reference's chunk of 64 MiB `linspace` float64 labelled typesize 4
+    (blosc_getitem decodes only the blocks it needs).  Plane 3 of blocks 8 and 9 is "2 literals, 32 766 bytes at distance 2, 1 literal, 32 767 bytes at
+    distance 2, ...": a periodic span that ends exactly on a row boundary, then a short-period match whose first source byte lies below the span's end -
+    in global memory only, not in the wave's LDS ring (dec_ring.h: dr_match).  tests/test_gpu_spans.py has the hand-built family."""
+    n = 64 << 20
+    data = DATASETS["linspace"](n)
+    r, chunk = orc_compress(oracle, data, 4, 5, 1, "lz4")
+    bs = header(chunk)["blocksize"]
+    assert r > 0 and bs == 512 << 10
+    ne = bs // 4
+    for blk in (7, 8, 9, 31, 32):
+        item = np.zeros(bs, np.uint8)
+        assert emulib.blosc_getitem(ptr(chunk), blk * ne, ne, ptr(item)) == bs
+        assert np.array_equal(item, data[blk * bs:(blk + 1) * bs]), (blk, int((item != data[blk * bs:(blk + 1) * bs]).sum()))
+
+
 @pytest.mark.parametrize("T", [8, 4, 1])
 def test_bitshuffle_inside_the_codec_kernels(emulib, oracle, ref, T):
     """Bit(un)shuffle as work of the encode / decode kernels' own waves (enc_shuffle.h: bitshuffle_block_wave_T, k_decode.hip:

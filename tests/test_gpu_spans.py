@@ -101,3 +101,44 @@ def test_self_span_base_beyond_24_bits_is_not_taken(pkg, oracle):
     assert ro == n
     got_r, got = pkg.decompress(chunk, n)
     assert got_r == n and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("off2", [1, 2, 3, 5, 16, 33, 63])
+def test_short_period_match_right_behind_a_span(pkg, oracle, off2):
+    """Round 5: the reference's chunks of `linspace` float64 data compressed as typesize 4 decoded wrongly (silently: right sizes, wrong bytes) -
+    their fourth byte plane is "2 literals, 32 766 bytes at distance 2, 1 literal, 32 767 bytes at distance 2, ...": the first match becomes a
+    periodic span that ends exactly on a 1 KiB row boundary, so the ring holds nothing below it, and the second match - a SHORT period (< 64),
+    longer than its distance - took its period bytes from the ring all the same (dec_ring.h: dr_match).  Hand-built: a span that ends on a row
+    boundary / one, two, 900 bytes behind one, followed by 0 .. 3 literals and a long match of distance 1 .. 63 whose source reaches below the span's
+    end; twice in a row; in every plane position of a typesize-4 and a typesize-8 block.  The oracle says what the bytes are."""
+    rng = np.random.default_rng(900 + off2)
+    bad = []
+    for period in (2, 1, 64, 1024):
+        for end_mis in (0, 1, 2, 900):                        # where the span's match ends relative to a row boundary
+            for nlit in (0, 1, 3):
+                if nlit + end_mis < 1 and off2 > period and period != 1:
+                    pass                                        # (a source that straddles the span's last period: fine, the oracle defines it)
+                pre = 7
+                mlen = 32768 + end_mis - (period + pre)        # first match ends at 32 KiB + end_mis
+                follow = [(nlit, off2, 20000), (1, min(off2, 2), 30000)]
+                a = _plane_stream(rng, period, pre, mlen, follow)
+                for T in (4, 8):
+                    planes = [_plane_stream(rng, 1, 0, NEB - 1 - 40, []) for _ in range(T)]
+                    for pos in range(T):
+                        streams = list(planes); streams[pos] = a
+                        if not _check(pkg, oracle, streams):
+                            bad.append((period, end_mis, nlit, T, pos))
+    assert not bad, bad[:10]
+
+
+def test_reference_linspace_chunk_at_typesize_4(pkg, oracle):
+    """... and the data that showed it: 16 MiB of linspace float64 labelled typesize 4, written by the reference's algorithm (the oracle's writer is
+    byte-identical to it), every byte compared."""
+    from helpers import DATASETS, orc_compress
+    for T in (4, 2, 8, 16):
+        n = 16 << 20
+        data = DATASETS["linspace"](64 << 20)[(4 << 20):(4 << 20) + n]      # the range of the 64 MiB set whose planes change pattern on a row boundary
+        r, chunk = orc_compress(oracle, data, T, 5, 1, "lz4")
+        assert r > 0
+        got_r, got = pkg.decompress(chunk, n)
+        assert got_r == n and np.array_equal(got, data), (T, int((got != data).sum()))
