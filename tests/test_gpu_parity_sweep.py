@@ -96,3 +96,30 @@ def test_grid_of_the_entropy_coded_formats(pkg, lib, oracle, ref, dname):
                 if not (bd2.decompress() == 0 and bd2.results() == [CSZ] * nch and bool(torch.equal(back, src))):
                     bad.append(("decode of own chunks", T, shuffle, codec, clevel, int((back != src).sum())))
     assert not bad, bad[:12]
+
+
+@pytest.mark.parametrize("dname", ["linspace", "bench19", "randwalk", "smallints"])
+def test_ragged_chunk_sizes_and_forced_blocks_at_scale(pkg, lib, oracle, ref, dname):
+    """Chunks that do not end on a block boundary (a leftover block that is one unsplit stream), that are not a multiple of the typesize, with forced
+    block sizes and the other split modes - at tens of MiB, where the queues, spans and hand-offs are the benchmark's; host buffers through the
+    stock entry points (one chunk per call)."""
+    full = DATASETS[dname](48 << 20)
+    writer = (lambda d, T, cl, sh, c, bs: ref_compress(ref, d, T, cl, sh, c.encode(), blocksize=bs, nthreads=16)) if ref is not None else \
+             (lambda d, T, cl, sh, c, bs: orc_compress(oracle, d, T, cl, sh, c, blocksize=bs))
+    bad = []
+    for n, T, shuffle, codec, bs in [((40 << 20) - 12345, 8, 1, "lz4", 0), ((33 << 20) + 7, 4, 1, "lz4", 0), ((33 << 20) + 7, 4, 2, "blosclz", 0),
+                                     ((24 << 20) + 1000, 8, 1, "blosclz", 65536), ((24 << 20) + 1000, 2, 1, "lz4", 40000), ((20 << 20) + 24, 8, 2, "lz4", 1 << 20),
+                                     ((16 << 20) + 3, 16, 1, "lz4", 0), ((16 << 20) + 3, 3, 1, "lz4", 0), ((16 << 20) - 1, 1, 2, "lz4", 0)]:
+        data = full[:n]
+        r, stock = writer(data, T, 5, shuffle, codec, bs)
+        assert r > 0
+        rr, got = pkg.decompress(stock, n)
+        if rr != n or not np.array_equal(got, data):
+            bad.append(("decode of a reference-written chunk", n, T, shuffle, codec, bs, int((got != data).sum()) if rr == n else rr))
+        rc, chunk = pkg.compress(data, T, 5, shuffle, codec.encode(), blocksize=bs)
+        if rc <= 0:
+            bad.append(("compress", n, T, shuffle, codec, bs, rc)); continue
+        ro, out = ref_decompress(ref, chunk, n) if ref is not None else orc_decompress(oracle, chunk, n)
+        if ro != n or not np.array_equal(out, data):
+            bad.append(("the reference reading a chunk written here", n, T, shuffle, codec, bs))
+    assert not bad, bad
