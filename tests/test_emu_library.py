@@ -103,6 +103,24 @@ def test_split_blocks_followed_by_an_unsplit_leftover_block(emulib, oracle, ref)
         assert r2 == n and np.array_equal(out, data)
 
 
+@pytest.mark.parametrize("fmt", [1, 0])
+def test_random_structured_streams(emulib, oracle, fmt):
+    """tests/test_gpu_random_streams.py's generator (sequences drawn from the shapes the ring decoder treats differently: spans, rows, far and near
+    sources, short periods) on the emulated library: chunks of split shuffled blocks whose planes are random LZ4 / BloscLZ streams, the oracle's reader
+    says what they decode to.  (With the decoder of round 4 this sample has failing chunks: the short-period match behind a span.)"""
+    from helpers import wrap_planes_as_chunk
+    from test_gpu_random_streams import rand_stream
+    rng = np.random.default_rng(1000 + (1 if fmt == 1 else 3))
+    for k in range(160 if FULL else 40):
+        T = int(rng.choice([8, 4, 2, 16])); neb = int(rng.choice([128 << 10, 128 << 10, 64 << 10, 40 << 10, 17 << 10]))
+        chunk = wrap_planes_as_chunk([rand_stream(rng, neb, fmt) for _ in range(T)], neb, fmt)
+        n = T * neb
+        want = np.zeros(n, np.uint8)
+        assert oracle.orc_decompress(ptr(chunk), ptr(want), n) == n
+        r, out = _decompress(emulib, chunk, n)
+        assert r == n and np.array_equal(out, want), (fmt, k, T, neb, r, int((out != want).sum()) if r == n else -1)
+
+
 def test_short_period_match_right_behind_a_span_on_reference_data(emulib, oracle):
     """Round 5's silent decode error, on the emulator: blocks 7 .. 9 of the reference's chunk of 64 MiB `linspace` float64 labelled typesize 4
     (blosc_getitem decodes only the blocks it needs).  Plane 3 of blocks 8 and 9 is "2 literals, 32 766 bytes at distance 2, 1 literal, 32 767 bytes at
