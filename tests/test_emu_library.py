@@ -111,7 +111,7 @@ def test_random_structured_streams(emulib, oracle, fmt):
     from helpers import wrap_planes_as_chunk
     from test_gpu_random_streams import rand_stream
     rng = np.random.default_rng(1000 + (1 if fmt == 1 else 3))
-    for k in range(160 if FULL else 40):
+    for k in range(160 if FULL else 24):
         T = int(rng.choice([8, 4, 2, 16])); neb = int(rng.choice([128 << 10, 128 << 10, 64 << 10, 40 << 10, 17 << 10]))
         chunk = wrap_planes_as_chunk([rand_stream(rng, neb, fmt) for _ in range(T)], neb, fmt)
         n = T * neb
