@@ -39,10 +39,55 @@ def smallints_i32(nbytes, seed=7):
     return np.random.default_rng(seed).integers(0, 1 << 12, (nbytes + 3) // 4).astype("<i4").view(np.uint8)[:nbytes].copy()
 
 
+def synth_segments(nbytes, seed=99):
+    """Not a SURVEY data set: a patchwork for bug hunting (tests/test_gpu_parity_sweep.py, scripts/parity_hunt.py).  Segments of 1 byte ... 300 KiB laid end
+    to end: zeros, one repeated byte, short periods (1 ... 300 bytes, powers of two and not), noise, noise over a few values, counters of 1 / 2 / 4 / 8 byte
+    width, slowly varying float64, and COPIES of earlier ranges at distances from a few bytes to beyond 64 KiB (beyond any LZ window), with segment borders that
+    land on, right before and right behind 1 KiB / 64 KiB / block boundaries."""
+    rng = np.random.default_rng(seed)
+    out = np.empty(nbytes, np.uint8)
+    p = 0
+    while p < nbytes:
+        u = rng.random()
+        n = int(rng.choice([1, 3, 17, 255, 1024, 4096, 65536])) if u < 0.3 else int(rng.integers(1, 300 << 10))
+        if rng.random() < 0.15:                              # end exactly on / around a boundary
+            b = int(rng.choice([1024, 65536, 131072, 1 << 20]))
+            n = (-p) % b + int(rng.choice([0, 0, 1, b - 1, -1 % b]))
+            n = max(n, 1)
+        n = min(n, nbytes - p)
+        kind = int(rng.integers(0, 9))
+        if kind == 0: seg = np.zeros(n, np.uint8)
+        elif kind == 1: seg = np.full(n, int(rng.integers(0, 256)), np.uint8)
+        elif kind == 2:
+            per = int(rng.choice([1, 2, 3, 4, 7, 8, 16, 31, 32, 64, 100, 128, 256, 300, 1024, 4096]))
+            seg = np.resize(rng.integers(0, 256, per, dtype=np.uint8), n)
+        elif kind == 3: seg = rng.integers(0, 256, n, dtype=np.uint8)
+        elif kind == 4: seg = rng.integers(0, int(rng.choice([2, 3, 16])), n, dtype=np.uint8)
+        elif kind == 5:
+            w = int(rng.choice([1, 2, 4, 8]))
+            cnt = (int(rng.integers(0, 1 << 20)) + np.arange((n + w - 1) // w, dtype=np.uint64) * int(rng.choice([1, 1, 3, 256])))
+            seg = cnt.astype({1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}[w]).view(np.uint8)[:n]
+        elif kind == 6:
+            x = np.cumsum(rng.standard_normal((n + 7) // 8) * 1e-3) + float(rng.integers(-5, 5))
+            seg = x.view(np.uint8)[:n]
+        elif p > 0:
+            d = int(rng.choice([1, 2, 8, 100, 1024, 8192, 65535, 65536, 70000, 200000])) if rng.random() < 0.6 else int(rng.integers(1, p + 1))
+            d = min(d, p)
+            seg = np.empty(n, np.uint8)
+            for k in range(0, n, d):                          # (a copy that may overlap itself, like an LZ match)
+                m = min(d, n - k); seg[k:k + m] = out[p - d:p - d + m] if k == 0 else seg[k - d:k - d + m]
+        else:
+            seg = np.zeros(n, np.uint8)
+        out[p:p + n] = seg
+        p += n
+    return out
+
+
 DATASETS = {
     "bench19": bench19, "linspace": linspace_f64, "randwalk": randwalk_f64, "random": randbytes,
     "arange": arange_i32, "smallints": smallints_i32,
     "zeros": lambda n: np.zeros(n, np.uint8),
+    "synth": synth_segments,
 }
 
 
