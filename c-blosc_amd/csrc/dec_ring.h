@@ -40,7 +40,11 @@ constexpr uint32_t DR_LDS_BYTES = 256u + DR_IN + DR_RING;   // 64 scratch dwords
 static_assert((DR_RING & DR_MASK) == 0u && DR_RING >= 4096u, "ring size");
 // a step's sources are either in the ring (>= W - DR_RING, W = the step's end) or in rows already written (< W - DR_RING):
 // W - DR_RING + longest match must not exceed what has certainly been flushed (op - DR_ROW)
-static_assert(DR_STEP_MAX + 273u + DR_ROW <= DR_RING, "far sources must lie in flushed rows");
+#ifndef BAMD_DEC_ROWREG
+#define BAMD_DEC_ROWREG 1           // long power-of-two matches: everything behind the doubled period out of one register set (round 5)
+#endif
+constexpr uint32_t DR_GUARD = BAMD_DEC_ROWREG ? 16u : 0u;
+static_assert(DR_STEP_MAX + 273u + DR_ROW + DR_GUARD <= DR_RING, "far sources must lie in flushed rows");
 
 #ifdef BAMD_WAVE_EMU
 inline unsigned long long g_emu_ring_steps = 0;       // emulator only: batched steps executed (tests assert that they run at all)
@@ -158,7 +162,9 @@ __device__ __forceinline__ void dr_flush_tail(RingIO& io, uint32_t op) {
 }
 // lowest plane position a copy ending at W may still read from the ring
 __device__ __forceinline__ uint32_t dr_near_lo(const RingIO& io, uint32_t W) {
-  const uint32_t lo = W > DR_RING ? W - DR_RING : 0u;
+  // (DR_GUARD: the row-register form of long power-of-two matches, dr_match, may store up to 15 bytes beyond the match's end - ring slots of the
+  //  oldest 15 positions of the window, which therefore do not count as "in the ring")
+  const uint32_t lo = W > DR_RING - DR_GUARD ? W - (DR_RING - DR_GUARD) : 0u;
   return lo > io.rfloor ? lo : io.rfloor;
 }
 
@@ -244,6 +250,31 @@ __device__ __forceinline__ void dr_match(RingIO& io, uint32_t& op, uint32_t off,
     };
     uint32_t pos = mpos + done;
     const uint32_t end = mpos + len, mis = pos & (DR_ROW - 1u);
+#if BAMD_DEC_ROWREG
+    // Round 5: a lane's 16 bytes of ANY row are the same (the period divides a row), so ONE read out of the two periods serves the rest of the first
+    // row, every whole row and the piece behind the last boundary - 7 LDS round trips per match instead of 13 - 15 (bench19's planes 2 / 6 are 32 such
+    // matches each, a quarter of the block's wave cycles: profiles/r04/r04zl_*).  Lanes that straddle `pos` rewrite up to 15 bytes in front of it with
+    // the same bytes (this match's own output, >= 33 bytes of it exist); the last piece may write up to 15 bytes BEYOND the match (DR_GUARD).
+    {
+      const uint32_t rb = pos - mis, b = base_for(pos);
+      DR_SYNC();
+      const uint4 row = dr_get16(io.hist, b + ((rb + l16 - b) & pm));
+      DR_SYNC();
+      if (mis) {
+        if (l16 + 16u > mis) l_st16(io.hist + ((rb + l16) & DR_MASK), row);
+        pos = rb + DR_ROW; op = pos;                           // (len >= 2 rows and done <= 1 row: the boundary lies inside the match)
+        dr_flush_rows(io, op);
+      }
+      for (; end - pos >= DR_ROW; pos += DR_ROW) {             // pos is a row boundary and everything below it has been flushed
+        l_st16(io.hist + ((pos + l16) & DR_MASK), row);
+        if (DR_FLUSH_ON(io)) g_st16(io.out + pos + l16, row);
+      }
+      io.flushed = pos; op = pos;
+      if (end > pos) { if (l16 < end - pos) l_st16(io.hist + ((pos + l16) & DR_MASK), row); op = end; }
+      DR_SYNC();
+      return;
+    }
+#endif
     if (mis) { const uint32_t c = DR_ROW - mis; fill(pos, c); pos += c; op = pos; dr_flush_rows(io, op); }      // (len >= 2 rows: the boundary lies inside the match)
     if (end - pos >= DR_ROW) {                              // pos is a row boundary and everything below it has been flushed
       const uint32_t b = base_for(pos);

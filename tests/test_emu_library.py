@@ -121,6 +121,23 @@ def test_random_structured_streams(emulib, oracle, fmt):
         assert r == n and np.array_equal(out, want), (fmt, k, T, neb, r, int((out != want).sum()) if r == n else -1)
 
 
+@pytest.mark.parametrize("fmt", [1, 0])
+def test_long_power_of_two_matches_and_the_window_edge(emulib, oracle, fmt):
+    """tests/test_gpu_random_streams.py::edge_stream on the emulated library: the row-register form of long power-of-two matches (dec_ring.h: dr_match)
+    and the 16-byte guard band at the far edge of the ring it needs."""
+    from helpers import wrap_planes_as_chunk
+    from test_gpu_random_streams import edge_stream
+    rng = np.random.default_rng(4242 + fmt)
+    for k in range(120 if FULL else 16):
+        T = int(rng.choice([8, 4, 2])); neb = int(rng.choice([128 << 10, 64 << 10, 33 << 10]))
+        chunk = wrap_planes_as_chunk([edge_stream(rng, neb, fmt) for _ in range(T)], neb, fmt)
+        n = T * neb
+        want = np.zeros(n, np.uint8)
+        assert oracle.orc_decompress(ptr(chunk), ptr(want), n) == n
+        r, out = _decompress(emulib, chunk, n)
+        assert r == n and np.array_equal(out, want), (fmt, k, T, neb, r, int((out != want).sum()) if r == n else -1)
+
+
 def test_short_period_match_right_behind_a_span_on_reference_data(emulib, oracle):
     """Round 5's silent decode error, on the emulator: blocks 7 .. 9 of the reference's chunk of 64 MiB `linspace` float64 labelled typesize 4
     (blosc_getitem decodes only the blocks it needs).  Plane 3 of blocks 8 and 9 is "2 literals, 32 766 bytes at distance 2, 1 literal, 32 767 bytes at

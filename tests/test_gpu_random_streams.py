@@ -75,6 +75,49 @@ def rand_stream(rng, neb, fmt):
     return bytes(s)
 
 
+def edge_stream(rng, neb, fmt):
+    """Long matches with power-of-two distances <= 1 KiB (dec_ring.h: dr_match's row-register form: the rest of the first row, whole rows and the piece
+    behind the last row boundary out of one register set, up to 15 bytes written beyond the match's end), at every alignment of start and end, each
+    followed by short sequences whose sources sit at the far edge of the 8 KiB window - the ring slots those extra bytes land in."""
+    s = bytearray(); p = 0
+    minml = 4 if fmt == 1 else 3
+
+    def emit(lit, off, ml):
+        nonlocal s, p
+        if fmt == 1: s += _lz4_seq(lit, off, ml)
+        else: s += _blz_lits(lit) + _blz_match(off, ml)
+        p += len(lit) + ml
+    emit(rng.integers(0, 256, int(rng.integers(1100, 1300)), dtype=np.uint8).tobytes(), int(rng.integers(1, 900)), int(rng.integers(minml, 60)))
+    while neb - p > 12000:
+        off = 1 << int(rng.integers(0, 11))
+        ll = int(rng.integers(0, 40)) if rng.random() < 0.7 else int(rng.integers(0, 1100))
+        ml = 2048 + int(rng.integers(0, 4200)) if rng.random() < 0.8 else 2048 + 1024 * int(rng.integers(0, 4)) + (-(p + ll)) % 1024
+        emit(rng.integers(0, 256, ll, dtype=np.uint8).tobytes(), min(off, p + ll), ml)
+        for _ in range(int(rng.integers(1, 5))):                      # sources around the window's far edge, relative to the end of the long match
+            ll = int(rng.integers(0, 3))
+            off = int(rng.integers(8192 - 40, 8192 + 24)) - int(rng.integers(0, 30))
+            emit(rng.integers(0, 256, ll, dtype=np.uint8).tobytes(), max(1, min(off, p + ll)), int(rng.integers(minml, 40)))
+    tail = rng.integers(0, 256, neb - p, dtype=np.uint8).tobytes()
+    s += _lz4_tail(tail) if fmt == 1 else _blz_lits(tail)
+    return bytes(s)
+
+
+@pytest.mark.parametrize("fmt", [1, 0])
+def test_long_power_of_two_matches_and_the_window_edge(pkg, oracle, fmt):
+    rng = np.random.default_rng(4242 + fmt)
+    bad = []
+    for k in range(120):
+        T = int(rng.choice([8, 4, 2])); neb = int(rng.choice([128 << 10, 64 << 10, 33 << 10]))
+        chunk = wrap_planes_as_chunk([edge_stream(rng, neb, fmt) for _ in range(T)], neb, fmt)
+        n = T * neb
+        want = np.zeros(n, np.uint8)
+        assert oracle.orc_decompress(ptr(chunk), ptr(want), n) == n, k
+        r, out = pkg.decompress(chunk, n)
+        if r != n or not np.array_equal(out, want):
+            bad.append((k, T, neb, r, int((out != want).sum()) if r == n else -1))
+    assert not bad, bad[:8]
+
+
 @pytest.mark.parametrize("fmt,seed", [(1, 1), (1, 2), (0, 3), (0, 4)])
 def test_random_streams_as_planes_of_split_blocks(pkg, oracle, fmt, seed):
     rng = np.random.default_rng(1000 + seed)
