@@ -41,7 +41,7 @@ static_assert((DR_RING & DR_MASK) == 0u && DR_RING >= 4096u, "ring size");
 // a step's sources are either in the ring (>= W - DR_RING, W = the step's end) or in rows already written (< W - DR_RING):
 // W - DR_RING + longest match must not exceed what has certainly been flushed (op - DR_ROW)
 #ifndef BAMD_DEC_ROWREG
-#define BAMD_DEC_ROWREG 2           // long power-of-two matches: 1 = everything behind the doubled period out of one register set, 2 = (distances >= 16) the row pattern straight out of the one period, no doubling copy (round 5)
+#define BAMD_DEC_ROWREG 1           // long power-of-two matches: everything behind the doubled period out of one register set (round 5: - 7 % on reference-written config-2 chunks, profiles/r05j_*; composing the row pattern out of the ONE period with funnel shifts, no doubling copy: no further gain, profiles/r05k_*)
 #endif
 constexpr uint32_t DR_GUARD = BAMD_DEC_ROWREG ? 16u : 0u;
 static_assert(DR_STEP_MAX + 273u + DR_ROW + DR_GUARD <= DR_RING, "far sources must lie in flushed rows");
@@ -199,45 +199,6 @@ __device__ __forceinline__ void dr_copy_chunk(RingIO& io, uint32_t pos, uint32_t
 __device__ __forceinline__ void dr_match(RingIO& io, uint32_t& op, uint32_t off, uint32_t len, int lane) {
   uint32_t done = 0, off_e = off;
   const uint32_t mpos = op;
-#if BAMD_DEC_ROWREG >= 2
-  // Long matches with a power-of-two distance of 16 bytes ... one row, the period in the ring (round 5, second step): the row pattern straight out
-  // of the ONE period in front of the match - no copy that lays two periods back to back, no head of the first bytes.  A lane's 16 bytes start at
-  // offset o = (row base + 16 lane - b0) mod off of the period; where they wrap around its end they are a window of (last 16 bytes of the period,
-  // first 16 bytes of the period) - two reads at wave-uniform addresses and byte funnel shifts.  Then as below: the rest of the first row, whole
-  // rows (ring + global memory from the same registers), the piece behind the last row boundary.  Lanes that straddle the match's start rewrite
-  // up to 15 bytes in front of it with the same bytes (they lie inside the period: off >= 16).
-  if ((off & (off - 1u)) == 0u && off >= 16u && off <= DR_ROW && len >= 2u * DR_ROW && mpos - off >= dr_near_lo(io, mpos + off)) {
-    const uint32_t b0 = mpos - off, pm = off - 1u, l16 = 16u * (uint32_t)lane, rb = mpos & ~(DR_ROW - 1u), mis = mpos - rb, end = mpos + len;
-    const uint32_t o = (rb + l16 - b0) & pm;
-    const bool wraps = o > off - 16u;
-    DR_SYNC();
-    const uint4 A = dr_get16(io.hist, mpos - 16u), B = dr_get16(io.hist, b0);
-    uint4 row = dr_get16(io.hist, b0 + (wraps ? 0u : o));
-    DR_SYNC();
-    if (wraps) {
-      const uint32_t sh = o + 16u - off, q = sh >> 2, r = sh & 3u;      // bytes [sh, sh + 16) of A ++ B, sh = 1 .. 15
-      const uint32_t W0 = A.x, W1 = A.y, W2 = A.z, W3 = A.w, W4 = B.x, W5 = B.y, W6 = B.z, W7 = B.w;
-      const uint32_t s0 = q == 0u ? W0 : (q == 1u ? W1 : (q == 2u ? W2 : W3)), s1 = q == 0u ? W1 : (q == 1u ? W2 : (q == 2u ? W3 : W4));
-      const uint32_t s2 = q == 0u ? W2 : (q == 1u ? W3 : (q == 2u ? W4 : W5)), s3 = q == 0u ? W3 : (q == 1u ? W4 : (q == 2u ? W5 : W6));
-      const uint32_t s4 = q == 0u ? W4 : (q == 1u ? W5 : (q == 2u ? W6 : W7));
-      row = make_uint4(__builtin_amdgcn_alignbyte(s1, s0, r), __builtin_amdgcn_alignbyte(s2, s1, r), __builtin_amdgcn_alignbyte(s3, s2, r), __builtin_amdgcn_alignbyte(s4, s3, r));
-    }
-    uint32_t pos = rb;
-    if (mis) {
-      if (l16 + 16u > mis) l_st16(io.hist + ((rb + l16) & DR_MASK), row);
-      pos = rb + DR_ROW; op = pos;                            // (len >= 2 rows: the boundary lies inside the match)
-      dr_flush_rows(io, op);
-    }
-    for (; end - pos >= DR_ROW; pos += DR_ROW) {               // pos is a row boundary and everything below it has been flushed
-      l_st16(io.hist + ((pos + l16) & DR_MASK), row);
-      if (DR_FLUSH_ON(io)) g_st16(io.out + pos + l16, row);
-    }
-    io.flushed = pos; op = pos;
-    if (end > pos) { if (l16 < end - pos) l_st16(io.hist + ((pos + l16) & DR_MASK), row); op = end; }
-    DR_SYNC();
-    return;
-  }
-#endif
   if (off < 64u && off < len) {
     // short period: the off bytes in front of the match, replicated from registers, give the first G = off * floor(64 / off) bytes
     DR_SYNC();
