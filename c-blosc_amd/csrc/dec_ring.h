@@ -40,9 +40,6 @@ constexpr uint32_t DR_LDS_BYTES = 256u + DR_IN + DR_RING;   // 64 scratch dwords
 static_assert((DR_RING & DR_MASK) == 0u && DR_RING >= 4096u, "ring size");
 // a step's sources are either in the ring (>= W - DR_RING, W = the step's end) or in rows already written (< W - DR_RING):
 // W - DR_RING + longest match must not exceed what has certainly been flushed (op - DR_ROW)
-#ifndef BAMD_DEC_MERGE34
-#define BAMD_DEC_MERGE34 1          // the batched step's literal placement and short matches in three LDS round trips instead of six (round 5)
-#endif
 #ifndef BAMD_DEC_ROWREG
 #define BAMD_DEC_ROWREG 1           // long power-of-two matches: everything behind the doubled period out of one register set (round 5: - 7 % on reference-written config-2 chunks, profiles/r05j_*; composing the row pattern out of the ONE period with funnel shifts, no doubling copy: no further gain, profiles/r05k_*)
 #endif
@@ -450,6 +447,39 @@ __device__ __forceinline__ void dr_span_materialize(RingIO& io, SpanCtx& sp, int
   sp.lo = 0; sp.hi = 0; sp.enabled = 0;
 }
 
+#ifndef BAMD_DEC_FAR_CALL
+#define BAMD_DEC_FAR_CALL 1
+#endif
+// The short matches of a batched step when at least one of them has a source older than the ring: 4 lanes per match, overlapping 4 / 8 / 16-byte
+// pieces, each from the rows in global memory (isfar) or from the ring.  A real call with plain arguments (see its call site in dr_step).
+// fa: length | 0x200 "take it" | far << 31 as gathered by the step; spos / dp: source and destination plane positions of this lane's match.
+__device__ __attribute__((noinline)) void dr_far_pieces_call(volatile uint32_t* lds_, const gu8* out_, uint32_t spos, uint32_t dp, uint32_t fa, int lane) {
+  const uint64_t lv = (uint64_t)lds_;
+  volatile uint32_t* lds = (volatile uint32_t*)(((uint64_t)uni((uint32_t)(lv >> 32)) << 32) | uni((uint32_t)lv));
+  lu8* hist = (lu8*)((BAMD_LAS uint32_t*)lds + 64 + DR_IN / 4u);
+  const gu8* out = uni_ptr(out_);
+  const uint32_t q = (uint32_t)lane & 3u, mlen = fa & 0x1ffu;
+  const bool go = (fa & 0x200u) != 0u, isfar = (fa >> 31) != 0u;
+  lu8* d = hist + (dp & DR_MASK);
+  const lu8* sl = hist + (spos & DR_MASK);
+  const gu8* sg = out + spos;
+  const uint32_t np16 = (mlen + 15u) >> 4;
+  const bool w16 = go && mlen >= 16u && q < np16;
+  const bool w8 = go && mlen >= 8u && mlen < 16u && q < 2u;
+  const bool w4 = go && mlen < 8u && q < 2u;
+  const uint32_t po16 = (q == np16 - 1u) ? mlen - 16u : 16u * q;
+  const uint32_t po8 = q ? mlen - 8u : 0u, po4 = q ? mlen - 4u : 0u;
+  uint4 v16 = make_uint4(0, 0, 0, 0); uint64_t v8 = 0; uint32_t v4 = 0;
+  BAMD_MEM_SYNC();
+  if (w16) v16 = isfar ? g_ld16(sg + po16) : l_ld16(sl + po16);
+  if (w8) v8 = isfar ? g_ld8(sg + po8) : l_ld8(sl + po8);
+  if (w4) v4 = isfar ? g_ld4(sg + po4) : l_ld4(sl + po4);
+  DR_SYNC();
+  if (w16) l_st16(d + po16, v16);
+  if (w8) l_st8(d + po8, v8);
+  if (w4) l_st4(d + po4, v4);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Batched step: up to 16 consecutive sequences whose tokens, literals, offsets (and at most one extension byte per length) all
 // lie in the 64 stream bytes at ip.
@@ -549,69 +579,6 @@ __device__ __forceinline__ uint32_t dr_step(RingIO& io, uint32_t& ip, uint32_t& 
   const uint32_t consumed = (uint32_t)__builtin_amdgcn_readlane((int)nxt_r, (int)(cnt - 1u));
   const uint32_t acc = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)(cnt - 1u));
   const uint32_t W = op + acc, nlo = dr_near_lo(io, W);
-#if BAMD_DEC_MERGE34
-  // ---- 3 + 4 in three LDS round trips (round 5; six before: profiles/r05l_*).  The step is bound by its DEPENDENT LDS round trips (about 300 cycles
-  //      each with 16 waves on the CU, 15 of them per step), not by instructions in flight.  Nothing in section 4 depends on section 3: the short
-  //      matches taken here read only positions in front of the step's output (off >= mrel + ml), which the literal scatter cannot touch, and
-  //      they write positions the literals do not.  So: (a) the two gathers of the match table and the token table's stores + its first read
-  //      travel together; (b) the token word of every byte lane and ALL match sources (ring or rows in global memory) travel together; (c) the
-  //      literal bytes and the match pieces are stored together, one wait behind them. ----
-  // scratch word of a token: valid | length-extension flag << 25 | literal count << 16 | output offset (<= DR_STEP_MAX)
-  const uint32_t dpos_r = op + mrel_r;
-  // a source is taken from the ring (wholly at or above nlo) or from the rows already written (wholly below nlo: nlo <= flushed, by the
-  // static_assert above and because a span's floor is a flushed position); one that straddles nlo goes byte by byte in step 5
-  const bool far_r = src_r + ml_r <= nlo;
-  const bool fast_r = mine && (G == 0 || ml_r >= 4u) && ml_r <= 64u && off_r >= mrel_r + ml_r && (dpos_r & DR_MASK) + ml_r <= DR_RING && (far_r || (src_r >= nlo && (src_r & DR_MASK) + ml_r <= DR_RING));
-  const bool anyfar = __ballot(fast_r && far_r) != 0ull;
-  {
-    const uint32_t r = (uint32_t)lane >> 2, q = (uint32_t)lane & 3u;
-    // (a)
-    const uint32_t fA = bperm(r, fast_r ? (ml_r | 0x200u | (mrel_r << 10) | (far_r ? 0x80000000u : 0u)) : 0u);
-    const uint32_t fB = bperm(r, off_r);
-    io.scr[lane] = 0u;
-    BAMD_LDS_SYNC();
-    if (mine) io.scr[c] = 0x80000000u | excl | (ll_r << 16) | (ext_r << 25);
-    BAMD_LDS_SYNC();
-    const uint64_t mask = __ballot(io.scr[lane] >> 31);
-    const uint64_t below = mask & ((2ull << lane) - 1ull);     // accepted tokens at or before this byte lane
-    const uint32_t s = 63u - (uint32_t)__builtin_clzll(below | 1ull);
-    const uint32_t mlen = fA & 0x1ffu;
-    const bool go = (fA & 0x200u) != 0u, isfar = (fA >> 31) != 0u;
-    const uint32_t dp = op + ((fA >> 10) & 0xfffu), spos = dp - fB;
-    lu8* d = io.hist + (dp & DR_MASK);
-    const lu8* sl = io.hist + (spos & DR_MASK);
-    const uint32_t np16 = (mlen + 15u) >> 4;
-    const bool w16 = go && mlen >= 16u && q < np16;
-    const bool w8 = go && mlen >= 8u && mlen < 16u && q < 2u;
-    const bool w4 = go && mlen < 8u && q < 2u;
-    const uint32_t po16 = (q == np16 - 1u) ? mlen - 16u : 16u * q;
-    const uint32_t po8 = q ? mlen - 8u : 0u, po4 = q ? mlen - 4u : 0u;
-    uint4 v16 = make_uint4(0, 0, 0, 0); uint64_t v8 = 0; uint32_t v4 = 0;
-    // (b)
-    const uint32_t inf = io.scr[s];
-    if (anyfar) {                                              // (wave-uniform: a step without far sources never waits for memory)
-      const gu8* sg = io.out + spos;
-      BAMD_MEM_SYNC();
-      if (w16) v16 = isfar ? g_ld16(sg + po16) : l_ld16(sl + po16);
-      if (w8) v8 = isfar ? g_ld8(sg + po8) : l_ld8(sl + po8);
-      if (w4) v4 = isfar ? g_ld4(sg + po4) : l_ld4(sl + po4);
-#ifdef BAMD_WAVE_EMU
-      if (lane == 0) g_emu_ring_far++;
-#endif
-    } else {
-      if (w16) v16 = l_ld16(sl + po16);
-      if (w8) v8 = l_ld8(sl + po8);
-      if (w4) v4 = l_ld4(sl + po4);
-    }
-    // (c)
-    const uint32_t xe = (inf >> 25) & 1u;
-    const uint32_t k = (uint32_t)lane - s - 1u - xe;
-    if ((uint32_t)lane < consumed && (uint32_t)lane > s + xe && k < ((inf >> 16) & 0x1ffu)) io.hist[(op + (inf & 0xffffu) + k) & DR_MASK] = (uint8_t)B;
-    if (w16) l_st16(d + po16, v16);
-    if (w8) l_st8(d + po8, v8);
-    if (w4) l_st4(d + po4, v4);
-  }
-#else
   // ---- 3. literals: token info goes back to byte-lane space through the 64-dword scratch, then one scattered byte store ----
   // scratch word of a token: valid | length-extension flag << 25 | literal count << 16 | output offset (<= DR_STEP_MAX)
   {
@@ -650,10 +617,31 @@ __device__ __forceinline__ uint32_t dr_step(RingIO& io, uint32_t& ip, uint32_t& 
     const bool w4 = go && mlen < 8u && q < 2u;
     const uint32_t po16 = (q == np16 - 1u) ? mlen - 16u : 16u * q;
     const uint32_t po8 = q ? mlen - 8u : 0u, po4 = q ? mlen - 4u : 0u;
-    uint4 v16 = make_uint4(0, 0, 0, 0); uint64_t v8 = 0; uint32_t v4 = 0;
     // (Tried in round 4: the far pieces kept in their registers and stored into the ring behind the NEXT step's parse, so that their round
     //  trip runs under it.  5-9 % SLOWER on every data set, typesize 2 included where one step in two has a far source - the state it
     //  carries across steps costs more than the wait: profiles/r04/r04n_dec_ab_deferred_far_pieces_rejected.txt.)
+#if BAMD_DEC_FAR_CALL
+    // Round 5: a step with far sources is a function of its own (dr_far_pieces_call).  Inline, its global loads and the ring loads of the
+    // ordinary step shared their destination registers, and the compiler - which cannot know which of the two ran - waited for vmcnt(0) in
+    // front of the ring loads and of every piece store of EVERY step: i.e. for the acknowledgement of the rows the previous step had flushed
+    // (the one in-order counter).  The ordinary step now contains no vector-memory load at all.
+    if (anyfar) {                                              // (wave-uniform: a step without far sources never waits for memory)
+      dr_far_pieces_call((volatile uint32_t*)io.scr, io.out, spos, dp, fA, lane);
+#ifdef BAMD_WAVE_EMU
+      if (lane == 0) g_emu_ring_far++;
+#endif
+    } else {
+      uint4 v16 = make_uint4(0, 0, 0, 0); uint64_t v8 = 0; uint32_t v4 = 0;
+      if (w16) v16 = l_ld16(sl + po16);
+      if (w8) v8 = l_ld8(sl + po8);
+      if (w4) v4 = l_ld4(sl + po4);
+      DR_SYNC();
+      if (w16) l_st16(d + po16, v16);
+      if (w8) l_st8(d + po8, v8);
+      if (w4) l_st4(d + po4, v4);
+    }
+#else
+    uint4 v16 = make_uint4(0, 0, 0, 0); uint64_t v8 = 0; uint32_t v4 = 0;
     if (anyfar) {                                              // (wave-uniform: a step without far sources never waits for memory)
       const gu8* sg = io.out + spos;
       BAMD_MEM_SYNC();
@@ -672,8 +660,8 @@ __device__ __forceinline__ uint32_t dr_step(RingIO& io, uint32_t& ip, uint32_t& 
     if (w16) l_st16(d + po16, v16);
     if (w8) l_st8(d + po8, v8);
     if (w4) l_st4(d + po4, v4);
-  }
 #endif
+  }
   DR_SYNC();
   PROF_LAP(10);
   // ---- 5. everything else in stream order: byte lanes, the periodic extension of the off bytes in front of the match when it
