@@ -447,39 +447,6 @@ __device__ __forceinline__ void dr_span_materialize(RingIO& io, SpanCtx& sp, int
   sp.lo = 0; sp.hi = 0; sp.enabled = 0;
 }
 
-#ifndef BAMD_DEC_FAR_CALL
-#define BAMD_DEC_FAR_CALL 1
-#endif
-// The short matches of a batched step when at least one of them has a source older than the ring: 4 lanes per match, overlapping 4 / 8 / 16-byte
-// pieces, each from the rows in global memory (isfar) or from the ring.  A real call with plain arguments (see its call site in dr_step).
-// fa: length | 0x200 "take it" | far << 31 as gathered by the step; spos / dp: source and destination plane positions of this lane's match.
-__device__ __attribute__((noinline)) void dr_far_pieces_call(volatile uint32_t* lds_, const gu8* out_, uint32_t spos, uint32_t dp, uint32_t fa, int lane) {
-  const uint64_t lv = (uint64_t)lds_;
-  volatile uint32_t* lds = (volatile uint32_t*)(((uint64_t)uni((uint32_t)(lv >> 32)) << 32) | uni((uint32_t)lv));
-  lu8* hist = (lu8*)((BAMD_LAS uint32_t*)lds + 64 + DR_IN / 4u);
-  const gu8* out = uni_ptr(out_);
-  const uint32_t q = (uint32_t)lane & 3u, mlen = fa & 0x1ffu;
-  const bool go = (fa & 0x200u) != 0u, isfar = (fa >> 31) != 0u;
-  lu8* d = hist + (dp & DR_MASK);
-  const lu8* sl = hist + (spos & DR_MASK);
-  const gu8* sg = out + spos;
-  const uint32_t np16 = (mlen + 15u) >> 4;
-  const bool w16 = go && mlen >= 16u && q < np16;
-  const bool w8 = go && mlen >= 8u && mlen < 16u && q < 2u;
-  const bool w4 = go && mlen < 8u && q < 2u;
-  const uint32_t po16 = (q == np16 - 1u) ? mlen - 16u : 16u * q;
-  const uint32_t po8 = q ? mlen - 8u : 0u, po4 = q ? mlen - 4u : 0u;
-  uint4 v16 = make_uint4(0, 0, 0, 0); uint64_t v8 = 0; uint32_t v4 = 0;
-  BAMD_MEM_SYNC();
-  if (w16) v16 = isfar ? g_ld16(sg + po16) : l_ld16(sl + po16);
-  if (w8) v8 = isfar ? g_ld8(sg + po8) : l_ld8(sl + po8);
-  if (w4) v4 = isfar ? g_ld4(sg + po4) : l_ld4(sl + po4);
-  DR_SYNC();
-  if (w16) l_st16(d + po16, v16);
-  if (w8) l_st8(d + po8, v8);
-  if (w4) l_st4(d + po4, v4);
-}
-
 // ---------------------------------------------------------------------------------------------
 // Batched step: up to 16 consecutive sequences whose tokens, literals, offsets (and at most one extension byte per length) all
 // lie in the 64 stream bytes at ip.
@@ -619,28 +586,10 @@ __device__ __forceinline__ uint32_t dr_step(RingIO& io, uint32_t& ip, uint32_t& 
     const uint32_t po8 = q ? mlen - 8u : 0u, po4 = q ? mlen - 4u : 0u;
     // (Tried in round 4: the far pieces kept in their registers and stored into the ring behind the NEXT step's parse, so that their round
     //  trip runs under it.  5-9 % SLOWER on every data set, typesize 2 included where one step in two has a far source - the state it
-    //  carries across steps costs more than the wait: profiles/r04/r04n_dec_ab_deferred_far_pieces_rejected.txt.)
-#if BAMD_DEC_FAR_CALL
-    // Round 5: a step with far sources is a function of its own (dr_far_pieces_call).  Inline, its global loads and the ring loads of the
-    // ordinary step shared their destination registers, and the compiler - which cannot know which of the two ran - waited for vmcnt(0) in
-    // front of the ring loads and of every piece store of EVERY step: i.e. for the acknowledgement of the rows the previous step had flushed
-    // (the one in-order counter).  The ordinary step now contains no vector-memory load at all.
-    if (anyfar) {                                              // (wave-uniform: a step without far sources never waits for memory)
-      dr_far_pieces_call((volatile uint32_t*)io.scr, io.out, spos, dp, fA, lane);
-#ifdef BAMD_WAVE_EMU
-      if (lane == 0) g_emu_ring_far++;
-#endif
-    } else {
-      uint4 v16 = make_uint4(0, 0, 0, 0); uint64_t v8 = 0; uint32_t v4 = 0;
-      if (w16) v16 = l_ld16(sl + po16);
-      if (w8) v8 = l_ld8(sl + po8);
-      if (w4) v4 = l_ld4(sl + po4);
-      DR_SYNC();
-      if (w16) l_st16(d + po16, v16);
-      if (w8) l_st8(d + po8, v8);
-      if (w4) l_st4(d + po4, v4);
-    }
-#else
+    //  carries across steps costs more than the wait: profiles/r04/r04n_dec_ab_deferred_far_pieces_rejected.txt.
+    //  Round 5: because the far loads and the ring loads share their registers, the compiler waits for vmcnt(0) - the previous step's row stores -
+    //  in front of the ring loads and piece stores of EVERY step; with the far form out of line the ordinary step holds no such wait, and
+    //  nothing changes: profiles/r05m_*.  Sections 3 and 4 merged into three LDS round trips instead of six: 6 % SLOWER, profiles/r05l_*.)
     uint4 v16 = make_uint4(0, 0, 0, 0); uint64_t v8 = 0; uint32_t v4 = 0;
     if (anyfar) {                                              // (wave-uniform: a step without far sources never waits for memory)
       const gu8* sg = io.out + spos;
@@ -660,7 +609,6 @@ __device__ __forceinline__ uint32_t dr_step(RingIO& io, uint32_t& ip, uint32_t& 
     if (w16) l_st16(d + po16, v16);
     if (w8) l_st8(d + po8, v8);
     if (w4) l_st4(d + po4, v4);
-#endif
   }
   DR_SYNC();
   PROF_LAP(10);
