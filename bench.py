@@ -98,16 +98,39 @@ def make_chunk(kind, nbytes):
     return DATASETS[kind](nbytes)
 
 
+def _strip_comments(text):
+    """C / C++ source without comments and with runs of white space collapsed (string and character literals are kept as they are)"""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c == '"' or c == "'":
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1]); i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        else:
+            out.append(c); i += 1
+    return " ".join("".join(out).split())
+
+
 def src_fingerprint():
-    """12 hex digits over every file of c-blosc_amd/csrc (the kernels and the engine): stamps the traffic files and the extra file, so
-    that a figure measured on other kernels than the ones running is never quoted (.git does not travel to the GPU box)."""
+    """12 hex digits over the CODE of every file of c-blosc_amd/csrc (the kernels and the engine; comments and white space do not count): stamps
+    the traffic files and the extra file, so that a figure measured on other kernels than the ones running is never quoted (.git does not travel to
+    the GPU box)."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "c-blosc_amd", "csrc")
     for f in sorted(os.listdir(d)):
         h.update(f.encode())
-        with open(os.path.join(d, f), "rb") as fh:
-            h.update(fh.read())
+        with open(os.path.join(d, f), "r", errors="replace") as fh:
+            h.update(_strip_comments(fh.read()).encode())
     return h.hexdigest()[:12]
 
 
