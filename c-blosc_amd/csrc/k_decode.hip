@@ -4,11 +4,10 @@
 // Replaces  blosc_d's split loop (blosc/blosc.c:760-787) and the codecs it calls:
 //   LZ4_decompress_safe   (internal-complibs/lz4-1.10.0/lz4.c:2451 -> LZ4_decompress_generic :2023-2445)
 //   blosclz_decompress    (blosc/blosclz.c:679-789)
-// One wavefront decodes one stream (= one split of one block).  LZ4 (dec_ring.h, round 4): the wave's recent
-// output lives in an LDS ring, sequences are parsed and executed 16 at a time out of LDS, complete 1 KiB rows
-// leave for global memory (the plane-major scratch, or the destination when the chunk has no filter) as
-// coalesced stores nobody waits for.  BloscLZ (below): a 512-byte register window over the compressed bytes,
-// output straight to global memory.
+// One wavefront decodes one stream (= one split of one block).  Both grammars (dec_ring.h): the wave's recent output lives in an LDS ring,
+// sequences are parsed and executed 16 at a time out of LDS, complete 1 KiB rows leave for global memory (the plane-major scratch, or the
+// destination when the chunk has no filter) as coalesced stores nobody waits for.  The wave that completes a block's last stream
+// (bit-)unshuffles the block into the destination (below).
 //
 // Algorithmic HBM bytes per stream: csize read + neblock written.
 #include <hip/hip_runtime.h>

@@ -3,7 +3,7 @@
 // Zlib chunk.  One wavefront per stream, persistent waves + ticket queue, in a kernel of its own (like Zstd's):
 //   * the bit stream is serial: every lane runs the plain-C++ primitives of inflate_serial.h with the SAME values
 //     (wave-uniform; tests/test_inflate_serial_cpu.py checks exactly that code on the CPU against the reference's own zlib).
-//     The stream bytes come out of the 512-byte register window of the LZ4 / BloscLZ decoder (one coalesced load per 256
+//     The stream bytes come out of a 512-byte register window (wave_prims.h; the LZ4 / BloscLZ decoders used it until they moved onto the LDS ring) (one coalesced load per 256
 //     bytes, fetched one slide ahead), the code tables sit in LDS (2.3 KiB per wave), written by lane 0;
 //   * bytes move wave-parallel: literals are collected one per lane (with their final position) and leave 64 at a time,
 //     matches are executed 16 at a time (independent ones by their own lanes in one round trip, the rest through
