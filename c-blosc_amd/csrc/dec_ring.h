@@ -28,11 +28,11 @@ namespace bamd {
 constexpr uint32_t DR_RING = BAMD_DEC_RING, DR_MASK = DR_RING - 1u;
 constexpr uint32_t DR_ROW = 1024u;                 // a row of the ring goes to global memory when it is complete
 constexpr uint32_t DR_STEP_MAX = 2048u;            // output bytes of one batched step at most
+#ifndef BAMD_DEC_HDR_T2
+#define BAMD_DEC_HDR_T2 1
+#endif
 #ifndef BAMD_DEC_INBLOCKS
 #define BAMD_DEC_INBLOCKS 4
-#endif
-#ifndef BAMD_DEC_LAZYIN
-#define BAMD_DEC_LAZYIN 0
 #endif
 constexpr uint32_t DR_INB = BAMD_DEC_INBLOCKS;     // input ring: this many blocks of 256 bytes (a power of two >= 2)
 constexpr uint32_t DR_IN = 256u * DR_INB;
@@ -40,10 +40,10 @@ constexpr uint32_t DR_LDS_BYTES = 256u + DR_IN + DR_RING;   // 64 scratch dwords
 static_assert((DR_RING & DR_MASK) == 0u && DR_RING >= 4096u, "ring size");
 // a step's sources are either in the ring (>= W - DR_RING, W = the step's end) or in rows already written (< W - DR_RING):
 // W - DR_RING + longest match must not exceed what has certainly been flushed (op - DR_ROW)
-#ifndef BAMD_DEC_ROWREG
-#define BAMD_DEC_ROWREG 1           // long power-of-two matches: everything behind the doubled period out of one register set (round 5: - 7 % on reference-written config-2 chunks, profiles/r05j_*; composing the row pattern out of the ONE period with funnel shifts, no doubling copy: no further gain, profiles/r05k_*)
-#endif
-constexpr uint32_t DR_GUARD = BAMD_DEC_ROWREG ? 16u : 0u;
+// Long power-of-two matches take everything behind the doubled period out of one register set (dr_match; round 5: - 7 % on reference-written
+// config-2 chunks against byte-granular pieces around the row boundaries, profiles/r05j_*; composing the row pattern out of the ONE period with funnel
+// shifts, no doubling copy: no further gain, profiles/r05k_*).  Their last piece may store up to 15 bytes beyond the match: the guard band.
+constexpr uint32_t DR_GUARD = 16u;
 static_assert(DR_STEP_MAX + 273u + DR_ROW + DR_GUARD <= DR_RING, "far sources must lie in flushed rows");
 
 #ifdef BAMD_WAVE_EMU
@@ -92,13 +92,8 @@ __device__ __forceinline__ void dr_input(RingIO& io, uint32_t ip) {
   const uint32_t bi = ip >> 8;
   if (bi > io.b_hi) { io.pend = 0u; io.b_hi = bi; }            // jumped over everything present (a long literal run): start again at ip's block
   // the block requested earlier goes in once nothing still needed lives in its slot (its old tenant is block b_hi - 4)
-#if BAMD_DEC_LAZYIN > 0
-  // ... and not before the BAMD_DEC_LAZYIN-th call after the request unless this call needs it: the first use of pv is where the wave waits for
-  // the load, and a step is shorter than a memory round trip under load
-  if (io.pend && io.b_hi < bi + DR_INB && (((ip + 71u) >> 8) >= io.b_hi || ++io.pend > (uint32_t)BAMD_DEC_LAZYIN)) { dr_in_store(io, io.b_hi, io.pv); io.b_hi++; io.pend = 0u; }
-#else
+  // (handing it over one, two or four calls later - the first use of pv is where the wave waits for the load - changes nothing: profiles/r05b_*)
   if (io.pend && io.b_hi < bi + DR_INB) { dr_in_store(io, io.b_hi, io.pv); io.b_hi++; io.pend = 0u; }
-#endif
   if (((ip + 71u) >> 8) >= io.b_hi) {                          // stream start, behind a jump, or the prefetch fell behind: up to three blocks in one round trip
     const uint32_t room = DR_INB - (io.b_hi - bi);             // blocks that may come in without evicting ip's own (b_hi - bi is 0 or 1 here)
     const uint32_t v0 = dr_in_load(io.in, io.n, io.b_hi, io.lane);
@@ -226,31 +221,19 @@ __device__ __forceinline__ void dr_match(RingIO& io, uint32_t& op, uint32_t off,
   }
   // Power-of-two periods up to a row, long matches (byte planes of a few significant bits decode into dozens of 4 KiB runs of period 128;
   // constant planes when spans are off).  The general loop below doubles its stride from `off` up to a row - five dependent LDS copies
-  // before the first full row, 240 k of a 450 k-cycle stream on bench19's planes 2 / 6.  Here: ONE copy of the period (so that two
-  // periods lie back to back), then every lane reads its 16 bytes of any later position straight out of those periods
-  // (plane[q] = plane[b + ((q - b) & (per - 1))]: unaligned 16-byte LDS reads), the piece up to the next row boundary and the one behind
-  // the last are one read + one write each, and the rows in between are the SAME registers stored to the ring and to global memory.
-  // (Every ring write counted from the match's own start instead - one register set for all of them, no piece up to the row boundary - is
-  //  9 % slower: 16-byte LDS writes that are not 16-byte aligned.  profiles/r04/r04zt_*)
+  // before the first full row.  Here: ONE copy of the period (so that two periods lie back to back), then every lane reads its 16 bytes of a
+  // row straight out of those periods (plane[q] = plane[b + ((q - b) & (per - 1))]: one unaligned 16-byte LDS read) - the same 16 bytes for
+  // EVERY row, because the period divides a row - and that one register set is the rest of the first row, every whole row (stored to the
+  // ring and to global memory) and the piece behind the last row boundary.
+  // (Every ring write counted from the match's own start instead - no piece up to the row boundary - is 9 % slower: 16-byte LDS writes that
+  //  are not 16-byte aligned.  profiles/r04/r04zt_*)
   if ((off & (off - 1u)) == 0u && off <= DR_ROW && len >= 2u * DR_ROW && mpos - off >= dr_near_lo(io, mpos + off)) {
     if (off >= 64u) { dr_copy_chunk(io, mpos, mpos - off, off, false, lane); done = off; op = mpos + done; dr_flush_rows(io, op); }
     const uint32_t per = off < 64u ? 32u : off, pm = per - 1u, b0 = mpos - off, l16 = 16u * (uint32_t)lane;     // (off < 64: the head above wrote 64 bytes, off divides 32)
     // 16 bytes of plane position q out of the two periods that end closest in front of `front` (everything written so far is periodic)
     auto base_for = [&](uint32_t front) { const uint32_t t = front - per - 16u; return t - ((t - b0) & pm); };
-    auto fill = [&](uint32_t pos, uint32_t c) {            // plane positions [pos, pos + c), c <= DR_ROW: one read and one write per lane
-      const uint32_t b = base_for(pos), n16 = c >> 4, t0 = c & ~15u;
-      DR_SYNC();
-      uint4 v = make_uint4(0u, 0u, 0u, 0u); uint32_t tb = 0u;
-      if ((uint32_t)lane < n16) v = dr_get16(io.hist, b + ((pos + l16 - b) & pm));
-      if (t0 + (uint32_t)lane < c) tb = io.hist[(b + ((pos + t0 + (uint32_t)lane - b) & pm)) & DR_MASK];
-      DR_SYNC();
-      if ((uint32_t)lane < n16) dr_put16(io.hist, pos + l16, v);
-      if (t0 + (uint32_t)lane < c) io.hist[(pos + t0 + (uint32_t)lane) & DR_MASK] = (uint8_t)tb;
-      DR_SYNC();
-    };
     uint32_t pos = mpos + done;
     const uint32_t end = mpos + len, mis = pos & (DR_ROW - 1u);
-#if BAMD_DEC_ROWREG
     // Round 5: a lane's 16 bytes of ANY row are the same (the period divides a row), so ONE read out of the two periods serves the rest of the first
     // row, every whole row and the piece behind the last boundary - 7 LDS round trips per match instead of 13 - 15 (bench19's planes 2 / 6 are 32 such
     // matches each, a quarter of the block's wave cycles: profiles/r04/r04zl_*).  Lanes that straddle `pos` rewrite up to 15 bytes in front of it with
@@ -274,22 +257,6 @@ __device__ __forceinline__ void dr_match(RingIO& io, uint32_t& op, uint32_t off,
       DR_SYNC();
       return;
     }
-#endif
-    if (mis) { const uint32_t c = DR_ROW - mis; fill(pos, c); pos += c; op = pos; dr_flush_rows(io, op); }      // (len >= 2 rows: the boundary lies inside the match)
-    if (end - pos >= DR_ROW) {                              // pos is a row boundary and everything below it has been flushed
-      const uint32_t b = base_for(pos);
-      DR_SYNC();
-      const uint4 row = dr_get16(io.hist, b + ((pos + l16 - b) & pm));
-      DR_SYNC();
-      for (; end - pos >= DR_ROW; pos += DR_ROW) {
-        l_st16(io.hist + ((pos + l16) & DR_MASK), row);
-        if (DR_FLUSH_ON(io)) g_st16(io.out + pos + l16, row);
-      }
-      io.flushed = pos; op = pos;
-      DR_SYNC();
-    }
-    if (end > pos) { fill(pos, end - pos); op = end; dr_flush_rows(io, op); }
-    return;
   }
   while (done < len) {
     const uint32_t pos = mpos + done, rem = len - done;
@@ -714,7 +681,13 @@ __device__ int lz4_decode_wave(const gu8* __restrict__ in_, int32_t n_, gu8* out
       dr_literals(io, ip, op, ll, lane);
       dr_input(io, ip);
     }
+#if BAMD_DEC_HDR_T2
+    // (a match right behind a match - every long match of a plane of periodic runs: its offset and first length byte are bytes 1 .. 3 of the word
+    //  the step or the peek above has already read; one LDS round trip less per such sequence)
+    const uint32_t t2 = ll ? dr_peek32(io, ip) : hdr >> 8;
+#else
     const uint32_t t2 = dr_peek32(io, ip);
+#endif
     const uint32_t off = t2 & 0xffffu;
     ip += 2;
     uint32_t ml = token & 15u;
