@@ -28,9 +28,6 @@ namespace bamd {
 constexpr uint32_t DR_RING = BAMD_DEC_RING, DR_MASK = DR_RING - 1u;
 constexpr uint32_t DR_ROW = 1024u;                 // a row of the ring goes to global memory when it is complete
 constexpr uint32_t DR_STEP_MAX = 2048u;            // output bytes of one batched step at most
-#ifndef BAMD_DEC_HDR_T2
-#define BAMD_DEC_HDR_T2 1
-#endif
 #ifndef BAMD_DEC_INBLOCKS
 #define BAMD_DEC_INBLOCKS 4
 #endif
@@ -681,13 +678,7 @@ __device__ int lz4_decode_wave(const gu8* __restrict__ in_, int32_t n_, gu8* out
       dr_literals(io, ip, op, ll, lane);
       dr_input(io, ip);
     }
-#if BAMD_DEC_HDR_T2
-    // (a match right behind a match - every long match of a plane of periodic runs: its offset and first length byte are bytes 1 .. 3 of the word
-    //  the step or the peek above has already read; one LDS round trip less per such sequence)
-    const uint32_t t2 = ll ? dr_peek32(io, ip) : hdr >> 8;
-#else
-    const uint32_t t2 = dr_peek32(io, ip);
-#endif
+    const uint32_t t2 = dr_peek32(io, ip);      // (taking these bytes out of `hdr` when there were no literals - one LDS read less per long match of a run plane - changes nothing: profiles/r05n_*)
     const uint32_t off = t2 & 0xffffu;
     ip += 2;
     uint32_t ml = token & 15u;
