@@ -37,9 +37,10 @@ constexpr uint32_t DR_LDS_BYTES = 256u + DR_IN + DR_RING;   // 64 scratch dwords
 static_assert((DR_RING & DR_MASK) == 0u && DR_RING >= 4096u, "ring size");
 // a step's sources are either in the ring (>= W - DR_RING, W = the step's end) or in rows already written (< W - DR_RING):
 // W - DR_RING + longest match must not exceed what has certainly been flushed (op - DR_ROW)
-// Long power-of-two matches take everything behind the doubled period out of one register set (dr_match; round 5: - 7 % on reference-written
-// config-2 chunks against byte-granular pieces around the row boundaries, profiles/r05j_*; composing the row pattern out of the ONE period with funnel
-// shifts, no doubling copy: no further gain, profiles/r05k_*).  Their last piece may store up to 15 bytes beyond the match: the guard band.
+// Long power-of-two matches take everything behind the doubled period out of one register set (dr_match; round 5).  Simpler than the byte-granular
+// pieces around the row boundaries it replaces, and NEUTRAL in time: the "- 7 %" of profiles/r05j_* was one slow library instance of two - with
+// three copies of each build taking turns old and new forms are equal (profiles/r05r_*).  Their last piece may store up to 15 bytes beyond the
+// match: the guard band.
 constexpr uint32_t DR_GUARD = 16u;
 static_assert(DR_STEP_MAX + 273u + DR_ROW + DR_GUARD <= DR_RING, "far sources must lie in flushed rows");
 

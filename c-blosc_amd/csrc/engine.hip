@@ -44,17 +44,21 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 struct DeviceArena {   // one grow-only device allocation carved up per call
   uint8_t* base = nullptr;
+  uint8_t* raw = nullptr;   // what hipMalloc returned (base = raw + skew; BLOSC_AMD_ARENA_SKEW_KIB, a placement experiment: scripts/placement_probe.py)
   size_t cap = 0;
   int ensure(size_t bytes) {
     if (bytes <= cap) return 0;
-    if (base) { (void)hipFree(base); base = nullptr; cap = 0; }
+    if (raw) { (void)hipFree(raw); raw = base = nullptr; cap = 0; }
     size_t want = align_up(bytes + bytes / 8, 1 << 20);
-    HIP_TRY(hipMalloc((void**)&base, want));
+    const char* sk = getenv("BLOSC_AMD_ARENA_SKEW_KIB");
+    const size_t skew = sk ? (size_t)atol(sk) << 10 : 0;
+    HIP_TRY(hipMalloc((void**)&raw, want + skew));
+    base = raw + skew;
     cap = want;
     if (getenv("BLOSC_AMD_DEBUG")) fprintf(stderr, "[blosc_amd] device arena %p, %zu MiB\n", (void*)base, want >> 20);
     return 0;
   }
-  void release() { if (base) (void)hipFree(base); base = nullptr; cap = 0; }
+  void release() { if (raw) (void)hipFree(raw); raw = base = nullptr; cap = 0; }
 };
 struct PinnedArena {
   uint8_t* base = nullptr;
@@ -954,6 +958,11 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   prof_collect(st);
   if (nblk && check_done((const uint32_t*)(P + p_cost), nstr - nstr_z, L.any_zstd ? nstr : 0, "decompress", nstr_zlib)) return -1;
   if (nstr >= 4096) { memcpy(st.dec_cost, P + p_cost, sizeof st.dec_cost); st.dec_cost_valid = true; }
+  if (getenv("BLOSC_AMD_DEBUG_COST")) {
+    fprintf(stderr, "[blosc_amd] decode plane costs:");
+    for (int k = 0; k < 16; k++) fprintf(stderr, " %u", st.dec_cost[k]);
+    fprintf(stderr, "\n");
+  }
   const int32_t* stt = (const int32_t*)(P + p_status);
   for (int i = 0; i < n; i++) {
     if (!live[(size_t)i]) continue;
