@@ -4,7 +4,7 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
 make -C oracle oracle > /dev/null 2>&1
-T=r05_final3
+T=r05_final4
 timeout 1500 python -m pytest tests -m gpu -x -q --no-header -p no:cacheprovider 2>&1 | tee gpurun_out/${T}_pytest_gpu.log | tail -6
 echo "== default bench"; timeout 400 python bench.py --steps 20 --warmup 5 2> gpurun_out/${T}_bench_default.err > gpurun_out/${T}_bench_default.json; wc -c gpurun_out/${T}_bench_default.json gpurun_out/${T}_bench_default.err; cut -c1-700 gpurun_out/${T}_bench_default.json
 cp gpurun_out/bench_extra.json gpurun_out/${T}_bench_extra.json 2>/dev/null
