@@ -16,6 +16,7 @@ from helpers import DATASETS, header, orc_compress, orc_decompress, ptr, ref_com
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+SEED = int(os.environ.get("BLOSC_EMU_SEED", "0"))        # soak runs: BLOSC_EMU_FULL=1 BLOSC_EMU_SEED=1, 2, ... draw other streams in the two random-stream tests and another sample of the parameter grid
 FULL = os.environ.get("BLOSC_EMU_FULL") == "1"          # the default run is sized for a CPU suite of a few minutes; BLOSC_EMU_FULL=1 takes everything
 
 
@@ -110,7 +111,7 @@ def test_random_structured_streams(emulib, oracle, fmt):
     says what they decode to.  (With the decoder of round 4 this sample has failing chunks: the short-period match behind a span.)"""
     from helpers import wrap_planes_as_chunk
     from test_gpu_random_streams import rand_stream
-    rng = np.random.default_rng(1000 + (1 if fmt == 1 else 3))
+    rng = np.random.default_rng(1000 + (1 if fmt == 1 else 3) + 7919 * SEED)
     for k in range(160 if FULL else 24):
         T = int(rng.choice([8, 4, 2, 16])); neb = int(rng.choice([128 << 10, 128 << 10, 64 << 10, 40 << 10, 17 << 10]))
         chunk = wrap_planes_as_chunk([rand_stream(rng, neb, fmt) for _ in range(T)], neb, fmt)
@@ -127,7 +128,7 @@ def test_long_power_of_two_matches_and_the_window_edge(emulib, oracle, fmt):
     and the 16-byte guard band at the far edge of the ring it needs."""
     from helpers import wrap_planes_as_chunk
     from test_gpu_random_streams import edge_stream
-    rng = np.random.default_rng(4242 + fmt)
+    rng = np.random.default_rng(4242 + fmt + 7919 * SEED)
     for k in range(120 if FULL else 16):
         T = int(rng.choice([8, 4, 2])); neb = int(rng.choice([128 << 10, 64 << 10, 33 << 10]))
         chunk = wrap_planes_as_chunk([edge_stream(rng, neb, fmt) for _ in range(T)], neb, fmt)
@@ -363,7 +364,7 @@ def test_damaged_chunks_get_the_references_verdict(emulib, oracle, cname):
 def test_sampled_parameter_grid(emulib, oracle, ref):
     """A random sample of tests/test_gpu_compress.py's grid (typesize x size x data x shuffle x clevel x codec, leftovers and
     typesizes that are not split included), sized for the emulator: headers as the reference writes them, chunks read by everybody."""
-    rng = np.random.default_rng(99)
+    rng = np.random.default_rng(99 + 7919 * SEED)
     for k in range(70 if FULL else 25):
         cname = [b"lz4hc", b"lz4", b"blosclz", b"zstd", b"zlib"][k % 5]
         T = int(rng.choice([1, 2, 3, 4, 7, 8, 16, 17, 32]))
