@@ -328,6 +328,48 @@ def test_reference_written_zlib_chunks_through_the_queued_kernel(emulib, oracle)
     assert rejected >= 2
 
 
+def test_getitem_ranges_and_tight_destinations_sample(emulib, oracle, ref):
+    """A seeded sample of blosc_getitem ranges - valid, empty, negative, past the end - on reference-written chunks (return value and bytes of the
+    oracle = the reference, blosc.c:1601-1740), and of blosc_compress_ctx into destinations from too small to ample: never more than destsize,
+    0 only when it does not fit, whatever is returned decodes with the oracle (blosc.c:1165-1178, :1322-1367; tests/test_maxout.c)."""
+    rng = np.random.default_rng(4711 + 7919 * SEED)
+    for k in range(60 if FULL else 16):
+        cname = ["lz4", "blosclz", "lz4hc", "zlib", "zstd"][k % (5 if ref is not None else 2)]       # (the oracle writes LZ4 and BloscLZ only)
+        T = int(rng.choice([1, 2, 3, 4, 8, 16])); shuffle = int(rng.choice([0, 1, 2]))
+        n = int(rng.choice([16, 1000, 4096 + 7, 30000, 70001])); n -= n % T if rng.integers(0, 2) else 0
+        data = DATASETS[str(rng.choice(["bench19", "smallints", "randwalk", "zeros"]))](n)
+        clevel, bs = int(rng.choice([1, 5, 9])), int(rng.choice([0, 0, 1024, 4096]))
+        r, chunk = ref_compress(ref, data, T, clevel, shuffle, cname.encode(), blocksize=bs) if ref is not None else orc_compress(oracle, data, T, clevel, shuffle, cname, blocksize=bs)
+        assert r > 0
+        ni = n // T
+        for _ in range(10):
+            mode = int(rng.integers(0, 6))
+            if mode == 0: s0, cnt = int(rng.integers(0, max(ni, 1))), 0
+            elif mode == 1: s0, cnt = -int(rng.integers(1, 5)), int(rng.integers(0, 5))
+            elif mode == 2: s0 = int(rng.integers(0, ni + 1)); cnt = ni - s0 + int(rng.integers(1, 4))
+            else:
+                s0 = int(rng.integers(0, max(ni, 1))); cnt = int(rng.integers(0, ni - s0 + 1))
+            want = np.full(max(cnt, 0) * T + 64, 0xEE, np.uint8); got = want.copy()
+            r0 = ref.blosc_getitem(ptr(chunk), s0, cnt, ptr(want)) if ref is not None else oracle.orc_getitem(ptr(chunk), s0, cnt, ptr(want))
+            r1 = emulib.blosc_getitem(ptr(chunk), s0, cnt, ptr(got))
+            assert r0 == r1, (cname, T, n, s0, cnt, r0, r1)
+            if r0 > 0: assert np.array_equal(got[:r0], want[:r0])
+            assert np.all(got[max(r0, 0):] == 0xEE)
+        if cname in ("zlib", "zstd") and n > 40000:
+            continue
+        for _ in range(4):
+            room = int(rng.choice([0, 1, 15, 16, 17, n // 4, n // 2, n, n + 15, n + 16, n + 100]))
+            out = np.full(room + 64, 0xEE, np.uint8)
+            rc = emulib.blosc_compress_ctx(5, shuffle, T, n, ptr(data), ptr(out), room, cname.encode(), 0, 1)
+            assert np.all(out[room:] == 0xEE), "wrote past destsize"
+            assert 0 <= rc <= room, (cname, T, n, room, rc)
+            if room >= n + 16: assert rc > 0
+            if rc > 0:
+                back = np.zeros(n, np.uint8)
+                rd = ref.blosc_decompress_ctx(ptr(out), ptr(back), n, 1) if ref is not None else oracle.orc_decompress(ptr(out), ptr(back), n)
+                assert rd == n and np.array_equal(back, data), (cname, T, n, room, rc, rd)
+
+
 def test_negative_nbytes_is_rejected_where_the_reference_returns_0(emulib, oracle, ref):
     """bit 31 of the header's nbytes set.  The reference (blosc.c:1485-1511) counts a negative number of blocks, runs none and
     returns 0 with nothing written; the library answers -1 and writes nothing.  Pinned here so that the difference is a stated one."""
