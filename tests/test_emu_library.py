@@ -20,6 +20,8 @@ SEED = int(os.environ.get("BLOSC_EMU_SEED", "0"))        # soak runs: BLOSC_EMU_
 FULL = os.environ.get("BLOSC_EMU_FULL") == "1"          # the default run is sized for a CPU suite of a few minutes; BLOSC_EMU_FULL=1 takes everything
 
 
+SOAK = 7919 * int(os.environ.get("BLOSC_EMU_SEED", "0"))      # soak runs (BLOSC_EMU_SEED=1, 2, ...): every random draw of this file moves
+
 @pytest.fixture(scope="module")
 def emulib():
     if not os.path.exists(CLANG):
@@ -181,7 +183,7 @@ def test_typesize_2_and_16_take_the_fused_paths(emulib, oracle, ref, T):
     """Round 3: the byte (un)shuffle of typesize 2 and 16 runs inside the encode / decode kernels like that of 4 and 8 (enc_shuffle.h:
     shuffle_block_task_x, k_decode.hip: unshuffle_block_wave_T<2> / unshuffle_block_wave_16 with the lane table): split blocks with
     constant, periodic, noisy and incompressible planes + an unsplit leftover block, written here and by the reference."""
-    rng = np.random.default_rng(70 + T)
+    rng = np.random.default_rng(70 + T + SOAK)
     ne = 16384                                                    # bytes per plane of a full block: spans need >= 16 KiB matches
     nfull = 2 if (FULL or T == 2) else 1
     planes = []
@@ -259,7 +261,7 @@ def test_reference_written_zstd_chunks_through_the_two_phase_path(emulib, oracle
     three-refill bit reader of round 3), k_zstd_exec with the unshuffle of the decoding wave - intact, and damaged with the oracle's verdict
     and bytes (the oracle is pinned to the reference on damaged frames, tests/test_oracle_zstd.py)."""
     z = np.load(os.path.join(ROOT, "tests", "golden", "ref_zstd_chunks.npz"))
-    rng = np.random.default_rng(33)
+    rng = np.random.default_rng(33 + SOAK)
     before = (C.c_ulonglong * 5)(); emulib.emu_zstd_path_counts(before)
     items = []
     for k, m in enumerate(z["meta"]):
@@ -299,7 +301,7 @@ def test_reference_written_zlib_chunks_through_the_queued_kernel(emulib, oracle)
     launches it since round 3 - per-XCD queues, the block unshuffled by the wave that completes its last stream - intact, and damaged
     with the oracle's verdict and bytes."""
     z = np.load(os.path.join(ROOT, "tests", "golden", "ref_zlib_chunks.npz"))
-    rng = np.random.default_rng(34)
+    rng = np.random.default_rng(34 + SOAK)
     items = []
     for k, m in enumerate(z["meta"]):
         dname, n, T, clevel, shuffle, bs = m.split(",")

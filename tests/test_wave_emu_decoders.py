@@ -18,6 +18,8 @@ LZ4, BLOSCLZ = 0, 1
 FULL = __import__("os").environ.get("BLOSC_EMU_FULL") == "1"      # the default run is sized for a CPU suite of a few minutes
 
 
+SOAK = 7919 * int(os.environ.get("BLOSC_EMU_SEED", "0"))      # soak runs (BLOSC_EMU_SEED=1, 2, ...): every random draw of this file moves
+
 def _decode(emu, kind, stream, cap):
     emu.emu_lz_decode.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     s = np.concatenate([np.ascontiguousarray(stream, dtype=np.uint8), np.zeros(256, np.uint8)])     # the engine pads its buffers as well
@@ -57,7 +59,7 @@ def _compress(oracle, kind, data, clevel=5):
 
 
 def _inputs(oracle):
-    rng = np.random.default_rng(21)
+    rng = np.random.default_rng(21 + SOAK)
     out = []
     for dname, T in (("bench19", 8), ("linspace", 8), ("randwalk", 8), ("smallints", 4), ("arange", 4)):
         d = DATASETS[dname](T * 16384)
@@ -92,7 +94,7 @@ def test_reference_written_streams(emu, oracle, kind):
 def test_handbuilt_lz4_streams(emu, oracle):
     """The adversarial streams of tests/test_gpu_decompress.py (a thinner grid): overlapping matches at small offsets and at the
     copy-path boundaries, matches that read their own sequence's literals, long literal runs, long runs."""
-    rng = np.random.default_rng(11)
+    rng = np.random.default_rng(11 + SOAK)
     streams = []
     for off in list(range(1, 20)) + [31, 32, 33, 63, 64, 65, 127, 128, 255, 256, 1023, 1024, 1025, 2048, 4099]:
         for mlen in [4, 7, 16, 19, 63, 64, 65, 255, 300, 1024, 1025, 2049, 5000, 70000]:
@@ -121,7 +123,7 @@ def test_handbuilt_lz4_streams(emu, oracle):
 def test_dense_near_match_chains(emu, oracle):
     """Many short sequences per 64 stream bytes whose matches reach into the output of the sequences right before them: the
     LDS-assembled step (lz4_step_lds)."""
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(77 + SOAK)
 
     def chain(nseq, maxoff, maxml, maxll, first_lit):
         s = bytearray(); produced = 0
@@ -149,7 +151,7 @@ def test_dense_near_match_chains(emu, oracle):
 
 
 def test_handbuilt_blosclz_streams(emu, oracle):
-    rng = np.random.default_rng(12)
+    rng = np.random.default_rng(12 + SOAK)
     oracle.orc_blosclz_decompress.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     streams = []
     for dist in list(range(1, 9)) + [32, 63, 64, 256, 1024, 8191, 8192, 8193, 20000]:          # (the 73 KiB distances stay with the GPU suite: minutes of 32-byte literal runs here)
@@ -227,7 +229,7 @@ def test_zlib_streams_written_by_zlib(emu, oracle):
     stored blocks - and damaged copies of them, which must get the oracle's verdict."""
     from test_oracle_zlib import _un, _zo, stock_streams
     zo = _zo(oracle)
-    rng = np.random.default_rng(8)
+    rng = np.random.default_rng(8 + SOAK)
     n_ok = n_bad = 0
     for s, data in stock_streams(sizes=(1, 17, 255, 1500) if FULL else (17, 1500)):
         r, got = _entropy_decode(emu, ZLIB, s, data.size)
@@ -252,7 +254,7 @@ def test_zstd_frames(emu, oracle, ref):
     """Frames of the reference's ZSTD_compress (levels 1 / 3 / 5 / 19: raw, RLE and Huffman literals, predefined / RLE / FSE / repeat
     sequence tables) where oracle/_ref ships, and frames written by this repo's own encoder (all its modes) run on the same emulator."""
     oracle.orc_zstd_decompress.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
-    rng = np.random.default_rng(14)
+    rng = np.random.default_rng(14 + SOAK)
     inputs = [x for x in _inputs(oracle) if x.size <= 40000][:9 if FULL else 3]
     inputs.append(np.concatenate([DATASETS["bench19"](131072 * 8).reshape(-1, 8).T[1], rng.integers(0, 256, 3000, dtype=np.uint8)]))   # several blocks
     n = 0
@@ -305,7 +307,7 @@ def test_fused_block_decode(emu, oracle, codec, fmt, T):
     table / register row), incompressible planes are read where they lie in the chunk, and the last stream's wave unshuffles."""
     from helpers import header, orc_compress
     emu.emu_decode_block.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_uint, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
-    rng = np.random.default_rng(30 + T)
+    rng = np.random.default_rng(30 + T + SOAK)
     ne = 65536                                                     # bytes per plane: long enough for spans (>= 16 KiB matches)
     bsize = ne * T
     seen = {"span": 0, "small": 0, "raw": 0, "plain": 0, "self": 0}
@@ -382,7 +384,7 @@ def test_ring_steps_take_reference_streams(emu, oracle, ref):
     assert seqs >= 4 and steps >= 50 * seqs, (seqs, steps)
     assert emu.emu_ring_far() - far0 >= 20, emu.emu_ring_far() - far0        # bench19 planes reach back up to 32 KiB: beyond the 8 KiB ring
     # damaged copies of one stream: verdict and bytes of the oracle
-    rng = np.random.default_rng(5)
+    rng = np.random.default_rng(5 + SOAK)
     stream = _compress(oracle, LZ4, planes[1])
     for trial in range(60 if FULL else 25):
         s = stream.copy()
@@ -395,7 +397,7 @@ def test_long_periodic_matches_take_the_row_path(emu, oracle):
     """dec_ring.h: dr_match's path for power-of-two periods (one copy of the period, 16-byte pieces read out of two periods, identical rows
     stored from registers): every period 1 ... 1024, matches of 2 ... 40 rows starting at odd plane positions, several in one stream (the
     ring wraps, rows are flushed in between), and the neighbours of the powers of two (which must NOT take it) - the oracle's bytes."""
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(77 + SOAK)
     offs = [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 3, 48, 96, 127, 129, 1000, 1023, 1025, 2048]
     for trial, off in enumerate(offs * (2 if FULL else 1)):
         stream = bytearray()

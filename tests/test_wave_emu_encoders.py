@@ -22,6 +22,8 @@ FULL = os.environ.get("BLOSC_EMU_FULL") == "1"          # the default run is siz
 LZ4, BLOSCLZ, LZ4HC, ZSTD, ZLIB, ZSTD_TABLES, ZSTD_SEARCH, ZLIB_SEARCH, ZSTD_HUF, ZSTD_SEARCH_HUF, ZLIB_DYN, ZLIB_DYN_SEARCH = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 
 
+SOAK = 7919 * int(os.environ.get("BLOSC_EMU_SEED", "0"))      # soak runs (BLOSC_EMU_SEED=1, 2, ...): every random draw of this file moves
+
 @pytest.fixture(scope="module")
 def emu():
     if not os.path.exists(CLANG):
@@ -74,7 +76,7 @@ def _plane(dname, n, T=8, j=0):
 @pytest.mark.parametrize("kind", [LZ4, BLOSCLZ, LZ4HC], ids=["lz4", "blosclz", "lz4hc"])
 def test_streams_decode_with_oracle_and_reference(emu, oracle, ref, kind):
     oracle.orc_blosclz_decompress.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
-    rng = np.random.default_rng(5)
+    rng = np.random.default_rng(5 + SOAK)
     cases = 0
     inputs = []
     for dname in ["bench19", "linspace", "randwalk", "smallints", "arange"]:
@@ -153,7 +155,7 @@ def _zstd_reads(oracle, ref, stream, data):
 
 
 def _entropy_inputs():
-    rng = np.random.default_rng(9)
+    rng = np.random.default_rng(9 + SOAK)
     inputs = []
     for dname in ["bench19", "linspace", "randwalk", "smallints", "arange"]:
         for j in (1, 5):
@@ -225,7 +227,7 @@ def test_zstd_huffman_literals(emu, oracle, ref):
     space), values above 128 (the weights travel FSE-compressed), runs of 64 .. 130 000 literals (one stream / four streams, the three
     header sizes).  Every frame is read by the oracle and ZSTD_decompress; where the bytes are compressible as literals the frames must
     be smaller than with raw literals."""
-    rng = np.random.default_rng(3)
+    rng = np.random.default_rng(3 + SOAK)
     smaller = tried = 0
     for trial in range(16):
         n = int(rng.choice([255, 256, 300, 1000, 1023, 1024, 5000, 16383, 16384, 20000]))
@@ -270,7 +272,7 @@ def test_zlib_dynamic_codes_pay(emu):
     rb, s = _encode(emu, ZLIB_DYN, block, clevel=5)
     assert 0 < rb < block.size * 0.6 and zlib.decompress(s.tobytes()) == block.tobytes()
     # odd symbol statistics: one literal value, no match at all, one distance only, every length symbol
-    rng = np.random.default_rng(6)
+    rng = np.random.default_rng(6 + SOAK)
     odd = [np.zeros(5000, np.uint8), rng.integers(0, 256, 3000, dtype=np.uint8), np.tile(rng.integers(0, 256, 700, dtype=np.uint8), 30),
            np.concatenate([np.tile(rng.integers(0, 256, int(k), dtype=np.uint8), 3) for k in range(3, 300)]),
            rng.choice(3, 20000, p=[0.98, 0.01, 0.01]).astype(np.uint8), np.arange(70000, dtype=np.uint32).view(np.uint8)[:70000]]

@@ -4,12 +4,15 @@ unshuffle_block_wave) - the device source on the wavefront emulator, against the
 blosc/shuffle-generic.h) and the oracle's stream decoders."""
 import ctypes as C
 
+import os
 import numpy as np
 import pytest
 
 from helpers import DATASETS, ptr
 from test_wave_emu_encoders import emu  # noqa: F401
 
+
+SOAK = 7919 * int(os.environ.get("BLOSC_EMU_SEED", "0"))      # soak runs (BLOSC_EMU_SEED=1, 2, ...): every random draw of this file moves
 
 def _api(emu):
     emu.emu_shuffle_block.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p]
@@ -22,7 +25,7 @@ def _api(emu):
 @pytest.mark.parametrize("T", [2, 4, 8, 16, 3, 5, 6, 7, 12, 17, 24, 25, 31, 32])      # 2 / 4 / 8 / 16: register transposes; the others: the LDS-tile forms of round 4
 def test_shuffle_and_unshuffle_equal_the_oracles(emu, oracle, T):
     e = _api(emu)
-    rng = np.random.default_rng(T)
+    rng = np.random.default_rng(T + SOAK)
     for bsize in [256 * T, 1024 * T, 1280 * T, 4096 * T, 256 * 1024] + ([128 * T, 384 * T + 7] if T not in (2, 4, 8, 16) else []):
         for data in (rng.integers(0, 256, bsize, dtype=np.uint8), DATASETS["bench19"](bsize), DATASETS["linspace"](bsize)):
             want = np.zeros(bsize, np.uint8)
@@ -51,7 +54,7 @@ def test_periodic_planes_are_found_and_written_as_one_match(emu, oracle, T):
     are not periodic, or periodic only up to some row."""
     e = _api(emu)
     oracle.orc_blosclz_decompress.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
-    rng = np.random.default_rng(40 + T)
+    rng = np.random.default_rng(40 + T + SOAK)
     N = 8192                                                                  # bytes per plane
     for trial in range(12):
         planes = []; expect = []
@@ -97,7 +100,7 @@ def test_block_through_the_kernels_task_functions(emu, oracle, T, fmt, mode):
     short-period planes through emit_periodic_stream, the others through the match finder), incompressible planes report 0."""
     emu.emu_encode_block.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint, C.c_void_p, C.c_uint, C.POINTER(C.c_int)]
     oracle.orc_blosclz_decompress.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
-    rng = np.random.default_rng(50 + T + fmt)
+    rng = np.random.default_rng(50 + T + fmt + SOAK)
     ne = 8192
     for trial in range(4):
         planes = []
