@@ -243,7 +243,7 @@ def test_zstd_huffman_literals(emu, oracle, ref):
             tried += 1
             assert rb <= (ra or data.size)
             smaller += rb < (ra or data.size)
-    assert tried > 6 and smaller > (0 if SOAK else 5)          # (how many draws are compressible as literals depends on the draws: the count is pinned for the default seed only)
+    assert tried > (0 if SOAK else 6) and smaller > (0 if SOAK else 5)          # (how many draws are compressible as literals depends on the draws: the count is pinned for the default seed only)
     for dname, T, want in (("smallints", 4, 0.90), ("randwalk", 8, 1.001)):
         d = DATASETS[dname](131072)
         block = np.ascontiguousarray(d.reshape(-1, T).T).reshape(-1)           # an unsplit shuffled block, as blosc hands it to Zstd
