@@ -31,7 +31,9 @@ def emulib():
     so = os.path.join(tools, "libblosc_amd_emu.so")
     deps = [os.path.join(tools, "blosc_emu_lib.cpp"), os.path.join(tools, "wave_emu", "wave_emu.h"), os.path.join(tools, "wave_emu", "hip_emu_runtime.h")]
     deps += [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h"))]
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
+    if os.environ.get("BLOSC_EMU_LIB"):          # a build of one's own, e.g. with -fsanitize=address (HISTORY.md: the sanitizer pass of round 5)
+        so = os.environ["BLOSC_EMU_LIB"]
+    elif not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call([CLANG, "-std=c++17", "-O1", "-shared", "-fPIC", "-w", "-I", os.path.join(tools, "wave_emu"), "-I", csrc,
                                "-I", os.path.join(ROOT, "include"), "-x", "c++", deps[0], "-o", so, "-lpthread"])
     L = C.CDLL(so)
