@@ -624,19 +624,26 @@ static int classify_for_decompress(const Header& h, size_t srcsize, size_t dests
   if (h.blocksize <= 0 || (size_t)h.blocksize > destsize || h.blocksize > kMaxBlockSize || h.typesize <= 0) { *res = -1; return 0; }
   if (h.version != kVersionFormat) { *res = -1; return 0; }                    // blosc.c:1474-1477
   if (h.flags & kFlagReserved) { *res = -1; return 0; }                        // blosc.c:1478-1481
-  if (h.nbytes < 0 || (size_t)h.nbytes > destsize) { *res = -1; return 0; }    // blosc.c:1490-1492
+  // A NEGATIVE nbytes (bit 31 set: damaged input only) is not "> destsize" for the reference's signed comparison (blosc.c:1490); it then counts
+  // nbytes / blocksize <= 0 blocks (C's truncating division, the leftover is <= 0: blosc.c:1485-1487), passes or fails the remaining header
+  // checks with that count, runs no block and returns 0 with nothing written (serial_blosc's loop, blosc.c:814).  Same here (round 6; rounds 1 - 5
+  // answered -1).
+  const bool neg = h.nbytes < 0;
+  if (!neg && (size_t)h.nbytes > destsize) { *res = -1; return 0; }            // blosc.c:1490-1492
   if (srcsize && (h.cbytes < 0 || (size_t)h.cbytes > srcsize)) { *res = -1; return 0; }  // extension: caller told us the buffer size
   if (h.flags & kFlagMemcpyed) {
-    if (h.nbytes + kMaxOverhead != h.cbytes) { *res = -1; return 0; }          // blosc.c:1494-1499
+    if ((int32_t)((uint32_t)h.nbytes + (uint32_t)kMaxOverhead) != h.cbytes) { *res = -1; return 0; }   // blosc.c:1494-1499
     *fmt = 0;
+    if (neg) { *res = 0; return 0; }
     return 1;
   }
   const int f = (h.flags & 0xe0) >> 5;                                         // blosc.c:525-574
   if (f != FMT_BLOSCLZ && f != FMT_LZ4 && f != FMT_ZLIB && f != FMT_ZSTD) { *res = -5; return 0; }   // Snappy: not built, like a stock build without it
   if (h.versionlz != 1) { *res = -9; return 0; }
   *fmt = f;
-  int32_t nblocks = h.nbytes / h.blocksize + ((h.nbytes % h.blocksize) ? 1 : 0);
+  int32_t nblocks = h.nbytes / h.blocksize + ((h.nbytes % h.blocksize) > 0 ? 1 : 0);
   if (nblocks > (h.cbytes - 16) / 4) { *res = -1; return 0; }                  // blosc.c:1504-1507
+  if (neg) { *res = 0; return 0; }                                             // nblocks <= 0: nothing runs
   return 1;
 }
 

@@ -697,6 +697,7 @@ int orc_decompress(const void* src_, void* dest_, size_t destsize) {
   int fmt = 0;
   if (flags & 2) {
     if (n + ORC_MAX_OVERHEAD != cbytes) return -1;
+    if (n < 0) return 0;                   /* a negative size counts nblocks <= 0: serial_blosc's loop (blosc.c:814) runs no block and returns 0 */
     memcpy(dest, src + 16, (size_t)n);     /* serial_blosc:843-848, block by block == one copy */
     return n;
   }

@@ -103,6 +103,46 @@ def test_error_returns_match_oracle(pkg, oracle, lib):
     assert got == -1
 
 
+def test_negative_nbytes_gets_the_references_verdict(pkg, oracle, lib, ref):
+    """A header whose nbytes has bit 31 set (damaged input only): the reference counts nbytes / blocksize <= 0 blocks, runs none and returns 0 with
+    nothing written, unless one of its remaining header checks fails first (blosc.c:1463-1511).  Rounds 1 - 5 answered -1 (a stated deviation, closed in
+    round 6): the verdicts must be EQUAL, through the stock entry point and through the batched device-resident one."""
+    import torch
+    assert ref is not None, "oracle/_ref must travel to the GPU box"
+    data = DATASETS["bench19"](300000)
+    for cname in ("lz4", "blosclz"):
+        _, good = orc_compress(oracle, data, 8, 5, 1, cname)
+        base = good.copy(); base[7] ^= 0x80
+        variants = [("plain", base)]
+        t = base.copy(); t[4:8] = np.array([-1], "<i4").view(np.uint8); variants.append(("nbytes -1", t))
+        t = base.copy(); t[4:8] = np.array([-(1 << 31)], "<i4").view(np.uint8); variants.append(("nbytes INT_MIN", t))
+        t = base.copy(); t[2] |= 0x02; variants.append(("memcpyed flag, sizes disagree", t))
+        t = base.copy(); t[2] |= 0x02; t[12:16] = (t[4:8].view("<i4") + 16).view(np.uint8); variants.append(("memcpyed flag, sizes agree", t))
+        t = base.copy(); t[2] = (t[2] & 0x1f) | (2 << 5); variants.append(("snappy format id", t))
+        t = base.copy(); t[1] = 7; variants.append(("versionlz", t))
+        t = base.copy(); t[12:16] = np.array([0], "<i4").view(np.uint8); variants.append(("cbytes 0", t))
+        t = base.copy(); t[0] = 3; variants.append(("version", t))
+        t = base.copy(); t[2] |= 0x08; variants.append(("reserved flag", t))
+        t = base.copy(); t[8:12] = np.array([64], "<i4").view(np.uint8); variants.append(("small blocksize", t))
+        want = []
+        for name, t in variants:
+            dst = np.full(data.size, 0xEE, np.uint8)
+            rr = ref.blosc_decompress_ctx(ptr(t), ptr(dst), data.size, 1)
+            assert np.all(dst == 0xEE)
+            want.append(rr)
+            dst = np.full(data.size, 0xEE, np.uint8)
+            rg = lib.blosc_decompress_ctx(ptr(t), ptr(dst), data.size, 1)
+            assert rg == rr and np.all(dst == 0xEE), (cname, name, rg, rr)
+        assert want[0] == 0
+        dev = torch.device("cuda:0")
+        d_src = [torch.from_numpy(t).to(dev) for _, t in variants]
+        d_dst = [torch.full((data.size,), 0xA5, dtype=torch.uint8, device=dev) for _ in variants]
+        b = pkg.DeviceBatch([t.data_ptr() for t in d_src], [t.size for _, t in variants], [t.data_ptr() for t in d_dst], [data.size] * len(variants))
+        assert b.decompress(with_srcsize=False) == 0          # (with source sizes the batched call also rejects a cbytes beyond the buffer: an extension the reference has no argument for)
+        assert list(b.results()) == want, (cname, list(b.results()), want)
+        for t in d_dst: assert bool((t == 0xA5).all())
+
+
 def test_corrupt_payload_same_verdict_and_bytes_as_oracle(pkg, oracle):
     """Random damage to LZ4 / BloscLZ chunks, device-resident, output in canary-padded buffers: the verdict equals
     the oracle's (itself pinned to the reference), accepted chunks carry the oracle's bytes, and nothing is
