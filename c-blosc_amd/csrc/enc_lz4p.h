@@ -1,0 +1,342 @@
+// enc_lz4p.h — the LZ4 stream encoder of one wavefront with a PARALLEL parse and emit (round 6; included by k_encode.hip inside namespace bamd,
+// behind enc_lz.h whose window, table and helper functions it uses).
+//
+// Replaces  LZ4_compress_fast  (lz4.c:1453 -> LZ4_compress_generic_validated :930-1338) for one stream, like lz_encode_wave<EF_LZ4> (enc_lz.h),
+// which it supersedes for LZ4 (BAMD_ENC_PAR=0 brings the old loop back for A/B runs; BloscLZ and the Zstd / zlib front ends still use it).
+//
+// Why: lz_encode_wave looks at 64 positions per step in parallel, but then SELECTS AND EMITS ONE SEQUENCE AT A TIME: wave-wide maximum, readlanes,
+// extension loads, a store, re-selection behind the match - about 160 wave-instructions and two to three dependent round trips per sequence, 2.3
+// sequences per step on bench19's noisy planes (profiles/r05a_enc_phase_t8.txt: 6.3 k of a step's 10.3 k cycles; the CU's scalar unit 60 % busy).
+// Here the step's whole greedy parse is resolved at once:
+//   * every lane packs (length - lane | lane | length) of its candidate into one word; a SUFFIX maximum over the lanes (4 DPP row shifts + the three
+//     row totals) tells every position "who wins if the search starts here" - the selection rule of lz_encode_wave, for all start positions at once;
+//   * "start -> end of the winner's match" is a next-pointer per lane; the chain from the step's first free position is resolved by pointer
+//     doubling in rank space (7 ds_bpermute, the same trick as the decoder's token chain, dec_ring.h): rank lane r holds the r-th sequence;
+//   * backward extensions come out of the four bytes fetched in front of every candidate (never more than four here: see below), sizes are
+//     prefix-summed over the rank lanes (one DPP row scan), and ALL sequences of the step leave together: one byte store for every literal of
+//     the step, one for the tokens, one 2-byte store for the offsets;
+//   * only a match that fills all RANK_CAP compared bytes needs memory (its forward extension): the chain stops behind it and picks up again at
+//     its true end - one extra round trip for that sequence, as before.
+// The parse is the old one's (same ranking, same table insertions) with two simplifications that cost a fraction of a per cent of ratio:
+// backward extension stops at four bytes (the old loop fetched more from memory when all four matched: 5 % of bench19's sequences), and a search
+// never STARTS at the step's last position (lane 63 is the chain's absorbing stop).
+#ifndef BAMD_ENC_PAR
+#define BAMD_ENC_PAR 1
+#endif
+constexpr int ENC_SCR_BYTES = 256;     // 64 dwords behind the hash table: sequence info on its way from rank lanes to byte lanes
+#ifndef BAMD_ENC_BACK2
+#define BAMD_ENC_BACK2 1     // sequences whose four bytes in front all match look at eight more (one more memory round trip for the steps that hold such a sequence)
+#endif
+#ifndef BAMD_ENC_PREFULL
+#define BAMD_ENC_PREFULL 1   // a step that begins with pending literals (behind skipped, match-less steps) extends its first match backwards into them, up to 64 bytes
+#endif
+
+template <int N> __device__ __forceinline__ uint32_t dpp_row_shl0(uint32_t v) {   // lane i <- lane i+N of its 16-lane row, 0 outside
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x100 + N, 0xf, 0xf, true);
+}
+__device__ __forceinline__ uint32_t umax32(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+// wave_common_fwd (enc_lz.h) with one row per trip instead of two behind the first 256 bytes: 8 registers in flight instead of 16 - inside the parse of
+// lz4_encode_wave_par the rank lanes' state is live around it, and the long comparisons (a run plane's 4 KiB, a 96 KiB period) are few per stream.
+// Same contract: leading equal bytes of src[a..] and src[b..], at most maxlen, a > b, never reads at or beyond src + n; uniform arguments and result.
+__device__ __forceinline__ uint32_t wave_common_fwd_lite(const gu8* src, uint32_t n, uint32_t a, uint32_t b, uint32_t maxlen, int lane) {
+  uint32_t done = 0;
+  if (maxlen && a + 256u <= n) {
+    const uint32_t x = g_ld4(src + a + 4 * lane) ^ g_ld4(src + b + 4 * lane);
+    const uint32_t q = 4u * (uint32_t)lane;
+    uint32_t e0 = x ? (uint32_t)(__builtin_ctz(x) >> 3) : 4u;
+    const uint32_t r0 = q < maxlen ? maxlen - q : 0u;
+    if (e0 > r0) e0 = r0;
+    const uint64_t s0 = __ballot(e0 < 4u);
+    if (s0) { const int f = __builtin_ctzll(s0); return 4u * (uint32_t)f + (uint32_t)__builtin_amdgcn_readlane((int)e0, f); }
+    done = 256u;
+  }
+  while (done < maxlen && a + done + 1024u <= n) {
+    const uint4 x0 = g_ld16(src + a + done + 16 * lane), y0 = g_ld16(src + b + done + 16 * lane);
+    const uint32_t q1 = done + 16u * (uint32_t)lane;
+    uint32_t e1 = common16(x0, y0);
+    const uint32_t r1 = q1 < maxlen ? maxlen - q1 : 0u;
+    if (e1 > r1) e1 = r1;
+    const uint64_t s1 = __ballot(e1 < 16u);
+    if (s1) { const int f = __builtin_ctzll(s1); return done + 16u * (uint32_t)f + (uint32_t)__builtin_amdgcn_readlane((int)e1, f); }
+    done += 1024u;
+  }
+  while (done < maxlen) {                                  // the last < 1 KiB of a stream: 8 bytes per lane, byte-safe at the very end
+    const uint32_t q = done + 8u * (uint32_t)lane;
+    uint32_t vb = 0;
+    if (q < maxlen) vb = (maxlen - q < 8u) ? maxlen - q : 8u;
+    uint32_t eq = 0;
+    if (vb) {
+      if (a + q + 8u <= n) {
+        const uint64_t x = ld8u(src + a + q) ^ ld8u(src + b + q);
+        eq = x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8u;
+        if (eq > vb) eq = vb;
+      } else {
+        while (eq < vb && src[a + q + eq] == src[b + q + eq]) eq++;
+      }
+    }
+    const uint64_t stop = __ballot(eq < 8u);
+    if (stop) { const int f = __builtin_ctzll(stop); return done + 8u * (uint32_t)f + (uint32_t)__builtin_amdgcn_readlane((int)eq, f); }
+    done += 512u;
+  }
+  return maxlen;
+}
+
+__device__ uint32_t lz4_encode_wave_par(const gu8* __restrict__ src, uint32_t n, gu8* __restrict__ dst, uint32_t cap,
+                                        int clevel, enc_entry_t* tab_generic, int lane EPROF_ARG) {
+  EncTable tab;
+  tab.init((void*)tab_generic);
+  volatile BAMD_LAS uint32_t* scr = (volatile BAMD_LAS uint32_t*)((BAMD_LAS uint8_t*)(void*)tab_generic + ENC_TAB_BYTES);
+  if (n < 13u) return 0u;                                     // lz4.c:245-246, :963-964
+  const uint32_t last_start = n - 12u;                        // inclusive bound on match starts
+  const uint32_t mlimit = n - 5u;                             // matches end at or before this position
+  const int accel = 10 - clevel;                              // blosc/blosc.c:577-587
+  const uint32_t minlen = clevel >= 9 ? 4u : (clevel >= 6 ? 5u : 7u);      // (enc_lz.h: the effort knob)
+  tab.clear(lane);
+  EncWindow win;
+  win.init(src, n, lane);
+  uint32_t ip = 0, anchor = 0, op = 0, nfail = 0;
+  bool ins_pending = false;                       // position ip-2 still has to enter the table (lz4.c:1236-1242)
+  while (ip <= last_start) {
+    const uint32_t p = ip + (uint32_t)lane;
+    const bool live = p <= last_start;
+    // ---- round 1 (registers + LDS only): own bytes from the window, table probe (as in lz_encode_wave) ----
+    win.seek(ip, lane);
+    const uint32_t lo = ip >= 4u ? ip - 4u : 0u;
+    const uint32_t rb = lo & ~3u;
+    const uint32_t D = (rb - win.wbase) >> 2;
+    const int gsel = (int)((D + (uint32_t)lane) << 2);
+    const uint32_t ra = (uint32_t)__builtin_amdgcn_ds_bpermute(gsel, (int)win.w0);
+    const uint32_t rc = (uint32_t)__builtin_amdgcn_ds_bpermute(gsel, (int)win.w1);
+    const uint32_t r = (D + (uint32_t)lane < 64u) ? ra : rc;
+    const uint32_t bo0 = ip - rb;
+    const uint32_t bo = bo0 + (uint32_t)lane;
+    const int ksel = (int)((bo >> 2) << 2);
+    const uint32_t x0 = (uint32_t)__builtin_amdgcn_ds_bpermute(ksel, (int)r);
+    const uint32_t x1 = (uint32_t)__builtin_amdgcn_ds_bpermute(ksel + 4, (int)r);
+    const uint32_t x2 = (uint32_t)__builtin_amdgcn_ds_bpermute(ksel + 8, (int)r);
+    const uint32_t x3 = (uint32_t)__builtin_amdgcn_ds_bpermute(ksel + 12, (int)r);
+    const uint32_t x4 = (uint32_t)__builtin_amdgcn_ds_bpermute(ksel + 16, (int)r);
+    const uint32_t x5 = (uint32_t)__builtin_amdgcn_ds_bpermute(ksel + 20, (int)r);
+    const uint32_t sh = bo & 3u;
+    const uint32_t o0 = __builtin_amdgcn_alignbyte(x1, x0, sh), o1 = __builtin_amdgcn_alignbyte(x2, x1, sh);
+    const uint32_t o2 = __builtin_amdgcn_alignbyte(x3, x2, sh), o3 = __builtin_amdgcn_alignbyte(x4, x3, sh);
+    const uint32_t o4 = __builtin_amdgcn_alignbyte(x5, x4, sh);
+    const uint32_t ownpre = __builtin_amdgcn_alignbyte(x0, (uint32_t)__builtin_amdgcn_ds_bpermute(ksel - 4, (int)r), sh);   // src[p-4 .. p-1] (p >= 4)
+    Bytes20 own;
+    own.a = ((uint64_t)o1 << 32) | o0; own.b = ((uint64_t)o3 << 32) | o2; own.c = RANK_CAP > 16u ? o4 : 0u;
+    const uint64_t r01 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)r, 1) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)r, 0);
+    const uint32_t before2 = bo0 >= 2u ? (uint32_t)(r01 >> (8u * (bo0 - 2u))) & 0xffffu : 0u;   // src[ip-2] | src[ip-1] << 8
+    uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(o0 & 0xffu), 0x138, 0xf, 0xf, false);   // wave_shr:1
+    if (lane == 0) prev = ip ? (bo0 >= 2u ? before2 >> 8 : (uint32_t)(r01 >> (8u * (bo0 - 1u))) & 0xffu) : 0x100u;
+    if (ins_pending) {
+      const uint32_t m2 = enc_mix(before2 | (o0 << 16));
+      if (lane == 0) tab.put(enc_slot(m2), enc_entry(m2, ip - 2u));
+      ins_pending = false;
+    }
+    uint32_t cand = 0, limit = 0;
+    bool tab_ok = false;
+    const uint32_t mix = enc_mix(o0);              // (slot and entry are made from it again where the position enters the table: one register across the step instead of two)
+#define PAR_PUT() tab.put(enc_slot(mix), enc_entry(mix, p))
+    if (live) {
+      limit = mlimit - p; if (limit > RANK_CAP) limit = RANK_CAP;
+      const uint32_t h = enc_slot(mix), mine = enc_entry(mix, p);
+      const uint32_t e = tab.get(h);
+      const uint32_t d = (p - e) & 0xffffu;
+      if (d != 0u && d <= p && EncTable::tag_equal(e, mine)) { cand = p - d; tab_ok = true; }
+    } else {
+      prev = 0x100u;
+    }
+    PROF_LAP(8); PROF_ADD(0, 1);
+    // ---- round 2: candidate bytes, exact lengths up to RANK_CAP; nb = equal bytes right in front of the two positions, 0 .. 4 ----
+    uint32_t len = 0, nb = 0;
+    if (tab_ok) {
+      const uint32_t cpre = cand >= 4u ? ld4u(src + cand - 4u) : 0u;
+      const Bytes20 cb = load20(src, cand, n);
+      if (cand >= 4u) { const uint32_t x = cpre ^ ownpre; nb = x ? (uint32_t)__builtin_clz(x) >> 3 : 4u; }
+      len = common20(own, cb);
+      if (len > limit) len = limit;
+      if (len < minlen) len = 0;
+    }
+    if (live && prev < 0x100u) {                    // distance 1: run of the previous byte
+      uint32_t rl = runlen20(own, prev);
+      if (rl > limit) rl = limit;
+      if (rl >= minlen && rl > len) { len = rl; cand = p - 1u; nb = 0u; }
+    }
+    win.settle(lane);
+    PROF_LAP(9);
+    // ---- the parse of the whole step ----
+    const uint32_t step_end = ip + 64u;
+    const uint32_t cn = cand | (nb << 28);                       // (positions are below 2^28: a stream is a split of a block, <= 2 MiB)
+    // S[l] = the best key among the lanes at or above l: who wins when the search starts at l
+    uint32_t S = len ? (((len + 64u - (uint32_t)lane) << 11) | ((63u - (uint32_t)lane) << 5) | len) : 0u;
+    S = umax32(S, dpp_row_shl0<1>(S)); S = umax32(S, dpp_row_shl0<2>(S)); S = umax32(S, dpp_row_shl0<4>(S)); S = umax32(S, dpp_row_shl0<8>(S));
+    {
+      const uint32_t t3 = (uint32_t)__builtin_amdgcn_readlane((int)S, 48);
+      const uint32_t t2 = umax32((uint32_t)__builtin_amdgcn_readlane((int)S, 32), t3);
+      const uint32_t t1 = umax32((uint32_t)__builtin_amdgcn_readlane((int)S, 16), t2);
+      const uint32_t add = lane < 16 ? t1 : (lane < 32 ? t2 : (lane < 48 ? t3 : 0u));
+      S = umax32(S, add);
+    }
+    // next-pointer: the end of the winner's match; 63 = stop (no candidate left, the match leaves the step, or it needs its forward extension
+    // first).  Lane 63 is the absorbing stop: its own entry is 63 whatever it holds.
+    uint32_t J0;
+    {
+      const uint32_t wS = 63u - ((S >> 5) & 63u), LS = S & 31u;
+      const uint32_t nx = wS + LS;
+      J0 = (S == 0u || LS >= RANK_CAP || nx > 63u) ? 63u : nx;
+    }
+    uint32_t lane_lo = 0;                         // first position of the step not covered by a sequence emitted so far
+    bool any = false, tail_open = false;
+    for (;;) {
+      // rank lane r (< 16): c = start of the r-th search of the chain that begins at lane_lo
+      // (the doubled pointers are made here, not once per step: they would be live across everything below, and nine steps in ten run this once)
+      const uint32_t J1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(J0 << 2), (int)J0);
+      const uint32_t J2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(J1 << 2), (int)J1);
+      const uint32_t J3 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(J2 << 2), (int)J2);
+      uint32_t c = lane_lo;
+      { const uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)J0); c = (lane & 1) ? t : c; }
+      { const uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)J1); c = (lane & 2) ? t : c; }
+      { const uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)J2); c = (lane & 4) ? t : c; }
+      { const uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)J3); c = (lane & 8) ? t : c; }
+      const uint32_t Sr = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)S);
+      const bool valid = lane < 16 && c < 63u && Sr != 0u;
+      const uint32_t nseq = (uint32_t)__builtin_popcountll(__ballot(valid));      // valid ranks are 0 .. nseq - 1 (the stop is absorbing)
+      if (nseq == 0u) { tail_open = any; break; }
+      any = true;
+      const uint32_t last = nseq - 1u;
+      const uint32_t w = 63u - ((Sr >> 5) & 63u), L = Sr & 31u;                    // winner lane and its ranked length
+      const uint32_t cnr = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w << 2), (int)cn);
+      const uint32_t cand_r = cnr & 0x0fffffffu, nb_r = cnr >> 28;
+      const uint32_t room = w - c;                                                  // positions between the search start and the match
+      // the last sequence of the chain may need its forward extension (all RANK_CAP bytes equal)
+      const uint32_t w_last = (uint32_t)__builtin_amdgcn_readlane((int)w, (int)last), L_last = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)last);
+      const uint32_t pm_last = ip + w_last;
+      uint32_t mext = 0;
+      if (L_last >= RANK_CAP && pm_last + RANK_CAP < mlimit) {
+        const uint32_t c_last = (uint32_t)__builtin_amdgcn_readlane((int)cand_r, (int)last);
+        mext = wave_common_fwd_lite(src, n, pm_last + RANK_CAP, c_last + RANK_CAP, mlimit - (pm_last + RANK_CAP), lane);
+      }
+      uint32_t back = valid ? umin32(nb_r, umin32(room, cand_r)) : 0u;
+      if (BAMD_ENC_BACK2) {
+        // all four bytes in front equal and room for more: eight more bytes per such sequence, all of them in one round trip (bench19's noisy planes: 5 % of
+        // the sequences; without this their streams are 2.2 % larger, with it 0.1 %)
+        const bool more = valid && back == 4u && room > 4u && cand_r >= 12u;
+        if (__ballot(more)) {                                                       // uniform
+          const uint32_t pm = ip + w;
+          const uint64_t a = g_ld8(src + (more ? pm - 12u : 0u)), b = g_ld8(src + (more ? cand_r - 12u : 0u));
+          const uint64_t x = a ^ b;
+          const uint32_t eq = x ? (uint32_t)__builtin_clzll(x) >> 3 : 8u;
+          if (more) back += umin32(eq, room - 4u);
+        }
+      }
+      uint32_t pre = lane_lo == 0u ? ip - anchor : 0u;                              // literals in front of the step (rank 0 only; anchor <= ip there)
+      uint32_t pre_ext = 0;                                                         // rank 0's match extended backwards into them
+      if (BAMD_ENC_PREFULL && pre) {                                                // uniform, rare
+        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)back, 0), room0 = (uint32_t)__builtin_amdgcn_readlane((int)room, 0);
+        const uint32_t cand0 = (uint32_t)__builtin_amdgcn_readlane((int)cand_r, 0);
+        if (b0 == room0 && cand0 > b0) {                                            // everything between the step's start and the match is part of it
+          uint32_t maxb = umin32(pre, cand0 - b0);
+          if (maxb > 64u) maxb = 64u;
+          const uint32_t pm0 = ip + (uint32_t)__builtin_amdgcn_readlane((int)w, 0) - b0, cm0 = cand0 - b0;
+          const bool bl = (uint32_t)lane < maxb;
+          const uint32_t bx = src[bl ? pm0 - 1u - (uint32_t)lane : pm0], by = src[bl ? cm0 - 1u - (uint32_t)lane : cm0];
+          const uint64_t bm = __ballot(!bl || bx != by);
+          pre_ext = bm ? (uint32_t)__builtin_ctzll(bm) : 64u;
+          pre -= pre_ext;
+        }
+      }
+      PROF_LAP(10); PROF_ADD(2, L_last >= RANK_CAP); PROF_ADD(6, nseq);
+      const uint32_t mlen = L + back + ((uint32_t)lane == last ? mext : 0u) + (lane == 0 ? pre_ext : 0u);
+      const uint32_t mcode = mlen - 4u;
+      const uint32_t inl = room - back;                                             // literals of the sequence that lie inside the step
+      const uint32_t ll = inl + (lane == 0 ? pre : 0u);
+      const bool r0pre = pre != 0u && lane == 0;                                    // its token, length bytes and outside literals are written apart
+      const uint32_t hdr = r0pre ? 0u : (ll >= 15u ? 2u : 1u);                      // (inside the step ll <= 63: one length byte at most)
+      const uint32_t nme = mcode >= 15u ? 1u : 0u;                                  // (a second length byte and more: the extended last match only)
+      const uint32_t size = valid ? hdr + inl + 2u + nme : 0u;
+      uint32_t incl = size;
+      incl += dpp_row_shr0<1>(incl); incl += dpp_row_shr0<2>(incl); incl += dpp_row_shr0<4>(incl); incl += dpp_row_shr0<8>(incl);
+      const uint32_t excl = incl - size;
+      const uint32_t mcode_last = (uint32_t)__builtin_amdgcn_readlane((int)mcode, (int)last);
+      const uint32_t extra_last = mcode_last >= 15u + 255u ? (mcode_last - 15u) / 255u : 0u;
+      const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)last) + extra_last;
+      uint32_t ll0 = 0, prebytes = 0;
+      if (pre) { ll0 = (uint32_t)__builtin_amdgcn_readlane((int)ll, 0); prebytes = 1u + (ll0 >= 15u ? 1u + (ll0 - 15u) / 255u : 0u) + pre; }
+      // limitedOutput (lz4.c:1114-1117, :1187-1211): the stream is stored raw when it does not fit
+      if (op + prebytes + total + 8u > cap) return 0u;
+      if (pre) {                                                                    // uniform, rare (a step that begins with pending literals)
+        const uint32_t mc0 = (uint32_t)__builtin_amdgcn_readlane((int)mcode, 0);
+        if (lane == 0) ENC_ST1(dst + op, (uint8_t)(((ll0 < 15u ? ll0 : 15u) << 4) | (mc0 < 15u ? mc0 : 15u)));
+        op += 1u;
+        if (ll0 >= 15u) op += emit_ext255(dst + op, ll0 - 15u, lane);
+        wave_copy_disjoint(dst + op, src + anchor, pre, lane);
+        op += pre;
+        PROF_ADD(3, 1);
+      }
+      // sequence info from rank lanes to byte lanes: the word lands on the sequence's first position (the search start c)
+      scr[lane] = 0u;
+      BAMD_LDS_SYNC();
+      if (valid) scr[c] = 0x80000000u | (excl + hdr) | (inl << 10) | (w << 17) | (L << 23);
+      BAMD_LDS_SYNC();
+      const uint32_t myw = scr[lane];
+      const uint64_t fm = __ballot((myw >> 31) != 0u);
+      const uint64_t below = fm & ((2ull << lane) - 1ull);                          // sequence starts at or before this byte lane
+      const uint32_t s = 63u - (uint32_t)__builtin_clzll(below | 1ull);
+      const uint32_t inf = scr[s];
+      BAMD_LDS_SYNC();
+      const bool has = below != 0ull;                                               // (lanes below lane_lo belong to sequences emitted earlier)
+      const uint32_t k = (uint32_t)lane - s;
+      const uint32_t i_out = inf & 1023u, i_inl = (inf >> 10) & 127u, i_w = (inf >> 17) & 63u, i_L = (inf >> 23) & 31u;
+      // ---- all stores of the step: literals (byte lanes), tokens, length bytes, offsets (rank lanes) ----
+      if (has && k < i_inl) ENC_ST1(dst + op + i_out + k, (uint8_t)own.a);
+      const uint32_t tpos = op + excl;
+      if (valid && hdr) ENC_ST1(dst + tpos, (uint8_t)(((ll < 15u ? ll : 15u) << 4) | (mcode < 15u ? mcode : 15u)));
+      if (valid && hdr == 2u) ENC_ST1(dst + tpos + 1u, (uint8_t)(ll - 15u));
+      const uint32_t opos = tpos + hdr + inl;
+      if (valid) g_st2(dst + opos, ip + w - cand_r);
+      if (valid && nme) ENC_ST1(dst + opos + 2u, (uint8_t)(mcode - 15u < 255u ? mcode - 15u : 255u));
+      if (extra_last) {                                                             // uniform: the 255-run of a long match (lz4.c:1213-1226)
+        const uint32_t opos_last = (uint32_t)__builtin_amdgcn_readlane((int)opos, (int)last);
+        emit_ext255(dst + opos_last + 2u, mcode_last - 15u, lane);
+      }
+      op += total;
+      // ---- table: like the reference, nothing inside a match is inserted (lz4.c:1236-1242 inserts ip-2 only): positions up to the winner,
+      //      the position two bytes before the match's end, and what lies behind the chain's last match when nothing more was found ----
+      {
+        const bool open_end = i_L < RANK_CAP;                                       // (behind a match that was extended the chain picks up again below)
+        const uint32_t e = i_w + i_L;
+        if (live && has && ((uint32_t)lane <= i_w || (open_end && ((uint32_t)lane + 2u == e || (uint32_t)lane >= e)))) PAR_PUT();
+      }
+      const uint32_t e_last = w_last + L_last + mext;                               // end of the chain's last match, relative to ip
+      anchor = ip + e_last;
+      PROF_LAP(11);
+      if (L_last < RANK_CAP || e_last >= 64u) break;                                // the chain ended by itself / the match leaves the step
+      lane_lo = e_last;
+      if (live && (uint32_t)lane + 2u == lane_lo) PAR_PUT();                 // (lz4.c:1236-1242)
+    }
+    if (!any) {
+      PROF_ADD(1, 1);
+      if (live) PAR_PUT();
+      nfail++;
+      uint32_t adv = 1u + (nfail * (uint32_t)accel) / 16u;   // skip faster through incompressible data
+      if (adv > 16u) adv = 16u;
+      ip += 64u * adv;
+      continue;
+    }
+    nfail = 0;
+    if (anchor >= step_end) {
+      ip = anchor;
+      ins_pending = true;                         // anchor-2 enters the table at the top of the next step (bytes in registers there)
+    } else {
+      if (tail_open && live && (uint32_t)lane >= lane_lo) PAR_PUT();       // nothing more to find behind an extended match
+      ip = step_end;
+    }
+  }
+#undef PAR_PUT
+  op = lz4_emit_tail(dst, op, cap, src + anchor, n - anchor, lane);
+  if (op == 0xffffffffu) return 0u;
+  PROF_LAP(12);
+  return op < n ? op : 0u;
+}

@@ -47,6 +47,7 @@ namespace bamd {
 #endif
 
 #include "enc_lz.h"
+#include "enc_lz4p.h"
 #include "enc_zstd.h"
 #include "enc_zlib.h"
 #include "enc_shuffle.h"
@@ -66,15 +67,27 @@ constexpr bool enc_mode_zstd(int mode) { return mode == ENC_ZSTD || mode == ENC_
 #define BAMD_ENC_HELP 256     // a wave whose stream's block is not shuffled yet takes shuffle tasks instead of sleeping, up to this many blocks ahead (0: never)
 #endif
 template <int MODE>
-__device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, enc_entry_t* tab, const ChunkDesc* chunks, uint32_t* blk_ready, int lane,
-                                                            const BlockDesc* blocks, uint32_t sid, uint32_t* plane_cost, uint64_t* seqbuf
+__device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd_, enc_entry_t* tab_, const ChunkDesc* chunks_, uint32_t* blk_ready_, int lane,
+                                                            const BlockDesc* blocks_, uint32_t sid_, uint32_t* plane_cost_, uint64_t* seqbuf_
 #ifdef BAMD_PROFILE_DECODE
-                                                            , uint32_t* profslot
+                                                            , uint32_t* profslot_
 #endif
                                                             ) {
+  StreamDesc* sd; enc_entry_t* tab; const ChunkDesc* chunks; uint32_t* blk_ready; const BlockDesc* blocks; uint32_t sid; uint32_t* plane_cost; uint64_t* seqbuf;
+#ifdef BAMD_PROFILE_DECODE
+  uint32_t* profslot;
+#endif
   PROF_DECL
 #ifdef BAMD_PROFILE_DECODE
   prof_.c[4] = 0; prof_.c[5] = 0;
+#endif
+  // The arguments of a real call arrive in vector registers; every one of them is wave-uniform and most are needed again behind the encoder's loop.
+  // Left where they are they cost the loop 16 of its 80 registers - or are spilled and RELOADED inside it, and a scratch reload waits for vmcnt(0),
+  // i.e. for the step's stores (round 6: the parallel LZ4 step at 9.2 ms instead of 8.2 until these moved to scalar registers).
+  sd = uni_gp(sd_); tab = uni_gp(tab_); chunks = uni_gp(chunks_); blk_ready = uni_gp(blk_ready_); blocks = uni_gp(blocks_);
+  plane_cost = uni_gp(plane_cost_); seqbuf = uni_gp(seqbuf_); sid = uni(sid_);
+#ifdef BAMD_PROFILE_DECODE
+  profslot = uni_gp(profslot_);
 #endif
   const uint32_t n = uni((uint32_t)sd->in_size), cap = uni((uint32_t)sd->out_size);
   const uint32_t aux = uni((uint32_t)sd->aux);
@@ -100,7 +113,8 @@ __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd, enc_
   else if (MODE == ENC_ZLIB) r = zlib_encode_wave(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, lane EPROF_PASS);
   else if (hint < 0) r = emit_periodic_stream(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, (uint32_t)-hint, uni((uint32_t)sd->fmt) == (uint32_t)FMT_LZ4, lane);
   else if (MODE == ENC_HC) r = lz4hc_encode_wave(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, tab, lane);
-  else if (sd->fmt == FMT_LZ4) r = lz_encode_wave<EF_LZ4>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, lane EPROF_PASS);
+  else if (sd->fmt == FMT_LZ4) r = BAMD_ENC_PAR ? lz4_encode_wave_par(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, lane EPROF_PASS)
+                                                : lz_encode_wave<EF_LZ4>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, lane EPROF_PASS);
   else r = lz_encode_wave<EF_BLOSCLZ>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, lane EPROF_PASS);
   if (lane == 0) sd->result = (int32_t)r;
   // cost feedback for the host's queue order (queue_order.h: build_encode_queues): cycles per plane index
@@ -132,7 +146,7 @@ __global__ __launch_bounds__(64 * ENC_WAVES, enc_mode_hc(MODE) ? 2 : ((MODE == E
     ) {
   constexpr bool ZSTD = enc_mode_zstd(MODE);
   constexpr int TABBYTES = enc_mode_hc(MODE) ? HC_TAB_BYTES : ENC_TAB_BYTES;      // the match finder's table; the writers' LDS sits behind it
-  __shared__ __attribute__((aligned(16))) enc_entry_t tabs[ENC_WAVES][(TABBYTES + (ZSTD ? ZS_LDS_BYTES : (enc_mode_zlib(MODE) ? DFL_LDS_BYTES : 0))) / 4];      // ENC_LZ: the LZ4 emitter's run buffer behind the table (enc_lz.h)
+  __shared__ __attribute__((aligned(16))) enc_entry_t tabs[ENC_WAVES][(TABBYTES + (ZSTD ? ZS_LDS_BYTES : (enc_mode_zlib(MODE) ? DFL_LDS_BYTES : (MODE == ENC_LZ ? ENC_SCR_BYTES : 0)))) / 4];      // ENC_LZ: the 64 scratch dwords of the parallel LZ4 emitter behind the table (enc_lz4p.h)
   static_assert(ENC_WAVES == 1, "one stream per wave, one wave per workgroup");
   const int lane = threadIdx.x & 63;
   uint64_t* seqbuf = nullptr;

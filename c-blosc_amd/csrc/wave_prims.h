@@ -39,6 +39,12 @@ __device__ __forceinline__ gu8* uni_ptr(gu8* p) {
   const uint64_t v = (uint64_t)p;
   return (gu8*)(((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v));
 }
+// the same for a pointer of any type (generic address space)
+template <typename T>
+__device__ __forceinline__ T* uni_gp(T* p) {
+  const uint64_t v = (uint64_t)p;
+  return (T*)(((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v));
+}
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // Next index of a global work queue, the same value in every lane.  Lane 0 draws the ticket; the value
