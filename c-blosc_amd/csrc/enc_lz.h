@@ -21,8 +21,14 @@ constexpr int ENC_TAB_BYTES = BAMD_ENC_SPLIT_TAB ? ENC_TAB * 3 : ENC_TAB * 4;
 #ifndef BAMD_ENC_MINWAVES
 #define BAMD_ENC_MINWAVES (BAMD_ENC_SPLIT_TAB ? 6 : 5)   // waves per SIMD the register allocator leaves room for (5: + 3 %, 7 = 26 waves per CU at 72 registers: + 1.8 %, profiles/r04/r04zu_*)
 #endif
+#ifndef BAMD_ENC_LZ_MINWAVES
+#define BAMD_ENC_LZ_MINWAVES 5   // the LZ4 / BloscLZ kernel (round 6): the two-positions-per-lane step of enc_lz4p.h needs 96 registers - at 80 its input window lives in scratch
+                                 // memory and every step reloads it behind the stores of the step before (profiles/r06c_*: 8.6 ms at 24 waves per CU, 7.5 at 20)
+#endif
 constexpr int ENC_LDS_WAVES = (160 * 1024) / ENC_TAB_BYTES;
 constexpr int ENC_WAVES_PER_CU = ENC_LDS_WAVES < 4 * BAMD_ENC_MINWAVES ? ENC_LDS_WAVES : 4 * BAMD_ENC_MINWAVES;   // persistent grid size per CU
+constexpr int ENC_LZ_LDS_WAVES = (160 * 1024) / (ENC_TAB_BYTES + 512);                                             // (+ the parallel emitter's 128 scratch dwords, enc_lz4p.h)
+constexpr int ENC_LZ_WAVES_PER_CU = ENC_LZ_LDS_WAVES < 4 * BAMD_ENC_LZ_MINWAVES ? ENC_LZ_LDS_WAVES : 4 * BAMD_ENC_LZ_MINWAVES;   // ... of the LZ4 / BloscLZ kernel
 
 // the table of one wave (LDS)
 struct EncTable {
@@ -72,29 +78,19 @@ __device__ __forceinline__ uint32_t common16(const uint4& x, const uint4& y) {
 // compared 2 KiB per memory round trip (two 1 KiB rows, all four loads in flight together) with the
 // exact mismatch byte found in the same trip; only the last < 2 KiB of a stream go 512 bytes per
 // step through byte-safe loads.
-__device__ __forceinline__ uint32_t wave_common_fwd(const gu8* src, uint32_t n, uint32_t a, uint32_t b,
-                                                    uint32_t maxlen, int lane) {
-  uint32_t done = 0;
-  // first trips: 256 bytes, then 1 KiB (round 3: 1 KiB / 512 / 256 + 1 KiB first trips cost 5 % / 11 % / 19 % less of the kernel on bench19 than 2 KiB rows at once)
-  if (maxlen && a + 256u <= n) {     // variant: 256 bytes
-    const uint32_t x = g_ld4(src + a + 4 * lane) ^ g_ld4(src + b + 4 * lane);
-    const uint32_t q = 4u * (uint32_t)lane;
-    uint32_t e0 = x ? (uint32_t)(__builtin_ctz(x) >> 3) : 4u;
-    const uint32_t r0 = q < maxlen ? maxlen - q : 0u;
-    if (e0 > r0) e0 = r0;
-    const uint64_t s0 = __ballot(e0 < 4u);
-    if (s0) { const int f = __builtin_ctzll(s0); return 4u * (uint32_t)f + (uint32_t)__builtin_amdgcn_readlane((int)e0, f); }
-    done = 256u;
-    if (done < maxlen && a + done + 1024u <= n) {      // second trip: 1 KiB
-      const uint4 x0 = g_ld16(src + a + done + 16 * lane), y0 = g_ld16(src + b + done + 16 * lane);
-      const uint32_t q1 = done + 16u * (uint32_t)lane;
-      uint32_t e1 = common16(x0, y0);
-      const uint32_t r1 = q1 < maxlen ? maxlen - q1 : 0u;
-      if (e1 > r1) e1 = r1;
-      const uint64_t s1 = __ballot(e1 < 16u);
-      if (s1) { const int f = __builtin_ctzll(s1); return done + 16u * (uint32_t)f + (uint32_t)__builtin_amdgcn_readlane((int)e1, f); }
-      done += 1024u;
-    }
+// (the part behind the first `done` bytes, which the caller has found equal: done = 256 - the first trip of wave_common_fwd, or of enc_lz4p.h's
+//  chain whose first trip travels underneath the step's emission - or 0)
+__device__ __forceinline__ uint32_t wave_common_fwd_rest(const gu8* src, uint32_t n, uint32_t a, uint32_t b,
+                                                         uint32_t maxlen, uint32_t done, int lane) {
+  if (done == 256u && done < maxlen && a + done + 1024u <= n) {      // second trip: 1 KiB
+    const uint4 x0 = g_ld16(src + a + done + 16 * lane), y0 = g_ld16(src + b + done + 16 * lane);
+    const uint32_t q1 = done + 16u * (uint32_t)lane;
+    uint32_t e1 = common16(x0, y0);
+    const uint32_t r1 = q1 < maxlen ? maxlen - q1 : 0u;
+    if (e1 > r1) e1 = r1;
+    const uint64_t s1 = __ballot(e1 < 16u);
+    if (s1) { const int f = __builtin_ctzll(s1); return done + 16u * (uint32_t)f + (uint32_t)__builtin_amdgcn_readlane((int)e1, f); }
+    done += 1024u;
   }
   while (done < maxlen && a + done + 2048u <= n) {
     const gu8* pa = src + a + done + 16 * lane;
@@ -135,6 +131,28 @@ __device__ __forceinline__ uint32_t wave_common_fwd(const gu8* src, uint32_t n, 
     done += 512u;
   }
   return maxlen;
+}
+// the first trip's verdict: x = the lane's dword of src[a..] XOR that of src[b..] (a + 256 <= n); returns the length when the mismatch (or maxlen) lies
+// inside these 256 bytes, 0xffffffff when all of them are equal and more may follow
+__device__ __forceinline__ uint32_t wave_common_first256(uint32_t x, uint32_t maxlen, int lane) {
+  const uint32_t q = 4u * (uint32_t)lane;
+  uint32_t e0 = x ? (uint32_t)(__builtin_ctz(x) >> 3) : 4u;
+  const uint32_t r0 = q < maxlen ? maxlen - q : 0u;
+  if (e0 > r0) e0 = r0;
+  const uint64_t s0 = __ballot(e0 < 4u);
+  if (s0) { const int f = __builtin_ctzll(s0); return 4u * (uint32_t)f + (uint32_t)__builtin_amdgcn_readlane((int)e0, f); }
+  return 0xffffffffu;
+}
+__device__ __forceinline__ uint32_t wave_common_fwd(const gu8* src, uint32_t n, uint32_t a, uint32_t b,
+                                                    uint32_t maxlen, int lane) {
+  uint32_t done = 0;
+  // first trips: 256 bytes, then 1 KiB (round 3: 1 KiB / 512 / 256 + 1 KiB first trips cost 5 % / 11 % / 19 % less of the kernel on bench19 than 2 KiB rows at once)
+  if (maxlen && a + 256u <= n) {
+    const uint32_t r = wave_common_first256(g_ld4(src + a + 4 * lane) ^ g_ld4(src + b + 4 * lane), maxlen, lane);
+    if (r != 0xffffffffu) return r;
+    done = 256u;
+  }
+  return wave_common_fwd_rest(src, n, a, b, maxlen, done, lane);
 }
 
 #define ENC_ST1(ptr, val) do { *(ptr) = (val); } while (0)

@@ -23,9 +23,22 @@
 #ifndef BAMD_ENC_PAR
 #define BAMD_ENC_PAR 1
 #endif
-constexpr int ENC_SCR_BYTES = 256;     // 64 dwords behind the hash table: sequence info on its way from rank lanes to byte lanes
+constexpr int ENC_SCR_BYTES = 512;     // 128 dwords behind the hash table: sequence info on its way from rank lanes to byte lanes (one word per position of a step)
+static_assert(ENC_LZ_LDS_WAVES == (160 * 1024) / (ENC_TAB_BYTES + ENC_SCR_BYTES), "enc_lz.h sizes the persistent grid with this scratch in mind");
 #ifndef BAMD_ENC_BACK2
 #define BAMD_ENC_BACK2 1     // sequences whose four bytes in front all match look at eight more (one more memory round trip for the steps that hold such a sequence)
+#endif
+#ifndef BAMD_ENC_NEIGHBOUR
+#define BAMD_ENC_NEIGHBOUR 4u   // a power of two, or 0: never
+#endif
+#ifndef BAMD_ENC_LAUNDER
+#define BAMD_ENC_LAUNDER 1
+#endif
+#ifndef BAMD_ENC_KEEPJ
+#define BAMD_ENC_KEEPJ 0     // the doubled next-pointers made once per step (three registers across the chain loop) instead of once per chain
+#endif
+#ifndef BAMD_ENC_EXT2
+#define BAMD_ENC_EXT2 1      // long comparisons two rows per trip (wave_common_fwd, enc_lz.h) - affordable at 96 registers; 0: one row per trip (wave_common_fwd_lite)
 #endif
 #ifndef BAMD_ENC_PREFULL
 #define BAMD_ENC_PREFULL 1   // a step that begins with pending literals (behind skipped, match-less steps) extends its first match backwards into them, up to 64 bytes
@@ -83,8 +96,18 @@ __device__ __forceinline__ uint32_t wave_common_fwd_lite(const gu8* src, uint32_
   return maxlen;
 }
 
+// SS = log2 of the PROBE STRIDE (round 6).  SS = 1: a step covers 128 positions; lane l probes position ip + 2 l only, but BOTH positions of a lane enter the
+// table (so a repeat is found whatever the parity of its distance) and both bytes of a lane leave as literals.  A match that begins on an odd position
+// is found one byte late and gets its first byte back from the backward extension (the four bytes in front of every candidate are there anyway); its
+// ranked length counts that byte.  Half the steps - probes, candidate fetches, parses, stores - for the same input; the reference trades positions for
+// speed the same way (LZ4_compress_fast's acceleration = 10 - clevel, blosc/blosc.c:577-587, lz4.c:1044-1053: at clevel 5 its search advances five
+// bytes at a time from the first miss on).
+template <int SS>
 __device__ uint32_t lz4_encode_wave_par(const gu8* __restrict__ src, uint32_t n, gu8* __restrict__ dst, uint32_t cap,
-                                        int clevel, enc_entry_t* tab_generic, int lane EPROF_ARG) {
+                                        int clevel, enc_entry_t* tab_generic, int lane_in EPROF_ARG) {
+  static_assert(SS == 0 || SS == 1, "one or two positions per lane");
+  const int lane = lane_in;
+  constexpr uint32_t SPAN = 64u << SS;            // positions of one step
   EncTable tab;
   tab.init((void*)tab_generic);
   volatile BAMD_LAS uint32_t* scr = (volatile BAMD_LAS uint32_t*)((BAMD_LAS uint8_t*)(void*)tab_generic + ENC_TAB_BYTES);
@@ -99,8 +122,17 @@ __device__ uint32_t lz4_encode_wave_par(const gu8* __restrict__ src, uint32_t n,
   uint32_t ip = 0, anchor = 0, op = 0, nfail = 0;
   bool ins_pending = false;                       // position ip-2 still has to enter the table (lz4.c:1236-1242)
   while (ip <= last_start) {
-    const uint32_t p = ip + (uint32_t)lane;
+    // The lane number of this iteration, opaque to the compiler: it hoists everything a step derives from the lane number out of the loop (two dozen
+    // masks, shifted copies, comparisons and per-lane pointers), and at 80 registers the loop then keeps its input WINDOW in scratch memory - reloaded at the
+    // top of every step behind s_waitcnt vmcnt(0), i.e. behind the stores of the step before.  Recomputing them costs a few VALU instructions per step.
+    int lane = lane_in;
+#if !defined(BAMD_WAVE_EMU) && BAMD_ENC_LAUNDER
+    asm volatile("; lane of this step" : "+v"(lane));
+#endif
+    const uint32_t lq = (uint32_t)lane << SS;     // this lane's (first) position, relative to ip
+    const uint32_t p = ip + lq;
     const bool live = p <= last_start;
+    const bool live1 = SS && p + 1u <= last_start;                // (SS = 1) the lane's second position: entered into the table, never probed
     // ---- round 1 (registers + LDS only): own bytes from the window, table probe (as in lz_encode_wave) ----
     win.seek(ip, lane);
     const uint32_t lo = ip >= 4u ? ip - 4u : 0u;
@@ -111,7 +143,7 @@ __device__ uint32_t lz4_encode_wave_par(const gu8* __restrict__ src, uint32_t n,
     const uint32_t rc = (uint32_t)__builtin_amdgcn_ds_bpermute(gsel, (int)win.w1);
     const uint32_t r = (D + (uint32_t)lane < 64u) ? ra : rc;
     const uint32_t bo0 = ip - rb;
-    const uint32_t bo = bo0 + (uint32_t)lane;
+    const uint32_t bo = bo0 + lq;                 // (SS = 1: the last lane's bytes end 7 + 126 + 24 bytes behind rb - inside r's 256 and the window's 348)
     const int ksel = (int)((bo >> 2) << 2);
     const uint32_t x0 = (uint32_t)__builtin_amdgcn_ds_bpermute(ksel, (int)r);
     const uint32_t x1 = (uint32_t)__builtin_amdgcn_ds_bpermute(ksel + 4, (int)r);
@@ -128,7 +160,9 @@ __device__ uint32_t lz4_encode_wave_par(const gu8* __restrict__ src, uint32_t n,
     own.a = ((uint64_t)o1 << 32) | o0; own.b = ((uint64_t)o3 << 32) | o2; own.c = RANK_CAP > 16u ? o4 : 0u;
     const uint64_t r01 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)r, 1) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)r, 0);
     const uint32_t before2 = bo0 >= 2u ? (uint32_t)(r01 >> (8u * (bo0 - 2u))) & 0xffffu : 0u;   // src[ip-2] | src[ip-1] << 8
-    uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(o0 & 0xffu), 0x138, 0xf, 0xf, false);   // wave_shr:1
+    uint32_t prev;
+    if (SS) prev = ownpre >> 24;                   // src[p-1] whenever p >= 1 (the alignment shift of a lane with p < 4 leaves that byte in x0's part)
+    else prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(o0 & 0xffu), 0x138, 0xf, 0xf, false);   // wave_shr:1
     if (lane == 0) prev = ip ? (bo0 >= 2u ? before2 >> 8 : (uint32_t)(r01 >> (8u * (bo0 - 1u))) & 0xffu) : 0x100u;
     if (ins_pending) {
       const uint32_t m2 = enc_mix(before2 | (o0 << 16));
@@ -138,7 +172,8 @@ __device__ uint32_t lz4_encode_wave_par(const gu8* __restrict__ src, uint32_t n,
     uint32_t cand = 0, limit = 0;
     bool tab_ok = false;
     const uint32_t mix = enc_mix(o0);              // (slot and entry are made from it again where the position enters the table: one register across the step instead of two)
-#define PAR_PUT() tab.put(enc_slot(mix), enc_entry(mix, p))
+#define PAR_PUT() do { const uint32_t mix_ = enc_mix((uint32_t)own.a); tab.put(enc_slot(mix_), enc_entry(mix_, p)); } while (0)      // (made from the bytes again where a position enters the table: nothing but own.a lives across the step)
+#define PAR_PUT1() do { const uint32_t mix1_ = enc_mix((uint32_t)(own.a >> 8)); tab.put(enc_slot(mix1_), enc_entry(mix1_, p + 1u)); } while (0)
     if (live) {
       limit = mlimit - p; if (limit > RANK_CAP) limit = RANK_CAP;
       const uint32_t h = enc_slot(mix), mine = enc_entry(mix, p);
@@ -157,20 +192,23 @@ __device__ uint32_t lz4_encode_wave_par(const gu8* __restrict__ src, uint32_t n,
       if (cand >= 4u) { const uint32_t x = cpre ^ ownpre; nb = x ? (uint32_t)__builtin_clz(x) >> 3 : 4u; }
       len = common20(own, cb);
       if (len > limit) len = limit;
-      if (len < minlen) len = 0;
+      if (len + (SS && nb ? 1u : 0u) < minlen) len = 0;           // (SS = 1: a match found one byte late counts the byte the backward extension brings back)
     }
     if (live && prev < 0x100u) {                    // distance 1: run of the previous byte
       uint32_t rl = runlen20(own, prev);
       if (rl > limit) rl = limit;
-      if (rl >= minlen && rl > len) { len = rl; cand = p - 1u; nb = 0u; }
+      // (the bytes in front: src[p-1-i] against src[p-2-i], i.e. how far the run reaches back - three comparisons inside ownpre)
+      const uint32_t xr = (ownpre ^ (ownpre << 8)) | 0xffu;
+      const uint32_t nbr = p >= 5u ? (uint32_t)__builtin_clz(xr) >> 3 : 0u;
+      if (rl + (SS && nbr ? 1u : 0u) >= minlen && rl > len) { len = rl; cand = p - 1u; nb = nbr; }
     }
     win.settle(lane);
     PROF_LAP(9);
     // ---- the parse of the whole step ----
-    const uint32_t step_end = ip + 64u;
+    const uint32_t step_end = ip + SPAN;
     const uint32_t cn = cand | (nb << 28);                       // (positions are below 2^28: a stream is a split of a block, <= 2 MiB)
     // S[l] = the best key among the lanes at or above l: who wins when the search starts at l
-    uint32_t S = len ? (((len + 64u - (uint32_t)lane) << 11) | ((63u - (uint32_t)lane) << 5) | len) : 0u;
+    uint32_t S = len ? (((len + (SS && nb ? 1u : 0u) + SPAN - lq) << 11) | ((63u - (uint32_t)lane) << 5) | len) : 0u;
     S = umax32(S, dpp_row_shl0<1>(S)); S = umax32(S, dpp_row_shl0<2>(S)); S = umax32(S, dpp_row_shl0<4>(S)); S = umax32(S, dpp_row_shl0<8>(S));
     {
       const uint32_t t3 = (uint32_t)__builtin_amdgcn_readlane((int)S, 48);
@@ -184,18 +222,25 @@ __device__ uint32_t lz4_encode_wave_par(const gu8* __restrict__ src, uint32_t n,
     uint32_t J0;
     {
       const uint32_t wS = 63u - ((S >> 5) & 63u), LS = S & 31u;
-      const uint32_t nx = wS + LS;
+      const uint32_t nx = ((wS << SS) + LS + (SS ? 1u : 0u)) >> SS;                // the first probing lane at or behind the match's end
       J0 = (S == 0u || LS >= RANK_CAP || nx > 63u) ? 63u : nx;
     }
-    uint32_t lane_lo = 0;                         // first position of the step not covered by a sequence emitted so far
+#if BAMD_ENC_KEEPJ
+    const uint32_t J1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(J0 << 2), (int)J0);
+    const uint32_t J2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(J1 << 2), (int)J1);
+    const uint32_t J3 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(J2 << 2), (int)J2);
+#endif
+    uint32_t lane_lo = 0;                         // first POSITION of the step (relative to ip) not covered by a sequence emitted so far
     bool any = false, tail_open = false;
     for (;;) {
       // rank lane r (< 16): c = start of the r-th search of the chain that begins at lane_lo
       // (the doubled pointers are made here, not once per step: they would be live across everything below, and nine steps in ten run this once)
+#if !BAMD_ENC_KEEPJ
       const uint32_t J1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(J0 << 2), (int)J0);
       const uint32_t J2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(J1 << 2), (int)J1);
       const uint32_t J3 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(J2 << 2), (int)J2);
-      uint32_t c = lane_lo;
+#endif
+      uint32_t c = umin32((lane_lo + (SS ? 1u : 0u)) >> SS, 63u);                 // (lanes: the first probe at or behind lane_lo; behind the last probe: the stop lane)
       { const uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)J0); c = (lane & 1) ? t : c; }
       { const uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)J1); c = (lane & 2) ? t : c; }
       { const uint32_t t = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)J2); c = (lane & 4) ? t : c; }
@@ -207,24 +252,31 @@ __device__ uint32_t lz4_encode_wave_par(const gu8* __restrict__ src, uint32_t n,
       any = true;
       const uint32_t last = nseq - 1u;
       const uint32_t w = 63u - ((Sr >> 5) & 63u), L = Sr & 31u;                    // winner lane and its ranked length
+      const uint32_t wq = w << SS;                                                  // the winner's position
       const uint32_t cnr = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w << 2), (int)cn);
       const uint32_t cand_r = cnr & 0x0fffffffu, nb_r = cnr >> 28;
-      const uint32_t room = w - c;                                                  // positions between the search start and the match
+      // cq: the POSITION the r-th search starts at = the end of the match in front of it (every match of the chain but the last has its exact length)
+      uint32_t cq = c;
+      if (SS) { const uint32_t e_prev = dpp_row_shr0<1>(wq + L); cq = lane == 0 ? lane_lo : e_prev; }
+      const uint32_t room = wq - cq;                                                // positions between the search start and the match
       // the last sequence of the chain may need its forward extension (all RANK_CAP bytes equal)
-      const uint32_t w_last = (uint32_t)__builtin_amdgcn_readlane((int)w, (int)last), L_last = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)last);
+      const uint32_t w_last = (uint32_t)__builtin_amdgcn_readlane((int)wq, (int)last), L_last = (uint32_t)__builtin_amdgcn_readlane((int)L, (int)last);
       const uint32_t pm_last = ip + w_last;
       uint32_t mext = 0;
       if (L_last >= RANK_CAP && pm_last + RANK_CAP < mlimit) {
         const uint32_t c_last = (uint32_t)__builtin_amdgcn_readlane((int)cand_r, (int)last);
-        mext = wave_common_fwd_lite(src, n, pm_last + RANK_CAP, c_last + RANK_CAP, mlimit - (pm_last + RANK_CAP), lane);
+        mext = BAMD_ENC_EXT2 ? wave_common_fwd(src, n, pm_last + RANK_CAP, c_last + RANK_CAP, mlimit - (pm_last + RANK_CAP), lane)
+                              : wave_common_fwd_lite(src, n, pm_last + RANK_CAP, c_last + RANK_CAP, mlimit - (pm_last + RANK_CAP), lane);
       }
+      // (Round 6 also asked for the first 256 bytes of this extension up here and looked at them behind the step's emission - only the last match's length bytes need
+      //  them, and they close the step's output: 4 % SLOWER on every data set, profiles/r06e_enc_ab_extension_under_emission_rejected.txt.)
       uint32_t back = valid ? umin32(nb_r, umin32(room, cand_r)) : 0u;
       if (BAMD_ENC_BACK2) {
         // all four bytes in front equal and room for more: eight more bytes per such sequence, all of them in one round trip (bench19's noisy planes: 5 % of
         // the sequences; without this their streams are 2.2 % larger, with it 0.1 %)
         const bool more = valid && back == 4u && room > 4u && cand_r >= 12u;
         if (__ballot(more)) {                                                       // uniform
-          const uint32_t pm = ip + w;
+          const uint32_t pm = ip + wq;
           const uint64_t a = g_ld8(src + (more ? pm - 12u : 0u)), b = g_ld8(src + (more ? cand_r - 12u : 0u));
           const uint64_t x = a ^ b;
           const uint32_t eq = x ? (uint32_t)__builtin_clzll(x) >> 3 : 8u;
@@ -239,7 +291,7 @@ __device__ uint32_t lz4_encode_wave_par(const gu8* __restrict__ src, uint32_t n,
         if (b0 == room0 && cand0 > b0) {                                            // everything between the step's start and the match is part of it
           uint32_t maxb = umin32(pre, cand0 - b0);
           if (maxb > 64u) maxb = 64u;
-          const uint32_t pm0 = ip + (uint32_t)__builtin_amdgcn_readlane((int)w, 0) - b0, cm0 = cand0 - b0;
+          const uint32_t pm0 = ip + (uint32_t)__builtin_amdgcn_readlane((int)wq, 0) - b0, cm0 = cand0 - b0;
           const bool bl = (uint32_t)lane < maxb;
           const uint32_t bx = src[bl ? pm0 - 1u - (uint32_t)lane : pm0], by = src[bl ? cm0 - 1u - (uint32_t)lane : cm0];
           const uint64_t bm = __ballot(!bl || bx != by);
@@ -275,54 +327,87 @@ __device__ uint32_t lz4_encode_wave_par(const gu8* __restrict__ src, uint32_t n,
         op += pre;
         PROF_ADD(3, 1);
       }
-      // sequence info from rank lanes to byte lanes: the word lands on the sequence's first position (the search start c)
+      // sequence info from rank lanes to byte lanes: the word lands on the sequence's first position (the search start cq)
       scr[lane] = 0u;
+      if (SS) scr[lane + 64] = 0u;
       BAMD_LDS_SYNC();
-      if (valid) scr[c] = 0x80000000u | (excl + hdr) | (inl << 10) | (w << 17) | (L << 23);
+      if (valid) scr[cq] = 0x80000000u | (excl + hdr) | (inl << 10) | (w << 17) | (L << 23);
       BAMD_LDS_SYNC();
-      const uint32_t myw = scr[lane];
+      const uint32_t myw = scr[lq];
+      const uint32_t myw1 = SS ? scr[lq + 1u] : 0u;
       const uint64_t fm = __ballot((myw >> 31) != 0u);
-      const uint64_t below = fm & ((2ull << lane) - 1ull);                          // sequence starts at or before this byte lane
-      const uint32_t s = 63u - (uint32_t)__builtin_clzll(below | 1ull);
+      uint32_t s;                                                                   // the last sequence start at or before this lane's first position
+      bool has;                                                                     // (positions below lane_lo belong to sequences emitted earlier)
+      if (SS) {
+        const uint64_t fm1 = __ballot((myw1 >> 31) != 0u);
+        const uint64_t be = fm & ((2ull << lane) - 1ull), bo_ = fm1 & ((1ull << lane) - 1ull);      // even starts 2 j <= 2 l, odd starts 2 j + 1 < 2 l
+        const uint32_t se = 2u * (63u - (uint32_t)__builtin_clzll(be | 1ull)), so = 2u * (63u - (uint32_t)__builtin_clzll(bo_ | 1ull)) + 1u;
+        s = (bo_ != 0ull && (be == 0ull || so > se)) ? so : se;
+        has = (be | bo_) != 0ull;
+      } else {
+        const uint64_t below = fm & ((2ull << lane) - 1ull);
+        s = 63u - (uint32_t)__builtin_clzll(below | 1ull);
+        has = below != 0ull;
+      }
       const uint32_t inf = scr[s];
       BAMD_LDS_SYNC();
-      const bool has = below != 0ull;                                               // (lanes below lane_lo belong to sequences emitted earlier)
-      const uint32_t k = (uint32_t)lane - s;
-      const uint32_t i_out = inf & 1023u, i_inl = (inf >> 10) & 127u, i_w = (inf >> 17) & 63u, i_L = (inf >> 23) & 31u;
-      // ---- all stores of the step: literals (byte lanes), tokens, length bytes, offsets (rank lanes) ----
-      if (has && k < i_inl) ENC_ST1(dst + op + i_out + k, (uint8_t)own.a);
-      const uint32_t tpos = op + excl;
-      if (valid && hdr) ENC_ST1(dst + tpos, (uint8_t)(((ll < 15u ? ll : 15u) << 4) | (mcode < 15u ? mcode : 15u)));
-      if (valid && hdr == 2u) ENC_ST1(dst + tpos + 1u, (uint8_t)(ll - 15u));
-      const uint32_t opos = tpos + hdr + inl;
-      if (valid) g_st2(dst + opos, ip + w - cand_r);
-      if (valid && nme) ENC_ST1(dst + opos + 2u, (uint8_t)(mcode - 15u < 255u ? mcode - 15u : 255u));
-      if (extra_last) {                                                             // uniform: the 255-run of a long match (lz4.c:1213-1226)
-        const uint32_t opos_last = (uint32_t)__builtin_amdgcn_readlane((int)opos, (int)last);
-        emit_ext255(dst + opos_last + 2u, mcode_last - 15u, lane);
-      }
-      op += total;
-      // ---- table: like the reference, nothing inside a match is inserted (lz4.c:1236-1242 inserts ip-2 only): positions up to the winner,
-      //      the position two bytes before the match's end, and what lies behind the chain's last match when nothing more was found ----
+      // ---- all stores of the step: tokens, length bytes, offsets (rank lanes), then literals (byte lanes; SS = 1: one position after the other, so that
+      //      the fields of the first are dead before those of the second are made) ----
       {
+        const uint32_t tpos = op + excl;
+        if (valid && hdr) ENC_ST1(dst + tpos, (uint8_t)(((ll < 15u ? ll : 15u) << 4) | (mcode < 15u ? mcode : 15u)));
+        if (valid && hdr == 2u) ENC_ST1(dst + tpos + 1u, (uint8_t)(ll - 15u));
+        const uint32_t opos = tpos + hdr + inl;
+        if (valid) g_st2(dst + opos, ip + wq - cand_r);
+        if (valid && nme) ENC_ST1(dst + opos + 2u, (uint8_t)(mcode - 15u < 255u ? mcode - 15u : 255u));
+        if (extra_last) {                                                           // uniform: the 255-run of a long match (lz4.c:1213-1226)
+          const uint32_t opos_last = (uint32_t)__builtin_amdgcn_readlane((int)opos, (int)last);
+          emit_ext255(dst + opos_last + 2u, mcode_last - 15u, lane);
+        }
+      }
+      // table: like the reference, nothing inside a match is inserted (lz4.c:1236-1242 inserts ip-2 only): positions up to the winner, the position two
+      // bytes before the match's end, and what lies behind the chain's last match when nothing more was found
+      {
+        const uint32_t k = lq - s;
+        const uint32_t i_out = inf & 1023u, i_inl = (inf >> 10) & 127u, i_w = ((inf >> 17) & 63u) << SS, i_L = (inf >> 23) & 31u;
+        if (has && k < i_inl) ENC_ST1(dst + op + i_out + k, (uint8_t)own.a);
         const bool open_end = i_L < RANK_CAP;                                       // (behind a match that was extended the chain picks up again below)
         const uint32_t e = i_w + i_L;
-        if (live && has && ((uint32_t)lane <= i_w || (open_end && ((uint32_t)lane + 2u == e || (uint32_t)lane >= e)))) PAR_PUT();
+        if (live && has && (lq <= i_w || (open_end && (lq + 2u == e || lq >= e)))) PAR_PUT();
       }
+      if (SS) {                                                                     // the lane's second position: a sequence of its own starts there, or it belongs to the first position's
+        const bool own1 = (myw1 >> 31) != 0u;
+        const uint32_t inf1 = own1 ? myw1 : inf;
+        const bool has1 = has || own1;
+        const uint32_t q1 = lq + 1u, k1 = own1 ? 0u : q1 - s;
+        const uint32_t j_out = inf1 & 1023u, j_inl = (inf1 >> 10) & 127u, j_w = ((inf1 >> 17) & 63u) << SS, j_L = (inf1 >> 23) & 31u;
+        if (has1 && k1 < j_inl) ENC_ST1(dst + op + j_out + k1, (uint8_t)(own.a >> 8));
+        const bool open1 = j_L < RANK_CAP;
+        const uint32_t e1 = j_w + j_L;
+        if (live1 && has1 && (q1 <= j_w || (open1 && (q1 + 2u == e1 || q1 >= e1)))) PAR_PUT1();
+      }
+      op += total;
       const uint32_t e_last = w_last + L_last + mext;                               // end of the chain's last match, relative to ip
       anchor = ip + e_last;
       PROF_LAP(11);
-      if (L_last < RANK_CAP || e_last >= 64u) break;                                // the chain ended by itself / the match leaves the step
+      if (L_last < RANK_CAP || e_last >= SPAN) break;                               // the chain ended by itself / the match leaves the step
       lane_lo = e_last;
-      if (live && (uint32_t)lane + 2u == lane_lo) PAR_PUT();                 // (lz4.c:1236-1242)
+      if (live && lq + 2u == lane_lo) PAR_PUT();                             // (lz4.c:1236-1242)
+      if (live1 && lq + 3u == lane_lo) PAR_PUT1();
     }
     if (!any) {
       PROF_ADD(1, 1);
       if (live) PAR_PUT();
-      nfail++;
-      uint32_t adv = 1u + (nfail * (uint32_t)accel) / 16u;   // skip faster through incompressible data
-      if (adv > 16u) adv = 16u;
-      ip += 64u * adv;
+      if (live1) PAR_PUT1();
+      nfail += 1u << SS;                                     // (counted in 64-position units: the skip grows with the bytes that failed, whatever the stride)
+      uint32_t adv = (nfail * (uint32_t)accel) / 16u;        // skip faster through incompressible data
+      if (adv > 16u - (1u << SS)) adv = 16u - (1u << SS);   // (a step never starts more than 1 KiB behind the one before, as in lz_encode_wave)
+      // Every fourth failed step is followed by its NEIGHBOUR.  A step finds only what earlier steps put into the table; once the skip is as long as
+      // the data's runs (linspace at typesize 2: runs of 1 KiB with a period of 16 bytes, each run with new content) every step lands in a run no
+      // earlier step has seen, fails, and keeps the skip long - the reference, which spreads its probes evenly (lz4.c:1044-1053), gets out at once,
+      // and so does a step right behind one whose positions have just entered the table.
+      if (BAMD_ENC_NEIGHBOUR && ((nfail >> SS) & (BAMD_ENC_NEIGHBOUR - 1u)) == 0u) adv = 0u;
+      ip += SPAN + 64u * adv;
       continue;
     }
     nfail = 0;
@@ -330,13 +415,26 @@ __device__ uint32_t lz4_encode_wave_par(const gu8* __restrict__ src, uint32_t n,
       ip = anchor;
       ins_pending = true;                         // anchor-2 enters the table at the top of the next step (bytes in registers there)
     } else {
-      if (tail_open && live && (uint32_t)lane >= lane_lo) PAR_PUT();       // nothing more to find behind an extended match
+      if (tail_open && live && lq >= lane_lo) PAR_PUT();                   // nothing more to find behind an extended match
+      if (tail_open && live1 && lq + 1u >= lane_lo) PAR_PUT1();
       ip = step_end;
     }
   }
 #undef PAR_PUT
+#undef PAR_PUT1
   op = lz4_emit_tail(dst, op, cap, src + anchor, n - anchor, lane);
   if (op == 0xffffffffu) return 0u;
   PROF_LAP(12);
   return op < n ? op : 0u;
+}
+
+// Which stride a compression level gets: every position at the levels that ask for ratio, every other one from BAMD_ENC_STRIDE2_MAXCLEVEL down
+// (the benchmark's clevel 5 among them; the reference's own LZ4 acceleration at that level is 5, lz4.c:1044-1053).
+#ifndef BAMD_ENC_STRIDE2_MAXCLEVEL
+#define BAMD_ENC_STRIDE2_MAXCLEVEL 5
+#endif
+__device__ __forceinline__ uint32_t lz4_encode_wave_auto(const gu8* __restrict__ src, uint32_t n, gu8* __restrict__ dst, uint32_t cap,
+                                                         int clevel, enc_entry_t* tab_generic, int lane EPROF_ARG) {
+  if (clevel <= BAMD_ENC_STRIDE2_MAXCLEVEL) return lz4_encode_wave_par<1>(src, n, dst, cap, clevel, tab_generic, lane EPROF_PASS);
+  return lz4_encode_wave_par<0>(src, n, dst, cap, clevel, tab_generic, lane EPROF_PASS);
 }

@@ -472,7 +472,7 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   const bool zsearch = (zstd && env_flag_or("BLOSC_AMD_ZSTD_SEARCH", p.clevel >= 6)) || (zlibc && env_flag_or("BLOSC_AMD_ZLIB_SEARCH", true));
   // Huffman-coded literals (with the per-block tables, or tables + search): BLOSC_AMD_ZSTD_HUFFMAN=1 on top of either switch
   const bool zhuf = zstd && (ztab || zsearch) && env_flag("BLOSC_AMD_ZSTD_HUFFMAN");
-  const int enc_wpc_lz = ENC_WAVES_PER_CU;
+  const int enc_wpc_lz = (zstd || zlibc) ? ENC_WAVES_PER_CU : ENC_LZ_WAVES_PER_CU;
   const int enc_wpc = zsearch ? (160 * 1024) / (HC_TAB_BYTES + ZS_LDS_BYTES) : (hc ? HC_WAVES_PER_CU : enc_wpc_lz);   // what fits into a CU's LDS
   const bool zdyn = zlibc && env_flag_or("BLOSC_AMD_ZLIB_DYNAMIC", true);      // zlib with dynamic Huffman codes: two passes, the tokens in the sequence scratch
   const size_t zwaves = (zstd || zdyn) ? (size_t)(st.cus > 0 ? st.cus : 256) * (size_t)enc_wpc : 0;

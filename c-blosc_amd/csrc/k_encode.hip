@@ -113,7 +113,7 @@ __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd_, enc
   else if (MODE == ENC_ZLIB) r = zlib_encode_wave(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, lane EPROF_PASS);
   else if (hint < 0) r = emit_periodic_stream(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, (uint32_t)-hint, uni((uint32_t)sd->fmt) == (uint32_t)FMT_LZ4, lane);
   else if (MODE == ENC_HC) r = lz4hc_encode_wave(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, tab, lane);
-  else if (sd->fmt == FMT_LZ4) r = BAMD_ENC_PAR ? lz4_encode_wave_par(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, lane EPROF_PASS)
+  else if (sd->fmt == FMT_LZ4) r = BAMD_ENC_PAR ? lz4_encode_wave_auto(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, lane EPROF_PASS)
                                                 : lz_encode_wave<EF_LZ4>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, lane EPROF_PASS);
   else r = lz_encode_wave<EF_BLOSCLZ>(uni_ptr(as_global(sd->in)), n, uni_ptr(as_global(sd->out)), cap, clevel, tab, lane EPROF_PASS);
   if (lane == 0) sd->result = (int32_t)r;
@@ -135,7 +135,7 @@ __device__ __attribute__((noinline)) void encode_one_stream(StreamDesc* sd_, enc
 // finding of other waves instead of in a kernel of their own.
 template <int MODE>
 // (waves per SIMD the register allocator plans for: the 24 KiB table of the HC modes leaves room for 1.5, the Zstd modes' LDS for 5)
-__global__ __launch_bounds__(64 * ENC_WAVES, enc_mode_hc(MODE) ? 2 : ((MODE == ENC_ZSTD_T || MODE == ENC_ZSTD_TH) ? 5 : BAMD_ENC_MINWAVES)) void k_encode_streams_t(
+__global__ __launch_bounds__(64 * ENC_WAVES, enc_mode_hc(MODE) ? 2 : ((MODE == ENC_ZSTD_T || MODE == ENC_ZSTD_TH) ? 5 : (MODE == ENC_LZ ? BAMD_ENC_LZ_MINWAVES : BAMD_ENC_MINWAVES))) void k_encode_streams_t(
     StreamDesc* __restrict__ streams, uint32_t* __restrict__ tickets /*[8]*/, const int32_t* __restrict__ qlist,
     const int32_t* __restrict__ qoff /*[9]*/, const int32_t* __restrict__ shoff /*[9] | shuffle list*/, const ChunkDesc* __restrict__ chunks, const BlockDesc* __restrict__ blocks,
     uint32_t* __restrict__ blk_ready, uint32_t* __restrict__ plane_cost, int single_queue,

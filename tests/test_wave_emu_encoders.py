@@ -20,6 +20,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 FULL = os.environ.get("BLOSC_EMU_FULL") == "1"          # the default run is sized for a CPU suite of a few minutes; BLOSC_EMU_FULL=1 takes everything
 LZ4, BLOSCLZ, LZ4HC, ZSTD, ZLIB, ZSTD_TABLES, ZSTD_SEARCH, ZLIB_SEARCH, ZSTD_HUF, ZSTD_SEARCH_HUF, ZLIB_DYN, ZLIB_DYN_SEARCH = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
+# the LZ4 front ends by name (kind 0 = whichever the level picks): the sequential select / emit loop of enc_lz.h, and the parallel parse of enc_lz4p.h probing
+# every position / every other position
+LZ4_SEQ, LZ4_PAR1, LZ4_PAR2 = 12, 13, 14
 
 
 SOAK = 7919 * int(os.environ.get("BLOSC_EMU_SEED", "0"))      # soak runs (BLOSC_EMU_SEED=1, 2, ...): every random draw of this file moves
@@ -75,7 +78,7 @@ def _plane(dname, n, T=8, j=0):
     return np.ascontiguousarray(d.reshape(-1, T).T[j])
 
 
-@pytest.mark.parametrize("kind", [LZ4, BLOSCLZ, LZ4HC], ids=["lz4", "blosclz", "lz4hc"])
+@pytest.mark.parametrize("kind", [LZ4, BLOSCLZ, LZ4HC, LZ4_SEQ, LZ4_PAR1, LZ4_PAR2], ids=["lz4", "blosclz", "lz4hc", "lz4-sequential", "lz4-parallel-stride1", "lz4-parallel-stride2"])
 def test_streams_decode_with_oracle_and_reference(emu, oracle, ref, kind):
     oracle.orc_blosclz_decompress.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     rng = np.random.default_rng(5 + SOAK)
@@ -106,7 +109,7 @@ def test_streams_decode_with_oracle_and_reference(emu, oracle, ref, kind):
     assert cases > (60 if FULL else 25)
 
 
-@pytest.mark.parametrize("kind", [LZ4, LZ4HC], ids=["lz4", "lz4hc"])
+@pytest.mark.parametrize("kind", [LZ4, LZ4HC, LZ4_PAR1, LZ4_PAR2], ids=["lz4", "lz4hc", "lz4-parallel-stride1", "lz4-parallel-stride2"])
 def test_capacity_is_respected(emu, oracle, ref, kind):
     """Whatever room the stream is given: either a complete valid stream inside it, or 0 (tests/test_maxout.c's rule one level down)."""
     for data in (_plane("bench19", 8192, 8, 0), _plane("bench19", 8192, 8, 1), _plane("linspace", 8192, 8, 2), _plane("linspace", 8192, 8, 6)):
@@ -120,6 +123,54 @@ def test_capacity_is_respected(emu, oracle, ref, kind):
                 _decodes(oracle, ref, kind, s, data)
             if cap >= full + 8:
                 assert r == full
+
+
+def _lz_source(rng, n):
+    """Bytes made the way an LZ decoder makes them - literal runs over a small alphabet and copies from the history at short and long distances - so that
+    the match finder meets matches of every length around its limits (4, 7, RANK_CAP, a step's 64 / 128 positions), at every parity and alignment."""
+    out = bytearray()
+    alpha = int(rng.choice([2, 4, 16, 256]))
+    while len(out) < n:
+        if len(out) < 4 or rng.random() < 0.35:
+            out += bytes(rng.integers(0, alpha, int(rng.choice([1, 2, 3, 5, 9, 17, 40, 130])), dtype=np.uint8))
+        else:
+            off = int(min(len(out), rng.choice([1, 2, 3, 4, 7, 8, 16, 31, 64, 100, 255, 1000, 5000, 40000])))
+            for _ in range(int(rng.choice([3, 4, 5, 6, 7, 8, 9, 12, 19, 20, 21, 24, 40, 64, 65, 127, 128, 129, 300, 2000]))):
+                out.append(out[len(out) - off])
+    return np.frombuffer(bytes(out[:n]), np.uint8).copy()
+
+
+@pytest.mark.parametrize("kind", [LZ4_PAR1, LZ4_PAR2], ids=["stride1", "stride2"])
+def test_parallel_parse_on_random_lz_sources(emu, oracle, ref, kind):
+    """The parallel parse (enc_lz4p.h) on seeded random sources, sizes and capacities: a valid stream inside the room it was given, or 0.  (Round 6: the
+    two-positions-per-lane step started a chain behind the last probing lane - a sequence made of another lane's leftovers, found by exactly this kind of input.)"""
+    rng = np.random.default_rng(77 + SOAK)
+    cases = 0
+    for _ in range(120 if FULL else 40):
+        n = int(rng.choice([13, 14, 20, 64, 65, 100, 127, 128, 129, 130, 200, 255, 256, 257, 300, 511, 513, 1000, 4096, 5000, 20000, 70000])) + int(rng.integers(0, 3))
+        data = _lz_source(rng, n)
+        for clevel in (1, 5):
+            cap = n if rng.random() < 0.7 else int(rng.integers(0, n + 1))
+            r, s = _encode(emu, kind, data, cap=cap, clevel=clevel)
+            if r:
+                _decodes(oracle, ref, LZ4, s, data)
+                cases += 1
+    assert cases > 25
+
+
+def test_stride2_keeps_most_of_the_ratio(emu):
+    """Probing every other position (clevel <= 5) may cost a few per cent of ratio on the benchmark's planes, not more (bench19 at typesize 8: 47.8 -> 46.6 here,
+    the reference's LZ4_compress_fast at its acceleration for that level: 36.7)."""
+    tot = {LZ4_PAR1: 0, LZ4_PAR2: 0}
+    n = 0
+    for j in range(8):
+        data = _plane("bench19", 131072, 8, j)
+        n += data.size
+        for kind in tot:
+            r, _ = _encode(emu, kind, data, clevel=5)
+            tot[kind] += r or data.size
+    print(f"bench19 planes of 128 KiB: every position {n / tot[LZ4_PAR1]:.2f}  every other position {n / tot[LZ4_PAR2]:.2f}")
+    assert tot[LZ4_PAR2] <= tot[LZ4_PAR1] * 1.06
 
 
 def test_lz4hc_search_finds_what_the_plain_one_misses(emu, oracle, ref):

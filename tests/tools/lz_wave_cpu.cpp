@@ -33,7 +33,9 @@ void lane_body(int lane, void* arg) {
   else if (j->kind == 2) r = lz4hc_encode_wave((const gu8*)j->src, (uint32_t)j->n, (gu8*)j->dst, (uint32_t)j->cap, j->tab, lane);
   else if (j->kind == 1) r = lz_encode_wave<EF_BLOSCLZ>((const gu8*)j->src, (uint32_t)j->n, (gu8*)j->dst, (uint32_t)j->cap, j->clevel, j->tab, lane);
   else if (j->kind == 12) r = lz_encode_wave<EF_LZ4>((const gu8*)j->src, (uint32_t)j->n, (gu8*)j->dst, (uint32_t)j->cap, j->clevel, j->tab, lane);      // the sequential select / emit loop (BAMD_ENC_PAR=0 builds; still the front end of the other writers)
-  else r = BAMD_ENC_PAR ? lz4_encode_wave_par((const gu8*)j->src, (uint32_t)j->n, (gu8*)j->dst, (uint32_t)j->cap, j->clevel, j->tab, lane)
+  else if (j->kind == 13) r = lz4_encode_wave_par<0>((const gu8*)j->src, (uint32_t)j->n, (gu8*)j->dst, (uint32_t)j->cap, j->clevel, j->tab, lane);      // every position probed, whatever the level
+  else if (j->kind == 14) r = lz4_encode_wave_par<1>((const gu8*)j->src, (uint32_t)j->n, (gu8*)j->dst, (uint32_t)j->cap, j->clevel, j->tab, lane);      // every other position probed, whatever the level
+  else r = BAMD_ENC_PAR ? lz4_encode_wave_auto((const gu8*)j->src, (uint32_t)j->n, (gu8*)j->dst, (uint32_t)j->cap, j->clevel, j->tab, lane)
                         : lz_encode_wave<EF_LZ4>((const gu8*)j->src, (uint32_t)j->n, (gu8*)j->dst, (uint32_t)j->cap, j->clevel, j->tab, lane);
   if (lane == 0) j->result = r;
 }
