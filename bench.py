@@ -599,6 +599,7 @@ def assemble(res, world, cpu, extra, mixed, args):
         "decompress_ms": sum(k[n]["ms_avg"] for n in DECOMPRESS_KERNELS if n in k),
         "decompress_stock_ms": sum(stock["kernels_ms"].values()) if stock else None,
         "ratio_stock": stock["ratio"] if stock else None,
+        "sched_cold_ms": res["sched_cold"]["ms_per_step"] if "sched_cold" in res else None,      # one step in plain block order (no cost feedback from an earlier call), arenas warm
         "roofline": roof,
         "verified": res["verified"],
     }
@@ -808,7 +809,7 @@ def main():
     mixed = None
     if args.config == "2" and not overridden and not args.no_extra and world == 1:
         extra = {}
-        for name in ("3", "4", "1g", "2t", "2x", "3e"):       # 1g: config #1's call (BloscLZ) on the GPU; 2t / 2x: config 2 at typesize 2 and 16, 3e: config 3 at typesize 8 (the reference's bench takes the typesize as an argument over the same data, bench/bench.c:250-320)
+        for name in ("3", "4", "1g", "2t", "2x", "3e", "2b", "2c", "2d", "3b", "3c"):       # 2b / 2c / 2d, 3b / 3c: the other data classes of configs 2 and 3 (linspace, random walk, random bytes -> MEMCPYED; arange, small integers - bench/bench.c:141-170 is one generator of several); 1g: config #1's call (BloscLZ) on the GPU; 2t / 2x: config 2 at typesize 2 and 16, 3e: config 3 at typesize 8 (the reference's bench takes the typesize as an argument over the same data, bench/bench.c:250-320)
             r = measure(rig, name, dict(CONFIGS[name]), min(args.steps, 5), 1, args)
             r.pop("_host_chunk")
             keep = ("value", "unit", "steps", "ms_per_step", "first_call_ms", "sched_cold", "ratio", "roofline", "kernels", "decompress_stock_chunks", "verified", "compress", "decompress")

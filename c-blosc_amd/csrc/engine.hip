@@ -42,6 +42,27 @@ static std::atomic<bool> g_warned{false};
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Experiment switches of the placement / scheduling studies (scripts/placement_*.py): read ONCE per process - a getenv on a production path races with a
+// concurrent setenv of the caller - and clamped: the skew shifts the arena's base inside its allocation, 0 .. 64 MiB.
+static size_t arena_skew_bytes() {
+#ifdef BAMD_ENV_EVERY_CALL      // (the placement scripts move the skew between re-allocations inside ONE process: make tune NAME=env DEFS=-DBAMD_ENV_EVERY_CALL)
+  const
+#else
+  static const
+#endif
+  size_t v = [] {
+    const char* sk = getenv("BLOSC_AMD_ARENA_SKEW_KIB");
+    long k = sk ? atol(sk) : 0;
+    if (k < 0) k = 0;
+    if (k > 65536) k = 65536;
+    return (size_t)k << 10;
+  }();
+  return v;
+}
+static bool debug_cost_enabled() {
+  static const bool v = getenv("BLOSC_AMD_DEBUG_COST") != nullptr;
+  return v;
+}
 struct DeviceArena {   // one grow-only device allocation carved up per call
   uint8_t* base = nullptr;
   uint8_t* raw = nullptr;   // what hipMalloc returned (base = raw + skew; BLOSC_AMD_ARENA_SKEW_KIB, a placement experiment: scripts/placement_probe.py)
@@ -50,8 +71,7 @@ struct DeviceArena {   // one grow-only device allocation carved up per call
     if (bytes <= cap) return 0;
     if (raw) { (void)hipFree(raw); raw = base = nullptr; cap = 0; }
     size_t want = align_up(bytes + bytes / 8, 1 << 20);
-    const char* sk = getenv("BLOSC_AMD_ARENA_SKEW_KIB");
-    const size_t skew = sk ? (size_t)atol(sk) << 10 : 0;
+    const size_t skew = arena_skew_bytes();
     HIP_TRY(hipMalloc((void**)&raw, want + skew));
     base = raw + skew;
     cap = want;
@@ -210,9 +230,11 @@ static void probe_topology(EngineState& st) {
 // context does not survive fork(), so there is nothing to re-create here: the child is marked and every compute call
 // in it fails loudly (-1) instead of touching the parent's device state.  prepare/parent keep the context mutexes
 // consistent across the fork (a forking thread never inherits one locked by somebody else).
-static void atfork_prepare() { for (int i = 0; i < kMaxCtx; i++) g_ctx[i].mu.lock(); }
-static void atfork_parent() { for (int i = kMaxCtx - 1; i >= 0; i--) g_ctx[i].mu.unlock(); }
-static void atfork_child() { for (int i = kMaxCtx - 1; i >= 0; i--) g_ctx[i].mu.unlock(); g_forked = true; }
+// (g_pick_mu first, as CtxGuard takes it: a child forked while another thread was choosing a context would inherit it locked and hang in its first
+//  call instead of failing with the message below)
+static void atfork_prepare() { g_pick_mu.lock(); for (int i = 0; i < kMaxCtx; i++) g_ctx[i].mu.lock(); }
+static void atfork_parent() { for (int i = kMaxCtx - 1; i >= 0; i--) g_ctx[i].mu.unlock(); g_pick_mu.unlock(); }
+static void atfork_child() { for (int i = kMaxCtx - 1; i >= 0; i--) g_ctx[i].mu.unlock(); g_pick_mu.unlock(); g_forked = true; }
 
 static int ensure_device(EngineState& st) {
   if (g_forked) {
@@ -965,7 +987,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   prof_collect(st);
   if (nblk && check_done((const uint32_t*)(P + p_cost), nstr - nstr_z, L.any_zstd ? nstr : 0, "decompress", nstr_zlib)) return -1;
   if (nstr >= 4096) { memcpy(st.dec_cost, P + p_cost, sizeof st.dec_cost); st.dec_cost_valid = true; }
-  if (getenv("BLOSC_AMD_DEBUG_COST")) {
+  if (debug_cost_enabled()) {
     fprintf(stderr, "[blosc_amd] decode plane costs:");
     for (int k = 0; k < 16; k++) fprintf(stderr, " %u", st.dec_cost[k]);
     fprintf(stderr, "\n");

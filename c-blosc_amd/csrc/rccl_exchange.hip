@@ -18,6 +18,7 @@ struct blosc_gpu_comm {
   hipStream_t stream = nullptr;
   uint8_t* scratch = nullptr;      // device: the padded cbytes exchange, then this rank's chunks back to back
   size_t scratch_bytes = 0;
+  int32_t* flag = nullptr;         // device, two words, made with the communicator: agree() never allocates
 };
 
 #define X_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fprintf(stderr, "blosc_amd (rccl exchange): %s: %s\n", #call, hipGetErrorString(e_)); return -2; } } while (0)
@@ -48,10 +49,31 @@ static int need_scratch(blosc_gpu_comm* c, size_t bytes) {
 static int finish_create(blosc_gpu_comm* c) {
   X_HIP(hipSetDevice(c->device));
   X_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  X_HIP(hipMalloc((void**)&c->flag, 2 * sizeof(int32_t)));
   return 0;
 }
+// One verdict for all ranks: the minimum of everybody's status (0 = fine, negative = this rank cannot go on).  Every exchange below first
+// agrees, THEN enters its group of sends and receives - a rank that returned on a condition only it can see (no container on the receiver, a
+// failed batch call, too small a buffer) would leave its peers inside a group nobody completes.  A rank whose own status was 0 gets -3 when a
+// peer's was not.  What cannot be agreed on is a call without a communicator, and arguments that must be equal on all ranks by contract
+// (nchunks, root, the table): see include/blosc_gpu_rccl.h.
+static int agree(blosc_gpu_comm* c, int status) {
+  if (c->world == 1) return status;
+  int32_t h = status, worst = 0;
+  X_HIP(hipMemcpyAsync(c->flag, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+  X_NCCL(ncclAllReduce(c->flag, c->flag + 1, 1, ncclInt32, ncclMin, c->comm, c->stream));
+  X_HIP(hipMemcpyAsync(&worst, c->flag + 1, sizeof worst, hipMemcpyDeviceToHost, c->stream));
+  X_HIP(hipStreamSynchronize(c->stream));
+  return status ? status : (worst ? -3 : 0);
+}
+// inside ncclGroupStart / ncclGroupEnd: remember the first failure, keep going, ALWAYS close the group (an early return would leave the thread's
+// group open and queue the next RCCL call of this thread behind it)
+#define G_HIP(call) do { if (!gerr) { hipError_t e_ = (call); if (e_ != hipSuccess) { fprintf(stderr, "blosc_amd (rccl exchange): %s: %s\n", #call, hipGetErrorString(e_)); gerr = -2; } } } while (0)
+#define G_NCCL(call) do { if (!gerr) { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { fprintf(stderr, "blosc_amd (rccl exchange): %s: %s\n", #call, ncclGetErrorString(r_)); gerr = -2; } } } while (0)
 
 extern "C" {
+
+void blosc_gpu_comm_destroy(blosc_gpu_comm* c);
 
 int blosc_gpu_comm_unique_id(void* id) {
   if (!id) return -1;
@@ -72,6 +94,8 @@ int blosc_gpu_comm_create(blosc_gpu_comm** out, int world, int rank, const void*
   memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
   if (hipSetDevice(device) != hipSuccess || ncclCommInitRank(&c->comm, world, u, rank) != ncclSuccess || finish_create(c) != 0) {
     fprintf(stderr, "blosc_amd (rccl exchange): communicator rank %d of %d on device %d could not be created\n", rank, world, device);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->flag) (void)hipFree(c->flag);
     if (c->comm) (void)ncclCommDestroy(c->comm);
     delete c;
     return -2;
@@ -92,13 +116,17 @@ int blosc_gpu_comm_create_all(blosc_gpu_comm** comms, int ndev, const int* devic
   }
   std::vector<ncclComm_t> raw((size_t)ndev, nullptr);
   X_NCCL(ncclCommInitAll(raw.data(), ndev, devs.data()));
+  int rc = 0;
   for (int r = 0; r < ndev; r++) {
     blosc_gpu_comm* c = new blosc_gpu_comm;
     c->comm = raw[(size_t)r]; c->world = ndev; c->rank = r; c->device = devs[(size_t)r];
     comms[r] = c;
-    if (finish_create(c) != 0) return -2;
+    if (!rc && finish_create(c) != 0) rc = -2;
   }
-  return 0;
+  if (rc) {      // nothing half-made is handed out: every communicator of the set goes, the caller's slots are cleared
+    for (int r = 0; r < ndev; r++) { blosc_gpu_comm_destroy(comms[r]); comms[r] = nullptr; }
+  }
+  return rc;
 }
 
 void blosc_gpu_comm_destroy(blosc_gpu_comm* c) {
@@ -106,6 +134,7 @@ void blosc_gpu_comm_destroy(blosc_gpu_comm* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
   if (c->scratch) (void)hipFree(c->scratch);
+  if (c->flag) (void)hipFree(c->flag);
   if (c->comm) (void)ncclCommDestroy(c->comm);
   delete c;
 }
@@ -163,48 +192,60 @@ static int pack_own(blosc_gpu_comm* c, size_t nchunks, const int* table, const v
   return 0;
 }
 
-int blosc_gpu_gather_chunks(blosc_gpu_comm* c, size_t nchunks, const int* table, const void* const* local_chunks, void* container, int root, size_t* offsets) {
-  if (!c || (nchunks && !table) || root < -1 || root >= c->world) return -1;
-  if (offsets) { size_t acc = 0; for (size_t ch = 0; ch < nchunks; ch++) { offsets[ch] = acc; if (table[ch] > 0) acc += (size_t)table[ch]; } }
-  if (nchunks == 0) return 0;
+static int gather_impl(blosc_gpu_comm* c, size_t nchunks, const int* table, const void* const* local_chunks, void* container, int root, size_t* offsets, int status) {
+  if (offsets && table) { size_t acc = 0; for (size_t ch = 0; ch < nchunks; ch++) { offsets[ch] = acc; if (table[ch] > 0) acc += (size_t)table[ch]; } }
+  if (nchunks == 0) return status;            // (nchunks is the same on every rank: nobody enters anything)
   X_HIP(hipSetDevice(c->device));
   const bool receiver = root < 0 || root == c->rank;
-  if (receiver && !container && bytes_of(table, 0, nchunks)) return -1;
   size_t mine = 0;
-  const int rc = pack_own(c, nchunks, table, local_chunks, &mine);
-  if (rc) return rc;
+  if (!status && receiver && !container && bytes_of(table, 0, nchunks)) status = -1;
+  if (!status) status = pack_own(c, nchunks, table, local_chunks, &mine);
+  status = agree(c, status);
+  if (status) return status;
   // one group: what every receiver takes from every other rank, what this rank sends to every receiver
-  X_NCCL(ncclGroupStart());
+  int gerr = 0;
+  G_NCCL(ncclGroupStart());
+  if (gerr) return gerr;
   size_t base = 0;
   for (int r = 0; r < c->world; r++) {
     size_t l, u;
     range_of(nchunks, c->world, r, &l, &u);
     const size_t n = bytes_of(table, l, u);
     if (receiver && n) {
-      if (r == c->rank) X_HIP(hipMemcpyAsync((uint8_t*)container + base, c->scratch, n, hipMemcpyDeviceToDevice, c->stream));
-      else X_NCCL(ncclRecv((uint8_t*)container + base, n, ncclUint8, r, c->comm, c->stream));
+      if (r == c->rank) G_HIP(hipMemcpyAsync((uint8_t*)container + base, c->scratch, n, hipMemcpyDeviceToDevice, c->stream));
+      else G_NCCL(ncclRecv((uint8_t*)container + base, n, ncclUint8, r, c->comm, c->stream));
     }
     base += n;
   }
   if (mine)
     for (int r = 0; r < c->world; r++)
-      if (r != c->rank && (root < 0 || root == r)) X_NCCL(ncclSend(c->scratch, mine, ncclUint8, r, c->comm, c->stream));
-  X_NCCL(ncclGroupEnd());
+      if (r != c->rank && (root < 0 || root == r)) G_NCCL(ncclSend(c->scratch, mine, ncclUint8, r, c->comm, c->stream));
+  { const ncclResult_t r_ = ncclGroupEnd(); if (r_ != ncclSuccess && !gerr) { fprintf(stderr, "blosc_amd (rccl exchange): ncclGroupEnd: %s\n", ncclGetErrorString(r_)); gerr = -2; } }
+  if (gerr) return gerr;
   X_HIP(hipStreamSynchronize(c->stream));
   return 0;
 }
+int blosc_gpu_gather_chunks(blosc_gpu_comm* c, size_t nchunks, const int* table, const void* const* local_chunks, void* container, int root, size_t* offsets) {
+  if (!c) return -1;
+  // (arguments that are equal on all ranks by contract decide for all ranks alike; what only this rank can see goes through agree())
+  if (root < -1 || root >= c->world) return -1;
+  return gather_impl(c, nchunks, table, local_chunks, container, root, offsets, (nchunks && !table) ? -1 : 0);
+}
 
-int blosc_gpu_scatter_chunks(blosc_gpu_comm* c, size_t nchunks, const int* table, const void* container, int root, void* local_packed, size_t* local_offsets) {
-  if (!c || (nchunks && !table) || root < 0 || root >= c->world) return -1;
+static int scatter_impl(blosc_gpu_comm* c, size_t nchunks, const int* table, const void* container, int root, void* local_packed, size_t* local_offsets, int status) {
   size_t lo, hi;
   range_of(nchunks, c->world, c->rank, &lo, &hi);
-  if (local_offsets) { size_t acc = 0; for (size_t ch = lo; ch < hi; ch++) { local_offsets[ch - lo] = acc; if (table[ch] > 0) acc += (size_t)table[ch]; } }
-  if (nchunks == 0) return 0;
+  if (local_offsets && table) { size_t acc = 0; for (size_t ch = lo; ch < hi; ch++) { local_offsets[ch - lo] = acc; if (table[ch] > 0) acc += (size_t)table[ch]; } }
+  if (nchunks == 0) return status;
   X_HIP(hipSetDevice(c->device));
-  const size_t mine = bytes_of(table, lo, hi);
-  if (mine && !local_packed) return -1;
-  if (c->rank == root && !container && bytes_of(table, 0, nchunks)) return -1;
-  X_NCCL(ncclGroupStart());
+  const size_t mine = status ? 0 : bytes_of(table, lo, hi);
+  if (!status && mine && !local_packed) status = -1;
+  if (!status && c->rank == root && !container && bytes_of(table, 0, nchunks)) status = -1;
+  status = agree(c, status);
+  if (status) return status;
+  int gerr = 0;
+  G_NCCL(ncclGroupStart());
+  if (gerr) return gerr;
   if (c->rank == root) {
     size_t base = 0;
     for (int r = 0; r < c->world; r++) {
@@ -212,50 +253,63 @@ int blosc_gpu_scatter_chunks(blosc_gpu_comm* c, size_t nchunks, const int* table
       range_of(nchunks, c->world, r, &l, &u);
       const size_t n = bytes_of(table, l, u);
       if (n) {
-        if (r == root) X_HIP(hipMemcpyAsync(local_packed, (const uint8_t*)container + base, n, hipMemcpyDeviceToDevice, c->stream));
-        else X_NCCL(ncclSend((const uint8_t*)container + base, n, ncclUint8, r, c->comm, c->stream));
+        if (r == root) G_HIP(hipMemcpyAsync(local_packed, (const uint8_t*)container + base, n, hipMemcpyDeviceToDevice, c->stream));
+        else G_NCCL(ncclSend((const uint8_t*)container + base, n, ncclUint8, r, c->comm, c->stream));
       }
       base += n;
     }
   } else if (mine) {
-    X_NCCL(ncclRecv(local_packed, mine, ncclUint8, root, c->comm, c->stream));
+    G_NCCL(ncclRecv(local_packed, mine, ncclUint8, root, c->comm, c->stream));
   }
-  X_NCCL(ncclGroupEnd());
+  { const ncclResult_t r_ = ncclGroupEnd(); if (r_ != ncclSuccess && !gerr) { fprintf(stderr, "blosc_amd (rccl exchange): ncclGroupEnd: %s\n", ncclGetErrorString(r_)); gerr = -2; } }
+  if (gerr) return gerr;
   X_HIP(hipStreamSynchronize(c->stream));
   return 0;
+}
+int blosc_gpu_scatter_chunks(blosc_gpu_comm* c, size_t nchunks, const int* table, const void* container, int root, void* local_packed, size_t* local_offsets) {
+  if (!c) return -1;
+  if (root < 0 || root >= c->world) return -1;
+  return scatter_impl(c, nchunks, table, container, root, local_packed, local_offsets, (nchunks && !table) ? -1 : 0);
 }
 
 // ---- the sharded calls: partition + the drop-in's batched call on the own range + the exchanges above ----
 int blosc_gpu_compress_sharded(blosc_gpu_comm* c, int clevel, int doshuffle, size_t typesize, const char* compressor, size_t blocksize,
                                size_t nchunks, const void* const* src, const size_t* nbytes, void* const* dest, const size_t* destsize,
                                int* table, void* container, size_t container_capacity, int root, size_t* offsets, size_t* container_bytes) {
-  if (!c || !table || (nchunks && (!src || !nbytes || !dest || !destsize)) || nchunks > 0x7fffffffu) return -1;
+  if (!c) return -1;
+  if (root < -1 || root >= c->world || nchunks > 0x7fffffffu) return -1;      // (equal on all ranks by contract)
+  int status = (!table || (nchunks && (!src || !nbytes || !dest || !destsize))) ? -1 : 0;
   size_t lo, hi;
   range_of(nchunks, c->world, c->rank, &lo, &hi);
   X_HIP(hipSetDevice(c->device));
   std::vector<int> local(hi - lo + 1, 0);
-  if (hi > lo) {
+  if (!status && hi > lo) {
     // blosc_gpu_set_device is process-wide: in the thread-per-GPU layout the call must not move other threads, so the device is bound the way
     // the _multi calls bind it - through a one-device _multi call on this rank's device
     const int dev = c->device;
-    if (blosc_gpu_compress_batch_multi(1, &dev, clevel, doshuffle, typesize, compressor, blocksize, (int)(hi - lo), src + lo, nbytes + lo, dest + lo, destsize + lo, local.data()) != 0) return -2;
+    if (blosc_gpu_compress_batch_multi(1, &dev, clevel, doshuffle, typesize, compressor, blocksize, (int)(hi - lo), src + lo, nbytes + lo, dest + lo, destsize + lo, local.data()) != 0) status = -2;
   }
+  // a rank whose batch call failed (or whose arguments are no good) tells the others BEFORE anybody enters the table's all-gather
+  status = agree(c, status);
+  if (status) return status;
   int rc = blosc_gpu_allgather_cbytes(c, nchunks, local.data(), table);
   if (rc) return rc;
   const size_t total = bytes_of(table, 0, nchunks);
   if (container_bytes) *container_bytes = total;
-  if ((root < 0 || root == c->rank) && total > container_capacity) return -1;
-  return blosc_gpu_gather_chunks(c, nchunks, table, (const void* const*)(dest + lo), container, root, offsets);
+  // the receivers' capacity is theirs alone to know: the verdict is agreed on inside the gather, before its group
+  return gather_impl(c, nchunks, table, (const void* const*)(dest + lo), container, root, offsets, ((root < 0 || root == c->rank) && total > container_capacity) ? -1 : 0);
 }
 
 int blosc_gpu_decompress_sharded(blosc_gpu_comm* c, size_t nchunks, const int* table, const void* container, int root,
                                  void* packed, size_t packed_capacity, void* const* dest, const size_t* destsize, int* nbytes_out) {
-  if (!c || (nchunks && (!table || !dest || !destsize || !nbytes_out)) || nchunks > 0x7fffffffu) return -1;
+  if (!c) return -1;
+  if (root < 0 || root >= c->world || nchunks > 0x7fffffffu) return -1;       // (equal on all ranks by contract)
+  int status = (nchunks && (!table || !dest || !destsize || !nbytes_out)) ? -1 : 0;
   size_t lo, hi;
   range_of(nchunks, c->world, c->rank, &lo, &hi);
-  if (bytes_of(table, lo, hi) > packed_capacity) return -1;
+  if (!status && bytes_of(table, lo, hi) > packed_capacity) status = -1;
   std::vector<size_t> loff(hi - lo + 1, 0);
-  int rc = blosc_gpu_scatter_chunks(c, nchunks, table, container, root, packed, loff.data());
+  int rc = scatter_impl(c, nchunks, table, container, root, packed, loff.data(), status);      // (agrees on `status` before its group)
   if (rc || hi == lo) return rc;
   std::vector<const void*> s(hi - lo); std::vector<size_t> ss(hi - lo);
   for (size_t ch = lo; ch < hi; ch++) { s[ch - lo] = (const uint8_t*)packed + loff[ch - lo]; ss[ch - lo] = table[ch] > 0 ? (size_t)table[ch] : 0; }

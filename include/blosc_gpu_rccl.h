@@ -12,9 +12,18 @@
  * Chunks are moved as opaque runs of cbytes bytes: their bstarts are offsets from the chunk's own start (blosc/blosc.c:816).
  *
  * This is a library of its own (c-blosc_amd/libblosc_amd_rccl.so, links librccl): the drop-in libblosc.so.1 does not depend on RCCL.
+ * Loading it: its DT_NEEDED names the drop-in by its SONAME (libblosc.so.1) and its run path is $ORIGIN, so the drop-in must sit NEXT TO
+ * this library under that name - `make -C c-blosc_amd rccl` puts the symlink libblosc.so.1 -> libblosc_amd.so there.  (Without it the
+ * loader would pick a stock c-blosc from the system's library path, which has none of the blosc_gpu_* symbols.)
+ *
  * A communicator rank belongs to the thread that uses it; the calls are collective: every rank of the communicator makes the same
- * call with the same nchunks / table / root.  All return 0, or < 0 (-1: bad arguments, -2: a HIP or RCCL call failed; the message goes
- * to stderr).  Device pointers are memory of the communicator rank's device.
+ * call with the same nchunks / table / root - those are equal on all ranks BY CONTRACT and decide alike everywhere.  What only one rank
+ * can see (a missing container or too small a buffer on a receiver, a NULL pointer for its own range, a batch call that failed on its
+ * device) is AGREED ON before any payload moves: every exchange first takes the minimum of all ranks' verdicts (one 4-byte all-reduce),
+ * so either every rank enters the group of sends and receives or none does - a mis-call on one rank cannot leave the others waiting.
+ * All return 0, or < 0: -1 bad arguments on this rank, -2 a HIP or RCCL call (or the batched call) failed on this rank (the message goes
+ * to stderr), -3 this rank was fine but a peer reported -1 / -2, and nothing was exchanged.  The one thing that cannot be agreed on is a
+ * call without a communicator (-1 at once).  Device pointers are memory of the communicator rank's device.
  */
 #ifndef BLOSC_AMD_BLOSC_GPU_RCCL_H
 #define BLOSC_AMD_BLOSC_GPU_RCCL_H
