@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 CFG=${CFG:-2}; TAG=${TAG:-r05}_cfg${CFG}
 # which kernel sources these passes ran on (bench.py quotes a traffic figure only for the sources it runs itself)
 python -c "import bench; print(bench.src_fingerprint())" > gpurun_out/${TAG}_src_fingerprint.txt
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_trace -o trace -- python bench.py --config $CFG --no-cpu-baseline --no-extra > gpurun_out/${TAG}_bench_under_trace.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_trace -o trace -- python bench.py --config $CFG --no-cpu-baseline --no-extra ${NOSTOCK:+--no-stock} > gpurun_out/${TAG}_bench_under_trace.log 2>&1      # NOSTOCK=1: own chunks only, the decode of reference-written chunks is traced apart (scripts/r06_final.sh)
 grep '^{' gpurun_out/${TAG}_bench_under_trace.log | tail -1 > gpurun_out/${TAG}_bench_under_trace.json
 f=$(find gpurun_out/${TAG}_trace -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp "$f" gpurun_out/${TAG}_kernel_stats.csv && head -14 "$f" | cut -c1-160
