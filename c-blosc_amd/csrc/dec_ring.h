@@ -50,6 +50,10 @@ inline unsigned long long g_emu_ring_far = 0;         // ... and matches served 
 #endif
 
 #define DR_SYNC() do { LDS_ORDER(); BAMD_LDS_SYNC(); } while (0)
+// lane i <- lane i + N of its 16-lane row (0 beyond the row): DPP row_shl
+__device__ __forceinline__ uint32_t dpp_shl1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xf, 0xf, true); }
+__device__ __forceinline__ uint32_t dpp_shl2(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x102, 0xf, 0xf, true); }
+__device__ __forceinline__ uint32_t dpp_shl3(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x103, 0xf, 0xf, true); }
 
 struct RingIO {
   volatile BAMD_LAS uint32_t* scr;     // 64 dwords: token info of a step on its way back to byte-lane space
@@ -210,6 +214,25 @@ __device__ __forceinline__ void dr_match(RingIO& io, uint32_t& op, uint32_t off,
     const uint32_t G = ((64u * M) >> 16) * off;
     const uint32_t i_mod = (uint32_t)lane - (((uint32_t)lane * M) >> 16) * off;
     const uint32_t val = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(i_mod << 2), (int)pat);
+    if ((16u % off) == 0u && len >= 64u && len < 2u * DR_ROW) {      // (longer ones: the row-register form below, which also stores the rows itself)
+      // Periods 1, 2, 4, 8, 16 (runs and narrow counters: a smooth byte plane is made of them - the reference's linspace chunks hold 256 runs of 511 bytes in one
+      // plane, 256 of 255 in another): the 16 bytes every lane would write are the SAME - the first sixteen lanes of `val` - so the whole match goes into the
+      // ring a row's worth per store, straight from registers.  Before (round 6): 64 bytes from registers, then three to five copies of doubling stride through
+      // the ring, each with its three LDS barriers - 7.6 k cycles per run (profiles/r06m_dec_phase_linspace.txt).
+      const uint32_t b4 = val | (dpp_shl1(val) << 8) | (dpp_shl2(val) << 16) | (dpp_shl3(val) << 24);      // lane i: pattern bytes i .. i + 3 (i + 3 < 16 is all that is read)
+      const uint4 row = make_uint4((uint32_t)__builtin_amdgcn_readlane((int)b4, 0), (uint32_t)__builtin_amdgcn_readlane((int)b4, 4),
+                                   (uint32_t)__builtin_amdgcn_readlane((int)b4, 8), (uint32_t)__builtin_amdgcn_readlane((int)b4, 12));
+      DR_SYNC();
+      for (uint32_t d = 0; d < len; d += DR_ROW) {             // (every piece starts a multiple of 1 KiB behind the match's start: the pattern's phase is 0 again)
+        const uint32_t c = len - d < DR_ROW ? len - d : DR_ROW, pos = mpos + d, n16 = c >> 4, t0 = c & ~15u;
+        if ((uint32_t)lane < n16) dr_put16(io.hist, pos + 16u * (uint32_t)lane, row);
+        if (t0 + (uint32_t)lane < c) io.hist[(pos + t0 + (uint32_t)lane) & DR_MASK] = (uint8_t)val;      // (lane j < 16: pattern byte j)
+        op = pos + c;
+        dr_flush_rows(io, op);
+      }
+      DR_SYNC();
+      return;
+    }
     const uint32_t head = len < G ? len : G;
     DR_SYNC();
     if ((uint32_t)lane < head) io.hist[(mpos + (uint32_t)lane) & DR_MASK] = (uint8_t)val;
@@ -590,6 +613,10 @@ __device__ __forceinline__ uint32_t dr_step(RingIO& io, uint32_t& ip, uint32_t& 
     const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)off_r, sl);
     const uint32_t mr = (uint32_t)__builtin_amdgcn_readlane((int)mrel_r, sl);
     const uint32_t s0 = op + mr - o;
+    // (Round 6: every byte read here is final before the sequence begins and none is written by it, so all - up to five - reads of a lane could go out before its
+    //  writes, one round trip instead of five (memory trips when the source is older than the ring: the reference's linspace planes take runs of 255 bytes from
+    //  65 535 bytes back).  Built: 3 - 12 % SLOWER on linspace, bench19 and the bit planes alike, profiles/r06r_*.  So was dr_match's register fill for runs of more than
+    //  64 bytes in here: nothing on linspace, 5 - 9 % slower on the bit planes, whose steps send dozens of sequences through this loop (profiles/r06s_*).  The in-order loops stay.)
     if (s0 >= nlo) {
       // k mod o per lane with a float reciprocal (exact here: the quotient is only needed when o < m <= 273, k < 512; an integer division
       // per match was 23 scalar instructions, k_zstd.hip: zstd_exec16_lds has the story)
