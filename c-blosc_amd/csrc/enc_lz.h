@@ -155,7 +155,11 @@ __device__ __forceinline__ uint32_t wave_common_fwd(const gu8* src, uint32_t n, 
   return wave_common_fwd_rest(src, n, a, b, maxlen, done, lane);
 }
 
+#ifdef BAMD_ENC_NOSTORE      // timing-only build (wrong output): what do the encoder's byte stores cost?  (scripts/enc_ab.py does not check the output)
+#define ENC_ST1(ptr, val) do { (void)(ptr); (void)(val); } while (0)
+#else
 #define ENC_ST1(ptr, val) do { *(ptr) = (val); } while (0)
+#endif
 // write `v` as LZ4's 255-run length extension starting at p; returns bytes written
 __device__ __forceinline__ uint32_t emit_ext255(gu8* p, uint32_t v, int lane) {
   const uint32_t n255 = v / 255u, rem = v - n255 * 255u;

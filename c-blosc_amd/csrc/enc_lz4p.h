@@ -358,7 +358,9 @@ __device__ uint32_t lz4_encode_wave_par(const gu8* __restrict__ src, uint32_t n,
         if (valid && hdr) ENC_ST1(dst + tpos, (uint8_t)(((ll < 15u ? ll : 15u) << 4) | (mcode < 15u ? mcode : 15u)));
         if (valid && hdr == 2u) ENC_ST1(dst + tpos + 1u, (uint8_t)(ll - 15u));
         const uint32_t opos = tpos + hdr + inl;
+#ifndef BAMD_ENC_NOSTORE
         if (valid) g_st2(dst + opos, ip + wq - cand_r);
+#endif
         if (valid && nme) ENC_ST1(dst + opos + 2u, (uint8_t)(mcode - 15u < 255u ? mcode - 15u : 255u));
         if (extra_last) {                                                           // uniform: the 255-run of a long match (lz4.c:1213-1226)
           const uint32_t opos_last = (uint32_t)__builtin_amdgcn_readlane((int)opos, (int)last);
