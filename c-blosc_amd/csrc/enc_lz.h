@@ -22,8 +22,10 @@ constexpr int ENC_TAB_BYTES = BAMD_ENC_SPLIT_TAB ? ENC_TAB * 3 : ENC_TAB * 4;
 #define BAMD_ENC_MINWAVES (BAMD_ENC_SPLIT_TAB ? 6 : 5)   // waves per SIMD the register allocator leaves room for (5: + 3 %, 7 = 26 waves per CU at 72 registers: + 1.8 %, profiles/r04/r04zu_*)
 #endif
 #ifndef BAMD_ENC_LZ_MINWAVES
-#define BAMD_ENC_LZ_MINWAVES 5   // the LZ4 / BloscLZ kernel (round 6): the two-positions-per-lane step of enc_lz4p.h needs 96 registers - at 80 its input window lives in scratch
-                                 // memory and every step reloads it behind the stores of the step before (profiles/r06c_*: 8.6 ms at 24 waves per CU, 7.5 at 20)
+#define BAMD_ENC_LZ_MINWAVES 6   // the LZ4 / BloscLZ kernel.  Round 6: the two-positions-per-lane step of enc_lz4p.h first needed 96 registers (5) - at 80 its input window lived in
+                                 // scratch memory and every step reloaded it behind the stores of the step before (profiles/r06c_*: 8.6 ms at 24 waves per CU, 7.5 at 20).  What
+                                 // filled the registers were two dozen loop-invariant values derived from the lane number that the compiler hoists out of the step and the chain
+                                 // loop; with the lane number made opaque at the top of both (enc_lz4p.h) the step fits 80 registers without a spill: 24 waves, 7.6 ms (r06w)
 #endif
 constexpr int ENC_LDS_WAVES = (160 * 1024) / ENC_TAB_BYTES;
 constexpr int ENC_WAVES_PER_CU = ENC_LDS_WAVES < 4 * BAMD_ENC_MINWAVES ? ENC_LDS_WAVES : 4 * BAMD_ENC_MINWAVES;   // persistent grid size per CU
@@ -160,6 +162,8 @@ __device__ __forceinline__ uint32_t wave_common_fwd(const gu8* src, uint32_t n, 
 #else
 #define ENC_ST1(ptr, val) do { *(ptr) = (val); } while (0)
 #endif
+// (Round 6: making the lane number opaque at the top of lz_encode_wave's loops, as enc_lz4p.h does, takes most spills out of the BloscLZ path - 21 -> 7 scratch
+//  accesses in the function - and changes nothing that can be measured: BloscLZ - 1 %, Zstd + 1.5 %, zlib + 0.5 %, profiles/r06x_*; not kept here.)
 // write `v` as LZ4's 255-run length extension starting at p; returns bytes written
 __device__ __forceinline__ uint32_t emit_ext255(gu8* p, uint32_t v, int lane) {
   const uint32_t n255 = v / 255u, rem = v - n255 * 255u;

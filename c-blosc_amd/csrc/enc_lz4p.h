@@ -31,14 +31,14 @@ static_assert(ENC_LZ_LDS_WAVES == (160 * 1024) / (ENC_TAB_BYTES + ENC_SCR_BYTES)
 #ifndef BAMD_ENC_NEIGHBOUR
 #define BAMD_ENC_NEIGHBOUR 4u   // a power of two, or 0: never
 #endif
-#ifndef BAMD_ENC_LAUNDER
-#define BAMD_ENC_LAUNDER 1
-#endif
 #ifndef BAMD_ENC_KEEPJ
 #define BAMD_ENC_KEEPJ 0     // the doubled next-pointers made once per step (three registers across the chain loop) instead of once per chain
 #endif
 #ifndef BAMD_ENC_EXT2
 #define BAMD_ENC_EXT2 1      // long comparisons two rows per trip (wave_common_fwd, enc_lz.h) - affordable at 96 registers; 0: one row per trip (wave_common_fwd_lite)
+#endif
+#ifndef BAMD_ENC_LAUNDER
+#define BAMD_ENC_LAUNDER 1
 #endif
 #ifndef BAMD_ENC_PREFULL
 #define BAMD_ENC_PREFULL 1   // a step that begins with pending literals (behind skipped, match-less steps) extends its first match backwards into them, up to 64 bytes
@@ -233,6 +233,11 @@ __device__ uint32_t lz4_encode_wave_par(const gu8* __restrict__ src, uint32_t n,
     uint32_t lane_lo = 0;                         // first POSITION of the step (relative to ip) not covered by a sequence emitted so far
     bool any = false, tail_open = false;
     for (;;) {
+#if !defined(BAMD_WAVE_EMU) && BAMD_ENC_LAUNDER
+      // (again for the chain: hoisted out of THIS loop, the per-lane address of the extension's first loads was spilled at the top of every step and
+      //  reloaded - behind s_waitcnt vmcnt(0) - in front of every extension: 3.4 GB of scratch writes per 8 GiB, profiles/r06v_*)
+      asm volatile("; lane of this chain" : "+v"(lane));
+#endif
       // rank lane r (< 16): c = start of the r-th search of the chain that begins at lane_lo
       // (the doubled pointers are made here, not once per step: they would be live across everything below, and nine steps in ten run this once)
 #if !BAMD_ENC_KEEPJ
