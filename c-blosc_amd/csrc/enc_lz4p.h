@@ -274,7 +274,7 @@ __device__ uint32_t lz4_encode_wave_par(const gu8* __restrict__ src, uint32_t n,
                               : wave_common_fwd_lite(src, n, pm_last + RANK_CAP, c_last + RANK_CAP, mlimit - (pm_last + RANK_CAP), lane);
       }
       // (Round 6 also asked for the first 256 bytes of this extension up here and looked at them behind the step's emission - only the last match's length bytes need
-      //  them, and they close the step's output: 4 % SLOWER on every data set, profiles/r06e_enc_ab_extension_under_emission_rejected.txt.)
+      //  them, and they close the step's output: 4 % SLOWER on every data set, profiles/r06e_enc_ab_extension_under_emission_rejected.txt; again at 80 registers, without the spill of r06v in front of every extension: no difference, r06y.)
       uint32_t back = valid ? umin32(nb_r, umin32(room, cand_r)) : 0u;
       if (BAMD_ENC_BACK2) {
         // all four bytes in front equal and room for more: eight more bytes per such sequence, all of them in one round trip (bench19's noisy planes: 5 % of
