@@ -96,6 +96,10 @@ __device__ __forceinline__ uint32_t wave_common_fwd_lite(const gu8* src, uint32_
   return maxlen;
 }
 
+// (Round 6 also asked for the window of a step that starts behind a jump - after a long match, or in the long strides through data that does not match - a
+//  step ahead, where the jump is known: profiles/r06z_* show 4 - 5 k of a match-less step's 5.7 k cycles in front of its window, and the position a match-less
+//  step goes on to depends only on the count of misses.  3 - 6 % SLOWER on bench19, random-walk data and typesize 2 alike; only pure noise gained 2 %:
+//  profiles/r06za_*.  Not kept.)
 // SS = log2 of the PROBE STRIDE (round 6).  SS = 1: a step covers 128 positions; lane l probes position ip + 2 l only, but BOTH positions of a lane enter the
 // table (so a repeat is found whatever the parity of its distance) and both bytes of a lane leave as literals.  A match that begins on an odd position
 // is found one byte late and gets its first byte back from the backward extension (the four bytes in front of every candidate are there anyway); its
