@@ -136,24 +136,30 @@ def src_fingerprint():
 
 def measured_traffic(kernel, config_name, nchunks, chunk_mib, stock=False):
     """(HBM bytes per launch of `kernel`, where they come from) out of the committed rocprofv3 PMC passes of THIS workload
-    (profiles/r05_traffic_cfg<config>.json, made by scripts/profile_config.sh + scripts/make_traffic_json.py: FETCH_SIZE and WRITE_SIZE
+    (profiles/r<NN>_traffic_cfg<config>.json, made by scripts/profile_config.sh + scripts/make_traffic_json.py: FETCH_SIZE and WRITE_SIZE
     in separate passes, gfx950 corrections applied).  PMC counters cannot be read from inside a timed run, so the figure is the committed
     one - and only when the file was made from the SAME kernel sources as the running build (`src_fingerprint` inside it); a file of
     other sources, or of another geometry than 128 x 64 MiB, gives null and says why.  stock=True: the launches that decoded
     REFERENCE-written chunks ("kernels_stock")."""
     if nchunks != 128 or chunk_mib != 64:
         return None, "no PMC pass of this geometry"
-    path = os.path.join(ROOT, "profiles", f"r05_traffic_cfg{config_name}.json")
-    if not os.path.exists(path):
+    # the newest round's file whose sources are the running ones (r06_traffic_cfg2.json, r05_...: one per round that ran the passes)
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_traffic_cfg{config_name}.json")), reverse=True)
+    if not cands:
         return None, "no PMC pass of this configuration on the round's kernels"
-    with open(path) as fh:
-        doc = json.load(fh)
-    if doc.get("src_fingerprint") != src_fingerprint():
-        return None, f"profiles/r05_traffic_cfg{config_name}.json is stale (sources {doc.get('src_fingerprint')}, running {src_fingerprint()})"
-    k = (doc.get("kernels_stock") or {}).get(kernel) if stock else None
-    k = k or doc["kernels"].get(kernel)
-    return (k["hbm_bytes"] if k else None), f"profiles/r05_traffic_cfg{config_name}.json"
-
+    fp, stale = src_fingerprint(), None
+    for path in cands:
+        with open(path) as fh:
+            doc = json.load(fh)
+        rel = os.path.relpath(path, ROOT)
+        if doc.get("src_fingerprint") != fp:
+            stale = stale or f"{rel} is stale (sources {doc.get('src_fingerprint')}, running {fp})"
+            continue
+        k = (doc.get("kernels_stock") or {}).get(kernel) if stock else None
+        k = k or doc["kernels"].get(kernel)
+        return (k["hbm_bytes"] if k else None), rel
+    return None, stale
 
 # ---------------------------------------------------------------------------------------------
 # CPU baseline: the reference itself (oracle/_ref, built from /root/reference's sources) on this box's cores

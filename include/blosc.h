@@ -111,7 +111,8 @@ BLOSC_EXPORT void blosc_destroy(void);
  * Which BYTES a compress call writes (the reference pins none: no test of it compares compressed bytes, and with nthreads > 1 its block
  * order depends on thread timing, blosc/blosc.c:1845-1860; single-threaded it is deterministic, :803-867):
  *   - header, blocksize, split decision, bstarts layout (blocks in block order): a function of the arguments alone, equal to stock's;
- *   - "blosclz", "lz4", and "zstd" up to clevel 5 (one match finder, one probe per position): the same input and arguments give the
+ *   - "blosclz", "lz4", and "zstd" up to clevel 5 (one match finder, one table probe per probed position - "lz4" at clevel <= 5 probes every
+ *     other position, the way the reference's acceleration 10 - clevel skips positions, blosc/blosc.c:577-587): the same input and arguments give the
  *     same chunk, call after call, from any number of threads (tests/test_gpu_threads.py compares the bytes) - but NOT the reference's
  *     bytes: a different, wave-parallel match finder;
  *   - "lz4hc", "zlib" at every clevel and "zstd" from clevel 6: the deeper search inserts into hash buckets from several lanes at
