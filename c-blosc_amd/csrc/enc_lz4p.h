@@ -196,7 +196,8 @@ __device__ uint32_t lz4_encode_wave_par(const gu8* __restrict__ src, uint32_t n,
       if (cand >= 4u) { const uint32_t x = cpre ^ ownpre; nb = x ? (uint32_t)__builtin_clz(x) >> 3 : 4u; }
       len = common20(own, cb);
       if (len > limit) len = limit;
-      if (len + (SS && nb ? 1u : 0u) < minlen) len = 0;           // (SS = 1: a match found one byte late counts the byte the backward extension brings back)
+      if (len < 4u || len + (SS && nb ? 1u : 0u) < minlen) len = 0;      // (SS = 1: a match found one byte late counts the byte the backward extension brings back - but the four
+                                                                           //  bytes LZ4 asks for, lz4.c:240 MINMATCH, must be there without it: the extension may have no room)
     }
     if (live && prev < 0x100u) {                    // distance 1: run of the previous byte
       uint32_t rl = runlen20(own, prev);
@@ -204,7 +205,7 @@ __device__ uint32_t lz4_encode_wave_par(const gu8* __restrict__ src, uint32_t n,
       // (the bytes in front: src[p-1-i] against src[p-2-i], i.e. how far the run reaches back - three comparisons inside ownpre)
       const uint32_t xr = (ownpre ^ (ownpre << 8)) | 0xffu;
       const uint32_t nbr = p >= 5u ? (uint32_t)__builtin_clz(xr) >> 3 : 0u;
-      if (rl + (SS && nbr ? 1u : 0u) >= minlen && rl > len) { len = rl; cand = p - 1u; nb = nbr; }
+      if (rl >= 4u && rl + (SS && nbr ? 1u : 0u) >= minlen && rl > len) { len = rl; cand = p - 1u; nb = nbr; }
     }
     win.settle(lane);
     PROF_LAP(9);
