@@ -12,14 +12,17 @@
 //     row totals) tells every position "who wins if the search starts here" - the selection rule of lz_encode_wave, for all start positions at once;
 //   * "start -> end of the winner's match" is a next-pointer per lane; the chain from the step's first free position is resolved by pointer
 //     doubling in rank space (7 ds_bpermute, the same trick as the decoder's token chain, dec_ring.h): rank lane r holds the r-th sequence;
-//   * backward extensions come out of the four bytes fetched in front of every candidate (never more than four here: see below), sizes are
-//     prefix-summed over the rank lanes (one DPP row scan), and ALL sequences of the step leave together: one byte store for every literal of
-//     the step, one for the tokens, one 2-byte store for the offsets;
+//   * backward extensions come out of the four bytes fetched in front of every candidate (the sequences whose four all match look at eight more, one
+//     round trip for all of them: BAMD_ENC_BACK2), sizes are prefix-summed over the rank lanes (one DPP row scan), and ALL sequences of the step leave
+//     together: one byte store for every literal position of the step, one for the tokens, one 2-byte store for the offsets;
 //   * only a match that fills all RANK_CAP compared bytes needs memory (its forward extension): the chain stops behind it and picks up again at
 //     its true end - one extra round trip for that sequence, as before.
 // The parse is the old one's (same ranking, same table insertions) with two simplifications that cost a fraction of a per cent of ratio:
-// backward extension stops at four bytes (the old loop fetched more from memory when all four matched: 5 % of bench19's sequences), and a search
-// never STARTS at the step's last position (lane 63 is the chain's absorbing stop).
+// backward extension stops at twelve bytes (the old loop went on byte by byte), and a search never STARTS at the step's last probing lane (lane 63 is
+// the chain's absorbing stop).  Both loops of the step begin by making the lane number opaque to the compiler (BAMD_ENC_LAUNDER): hoisted out of them, the
+// two dozen values it derives from the lane number filled the registers and the step's window or a per-lane address lived in scratch memory.
+// What round 6 measured and did not keep is listed where it would have gone (extension under the emission, window ahead of a jump) and in HISTORY.md
+// (the lanes' own look beyond RANK_CAP bytes, an LDS-staged output).
 #ifndef BAMD_ENC_PAR
 #define BAMD_ENC_PAR 1
 #endif
@@ -35,10 +38,10 @@ static_assert(ENC_LZ_LDS_WAVES == (160 * 1024) / (ENC_TAB_BYTES + ENC_SCR_BYTES)
 #define BAMD_ENC_KEEPJ 0     // the doubled next-pointers made once per step (three registers across the chain loop) instead of once per chain
 #endif
 #ifndef BAMD_ENC_EXT2
-#define BAMD_ENC_EXT2 1      // long comparisons two rows per trip (wave_common_fwd, enc_lz.h) - affordable at 96 registers; 0: one row per trip (wave_common_fwd_lite)
+#define BAMD_ENC_EXT2 1      // long comparisons two rows per trip (wave_common_fwd, enc_lz.h) - 0: one row per trip (wave_common_fwd_lite)
 #endif
 #ifndef BAMD_ENC_LAUNDER
-#define BAMD_ENC_LAUNDER 1
+#define BAMD_ENC_LAUNDER 1   // the lane number opaque at the top of the step and of the chain loop (0: the compiler hoists what it derives from it, and spills)
 #endif
 #ifndef BAMD_ENC_PREFULL
 #define BAMD_ENC_PREFULL 1   // a step that begins with pending literals (behind skipped, match-less steps) extends its first match backwards into them, up to 64 bytes
