@@ -214,7 +214,10 @@ __device__ uint32_t lz4_encode_wave_par(const gu8* __restrict__ src, uint32_t n,
     PROF_LAP(9);
     // ---- the parse of the whole step ----
     const uint32_t step_end = ip + SPAN;
-    const uint32_t cn = cand | (nb << 28);                       // (positions are below 2^28: a stream is a split of a block, <= 2 MiB)
+    // what the rank lanes fetch from a winner: the DISTANCE to its candidate (1 .. 65535: the table holds 16-bit positions) | equal bytes in front << 28.  (The
+    // candidate's position itself travelled here until a stream of 266 MiB - forced blocksize, BLOSC_SPLITMODE=NEVER - came out unreadable: positions beyond 2^28 ran
+    // into the count's bits.  scripts/dbg_big_stream.py, tests/test_gpu_compress.py::test_one_lz4_stream_beyond_256_mib.)
+    const uint32_t cn = (p - cand) | (nb << 28);
     // S[l] = the best key among the lanes at or above l: who wins when the search starts at l
     uint32_t S = len ? (((len + (SS && nb ? 1u : 0u) + SPAN - lq) << 11) | ((63u - (uint32_t)lane) << 5) | len) : 0u;
     S = umax32(S, dpp_row_shl0<1>(S)); S = umax32(S, dpp_row_shl0<2>(S)); S = umax32(S, dpp_row_shl0<4>(S)); S = umax32(S, dpp_row_shl0<8>(S));
@@ -267,7 +270,8 @@ __device__ uint32_t lz4_encode_wave_par(const gu8* __restrict__ src, uint32_t n,
       const uint32_t w = 63u - ((Sr >> 5) & 63u), L = Sr & 31u;                    // winner lane and its ranked length
       const uint32_t wq = w << SS;                                                  // the winner's position
       const uint32_t cnr = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(w << 2), (int)cn);
-      const uint32_t cand_r = cnr & 0x0fffffffu, nb_r = cnr >> 28;
+      const uint32_t dist_r = cnr & 0xffffu, nb_r = cnr >> 28;
+      const uint32_t cand_r = ip + wq - dist_r;                                     // the candidate's position
       // cq: the POSITION the r-th search starts at = the end of the match in front of it (every match of the chain but the last has its exact length)
       uint32_t cq = c;
       if (SS) { const uint32_t e_prev = dpp_row_shr0<1>(wq + L); cq = lane == 0 ? lane_lo : e_prev; }
@@ -372,7 +376,7 @@ __device__ uint32_t lz4_encode_wave_par(const gu8* __restrict__ src, uint32_t n,
         if (valid && hdr == 2u) ENC_ST1(dst + tpos + 1u, (uint8_t)(ll - 15u));
         const uint32_t opos = tpos + hdr + inl;
 #ifndef BAMD_ENC_NOSTORE
-        if (valid) g_st2(dst + opos, ip + wq - cand_r);
+        if (valid) g_st2(dst + opos, dist_r);
 #endif
         if (valid && nme) ENC_ST1(dst + opos + 2u, (uint8_t)(mcode - 15u < 255u ? mcode - 15u : 255u));
         if (extra_last) {                                                           // uniform: the 255-run of a long match (lz4.c:1213-1226)

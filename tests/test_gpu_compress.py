@@ -1,6 +1,8 @@
 """GPU compress path: chunks are valid c-blosc chunks — the oracle (pinned to the reference) and,
 when present, the real reference decode them bit-exactly; headers equal the reference's for the
 same parameters; return codes follow tests/test_maxout.c and tests/test_compressor.c."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -128,3 +130,44 @@ def test_global_api_and_env(pkg, lib, oracle, monkeypatch):
     assert lib.blosc_decompress(ptr(out), ptr(back), back.size) == data.size and np.array_equal(back, data)
     lib.blosc_set_compressor(b"blosclz")
     lib.blosc_destroy()
+
+
+def test_one_lz4_stream_beyond_256_mib(pkg, lib, ref, monkeypatch):
+    """ONE stream of 266 MiB: a forced blocksize as large as the chunk and BLOSC_SPLITMODE=NEVER make the whole chunk a single LZ4 stream (with the
+    default split the reference caps a block at 1 MiB, blosc/blosc.c:1031-1047).  Round 6's parallel LZ4 writer carried a candidate's POSITION
+    next to a 4-bit count in one word - fine below 2^28, silently wrong above: the chunk came out with the right size and return value and could
+    not be read back (scripts/dbg_big_stream.py).  Matches of the stream's last megabytes must decode, here and in the reference."""
+    if ref is None:
+        pytest.skip("needs the reference (oracle/_ref) as reader")
+    rng = np.random.default_rng(1)
+    head = rng.integers(0, 256, 258 << 20, dtype=np.uint8)                           # match-less: crossed in long strides
+    tail = np.ascontiguousarray(DATASETS["bench19"](8 << 20).reshape(-1, 8).T).reshape(-1)      # planes of the bench data as one byte stream: matches a few KiB back
+    data = np.concatenate([head, tail])
+    n = data.size
+    out = np.zeros(n + 16, np.uint8)
+    monkeypatch.setenv("BLOSC_SPLITMODE", "NEVER")
+    lib.blosc_init()
+    try:
+        assert lib.blosc_set_compressor(b"lz4") == 1
+        lib.blosc_set_blocksize(n)
+        for clevel in (5, 9):                                                        # (both strides of the parallel parse)
+            cb = lib.blosc_compress(clevel, 0, 8, n, ptr(data), ptr(out), n + 16)
+            assert 0 < cb < n - (4 << 20), cb                                        # the tail did compress
+            assert int(out[8:12].view("<i4")[0]) == n and (out[2] & 0x10)            # one block, not split
+            r, back = ref_decompress(ref, out[:cb], n)
+            assert r == n and np.array_equal(back, data), ("the reference cannot read the chunk", clevel)
+            mine = np.zeros(n, np.uint8)
+            assert lib.blosc_decompress(ptr(out), ptr(mine), n) == n and np.array_equal(mine, data)
+        # ... and the other direction: the reference's own single stream of that size, decoded here
+        ref.blosc_init()
+        ref.blosc_set_compressor(b"lz4"); ref.blosc_set_blocksize(n)
+        ref.blosc_compress.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
+        cb = ref.blosc_compress(5, 0, 8, n, ptr(data), ptr(out), n + 16)
+        ref.blosc_set_blocksize(0); ref.blosc_destroy()
+        assert 0 < cb < n and int(out[8:12].view("<i4")[0]) == n and (out[2] & 0x10)
+        mine = np.zeros(n, np.uint8)
+        assert lib.blosc_decompress(ptr(out), ptr(mine), n) == n and np.array_equal(mine, data), "a reference-written stream of 266 MiB"
+    finally:
+        lib.blosc_set_blocksize(0)
+        lib.blosc_set_compressor(b"blosclz")
+        lib.blosc_destroy()
