@@ -21,6 +21,9 @@ constexpr int ENC_TAB_BYTES = BAMD_ENC_SPLIT_TAB ? ENC_TAB * 3 : ENC_TAB * 4;
 #ifndef BAMD_ENC_MINWAVES
 #define BAMD_ENC_MINWAVES (BAMD_ENC_SPLIT_TAB ? 6 : 5)   // waves per SIMD the register allocator leaves room for (5: + 3 %, 7 = 26 waves per CU at 72 registers: + 1.8 %, profiles/r04/r04zu_*)
 #endif
+#ifndef BAMD_ENC_SEQ_SKIPCAP
+#define BAMD_ENC_SEQ_SKIPCAP 32u    // the longest step of the sequential finder through match-less data, in 64-byte units (see BAMD_ENC_SKIPCAP in enc_lz4p.h)
+#endif
 #ifndef BAMD_ENC_LZ_MINWAVES
 #define BAMD_ENC_LZ_MINWAVES 6   // the LZ4 / BloscLZ kernel.  Round 6: the two-positions-per-lane step of enc_lz4p.h first needed 96 registers (5) - at 80 its input window lived in
                                  // scratch memory and every step reloaded it behind the stores of the step before (profiles/r06c_*: 8.6 ms at 24 waves per CU, 7.5 at 20).  What
@@ -650,7 +653,7 @@ __device__ uint32_t lz_encode_wave(const gu8* __restrict__ src, uint32_t n, gu8*
       if (live) tab.put(h, mine);
       nfail++;
       uint32_t adv = 1u + (nfail * (uint32_t)accel) / 16u;   // skip faster through incompressible data
-      if (adv > 16u) adv = 16u;
+      if (adv > BAMD_ENC_SEQ_SKIPCAP) adv = BAMD_ENC_SEQ_SKIPCAP;
       ip += 64u * adv;
       continue;
     }

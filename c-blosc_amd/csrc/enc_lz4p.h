@@ -31,6 +31,11 @@ static_assert(ENC_LZ_LDS_WAVES == (160 * 1024) / (ENC_TAB_BYTES + ENC_SCR_BYTES)
 #ifndef BAMD_ENC_BACK2
 #define BAMD_ENC_BACK2 1     // sequences whose four bytes in front all match look at eight more (one more memory round trip for the steps that hold such a sequence)
 #endif
+#ifndef BAMD_ENC_SKIPCAP
+#define BAMD_ENC_SKIPCAP 32u    // the longest distance between the starts of two failed steps, in 64-byte units.  16 until late in round 6; 32 / 64 (profiles/r06zm_*): random bytes
+                                // - 11 / - 16 %, random-walk planes - 5 / - 9 %, everything else 0 / - 1 %, no ratio of the test data changes by more than 1.5 %; but noise with islands
+                                // of 0.5 - 2 KiB of repeated content (1.03 here at 16, 1.13 in the reference: a step enters only what it probes) keeps its 1.01 - 1.08 at 32 and loses all of it at 64
+#endif
 #ifndef BAMD_ENC_NEIGHBOUR
 #define BAMD_ENC_NEIGHBOUR 4u   // a power of two, or 0: never
 #endif
@@ -420,7 +425,7 @@ __device__ uint32_t lz4_encode_wave_par(const gu8* __restrict__ src, uint32_t n,
       if (live1) PAR_PUT1();
       nfail += 1u << SS;                                     // (counted in 64-position units: the skip grows with the bytes that failed, whatever the stride)
       uint32_t adv = (nfail * (uint32_t)accel) / 16u;        // skip faster through incompressible data
-      if (adv > 16u - (1u << SS)) adv = 16u - (1u << SS);   // (a step never starts more than 1 KiB behind the one before, as in lz_encode_wave)
+      if (adv > BAMD_ENC_SKIPCAP - (1u << SS)) adv = BAMD_ENC_SKIPCAP - (1u << SS);   // (a step never starts more than 2 KiB behind the one before, as in lz_encode_wave)
       // Every fourth failed step is followed by its NEIGHBOUR.  A step finds only what earlier steps put into the table; once the skip is as long as
       // the data's runs (linspace at typesize 2: runs of 1 KiB with a period of 16 bytes, each run with new content) every step lands in a run no
       // earlier step has seen, fails, and keeps the skip long - the reference, which spreads its probes evenly (lz4.c:1044-1053), gets out at once,

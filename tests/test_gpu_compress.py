@@ -171,3 +171,42 @@ def test_one_lz4_stream_beyond_256_mib(pkg, lib, ref, monkeypatch):
         lib.blosc_set_blocksize(0)
         lib.blosc_set_compressor(b"blosclz")
         lib.blosc_destroy()
+
+
+@pytest.mark.parametrize("cname,shuffle", [(b"blosclz", 1), (b"lz4", 2), (b"lz4hc", 1), (b"zstd", 1), (b"zlib", 2)])
+def test_one_stream_beyond_256_mib_of_the_other_writers(pkg, lib, ref, monkeypatch, cname, shuffle):
+    """The same question as above put to the other writers, the decoders and the fused filters: a block of 266 MiB, not split, under a byte or bit
+    shuffle - eight planes of 33 MiB as ONE stream whose last plane lies beyond 2^27 * 1.75, every plane with its matches.  Written here and read
+    by the reference, written by the reference and read here (scripts/dbg_big_stream_all.py is the full grid: 5 codecs x 3 filters x 3 pairings,
+    profiles/r06zl_*)."""
+    if ref is None:
+        pytest.skip("needs the reference (oracle/_ref) as writer and reader")
+    n = 266 << 20
+    data = DATASETS["bench19"](n)
+    out = np.zeros(n + 16, np.uint8)
+    clevel = 5 if cname in (b"blosclz", b"lz4") else 1
+    monkeypatch.setenv("BLOSC_SPLITMODE", "NEVER")
+    for L in (lib, ref):
+        L.blosc_compress.argtypes = [C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.blosc_set_blocksize.argtypes = [C.c_size_t]
+    lib.blosc_init()
+    try:
+        assert lib.blosc_set_compressor(cname) >= 0
+        lib.blosc_set_blocksize(n)
+        cb = lib.blosc_compress(clevel, shuffle, 8, n, ptr(data), ptr(out), n + 16)
+        lib.blosc_set_blocksize(0)
+        assert 0 < cb < n // 8, cb
+        assert int(out[8:12].view("<i4")[0]) == n and (out[2] & 0x10)                # one block, not split
+        r, back = ref_decompress(ref, out[:cb], n)
+        assert r == n and np.array_equal(back, data), ("the reference cannot read the chunk", cname)
+        ref.blosc_init()
+        ref.blosc_set_compressor(cname); ref.blosc_set_blocksize(n)
+        cb = ref.blosc_compress(clevel, shuffle, 8, n, ptr(data), ptr(out), n + 16)
+        ref.blosc_set_blocksize(0); ref.blosc_destroy()
+        assert 0 < cb < n // 8 and int(out[8:12].view("<i4")[0]) == n and (out[2] & 0x10)
+        mine = np.zeros(n, np.uint8)
+        assert lib.blosc_decompress(ptr(out), ptr(mine), n) == n and np.array_equal(mine, data), ("a reference-written stream of 266 MiB", cname)
+    finally:
+        lib.blosc_set_blocksize(0)
+        lib.blosc_set_compressor(b"blosclz")
+        lib.blosc_destroy()
