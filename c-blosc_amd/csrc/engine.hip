@@ -130,6 +130,18 @@ struct EngineState {
   // or BLOSC_AMD_SINGLE_QUEUE=1) - one queue, shuffle / unshuffle in kernels of their own.
   bool single_queue = false;
   int cus = 0;          // compute units of the selected device (persistent grids)
+  // Tables that are a function of a batch's GEOMETRY alone - the block table and the task queues (0.5 MB for 128 chunks of 64 MiB) - stay on the
+  // device from one call to the next (round 6).  A call that finds its own block table, fusion flags and plane order equal to the ones the tables
+  // were made from neither builds the queues nor uploads anything but its chunk descriptors: callers send equal-shaped chunks call after call
+  // (bench/bench.c:383 does), and the host side of a call is time the device stands idle.  Buffers of their own: the call arena is overwritten by whatever call comes next.
+  struct TableCache {
+    std::vector<BlockDesc> blocks; std::vector<uint32_t> modes; std::vector<int> order; int nq = 0;
+    DeviceArena tabs; size_t o_queues = 0, o_zqueues = 0, sh_at = 0; int32_t ntasks = 0; bool valid = false;
+    bool same(const std::vector<BlockDesc>& b, const std::vector<uint32_t>& m, const std::vector<int>& o, int q) const {
+      return valid && nq == q && blocks.size() == b.size() && modes == m && order == o && (b.empty() || memcmp(blocks.data(), b.data(), b.size() * sizeof(BlockDesc)) == 0);
+    }
+    void drop() { valid = false; tabs.release(); }
+  } enc_tabs, dec_tabs;
   hipStream_t own = nullptr;   // host-buffer calls that name no stream run here (non-blocking: see the contexts below)
 };
 
@@ -249,7 +261,7 @@ static int ensure_device(EngineState& st) {
   if (st.device_ok && want_dev == st.device) { HIP_TRY(hipSetDevice(st.device)); return 0; }
   if (st.device_ok) {                      // the process moved to another device (engine_set_device through another context)
     (void)hipSetDevice(st.device);
-    st.dev.release(); st.io.release();     // arenas, stream and events belong to the device they were created on
+    st.dev.release(); st.io.release(); st.enc_tabs.drop(); st.dec_tabs.drop();     // arenas, stream and events belong to the device they were created on
     if (st.own) { (void)hipStreamDestroy(st.own); st.own = nullptr; }
     for (auto& p : st.prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     st.prof_pending.clear();
@@ -373,6 +385,24 @@ static bool bitunshuffle_fused_host(int T) { return T == 1 || T == 2 || T == 4 |
 static bool fuse_enabled() { static const bool on = !(getenv("BLOSC_AMD_FUSE") && atoi(getenv("BLOSC_AMD_FUSE")) == 0); return on; }
 
 // the stream a call runs on: the caller's, or - host buffers and no stream named - the context's own
+// What the queue builders make of the cost feedback for the stream counts of this batch's blocks: the part of a queue's identity that is not in the block table
+static bool table_cache_enabled() { static const bool on = !(getenv("BLOSC_AMD_TABLE_CACHE") && atoi(getenv("BLOSC_AMD_TABLE_CACHE")) == 0); return on; }
+static void order_signature(const std::vector<BlockDesc>& blocks, const uint32_t* cost, bool valid, std::vector<int>& sig) {
+  bool seen[257] = {false};
+  for (const BlockDesc& b : blocks) seen[b.nstreams < 0 ? 0 : (b.nstreams > 256 ? 256 : b.nstreams)] = true;
+  sig.clear();
+  std::vector<int> order; int nheavy = 0;
+  for (int T = 2; T <= 256; T++) {
+    if (!seen[T]) continue;
+    plane_order(cost, valid && sched_enabled(), T, order, &nheavy);
+    // WHICH planes are the expensive ones, not their order: the cheap planes of the benchmark data cost within a few percent of each other and
+    // change places from call to call (with the exact order as signature no second call ever found its tables: profiles/r06zo_*); any order of
+    // a queue is a correct one, and the one thing the order is there for - the expensive planes first - is what the set says
+    std::sort(order.begin(), order.begin() + (nheavy < T ? nheavy : T));
+    sig.push_back(T); sig.push_back(nheavy); sig.insert(sig.end(), order.begin(), order.begin() + (nheavy < T ? nheavy : 0));
+  }
+}
+
 static int call_stream(EngineState& st, bool host_buffers, hipStream_t* stream) {
   if (!host_buffers || *stream != (hipStream_t)0 || ctx_count() == 1) return 0;
   if (!st.own) HIP_TRY(hipStreamCreateWithFlags(&st.own, hipStreamNonBlocking));
@@ -467,13 +497,28 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   // ---- device workspace ----
   Carver cv;
   const size_t o_chunks = cv.take(sizeof(ChunkDesc) * (size_t)n);
-  const size_t o_blocks = cv.take(sizeof(BlockDesc) * (nblk ? nblk : 1));
   const size_t o_streams = cv.take(sizeof(StreamDesc) * (nstr ? nstr : 1));
   const size_t o_blkoff = cv.take(sizeof(int32_t) * (nblk ? nblk : 1));
   const size_t o_results = cv.take(sizeof(int32_t) * (size_t)n + 96);   // + the 8 ticket counters of the encode queues + the 8 of the shuffle lists
-  std::vector<int32_t> queues; size_t sh_at = 0;
-  build_encode_queues(blocks, chunks, st.enc_cost, st.enc_cost_valid, queues, st.single_queue ? 1 : 8, &sh_at);
-  const size_t o_queues = cv.take(sizeof(int32_t) * queues.size());
+  // the block table and the queues: still on the device from the last call of this geometry, or built and uploaded now (EngineState::TableCache)
+  EngineState::TableCache& tc = st.enc_tabs;
+  const int nq = st.single_queue ? 1 : 8;
+  std::vector<uint32_t> tmodes((size_t)n);
+  for (int i = 0; i < n; i++) tmodes[(size_t)i] = chunks[(size_t)i].mode & CH_FUSED_SHUF;
+  std::vector<int> tsig;
+  order_signature(blocks, st.enc_cost, st.enc_cost_valid, tsig);
+  const bool tabs_hit = table_cache_enabled() && tc.same(blocks, tmodes, tsig, nq);
+  if (debug_cost_enabled()) fprintf(stderr, "[blosc_amd] compress: block table and queues %s\n", tabs_hit ? "still on the device" : "built and uploaded");
+  std::vector<int32_t> queues; size_t sh_at = tc.sh_at;
+  Carver tcv;
+  const size_t t_blocks = tcv.take(sizeof(BlockDesc) * (nblk ? nblk : 1));
+  if (!tabs_hit) {
+    tc.valid = false;
+    build_encode_queues(blocks, chunks, st.enc_cost, st.enc_cost_valid, queues, nq, &sh_at);
+    tc.o_queues = tcv.take(sizeof(int32_t) * queues.size());
+    if (tc.tabs.ensure(tcv.off)) return -1;
+    tc.sh_at = sh_at; tc.ntasks = queues[8];
+  }
   const size_t o_ready = cv.take(sizeof(uint32_t) * (nblk ? nblk : 1));
   const size_t o_cost = cv.take(sizeof(uint32_t) * kCostWords);
   const size_t o_filt = cv.take(filt_bytes + 256);
@@ -535,25 +580,28 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   // ---- upload tables ----
   Carver pc;
   const size_t p_chunks = pc.take(sizeof(ChunkDesc) * (size_t)n);
-  const size_t p_blocks = pc.take(sizeof(BlockDesc) * (nblk ? nblk : 1));
+  const size_t p_blocks = pc.take(tabs_hit ? 0 : sizeof(BlockDesc) * (nblk ? nblk : 1));
   const size_t p_results = pc.take(sizeof(int32_t) * (size_t)n);
   const size_t p_queues = pc.take(sizeof(int32_t) * queues.size());
   const size_t p_cost = pc.take(sizeof(uint32_t) * kCostWords);
   if (st.pin.ensure(pc.off)) return -1;
   uint8_t* P = st.pin.base;
+  uint8_t* TB = tc.tabs.base;
   memcpy(P + p_chunks, chunks.data(), sizeof(ChunkDesc) * (size_t)n);
-  if (nblk) memcpy(P + p_blocks, blocks.data(), sizeof(BlockDesc) * nblk);
-  memcpy(P + p_queues, queues.data(), sizeof(int32_t) * queues.size());
-  HIP_TRY(hipMemcpyAsync(D + o_queues, P + p_queues, sizeof(int32_t) * queues.size(), hipMemcpyHostToDevice, stream));
+  if (!tabs_hit) {
+    if (nblk) memcpy(P + p_blocks, blocks.data(), sizeof(BlockDesc) * nblk);
+    memcpy(P + p_queues, queues.data(), sizeof(int32_t) * queues.size());
+    HIP_TRY(hipMemcpyAsync(TB + tc.o_queues, P + p_queues, sizeof(int32_t) * queues.size(), hipMemcpyHostToDevice, stream));
+    if (nblk) HIP_TRY(hipMemcpyAsync(TB + t_blocks, P + p_blocks, sizeof(BlockDesc) * nblk, hipMemcpyHostToDevice, stream));
+  }
   HIP_TRY(hipMemsetAsync(D + o_ready, 0, sizeof(uint32_t) * (nblk ? nblk : 1), stream));
   HIP_TRY(hipMemsetAsync(D + o_cost, 0, sizeof(uint32_t) * kCostWords, stream));
   HIP_TRY(hipMemcpyAsync(D + o_chunks, P + p_chunks, sizeof(ChunkDesc) * (size_t)n, hipMemcpyHostToDevice, stream));
-  if (nblk) HIP_TRY(hipMemcpyAsync(D + o_blocks, P + p_blocks, sizeof(BlockDesc) * nblk, hipMemcpyHostToDevice, stream));
   HIP_TRY(hipMemsetAsync(D + o_results, 0, sizeof(int32_t) * (size_t)n + 96, stream));
   uint32_t* d_ticket = (uint32_t*)(D + o_results + sizeof(int32_t) * (size_t)n + 32);
 
   ChunkDesc* d_chunks = (ChunkDesc*)(D + o_chunks);
-  BlockDesc* d_blocks = (BlockDesc*)(D + o_blocks);
+  BlockDesc* d_blocks = (BlockDesc*)(TB + t_blocks);
   StreamDesc* d_streams = (StreamDesc*)(D + o_streams);
   int32_t* d_blkoff = (int32_t*)(D + o_blkoff);
   int32_t* d_results = (int32_t*)(D + o_results);
@@ -573,9 +621,9 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   }
   if (nstr) {
     ProfScope ps(st, stream, zstd ? "k_zstd_encode" : (zlibc ? "k_zlib_encode" : (hc ? "k_lz4hc_encode" : "k_encode_streams")));
-    const int32_t* d_qoff = (const int32_t*)(D + o_queues); const int32_t* d_qlist = d_qoff + 9;
+    const int32_t* d_qoff = (const int32_t*)(TB + tc.o_queues); const int32_t* d_qlist = d_qoff + 9;
     uint32_t* d_ready = (uint32_t*)(D + o_ready);
-    const size_t ntasks = (size_t)queues[8];
+    const size_t ntasks = (size_t)tc.ntasks;
     const int32_t* d_shoff = d_qoff + sh_at;
     uint64_t* d_seqbufs = (zstd || zdyn) ? (uint64_t*)(D + o_seqbufs) : nullptr;
     const zenc::CTabs* d_ctabs = zstd ? (const zenc::CTabs*)(D + o_ctabs) : nullptr;
@@ -623,7 +671,8 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
   HIP_TRY(hipStreamSynchronize(stream));
   HT_MARK(0, 4);     // waiting for the device
   prof_collect(st);
-  if (nstr && check_done((const uint32_t*)(P + p_cost), (size_t)queues[8], 0, "compress")) return -1;
+  if (nstr && check_done((const uint32_t*)(P + p_cost), (size_t)tc.ntasks, 0, "compress")) return -1;
+  if (!tabs_hit) { tc.blocks.swap(blocks); tc.modes.swap(tmodes); tc.order.swap(tsig); tc.nq = nq; tc.valid = true; }      // (only now: the uploads are known to have arrived)
   if (nstr >= 4096) { memcpy(st.enc_cost, P + p_cost, sizeof st.enc_cost); st.enc_cost_valid = true; }   // small calls say little
   const int32_t* r = (const int32_t*)(P + p_results);
   for (int i = 0; i < n; i++) if (live[(size_t)i]) results[i] = r[i];
@@ -898,11 +947,8 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   const size_t nblk = blocks.size();
   Carver cv;
   const size_t o_chunks = cv.take(sizeof(ChunkDesc) * (size_t)n);
-  const size_t o_blocks = cv.take(sizeof(BlockDesc) * (nblk ? nblk : 1));
   const size_t o_streams = cv.take(sizeof(StreamDesc) * (nstr ? nstr : 1));
   const size_t o_status = cv.take(sizeof(int32_t) * (size_t)n + 64 + sizeof(uint32_t) * (nblk ? nblk : 1));   // + 8 tickets + per-block arrival counters
-  const size_t o_queues = cv.take(sizeof(int32_t) * (9 + (nstr ? nstr : 1)));
-  const size_t o_zqueues = cv.take(sizeof(int32_t) * (9 + (nstr ? nstr : 1)));      // k_zlib_streams' queues
   const size_t o_cost = cv.take(sizeof(uint32_t) * kCostWords);
   const size_t o_spans = cv.take(8 * (nstr ? nstr : 1));
   const size_t o_pat = cv.take(span_enabled() ? (size_t)2048 * (nstr ? nstr : 1) : 256);
@@ -936,13 +982,29 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
       if (c.fmt == FMT_ZSTD && !(c.mode & CH_MEMCPYED)) { zo = align_up(zo, 256); c.stage = D + o_zlit + zo; zo += (size_t)c.nbytes; }
     }
   }
-  std::vector<int32_t> queues;
-  build_xcd_queues(blocks, nstr, st.dec_cost, st.dec_cost_valid, queues, st.single_queue ? 1 : 8);
-  std::vector<int32_t> zqueues;
-  if (L.any_zlib) build_xcd_queues(blocks, nstr, nullptr, false, zqueues, st.single_queue ? 1 : 8, BLK_ZLIB);
+  // the block table and the queues: still on the device from the last call of this geometry, or built and uploaded now (EngineState::TableCache)
+  EngineState::TableCache& tc = st.dec_tabs;
+  const int nq = st.single_queue ? 1 : 8;
+  std::vector<uint32_t> tmodes;                      // (the decode queues are made of the block table and the plane order alone)
+  std::vector<int> tsig;
+  order_signature(blocks, st.dec_cost, st.dec_cost_valid, tsig);
+  const bool tabs_hit = table_cache_enabled() && tc.same(blocks, tmodes, tsig, nq);
+  if (debug_cost_enabled()) fprintf(stderr, "[blosc_amd] decompress: block table and queues %s\n", tabs_hit ? "still on the device" : "built and uploaded");
+  std::vector<int32_t> queues, zqueues;
+  Carver tcv;
+  const size_t t_blocks = tcv.take(sizeof(BlockDesc) * (nblk ? nblk : 1));
+  if (!tabs_hit) {
+    tc.valid = false;
+    build_xcd_queues(blocks, nstr, st.dec_cost, st.dec_cost_valid, queues, nq);
+    if (L.any_zlib) build_xcd_queues(blocks, nstr, nullptr, false, zqueues, nq, BLK_ZLIB);
+    tc.o_queues = tcv.take(sizeof(int32_t) * (9 + (nstr ? nstr : 1)));
+    tc.o_zqueues = tcv.take(sizeof(int32_t) * (9 + (nstr ? nstr : 1)));      // k_zlib_streams' queues
+    if (tc.tabs.ensure(tcv.off)) return -1;
+  }
+  uint8_t* TB = tc.tabs.base;
   Carver pc;
   const size_t p_chunks = pc.take(sizeof(ChunkDesc) * (size_t)n);
-  const size_t p_blocks = pc.take(sizeof(BlockDesc) * (nblk ? nblk : 1));
+  const size_t p_blocks = pc.take(tabs_hit ? 0 : sizeof(BlockDesc) * (nblk ? nblk : 1));
   const size_t p_status = pc.take(sizeof(int32_t) * (size_t)n);
   const size_t p_queues = pc.take(sizeof(int32_t) * queues.size());
   const size_t p_zqueues = pc.take(sizeof(int32_t) * (zqueues.size() + 1));
@@ -950,23 +1012,25 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   if (st.pin.ensure(pc.off)) return -1;
   uint8_t* P = st.pin.base;
   memcpy(P + p_chunks, chunks.data(), sizeof(ChunkDesc) * (size_t)n);
-  if (nblk) memcpy(P + p_blocks, blocks.data(), sizeof(BlockDesc) * nblk);
-  memcpy(P + p_queues, queues.data(), sizeof(int32_t) * queues.size());
   HIP_TRY(hipMemcpyAsync(D + o_chunks, P + p_chunks, sizeof(ChunkDesc) * (size_t)n, hipMemcpyHostToDevice, stream));
-  if (nblk) HIP_TRY(hipMemcpyAsync(D + o_blocks, P + p_blocks, sizeof(BlockDesc) * nblk, hipMemcpyHostToDevice, stream));
-  HIP_TRY(hipMemcpyAsync(D + o_queues, P + p_queues, sizeof(int32_t) * queues.size(), hipMemcpyHostToDevice, stream));
-  if (!zqueues.empty()) {
-    memcpy(P + p_zqueues, zqueues.data(), sizeof(int32_t) * zqueues.size());
-    HIP_TRY(hipMemcpyAsync(D + o_zqueues, P + p_zqueues, sizeof(int32_t) * zqueues.size(), hipMemcpyHostToDevice, stream));
+  if (!tabs_hit) {
+    if (nblk) memcpy(P + p_blocks, blocks.data(), sizeof(BlockDesc) * nblk);
+    memcpy(P + p_queues, queues.data(), sizeof(int32_t) * queues.size());
+    if (nblk) HIP_TRY(hipMemcpyAsync(TB + t_blocks, P + p_blocks, sizeof(BlockDesc) * nblk, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(TB + tc.o_queues, P + p_queues, sizeof(int32_t) * queues.size(), hipMemcpyHostToDevice, stream));
+    if (!zqueues.empty()) {
+      memcpy(P + p_zqueues, zqueues.data(), sizeof(int32_t) * zqueues.size());
+      HIP_TRY(hipMemcpyAsync(TB + tc.o_zqueues, P + p_zqueues, sizeof(int32_t) * zqueues.size(), hipMemcpyHostToDevice, stream));
+    }
   }
   HIP_TRY(hipMemsetAsync(D + o_status, 0, sizeof(int32_t) * (size_t)n + 64 + sizeof(uint32_t) * (nblk ? nblk : 1), stream));
 
-  L.d_chunks = (ChunkDesc*)(D + o_chunks); L.d_blocks = (BlockDesc*)(D + o_blocks);
+  L.d_chunks = (ChunkDesc*)(D + o_chunks); L.d_blocks = (BlockDesc*)(TB + t_blocks);
   L.d_streams = (StreamDesc*)(D + o_streams); L.d_status = (int32_t*)(D + o_status);
   L.d_ticket = (uint32_t*)(D + o_status + sizeof(int32_t) * (size_t)n + 32);
   L.d_blkdone = (uint32_t*)(D + o_status + sizeof(int32_t) * (size_t)n + 64);
-  L.d_qoff = (const int32_t*)(D + o_queues); L.d_qlist = L.d_qoff + 9;
-  L.d_zqoff = (const int32_t*)(D + o_zqueues); L.d_zqlist = L.d_zqoff + 9; L.nstr_zlib = nstr_zlib;
+  L.d_qoff = (const int32_t*)(TB + tc.o_queues); L.d_qlist = L.d_qoff + 9;
+  L.d_zqoff = (const int32_t*)(TB + tc.o_zqueues); L.d_zqlist = L.d_zqoff + 9; L.nstr_zlib = nstr_zlib;
   L.d_spans = span_enabled() ? (uint32_t*)(D + o_spans) : nullptr; L.d_pat = D + o_pat;
   L.d_cost = (uint32_t*)(D + o_cost);
   HIP_TRY(hipMemsetAsync(D + o_cost, 0, sizeof(uint32_t) * kCostWords, stream));
@@ -986,6 +1050,7 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   HT_MARK(1, 4);     // waiting for the device
   prof_collect(st);
   if (nblk && check_done((const uint32_t*)(P + p_cost), nstr - nstr_z, L.any_zstd ? nstr : 0, "decompress", nstr_zlib)) return -1;
+  if (!tabs_hit) { tc.blocks.swap(blocks); tc.modes.swap(tmodes); tc.order.swap(tsig); tc.nq = nq; tc.valid = true; }      // (only now: the uploads are known to have arrived)
   if (nstr >= 4096) { memcpy(st.dec_cost, P + p_cost, sizeof st.dec_cost); st.dec_cost_valid = true; }
   if (debug_cost_enabled()) {
     fprintf(stderr, "[blosc_amd] decode plane costs:");
@@ -1210,7 +1275,7 @@ void engine_release() {
     EngineState& st = g_ctx[i];
     std::lock_guard<std::mutex> lock(st.mu);
     if (!st.device_ok) continue;
-    st.dev.release(); st.io.release(); st.pin.release();
+    st.dev.release(); st.io.release(); st.pin.release(); st.enc_tabs.drop(); st.dec_tabs.drop();
     if (st.own) { (void)hipStreamDestroy(st.own); st.own = nullptr; }
   }
 }

@@ -518,3 +518,35 @@ def test_reference_bitshuffle_leftovers_and_compat_vectors(ref_programs, tmp_pat
         p = subprocess.run([os.path.join(bindir, "filegen"), "decompress", os.path.join(compat, f)], env=env, timeout=900,
                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         assert p.returncode == 0 and "Decompression successful!" in p.stdout, (f, p.stdout[-500:], p.stderr[-1500:])
+
+
+def test_tables_kept_on_the_device_serve_only_the_geometry_they_were_made_for(emulib, oracle, ref):
+    """Round 6: the block table and the task queues of a call stay on the device, and the next call takes them if ITS block table, fusion flags and
+    plane order are the same (engine.hip: EngineState::TableCache) - equal-shaped chunks call after call are the normal case.  Walk one context
+    through hits and misses in both directions: the same call twice, other content of the same shape, another typesize, filter, level and size in
+    between and back again; every chunk must read everywhere, every decode must return its own plaintext, and equal calls must write equal bytes."""
+    n = 3 * 65536 + 123
+    a, b = DATASETS["bench19"](n), DATASETS["linspace"](n)
+    calls = [(a, 8, 5, 1), (a, 8, 5, 1), (b, 8, 5, 1), (a, 4, 5, 1), (a, 8, 5, 1), (b, 8, 5, 0), (b, 8, 5, 1), (a, 8, 5, 2), (a, 8, 6, 1), (a, 8, 5, 1),
+             (a[:n - 8], 8, 5, 1), (a, 8, 5, 1), (b, 8, 5, 1), (b, 8, 1, 1), (b, 8, 5, 1)]
+    for cname in (b"lz4", b"blosclz"):
+        seen, chunks = {}, []
+        for data, T, clevel, shuffle in calls:
+            r, chunk = _compress(emulib, data, T, clevel, shuffle, cname)
+            assert 0 < r <= data.size + 16, (r, T, clevel, shuffle)
+            key = (data.ctypes.data, data.size, T, clevel, shuffle)
+            if key in seen:
+                assert np.array_equal(seen[key], chunk), ("the same call wrote other bytes", T, clevel, shuffle)
+            seen[key] = chunk
+            _everybody_reads(emulib, oracle, ref, chunk, data)
+            chunks.append((chunk, data))
+        # decode in an order of its own: equal geometries with other content back to back, other geometries in between
+        for k in (0, 2, 1, 3, 0, 5, 6, 7, 2, 10, 0, 13, 14, 4):
+            chunk, data = chunks[k]
+            r, out = _decompress(emulib, chunk, data.size)
+            assert r == data.size and np.array_equal(out, data), k
+        if ref is not None:            # ... and the reference's chunks of the same shapes through the same context
+            for data, T, clevel, shuffle in calls[:8]:
+                r, chunk = ref_compress(ref, data, T, clevel, shuffle, cname)
+                r2, out = _decompress(emulib, chunk[:r], data.size)
+                assert r2 == data.size and np.array_equal(out, data), (T, clevel, shuffle)

@@ -55,7 +55,7 @@ def test_zstd_decoder_modes(mode):
 # every other environment switch the library reads, one process each: mode_check.py with the entropy-coded formats switched in
 # (round trips of every codec under the switch; chunks written here are read by the oracle and by our own decoder)
 OTHERS = [{"BLOSC_AMD_PERIODIC": "0"}, {"BLOSC_AMD_CONTEXTS": "1"}, {"BLOSC_AMD_LZ4HC": "0"}, {"BLOSC_AMD_ZSTD_TABLES": "0"}, {"BLOSC_AMD_ZSTD_SEARCH": "1"},
-          {"BLOSC_AMD_ZSTD_HUFFMAN": "1", "BLOSC_AMD_ZSTD_TABLES": "1"}, {"BLOSC_AMD_ZLIB_DYNAMIC": "0"}, {"BLOSC_AMD_ZLIB_SEARCH": "0"},
+          {"BLOSC_AMD_ZSTD_HUFFMAN": "1", "BLOSC_AMD_ZSTD_TABLES": "1"}, {"BLOSC_AMD_ZLIB_DYNAMIC": "0"}, {"BLOSC_AMD_ZLIB_SEARCH": "0"}, {"BLOSC_AMD_TABLE_CACHE": "0"},
           {"BLOSC_AMD_DEBUG": "1", "BLOSC_AMD_HOSTTIME": "1"}, {"BLOSC_AMD_DEBUG_COST": "1", "BLOSC_AMD_ARENA_SKEW_KIB": "36"}, {"BLOSC_AMD_FUSE": "0", "BLOSC_AMD_SINGLE_QUEUE": "1", "BLOSC_AMD_PERIODIC": "0"}]
 
 
