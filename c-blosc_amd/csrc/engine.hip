@@ -594,10 +594,9 @@ int engine_compress_batch(const CompressParams& p, int n, const Job* jobs, int* 
     HIP_TRY(hipMemcpyAsync(TB + tc.o_queues, P + p_queues, sizeof(int32_t) * queues.size(), hipMemcpyHostToDevice, stream));
     if (nblk) HIP_TRY(hipMemcpyAsync(TB + t_blocks, P + p_blocks, sizeof(BlockDesc) * nblk, hipMemcpyHostToDevice, stream));
   }
-  HIP_TRY(hipMemsetAsync(D + o_ready, 0, sizeof(uint32_t) * (nblk ? nblk : 1), stream));
-  HIP_TRY(hipMemsetAsync(D + o_cost, 0, sizeof(uint32_t) * kCostWords, stream));
+  // results + tickets | block-ready flags | cost words lie back to back in the workspace (taken in that order above): one fill for the three of them
+  HIP_TRY(hipMemsetAsync(D + o_results, 0, (o_cost + sizeof(uint32_t) * kCostWords) - o_results, stream));
   HIP_TRY(hipMemcpyAsync(D + o_chunks, P + p_chunks, sizeof(ChunkDesc) * (size_t)n, hipMemcpyHostToDevice, stream));
-  HIP_TRY(hipMemsetAsync(D + o_results, 0, sizeof(int32_t) * (size_t)n + 96, stream));
   uint32_t* d_ticket = (uint32_t*)(D + o_results + sizeof(int32_t) * (size_t)n + 32);
 
   ChunkDesc* d_chunks = (ChunkDesc*)(D + o_chunks);
@@ -736,10 +735,11 @@ static int fetch_headers(EngineState& st, int n, const Job* jobs, bool device_pt
   bool any_short = false;
   for (int i = 0; i < n; i++) { const bool sh = jobs[i].srcsize && jobs[i].srcsize < (size_t)kMaxOverhead; any_short |= sh; pp[i] = sh ? (const void*)(st.dev.base + o_hdr) : jobs[i].src; }
   if (any_short) HIP_TRY(hipMemsetAsync(st.dev.base + o_hdr, 0, 16, stream));
-  HIP_TRY(hipMemcpyAsync(st.dev.base + o_ptrs, pp, sizeof(void*) * (size_t)n, hipMemcpyHostToDevice, stream));
+  // the kernel reads the pointer table from, and writes the headers to, the pinned (device-mapped) table memory itself: one device operation in
+  // front of the synchronisation instead of three (late in round 6; the call's host side is time the device stands idle)
   hipLaunchKernelGGL(k_gather_headers, grid1((size_t)n * 16, 256), dim3(256), 0, stream,
-                     (const uint8_t* const*)(st.dev.base + o_ptrs), st.dev.base + o_hdr, n);
-  HIP_TRY(hipMemcpyAsync(st.pin.base + o_hdr, st.dev.base + o_hdr, 16 * (size_t)n, hipMemcpyDeviceToHost, stream));
+                     (const uint8_t* const*)(st.pin.base + o_ptrs), st.pin.base + o_hdr, n);
+  HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(stream));
   for (int i = 0; i < n; i++) hdrs[(size_t)i] = parse_header(st.pin.base + o_hdr + 16 * (size_t)i);
   for (int i = 0; i < n; i++) if (jobs[i].srcsize && jobs[i].srcsize < (size_t)kMaxOverhead) { hdrs[(size_t)i] = Header{}; hdrs[(size_t)i].nbytes = -1; hdrs[(size_t)i].version = -1; }
@@ -1023,7 +1023,8 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
       HIP_TRY(hipMemcpyAsync(TB + tc.o_zqueues, P + p_zqueues, sizeof(int32_t) * zqueues.size(), hipMemcpyHostToDevice, stream));
     }
   }
-  HIP_TRY(hipMemsetAsync(D + o_status, 0, sizeof(int32_t) * (size_t)n + 64 + sizeof(uint32_t) * (nblk ? nblk : 1), stream));
+  // status words + tickets + arrival counters | cost words lie back to back in the workspace (taken in that order above): one fill
+  HIP_TRY(hipMemsetAsync(D + o_status, 0, (o_cost + sizeof(uint32_t) * kCostWords) - o_status, stream));
 
   L.d_chunks = (ChunkDesc*)(D + o_chunks); L.d_blocks = (BlockDesc*)(TB + t_blocks);
   L.d_streams = (StreamDesc*)(D + o_streams); L.d_status = (int32_t*)(D + o_status);
@@ -1033,7 +1034,6 @@ int engine_decompress_batch(int n, const Job* jobs, int* results, bool device_pt
   L.d_zqoff = (const int32_t*)(TB + tc.o_zqueues); L.d_zqlist = L.d_zqoff + 9; L.nstr_zlib = nstr_zlib;
   L.d_spans = span_enabled() ? (uint32_t*)(D + o_spans) : nullptr; L.d_pat = D + o_pat;
   L.d_cost = (uint32_t*)(D + o_cost);
-  HIP_TRY(hipMemsetAsync(D + o_cost, 0, sizeof(uint32_t) * kCostWords, stream));
   L.d_zticket = (uint32_t*)(D + o_zticket);
   if (L.any_zstd || L.any_zlib) HIP_TRY(hipMemsetAsync(D + o_zticket, 0, 64, stream));
   L.d_zmeta = L.any_zstd ? (ZMeta*)(D + o_zmeta) : nullptr; L.zseq_delta = (ptrdiff_t)o_zseq - (ptrdiff_t)o_zlit + 8;
