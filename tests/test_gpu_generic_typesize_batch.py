@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from helpers import DATASETS, orc_compress, orc_decompress
+from helpers import DATASETS, orc_compress, orc_decompress, ref_compress, ref_decompress
 
 pytestmark = pytest.mark.gpu
 
@@ -51,3 +51,45 @@ def test_many_chunk_batches_of_other_typesizes(pkg, lib, oracle, T):
     res = _batch(L, L.blosc_gpu_decompress_batch_host, 8, refc, [c.size for c in refc], outs, [n] * 8)
     for k in range(8):
         assert res[k] == n and np.array_equal(outs[k], datas[k]), (T, "stock", k)
+
+
+def test_batches_of_one_geometry_after_another(pkg, lib, oracle, ref):
+    """Late in round 6 a workspace keeps the block table and the task queues of its last call per direction on the device (engine.hip: TableCache) and a
+    call of the same geometry takes them.  Batches back to back: the same shape with OTHER content in OTHER buffers (a hit), a ragged one, another
+    typesize, one chunk less, the first shape again - every chunk must read back everywhere, and the reference's chunks of the same shapes must decode
+    through the tables a batch of OUR chunks left behind (equal geometry, other compressed sizes)."""
+    L = pkg.load()
+    rng = np.random.default_rng(11)
+    n = (2 << 20) + 4096
+
+    def run(datas, T, shuffle, cname):
+        k = len(datas)
+        comps = [np.zeros(d.size + 16, np.uint8) for d in datas]
+        cb = _batch(L, L.blosc_gpu_compress_batch_host, k, datas, [d.size for d in datas], comps, [d.size + 16 for d in datas], 5, shuffle, T, cname, 0)
+        assert all(0 < c <= d.size + 16 for c, d in zip(cb, datas)), cb[:8]
+        outs = [np.full(d.size, 0xEE, np.uint8) for d in datas]
+        res = _batch(L, L.blosc_gpu_decompress_batch_host, k, comps, cb, outs, [d.size for d in datas])
+        for i in range(k):
+            assert res[i] == datas[i].size and np.array_equal(outs[i], datas[i]), (T, shuffle, cname, i)
+        for i in (0, k // 2, k - 1):
+            ro, back = (ref_decompress(ref, comps[i][:cb[i]], datas[i].size) if ref is not None else orc_decompress(oracle, comps[i][:cb[i]], datas[i].size))
+            assert ro == datas[i].size and np.array_equal(back, datas[i]), ("the reference's reader", T, shuffle, cname, i)
+        return comps, cb
+
+    a = [DATASETS["bench19"](n) for _ in range(24)]
+    b = [DATASETS[("linspace", "randwalk", "bench19")[i % 3]](n) if i % 4 else rng.integers(0, 256, n, dtype=np.uint8) for i in range(24)]
+    ragged = [DATASETS["bench19"](n - 997 * i) for i in range(24)]
+    for cname in (b"lz4", b"blosclz", b"zstd"):
+        run(a, 8, 1, cname); run(a, 8, 1, cname); run(b, 8, 1, cname); run(ragged, 8, 1, cname); run(b, 4, 1, cname); run(b, 8, 2, cname)
+        run(b[:23], 8, 1, cname); run(a, 8, 1, cname); run(b, 8, 0, cname); run(a, 8, 1, cname)
+        # reference-written chunks of the same geometry as the last batch, then of another one
+        for datas, T in ((a, 8), (b, 8), (b, 4)):
+            refc = []
+            for d in datas[:12]:
+                r, ch = (ref_compress(ref, d, T, 5, 1, cname) if ref is not None else orc_compress(oracle, d, T, 5, 1, cname.decode()))
+                assert r > 0
+                refc.append(np.ascontiguousarray(ch[:r]))
+            outs = [np.full(n, 0xEE, np.uint8) for _ in range(12)]
+            res = _batch(L, L.blosc_gpu_decompress_batch_host, 12, refc, [c.size for c in refc], outs, [n] * 12)
+            for i in range(12):
+                assert res[i] == n and np.array_equal(outs[i], datas[i]), ("reference-written", cname, T, i)
