@@ -131,7 +131,7 @@ struct EngineState {
   bool single_queue = false;
   int cus = 0;          // compute units of the selected device (persistent grids)
   // Tables that are a function of a batch's GEOMETRY alone - the block table and the task queues (0.5 MB for 128 chunks of 64 MiB) - stay on the
-  // device from one call to the next (round 6).  A call that finds its own block table, fusion flags and plane order equal to the ones the tables
+  // device from one call to the next (round 6).  A call that finds its own block table, fusion flags and SET of expensive planes (order_signature) equal to the ones the tables
   // were made from neither builds the queues nor uploads anything but its chunk descriptors: callers send equal-shaped chunks call after call
   // (bench/bench.c:383 does), and the host side of a call is time the device stands idle.  Buffers of their own: the call arena is overwritten by whatever call comes next.
   struct TableCache {
