@@ -221,6 +221,34 @@ def _mem_available():
     return 64 << 30
 
 
+def host_abi_rate(lib, chunk_host, typesize, clevel, shuffle, cname, reps=5):
+    """What an UNMODIFIED c-blosc caller gets: blosc_compress / blosc_decompress of the stock ABI on host buffers (pageable numpy memory), one caller,
+    one chunk at a time, PCIe both ways included (the number next to `cpu_baseline`).  Never `value`: the headline is device-resident."""
+    import ctypes as C
+    n = chunk_host.size
+    src = np.ascontiguousarray(chunk_host); dst = np.empty(n + 16, np.uint8); back = np.empty(n, np.uint8)
+    lib.blosc_init()
+    try:
+        lib.blosc_set_compressor(cname)
+        cb = lib.blosc_compress(clevel, shuffle, typesize, n, src.ctypes.data, dst.ctypes.data, n + 16)
+        assert cb > 0, cb
+        assert lib.blosc_decompress(dst.ctypes.data, back.ctypes.data, n) == n
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            cb = lib.blosc_compress(clevel, shuffle, typesize, n, src.ctypes.data, dst.ctypes.data, n + 16)
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            r = lib.blosc_decompress(dst.ctypes.data, back.ctypes.data, n)
+        t2 = time.perf_counter()
+        assert r == n and np.array_equal(back, src)
+    finally:
+        lib.blosc_set_compressor(b"blosclz")
+        lib.blosc_destroy()
+    c, d = n * reps / (t1 - t0) / 1e9, n * reps / (t2 - t1) / 1e9
+    return {"compress_GBps": c, "decompress_GBps": d, "round_trip_GBps": n * reps / (t2 - t0) / 1e9, "unit": "GB/s",
+            "sample": f"{reps} x one {n >> 20} MiB chunk through blosc_compress / blosc_decompress on pageable host memory, one caller, PCIe both ways included"}
+
+
 def cpu_baseline(chunk_host, typesize, clevel, shuffle, cname, budget_s=20.0):
     """SURVEY §8d / BASELINE.md §4: nthreads = 1, a sweep up to nproc (cap 256, blosc.h:51) and — because one
     64 MiB chunk has only 64-128 blocks for the pool to share — `P` independent blosc_compress_ctx /
@@ -625,6 +653,8 @@ def assemble(res, world, cpu, extra, mixed, args):
         out["legs"] = {"columns": "GBps, ratio, compress_ms, decompress_ms, decompress_stock_ms", **{n: five(r) for n, r in extra.items()}}
         if mixed is not None:
             out["legs"]["mixed"] = [mixed["value"], mixed["ratio"], None, None, None]
+    if "host_abi" in res:       # the stock ABI on host buffers, one caller, one 64 MiB chunk, PCIe included: [compress, decompress, round trip] GB/s - to be read next to cpu_baseline
+        out["host_abi_GBps"] = [res["host_abi"]["compress_GBps"], res["host_abi"]["decompress_GBps"], res["host_abi"]["round_trip_GBps"]]
     out["extra_file"] = extra_file
     out["src_fingerprint"] = fp
     out = _r(out)
@@ -831,6 +861,8 @@ def main():
     cpu = None
     if not args.no_cpu_baseline and world == 1:      # the host-core baseline is a 1-GPU artefact (rank 0, N = 1)
         cpu = cpu_baseline(host_chunk, cfg["typesize"], cfg["clevel"], cfg["shuffle"], cfg["codec"].encode(), args.cpu_seconds)
+    if extra is not None:
+        res["host_abi"] = host_abi_rate(rig.lib, host_chunk, cfg["typesize"], cfg["clevel"], cfg["shuffle"], cfg["codec"].encode())
     line, detail = assemble(res, world, cpu, extra, mixed, args)
     print(line)
     sys.stdout.flush()
